@@ -1,0 +1,223 @@
+/* strive_hip.h -- C ABI of libstrive_hip.so: STRIVE's latent-optimisation hot path on MI355X (gfx950).
+ *
+ * The reference (nv-tlabs/STRIVE) is pure Python/PyTorch and has no FFI; its boundary for this path is
+ * the Python surface of src/models/traffic_model.py, src/models/interaction_net.py,
+ * src/datasets/nuscenes_utils.py and src/losses/adv_gen_nusc.py.  Each entry point below names the
+ * reference function (file:line under /root/reference) whose arithmetic it replaces; INTEGRATION.md
+ * shows the ctypes stub a maintainer of the reference would add at those lines.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless the comment says "host";
+ *   - fp32 tensors are row-major contiguous; index tensors are int32; the raster is uint8, metres-per-
+ *     pixel is float64 (as the reference keeps it, src/datasets/map_env.py:166);
+ *   - nothing is allocated or freed: the caller passes outputs and a workspace whose size comes from the
+ *     matching *_bytes() query; workspaces are scratch (contents undefined on return) except "tape";
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*), no hidden synchronisation;
+ *   - return 0 on success, a negative code on failure; strive_last_error() (thread local) explains it;
+ *   - re-entrant; no global mutable state besides the error string.
+ */
+#ifndef STRIVE_HIP_H
+#define STRIVE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STRIVE_ABI_VERSION 1
+#define STRIVE_HID 128        /* hidden width of every MLP in the reference (models/common.py, interaction_net.py:32,41) */
+#define STRIVE_MAX_LAYERS 4
+#define STRIVE_ZDIM 32
+#define STRIVE_FEAT 64        /* map / past feature size and GRU hidden size (traffic_model.py:25-27) */
+
+typedef void* strive_stream_t;
+
+int strive_abi_version(void);
+const char* strive_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Shared descriptors (host structs holding device pointers)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Linear -> (LayerNorm -> ReLU -> Linear)* ; reference src/models/common.py:8-44.
+ * w[l]  : torch layout (dims[l+1], dims[l])      -- used by the backward (input-gradient) kernels
+ * wt[l] : transposed   (dims[l],   dims[l+1])    -- used by the forward kernels
+ * ln_g/ln_b[l] : LayerNorm(dims[l+1]) applied to the output of layer l, l < nlayers-1 (eps 1e-5). */
+typedef struct StriveMLP {
+    int32_t nlayers;
+    int32_t dims[STRIVE_MAX_LAYERS + 1];
+    const float* w[STRIVE_MAX_LAYERS];
+    const float* wt[STRIVE_MAX_LAYERS];
+    const float* b[STRIVE_MAX_LAYERS];
+    const float* ln_g[STRIVE_MAX_LAYERS];
+    const float* ln_b[STRIVE_MAX_LAYERS];
+} StriveMLP;
+
+/* One message-passing round over per-scene cliques; reference src/models/interaction_net.py:16-218
+ * (k=1, MLP update, max aggregation).  edge.dims[0] = 2*(D+NC)+4, update.dims[0] = 2*D+NC. */
+typedef struct StriveGNN {
+    StriveMLP mlp_in, edge, update, mlp_out;
+    int32_t D;   /* node embedding size during message passing: 64 (decoder) or 128 (prior/posterior) */
+    int32_t NC;  /* semantic classes */
+} StriveGNN;
+
+/* 3-layer GRU memory, hidden 64, input 4; reference src/models/traffic_model.py:151-156.
+ * wih_t[l]: (in_l, 192) with in_0 = 4, in_1 = in_2 = 64;  whh_t[l]: (64, 192); gate order r,z,n.
+ * wih[l], whh[l]: torch layouts (192, in_l), (192, 64) for the backward kernels. */
+typedef struct StriveGRU {
+    const float* wih[3];
+    const float* whh[3];
+    const float* wih_t[3];
+    const float* whh_t[3];
+    const float* bih[3];
+    const float* bhh[3];
+} StriveGRU;
+
+/* Rasterised maps + crop geometry; reference src/datasets/map_env.py:50-61,165-166 and
+ * src/datasets/nuscenes_utils.py:205-232.  lwise/wwise are the fp32 linspace tables over the crop
+ * bounds ([-17,60] m along the heading, [-38.5,38.5] m across), computed by the caller. */
+typedef struct StriveMap {
+    const uint8_t* raster;   /* (M, C, H, W) */
+    const double* dx;        /* (M, 2) metres per pixel: [m][0] divides x, [m][1] divides y */
+    int32_t M, C, H, W;
+    const float* lwise;      /* (L)  */
+    const float* wwise;      /* (Wc) */
+    int32_t L, Wc;
+} StriveMap;
+
+/* Map CNN: 6 x [Conv2d(stride 2, pad 0) -> GroupNorm(1 group) -> ReLU] + Linear(512, 64), default
+ * architecture only (kernels 7,5,5,3,3,3; channels 4->16->32->64->64->128->128; 256x256 input);
+ * reference src/models/traffic_model.py:69-87, 437-440.
+ * w[l]: packed for the MFMA kernels, layout [ci/2][ky][kx][ci&1][co] (l = 0: [ky][kx][ci][co]);
+ * fc_wt: (512, 64) transposed Linear weight. */
+typedef struct StriveCNN {
+    const float* w[6];
+    const float* b[6];
+    const float* gn_g[6];
+    const float* gn_b[6];
+    const float* fc_wt;
+    const float* fc_b;
+} StriveCNN;
+
+/* Scene structure of a batch: agents of scene b are rows ptr[b] .. ptr[b+1]-1, ego first
+ * (reference src/datasets/nuscenes_dataset.py:678-702, PyG Batch.ptr).  With NS > 1 every per-agent
+ * tensor has rows r = agent * NS + sample (the reference's (NA, NS, .) layout flattened). */
+typedef struct StriveScenes {
+    int32_t NA, NS, B;
+    const int32_t* ptr;       /* (B+1) */
+    const int32_t* scene_of;  /* (NA)  */
+} StriveScenes;
+
+/* Everything the decoder rollout needs besides per-call tensors. */
+typedef struct StriveDecoder {
+    StriveGNN gnn;
+    StriveGRU gru;
+    StriveCNN cnn;
+    StriveMap map;
+    float state_mean[6], state_std[6];   /* (x,y,hx,hy,s,hdot) normaliser, datasets/utils.py:44-113 */
+    float att_mean[2], att_std[2];       /* (l,w) normaliser */
+    float a_mean, a_std, ddh_mean, ddh_std, dt, max_hdot, max_s;   /* NUSC_BIKE_PARAMS, datasets/utils.py:121-127 */
+} StriveDecoder;
+
+/* ------------------------------------------------------------------------------------------------
+ * Map raster lookups
+ * ---------------------------------------------------------------------------------------------- */
+
+/* get_map_obs (reference src/datasets/nuscenes_utils.py:234-264) via NuScenesMapEnv.get_map_crop
+ * (src/datasets/map_env.py:168-203).  pos (N,4) is used as pos*pos_std + pos_mean (pass 1/0 for
+ * already-unnormalised frames); mapix (N) selects the map.  out: (N, C, L, Wc) uint8, bit-exact. */
+int strive_map_crop_u8(const StriveMap* map, const float* pos, const float* pos_mean4_host,
+                       const float* pos_std4_host, const int32_t* mapix, int32_t N, uint8_t* out,
+                       strive_stream_t stream);
+
+/* get_coll_point (reference src/datasets/nuscenes_utils.py:334-390) on raster layer 0.
+ * cars (N,4) unnormalised, lw (N,2); gl/gw = grid size (host computes it from the batch mean like the
+ * reference, lines 351-354); lin_l (gl), lin_w (gw) = fp32 linspace(-1,1,.) tables.
+ * out_pt (N,2): collision point or NaN; out_cnt (N) int32: number of non-drivable samples. */
+int strive_coll_point(const StriveMap* map, const float* cars, const float* lw, const int32_t* mapix,
+                      int32_t N, int32_t gl, int32_t gw, const float* lin_l, const float* lin_w,
+                      float* out_pt, int32_t* out_cnt, strive_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Map CNN (crop fused into the first convolution)
+ * ---------------------------------------------------------------------------------------------- */
+
+size_t strive_map_cnn_workspace_bytes(int32_t N);
+
+/* encode_map (reference src/models/traffic_model.py:416-451): feat (N,64) for N poses. */
+int strive_map_cnn_fwd(const StriveMap* map, const StriveCNN* cnn, const float* pos,
+                       const float* pos_mean4_host, const float* pos_std4_host, const int32_t* mapix,
+                       int32_t N, float* feat, void* ws, size_t ws_bytes, strive_stream_t stream);
+
+/* The same CNN on an explicit crop (N,4,256,256) uint8 -- for parity tests of the convolution stack. */
+int strive_map_cnn_fwd_from_crop(const StriveCNN* cnn, const uint8_t* crop, int32_t N, float* feat,
+                                 void* ws, size_t ws_bytes, strive_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small operators
+ * ---------------------------------------------------------------------------------------------- */
+
+/* MLP.forward (reference src/models/common.py:41-44): y (rows, dims[nlayers]). */
+int strive_mlp_fwd(const StriveMLP* mlp, const float* x, int32_t rows, float* y, strive_stream_t stream);
+
+/* transform2frame (reference src/utils/transforms.py:78-139), 4-d poses: frame (Bf,4), poses (Bf,N,4). */
+int strive_transform2frame(const float* frame, const float* poses, int32_t Bf, int32_t N, int32_t inverse,
+                           float* out, strive_stream_t stream);
+
+size_t strive_gnn_workspace_bytes(const StriveGNN* gnn, const StriveScenes* sc);
+
+/* SceneInteractionNet.forward (reference src/models/interaction_net.py:52-77) on clique scenes.
+ * x (R, mlp_in.dims[0]), pos (R,4) [NaN poses give a zero relative pose, :162], sem (NA,NC);
+ * out (R, mlp_out out dim).  R = NA*NS. */
+int strive_gnn_fwd(const StriveGNN* gnn, const StriveScenes* sc, const float* x, const float* pos,
+                   const float* sem, float* out, void* ws, size_t ws_bytes, strive_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Decoder rollout (forward, and backward to the latents)
+ * ---------------------------------------------------------------------------------------------- */
+
+size_t strive_rollout_tape_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT);
+size_t strive_rollout_workspace_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT);
+
+/* TrafficModel.autoregressive_decoder (reference src/models/traffic_model.py:589-704).
+ * past_last (NA,6) normalised last past state; lw (NA,2) normalised; sem (NA,NC); past_feat, map_feat
+ * (NA,64); z (R,32); mapix (NA); ext_future (B,FT,4) normalised or NULL (ego rows teacher-forced,
+ * lines 667-675).  traj (R,FT,4): normalised global (x,y,hx,hy).  tape keeps what the backward needs. */
+int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* sc, const float* past_last,
+                       const float* lw, const float* sem, const float* past_feat, const float* map_feat,
+                       const float* z, const int32_t* mapix, const float* ext_future, int32_t FT,
+                       float* traj, void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
+                       strive_stream_t stream);
+
+/* d(loss)/dz given d(loss)/d(traj): the reverse-time sweep of SURVEY.md Appendix A (no gradient flows
+ * through the map crop / CNN: the reference crops at pos.detach(), traffic_model.py:694). */
+int strive_rollout_bwd(const StriveDecoder* dec, const StriveScenes* sc, const float* lw, const float* sem,
+                       const float* z, const float* ext_future, int32_t FT, const float* d_traj,
+                       float* dz, const void* tape, size_t tape_bytes, void* ws, size_t ws_bytes,
+                       strive_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Collision penalties
+ * ---------------------------------------------------------------------------------------------- */
+
+/* VehCollLoss.forward (reference src/losses/adv_gen_nusc.py:464-512) restricted to in-scene pairs.
+ * traj (NA,T,4) unnormalised; cent_x (NA,5) circle centres on the length axis; rad (NA).
+ * Pair enumeration: for each t, for each agent i (global order), for each j in scene(i) (ascending,
+ * j == i included as an always-invalid slot): index  t*P + pair_off[i] + (j - ptr[scene(i)]),
+ * P = sum_b n_b^2.  pen (T,P) = 1 - dmin/(r_i+r_j+buffer); hit (T,P) uint8 = dmin <= that distance and
+ * i != j; amin (T,P) uint8 = argmin over the 25 circle pairs (ci*5+cj). */
+int strive_veh_coll_fwd(const StriveScenes* sc, const int32_t* pair_off, int32_t P, const float* traj,
+                        int32_t T, const float* cent_x, const float* rad, float buffer, float* pen,
+                        uint8_t* hit, uint8_t* amin, strive_stream_t stream);
+
+/* d_traj (NA,T,4) += sum over pairs of d_pen * d(pen)/d(traj) (both members of each pair). */
+int strive_veh_coll_bwd(const StriveScenes* sc, const int32_t* pair_off, int32_t P, const float* traj,
+                        int32_t T, const float* cent_x, const float* rad, float buffer, const float* d_pen,
+                        const uint8_t* amin, float* d_traj, strive_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRIVE_HIP_H */

@@ -1,0 +1,156 @@
+"""ORACLE (test infrastructure only) -- the four latent-optimisation loops.
+
+CPU restatement of the Adam-over-latents drivers that call the hot path hundreds of times per
+scene batch.  Each iteration is exactly one closure (zero_grad -> rollout(s) -> losses ->
+backward) followed by one ``Adam.step()`` with torch defaults, like the reference.  Progress
+bars, prints and ``.item()`` logging are dropped; a per-iteration trace of latents and loss
+entries can be recorded for the G6 golden fixture.
+"""
+import torch
+
+from .losses import AvoidColl, AdvGen, tgt_matching_loss
+
+
+def collate_tgt_other_z(ptr, tgt_z, other_z):
+    """Interleave per-scene ego latents and the other agents' latents back into graph order
+    (ego first in every scene).  (reference src/utils/adv_gen_optim.py:19-36)"""
+    parts = []
+    prev = 0
+    for b in range(tgt_z.shape[0]):
+        n = int(ptr[b + 1] - ptr[b]) - 1
+        parts.append(tgt_z[b:b + 1])
+        parts.append(other_z[prev:prev + n])
+        prev += n
+    return torch.cat(parts, dim=0)
+
+
+def _trace_entry(z_list, loss_dict):
+    ent = {'z': [z.detach().clone() for z in z_list]}
+    for k, v in loss_dict.items():
+        if torch.is_tensor(v):
+            ent[k] = v.detach().clone()
+    return ent
+
+
+def refine_loop(model, g, map_idx, map_env, embed_info, z_init, weights, num_iters, lr, nfuture,
+                veh_coll_buffer=0.2, trace=None):
+    """Collision-refinement optimisation.  (reference src/refine_traffic_optim.py:146-226, Adam branch)"""
+    z = z_init.clone().detach()
+    z.requires_grad = True
+    opt = torch.optim.Adam([z], lr=lr)
+    loss_fn = AvoidColl(weights, model.get_att_normalizer().unnormalize(g.lw), map_idx[g.batch], map_env,
+                        z.clone().detach(), veh_coll_buffer=veh_coll_buffer)
+    for _ in range(num_iters):
+        opt.zero_grad()
+        pred = model.decode_embedding(z, embed_info, g, map_idx, map_env, nfuture=nfuture)['future_pred']
+        ld = loss_fn(model.get_normalizer().unnormalize(pred), z, embed_info['prior_out'])
+        ld['loss'].backward()
+        if trace is not None:
+            ent = _trace_entry([z], ld)
+            ent['grad'] = z.grad.detach().clone()
+            trace.append(ent)
+        opt.step()
+    return z.detach()
+
+
+def init_loop(model, g, map_idx, map_env, embed_info, z_init, init_traj, traj_vis, weights, num_iters, lr,
+              prior_out, trace=None):
+    """Fit latents to observed futures.  (reference src/utils/init_optim.py:11-68)"""
+    tgt = model.get_normalizer().unnormalize(init_traj)[traj_vis == 1.0]
+    z = z_init.clone().detach()
+    z.requires_grad = True
+    opt = torch.optim.Adam([z], lr=lr)
+    w = {k[5:]: v for k, v in weights.items() if k[:5] == 'init_'}
+    for _ in range(num_iters):
+        opt.zero_grad()
+        pred = model.decode_embedding(z, embed_info, g, map_idx, map_env)['future_pred']
+        pred = model.get_normalizer().unnormalize(pred)[traj_vis == 1.0]
+        ld = tgt_matching_loss(w, pred, tgt, z, prior_out)
+        ld['loss'].backward()
+        if trace is not None:
+            trace.append(_trace_entry([z], ld))
+        opt.step()
+    return z.detach()
+
+
+def adv_loop(model, g, map_idx, map_env, embed_info, z_init, weights, num_iters, lr, tgt_prior, other_prior,
+             feasibility_time=0, feasibility_infront_min=None, attack_agt_idx=None, future_len=None,
+             veh_coll_buffer=0.1, trace=None):
+    """Adversarial optimisation in open-loop ('ego' planner) mode: the planner trajectory is the
+    ego's ground-truth future, injected into both rollouts as ``ext_future``; two rollouts with
+    complementary detach so each latent group only sees its own loss.
+    (reference src/utils/adv_gen_optim.py:39-211, planner_name == 'ego')"""
+    ptr = g.ptr
+    NA = z_init.shape[0]
+    ego_mask = torch.zeros((NA,), dtype=torch.bool)
+    ego_mask[ptr[:-1]] = True
+    if attack_agt_idx is not None:
+        attack_agt_idx = torch.as_tensor(attack_agt_idx).to(ptr) + ptr[:-1]
+    FT = model.FT if future_len is None else future_len
+    tgt_z = z_init[ego_mask].clone().detach()
+    tgt_z.requires_grad = True
+    other_z = z_init[~ego_mask].clone().detach()
+    other_z.requires_grad = True
+    opt = torch.optim.Adam([tgt_z, other_z], lr=lr)
+    cur = collate_tgt_other_z(ptr, tgt_z, other_z)
+    adv = AdvGen(weights, model.get_att_normalizer().unnormalize(g.lw), map_idx[g.batch], map_env,
+                 cur[~ego_mask].clone().detach(), ptr, veh_coll_buffer=veh_coll_buffer,
+                 crash_loss_min_time=feasibility_time, crash_loss_min_infront=feasibility_infront_min)
+    planner_fut = g.future_gt[ego_mask][:, :, :4]
+    unn = model.get_normalizer().unnormalize
+    for _ in range(num_iters):
+        opt.zero_grad()
+        z_a = collate_tgt_other_z(ptr, tgt_z, other_z.clone().detach())
+        z_b = collate_tgt_other_z(ptr, tgt_z.clone().detach(), other_z)
+        pa = model.decode_embedding(z_a, embed_info, g, map_idx, map_env, ext_future=planner_fut, nfuture=FT)
+        pb = model.decode_embedding(z_b, embed_info, g, map_idx, map_env, ext_future=planner_fut, nfuture=FT)
+        lt = tgt_matching_loss(weights, unn(pa['future_pred'][ego_mask]), unn(planner_fut), tgt_z, tgt_prior)
+        la = adv(unn(pb['future_pred']), unn(planner_fut), other_z, other_prior, attack_agt_idx=attack_agt_idx)
+        ld = {'tgt_match_' + k: v for k, v in lt.items()}
+        ld.update({'adv_' + k: v for k, v in la.items()})
+        loss = ld['tgt_match_loss'] + ld['adv_loss']
+        loss.backward()
+        if trace is not None:
+            trace.append(_trace_entry([tgt_z, other_z], ld))
+        opt.step()
+    return collate_tgt_other_z(ptr, tgt_z, other_z).detach()
+
+
+def sol_loop(model, g, map_idx, map_env, embed_info, cur_z, final_result_traj, future_len, weights, num_iters,
+             lr, tgt_prior, other_prior, trace=None):
+    """Solution optimisation: ego avoids collisions (rollout of ``future_len`` steps through the
+    multi-sample code path with NS=1) while the others keep matching the adversarial scenario.
+    (reference src/utils/sol_optim.py:19-123)"""
+    ptr = g.ptr
+    B = map_idx.shape[0]
+    NA = final_result_traj.shape[0]
+    tgt_mask = torch.zeros((NA,), dtype=torch.bool)
+    tgt_mask[ptr[:-1]] = True
+    unn = model.get_normalizer().unnormalize
+    other_match = unn(final_result_traj[:, 0][~tgt_mask])
+    other_match = other_match.view(other_match.shape[0], 1, other_match.shape[1], 4)
+    tgt_z = tgt_prior[0].view(B, 1, -1).clone().detach()
+    tgt_z.requires_grad = True
+    other_z = cur_z[~tgt_mask].view(NA - B, 1, -1).clone().detach()
+    other_z.requires_grad = True
+    opt = torch.optim.Adam([tgt_z, other_z], lr=lr)
+    w = {k[4:]: v for k, v in weights.items() if k[:4] == 'sol_'}
+    avoid = AvoidColl(w, model.get_att_normalizer().unnormalize(g.lw), map_idx[g.batch], map_env,
+                      tgt_z.clone().detach(), veh_coll_buffer=0.5, single_veh_idx=0, ptr=ptr)
+    for _ in range(num_iters):
+        opt.zero_grad()
+        z_a = collate_tgt_other_z(ptr, tgt_z, other_z.detach())
+        pa = model.decode_embedding(z_a, embed_info, g, map_idx, map_env, nfuture=future_len)
+        z_b = collate_tgt_other_z(ptr, tgt_z.detach(), other_z)
+        pb = model.decode_embedding(z_b, embed_info, g, map_idx, map_env)
+        tp = unn(pa['future_pred']).transpose(0, 1).reshape(NA, future_len, 4)
+        lt = avoid(tp, tgt_z, tgt_prior)
+        ld = {'tgt_' + k: v for k, v in lt.items()}
+        lo = tgt_matching_loss(w, unn(pb['future_pred'])[~tgt_mask], other_match, other_z, other_prior)
+        ld.update({'other_' + k: v for k, v in lo.items()})
+        loss = ld['tgt_loss'] + ld['other_loss']
+        loss.backward()
+        if trace is not None:
+            trace.append(_trace_entry([tgt_z, other_z], ld))
+        opt.step()
+    return collate_tgt_other_z(ptr, tgt_z, other_z).detach()

@@ -1,0 +1,164 @@
+"""ctypes binding of libstrive_hip.so (include/strive_hip.h).
+
+The product loads exactly one library: ``strive_amd/libstrive_hip.so`` built by hipcc for gfx950
+(strive_amd/build.py).  If it is missing or cannot be loaded every HIP-backed operator raises
+``StriveHipError`` -- there is no CPU fallback.  ``StriveLib(path)`` is also instantiated by the
+CPU-side tests with the host-emulation build of the same sources (tests/hipemu); the product never
+does that.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, 'libstrive_hip.so')
+
+MAXL = 4
+
+
+class StriveHipError(RuntimeError):
+    pass
+
+
+fp = C.POINTER(C.c_float)
+ip = C.POINTER(C.c_int32)
+u8p = C.POINTER(C.c_uint8)
+dp = C.POINTER(C.c_double)
+
+
+class StriveMLP(C.Structure):
+    _fields_ = [('nlayers', C.c_int32), ('dims', C.c_int32 * (MAXL + 1)),
+                ('w', C.c_void_p * MAXL), ('wt', C.c_void_p * MAXL), ('b', C.c_void_p * MAXL),
+                ('ln_g', C.c_void_p * MAXL), ('ln_b', C.c_void_p * MAXL)]
+
+
+class StriveGNN(C.Structure):
+    _fields_ = [('mlp_in', StriveMLP), ('edge', StriveMLP), ('update', StriveMLP), ('mlp_out', StriveMLP),
+                ('D', C.c_int32), ('NC', C.c_int32)]
+
+
+class StriveGRU(C.Structure):
+    _fields_ = [('wih', C.c_void_p * 3), ('whh', C.c_void_p * 3), ('wih_t', C.c_void_p * 3),
+                ('whh_t', C.c_void_p * 3), ('bih', C.c_void_p * 3), ('bhh', C.c_void_p * 3)]
+
+
+class StriveMap(C.Structure):
+    _fields_ = [('raster', C.c_void_p), ('dx', C.c_void_p), ('M', C.c_int32), ('C', C.c_int32),
+                ('H', C.c_int32), ('W', C.c_int32), ('lwise', C.c_void_p), ('wwise', C.c_void_p),
+                ('L', C.c_int32), ('Wc', C.c_int32)]
+
+
+class StriveCNN(C.Structure):
+    _fields_ = [('w', C.c_void_p * 6), ('b', C.c_void_p * 6), ('gn_g', C.c_void_p * 6), ('gn_b', C.c_void_p * 6),
+                ('fc_wt', C.c_void_p), ('fc_b', C.c_void_p)]
+
+
+class StriveScenes(C.Structure):
+    _fields_ = [('NA', C.c_int32), ('NS', C.c_int32), ('B', C.c_int32), ('ptr', C.c_void_p), ('scene_of', C.c_void_p)]
+
+
+class StriveDecoder(C.Structure):
+    _fields_ = [('gnn', StriveGNN), ('gru', StriveGRU), ('cnn', StriveCNN), ('map', StriveMap),
+                ('state_mean', C.c_float * 6), ('state_std', C.c_float * 6),
+                ('att_mean', C.c_float * 2), ('att_std', C.c_float * 2),
+                ('a_mean', C.c_float), ('a_std', C.c_float), ('ddh_mean', C.c_float), ('ddh_std', C.c_float),
+                ('dt', C.c_float), ('max_hdot', C.c_float), ('max_s', C.c_float)]
+
+
+P = C.c_void_p
+I = C.c_int32
+SZ = C.c_size_t
+F4 = C.c_float * 4
+
+# name -> (restype, argtypes).  Every symbol declared in include/strive_hip.h is listed here and
+# tests/test_abi.py checks the two stay in sync.
+PROTOTYPES = {
+    'strive_abi_version': (C.c_int, []),
+    'strive_last_error': (C.c_char_p, []),
+    'strive_map_crop_u8': (C.c_int, [C.POINTER(StriveMap), P, F4, F4, P, I, P, P]),
+    'strive_coll_point': (C.c_int, [C.POINTER(StriveMap), P, P, P, I, I, I, P, P, P, P, P]),
+    'strive_map_cnn_workspace_bytes': (SZ, [I]),
+    'strive_map_cnn_fwd': (C.c_int, [C.POINTER(StriveMap), C.POINTER(StriveCNN), P, F4, F4, P, I, P, P, SZ, P]),
+    'strive_map_cnn_fwd_from_crop': (C.c_int, [C.POINTER(StriveCNN), P, I, P, P, SZ, P]),
+    'strive_mlp_fwd': (C.c_int, [C.POINTER(StriveMLP), P, I, P, P]),
+    'strive_transform2frame': (C.c_int, [P, P, I, I, I, P, P]),
+    'strive_gnn_workspace_bytes': (SZ, [C.POINTER(StriveGNN), C.POINTER(StriveScenes)]),
+    'strive_gnn_fwd': (C.c_int, [C.POINTER(StriveGNN), C.POINTER(StriveScenes), P, P, P, P, P, SZ, P]),
+    'strive_rollout_tape_bytes': (SZ, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), I]),
+    'strive_rollout_workspace_bytes': (SZ, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), I]),
+    'strive_rollout_fwd': (C.c_int, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), P, P, P, P, P, P, P, P, I,
+                                     P, P, SZ, P, SZ, P]),
+    'strive_rollout_bwd': (C.c_int, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), P, P, P, P, I, P, P,
+                                     P, SZ, P, SZ, P]),
+    'strive_veh_coll_fwd': (C.c_int, [C.POINTER(StriveScenes), P, I, P, I, P, P, C.c_float, P, P, P, P]),
+    'strive_veh_coll_bwd': (C.c_int, [C.POINTER(StriveScenes), P, I, P, I, P, P, C.c_float, P, P, P, P]),
+}
+
+
+class StriveLib(object):
+    def __init__(self, path=None, require_all=True):
+        self.path = DEFAULT_LIB if path is None else path
+        if not os.path.exists(self.path):
+            raise StriveHipError('HIP library not found at %s -- run `python -m strive_amd.build` '
+                                 '(hipcc, gfx950); there is no CPU fallback' % self.path)
+        try:
+            self.cdll = C.CDLL(self.path)
+        except OSError as e:
+            raise StriveHipError('cannot load %s: %s' % (self.path, e))
+        self.missing = []
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                fn = getattr(self.cdll, name)
+            except AttributeError:
+                self.missing.append(name)
+                continue
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, '_' + name, fn)
+        if require_all and self.missing:
+            raise StriveHipError('%s lacks symbols: %s' % (self.path, ', '.join(self.missing)))
+        if not self.missing or 'strive_abi_version' not in self.missing:
+            v = self._strive_abi_version()
+            if v != 1:
+                raise StriveHipError('ABI version mismatch: library %d, binding 1' % v)
+
+    def call(self, name, *args):
+        fn = getattr(self, '_' + name, None)
+        if fn is None:
+            raise StriveHipError('symbol %s missing from %s' % (name, self.path))
+        rc = fn(*args)
+        if rc != 0:
+            raise StriveHipError('%s failed (%d): %s' % (name, rc, self._strive_last_error().decode()))
+
+    def query(self, name, *args):
+        return getattr(self, '_' + name)(*args)
+
+
+_default = None
+
+
+def get_lib():
+    """The product's single library instance (hipcc build).  Raises StriveHipError if unavailable."""
+    global _default
+    if _default is None:
+        _default = StriveLib(DEFAULT_LIB)
+    return _default
+
+
+def ptr(t):
+    """Device (or, under the test emulation, host) address of a contiguous tensor; None -> NULL."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'non-contiguous tensor passed to the C ABI'
+    return C.c_void_p(t.data_ptr())
+
+
+def f4(vals):
+    return F4(*[float(v) for v in vals])
+
+
+def stream_ptr(t):
+    """hipStream_t of torch's current stream on t's device (NULL stream for host tensors)."""
+    import torch
+    if t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return C.c_void_p(0)

@@ -1,0 +1,471 @@
+// Map CNN forward: 6 x [Conv2d(stride 2, pad 0) -> GroupNorm(1 group) -> ReLU] -> Linear(512,64)
+// (reference src/models/traffic_model.py:69-87, 437-440), with the raster crop fused into the
+// first convolution so the (N,4,256,256) crop never exists in HBM.
+//
+// Every convolution is an implicit GEMM on the f32 matrix cores (exact fp32, = an fmaf chain):
+//     D[co][pixel] += W[co][k] * patch[k][pixel],    k = (ci, ky, kx)
+// with A = weights (M = output channels) and B = input patches (N = output pixels), so that the
+// accumulator columns are pixels and the NCHW stores are contiguous along x.
+//   layer 1 (Cout = 16):        v_mfma_f32_16x16x4_f32, the 4 k-lanes are the 4 input channels
+//   layers 2-6 (Cout = 32..128): v_mfma_f32_32x32x2_f32, the 2 k-lanes are an even/odd channel pair
+// Input tiles are staged once per workgroup into LDS with the previous layer's GroupNorm + ReLU applied
+// on the way in (so normalised activations never exist in HBM either); columns are stored
+// de-interleaved by parity so the stride-2 window reads of consecutive output pixels hit consecutive
+// banks.  GroupNorm statistics (sum, sum of squares per sample, float64) are accumulated in the
+// epilogue of the producing convolution.
+#include "common.h"
+#include "crop_dev.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GN_EPS 1e-5
+
+struct GNStats { double sum, sq; };
+
+__device__ __forceinline__ void gn_scale_shift(const GNStats* __restrict__ st, int n, double count, float gamma,
+                                               float beta, float& scale, float& shift) {
+    const double mean = st[n].sum / count;
+    double var = st[n].sq / count - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + GN_EPS));
+    const float fm = (float)mean;
+    scale = rstd * gamma;
+    shift = beta - fm * scale;
+}
+
+// =============================================================================================
+// Layer 1: (crop u8 4x256x256) -> raw conv output (16x125x125), 7x7 stride 2.
+// Workgroup = 4 waves, output tile 16x16; wave w owns output rows 4w..4w+3 (4 MFMA pixel tiles of 16).
+// =============================================================================================
+namespace l1 {
+constexpr int CIN = 4, COUT = 16, KS = 7, IH = 256, OH = 125;
+constexpr int TO = 16;                 // output tile edge
+constexpr int IT = 2 * TO + KS - 2;    // 37 input rows/cols per tile
+constexpr int HALFW = (IT + 1) / 2;    // 19
+constexpr int RS = 2 * HALFW;          // 38
+constexpr int PS = 1424;               // >= IT*RS = 1406, == 16 (mod 32): ci 0/1 land on disjoint banks
+constexpr int TILES = (OH + TO - 1) / TO;   // 8
+constexpr int WSZ = KS * KS * CIN * COUT;   // 3136 floats
+}  // namespace l1
+
+template <bool FUSED_CROP>
+__global__ __launch_bounds__(256) void conv1_kernel(StriveMap map, const float* __restrict__ pos, Float4Host pmean,
+                                                      Float4Host pstd, const int32_t* __restrict__ mapix,
+                                                      const uint8_t* __restrict__ crop, const float* __restrict__ wpk,
+                                                      const float* __restrict__ bias, float* __restrict__ out,
+                                                      GNStats* __restrict__ stats) {
+    using namespace l1;
+    __shared__ float s_in[CIN * PS];
+    __shared__ float s_w[WSZ];
+    __shared__ double s_red[8];
+    const int n = blockIdx.z;
+    const int oy0 = blockIdx.y * TO, ox0 = blockIdx.x * TO;
+    const int tid = threadIdx.x;
+
+    // ---- stage weights (already packed [ky][kx][ci][co]) ----
+    for (int i = tid; i < WSZ; i += 256) s_w[i] = wpk[i];
+
+    // ---- stage the input window, crop computed on the fly ----
+    CropFrame fr;
+    if (FUSED_CROP) fr = load_crop_frame(map, pos, pmean.v, pstd.v, mapix, n);
+    const size_t plane = FUSED_CROP ? (size_t)map.H * map.W : 0;
+    for (int idx = tid; idx < IT * IT; idx += 256) {
+        const int r = idx / IT, c = idx - r * IT;
+        const int l = 2 * oy0 + r, w = 2 * ox0 + c;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (l < IH && w < IH) {
+            if (FUSED_CROP) {
+                int px, py;
+                crop_pixel(fr, map.lwise[l], map.wwise[w], true, px, py);
+                const uint8_t* src = fr.base + (size_t)py * map.W + px;
+                v0 = (float)src[0];
+                v1 = (float)src[plane];
+                v2 = (float)src[2 * plane];
+                v3 = (float)src[3 * plane];
+            } else {
+                const uint8_t* src = crop + (size_t)n * CIN * IH * IH + (size_t)l * IH + w;
+                v0 = (float)src[0];
+                v1 = (float)src[(size_t)IH * IH];
+                v2 = (float)src[(size_t)2 * IH * IH];
+                v3 = (float)src[(size_t)3 * IH * IH];
+            }
+        }
+        const int cc = (c >> 1) + (c & 1) * HALFW;
+        const int o = r * RS + cc;
+        s_in[o] = v0;
+        s_in[PS + o] = v1;
+        s_in[2 * PS + o] = v2;
+        s_in[3 * PS + o] = v3;
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int kq = lane >> 4;      // k lane group = input channel
+    const int j = lane & 15;       // pixel column within the tile / output channel for A
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int bbase = kq * PS + (2 * (wave * 4)) * RS + j;
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const float a = s_w[((ky * KS + kx) * CIN + kq) * COUT + j];
+            const int off = ky * RS + (kx >> 1) + (kx & 1) * HALFW;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float b = s_in[bbase + i * 2 * RS + off];
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: bias, store, GroupNorm statistics ----
+    // D layout: column = lane&15 = pixel x, row = (lane>>4)*4 + r = output channel
+    double lsum = 0.0, lsq = 0.0;
+    const int ox = ox0 + j;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int oy = oy0 + wave * 4 + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = kq * 4 + r;
+            const float v = acc[i][r] + bias[co];
+            if (oy < OH && ox < OH) {
+                out[(((size_t)n * COUT + co) * OH + oy) * OH + ox] = v;
+                lsum += (double)v;
+                lsq += (double)v * (double)v;
+            }
+        }
+    }
+    lsum = wave_sum_d(lsum);
+    lsq = wave_sum_d(lsq);
+    if (lane == 0) { s_red[wave * 2] = lsum; s_red[wave * 2 + 1] = lsq; }
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(&stats[n].sum, s_red[0] + s_red[2] + s_red[4] + s_red[6]);
+        atomicAdd(&stats[n].sq, s_red[1] + s_red[3] + s_red[5] + s_red[7]);
+    }
+}
+
+// =============================================================================================
+// Layers 2-6: generic LDS-staged implicit GEMM on v_mfma_f32_32x32x2_f32.
+// A workgroup owns S samples x (TH x TW) output pixels (P = S*TH*TW, linearised) and all COUT channels;
+// waves form an NWP x NWM grid: wave (wp, wm) owns NPW pixel tiles of 32 and MTW channel tiles of 32.
+// Input channels are streamed through LDS in chunks of CC (even); k is ordered
+// (channel pair, ky, kx, parity) so the two 32-lane halves of a wave always read channel 2cp / 2cp+1
+// at the same window offset and every LDS address is lane_base + compile-time immediate.
+// =============================================================================================
+template <int CIN_, int COUT_, int KS_, int IH_, int OH_, int TH_, int TW_, int S_, int CC_, int NWP_, int NWM_, int NPW_,
+          int MTW_>
+struct ConvCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, KS = KS_, IH = IH_, OH = OH_, TH = TH_, TW = TW_, S = S_, CC = CC_;
+    static constexpr int NWP = NWP_, NWM = NWM_, NPW = NPW_, MTW = MTW_;
+    static constexpr int NW = NWP * NWM, NT = NW * 64;
+    static constexpr int TILES_Y = (OH + TH - 1) / TH, TILES_X = (OH + TW - 1) / TW;
+    static constexpr int ITH = 2 * TH + KS - 2, ITW = 2 * TW + KS - 2;
+    static constexpr int HALFW = (ITW + 1) / 2;
+    // row stride == 8 (mod 16) floats: pixels one output row apart (2 input rows) are 16 banks apart
+    static constexpr int RS = ((2 * HALFW + 7) / 16) * 16 + 8;
+    static constexpr int PS = ITH * RS;            // per-channel plane
+    static constexpr int SS = CC * PS;             // per-sample block of a chunk
+    static constexpr int P = S * TH * TW;
+    static constexpr int NTILE = (P + 31) / 32;
+    static constexpr int WCH = (CC / 2) * KS * KS * 2 * COUT;   // weight floats per chunk
+    static constexpr int IN_FLOATS = S * SS;
+    static constexpr int GN_FLOATS = S * CIN * 2;
+    static constexpr size_t LDS_BYTES = (size_t)(IN_FLOATS + WCH + GN_FLOATS) * 4 + 64 * 8;
+    static_assert(COUT == NWM * MTW * 32, "channel tiling");
+    static_assert(NTILE <= NWP * NPW, "pixel tiling");
+    static_assert(CC % 2 == 0 && CIN % CC == 0, "channel chunking");
+    static_assert(RS >= 2 * HALFW, "row stride");
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
+                                                             const float* __restrict__ gn_g, const float* __restrict__ gn_b,
+                                                             const float* __restrict__ wpk, const float* __restrict__ bias,
+                                                             float* __restrict__ out, GNStats* __restrict__ st_out, int N) {
+    constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, KS = Cfg::KS, IH = Cfg::IH, OH = Cfg::OH;
+    constexpr int TH = Cfg::TH, TW = Cfg::TW, S = Cfg::S, CC = Cfg::CC, RS = Cfg::RS, PS = Cfg::PS, SS = Cfg::SS;
+    constexpr int HALFW = Cfg::HALFW, ITH = Cfg::ITH, ITW = Cfg::ITW, NPW = Cfg::NPW, MTW = Cfg::MTW, P = Cfg::P;
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* s_in = smem;
+    float* s_w = smem + Cfg::IN_FLOATS;
+    float* s_gn = s_w + Cfg::WCH;                     // [S][CIN][2] scale, shift
+    double* s_red = (double*)(s_gn + Cfg::GN_FLOATS);   // [S][2] (S <= 32)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave % Cfg::NWP, wm = wave / Cfg::NWP;
+    const int half = lane >> 5, j = lane & 31;
+    const int n0 = blockIdx.z * S;
+    const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    const int iy0 = 2 * oy0, ix0 = 2 * ox0;
+
+    // ---- GroupNorm scale/shift of the producing layer, per (sample, channel) ----
+    const double cnt_in = (double)CIN * IH * IH;
+    for (int i = tid; i < S * CIN; i += Cfg::NT) {
+        const int s = i / CIN, c = i - s * CIN;
+        float sc = 0.f, sh = 0.f;
+        if (n0 + s < N) gn_scale_shift(st_in, n0 + s, cnt_in, gn_g[c], gn_b[c], sc, sh);
+        s_gn[2 * i] = sc;
+        s_gn[2 * i + 1] = sh;
+    }
+    if (tid < 2 * S) s_red[tid] = 0.0;
+
+    // ---- per-lane pixel bases ----
+    int pbase[NPW];
+    int ppix[NPW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int tile = wp * NPW + i;
+        int p = tile * 32 + j;
+        ppix[i] = p;
+        if (p >= P) p = 0;
+        const int s = p / (TH * TW);
+        const int q = p - s * (TH * TW);
+        const int oy = q / TW, ox = q - oy * TW;
+        pbase[i] = s * SS + half * PS + (2 * oy) * RS + ox;
+    }
+
+    f32x16 acc[NPW][MTW];
+#pragma unroll
+    for (int i = 0; i < NPW; ++i)
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
+
+    const int abase = half * COUT + wm * MTW * 32 + j;
+
+    for (int ch = 0; ch < CIN / CC; ++ch) {
+        __syncthreads();
+        // ---- stage input chunk with GN + ReLU applied ----
+        for (int idx = tid; idx < S * CC * ITH * ITW; idx += Cfg::NT) {
+            const int col = idx % ITW;
+            int t = idx / ITW;
+            const int r = t % ITH;
+            t /= ITH;
+            const int c = t % CC;
+            const int s = t / CC;
+            const int iy = iy0 + r, ix = ix0 + col;
+            float v = 0.f;
+            const int ci = ch * CC + c;
+            if (n0 + s < N && iy < IH && ix < IH) {
+                const float raw = in[(((size_t)(n0 + s) * CIN + ci) * IH + iy) * IH + ix];
+                v = fmaxf(fmaf(raw, s_gn[2 * (s * CIN + ci)], s_gn[2 * (s * CIN + ci) + 1]), 0.f);
+            }
+            s_in[s * SS + c * PS + r * RS + (col >> 1) + (col & 1) * HALFW] = v;
+        }
+        // ---- stage weight chunk (contiguous in the packed layout) ----
+        {
+            const float* wsrc = wpk + (size_t)ch * Cfg::WCH;
+            for (int i = tid; i < Cfg::WCH; i += Cfg::NT) s_w[i] = wsrc[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cp = 0; cp < CC / 2; ++cp) {
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const int step = (cp * KS + ky) * KS + kx;
+                    float a[MTW], b[NPW];
+#pragma unroll
+                    for (int m = 0; m < MTW; ++m) a[m] = s_w[step * 2 * COUT + abase + m * 32];
+                    const int off = cp * 2 * PS + ky * RS + (kx >> 1) + (kx & 1) * HALFW;
+#pragma unroll
+                    for (int i = 0; i < NPW; ++i) b[i] = s_in[pbase[i] + off];
+#pragma unroll
+                    for (int i = 0; i < NPW; ++i)
+#pragma unroll
+                        for (int m = 0; m < MTW; ++m)
+                            acc[i][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[i], acc[i][m], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue ----
+    // D layout: column = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel within the tile
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int p = ppix[i];
+        const int tile = wp * NPW + i;
+        if (tile * 32 >= P) continue;   // wave-uniform
+        const bool pv = p < P;
+        const int pc = pv ? p : 0;
+        const int s = pc / (TH * TW);
+        const int q = pc - s * (TH * TW);
+        const int oy = oy0 + q / TW, ox = ox0 + q % TW;
+        const bool valid = pv && (n0 + s < N) && oy < OH && ox < OH;
+        double lsum = 0.0, lsq = 0.0;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = wm * MTW * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float v = acc[i][m][r] + bias[co];
+                if (valid) {
+                    out[(((size_t)(n0 + s) * COUT + co) * OH + oy) * OH + ox] = v;
+                    lsum += (double)v;
+                    lsq += (double)v * (double)v;
+                }
+            }
+        }
+        if (S == 1) {
+            lsum = wave_sum_d(lsum);
+            lsq = wave_sum_d(lsq);
+            if (lane == 0) {
+                atomicAdd(&s_red[0], lsum);
+                atomicAdd(&s_red[1], lsq);
+            }
+        } else if (valid) {
+            atomicAdd(&s_red[2 * s], lsum);
+            atomicAdd(&s_red[2 * s + 1], lsq);
+        }
+    }
+    __syncthreads();
+    if (tid < S && n0 + tid < N) {
+        atomicAdd(&st_out[n0 + tid].sum, s_red[2 * tid]);
+        atomicAdd(&st_out[n0 + tid].sq, s_red[2 * tid + 1]);
+    }
+}
+
+// per-layer configurations            CIN COUT KS  IH  OH  TH  TW  S  CC NWP NWM NPW MTW
+typedef ConvCfg< 16,  32, 5, 125, 61, 16, 16,  1,  8,  4,  1,  2,  1> Cfg2;   // 256 px tile, 4 waves
+typedef ConvCfg< 32,  64, 5,  61, 29, 29, 29,  1,  2,  7,  1,  4,  2> Cfg3;   // whole image (841 px), 7 waves
+typedef ConvCfg< 64,  64, 3,  29, 14, 14, 14,  4,  2,  5,  1,  5,  2> Cfg4;   // 4 samples (784 px), 5 waves
+typedef ConvCfg< 64, 128, 3,  14,  6,  6,  6,  8,  4,  3,  2,  3,  2> Cfg5;   // 8 samples (288 px), 6 waves
+typedef ConvCfg<128, 128, 3,   6,  2,  2,  2, 32,  8,  2,  2,  2,  2> Cfg6;   // 32 samples (128 px), 4 waves
+
+template <class Cfg>
+static int launch_conv(const float* in, const GNStats* st_in, const float* g, const float* b, const float* w,
+                       const float* bias, float* out, GNStats* st_out, int N, hipStream_t stream) {
+    dim3 grid(Cfg::TILES_X, Cfg::TILES_Y, (N + Cfg::S - 1) / Cfg::S);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_mfma_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)Cfg::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_mfma_kernel<Cfg>, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, stream, in, st_in, g, b, w, bias, out,
+                       st_out, N);
+    return 0;
+}
+
+// =============================================================================================
+// GroupNorm6 + ReLU + flatten + Linear(512 -> 64): 4 samples per workgroup, thread = (sample, out)
+// =============================================================================================
+__global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ in, const GNStats* __restrict__ st,
+                                                   const float* __restrict__ gn_g, const float* __restrict__ gn_b,
+                                                   const float* __restrict__ wt, const float* __restrict__ bias,
+                                                   float* __restrict__ feat, int N) {
+    __shared__ float s_a[4][512];
+    const int n0 = blockIdx.x * 4;
+    for (int i = threadIdx.x; i < 4 * 512; i += 256) {
+        const int s = i >> 9, k = i & 511;
+        float v = 0.f;
+        if (n0 + s < N) {
+            float sc, sh;
+            const int c = k >> 2;
+            gn_scale_shift(st, n0 + s, 512.0, gn_g[c], gn_b[c], sc, sh);
+            v = fmaxf(fmaf(in[(size_t)(n0 + s) * 512 + k], sc, sh), 0.f);
+        }
+        s_a[s][k] = v;
+    }
+    __syncthreads();
+    const int s = threadIdx.x >> 6, o = threadIdx.x & 63;
+    if (n0 + s >= N) return;
+    float acc = bias[o];
+#pragma unroll 8
+    for (int k = 0; k < 512; ++k) acc = fmaf(s_a[s][k], wt[k * 64 + o], acc);
+    feat[(size_t)(n0 + s) * 64 + o] = acc;
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+namespace {
+constexpr size_t L_OUT[6] = {16u * 125 * 125, 32u * 61 * 61, 64u * 29 * 29, 64u * 14 * 14, 128u * 6 * 6, 128u * 2 * 2};
+constexpr int CNN_CHUNK = 256;   // agents pushed through the layer stack together (keeps the working set L3-sized)
+
+size_t per_agent_floats() {
+    size_t t = 0;
+    for (int l = 0; l < 6; ++l) t += L_OUT[l];
+    return t;
+}
+}  // namespace
+
+extern "C" size_t strive_map_cnn_workspace_bytes(int32_t N) {
+    const size_t ch = (size_t)(N < CNN_CHUNK ? (N > 0 ? N : 1) : CNN_CHUNK);
+    size_t bytes = 0;
+    for (int l = 0; l < 6; ++l) bytes += strive_align_up(ch * L_OUT[l] * 4, 256);
+    bytes += strive_align_up(ch * 6 * sizeof(GNStats), 256);
+    return bytes;
+}
+
+static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos, const float* pmean, const float* pstd,
+                   const int32_t* mapix, const uint8_t* crop, int32_t N, float* feat, void* ws, size_t ws_bytes,
+                   hipStream_t stream) {
+    if (N == 0) return 0;
+    if (ws_bytes < strive_map_cnn_workspace_bytes(N)) {
+        strive_set_error("map_cnn: workspace too small (%zu < %zu)", ws_bytes, strive_map_cnn_workspace_bytes(N));
+        return -1;
+    }
+    const int ch = N < CNN_CHUNK ? N : CNN_CHUNK;
+    StriveArena ar(ws, ws_bytes);
+    float* act[6];
+    for (int l = 0; l < 6; ++l) act[l] = ar.take<float>((size_t)ch * L_OUT[l]);
+    GNStats* stats = ar.take<GNStats>((size_t)ch * 6);
+    if (!ar.ok()) { strive_set_error("map_cnn: workspace arena overflow"); return -1; }
+    Float4Host m, s;
+    StriveMap mp;
+    memset(&mp, 0, sizeof(mp));
+    if (map) {
+        memcpy(m.v, pmean, 16);
+        memcpy(s.v, pstd, 16);
+        mp = *map;
+    } else {
+        memset(&m, 0, sizeof(m));
+        memset(&s, 0, sizeof(s));
+    }
+    for (int n0 = 0; n0 < N; n0 += ch) {
+        const int n = (N - n0) < ch ? (N - n0) : ch;
+        hipMemsetAsync(stats, 0, (size_t)ch * 6 * sizeof(GNStats), stream);
+        GNStats* st[6];
+        for (int l = 0; l < 6; ++l) st[l] = stats + (size_t)l * ch;
+        dim3 g1(l1::TILES, l1::TILES, n);
+        if (map) {
+            hipLaunchKernelGGL(conv1_kernel<true>, g1, dim3(256), 0, stream, mp, pos + (size_t)n0 * 4, m, s, mapix + n0,
+                               (const uint8_t*)nullptr, (const float*)cnn->w[0], (const float*)cnn->b[0], act[0], st[0]);
+        } else {
+            hipLaunchKernelGGL(conv1_kernel<false>, g1, dim3(256), 0, stream, mp, (const float*)nullptr, m, s,
+                               (const int32_t*)nullptr, crop + (size_t)n0 * 4 * 256 * 256, (const float*)cnn->w[0],
+                               (const float*)cnn->b[0], act[0], st[0]);
+        }
+        launch_conv<Cfg2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w[1], cnn->b[1], act[1], st[1], n, stream);
+        launch_conv<Cfg3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w[2], cnn->b[2], act[2], st[2], n, stream);
+        launch_conv<Cfg4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w[3], cnn->b[3], act[3], st[3], n, stream);
+        launch_conv<Cfg5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w[4], cnn->b[4], act[4], st[4], n, stream);
+        launch_conv<Cfg6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w[5], cnn->b[5], act[5], st[5], n, stream);
+        hipLaunchKernelGGL(fc_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, act[5], st[5], cnn->gn_g[5], cnn->gn_b[5],
+                           cnn->fc_wt, cnn->fc_b, feat + (size_t)n0 * 64, n);
+    }
+    STRIVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int strive_map_cnn_fwd(const StriveMap* map, const StriveCNN* cnn, const float* pos,
+                                  const float* pos_mean4_host, const float* pos_std4_host, const int32_t* mapix, int32_t N,
+                                  float* feat, void* ws, size_t ws_bytes, strive_stream_t stream) {
+    STRIVE_CHECK_ARG(map && cnn && pos && mapix && feat && ws && pos_mean4_host && pos_std4_host, "null argument");
+    STRIVE_CHECK_ARG(map->C == 4 && map->L == 256 && map->Wc == 256, "the HIP map CNN supports the default 4x256x256 crop only");
+    return cnn_run(map, cnn, pos, pos_mean4_host, pos_std4_host, mapix, nullptr, N, feat, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int strive_map_cnn_fwd_from_crop(const StriveCNN* cnn, const uint8_t* crop, int32_t N, float* feat, void* ws,
+                                            size_t ws_bytes, strive_stream_t stream) {
+    STRIVE_CHECK_ARG(cnn && crop && feat && ws, "null argument");
+    return cnn_run(nullptr, cnn, nullptr, nullptr, nullptr, nullptr, crop, N, feat, ws, ws_bytes, (hipStream_t)stream);
+}

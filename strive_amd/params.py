@@ -1,0 +1,189 @@
+"""Pack TrafficModel parameters into the descriptor structs of include/strive_hip.h.
+
+Packing is pure layout work (transposes / permutes with torch on the parameters' own device); the
+packed tensors are kept alive by the returned holder object.  Layouts are documented in
+include/strive_hip.h next to each struct.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class Packed(object):
+    """A ctypes struct plus the tensors its pointers refer to."""
+
+    def __init__(self, struct):
+        self.struct = struct
+        self.keep = []
+
+    def hold(self, t):
+        self.keep.append(t)
+        return t.data_ptr()
+
+    def ref(self):
+        return C.byref(self.struct)
+
+
+def _fill_mlp(s, holder, sd, prefix):
+    """sd keys ``<prefix>.net.{0,3,6,9}`` Linear, ``.net.{1,4,7}`` LayerNorm
+    (reference src/models/common.py:26-39)."""
+    k = 0
+    dims = []
+    while (prefix + '.net.%d.weight' % (3 * k)) in sd:
+        w = _c(sd[prefix + '.net.%d.weight' % (3 * k)])
+        b = _c(sd[prefix + '.net.%d.bias' % (3 * k)])
+        if k == 0:
+            dims.append(w.shape[1])
+        dims.append(w.shape[0])
+        s.w[k] = holder.hold(w)
+        s.wt[k] = holder.hold(w.t().contiguous())
+        s.b[k] = holder.hold(b)
+        gk = prefix + '.net.%d.weight' % (3 * k + 1)
+        if gk in sd:
+            s.ln_g[k] = holder.hold(_c(sd[gk]))
+            s.ln_b[k] = holder.hold(_c(sd[prefix + '.net.%d.bias' % (3 * k + 1)]))
+        k += 1
+    if k < 2 or k > L.MAXL:
+        raise ValueError('MLP %s has %d Linear layers; the HIP kernels support 2..%d' % (prefix, k, L.MAXL))
+    for d in dims[1:-1]:
+        if d != 128:
+            raise ValueError('MLP %s: hidden width %d, HIP kernels are built for 128' % (prefix, d))
+    s.nlayers = k
+    for i, d in enumerate(dims):
+        s.dims[i] = d
+    return dims
+
+
+def pack_mlp(sd, prefix):
+    p = Packed(L.StriveMLP())
+    p.dims = _fill_mlp(p.struct, p, sd, prefix)
+    return p
+
+
+def _fill_gnn(s, holder, sd, prefix, NC):
+    _fill_mlp(s.mlp_in, holder, sd, prefix + '.mlp_in')
+    _fill_mlp(s.edge, holder, sd, prefix + '.msg.0.edge_mlp')
+    _fill_mlp(s.update, holder, sd, prefix + '.msg.0.update_mlp')
+    _fill_mlp(s.mlp_out, holder, sd, prefix + '.mlp_out')
+    D = s.mlp_in.dims[s.mlp_in.nlayers]
+    s.D = D
+    s.NC = NC
+    if s.edge.dims[0] != 2 * (D + NC) + 4 or s.update.dims[0] != 2 * D + NC:
+        raise ValueError('GNN %s: unexpected edge/update input sizes' % prefix)
+    if D not in (64, 128):
+        raise ValueError('GNN %s: node size %d unsupported (64 or 128)' % (prefix, D))
+
+
+def pack_gnn(sd, prefix, NC):
+    p = Packed(L.StriveGNN())
+    _fill_gnn(p.struct, p, sd, prefix, NC)
+    return p
+
+
+def _fill_gru(s, holder, sd, prefix):
+    for l in range(3):
+        wih = _c(sd['%s.weight_ih_l%d' % (prefix, l)])
+        whh = _c(sd['%s.weight_hh_l%d' % (prefix, l)])
+        s.wih[l] = holder.hold(wih)
+        s.whh[l] = holder.hold(whh)
+        s.wih_t[l] = holder.hold(wih.t().contiguous())
+        s.whh_t[l] = holder.hold(whh.t().contiguous())
+        s.bih[l] = holder.hold(_c(sd['%s.bias_ih_l%d' % (prefix, l)]))
+        s.bhh[l] = holder.hold(_c(sd['%s.bias_hh_l%d' % (prefix, l)]))
+
+
+def _fill_cnn(s, holder, sd):
+    expect = [(16, 4, 7), (32, 16, 5), (64, 32, 5), (64, 64, 3), (128, 64, 3), (128, 128, 3)]
+    for l in range(6):
+        w = _c(sd['map_conv.%d.weight' % (3 * l)])
+        co, ci, k = expect[l]
+        if tuple(w.shape) != (co, ci, k, k):
+            raise NotImplementedError('the HIP map CNN implements the reference default architecture only '
+                                      '(layer %d weight %s, expected %s)' % (l, tuple(w.shape), (co, ci, k, k)))
+        if l == 0:
+            pk = w.permute(2, 3, 1, 0).contiguous()                       # [ky][kx][ci][co]
+        else:
+            pk = w.view(co, ci // 2, 2, k, k).permute(1, 3, 4, 2, 0).contiguous()   # [ci/2][ky][kx][ci&1][co]
+        s.w[l] = holder.hold(pk)
+        s.b[l] = holder.hold(_c(sd['map_conv.%d.bias' % (3 * l)]))
+        s.gn_g[l] = holder.hold(_c(sd['map_conv.%d.weight' % (3 * l + 1)]))
+        s.gn_b[l] = holder.hold(_c(sd['map_conv.%d.bias' % (3 * l + 1)]))
+    fw = _c(sd['map_feature.weight'])
+    if tuple(fw.shape) != (64, 512):
+        raise NotImplementedError('map_feature must be Linear(512, 64)')
+    s.fc_wt = holder.hold(fw.t().contiguous())
+    s.fc_b = holder.hold(_c(sd['map_feature.bias']))
+
+
+def pack_cnn(sd):
+    p = Packed(L.StriveCNN())
+    _fill_cnn(p.struct, p, sd)
+    return p
+
+
+def _fill_map(s, holder, map_env, device):
+    raster = map_env.nusc_raster
+    dx = map_env.nusc_dx
+    if raster.dtype != torch.uint8 or dx.dtype != torch.float64:
+        raise TypeError('map raster must be uint8 and nusc_dx float64 (reference src/datasets/map_env.py:165-166)')
+    raster = raster.to(device).contiguous()
+    dx = dx.to(device).contiguous()
+    M, Cc, H, W = raster.shape
+    s.raster = holder.hold(raster)
+    s.dx = holder.hold(dx)
+    s.M, s.C, s.H, s.W = M, Cc, H, W
+    b = map_env.bounds
+    # fp32 linspace tables, generated exactly like the reference does (torch.linspace, fp32)
+    s.lwise = holder.hold(torch.linspace(b[0], b[2], map_env.L).to(device))
+    s.wwise = holder.hold(torch.linspace(b[1], b[3], map_env.W).to(device))
+    s.L, s.Wc = map_env.L, map_env.W
+
+
+def pack_map(map_env, device):
+    p = Packed(L.StriveMap())
+    _fill_map(p.struct, p, map_env, device)
+    return p
+
+
+def pack_decoder(sd, NC, map_env, device, state_norm, att_norm, bike):
+    """state_norm / att_norm: objects with mean_vals/std_vals (MeanStdNormalizer API); bike: dict."""
+    p = Packed(L.StriveDecoder())
+    s = p.struct
+    _fill_gnn(s.gnn, p, sd, 'decoder_net', NC)
+    _fill_gru(s.gru, p, sd, 'decoder_memory')
+    _fill_cnn(s.cnn, p, sd)
+    _fill_map(s.map, p, map_env, device)
+    for i in range(6):
+        s.state_mean[i] = float(state_norm.mean_vals[i])
+        s.state_std[i] = float(state_norm.std_vals[i])
+    for i in range(2):
+        s.att_mean[i] = float(att_norm.mean_vals[i])
+        s.att_std[i] = float(att_norm.std_vals[i])
+    s.a_mean, s.a_std = bike['a_stats']
+    s.ddh_mean, s.ddh_std = bike['ddh_stats']
+    s.dt = bike['dt']
+    s.max_hdot = bike['maxhdot']
+    s.max_s = bike['maxs']
+    return p
+
+
+def pack_scenes(ptr, NS, device):
+    """ptr: (B+1,) long tensor of scene offsets -> StriveScenes (int32 device tensors)."""
+    p = Packed(L.StriveScenes())
+    ptr32 = ptr.to(device=device, dtype=torch.int32).contiguous()
+    sizes = (ptr[1:] - ptr[:-1]).to('cpu')
+    B = sizes.shape[0]
+    scene_of = torch.repeat_interleave(torch.arange(B, dtype=torch.int32), sizes).to(device).contiguous()
+    p.struct.NA = int(ptr[-1])
+    p.struct.NS = int(NS)
+    p.struct.B = int(B)
+    p.struct.ptr = p.hold(ptr32)
+    p.struct.scene_of = p.hold(scene_of)
+    p.sizes = sizes
+    return p

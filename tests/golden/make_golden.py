@@ -1,0 +1,534 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Only runs in the build container, where the reference is mounted read-only at /root/reference
+(it does not exist on the GPU box, and none of its source is copied here -- the committed
+fixtures are data: inputs are regenerated from strive_amd.synth's counter-based generator and only
+the reference's outputs are stored).
+
+The reference imports three third-party packages that are not installed (torch_geometric,
+nuscenes-devkit, pyquaternion).  They are replaced by the import stand-ins below:
+  * nuscenes / pyquaternion: empty symbols, needed only so module-level imports succeed;
+  * torch_geometric.nn.MessagePassing: restates the published semantics of PyG 1.7.1's
+    ``propagate`` for ``flow='source_to_target'``, ``aggr='max'`` (gather ``*_j`` with
+    ``edge_index[0]``, ``*_i`` with ``edge_index[1]`` on dim -2, call ``message``, scatter-max
+    by target with 0 for empty rows, call ``update``);
+  * torch_geometric.data: the Data/Batch containers of strive_amd.graph.
+numpy aliases removed in numpy>=1.24 (np.int/np.bool/np.float) are restored for the reference.
+
+Usage:  python tests/golden/make_golden.py   (writes tests/golden/*.npz)
+"""
+import inspect
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, '..', '..'))
+REF_SRC = '/root/reference/src'
+
+sys.path.insert(0, REPO)
+from strive_amd import synth                                    # noqa: E402
+from strive_amd.graph import Data, Batch                        # noqa: E402
+from strive_amd.constants import NUSC_BIKE_PARAMS, state_norm_tensors, att_norm_tensors  # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------
+# import stand-ins
+# ------------------------------------------------------------------------------------------
+
+def _install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    class _Empty(object):
+        def __init__(self, *a, **k):
+            pass
+
+    mod('nuscenes')
+    mod('nuscenes.map_expansion')
+    mod('nuscenes.map_expansion.map_api', NuScenesMap=_Empty)
+    mod('nuscenes.map_expansion.arcline_path_utils', discretize_lane=lambda *a, **k: None)
+    mod('nuscenes.nuscenes', NuScenes=_Empty)
+    mod('nuscenes.utils')
+    mod('nuscenes.utils.splits', create_splits_scenes=lambda *a, **k: {})
+    mod('pyquaternion', Quaternion=_Empty)
+
+    class MessagePassing(torch.nn.Module):
+        def __init__(self, aggr='add', flow='source_to_target', node_dim=-2):
+            super().__init__()
+            assert aggr == 'max' and flow == 'source_to_target'
+            self._msg_args = [p for p in inspect.signature(self.message).parameters]
+            self._upd_args = [p for p in inspect.signature(self.update).parameters][1:]
+
+        def propagate(self, edge_index, **kw):
+            src, dst = edge_index[0], edge_index[1]
+            margs = {}
+            for name in self._msg_args:
+                base, suffix = name[:-2], name[-2:]
+                v = kw.get(base)
+                if v is None or not torch.is_tensor(v):
+                    margs[name] = None
+                else:
+                    margs[name] = v.index_select(-2, dst if suffix == '_i' else src)
+            msg = self.message(**margs)
+            n = kw['x'].shape[0]
+            out = torch.zeros((n, msg.shape[1]), dtype=msg.dtype, device=msg.device)
+            if msg.shape[0] > 0:
+                out = out.scatter_reduce(0, dst.view(-1, 1).expand_as(msg), msg, reduce='amax', include_self=False)
+            return self.update(out, **{k: kw.get(k) for k in self._upd_args})
+
+    class DataLoader(object):
+        def __init__(self, *a, **k):
+            raise RuntimeError('not available in the golden harness')
+
+    mod('torch_geometric')
+    mod('torch_geometric.nn', MessagePassing=MessagePassing)
+    mod('torch_geometric.data', Data=Data, Batch=Batch, DataLoader=DataLoader)
+    mod('torch_geometric.utils')
+    for alias, typ in (('int', int), ('bool', bool), ('float', float)):
+        if not hasattr(np, alias):
+            setattr(np, alias, typ)
+
+
+def import_reference():
+    _install_stubs()
+    if sys.path[0] != REF_SRC:
+        sys.path.insert(0, REF_SRC)       # must beat the installed HF 'datasets' package
+    for name in list(sys.modules):
+        if name == 'datasets' or name.startswith('datasets.'):
+            del sys.modules[name]
+    import importlib
+    R = types.SimpleNamespace()
+    R.traffic_model = importlib.import_module('models.traffic_model')
+    R.interaction_net = importlib.import_module('models.interaction_net')
+    R.common = importlib.import_module('models.common')
+    R.transforms = importlib.import_module('utils.transforms')
+    R.nutils = importlib.import_module('datasets.nuscenes_utils')
+    R.dutils = importlib.import_module('datasets.utils')
+    R.map_env = importlib.import_module('datasets.map_env')
+    R.adv_losses = importlib.import_module('losses.adv_gen_nusc')
+    R.tm_losses = importlib.import_module('losses.traffic_model')
+    R.loss_common = importlib.import_module('losses.common')
+    R.scenario_gen = importlib.import_module('utils.scenario_gen')
+    R.init_optim = importlib.import_module('utils.init_optim')
+    R.adv_optim = importlib.import_module('utils.adv_gen_optim')
+    R.sol_optim = importlib.import_module('utils.sol_optim')
+    return R
+
+
+# ------------------------------------------------------------------------------------------
+# shared fixtures (also imported by the tests to regenerate inputs)
+# ------------------------------------------------------------------------------------------
+
+RASTER_HW = 1024
+
+
+def build_inputs(sizes, key, FT=12, NC=2, M=1, window=None):
+    """(batch, map_idx, raster, dx).  window=None keeps the default 120 m spread."""
+    if window is None:
+        batch, map_idx = synth.make_batch(sizes, key=key, FT=FT, NC=NC, M=M)
+    else:
+        scenes = [synth.make_scene(n, '%s/%d' % (key, b), FT=FT, NC=NC, window=window) for b, n in enumerate(sizes)]
+        batch = Batch.from_data_list(scenes)
+        map_idx = torch.tensor([b % M for b in range(len(sizes))], dtype=torch.long)
+    raster, dx = synth.make_raster(RASTER_HW, RASTER_HW, M=M)
+    return batch, map_idx, raster, dx
+
+
+def ref_map_env(R, raster, dx):
+    env = object.__new__(R.map_env.NuScenesMapEnv)
+    env.nusc_raster = raster
+    env.nusc_dx = dx
+    env.bounds = [-17.0, -38.5, 60.0, 38.5]
+    env.L = 256
+    env.W = 256
+    env.map_list = ['synthetic-%d' % i for i in range(raster.shape[0])]
+    env.num_layers = raster.shape[1]
+    env.device = torch.device('cpu')
+    return env
+
+
+def ref_model(R, NC=2, FT=12, key='weights'):
+    m = R.traffic_model.TrafficModel(4, FT, 256, NC)
+    sd = synth.fill_state_dict(m.state_dict(), key=key)
+    m.load_state_dict(sd)
+    m.set_normalizer(R.dutils.MeanStdNormalizer(*state_norm_tensors()))
+    m.set_att_normalizer(R.dutils.MeanStdNormalizer(*att_norm_tensors()))
+    m.set_bicycle_params(NUSC_BIKE_PARAMS)
+    m.eval()
+    return m, sd
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print('wrote %s (%.1f KB)' % (name, os.path.getsize(path) / 1024.0))
+
+
+# ------------------------------------------------------------------------------------------
+# fixture generators
+# ------------------------------------------------------------------------------------------
+
+def g1_ops(R):
+    out = {}
+    frame = synth.f32(synth.counter_uniform((7, 4), 'g1/frame', -2.0, 2.0))
+    poses = synth.f32(synth.counter_uniform((7, 5, 4), 'g1/poses', -3.0, 3.0))
+    out['t2f_fwd'] = npy(R.transforms.transform2frame(frame, poses))
+    out['t2f_inv'] = npy(R.transforms.transform2frame(frame, poses, inverse=True))
+    # bicycle step incl. clamp-active rows
+    st = synth.f32(synth.counter_uniform((9, 6), 'g1/state', -1.0, 1.0))
+    st[:, 0:2] *= 100.0
+    st[:, 4] = torch.tensor([0.0, 0.2, 3.0, 49.9, 12.0, 0.01, 7.0, 25.0, 1.0])
+    st[:, 5] = torch.tensor([0.0, 6.2, -6.2, 0.1, -0.1, 0.3, 0.0, 1.0, -1.0])
+    a = synth.f32(synth.counter_uniform((9,), 'g1/a', -4.0, 4.0))
+    a[0] = -3.0
+    a[3] = 4.0
+    ddh = synth.f32(synth.counter_uniform((9,), 'g1/ddh', -0.5, 0.5))
+    ddh[1] = 0.5
+    ddh[2] = -0.5
+    vlen = synth.f32(synth.counter_uniform((9,), 'g1/len', 3.5, 6.0))
+    tm, _ = ref_model(R)
+    sim = tm.sim_traj(st.unsqueeze(1), a.view(9, 1, 1), ddh.view(9, 1, 1), vlen.view(9, 1))[:, 0, 0]
+    out['bicycle'] = npy(sim)
+    # MLP + GRU one step with the model's own weights
+    x = synth.f32(synth.counter_uniform((6, 38), 'g1/mlp_in', -1.0, 1.0))
+    out['mlp_past_encoder'] = npy(tm.past_encoder(x))
+    xi = synth.f32(synth.counter_uniform((6, 1, 4), 'g1/gru_x', -1.0, 1.0))
+    h0 = synth.f32(synth.counter_uniform((3, 6, 64), 'g1/gru_h', -1.0, 1.0))
+    o, h1 = tm.decoder_memory(xi, h0)
+    out['gru_out'] = npy(o[:, 0])
+    out['gru_h'] = npy(h1)
+    tr = synth.f32(synth.counter_uniform((5, 12, 4), 'g1/traj', -2.0, 2.0))
+    out['interp'] = npy(R.adv_losses.interp_traj(tr, scale_factor=3))
+    zz = synth.f32(synth.counter_uniform((5, 32), 'g1/z', -2.0, 2.0))
+    mu = synth.f32(synth.counter_uniform((5, 32), 'g1/mu', -1.0, 1.0))
+    var = synth.f32(synth.counter_uniform((5, 32), 'g1/var', 0.2, 2.0))
+    var2 = synth.f32(synth.counter_uniform((5, 32), 'g1/var2', 0.2, 2.0))
+    out['log_normal'] = npy(R.loss_common.log_normal(zz, mu, var))
+    out['kl_normal'] = npy(R.loss_common.kl_normal(zz, var2, mu, var))
+    save('g1_ops.npz', **out)
+
+
+def g2_inputs():
+    raster, dx = synth.make_raster(RASTER_HW, RASTER_HW, M=2)
+    n = 12
+    frame = np.zeros((n, 4))
+    frame[:, 0] = synth.counter_uniform((n,), 'g2/x', 30.0, 226.0)
+    frame[:, 1] = synth.counter_uniform((n,), 'g2/y', 30.0, 226.0)
+    ang = synth.counter_uniform((n,), 'g2/h', -np.pi, np.pi)
+    frame[:, 2], frame[:, 3] = np.cos(ang), np.sin(ang)
+    frame[1, :2] = [3.0, 4.0]          # mostly out of bounds
+    frame[2, :2] = [250.0, 252.0]      # off the far corner
+    frame[3, 2:] = [1.0, 0.0]          # axis aligned
+    frame[4, 2:] = [0.0, 1.0]
+    frame = synth.f32(frame)
+    frame[5, 0] = float('nan')         # NaN frame -> samples world (0,0)
+    mapixes = torch.tensor([i % 2 for i in range(n)], dtype=torch.long)
+    lw = synth.f32(np.stack([synth.counter_uniform((n,), 'g2/l', 3.5, 6.5),
+                             synth.counter_uniform((n,), 'g2/w', 1.6, 2.5)], -1))
+    return raster, dx, frame, mapixes, lw
+
+
+def g2_crop(R):
+    raster, dx, frame, mapixes, lw = g2_inputs()
+    bounds = [-17.0, -38.5, 60.0, 38.5]
+    crop = R.nutils.get_map_obs(raster, dx, frame, mapixes, bounds, L=256, W=256)
+    out = {'crop_sum': npy(crop.long().sum(dim=(2, 3))),
+           'crop_rowsum': npy(crop.long().sum(dim=3)).astype(np.int16),
+           'crop_colsum': npy(crop.long().sum(dim=2)).astype(np.int16),
+           'crop_full_0': np.packbits(npy(crop[0])), 'crop_full_7': np.packbits(npy(crop[7])),
+           'crop_full_1': np.packbits(npy(crop[1]))}
+    ok = ~torch.isnan(frame[:, 0])
+    pt, frac = R.nutils.get_coll_point(raster[:, 0], dx, frame[ok], lw[ok], mapixes[ok], return_iou=True)
+    out['coll_pt'] = npy(pt)
+    out['coll_frac'] = npy(frac)
+    out['on_layer'] = npy(R.nutils.check_on_layer(raster[:, 0], dx, frame[ok], lw[ok], mapixes[ok]))
+    start = frame[ok][:, :2]
+    end = start + synth.f32(synth.counter_uniform((int(ok.sum()), 2), 'g2/end', -25.0, 25.0))
+    inb = (start.min(dim=1)[0] > 10) & (end.min(dim=1)[0] > 10) & (start.max(dim=1)[0] < 245) & (end.max(dim=1)[0] < 245)
+    out['line_sel'] = npy(inb)
+    out['line_hit'] = npy(R.nutils.check_line_layer(raster[:, 0], dx, start[inb], end[inb], mapixes[ok][inb]))
+    save('g2_crop.npz', **out)
+
+
+G3_SIZES = [3, 5, 1]
+
+
+def g3_gnn(R):
+    tm, _ = ref_model(R)
+    batch, map_idx, raster, dx = build_inputs(G3_SIZES, 'g3')
+    NA = batch.past.shape[0]
+    out = {}
+    for name, net, fin in (('decoder', tm.decoder_net, 164), ('prior', tm.prior_net, 130), ('posterior', tm.posterior_net, 194)):
+        x = synth.f32(synth.counter_uniform((NA, fin), 'g3/x/' + name, -1.0, 1.0)).requires_grad_(True)
+        pos = batch.past[:, -1, :4].clone()
+        if name == 'prior':
+            pos[1, 0] = float('nan')           # NaN pose on edges -> rel pose 0
+        pos.requires_grad_(True)
+        batch.x, batch.pos = x, pos
+        y = net(batch)
+        rw = synth.f32(synth.counter_uniform(tuple(y.shape), 'g3/r/' + name, -1.0, 1.0))
+        gx, gp = torch.autograd.grad((y * rw).sum(), [x, pos])
+        out[name + '_out'] = npy(y)
+        out[name + '_gx'] = npy(gx)
+        out[name + '_gpos'] = npy(gp)
+    # multi-sample path (NS=2) of the decoder net
+    x = synth.f32(synth.counter_uniform((NA, 2, 164), 'g3/x/ns', -1.0, 1.0))
+    pos = batch.past[:, -1, :4].unsqueeze(1).expand(NA, 2, 4) + 0.01 * synth.f32(synth.counter_uniform((NA, 2, 4), 'g3/p/ns', -1, 1))
+    batch.x, batch.pos = x, pos
+    out['decoder_ns_out'] = npy(tm.decoder_net(batch))
+    save('g3_gnn.npz', **out)
+
+
+G4_SIZES = [3, 5, 1]
+
+
+def g4_rollout(R):
+    out = {}
+    for FT in (12, 16):
+        tm, _ = ref_model(R, FT=12)
+        batch, map_idx, raster, dx = build_inputs(G4_SIZES, 'g4')
+        env = ref_map_env(R, raster, dx)
+        with torch.no_grad():
+            emb = tm.embed(batch, map_idx, env)
+        emb = R.scenario_gen.detach_embed_info(emb)
+        if FT == 12:
+            out['map_feat'] = npy(emb['map_feat'])
+            out['past_feat'] = npy(emb['past_feat'])
+            out['prior_mu'] = npy(emb['prior_out'][0])
+            out['prior_var'] = npy(emb['prior_out'][1])
+            out['post_mu'] = npy(emb['posterior_out'][0])
+            out['post_var'] = npy(emb['posterior_out'][1])
+        z = synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='g4/z').requires_grad_(True)
+        pred = tm.decode_embedding(z, emb, batch, map_idx, env, nfuture=FT)['future_pred']
+        rw = synth.f32(synth.counter_uniform(tuple(pred.shape), 'g4/r%d' % FT, -1.0, 1.0))
+        gz, = torch.autograd.grad((pred * rw).sum(), [z])
+        out['pred_ft%d' % FT] = npy(pred)
+        out['gz_ft%d' % FT] = npy(gz)
+    # ext_future (ego teacher forcing) -- FT = 12
+    NA = batch.past.shape[0]
+    ego = batch.ptr[:-1]
+    ext = batch.future_gt[ego][:, :, :4]
+    z = synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='g4/z').requires_grad_(True)
+    pred = tm.decode_embedding(z, emb, batch, map_idx, env, ext_future=ext)['future_pred']
+    rw = synth.f32(synth.counter_uniform(tuple(pred.shape), 'g4/rext', -1.0, 1.0))
+    gz, = torch.autograd.grad((pred * rw).sum(), [z])
+    out['pred_ext'] = npy(pred)
+    out['gz_ext'] = npy(gz)
+    # 3-D z, NS = 2
+    z3 = torch.stack([synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='g4/z'),
+                      synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='g4/z_b')], dim=1).requires_grad_(True)
+    pred = tm.decode_embedding(z3, emb, batch, map_idx, env)['future_pred']
+    rw = synth.f32(synth.counter_uniform(tuple(pred.shape), 'g4/rns', -1.0, 1.0))
+    gz, = torch.autograd.grad((pred * rw).sum(), [z3])
+    out['pred_ns'] = npy(pred)
+    out['gz_ns'] = npy(gz)
+    save('g4_rollout.npz', **out)
+
+
+G5_SIZES = [4, 6, 2]
+ADV_WEIGHTS = {'coll_veh': 20.0, 'coll_veh_plan': 20.0, 'coll_env': 20.0, 'init_z': 0.5, 'init_z_atk': 0.05,
+               'motion_prior': 1.0, 'motion_prior_atk': 0.005, 'motion_prior_ext': 0.0001, 'match_ext': 10.0,
+               'adv_crash': 2.0}
+REFINE_WEIGHTS = {'coll_veh': 100.0, 'coll_env': 100.0, 'init_z': 0.01, 'motion_prior': 1.0}
+
+
+def g5_inputs(R_or_none, model_builder):
+    """Trajectories for the loss fixtures: a rollout from a dense (window 14 m) batch so vehicle
+    and environment collisions actually occur."""
+    batch, map_idx, raster, dx = build_inputs(G5_SIZES, 'g5', window=14.0)
+    return batch, map_idx, raster, dx
+
+
+def g5_losses(R):
+    tm, _ = ref_model(R)
+    batch, map_idx, raster, dx = g5_inputs(R, None)
+    env = ref_map_env(R, raster, dx)
+    with torch.no_grad():
+        emb = R.scenario_gen.detach_embed_info(tm.embed(batch, map_idx, env))
+    NA = batch.past.shape[0]
+    B = len(G5_SIZES)
+    ego_mask = torch.zeros((NA,), dtype=torch.bool)
+    ego_mask[batch.ptr[:-1]] = True
+    veh_att = tm.get_att_normalizer().unnormalize(batch.lw)
+    mapixes = map_idx[batch.batch]
+    out = {}
+
+    def run_avoid(tag, buf, single, FT):
+        z = synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='g5/z').requires_grad_(True)
+        pred = tm.decode_embedding(z, emb, batch, map_idx, env, nfuture=FT)['future_pred']
+        out['pred_' + tag] = npy(pred)
+        predu = tm.get_normalizer().unnormalize(pred)
+        if single is None:
+            lf = R.adv_losses.AvoidCollLoss(REFINE_WEIGHTS, veh_att, mapixes, env, z.clone().detach() * 0.9, veh_coll_buffer=buf)
+            ld = lf(predu, z, emb['prior_out'])
+        else:
+            lf = R.adv_losses.AvoidCollLoss(REFINE_WEIGHTS, veh_att, mapixes, env, z[ego_mask].clone().detach() * 0.9,
+                                            veh_coll_buffer=buf, single_veh_idx=0, ptr=batch.ptr)
+            ld = lf(predu, z[ego_mask], (emb['prior_out'][0][ego_mask], emb['prior_out'][1][ego_mask]))
+        ld['loss'].backward()
+        for k, v in ld.items():
+            out['%s_%s' % (tag, k)] = npy(v)
+        out[tag + '_gz'] = npy(z.grad)
+
+    run_avoid('avoid02', 0.2, None, 16)
+    run_avoid('avoid05s', 0.5, 0, 12)
+
+    # adversarial loss, ego-planner mode (target trajectory = ego GT future), min time 2, infront 0.0
+    z = synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='g5/z')
+    other_z = z[~ego_mask].clone().requires_grad_(True)
+    tgt_z = z[ego_mask].clone().requires_grad_(True)
+    zc = R.adv_optim.collate_tgt_other_z(batch, tgt_z.detach(), other_z)
+    planner = batch.future_gt[ego_mask][:, :, :4]
+    pred = tm.decode_embedding(zc, emb, batch, map_idx, env, ext_future=planner)['future_pred']
+    lf = R.adv_losses.AdvGenLoss(ADV_WEIGHTS, veh_att, mapixes, env, other_z.clone().detach() * 0.9, batch.ptr,
+                                 veh_coll_buffer=0.1, crash_loss_min_time=2, crash_loss_min_infront=0.0)
+    oprior = (emb['prior_out'][0][~ego_mask], emb['prior_out'][1][~ego_mask])
+    ld = lf(tm.get_normalizer().unnormalize(pred), tm.get_normalizer().unnormalize(planner), other_z, oprior,
+            return_mins=True)
+    ld['loss'].backward()
+    for k, v in ld.items():
+        out['adv_%s' % k] = npy(v) if torch.is_tensor(v) else np.asarray(v)
+    out['adv_gz'] = npy(other_z.grad)
+    out['adv_pred'] = npy(pred)
+    # same with a fixed attacker per scene and without the in-front test
+    other_z2 = z[~ego_mask].clone().requires_grad_(True)
+    zc = R.adv_optim.collate_tgt_other_z(batch, tgt_z.detach(), other_z2)
+    pred = tm.decode_embedding(zc, emb, batch, map_idx, env, ext_future=planner)['future_pred']
+    lf2 = R.adv_losses.AdvGenLoss(ADV_WEIGHTS, veh_att, mapixes, env, other_z2.clone().detach() * 0.9, batch.ptr,
+                                  veh_coll_buffer=0.1, crash_loss_min_time=0, crash_loss_min_infront=None)
+    atk = torch.tensor([1, 2, 1]) + batch.ptr[:-1]
+    ld = lf2(tm.get_normalizer().unnormalize(pred), tm.get_normalizer().unnormalize(planner), other_z2, oprior,
+             attack_agt_idx=atk)
+    ld['loss'].backward()
+    for k, v in ld.items():
+        out['adv2_%s' % k] = npy(v)
+    out['adv2_gz'] = npy(other_z2.grad)
+    # all-behind case: put every attacker behind the target => fallback branch
+    far = tm.get_normalizer().unnormalize(pred).detach().clone()
+    tgt_far = tm.get_normalizer().unnormalize(planner).clone()
+    tgt_far[:, :, 0] += 500.0
+    tgt_far[:, :, 2] = 1.0
+    tgt_far[:, :, 3] = 0.0
+    ld = lf(far, tgt_far, other_z.detach(), oprior, return_mins=True)
+    out['advbehind_crash'] = npy(ld['adv_crash_loss'])
+    out['advbehind_min_agt'] = np.asarray(ld['min_agt'])
+    out['advbehind_min_t'] = np.asarray(ld['min_t'])
+
+    # TgtMatchingLoss (with its prior-term quirk)
+    tl = R.adv_losses.TgtMatchingLoss(ADV_WEIGHTS)
+    tz = z[ego_mask].clone().requires_grad_(True)
+    tprior = (emb['prior_out'][0][ego_mask], emb['prior_out'][1][ego_mask])
+    ld = tl(tm.get_normalizer().unnormalize(pred[ego_mask]), tm.get_normalizer().unnormalize(planner), tz, tprior)
+    for k, v in ld.items():
+        out['tgt_%s' % k] = npy(v)
+
+    # raw vehicle-collision matrices + a no-collision case + training variants
+    fine = R.adv_losses.interp_traj(tm.get_normalizer().unnormalize(pred).detach(), 3)
+    vl = R.adv_losses.VehCollLoss(veh_att, buffer_dist=0.1, ptr=batch.ptr)
+    pens, cmask = vl(fine, return_raw=True)
+    valid = vl.off_diag_mask.view(1, NA, NA).expand_as(pens)
+    out['veh_raw_pens_valid'] = npy(pens[valid])
+    out['veh_raw_mask_valid'] = npy(cmask[valid])
+    spread = fine.clone()
+    spread[:, :, 0] += 40.0 * torch.arange(NA).view(NA, 1)
+    out['veh_nocoll'] = npy(vl(spread))
+    tvl = R.tm_losses.VehCollLoss(veh_att, batch.batch, batch.ptr)
+    tp, npairs = tvl(tm.get_normalizer().unnormalize(pred).detach())
+    out['train_veh_pens'] = npy(tp)
+    out['train_veh_npairs'] = npy(npairs)
+    ego = batch.ptr[:-1]
+    tel = R.tm_losses.EnvCollLoss(tm.get_att_normalizer().unnormalize(batch.lw[ego]), map_idx, env, pred.shape[1])
+    out['train_env_pens'] = npy(tel(tm.get_normalizer().unnormalize(pred[ego]).detach()))
+
+    # full training loss (fwd values only; weight grads of a few tensors as checksums)
+    tm.train()
+    for p in tm.parameters():
+        p.grad = None
+    eps_post = synth.f32(synth.counter_normal((NA, 32), 'g5/eps_post'))
+    eps_prior = synth.f32(synth.counter_normal((NA, 32), 'g5/eps_prior'))
+    seq = [eps_post, eps_prior]
+    tm.rsample = lambda mean, var: mean + seq.pop(0) * torch.sqrt(var)
+    net_out = tm(batch, map_idx, env, future_sample=True)
+    tw = {'recon': 1.0, 'kl': 0.004, 'coll_veh_prior': 0.05, 'coll_env_prior': 0.1}
+    tloss = R.tm_losses.TrafficModelLoss(tw, tm.get_normalizer(), tm.get_att_normalizer())
+    ld = tloss(batch, net_out, map_idx, env)
+    ld['loss'].sum().backward()
+    for k, v in ld.items():
+        out['train_%s' % k] = npy(v)
+    out['train_future_pred'] = npy(net_out['future_pred'])
+    out['train_future_samp'] = npy(net_out['future_samp'])
+    sdg = {n: p.grad for n, p in tm.named_parameters() if p.grad is not None}
+    out['train_ngrads'] = np.asarray(len(sdg))
+    for n in ('decoder_net.mlp_out.net.6.weight', 'decoder_memory.weight_hh_l0', 'map_conv.0.weight',
+              'map_feature.weight', 'prior_net.msg.0.edge_mlp.net.0.weight', 'past_encoder.net.0.weight',
+              'posterior_net.mlp_in.net.0.weight', 'future_encoder.net.9.bias'):
+        out['train_grad/' + n] = npy(sdg[n]).astype(np.float32) if sdg[n].numel() < 20000 else npy(sdg[n].reshape(-1)[:20000])
+    save('g5_losses.npz', **out)
+
+
+G6_SIZES = [8]
+
+
+def g6_loop(R):
+    """config-1-like: 1 scene, 8 agents, refine closure, 10 Adam iterations at lr 0.05."""
+    tm, _ = ref_model(R)
+    batch, map_idx, raster, dx = build_inputs(G6_SIZES, 'g6', window=16.0)
+    env = ref_map_env(R, raster, dx)
+    with torch.no_grad():
+        emb = R.scenario_gen.detach_embed_info(tm.embed(batch, map_idx, env))
+    z0 = synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='g6/z')
+    z = z0.clone().detach().requires_grad_(True)
+    opt = torch.optim.Adam([z], lr=0.05)
+    lf = R.adv_losses.AvoidCollLoss(REFINE_WEIGHTS, tm.get_att_normalizer().unnormalize(batch.lw), map_idx[batch.batch],
+                                    env, z.clone().detach(), veh_coll_buffer=0.2)
+    zs, losses, grads = [], [], []
+    keys = ['coll_veh_loss', 'coll_env_loss', 'motion_prior_loss', 'init_loss', 'loss']
+    for it in range(10):
+        opt.zero_grad()
+        pred = tm.decode_embedding(z, emb, batch, map_idx, env, nfuture=16)['future_pred']
+        ld = lf(tm.get_normalizer().unnormalize(pred), z, emb['prior_out'])
+        ld['loss'].backward()
+        grads.append(npy(z.grad).copy())
+        losses.append([float(torch.mean(ld[k])) for k in keys])
+        opt.step()
+        zs.append(npy(z).copy())
+    save('g6_loop.npz', z=np.stack(zs), grad=np.stack(grads), losses=np.asarray(losses), loss_keys=np.asarray(keys))
+
+    # the reference's own refine_traffic_optim() function is exercised by tests/test_dropin_reference.py
+    # (build-container only); it draws its starting sample unseeded so it cannot be a fixture.
+
+
+def g7_sample(R):
+    """sample_batched NS=3 with injected eps + feasibility-style outputs."""
+    tm, _ = ref_model(R)
+    batch, map_idx, raster, dx = build_inputs([4, 2], 'g7')
+    env = ref_map_env(R, raster, dx)
+    NA = batch.past.shape[0]
+    eps = synth.f32(synth.counter_normal((3, NA, 32), 'g7/eps'))
+    tm.rsample = lambda mean, var: mean + eps * torch.sqrt(var)
+    with torch.no_grad():
+        so = tm.sample_batched(batch, map_idx, env, 3, include_mean=True, nfuture=8)
+    save('g7_sample.npz', future_pred=npy(so['future_pred']), z_samp=npy(so['z_samp']),
+         z_logprob=npy(so['z_logprob']), z_mdist=npy(so['z_mdist']))
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    R = import_reference()
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
+    fns = {'g1': g1_ops, 'g2': g2_crop, 'g3': g3_gnn, 'g4': g4_rollout, 'g5': g5_losses, 'g6': g6_loop, 'g7': g7_sample}
+    for w in which:
+        fns[w](R)

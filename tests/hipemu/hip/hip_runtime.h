@@ -1,0 +1,218 @@
+// TEST INFRASTRUCTURE ONLY -- a tiny host-side model of the HIP execution model.
+//
+// There is no GPU in the build container, so kernel *logic* (indexing, LDS staging, barriers,
+// wave shuffles, MFMA fragment layouts, atomics) would otherwise first run at round end on the
+// MI355X box.  tests/hipemu/build.py compiles the SAME strive_amd/csrc/*.hip sources, unmodified,
+// as host C++ against this header: every workgroup runs as a set of cooperative fibers on one OS
+// thread, __syncthreads() and the wave-collective builtins are rendezvous points, and the two f32
+// MFMA builtins are modelled with the fragment layout documented for gfx950
+// (/opt/skills/guides/cdna_hip_programming.md §3).  The resulting library is loaded ONLY by
+// tests (tests/test_emu_*.py); the product loader (strive_amd/_lib.py) never looks for it, and
+// nothing here is a fallback: no performance claim and no parity claim rests on it.
+#pragma once
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::g.dyn_smem);
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_emu { unsigned x, y, z; };
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+static const hipError_t hipSuccess = 0;
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+enum hipMemcpyKind { hipMemcpyDeviceToDevice = 3 };
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+template <typename F> inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+struct hipEvent_emu;
+typedef hipEvent_emu* hipEvent_t;
+
+namespace hipemu {
+
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    bool done = false;
+};
+
+struct Wave {
+    float f[64];
+    float f2[64];
+    double d[64];
+    long long i[64];
+    int arrived = 0;
+    unsigned gen = 0;
+    int nlanes = 64;
+};
+
+struct Globals {
+    std::vector<Fiber> fibers;
+    ucontext_t main_ctx;
+    int cur = 0;
+    int nthreads = 0;
+    int alive = 0;
+    int barrier_arrived = 0;
+    unsigned barrier_gen = 0;
+    std::vector<Wave> waves;
+    std::function<void()> body;
+    unsigned char* dyn_smem = nullptr;
+    size_t dyn_cap = 0;
+    uint3_emu tid[1024];
+};
+extern Globals g;
+static const size_t STACK_BYTES = 512 * 1024;
+
+void yield_();
+void block_barrier();
+void wave_barrier();
+void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t shmem);
+
+}  // namespace hipemu
+
+extern uint3_emu threadIdx, blockIdx;
+extern dim3 blockDim, gridDim;
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch([&]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block), (size_t)(shmem))
+
+inline void __syncthreads() { hipemu::block_barrier(); }
+inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+
+inline int hipemu_lane() { return (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)) & 63; }
+inline hipemu::Wave& hipemu_wave() {
+    int lin = (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z));
+    return hipemu::g.waves[lin >> 6];
+}
+
+template <typename T> inline T hipemu_exchange(T v, int src_lane) {
+    hipemu::Wave& w = hipemu_wave();
+    int lane = hipemu_lane();
+    static_assert(sizeof(T) <= 8, "exchange");
+    long long bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    w.i[lane] = bits;
+    hipemu::wave_barrier();
+    long long r = w.i[(src_lane >= 0 && src_lane < w.nlanes) ? src_lane : lane];
+    hipemu::wave_barrier();
+    T out;
+    memcpy(&out, &r, sizeof(T));
+    return out;
+}
+template <typename T> inline T __shfl_xor(T v, int mask, int width = 64) { return hipemu_exchange(v, hipemu_lane() ^ mask); }
+template <typename T> inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    int lane = hipemu_lane();
+    int src = lane + (int)delta;
+    if ((src / width) != (lane / width)) src = lane;
+    return hipemu_exchange(v, src);
+}
+template <typename T> inline T __shfl_up(T v, unsigned delta, int width = 64) {
+    int lane = hipemu_lane();
+    int src = lane - (int)delta;
+    if (src < 0 || (src / width) != (lane / width)) src = lane;
+    return hipemu_exchange(v, src);
+}
+template <typename T> inline T __shfl(T v, int src, int width = 64) {
+    int lane = hipemu_lane();
+    return hipemu_exchange(v, (lane / width) * width + (src % width));
+}
+inline unsigned long long __ballot(int pred) {
+    hipemu::Wave& w = hipemu_wave();
+    int lane = hipemu_lane();
+    w.i[lane] = pred ? 1 : 0;
+    hipemu::wave_barrier();
+    unsigned long long m = 0;
+    for (int l = 0; l < w.nlanes; ++l) if (w.i[l]) m |= (1ull << l);
+    hipemu::wave_barrier();
+    return m;
+}
+
+// ---- atomics (single OS thread: plain read-modify-write) ----
+template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
+inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
+inline int atomicExch(int* p, int v) { int o = *p; *p = v; return o; }
+inline int atomicCAS(int* p, int c, int v) { int o = *p; if (o == c) *p = v; return o; }
+
+// ---- math intrinsics: round-to-nearest single ops (the build uses -ffp-contract=off) ----
+inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
+inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
+inline double __ddiv_rn(double a, double b) { volatile double r = a / b; return r; }
+inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
+inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+inline float __expf(float x) { return expf(x); }
+inline float __frcp_rn(float x) { return 1.0f / x; }
+
+// ---- f32 MFMA builtins, gfx950 fragment layout ----
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
+
+// 16x16x4: A[i][k] held by lane k*16+i, B[k][j] by lane k*16+j; D col = lane&15, row = (lane>>4)*4 + reg
+inline hipemu_f32x4 hipemu_mfma_16x16x4(float a, float b, hipemu_f32x4 c, int, int, int) {
+    hipemu::Wave& w = hipemu_wave();
+    int lane = hipemu_lane();
+    w.f[lane] = a;
+    w.f2[lane] = b;
+    hipemu::wave_barrier();
+    hipemu_f32x4 d = c;
+    int j = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        int i = (lane >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(w.f[k * 16 + i], w.f2[k * 16 + j], acc);
+        d[r] = acc;
+    }
+    hipemu::wave_barrier();
+    return d;
+}
+// 32x32x2: A[i][k] held by lane k*32+i, B[k][j] by lane k*32+j; D col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+inline hipemu_f32x16 hipemu_mfma_32x32x2(float a, float b, hipemu_f32x16 c, int, int, int) {
+    hipemu::Wave& w = hipemu_wave();
+    int lane = hipemu_lane();
+    w.f[lane] = a;
+    w.f2[lane] = b;
+    hipemu::wave_barrier();
+    hipemu_f32x16 d = c;
+    int j = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) acc = fmaf(w.f[k * 32 + i], w.f2[k * 32 + j], acc);
+        d[r] = acc;
+    }
+    hipemu::wave_barrier();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_32x32x2

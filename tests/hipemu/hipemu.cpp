@@ -1,0 +1,122 @@
+// TEST INFRASTRUCTURE ONLY -- fiber scheduler behind tests/hipemu/hip/hip_runtime.h.
+#include <hip/hip_runtime.h>
+
+uint3_emu threadIdx, blockIdx;
+dim3 blockDim, gridDim;
+
+namespace hipemu {
+
+Globals g;
+static unsigned long long g_progress = 0;
+
+static void set_tid(int i) {
+    g.cur = i;
+    threadIdx = g.tid[i];
+}
+
+void yield_() {
+    int me = g.cur;
+    swapcontext(&g.fibers[me].ctx, &g.main_ctx);
+    set_tid(me);
+}
+
+void block_barrier() {
+    unsigned gen = g.barrier_gen;
+    g.barrier_arrived++;
+    if (g.barrier_arrived >= g.alive) {
+        g.barrier_arrived = 0;
+        g.barrier_gen++;
+        g_progress++;
+        return;
+    }
+    while (g.barrier_gen == gen) yield_();
+}
+
+void wave_barrier() {
+    Wave& w = g.waves[g.cur >> 6];
+    unsigned gen = w.gen;
+    w.arrived++;
+    if (w.arrived >= w.nlanes) {
+        w.arrived = 0;
+        w.gen++;
+        g_progress++;
+        return;
+    }
+    while (w.gen == gen) yield_();
+}
+
+static void trampoline() {
+    g.body();
+    g.fibers[g.cur].done = true;
+    g.alive--;
+    g_progress++;
+    // a thread that exits early must not leave a block barrier hanging
+    if (g.alive > 0 && g.barrier_arrived >= g.alive) {
+        g.barrier_arrived = 0;
+        g.barrier_gen++;
+    }
+    swapcontext(&g.fibers[g.cur].ctx, &g.main_ctx);
+}
+
+void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t shmem) {
+    int nthreads = (int)(block.x * block.y * block.z);
+    if (nthreads > 1024 || nthreads <= 0) { fprintf(stderr, "hipemu: bad block size %d\n", nthreads); abort(); }
+    if ((int)g.fibers.size() < nthreads) {
+        size_t old = g.fibers.size();
+        g.fibers.resize(nthreads);
+        for (size_t i = old; i < g.fibers.size(); ++i) g.fibers[i].stack = (char*)malloc(STACK_BYTES);
+    }
+    if (shmem + 64 > g.dyn_cap) {
+        free(g.dyn_smem);
+        g.dyn_cap = shmem + 64;
+        g.dyn_smem = (unsigned char*)aligned_alloc(64, (g.dyn_cap + 63) / 64 * 64);
+    }
+    g.body = body;
+    g.nthreads = nthreads;
+    blockDim = block;
+    gridDim = grid;
+    int nwaves = (nthreads + 63) / 64;
+    g.waves.assign(nwaves, Wave());
+    for (int t = 0; t < nthreads; ++t) {
+        g.tid[t].x = t % block.x;
+        g.tid[t].y = (t / block.x) % block.y;
+        g.tid[t].z = t / (block.x * block.y);
+    }
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                blockIdx.x = bx; blockIdx.y = by; blockIdx.z = bz;
+                if (shmem) memset(g.dyn_smem, 0xCD, shmem);   // poison: catches reads of unwritten LDS
+                g.alive = nthreads;
+                g.barrier_arrived = 0;
+                for (int w = 0; w < nwaves; ++w) {
+                    g.waves[w].arrived = 0;
+                    g.waves[w].nlanes = (w == nwaves - 1) ? nthreads - 64 * w : 64;
+                }
+                for (int t = 0; t < nthreads; ++t) {
+                    Fiber& f = g.fibers[t];
+                    f.done = false;
+                    getcontext(&f.ctx);
+                    f.ctx.uc_stack.ss_sp = f.stack;
+                    f.ctx.uc_stack.ss_size = STACK_BYTES;
+                    f.ctx.uc_link = &g.main_ctx;
+                    makecontext(&f.ctx, (void (*)())trampoline, 0);
+                }
+                int guard = 0;
+                while (g.alive > 0) {
+                    unsigned long long before = g_progress;
+                    int progressed = 0;
+                    for (int t = 0; t < nthreads; ++t) {
+                        if (g.fibers[t].done) continue;
+                        set_tid(t);
+                        swapcontext(&g.main_ctx, &g.fibers[t].ctx);
+                        progressed++;
+                    }
+                    if (!progressed) break;
+                    guard = (g_progress == before) ? guard + 1 : 0;
+                    if (guard > 4) { fprintf(stderr, "hipemu: deadlock in block (%u,%u,%u)\n", bx, by, bz); abort(); }
+                }
+            }
+}
+
+}  // namespace hipemu
