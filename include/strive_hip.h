@@ -106,6 +106,7 @@ typedef struct StriveCNN {
  * tensor has rows r = agent * NS + sample (the reference's (NA, NS, .) layout flattened). */
 typedef struct StriveScenes {
     int32_t NA, NS, B;
+    int32_t max_n;            /* largest scene size (host-known; sizes per-edge scratch) */
     const int32_t* ptr;       /* (B+1) */
     const int32_t* scene_of;  /* (NA)  */
 } StriveScenes;
@@ -161,10 +162,6 @@ int strive_map_cnn_fwd_from_crop(const StriveCNN* cnn, const uint8_t* crop, int3
 
 /* MLP.forward (reference src/models/common.py:41-44): y (rows, dims[nlayers]). */
 int strive_mlp_fwd(const StriveMLP* mlp, const float* x, int32_t rows, float* y, strive_stream_t stream);
-
-/* transform2frame (reference src/utils/transforms.py:78-139), 4-d poses: frame (Bf,4), poses (Bf,N,4). */
-int strive_transform2frame(const float* frame, const float* poses, int32_t Bf, int32_t N, int32_t inverse,
-                           float* out, strive_stream_t stream);
 
 size_t strive_gnn_workspace_bytes(const StriveGNN* gnn, const StriveScenes* sc);
 

@@ -53,7 +53,8 @@ class StriveCNN(C.Structure):
 
 
 class StriveScenes(C.Structure):
-    _fields_ = [('NA', C.c_int32), ('NS', C.c_int32), ('B', C.c_int32), ('ptr', C.c_void_p), ('scene_of', C.c_void_p)]
+    _fields_ = [('NA', C.c_int32), ('NS', C.c_int32), ('B', C.c_int32), ('max_n', C.c_int32), ('ptr', C.c_void_p),
+                ('scene_of', C.c_void_p)]
 
 
 class StriveDecoder(C.Structure):
@@ -80,7 +81,6 @@ PROTOTYPES = {
     'strive_map_cnn_fwd': (C.c_int, [C.POINTER(StriveMap), C.POINTER(StriveCNN), P, F4, F4, P, I, P, P, SZ, P]),
     'strive_map_cnn_fwd_from_crop': (C.c_int, [C.POINTER(StriveCNN), P, I, P, P, SZ, P]),
     'strive_mlp_fwd': (C.c_int, [C.POINTER(StriveMLP), P, I, P, P]),
-    'strive_transform2frame': (C.c_int, [P, P, I, I, I, P, P]),
     'strive_gnn_workspace_bytes': (SZ, [C.POINTER(StriveGNN), C.POINTER(StriveScenes)]),
     'strive_gnn_fwd': (C.c_int, [C.POINTER(StriveGNN), C.POINTER(StriveScenes), P, P, P, P, P, SZ, P]),
     'strive_rollout_tape_bytes': (SZ, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), I]),

@@ -1,0 +1,830 @@
+// Decoder rollout: forward over FT autoregressive steps and the explicit reverse-time backward to dL/dz.
+// (reference src/models/traffic_model.py:589-704; gradient dependency map: SURVEY.md Appendix A)
+//
+// Per step t the forward enqueues
+//   node1  : [past_feat_t | map_feat_t | sem | z | lw] -> mlp_in -> x, edge partials P, Q
+//   edge   : per target node, factorised edge MLP over its scene, running max / arg-max
+//   node2r : update MLP -> mlp_out -> (a, ddh) -> kinematic bicycle step -> local-frame pose -> 3-layer GRU
+//   map CNN: fused crop + 6 MFMA convolutions at the new (detached) poses   [t < FT-1]
+// and writes every step's inputs into the tape, so the backward re-derives activations by recomputation
+// (cheap: the GNN/GRU are ~1.6 MFLOP per agent-step against 300 MFLOP for the CNN, which needs no backward
+// at all because the reference crops at pos.detach()).  The backward is four launches per step:
+// node1 (recompute), gru_bwd, node2_bwd, edge_bwd, node1_bwd.
+#include "gnn_kernels.h"
+
+struct DynParams {
+    float smean[6], sstd[6];
+    float amean0, astd0;     // vehicle length normaliser (l)
+    float a_mean, a_std, ddh_mean, ddh_std, dt, max_hdot, max_s;
+};
+
+struct GRUDev {
+    const float* wih[3];
+    const float* whh[3];
+    const float* wih_t[3];
+    const float* whh_t[3];
+    const float* bih[3];
+    const float* bhh[3];
+};
+
+struct Tape {
+    float *pf, *mf, *pos, *state, *mem, *A, *loc;
+    int32_t* ARG;
+    size_t R;
+    __host__ __device__ float* pf_t(int t) const { return pf + (size_t)t * R * 64; }
+    __host__ __device__ float* mf_t(int t) const { return mf + (size_t)t * R * 64; }
+    __host__ __device__ float* pos_t(int t) const { return pos + (size_t)t * R * 4; }
+    __host__ __device__ float* state_t(int t) const { return state + (size_t)t * R * 8; }
+    __host__ __device__ float* mem_t(int t) const { return mem + (size_t)t * R * 192; }
+    __host__ __device__ float* A_t(int t) const { return A + (size_t)t * R * 64; }
+    __host__ __device__ float* loc_t(int t) const { return loc + (size_t)t * R * 4; }
+    __host__ __device__ int32_t* ARG_t(int t) const { return ARG + (size_t)t * R * 64; }
+};
+
+static size_t tape_bytes_for(size_t R, int FT) {
+    const size_t per = 64 + 64 + 4 + 8 + 192 + 64 + 4 + 64;
+    return strive_align_up(R * FT * per * 4 + 8 * 256, 256);
+}
+
+static Tape carve_tape(void* p, size_t bytes, size_t R, int FT) {
+    StriveArena ar(p, bytes);
+    Tape t;
+    t.R = R;
+    t.pf = ar.take<float>(R * FT * 64);
+    t.mf = ar.take<float>(R * FT * 64);
+    t.pos = ar.take<float>(R * FT * 4);
+    t.state = ar.take<float>(R * FT * 8);
+    t.mem = ar.take<float>(R * FT * 192);
+    t.A = ar.take<float>(R * FT * 64);
+    t.loc = ar.take<float>(R * FT * 4);
+    t.ARG = ar.take<int32_t>(R * FT * 64);
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bicycle step on one row (reference src/models/common.py:47-68, src/utils/transforms.py:8-29,
+// src/models/traffic_model.py:645-650) -- forward values + the partials the backward needs.
+// ---------------------------------------------------------------------------------------------
+struct BikeFwd {
+    float su[6];        // unnormalised input state
+    float h, nh, ns, nhd, sn, cs, len;
+    float pre_s, pre_hd;
+    float out[6];       // normalised output state
+};
+
+__device__ __forceinline__ void bike_forward(const DynParams& p, const float* st, float dec0, float dec1, float lw0, BikeFwd& b) {
+    for (int i = 0; i < 6; ++i) b.su[i] = unnorm1(st[i], p.smean[i], p.sstd[i]);
+    const float a = __fadd_rn(__fmul_rn(dec0, p.a_std), p.a_mean);
+    const float ddh = __fadd_rn(__fmul_rn(dec1, p.ddh_std), p.ddh_mean);
+    b.len = unnorm1(lw0, p.amean0, p.astd0);
+    b.h = atan2f(b.su[3], b.su[2]);
+    b.pre_hd = b.su[5] + ddh * p.dt;
+    b.nhd = fminf(fmaxf(b.pre_hd, -p.max_hdot), p.max_hdot);
+    b.nh = b.h + p.dt * fabsf(b.su[4]) / b.len * b.nhd;
+    b.pre_s = b.su[4] + a * p.dt;
+    b.ns = fminf(fmaxf(b.pre_s, 0.0f), p.max_s);
+    b.sn = sinf(b.nh);
+    b.cs = cosf(b.nh);
+    const float ny = b.su[1] + b.ns * b.sn * p.dt;
+    const float nx = b.su[0] + b.ns * b.cs * p.dt;
+    const float u[6] = {nx, ny, b.cs, b.sn, b.ns, b.nhd};
+    for (int i = 0; i < 6; ++i) b.out[i] = norm1(u[i], p.smean[i], p.sstd[i]);
+}
+
+// adjoint: gout (6, w.r.t. normalised output) -> gst (6, w.r.t. normalised input state), gdec (2)
+__device__ __forceinline__ void bike_backward(const DynParams& p, const BikeFwd& b, const float* gout, float* gst, float* gdec) {
+    float gu[6];
+    for (int i = 0; i < 6; ++i) gu[i] = gout[i] / p.sstd[i];
+    const float g_nx = gu[0], g_ny = gu[1];
+    float g_nh = gu[2] * (-b.sn) + gu[3] * b.cs + g_nx * (-b.ns * b.sn * p.dt) + g_ny * (b.ns * b.cs * p.dt);
+    float g_ns = gu[4] + g_nx * b.cs * p.dt + g_ny * b.sn * p.dt;
+    const float m_s = (b.pre_s >= 0.0f && b.pre_s <= p.max_s) ? 1.f : 0.f;
+    g_ns *= m_s;
+    float g_s = g_ns;
+    const float g_a = g_ns * p.dt;
+    // new_h = h + (dt*|s|/len) * new_hdot
+    const float coef = p.dt * fabsf(b.su[4]) / b.len;
+    const float g_h = g_nh;
+    const float sgn = (b.su[4] > 0.f) ? 1.f : ((b.su[4] < 0.f) ? -1.f : 0.f);
+    g_s += g_nh * (p.dt / b.len) * b.nhd * sgn;
+    float g_nhd = gu[5] + g_nh * coef;
+    const float m_h = (b.pre_hd >= -p.max_hdot && b.pre_hd <= p.max_hdot) ? 1.f : 0.f;
+    g_nhd *= m_h;
+    const float g_hd = g_nhd;
+    const float g_ddh = g_nhd * p.dt;
+    const float den = b.su[2] * b.su[2] + b.su[3] * b.su[3];
+    const float g_hx = g_h * (-b.su[3] / den);
+    const float g_hy = g_h * (b.su[2] / den);
+    const float gsu[6] = {g_nx, g_ny, g_hx, g_hy, g_s, g_hd};
+    for (int i = 0; i < 6; ++i) gst[i] = gsu[i] * p.sstd[i];
+    gdec[0] = g_a * p.a_std;
+    gdec[1] = g_ddh * p.ddh_std;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GRU helpers (one time step, 3 layers, hidden 64; torch.nn.GRU gate order r,z,n)
+// ---------------------------------------------------------------------------------------------
+#define GLD 192
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// x: LDS [RB][xld] (layer input), h: LDS [RB][64] (layer hidden), gi/gh: LDS [RB][GLD] scratch.
+// Writes the new hidden into hn [RB][64]; if gates != null stores (r,z,n,gh_n) at gates[RB][4*64].
+__device__ __forceinline__ void gru_layer_lds(const GRUDev& g, int l, const float* x, int xld, int xin, const float* h,
+                                              float* gi, float* gh, float* hn, float* gates, int tid) {
+    dense_lds<false>(x, xld, xin, g.wih_t[l], GLD, g.bih[l], gi, GLD, GLD, tid, 256);
+    dense_lds<false>(h, 64, 64, g.whh_t[l], GLD, g.bhh[l], gh, GLD, GLD, tid, 256);
+    __syncthreads();
+    for (int i = tid; i < RB * 64; i += 256) {
+        const int rr = i >> 6, c = i & 63;
+        const float r = sigmoidf_(gi[rr * GLD + c] + gh[rr * GLD + c]);
+        const float z = sigmoidf_(gi[rr * GLD + 64 + c] + gh[rr * GLD + 64 + c]);
+        const float ghn = gh[rr * GLD + 128 + c];
+        const float n = tanhf(gi[rr * GLD + 128 + c] + r * ghn);
+        hn[rr * 64 + c] = (1.0f - z) * n + z * h[rr * 64 + c];
+        if (gates) {
+            gates[rr * 256 + c] = r;
+            gates[rr * 256 + 64 + c] = z;
+            gates[rr * 256 + 128 + c] = n;
+            gates[rr * 256 + 192 + c] = ghn;
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward step kernel: node2 + dynamics + GRU.   grid = ceil(R/RB)
+// ---------------------------------------------------------------------------------------------
+struct StepArgs {
+    int t, FT, R, NS;
+    const float* X;            // (R, 64) from node1
+    const float* sem;          // (NA, NC)
+    const float* lw;           // (NA, 2) normalised
+    const float* ext;          // (B, FT, 4) or null
+    const int32_t* ptr;        // scene offsets (ego = first agent of a scene)
+    const int32_t* scene_of;
+    float* traj;               // (R, FT, 4)
+};
+
+static __global__ __launch_bounds__(256) void rollout_node2_kernel(GNNDev g, GRUDev gru, DynParams dp, StepArgs a, Tape tp) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const int in_ld = ld4(2 * g.D + g.NC);
+    Node2Lds L(smem, in_ld);
+    float* s_x = L.out + RB * HLD;        // [RB][4]  GRU input (local pose)
+    float* s_h = s_x + RB * 4;            // [RB][64]    hidden input of the current layer
+    float* s_hn = s_h + RB * 64;          // [2][RB][64] layer outputs, ping-pong (layer l+1 reads layer l's as input)
+    float* s_gi = s_hn + 2 * RB * 64;     // [RB][GLD]
+    float* s_gh = s_gi + RB * GLD;        // [RB][GLD]
+    const int tid = threadIdx.x, r0 = blockIdx.x * RB, t = a.t;
+    node2_forward(g, a.NS, a.X, tp.A_t(t), a.sem, r0, a.R, L, in_ld, tid);
+    const bool more = t < a.FT - 1;
+    if (tid < RB) {
+        const int r = r0 + tid;
+        float loc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < a.R) {
+            const int ag = r / a.NS;
+            const float* st = tp.state_t(t) + (size_t)r * 8;
+            BikeFwd b;
+            bike_forward(dp, st, L.out[tid * HLD + 0], L.out[tid * HLD + 1], a.lw[ag * 2], b);
+            float* tr = a.traj + ((size_t)r * a.FT + t) * 4;
+            for (int i = 0; i < 4; ++i) tr[i] = b.out[i];
+            float gin[4] = {b.out[0], b.out[1], b.out[2], b.out[3]};
+            if (a.ext) {
+                const int sc = a.scene_of[ag];
+                if (a.ptr[sc] == ag) {
+                    const float* e = a.ext + ((size_t)sc * a.FT + t) * 4;
+                    for (int i = 0; i < 4; ++i) gin[i] = e[i];
+                }
+            }
+            rel_pose(st, gin, loc);
+            float* lo = tp.loc_t(t) + (size_t)r * 4;
+            for (int i = 0; i < 4; ++i) lo[i] = loc[i];
+            if (more) {
+                float* ns = tp.state_t(t + 1) + (size_t)r * 8;
+                for (int i = 0; i < 6; ++i) ns[i] = b.out[i];
+                float* np = tp.pos_t(t + 1) + (size_t)r * 4;
+                for (int i = 0; i < 4; ++i) np[i] = gin[i];
+            }
+        }
+        for (int i = 0; i < 4; ++i) s_x[tid * 4 + i] = loc[i];
+    }
+    if (!more) return;
+    // ---- GRU memory step (reference traffic_model.py:684-688) ----
+    const float* x = s_x;
+    int xld = 4, xin = 4;
+    for (int l = 0; l < 3; ++l) {
+        __syncthreads();
+        for (int i = tid; i < RB * 64; i += 256) {
+            const int rr = i >> 6, c = i & 63;
+            const int r = r0 + rr;
+            s_h[i] = (r < a.R) ? tp.mem_t(t)[((size_t)r * 3 + l) * 64 + c] : 0.f;
+        }
+        __syncthreads();
+        float* hn = s_hn + (size_t)(l & 1) * RB * 64;
+        gru_layer_lds(gru, l, x, xld, xin, s_h, s_gi, s_gh, hn, nullptr, tid);
+        for (int i = tid; i < RB * 64; i += 256) {
+            const int rr = i >> 6, c = i & 63;
+            const int r = r0 + rr;
+            if (r < a.R) {
+                tp.mem_t(t + 1)[((size_t)r * 3 + l) * 64 + c] = hn[i];
+                if (l == 2) tp.pf_t(t + 1)[(size_t)r * 64 + c] = hn[i];
+            }
+        }
+        x = hn;
+        xld = 64;
+        xin = 64;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small helper kernels
+// ---------------------------------------------------------------------------------------------
+static __global__ void rollout_init_kernel(Tape tp, const float* __restrict__ past_last, const float* __restrict__ past_feat,
+                                           const float* __restrict__ map_feat, const int32_t* __restrict__ mapix,
+                                           int32_t* __restrict__ mapix_rows, int R, int NS) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * 64) return;
+    const int r = i >> 6, c = i & 63, ag = r / NS;
+    const float pf = past_feat[(size_t)ag * 64 + c];
+    tp.pf_t(0)[i] = pf;
+    tp.mf_t(0)[i] = map_feat[(size_t)ag * 64 + c];
+    for (int l = 0; l < 3; ++l) tp.mem_t(0)[((size_t)r * 3 + l) * 64 + c] = pf;
+    if (c < 6) tp.state_t(0)[(size_t)r * 8 + c] = past_last[(size_t)ag * 6 + c];
+    if (c < 4) tp.pos_t(0)[(size_t)r * 4 + c] = past_last[(size_t)ag * 6 + c];
+    if (c == 0) mapix_rows[r] = mapix[ag];
+}
+
+// =============================================================================================
+// host orchestration: forward
+// =============================================================================================
+namespace {
+
+struct FwdWs {
+    GnnBuffers gb;       // X, P, Q (A/ARG live in the tape)
+    int32_t* mapix_rows;
+    void* cnn_ws;
+    size_t cnn_bytes;
+};
+
+size_t fwd_ws_bytes(size_t R) {
+    size_t b = 0;
+    b += strive_align_up(R * 64 * 4, 256);
+    b += 2 * strive_align_up(R * STRIVE_HID * 4, 256);
+    b += strive_align_up(R * 4, 256);
+    b += strive_align_up(strive_map_cnn_workspace_bytes((int32_t)R), 256);
+    return b;
+}
+
+DynParams dyn_params(const StriveDecoder& d) {
+    DynParams p;
+    for (int i = 0; i < 6; ++i) { p.smean[i] = d.state_mean[i]; p.sstd[i] = d.state_std[i]; }
+    p.amean0 = d.att_mean[0];
+    p.astd0 = d.att_std[0];
+    p.a_mean = d.a_mean; p.a_std = d.a_std; p.ddh_mean = d.ddh_mean; p.ddh_std = d.ddh_std;
+    p.dt = d.dt; p.max_hdot = d.max_hdot; p.max_s = d.max_s;
+    return p;
+}
+
+GRUDev gru_dev(const StriveGRU& g) {
+    GRUDev d;
+    for (int l = 0; l < 3; ++l) {
+        d.wih[l] = g.wih[l]; d.whh[l] = g.whh[l]; d.wih_t[l] = g.wih_t[l]; d.whh_t[l] = g.whh_t[l];
+        d.bih[l] = g.bih[l]; d.bhh[l] = g.bhh[l];
+    }
+    return d;
+}
+
+FeatSrc decoder_features(const Tape& tp, int t, const float* sem, const float* z, const float* lw, int NC) {
+    FeatSrc f;
+    f.n = 5;
+    f.p[0] = tp.pf_t(t); f.w[0] = 64; f.per_agent[0] = 0;
+    f.p[1] = tp.mf_t(t); f.w[1] = 64; f.per_agent[1] = 0;
+    f.p[2] = sem;        f.w[2] = NC; f.per_agent[2] = 1;
+    f.p[3] = z;          f.w[3] = STRIVE_ZDIM; f.per_agent[3] = 0;
+    f.p[4] = lw;         f.w[4] = 2;  f.per_agent[4] = 1;
+    return f;
+}
+
+size_t node2r_lds_bytes(int in_ld) { return (Node2Lds::floats(in_ld) + RB * 4 + 3 * RB * 64 + 2 * RB * GLD) * 4; }
+
+int check_decoder(const StriveDecoder* dec, const StriveScenes* sc, int FT) {
+    if (gnn_check(dec->gnn)) return -1;
+    if (dec->gnn.D != 64 || dec->gnn.mlp_out.dims[3] != 2) { strive_set_error("rollout: decoder_net must have D=64 and 2 outputs"); return -1; }
+    if (dec->gnn.mlp_in.dims[0] != 64 + 64 + dec->gnn.NC + STRIVE_ZDIM + 2) { strive_set_error("rollout: decoder_net input width mismatch"); return -1; }
+    if (FT < 1 || sc->NA < 0 || sc->NS < 1) { strive_set_error("rollout: bad sizes"); return -1; }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t strive_rollout_tape_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT) {
+    if (!sc) return 0;
+    return tape_bytes_for((size_t)sc->NA * sc->NS, FT);
+}
+
+extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* sc, const float* past_last,
+                                  const float* lw, const float* sem, const float* past_feat, const float* map_feat,
+                                  const float* z, const int32_t* mapix, const float* ext_future, int32_t FT, float* traj,
+                                  void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, strive_stream_t stream_) {
+    STRIVE_CHECK_ARG(dec && sc && past_last && lw && sem && past_feat && map_feat && z && mapix && traj && tape && ws,
+                     "null argument");
+    if (check_decoder(dec, sc, FT)) return -1;
+    STRIVE_CHECK_ARG(!(ext_future && sc->NS != 1), "ext_future with multiple samples is not supported");
+    const size_t R = (size_t)sc->NA * sc->NS;
+    if (R == 0) return 0;
+    STRIVE_CHECK_ARG(tape_bytes >= tape_bytes_for(R, FT), "tape too small");
+    STRIVE_CHECK_ARG(ws_bytes >= strive_rollout_workspace_bytes(dec, sc, FT), "workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    Tape tp = carve_tape(tape, tape_bytes, R, FT);
+    StriveArena ar(ws, ws_bytes);
+    FwdWs w;
+    w.gb.X = ar.take<float>(R * 64);
+    w.gb.P = ar.take<float>(R * STRIVE_HID);
+    w.gb.Q = ar.take<float>(R * STRIVE_HID);
+    w.mapix_rows = ar.take<int32_t>(R);
+    w.cnn_bytes = strive_map_cnn_workspace_bytes((int32_t)R);
+    w.cnn_ws = ar.take<char>(w.cnn_bytes);
+    STRIVE_CHECK_ARG(ar.ok(), "workspace arena overflow");
+
+    const GNNDev gd = gnn_dev(dec->gnn);
+    const GRUDev gr = gru_dev(dec->gru);
+    const DynParams dp = dyn_params(*dec);
+    const ScenesDev sd = scenes_dev(*sc);
+    const int NC = dec->gnn.NC;
+    const int in_ld1 = ld4(dec->gnn.mlp_in.dims[0]), xs_ld = ld4(64 + NC), in_ld2 = ld4(128 + NC);
+    const int nb = (int)((R + RB - 1) / RB);
+
+    hipLaunchKernelGGL(rollout_init_kernel, dim3((unsigned)((R * 64 + 255) / 256)), dim3(256), 0, stream, tp, past_last,
+                       past_feat, map_feat, mapix, w.mapix_rows, (int)R, sc->NS);
+    for (int t = 0; t < FT; ++t) {
+        GnnBuffers gb = w.gb;
+        gb.A = tp.A_t(t);
+        gb.ARG = tp.ARG_t(t);
+        FeatSrc f = decoder_features(tp, t, sem, z, lw, NC);
+        hipLaunchKernelGGL(gnn_node1_kernel, dim3(nb), dim3(256), Node1Lds::bytes(in_ld1, xs_ld), stream, gd, sc->NS, f, sem,
+                           gb, (int)R);
+        hipLaunchKernelGGL(gnn_edge_kernel, dim3((unsigned)R), dim3(256), EdgeLds::bytes(), stream, gd, sd, tp.pos_t(t), gb);
+        StepArgs a;
+        a.t = t; a.FT = FT; a.R = (int)R; a.NS = sc->NS; a.X = gb.X; a.sem = sem; a.lw = lw; a.ext = ext_future;
+        a.ptr = sc->ptr; a.scene_of = sc->scene_of; a.traj = traj;
+        hipLaunchKernelGGL(rollout_node2_kernel, dim3(nb), dim3(256), node2r_lds_bytes(in_ld2), stream, gd, gr, dp, a, tp);
+        if (t < FT - 1) {
+            int rc = strive_map_cnn_fwd(&dec->map, &dec->cnn, tp.pos_t(t + 1), dec->state_mean, dec->state_std,
+                                        w.mapix_rows, (int32_t)R, tp.mf_t(t + 1), w.cnn_ws, w.cnn_bytes, stream_);
+            if (rc) return rc;
+        }
+    }
+    STRIVE_CHECK_LAUNCH();
+    return 0;
+}
+
+// =============================================================================================
+// backward kernels
+// =============================================================================================
+
+// ---- GRU backward for rows r0.. : consumes g_mem (adjoint of mem_{t+1}) and g_pf (adjoint of past_feat_{t+1}),
+//      produces g_mem (adjoint of mem_t) and d_loc (adjoint of the local pose fed to the GRU).  grid = ceil(R/RB)
+static __global__ __launch_bounds__(256) void gru_bwd_kernel(GRUDev gru, Tape tp, int t, int R, const float* __restrict__ g_pf,
+                                                               float* __restrict__ g_mem, float* __restrict__ d_loc) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* s_x = smem;                      // [RB][4]
+    float* s_h = s_x + RB * 4;              // [3][RB][64]   layer hidden inputs (mem_t)
+    float* s_hn = s_h + 3 * RB * 64;        // [3][RB][64]   layer outputs
+    float* s_gi = s_hn + 3 * RB * 64;       // [RB][GLD]
+    float* s_gh = s_gi + RB * GLD;          // [RB][GLD]
+    float* s_g = s_gh + RB * GLD;           // [3][RB][256]  gates r,z,n,gh_n
+    float* s_dx = s_g + 3 * RB * 256;       // [RB][64]      adjoint flowing to the layer below
+    const int tid = threadIdx.x, r0 = blockIdx.x * RB;
+    for (int i = tid; i < RB * 4; i += 256) {
+        const int r = r0 + (i >> 2);
+        s_x[i] = (r < R) ? tp.loc_t(t)[(size_t)r * 4 + (i & 3)] : 0.f;
+    }
+    for (int i = tid; i < 3 * RB * 64; i += 256) {
+        const int l = i / (RB * 64), rem = i - l * RB * 64;
+        const int r = r0 + (rem >> 6), c = rem & 63;
+        s_h[i] = (r < R) ? tp.mem_t(t)[((size_t)r * 3 + l) * 64 + c] : 0.f;
+    }
+    __syncthreads();
+    // forward recompute
+    for (int l = 0; l < 3; ++l) {
+        const float* x = (l == 0) ? s_x : s_hn + (size_t)(l - 1) * RB * 64;
+        gru_layer_lds(gru, l, x, l == 0 ? 4 : 64, l == 0 ? 4 : 64, s_h + (size_t)l * RB * 64, s_gi, s_gh,
+                      s_hn + (size_t)l * RB * 64, s_g + (size_t)l * RB * 256, tid);
+    }
+    // backward, top layer first
+    for (int l = 2; l >= 0; --l) {
+        float* gates = s_g + (size_t)l * RB * 256;
+        const float* h = s_h + (size_t)l * RB * 64;
+        // gate pre-activation adjoints into s_gi (d gi) and s_gh (d gh)
+        for (int i = tid; i < RB * 64; i += 256) {
+            const int rr = i >> 6, c = i & 63;
+            const int r = r0 + rr;
+            float dh = 0.f;
+            if (r < R) {
+                dh = g_mem[((size_t)r * 3 + l) * 64 + c];
+                if (l == 2) dh += g_pf[(size_t)r * 64 + c];
+                else dh += s_dx[rr * 64 + c];
+            }
+            const float rg = gates[rr * 256 + c], z = gates[rr * 256 + 64 + c], n = gates[rr * 256 + 128 + c];
+            const float ghn = gates[rr * 256 + 192 + c];
+            const float dn = dh * (1.0f - z);
+            const float dz = dh * (h[rr * 64 + c] - n);
+            const float dpn = dn * (1.0f - n * n);
+            const float dr = dpn * ghn;
+            const float dpz = dz * z * (1.0f - z);
+            const float dpr = dr * rg * (1.0f - rg);
+            s_gi[rr * GLD + c] = dpr;
+            s_gi[rr * GLD + 64 + c] = dpz;
+            s_gi[rr * GLD + 128 + c] = dpn;
+            s_gh[rr * GLD + c] = dpr;
+            s_gh[rr * GLD + 64 + c] = dpz;
+            s_gh[rr * GLD + 128 + c] = dpn * rg;
+            // direct path h' = ... + z*h
+            s_hn[(size_t)l * RB * 64 + i] = dh * z;
+        }
+        __syncthreads();
+        // adjoint of the hidden input: dh*z + dgh * W_hh ; adjoint of the layer input: dgi * W_ih
+        dense_lds<true>(s_gh, GLD, GLD, gru.whh[l], 64, nullptr, s_hn + (size_t)l * RB * 64, 64, 64, tid, 256);
+        const int xin = (l == 0) ? 4 : 64;
+        dense_lds<false>(s_gi, GLD, GLD, gru.wih[l], xin, nullptr, s_dx, 64, xin, tid, 256);
+        __syncthreads();
+        for (int i = tid; i < RB * 64; i += 256) {
+            const int r = r0 + (i >> 6), c = i & 63;
+            if (r < R) g_mem[((size_t)r * 3 + l) * 64 + c] = s_hn[(size_t)l * RB * 64 + i];
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < RB * 4; i += 256) {
+        const int rr = i >> 2, r = r0 + rr;
+        if (r < R) d_loc[(size_t)r * 4 + (i & 3)] = s_dx[rr * 64 + (i & 3)];
+    }
+}
+
+static size_t gru_bwd_lds_bytes() { return (size_t)(RB * 4 + 6 * RB * 64 + 2 * RB * GLD + 3 * RB * 256 + RB * 64) * 4; }
+
+// ---- node2 backward: dynamics + mlp_out + update.  grid = ceil(R/RB)
+struct Node2BwdArgs {
+    int t, FT, R, NS;
+    const float* X;
+    const float* sem;
+    const float* lw;
+    const float* ext;
+    const int32_t* ptr;
+    const int32_t* scene_of;
+    const float* g_traj;     // (R, FT, 4)
+    const float* g_pos;      // (R, 4)  adjoint of pos_{t+1}
+    const float* d_loc;      // (R, 4)
+    float* g_state;          // (R, 8)  in: adjoint of state_{t+1}; out: adjoint of state_t
+    float* dX;               // (R, 64) out: update-MLP part of dL/dx
+    float* dA;               // (R, 64) out: dL/d(aggregated message)
+};
+
+static __global__ __launch_bounds__(256) void node2_bwd_kernel(GNNDev g, DynParams dp, Node2BwdArgs a, Tape tp) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const int in_ld = ld4(2 * g.D + g.NC);
+    Node2Lds L(smem, in_ld);
+    float* s_go = L.out + RB * HLD;      // [RB][4]  gradient w.r.t. decoder output (2 used)
+    float* s_ga = s_go + RB * 4;         // [RB][HLD]
+    float* s_gb = s_ga + RB * HLD;       // [RB][HLD]
+    float* s_gx = s_gb + RB * HLD;       // [RB][HLD] gradient w.r.t. x'
+    float* s_gin = s_gx + RB * HLD;      // [RB][in_ld]
+    const int tid = threadIdx.x, r0 = blockIdx.x * RB, t = a.t;
+    node2_forward(g, a.NS, a.X, tp.A_t(t), a.sem, r0, a.R, L, in_ld, tid);
+    const bool more = t < a.FT - 1;
+    if (tid < RB) {
+        const int r = r0 + tid;
+        float gdec[2] = {0.f, 0.f};
+        if (r < a.R) {
+            const int ag = r / a.NS;
+            const float* st = tp.state_t(t) + (size_t)r * 8;
+            BikeFwd b;
+            bike_forward(dp, st, L.out[tid * HLD + 0], L.out[tid * HLD + 1], a.lw[ag * 2], b);
+            bool forced = false;
+            float gin[4] = {b.out[0], b.out[1], b.out[2], b.out[3]};
+            if (a.ext) {
+                const int sc = a.scene_of[ag];
+                if (a.ptr[sc] == ag) {
+                    forced = true;
+                    const float* e = a.ext + ((size_t)sc * a.FT + t) * 4;
+                    for (int i = 0; i < 4; ++i) gin[i] = e[i];
+                }
+            }
+            float gbike[6];
+            const float* gt = a.g_traj + ((size_t)r * a.FT + t) * 4;
+            for (int i = 0; i < 4; ++i) gbike[i] = gt[i];
+            gbike[4] = gbike[5] = 0.f;
+            float gfr[4] = {0.f, 0.f, 0.f, 0.f};
+            if (more) {
+                float gpo[4] = {0.f, 0.f, 0.f, 0.f};
+                rel_pose_bwd(st, gin, a.d_loc + (size_t)r * 4, gfr, gpo);
+                const float* gs = a.g_state + (size_t)r * 8;
+                for (int i = 0; i < 6; ++i) gbike[i] += gs[i];
+                if (!forced)
+                    for (int i = 0; i < 4; ++i) gbike[i] += gpo[i] + a.g_pos[(size_t)r * 4 + i];
+            }
+            float gst[6];
+            bike_backward(dp, b, gbike, gst, gdec);
+            float* go = a.g_state + (size_t)r * 8;
+            for (int i = 0; i < 6; ++i) go[i] = gst[i] + (i < 4 ? gfr[i] : 0.f);
+        }
+        s_go[tid * 4 + 0] = gdec[0];
+        s_go[tid * 4 + 1] = gdec[1];
+        s_go[tid * 4 + 2] = 0.f;
+        s_go[tid * 4 + 3] = 0.f;
+    }
+    __syncthreads();
+    mlp_backward_lds(g.mlp_out, L.pre_o, s_go, 4, s_ga, s_gb, s_gx, HLD, false, tid, 256);
+    mlp_backward_lds(g.update, L.pre_u, s_gx, HLD, s_ga, s_gb, s_gin, in_ld, false, tid, 256);
+    const int D = g.D;
+    for (int i = tid; i < RB * D; i += 256) {
+        const int rr = i / D, c = i - rr * D;
+        if (r0 + rr < a.R) {
+            a.dX[(size_t)(r0 + rr) * D + c] = s_gin[rr * in_ld + c];
+            a.dA[(size_t)(r0 + rr) * D + c] = s_gin[rr * in_ld + D + c];
+        }
+    }
+}
+
+static size_t node2_bwd_lds_bytes(int in_ld) { return (Node2Lds::floats(in_ld) + RB * 4 + 3 * RB * HLD + RB * in_ld) * 4; }
+
+// ---- edge backward: one workgroup per target row.  grid = R
+struct EdgeBwdArgs {
+    const float* dA;       // (R, D)
+    const int32_t* ARG;    // (R, D)
+    float* dP;             // (R, 128)
+    float* DE1;            // (R*max_n, 128)  per-edge layer-0 adjoint, slot = target_row*max_n + local source index
+    float* DPJ;            // (R*max_n, 4)    per-edge adjoint of the SOURCE pose
+    float* gpos_tgt;       // (R, 4)          adjoint of the TARGET pose (frame), summed over its edges
+};
+
+static __global__ __launch_bounds__(256) void edge_bwd_kernel(GNNDev g, ScenesDev sc, const float* __restrict__ pos, GnnBuffers gb,
+                                                                EdgeBwdArgs a) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    EdgeLds L(smem);
+    float* s_ga = (float*)(L.src + RB);       // [RB][HLD]
+    float* s_gb = s_ga + RB * HLD;            // [RB][HLD]
+    float* s_grel = s_gb + RB * HLD;          // [RB][4]
+    float* s_gfr = s_grel + RB * 4;           // [RB][4]
+    unsigned* s_nan = (unsigned*)(s_gfr + RB * 4);   // [RB]
+    const int r = blockIdx.x, tid = threadIdx.x, D = g.D, H = STRIVE_HID;
+    const int ag = r / sc.NS;
+    const int b = sc.scene_of[ag];
+    const int lo = sc.ptr[b];
+    const int nsrc = sc.ptr[b + 1] - lo - 1;
+    const int nchunks = (nsrc + RB - 1) / RB;
+    const float* Wrel = g.edge.wt[0] + (size_t)(2 * D + 2 * g.NC) * H;
+    float dp_acc = 0.f;                  // thread c < 128: sum over sources of d e1[.][c]
+    float gfr_acc[4] = {0.f, 0.f, 0.f, 0.f};   // thread 0
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int nv = edge_chunk_setup(g, sc, pos, gb, r, ch, L, s_nan, tid);
+        mlp_forward_lds(g.edge, nullptr, 0, L.pre, L.act, L.m, HLD, true, tid, 256);
+        // route d(aggregate) to the arg-max edge of every channel
+        for (int i = tid; i < RB * D; i += 256) {
+            const int jr = i / D, c = i - jr * D;
+            float v = 0.f;
+            if (jr < nv && a.ARG[(size_t)r * D + c] == L.src[jr]) v = a.dA[(size_t)r * D + c];
+            L.m[jr * HLD + c] = v;
+        }
+        __syncthreads();
+        mlp_backward_lds(g.edge, L.pre, L.m, HLD, s_ga, s_gb, nullptr, 0, true, tid, 256);   // d e1 -> s_ga
+        // per-edge outputs
+        for (int i = tid; i < RB * H; i += 256) {
+            const int jr = i / H, c = i - jr * H;
+            if (jr < nv) {
+                const int jl = L.src[jr] / sc.NS - lo;
+                a.DE1[((size_t)r * sc.max_n + jl) * H + c] = s_ga[jr * HLD + c];
+            }
+        }
+        if (tid < H) {
+            for (int jr = 0; jr < nv; ++jr) dp_acc += s_ga[jr * HLD + tid];
+        }
+        // d rel = d e1 . W_rel^T : one wave per edge row, lanes over channels
+        {
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int jr = wave; jr < RB; jr += 4) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int c = lane; c < H; c += 64) {
+                    const float ge = s_ga[jr * HLD + c];
+                    for (int d = 0; d < 4; ++d) v[d] = fmaf(ge, Wrel[d * H + c], v[d]);
+                }
+                for (int d = 0; d < 4; ++d) v[d] = wave_sum(v[d]);
+                if (lane == 0)
+                    for (int d = 0; d < 4; ++d) s_grel[jr * 4 + d] = v[d];
+            }
+        }
+        __syncthreads();
+        if (tid < RB) {
+            float gfr[4] = {0.f, 0.f, 0.f, 0.f}, gpo[4] = {0.f, 0.f, 0.f, 0.f};
+            if (tid < nv) {
+                const int srow = L.src[tid];
+                float gr[4];
+                for (int d = 0; d < 4; ++d) gr[d] = (s_nan[tid] >> d) & 1u ? 0.f : s_grel[tid * 4 + d];
+                rel_pose_bwd(pos + (size_t)r * 4, pos + (size_t)srow * 4, gr, gfr, gpo);
+                const int jl = srow / sc.NS - lo;
+                float* o = a.DPJ + ((size_t)r * sc.max_n + jl) * 4;
+                for (int d = 0; d < 4; ++d) o[d] = gpo[d];
+            }
+            for (int d = 0; d < 4; ++d) s_gfr[tid * 4 + d] = gfr[d];
+        }
+        __syncthreads();
+        if (tid == 0)
+            for (int jr = 0; jr < nv; ++jr)
+                for (int d = 0; d < 4; ++d) gfr_acc[d] += s_gfr[jr * 4 + d];
+        __syncthreads();
+    }
+    if (tid < H) a.dP[(size_t)r * H + tid] = dp_acc;
+    if (tid == 0)
+        for (int d = 0; d < 4; ++d) a.gpos_tgt[(size_t)r * 4 + d] = gfr_acc[d];
+}
+
+static size_t edge_bwd_lds_bytes() { return EdgeLds::bytes() + (size_t)(2 * RB * HLD + 2 * RB * 4 + RB) * 4; }
+
+// ---- node1 backward: gather source-side adjoints, back through edge layer 0 partials and mlp_in.  grid = ceil(R/RB)
+struct Node1BwdArgs {
+    int t, R;
+    const float* dX;        // (R, 64)
+    const float* dP;        // (R, 128)
+    const float* DE1;
+    const float* DPJ;
+    const float* gpos_tgt;
+    float* g_pf;            // (R, 64) out: adjoint of past_feat_t
+    float* g_pos;           // (R, 4)  out: adjoint of pos_t
+    float* dz;              // (R, 32) accumulated
+};
+
+static __global__ __launch_bounds__(256) void node1_bwd_kernel(GNNDev g, ScenesDev sc, FeatSrc f, Node1BwdArgs a) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const int F = g.mlp_in.dims[0], D = g.D, H = STRIVE_HID;
+    const int in_ld = ld4(F), xs_ld = ld4(D + g.NC);
+    Node1Lds L(smem, in_ld, xs_ld);
+    float* s_dp = L.po + RB * HLD;       // [RB][HLD]  dP rows
+    float* s_dq = s_dp + RB * HLD;       // [RB][HLD]  dQ rows
+    float* s_gx = s_dq + RB * HLD;       // [RB][HLD]  adjoint of x (D wide)
+    float* s_gb = s_gx + RB * HLD;       // [RB][HLD]
+    float* s_gin = s_gb + RB * HLD;      // [RB][in_ld]
+    const int tid = threadIdx.x, r0 = blockIdx.x * RB, NS = sc.NS;
+    // forward recompute of mlp_in (pre-activations)
+    gather_features(f, r0, a.R, NS, L.in, in_ld, tid, 256);
+    __syncthreads();
+    mlp_forward_lds(g.mlp_in, L.in, in_ld, L.pre, L.act, L.xs, xs_ld, false, tid, 256);
+    // gather dP, dQ = sum over targets of the per-edge adjoints, and the source-pose adjoint
+    for (int i = tid; i < RB * H; i += 256) {
+        const int rr = i / H, c = i - rr * H;
+        const int r = r0 + rr;
+        float vp = 0.f, vq = 0.f;
+        if (r < a.R) {
+            vp = a.dP[(size_t)r * H + c];
+            const int ag = r / NS, s = r - ag * NS;
+            const int b = sc.scene_of[ag];
+            const int lo = sc.ptr[b], hi = sc.ptr[b + 1];
+            const int jl = ag - lo;
+            for (int ia = lo; ia < hi; ++ia) {
+                if (ia == ag) continue;
+                vq += a.DE1[((size_t)(ia * NS + s) * sc.max_n + jl) * H + c];
+            }
+        }
+        s_dp[rr * HLD + c] = vp;
+        s_dq[rr * HLD + c] = vq;
+    }
+    if (tid < RB * 4) {
+        const int rr = tid >> 2, d = tid & 3;
+        const int r = r0 + rr;
+        if (r < a.R) {
+            float v = a.gpos_tgt[(size_t)r * 4 + d];
+            const int ag = r / NS, s = r - ag * NS;
+            const int b = sc.scene_of[ag];
+            const int lo = sc.ptr[b], hi = sc.ptr[b + 1];
+            const int jl = ag - lo;
+            for (int ia = lo; ia < hi; ++ia) {
+                if (ia == ag) continue;
+                v += a.DPJ[((size_t)(ia * NS + s) * sc.max_n + jl) * 4 + d];
+            }
+            a.g_pos[(size_t)r * 4 + d] = v;
+        }
+    }
+    __syncthreads();
+    // adjoint of x: dP . W_e0[:, 0:D] + dQ . W_e0[:, D:2D] + update-MLP part
+    const int EIN = g.edge.dims[0];
+    dense_lds<false>(s_dp, HLD, H, g.edge.w[0], EIN, nullptr, s_gx, HLD, D, tid, 256);
+    __syncthreads();
+    dense_lds<true>(s_dq, HLD, H, g.edge.w[0] + D, EIN, nullptr, s_gx, HLD, D, tid, 256);
+    __syncthreads();
+    for (int i = tid; i < RB * D; i += 256) {
+        const int rr = i / D, c = i - rr * D;
+        if (r0 + rr < a.R) s_gx[rr * HLD + c] += a.dX[(size_t)(r0 + rr) * D + c];
+    }
+    __syncthreads();
+    mlp_backward_lds(g.mlp_in, L.pre, s_gx, HLD, s_dp, s_gb, s_gin, in_ld, false, tid, 256);
+    // scatter: past_feat columns [0,64), z columns [128+NC, 128+NC+32)
+    for (int i = tid; i < RB * 64; i += 256) {
+        const int rr = i >> 6, c = i & 63;
+        if (r0 + rr < a.R) a.g_pf[(size_t)(r0 + rr) * 64 + c] = s_gin[rr * in_ld + c];
+    }
+    const int zoff = 128 + g.NC;
+    for (int i = tid; i < RB * STRIVE_ZDIM; i += 256) {
+        const int rr = i / STRIVE_ZDIM, c = i - rr * STRIVE_ZDIM;
+        if (r0 + rr < a.R) a.dz[(size_t)(r0 + rr) * STRIVE_ZDIM + c] += s_gin[rr * in_ld + zoff + c];
+    }
+}
+
+static size_t node1_bwd_lds_bytes(int in_ld, int xs_ld) { return Node1Lds::bytes(in_ld, xs_ld) + (size_t)(4 * RB * HLD + RB * in_ld) * 4; }
+
+// =============================================================================================
+// host orchestration: backward
+// =============================================================================================
+namespace {
+size_t bwd_ws_bytes(size_t R, int max_n) {
+    size_t b = 0;
+    b += strive_align_up(R * 64 * 4, 256);                 // X
+    b += 2 * strive_align_up(R * STRIVE_HID * 4, 256);     // P, Q
+    b += strive_align_up(R * 8 * 4, 256);                  // g_state
+    b += 2 * strive_align_up(R * 4 * 4, 256);              // g_pos, d_loc
+    b += strive_align_up(R * 64 * 4, 256);                 // g_pf
+    b += strive_align_up(R * 192 * 4, 256);                // g_mem
+    b += 2 * strive_align_up(R * 64 * 4, 256);             // dX, dA
+    b += strive_align_up(R * STRIVE_HID * 4, 256);         // dP
+    b += strive_align_up(R * 4 * 4, 256);                  // gpos_tgt
+    b += strive_align_up(R * (size_t)max_n * STRIVE_HID * 4, 256);   // DE1
+    b += strive_align_up(R * (size_t)max_n * 4 * 4, 256);            // DPJ
+    return b;
+}
+}  // namespace
+
+extern "C" size_t strive_rollout_workspace_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT) {
+    if (!sc) return 0;
+    const size_t R = (size_t)sc->NA * sc->NS;
+    const size_t f = fwd_ws_bytes(R), b = bwd_ws_bytes(R, sc->max_n > 0 ? sc->max_n : 1);
+    return (f > b ? f : b) + 4096;
+}
+
+extern "C" int strive_rollout_bwd(const StriveDecoder* dec, const StriveScenes* sc, const float* lw, const float* sem,
+                                  const float* z, const float* ext_future, int32_t FT, const float* d_traj, float* dz,
+                                  const void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, strive_stream_t stream_) {
+    STRIVE_CHECK_ARG(dec && sc && lw && sem && z && d_traj && dz && tape && ws, "null argument");
+    if (check_decoder(dec, sc, FT)) return -1;
+    const size_t R = (size_t)sc->NA * sc->NS;
+    if (R == 0) return 0;
+    STRIVE_CHECK_ARG(tape_bytes >= tape_bytes_for(R, FT), "tape too small");
+    STRIVE_CHECK_ARG(ws_bytes >= strive_rollout_workspace_bytes(dec, sc, FT), "workspace too small");
+    STRIVE_CHECK_ARG(sc->max_n >= 1, "max_n not set");
+    hipStream_t stream = (hipStream_t)stream_;
+    Tape tp = carve_tape(const_cast<void*>(tape), tape_bytes, R, FT);
+    StriveArena ar(ws, ws_bytes);
+    GnnBuffers gb;
+    gb.X = ar.take<float>(R * 64);
+    gb.P = ar.take<float>(R * STRIVE_HID);
+    gb.Q = ar.take<float>(R * STRIVE_HID);
+    float* g_state = ar.take<float>(R * 8);
+    float* g_pos = ar.take<float>(R * 4);
+    float* d_loc = ar.take<float>(R * 4);
+    float* g_pf = ar.take<float>(R * 64);
+    float* g_mem = ar.take<float>(R * 192);
+    float* dX = ar.take<float>(R * 64);
+    float* dA = ar.take<float>(R * 64);
+    float* dP = ar.take<float>(R * STRIVE_HID);
+    float* gpos_tgt = ar.take<float>(R * 4);
+    float* DE1 = ar.take<float>(R * (size_t)sc->max_n * STRIVE_HID);
+    float* DPJ = ar.take<float>(R * (size_t)sc->max_n * 4);
+    STRIVE_CHECK_ARG(ar.ok(), "workspace arena overflow");
+
+    const GNNDev gd = gnn_dev(dec->gnn);
+    const GRUDev gr = gru_dev(dec->gru);
+    const DynParams dp = dyn_params(*dec);
+    const ScenesDev sd = scenes_dev(*sc);
+    const int NC = dec->gnn.NC;
+    const int in_ld1 = ld4(dec->gnn.mlp_in.dims[0]), xs_ld = ld4(64 + NC), in_ld2 = ld4(128 + NC);
+    const int nb = (int)((R + RB - 1) / RB);
+
+    hipMemsetAsync(g_state, 0, R * 8 * 4, stream);
+    hipMemsetAsync(g_pos, 0, R * 4 * 4, stream);
+    hipMemsetAsync(d_loc, 0, R * 4 * 4, stream);
+    hipMemsetAsync(g_pf, 0, R * 64 * 4, stream);
+    hipMemsetAsync(g_mem, 0, R * 192 * 4, stream);
+    hipMemsetAsync(dz, 0, R * STRIVE_ZDIM * 4, stream);
+
+    for (int t = FT - 1; t >= 0; --t) {
+        GnnBuffers g2 = gb;
+        g2.A = tp.A_t(t);
+        g2.ARG = tp.ARG_t(t);
+        FeatSrc f = decoder_features(tp, t, sem, z, lw, NC);
+        // recompute x, P, Q of step t
+        hipLaunchKernelGGL(gnn_node1_kernel, dim3(nb), dim3(256), Node1Lds::bytes(in_ld1, xs_ld), stream, gd, sc->NS, f, sem,
+                           g2, (int)R);
+        if (t < FT - 1)
+            hipLaunchKernelGGL(gru_bwd_kernel, dim3(nb), dim3(256), gru_bwd_lds_bytes(), stream, gr, tp, t, (int)R, g_pf, g_mem,
+                               d_loc);
+        Node2BwdArgs a2;
+        a2.t = t; a2.FT = FT; a2.R = (int)R; a2.NS = sc->NS; a2.X = g2.X; a2.sem = sem; a2.lw = lw; a2.ext = ext_future;
+        a2.ptr = sc->ptr; a2.scene_of = sc->scene_of; a2.g_traj = d_traj; a2.g_pos = g_pos; a2.d_loc = d_loc;
+        a2.g_state = g_state; a2.dX = dX; a2.dA = dA;
+        hipLaunchKernelGGL(node2_bwd_kernel, dim3(nb), dim3(256), node2_bwd_lds_bytes(in_ld2), stream, gd, dp, a2, tp);
+        EdgeBwdArgs ae;
+        ae.dA = dA; ae.ARG = tp.ARG_t(t); ae.dP = dP; ae.DE1 = DE1; ae.DPJ = DPJ; ae.gpos_tgt = gpos_tgt;
+        hipLaunchKernelGGL(edge_bwd_kernel, dim3((unsigned)R), dim3(256), edge_bwd_lds_bytes(), stream, gd, sd, tp.pos_t(t), g2, ae);
+        Node1BwdArgs a1;
+        a1.t = t; a1.R = (int)R; a1.dX = dX; a1.dP = dP; a1.DE1 = DE1; a1.DPJ = DPJ; a1.gpos_tgt = gpos_tgt;
+        a1.g_pf = g_pf; a1.g_pos = g_pos; a1.dz = dz;
+        hipLaunchKernelGGL(node1_bwd_kernel, dim3(nb), dim3(256), node1_bwd_lds_bytes(in_ld1, xs_ld), stream, gd, sd, f, a1);
+    }
+    STRIVE_CHECK_LAUNCH();
+    return 0;
+}

@@ -183,6 +183,7 @@ def pack_scenes(ptr, NS, device):
     p.struct.NA = int(ptr[-1])
     p.struct.NS = int(NS)
     p.struct.B = int(B)
+    p.struct.max_n = int(sizes.max()) if B > 0 else 0
     p.struct.ptr = p.hold(ptr32)
     p.struct.scene_of = p.hold(scene_of)
     p.sizes = sizes

@@ -33,6 +33,9 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct uint3_emu { unsigned x, y, z; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) float2 { float x, y; };
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
 typedef void* hipStream_t;
 typedef int hipError_t;

@@ -1,13 +1,42 @@
 // TEST INFRASTRUCTURE ONLY -- fiber scheduler behind tests/hipemu/hip/hip_runtime.h.
+// Fibers are switched with a minimal x86-64 stack switch (callee-saved registers only): glibc's
+// swapcontext issues two sigprocmask system calls per switch, which made MFMA-heavy kernels
+// (two wave rendezvous per emulated instruction) impractically slow to model.
 #include <hip/hip_runtime.h>
 
 uint3_emu threadIdx, blockIdx;
 dim3 blockDim, gridDim;
 
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipemu_switch,.-hipemu_switch
+)");
+
 namespace hipemu {
 
 Globals g;
 static unsigned long long g_progress = 0;
+static void* g_main_sp = nullptr;
+static std::vector<void*> g_sp;
 
 static void set_tid(int i) {
     g.cur = i;
@@ -16,7 +45,7 @@ static void set_tid(int i) {
 
 void yield_() {
     int me = g.cur;
-    swapcontext(&g.fibers[me].ctx, &g.main_ctx);
+    hipemu_switch(&g_sp[me], g_main_sp);
     set_tid(me);
 }
 
@@ -55,7 +84,17 @@ static void trampoline() {
         g.barrier_arrived = 0;
         g.barrier_gen++;
     }
-    swapcontext(&g.fibers[g.cur].ctx, &g.main_ctx);
+    hipemu_switch(&g_sp[g.cur], g_main_sp);
+    abort();   // a finished fiber is never resumed
+}
+
+static void* make_stack(char* stack) {
+    uintptr_t top = ((uintptr_t)stack + STACK_BYTES) & ~(uintptr_t)15;
+    void** sp = (void**)top;
+    *--sp = nullptr;                 // fake return address of trampoline
+    *--sp = (void*)trampoline;       // 'ret' target of the first switch
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;   // rbp rbx r12 r13 r14 r15
+    return (void*)sp;
 }
 
 void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t shmem) {
@@ -64,6 +103,7 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t shm
     if ((int)g.fibers.size() < nthreads) {
         size_t old = g.fibers.size();
         g.fibers.resize(nthreads);
+        g_sp.resize(nthreads);
         for (size_t i = old; i < g.fibers.size(); ++i) g.fibers[i].stack = (char*)malloc(STACK_BYTES);
     }
     if (shmem + 64 > g.dyn_cap) {
@@ -94,13 +134,8 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t shm
                     g.waves[w].nlanes = (w == nwaves - 1) ? nthreads - 64 * w : 64;
                 }
                 for (int t = 0; t < nthreads; ++t) {
-                    Fiber& f = g.fibers[t];
-                    f.done = false;
-                    getcontext(&f.ctx);
-                    f.ctx.uc_stack.ss_sp = f.stack;
-                    f.ctx.uc_stack.ss_size = STACK_BYTES;
-                    f.ctx.uc_link = &g.main_ctx;
-                    makecontext(&f.ctx, (void (*)())trampoline, 0);
+                    g.fibers[t].done = false;
+                    g_sp[t] = make_stack(g.fibers[t].stack);
                 }
                 int guard = 0;
                 while (g.alive > 0) {
@@ -109,7 +144,7 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t shm
                     for (int t = 0; t < nthreads; ++t) {
                         if (g.fibers[t].done) continue;
                         set_tid(t);
-                        swapcontext(&g.main_ctx, &g.fibers[t].ctx);
+                        hipemu_switch(&g_main_sp, g_sp[t]);
                         progressed++;
                     }
                     if (!progressed) break;
