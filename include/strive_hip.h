@@ -156,6 +156,13 @@ int strive_map_cnn_fwd(const StriveMap* map, const StriveCNN* cnn, const float* 
 int strive_map_cnn_fwd_from_crop(const StriveCNN* cnn, const uint8_t* crop, int32_t N, float* feat,
                                  void* ws, size_t ws_bytes, strive_stream_t stream);
 
+/* Measurement hook for bench.py: launch ONE kernel of the stack (layer 0 = fused crop+conv1, 1..5 =
+ * conv2..6, 6 = GroupNorm+Linear) on the activations a previous strive_map_cnn_fwd over the same N <= 256
+ * poses left in `ws`, so a single kernel can be timed with events on the launching stream. */
+int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN* cnn, int32_t layer, const float* pos,
+                               const float* pos_mean4_host, const float* pos_std4_host, const int32_t* mapix,
+                               int32_t N, float* feat, void* ws, size_t ws_bytes, strive_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Small operators
  * ---------------------------------------------------------------------------------------------- */

@@ -37,24 +37,22 @@ def transform2frame(frame, poses, inverse=False):
     inverse   t' = R_f^T t + t_f,  h' = first column of R_p R_f^T
     with R_f = [[c, s], [-s, c]], R_p = [[pc, -ps], [ps, pc]].  Headings are not renormalised.
     """
-    c = frame[:, 2].unsqueeze(1)
-    s = frame[:, 3].unsqueeze(1)
-    fx = frame[:, 0].unsqueeze(1)
-    fy = frame[:, 1].unsqueeze(1)
-    px, py, pc, ps = poses[..., 0], poses[..., 1], poses[..., 2], poses[..., 3]
+    # The 2x2 products go through torch.matmul on (B,N,2,2) operands, as the reference does, so that the
+    # CPU oracle reproduces the reference's rounding (batched-matmul inner products) bit for bit; the rollout
+    # re-samples the map raster at every step, and a 1-ulp pose difference can flip a crop pixel.
+    B, N, _ = poses.shape
+    c, s = frame[:, 2], frame[:, 3]
+    Rf = torch.stack([c, s, -s, c], dim=1).reshape(B, 1, 2, 2).expand(B, N, 2, 2)
+    pc, ps = poses[:, :, 2], poses[:, :, 3]
+    Rp = torch.stack([pc, -ps, ps, pc], dim=2).reshape(B, N, 2, 2)
+    ft = frame[:, :2].reshape(B, 1, 2)
     if inverse:
-        tx = (c * px - s * py) + fx
-        ty = (s * px + c * py) + fy
-        hc = pc * c - ps * s
-        hs = ps * c + pc * s
+        R = torch.matmul(Rp, Rf.transpose(2, 3))
+        t = torch.matmul(Rf.transpose(2, 3), poses[:, :, :2].reshape(B, N, 2, 1))[:, :, :, 0] + ft
     else:
-        dx = px - fx
-        dy = py - fy
-        tx = c * dx + s * dy
-        ty = -s * dx + c * dy
-        hc = pc * c + ps * s
-        hs = ps * c - pc * s
-    return torch.stack([tx, ty, hc, hs], dim=-1)
+        R = torch.matmul(Rp, Rf)
+        t = torch.matmul(Rf, (poses[:, :, :2] - ft).reshape(B, N, 2, 1))[:, :, :, 0]
+    return torch.cat([t, torch.stack([R[:, :, 0, 0], R[:, :, 1, 0]], dim=2)], dim=-1)
 
 
 def bicycle_step(state_u, a, ddh, veh_len, dt, max_hdot, max_s):

@@ -85,6 +85,17 @@ def gru_step(sd, prefix, x, h, num_layers=3):
     """One time step of a stacked GRU: ``x (N,I)``, ``h (L,N,H)`` -> (top output, new h).
     Gate order r,z,n; n = tanh(W_in x + b_in + r*(W_hn h + b_hn)); h' = (1-z)*n + z*h
     (torch.nn.GRU semantics used at reference src/models/traffic_model.py:152-156, 686-688)."""
+    if hasattr(torch, '_VF') and hasattr(torch._VF, 'gru'):
+        # Same library primitive nn.GRU dispatches to, so the oracle reproduces the reference's GRU rounding
+        # bit for bit (the rollout is chaotic through the per-step raster re-sampling: a 1e-7 difference in a
+        # pose can flip a crop pixel and move the map feature by 1e-3).  The explicit gate arithmetic below is
+        # the definition and is what the HIP kernel implements.
+        flat = []
+        for l in range(num_layers):
+            flat += [sd['%s.weight_ih_l%d' % (prefix, l)], sd['%s.weight_hh_l%d' % (prefix, l)],
+                     sd['%s.bias_ih_l%d' % (prefix, l)], sd['%s.bias_hh_l%d' % (prefix, l)]]
+        out, hn = torch._VF.gru(x.unsqueeze(1), h.contiguous(), flat, True, num_layers, 0.0, False, False, True)
+        return out[:, 0], hn
     new_h = []
     inp = x
     for l in range(num_layers):

@@ -80,6 +80,7 @@ PROTOTYPES = {
     'strive_map_cnn_workspace_bytes': (SZ, [I]),
     'strive_map_cnn_fwd': (C.c_int, [C.POINTER(StriveMap), C.POINTER(StriveCNN), P, F4, F4, P, I, P, P, SZ, P]),
     'strive_map_cnn_fwd_from_crop': (C.c_int, [C.POINTER(StriveCNN), P, I, P, P, SZ, P]),
+    'strive_map_cnn_bench_layer': (C.c_int, [C.POINTER(StriveMap), C.POINTER(StriveCNN), I, P, F4, F4, P, I, P, P, SZ, P]),
     'strive_mlp_fwd': (C.c_int, [C.POINTER(StriveMLP), P, I, P, P]),
     'strive_gnn_workspace_bytes': (SZ, [C.POINTER(StriveGNN), C.POINTER(StriveScenes)]),
     'strive_gnn_fwd': (C.c_int, [C.POINTER(StriveGNN), C.POINTER(StriveScenes), P, P, P, P, P, SZ, P]),
@@ -144,12 +145,22 @@ def get_lib():
     return _default
 
 
+class _TensorArg(object):
+    """ctypes argument that keeps its tensor alive until the foreign call has been issued (temporaries such as
+    ``x.contiguous()`` would otherwise be freed between taking the address and making the call)."""
+    __slots__ = ('tensor', '_as_parameter_')
+
+    def __init__(self, t):
+        self.tensor = t
+        self._as_parameter_ = C.c_void_p(t.data_ptr())
+
+
 def ptr(t):
     """Device (or, under the test emulation, host) address of a contiguous tensor; None -> NULL."""
     if t is None:
         return None
     assert t.is_contiguous(), 'non-contiguous tensor passed to the C ABI'
-    return C.c_void_p(t.data_ptr())
+    return _TensorArg(t)
 
 
 def f4(vals):

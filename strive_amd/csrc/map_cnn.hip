@@ -23,15 +23,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GNStats { double sum, sq; };
 
-__device__ __forceinline__ void gn_scale_shift(const GNStats* __restrict__ st, int n, double count, float gamma,
-                                               float beta, float& scale, float& shift) {
-    const double mean = st[n].sum / count;
-    double var = st[n].sq / count - mean * mean;
+// Per-sample GroupNorm(1) moments from the producing layer's per-tile partial sums, added in tile order
+// (no atomics anywhere: the CNN is bitwise reproducible run to run, which matters because the rollout
+// re-samples the raster at poses that depend on these features).
+__device__ __forceinline__ void gn_moments(const GNStats* __restrict__ st, int n, int nparts, double count, float& mean,
+                                           float& rstd) {
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < nparts; ++i) {
+        s += st[(size_t)n * nparts + i].sum;
+        q += st[(size_t)n * nparts + i].sq;
+    }
+    const double m = s / count;
+    double var = q / count - m * m;
     var = var < 0.0 ? 0.0 : var;
-    const float rstd = (float)(1.0 / sqrt(var + GN_EPS));
-    const float fm = (float)mean;
-    scale = rstd * gamma;
-    shift = beta - fm * scale;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + GN_EPS));
 }
 
 // =============================================================================================
@@ -143,8 +149,9 @@ __global__ __launch_bounds__(256) void conv1_kernel(StriveMap map, const float* 
     if (lane == 0) { s_red[wave * 2] = lsum; s_red[wave * 2 + 1] = lsq; }
     __syncthreads();
     if (tid == 0) {
-        atomicAdd(&stats[n].sum, s_red[0] + s_red[2] + s_red[4] + s_red[6]);
-        atomicAdd(&stats[n].sq, s_red[1] + s_red[3] + s_red[5] + s_red[7]);
+        GNStats& o = stats[(size_t)n * (TILES * TILES) + blockIdx.y * TILES + blockIdx.x];
+        o.sum = ((s_red[0] + s_red[2]) + s_red[4]) + s_red[6];
+        o.sq = ((s_red[1] + s_red[3]) + s_red[5]) + s_red[7];
     }
 }
 
@@ -157,8 +164,9 @@ __global__ __launch_bounds__(256) void conv1_kernel(StriveMap map, const float* 
 // at the same window offset and every LDS address is lane_base + compile-time immediate.
 // =============================================================================================
 template <int CIN_, int COUT_, int KS_, int IH_, int OH_, int TH_, int TW_, int S_, int CC_, int NWP_, int NWM_, int NPW_,
-          int MTW_>
+          int MTW_, int NPART_IN_>
 struct ConvCfg {
+    static constexpr int NPART_IN = NPART_IN_;       // per-sample partial-statistics slots written by the producer
     static constexpr int CIN = CIN_, COUT = COUT_, KS = KS_, IH = IH_, OH = OH_, TH = TH_, TW = TW_, S = S_, CC = CC_;
     static constexpr int NWP = NWP_, NWM = NWM_, NPW = NPW_, MTW = MTW_;
     static constexpr int NW = NWP * NWM, NT = NW * 64;
@@ -174,7 +182,9 @@ struct ConvCfg {
     static constexpr int WCH = (CC / 2) * KS * KS * 2 * COUT;   // weight floats per chunk
     static constexpr int IN_FLOATS = S * SS;
     static constexpr int GN_FLOATS = S * CIN * 2;
-    static constexpr size_t LDS_BYTES = (size_t)(IN_FLOATS + WCH + GN_FLOATS) * 4 + 64 * 8;
+    static constexpr int NPART_OUT = TILES_X * TILES_Y;   // == 1 whenever S > 1 (whole images per workgroup)
+    static constexpr int RED_DOUBLES = (S == 1) ? 2 * NW : 2 * NW * NPW * 64;
+    static constexpr size_t LDS_BYTES = (size_t)(IN_FLOATS + WCH + GN_FLOATS) * 4 + (size_t)RED_DOUBLES * 8 + 64 * 4;
     static_assert(COUT == NWM * MTW * 32, "channel tiling");
     static_assert(NTILE <= NWP * NPW, "pixel tiling");
     static_assert(CC % 2 == 0 && CIN % CC == 0, "channel chunking");
@@ -193,7 +203,8 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
     float* s_in = smem;
     float* s_w = smem + Cfg::IN_FLOATS;
     float* s_gn = s_w + Cfg::WCH;                     // [S][CIN][2] scale, shift
-    double* s_red = (double*)(s_gn + Cfg::GN_FLOATS);   // [S][2] (S <= 32)
+    double* s_red = (double*)(s_gn + Cfg::GN_FLOATS);   // per-wave (S == 1) or per-lane (S > 1) partial sums
+    float* s_mr = (float*)(s_red + Cfg::RED_DOUBLES);   // [S][2] mean, rstd of the input samples (S <= 32)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave % Cfg::NWP, wm = wave / Cfg::NWP;
@@ -204,14 +215,19 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
 
     // ---- GroupNorm scale/shift of the producing layer, per (sample, channel) ----
     const double cnt_in = (double)CIN * IH * IH;
+    if (tid < S) {
+        float mean = 0.f, rstd = 0.f;
+        if (n0 + tid < N) gn_moments(st_in, n0 + tid, Cfg::NPART_IN, cnt_in, mean, rstd);
+        s_mr[2 * tid] = mean;
+        s_mr[2 * tid + 1] = rstd;
+    }
+    __syncthreads();
     for (int i = tid; i < S * CIN; i += Cfg::NT) {
         const int s = i / CIN, c = i - s * CIN;
-        float sc = 0.f, sh = 0.f;
-        if (n0 + s < N) gn_scale_shift(st_in, n0 + s, cnt_in, gn_g[c], gn_b[c], sc, sh);
+        const float sc = s_mr[2 * s + 1] * gn_g[c];
         s_gn[2 * i] = sc;
-        s_gn[2 * i + 1] = sh;
+        s_gn[2 * i + 1] = gn_b[c] - s_mr[2 * s] * sc;
     }
-    if (tid < 2 * S) s_red[tid] = 0.0;
 
     // ---- per-lane pixel bases ----
     int pbase[NPW];
@@ -288,11 +304,10 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
 
     // ---- epilogue ----
     // D layout: column = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel within the tile
+    double wsum = 0.0, wsq = 0.0;   // S == 1: this wave's running total
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
         const int p = ppix[i];
-        const int tile = wp * NPW + i;
-        if (tile * 32 >= P) continue;   // wave-uniform
         const bool pv = p < P;
         const int pc = pv ? p : 0;
         const int s = pc / (TH * TW);
@@ -314,30 +329,56 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
             }
         }
         if (S == 1) {
-            lsum = wave_sum_d(lsum);
-            lsq = wave_sum_d(lsq);
-            if (lane == 0) {
-                atomicAdd(&s_red[0], lsum);
-                atomicAdd(&s_red[1], lsq);
-            }
-        } else if (valid) {
-            atomicAdd(&s_red[2 * s], lsum);
-            atomicAdd(&s_red[2 * s + 1], lsq);
+            wsum += lsum;
+            wsq += lsq;
+        } else {
+            // per-lane slot, tagged with its sample through the reduction below
+            s_red[2 * ((wave * NPW + i) * 64 + lane)] = valid ? lsum : 0.0;
+            s_red[2 * ((wave * NPW + i) * 64 + lane) + 1] = valid ? lsq : 0.0;
         }
     }
-    __syncthreads();
-    if (tid < S && n0 + tid < N) {
-        atomicAdd(&st_out[n0 + tid].sum, s_red[2 * tid]);
-        atomicAdd(&st_out[n0 + tid].sq, s_red[2 * tid + 1]);
+    if (S == 1) {
+        wsum = wave_sum_d(wsum);
+        wsq = wave_sum_d(wsq);
+        if (lane == 0) { s_red[2 * wave] = wsum; s_red[2 * wave + 1] = wsq; }
+        __syncthreads();
+        if (tid == 0 && n0 < N) {
+            double a = 0.0, b = 0.0;
+            for (int w = 0; w < Cfg::NW; ++w) { a += s_red[2 * w]; b += s_red[2 * w + 1]; }
+            GNStats& o = st_out[(size_t)n0 * Cfg::NPART_OUT + blockIdx.y * Cfg::TILES_X + blockIdx.x];
+            o.sum = a;
+            o.sq = b;
+        }
+    } else {
+        __syncthreads();
+        // fixed-order reduction: thread s adds the slots whose pixel belongs to sample s
+        if (tid < S && n0 + tid < N) {
+            double a = 0.0, b = 0.0;
+            for (int w = 0; w < Cfg::NW; ++w) {
+                const int wpp = w % Cfg::NWP;
+                for (int i = 0; i < NPW; ++i) {
+                    const int tile = wpp * NPW + i;
+                    for (int l = 0; l < 64; ++l) {
+                        const int p = tile * 32 + (l & 31);
+                        if (p < P && p / (TH * TW) == tid) {
+                            a += s_red[2 * ((w * NPW + i) * 64 + l)];
+                            b += s_red[2 * ((w * NPW + i) * 64 + l) + 1];
+                        }
+                    }
+                }
+            }
+            st_out[n0 + tid].sum = a;
+            st_out[n0 + tid].sq = b;
+        }
     }
 }
 
-// per-layer configurations            CIN COUT KS  IH  OH  TH  TW  S  CC NWP NWM NPW MTW
-typedef ConvCfg< 16,  32, 5, 125, 61, 16, 16,  1,  8,  4,  1,  2,  1> Cfg2;   // 256 px tile, 4 waves
-typedef ConvCfg< 32,  64, 5,  61, 29, 29, 29,  1,  2,  7,  1,  4,  2> Cfg3;   // whole image (841 px), 7 waves
-typedef ConvCfg< 64,  64, 3,  29, 14, 14, 14,  4,  2,  5,  1,  5,  2> Cfg4;   // 4 samples (784 px), 5 waves
-typedef ConvCfg< 64, 128, 3,  14,  6,  6,  6,  8,  4,  3,  2,  3,  2> Cfg5;   // 8 samples (288 px), 6 waves
-typedef ConvCfg<128, 128, 3,   6,  2,  2,  2, 32,  8,  2,  2,  2,  2> Cfg6;   // 32 samples (128 px), 4 waves
+// per-layer configurations            CIN COUT KS  IH  OH  TH  TW  S  CC NWP NWM NPW MTW NPART_IN
+typedef ConvCfg< 16,  32, 5, 125, 61, 16, 16,  1,  8,  4,  1,  2,  1, 64> Cfg2;   // 256 px tile, 4 waves
+typedef ConvCfg< 32,  64, 5,  61, 29, 29, 29,  1,  2,  7,  1,  4,  2, 16> Cfg3;   // whole image (841 px), 7 waves
+typedef ConvCfg< 64,  64, 3,  29, 14, 14, 14,  4,  2,  7,  1,  4,  2,  1> Cfg4;   // 4 samples (784 px), 7 waves
+typedef ConvCfg< 64, 128, 3,  14,  6,  6,  6,  8,  4,  3,  2,  3,  2,  1> Cfg5;   // 8 samples (288 px), 6 waves
+typedef ConvCfg<128, 128, 3,   6,  2,  2,  2, 32,  8,  2,  2,  2,  2,  1> Cfg6;   // 32 samples (128 px), 4 waves
 
 template <class Cfg>
 static int launch_conv(const float* in, const GNStats* st_in, const float* g, const float* b, const float* w,
@@ -367,10 +408,11 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ in, c
         const int s = i >> 9, k = i & 511;
         float v = 0.f;
         if (n0 + s < N) {
-            float sc, sh;
+            float mean, rstd;
             const int c = k >> 2;
-            gn_scale_shift(st, n0 + s, 512.0, gn_g[c], gn_b[c], sc, sh);
-            v = fmaxf(fmaf(in[(size_t)(n0 + s) * 512 + k], sc, sh), 0.f);
+            gn_moments(st, n0 + s, 1, 512.0, mean, rstd);
+            const float sc = rstd * gn_g[c];
+            v = fmaxf(fmaf(in[(size_t)(n0 + s) * 512 + k], sc, gn_b[c] - mean * sc), 0.f);
         }
         s_a[s][k] = v;
     }
@@ -388,7 +430,9 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ in, c
 // =============================================================================================
 namespace {
 constexpr size_t L_OUT[6] = {16u * 125 * 125, 32u * 61 * 61, 64u * 29 * 29, 64u * 14 * 14, 128u * 6 * 6, 128u * 2 * 2};
-constexpr int CNN_CHUNK = 256;   // agents pushed through the layer stack together (keeps the working set L3-sized)
+constexpr int CNN_CHUNK = 256;
+constexpr int NPARTS[6] = {64, 16, 1, 1, 1, 1};   // statistics slots per sample written by each layer
+constexpr int STAT_SLOTS = 64 + 16 + 1 + 1 + 1 + 1;   // agents pushed through the layer stack together (keeps the working set L3-sized)
 
 size_t per_agent_floats() {
     size_t t = 0;
@@ -401,7 +445,7 @@ extern "C" size_t strive_map_cnn_workspace_bytes(int32_t N) {
     const size_t ch = (size_t)(N < CNN_CHUNK ? (N > 0 ? N : 1) : CNN_CHUNK);
     size_t bytes = 0;
     for (int l = 0; l < 6; ++l) bytes += strive_align_up(ch * L_OUT[l] * 4, 256);
-    bytes += strive_align_up(ch * 6 * sizeof(GNStats), 256);
+    bytes += strive_align_up(ch * STAT_SLOTS * sizeof(GNStats), 256);
     return bytes;
 }
 
@@ -417,7 +461,7 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
     StriveArena ar(ws, ws_bytes);
     float* act[6];
     for (int l = 0; l < 6; ++l) act[l] = ar.take<float>((size_t)ch * L_OUT[l]);
-    GNStats* stats = ar.take<GNStats>((size_t)ch * 6);
+    GNStats* stats = ar.take<GNStats>((size_t)ch * STAT_SLOTS);
     if (!ar.ok()) { strive_set_error("map_cnn: workspace arena overflow"); return -1; }
     Float4Host m, s;
     StriveMap mp;
@@ -432,9 +476,11 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
     }
     for (int n0 = 0; n0 < N; n0 += ch) {
         const int n = (N - n0) < ch ? (N - n0) : ch;
-        hipMemsetAsync(stats, 0, (size_t)ch * 6 * sizeof(GNStats), stream);
         GNStats* st[6];
-        for (int l = 0; l < 6; ++l) st[l] = stats + (size_t)l * ch;
+        {
+            size_t off = 0;
+            for (int l = 0; l < 6; ++l) { st[l] = stats + off; off += (size_t)ch * NPARTS[l]; }
+        }
         dim3 g1(l1::TILES, l1::TILES, n);
         if (map) {
             hipLaunchKernelGGL(conv1_kernel<true>, g1, dim3(256), 0, stream, mp, pos + (size_t)n0 * 4, m, s, mapix + n0,
@@ -468,4 +514,46 @@ extern "C" int strive_map_cnn_fwd_from_crop(const StriveCNN* cnn, const uint8_t*
                                             size_t ws_bytes, strive_stream_t stream) {
     STRIVE_CHECK_ARG(cnn && crop && feat && ws, "null argument");
     return cnn_run(nullptr, cnn, nullptr, nullptr, nullptr, nullptr, crop, N, feat, ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Measurement hook: launch ONE layer of the stack on activations left in `ws` by a previous
+// strive_map_cnn_fwd over the same N (<= 256) poses, so bench.py can time a single kernel with events
+// on the launching stream.  layer 0 = fused crop + conv1, 1..5 = conv2..conv6, 6 = GroupNorm + Linear.
+// ---------------------------------------------------------------------------------------------
+extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN* cnn, int32_t layer, const float* pos,
+                                          const float* pos_mean4_host, const float* pos_std4_host, const int32_t* mapix,
+                                          int32_t N, float* feat, void* ws, size_t ws_bytes, strive_stream_t stream_) {
+    STRIVE_CHECK_ARG(map && cnn && pos && mapix && feat && ws, "null argument");
+    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK && layer >= 0 && layer <= 6, "bad layer / N");
+    STRIVE_CHECK_ARG(ws_bytes >= strive_map_cnn_workspace_bytes(N), "workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    StriveArena ar(ws, ws_bytes);
+    float* act[6];
+    for (int l = 0; l < 6; ++l) act[l] = ar.take<float>((size_t)N * L_OUT[l]);
+    GNStats* stats = ar.take<GNStats>((size_t)N * STAT_SLOTS);
+    GNStats* st[6];
+    {
+        size_t off = 0;
+        for (int l = 0; l < 6; ++l) { st[l] = stats + off; off += (size_t)N * NPARTS[l]; }
+    }
+    Float4Host m, s;
+    memcpy(m.v, pos_mean4_host, 16);
+    memcpy(s.v, pos_std4_host, 16);
+    switch (layer) {
+        case 0:
+            hipLaunchKernelGGL(conv1_kernel<true>, dim3(l1::TILES, l1::TILES, N), dim3(256), 0, stream, *map, pos, m, s, mapix,
+                               (const uint8_t*)nullptr, (const float*)cnn->w[0], (const float*)cnn->b[0], act[0], st[0]);
+            break;
+        case 1: launch_conv<Cfg2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w[1], cnn->b[1], act[1], st[1], N, stream); break;
+        case 2: launch_conv<Cfg3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w[2], cnn->b[2], act[2], st[2], N, stream); break;
+        case 3: launch_conv<Cfg4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w[3], cnn->b[3], act[3], st[3], N, stream); break;
+        case 4: launch_conv<Cfg5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w[4], cnn->b[4], act[4], st[4], N, stream); break;
+        case 5: launch_conv<Cfg6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w[5], cnn->b[5], act[5], st[5], N, stream); break;
+        default:
+            hipLaunchKernelGGL(fc_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, act[5], st[5], cnn->gn_g[5], cnn->gn_b[5],
+                               cnn->fc_wt, cnn->fc_b, feat, N);
+    }
+    STRIVE_CHECK_LAUNCH();
+    return 0;
 }

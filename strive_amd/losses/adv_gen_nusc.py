@@ -1,0 +1,375 @@
+"""Optimisation-time losses with the reference's names, signatures and returned dict keys
+(reference src/losses/adv_gen_nusc.py:14-512, 625-673).
+
+The two expensive terms run in HIP kernels through strive_amd.ops:
+  * ``VehCollLoss``  -- strive_veh_coll_fwd/bwd over in-scene ordered pairs only (the reference enumerates
+    all NA^2 pairs of the batch and masks cross-scene ones afterwards);
+  * ``EnvCollLoss``  -- strive_coll_point (raster gather) for the collision point.
+Everything else (interpolation, prior NLL, soft-min bookkeeping, means) is elementwise torch glue on the
+device.  Per-scene Python loops and ``print`` calls of the reference's AdvGenLoss are replaced by segment
+operations; returned values are the same.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .common import log_normal
+from .. import ops
+
+
+def interp_traj(future_pred, scale_factor=3):
+    """Linear up-sampling in time + heading renormalisation (reference :625-644)."""
+    multi = future_pred.dim() == 4
+    if multi:
+        NA, NS, T, _ = future_pred.size()
+        future_pred = future_pred.reshape(NA * NS, T, 4)
+    up = nn.functional.interpolate(future_pred.transpose(1, 2), scale_factor=scale_factor, mode='linear').transpose(1, 2)
+    h = up[:, :, 2:4]
+    up = torch.cat([up[:, :, :2], h / torch.norm(h, dim=-1, keepdim=True)], dim=-1)
+    if multi:
+        up = up.reshape(NA, NS, up.size(1), 4)
+    return up
+
+
+def _expand_targets(tgt, sizes_minus_one):
+    """Repeat each scene's target row for that scene's non-ego agents."""
+    return torch.repeat_interleave(tgt, sizes_minus_one.to(tgt.device), dim=0)
+
+
+def check_behind(attacker_fut, tgt_fut, ptr, crash_min_infront):
+    """(NA-B,T) bool, True where the attacker is behind the target (reference :646-673)."""
+    sizes = (ptr[1:] - ptr[:-1]) - 1
+    tgt = _expand_targets(tgt_fut, sizes)
+    d = attacker_fut[:, :, :2] - tgt[:, :, :2]
+    d = d / torch.norm(d, dim=-1, keepdim=True)
+    return torch.sum(d * tgt[:, :, 2:4], dim=-1) < crash_min_infront
+
+
+class MotionPriorLoss(nn.Module):
+    """Negative log-likelihood of z under the prior (reference :343-364)."""
+
+    def forward(self, z, prior_out):
+        mu, var = prior_out[0], prior_out[1]
+        if z.dim() == 3:
+            mu, var = mu.unsqueeze(1), var.unsqueeze(1)
+        return -log_normal(z, mu, var)
+
+
+class TgtMatchingLoss(nn.Module):
+    """(reference :14-51) -- keeps the reference's behaviour that the prior term adds
+    ``w * tgt_loss.mean()`` to the objective while reporting the prior NLL (line 46)."""
+
+    def __init__(self, loss_weights):
+        super(TgtMatchingLoss, self).__init__()
+        self.loss_weights = loss_weights
+        self.motion_prior_loss = MotionPriorLoss()
+
+    def forward(self, future_pred, tgt_traj, z, prior_out):
+        out = {}
+        loss = 0.0
+        tgt_loss = None
+        if self.loss_weights['match_ext'] > 0.0:
+            tgt_loss = torch.sum((future_pred - tgt_traj) ** 2, dim=-1)
+            loss = loss + self.loss_weights['match_ext'] * tgt_loss.mean()
+            out['match_ext_loss'] = tgt_loss
+        if self.loss_weights['motion_prior_ext'] > 0.0:
+            out['motion_prior_ext_loss'] = self.motion_prior_loss(z, prior_out)
+            loss = loss + self.loss_weights['motion_prior_ext'] * tgt_loss.mean()
+        out['loss'] = loss
+        return out
+
+
+def _linspace5(lo, hi):
+    """torch.linspace(lo, hi, 5) for tensors of endpoints, with linspace's own evaluation order
+    (first half from the start, second half from the end) so values match the reference's
+    per-agent ``torch.linspace(cent_min.item(), cent_max.item(), 5)`` (reference :435)."""
+    step = (hi - lo) / 4.0
+    return torch.stack([lo, lo + step, hi - step * 2.0, hi - step, hi], dim=1)
+
+
+class VehCollLoss(nn.Module):
+    """Circle-approximation vehicle collision penalty (reference :405-512)."""
+
+    def __init__(self, veh_att, num_circ=5, buffer_dist=0.0, single_veh_idx=None, ptr=None):
+        super(VehCollLoss, self).__init__()
+        if num_circ != 5:
+            raise NotImplementedError('the HIP collision kernel is built for 5 circles per vehicle')
+        self.veh_att = veh_att
+        self.buffer_dist = buffer_dist
+        self.single_veh_idx = single_veh_idx
+        NA = veh_att.size(0)
+        dev = veh_att.device
+        if ptr is None:
+            ptr = torch.tensor([0, NA], dtype=torch.long)
+        self.ptr = ptr
+        self.info = ops.SceneInfo(ptr.cpu(), dev)
+        self.veh_rad = veh_att[:, 1] / 2.
+        cent_min = -(veh_att[:, 0] / 2.) + self.veh_rad
+        cent_max = (veh_att[:, 0] / 2.) - self.veh_rad
+        self.cent_x = _linspace5(cent_min, cent_max)
+        self.num_circ = num_circ
+        self.setup = ops.VehCollSetup(self.info, self.cent_x, self.veh_rad, buffer_dist)
+        # slot bookkeeping: slot = pair_off[i] + (j - ptr[scene(i)])
+        sizes = self.info.sizes.to(torch.long)
+        agent_scene = torch.repeat_interleave(torch.arange(self.info.B), sizes)
+        lo = ptr.cpu()[:-1][agent_scene]
+        n_of_agent = sizes[agent_scene]
+        self.slot_i = torch.repeat_interleave(torch.arange(NA), n_of_agent).to(dev)               # (P,)
+        within = torch.arange(self.info.P) - torch.repeat_interleave(self.info.pair_off.cpu().to(torch.long), n_of_agent)
+        self.slot_j = (torch.repeat_interleave(lo, n_of_agent) + within).to(dev)                   # (P,)
+        valid = self.slot_i != self.slot_j
+        if single_veh_idx is not None:
+            sel = torch.zeros((NA,), dtype=torch.bool, device=dev)
+            sel[(ptr.cpu()[:-1] + single_veh_idx).to(dev)] = True
+            valid = valid & (sel[self.slot_i] | sel[self.slot_j])
+        self.valid = valid
+
+    def forward(self, traj, att_inds=None, return_raw=False):
+        """traj (NA,T,4) UNNORMALISED.  Returns the 1-D penalties of colliding valid pairs in the reference's
+        (t, i, j) order, ``[0.]`` if none; with ``return_raw`` the dense (T,NA,NA) penalty matrix and mask
+        (cross-scene entries: penalty 0, mask False)."""
+        if att_inds is not None:
+            raise NotImplementedError('att_inds is not supported by the HIP collision kernel')
+        pen, hit = ops.veh_coll_penalties(traj, self.setup)
+        mask = hit.bool() & self.valid.view(1, -1)
+        if return_raw:
+            T, NA = pen.size(0), traj.size(0)
+            dense = torch.zeros((T, NA, NA), dtype=pen.dtype, device=pen.device)
+            dmask = torch.zeros((T, NA, NA), dtype=torch.bool, device=pen.device)
+            dense[:, self.slot_i, self.slot_j] = pen
+            dmask[:, self.slot_i, self.slot_j] = mask
+            return dense, dmask
+        if torch.sum(mask) == 0:
+            return torch.Tensor([0.0]).to(traj.device)
+        return pen[mask]
+
+    def block_penalties(self, traj):
+        """(pen (T,P), colliding&valid mask (T,P)) in slot layout -- what the fused loss modules use."""
+        pen, hit = ops.veh_coll_penalties(traj, self.setup)
+        return pen, hit.bool() & self.valid.view(1, -1)
+
+
+class EnvCollLoss(nn.Module):
+    """Off-road penalty from the estimated collision point (reference :366-403)."""
+
+    def __init__(self, veh_att, mapixes, map_env):
+        super(EnvCollLoss, self).__init__()
+        self.map_env = map_env
+        self.mapixes = mapixes
+        self.penalty_dists = torch.sqrt((veh_att[:, 0] ** 2 / 4.0) + (veh_att[:, 1] ** 2 / 4.0))
+        self.veh_att = veh_att
+        self._grid = {}
+
+    def _grid_size(self, NA, T):
+        # batch-mean size over the (NA*T, 2) expanded attributes, like nuscenes_utils.py:351-354; constant per T
+        g = self._grid.get(T)
+        if g is None:
+            att = self.veh_att.view(NA, 1, 2).expand(NA, T, 2).reshape(NA * T, 2)
+            mdx = torch.mean(self.map_env.nusc_dx) * 0.5
+            mlw = torch.mean(att, dim=0)
+            g = (torch.round(mlw[0] / mdx).int().item(), torch.round(mlw[1] / mdx).int().item())
+            self._grid[T] = g
+        return g
+
+    def valid_penalties(self, traj):
+        """(pen (NA*T,), valid (NA*T,) bool): penalty 1 - |c - p|/r for rows with a collision point."""
+        NA, T, _ = traj.size()
+        flat = traj.reshape(NA * T, 4)
+        att = self.veh_att.view(NA, 1, 2).expand(NA, T, 2).reshape(NA * T, 2)
+        mix = self.mapixes.view(NA, 1).expand(NA, T).reshape(NA * T)
+        gl, gw = self._grid_size(NA, T)
+        pt, _ = ops.coll_point(self.map_env, flat.detach(), att, mix, gl, gw)
+        valid = ~torch.isnan(torch.sum(pt, dim=1))
+        safe_pt = torch.where(valid.unsqueeze(1), pt, flat[:, :2].detach() + 1.0)
+        d = torch.norm(flat[:, :2] - safe_pt, dim=1)
+        pdist = self.penalty_dists.view(NA, 1).expand(NA, T).reshape(NA * T)
+        return 1.0 - (d / pdist), valid
+
+    def forward(self, traj):
+        pen, valid = self.valid_penalties(traj)
+        if torch.sum(valid) == 0:
+            return torch.Tensor([0.0]).to(traj.device)
+        return pen[valid]
+
+
+class AvoidCollLoss(nn.Module):
+    """(reference :264-341)"""
+
+    def __init__(self, loss_weights, veh_att, mapixes, map_env, init_z, veh_coll_buffer=0.0, single_veh_idx=None, ptr=None):
+        super(AvoidCollLoss, self).__init__()
+        self.loss_weights = loss_weights
+        self.init_z = init_z
+        self.single_veh_idx = single_veh_idx
+        self.ptr = ptr
+        self.use_single_agt = single_veh_idx is not None
+        self.motion_prior_loss = MotionPriorLoss()
+        self.veh_coll_loss = VehCollLoss(veh_att, buffer_dist=veh_coll_buffer, single_veh_idx=single_veh_idx, ptr=ptr)
+        if self.use_single_agt:
+            assert ptr is not None
+            self.single_mask = torch.zeros((veh_att.size(0),), dtype=torch.bool, device=veh_att.device)
+            self.single_mask[(ptr[:-1] + single_veh_idx).to(veh_att.device)] = True
+            veh_att = veh_att[self.single_mask]
+            mapixes = mapixes[self.single_mask]
+        self.env_coll_loss = EnvCollLoss(veh_att, mapixes, map_env)
+
+    def forward(self, future_pred, z, prior_out):
+        w = self.loss_weights
+        loss = 0.0
+        out = {}
+        fine = interp_traj(future_pred, scale_factor=3)
+        if w['coll_veh'] > 0.0:
+            v = self.veh_coll_loss(fine)
+            loss = loss + w['coll_veh'] * v.mean()
+            out['coll_veh_loss'] = v
+        if w['coll_env'] > 0.0:
+            e = self.env_coll_loss(fine if not self.use_single_agt else fine[self.single_mask])
+            loss = loss + w['coll_env'] * e.mean()
+            out['coll_env_loss'] = e
+        if w['motion_prior'] > 0.0:
+            p = self.motion_prior_loss(z, prior_out)
+            loss = loss + w['motion_prior'] * p.mean()
+            out['motion_prior_loss'] = p
+        if w['init_z'] > 0.0:
+            i = torch.sum((self.init_z - z) ** 2, dim=1)
+            loss = loss + w['init_z'] * i.mean()
+            out['init_loss'] = i
+        out['loss'] = loss
+        return out
+
+
+class AdvGenLoss(nn.Module):
+    """Adversarial objective (reference :53-262)."""
+
+    def __init__(self, loss_weights, veh_att, mapixes, map_env, init_z, ptr, veh_coll_buffer=0.0,
+                 crash_loss_min_time=0, crash_loss_min_infront=None):
+        super(AdvGenLoss, self).__init__()
+        dev = veh_att.device
+        self.loss_weights = loss_weights
+        self.init_z = init_z
+        self.motion_prior_loss = MotionPriorLoss()
+        self.ptr = ptr
+        ptr_c = ptr.cpu()
+        self.graph_sizes = ptr_c[1:] - ptr_c[:-1]
+        NA = veh_att.size(0)
+        self.B = self.graph_sizes.size(0)
+        self.ego_mask = torch.zeros((NA,), dtype=torch.bool, device=dev)
+        self.ego_mask[ptr_c[:-1].to(dev)] = True
+        self.nonego_ptr = ptr_c - torch.arange(len(ptr_c))
+        self.veh_coll_loss = VehCollLoss(veh_att, buffer_dist=veh_coll_buffer, ptr=ptr)
+        self.env_coll_loss = EnvCollLoss(veh_att[~self.ego_mask], mapixes[~self.ego_mask], map_env)
+        self.crash_min_t = crash_loss_min_time
+        self.crash_min_infront = crash_loss_min_infront
+        if crash_loss_min_infront is not None:
+            assert -1 <= crash_loss_min_infront <= 1
+        # scene id of every non-ego agent; ego involvement of every pair slot
+        self.seg = torch.repeat_interleave(torch.arange(self.B), self.graph_sizes - 1).to(dev)      # (NA-B,)
+        vl = self.veh_coll_loss
+        self.slot_ego = self.ego_mask[vl.slot_i] | self.ego_mask[vl.slot_j]
+        nonego_index = torch.cumsum((~self.ego_mask).to(torch.long), 0) - 1
+        self.slot_i_ne, self.slot_j_ne = nonego_index[vl.slot_i], nonego_index[vl.slot_j]
+        self.slot_i_ego, self.slot_j_ego = self.ego_mask[vl.slot_i], self.ego_mask[vl.slot_j]
+
+    def _segment_softmin(self, din):
+        """softmin over all (agent, t) entries of each scene; all-inf scenes give zeros (reference :133-135)."""
+        NT = din.size(1)
+        seg = self.seg.view(-1, 1).expand_as(din)
+        neg = -din
+        mx = torch.full((self.B,), float('-inf'), device=din.device).scatter_reduce(0, seg.reshape(-1), neg.reshape(-1),
+                                                                                    reduce='amax', include_self=True)
+        e = torch.exp(neg - mx[self.seg].view(-1, 1))
+        den = torch.zeros((self.B,), device=din.device).scatter_add(0, seg.reshape(-1), e.reshape(-1))
+        soft = e / den[self.seg].view(-1, 1)
+        return torch.where(torch.isnan(soft), torch.zeros_like(soft), soft)
+
+    def forward(self, future_pred, tgt_traj, z, prior_out, return_mins=False, attack_agt_idx=None):
+        w = self.loss_weights
+        NA, B = future_pred.size(0), tgt_traj.size(0)
+        dev = future_pred.device
+        crash = soft = None
+        cur_min_agt = cur_min_t = None
+        if w.get('adv_crash', 0.0) > 0.0:
+            atk = future_pred[~self.ego_mask][:, self.crash_min_t:, :]
+            tgt = tgt_traj[:, self.crash_min_t:, :4]
+            tgt_e = _expand_targets(tgt, self.graph_sizes - 1)
+            dist = torch.norm(atk[:, :, :2] - tgt_e[:, :, :2], dim=-1)
+            din = dist
+            inf = torch.full_like(din, float('inf'))
+            if self.crash_min_infront is not None:
+                behind = check_behind(atk.detach(), tgt.detach(), self.ptr.cpu(), self.crash_min_infront)
+                always = (torch.sum(behind, dim=1, keepdim=True) == behind.size(1)).expand_as(behind)
+                all_behind = torch.sum(always) == always.numel()
+                always = always & ~all_behind
+                din = torch.where(always, inf, din)
+            if attack_agt_idx is not None:
+                am = torch.zeros((NA,), dtype=torch.bool, device=dev)
+                am[attack_agt_idx.to(dev)] = True
+                am = am[~self.ego_mask].unsqueeze(1).expand_as(din)
+                din = torch.where(~am, inf, din)
+            NT = future_pred.size(1) - self.crash_min_t
+            soft = self._segment_softmin(din)
+            weighted = soft * dist ** 2
+            crash = torch.zeros((B,), device=dev).scatter_add(0, self.seg, weighted.sum(dim=1))
+            if return_mins:
+                flat = soft.detach().cpu()
+                cur_min_agt, cur_min_t = [], []
+                for b in range(B):
+                    a0, a1 = int(self.nonego_ptr[b]), int(self.nonego_ptr[b + 1])
+                    k = int(torch.max(flat[a0:a1].reshape(-1), dim=0)[1])
+                    cur_min_agt.append(k // NT + 1)
+                    cur_min_t.append(k % NT + self.crash_min_t)
+        rew = 1.0 - torch.sum(soft.detach(), dim=1)          # (NA-B,) high for non-attackers
+
+        prior_l = None
+        if w.get('motion_prior', 0.0) > 0.0:
+            prior_l = self.motion_prior_loss(z, prior_out) * (rew * w['motion_prior'] + (1.0 - rew) * w['motion_prior_atk'])
+
+        fine = interp_traj(future_pred, scale_factor=3)
+        veh_l = plan_l = None
+        if ('coll_veh' in w or 'coll_veh_plan' in w) and (w['coll_veh'] > 0.0 or w['coll_veh_plan'] > 0.0):
+            pen, cmask = self.veh_coll_loss.block_penalties(fine)
+            if w['coll_veh'] > 0.0:
+                m = cmask & (~self.slot_ego).view(1, -1)
+                veh_l = torch.Tensor([0.0]).to(dev) if torch.sum(m) == 0 else pen[m]
+            if w['coll_veh_plan'] > 0.0:
+                # weight of a planner-involving pair = prior_reweight of its non-ego member (reference :192-204)
+                one = torch.ones((1,), device=dev)
+                rew1 = torch.cat([rew, one])
+                wi = torch.where(self.slot_j_ego & ~self.slot_i_ego, rew1[self.slot_i_ne.clamp(min=0)], one)
+                wj = torch.where(self.slot_i_ego & ~self.slot_j_ego, rew1[self.slot_j_ne.clamp(min=0)], one)
+                pw = torch.where(self.slot_j_ego, wi, wj)
+                m = cmask & self.slot_ego.view(1, -1)
+                plan_l = torch.Tensor([0.0]).to(dev) if torch.sum(m) == 0 else (pen * pw.view(1, -1))[m]
+
+        env_l = None
+        if w.get('coll_env', 0.0) > 0.0:
+            env_l = self.env_coll_loss(fine[~self.ego_mask])
+        init_l = None
+        if w.get('init_z', 0.0) > 0.0:
+            coeff = rew * w['init_z'] + (1.0 - rew) * w['init_z_atk']
+            init_l = torch.sum(torch.sum((self.init_z - z) ** 2, dim=1) * coeff)
+
+        loss = 0.0
+        out = {}
+        if init_l is not None:
+            loss = loss + init_l.mean()
+            out['init_loss'] = init_l
+        if prior_l is not None:
+            loss = loss + prior_l.mean()
+            out['motion_prior_loss'] = prior_l
+        if veh_l is not None:
+            loss = loss + w['coll_veh'] * veh_l.mean()
+            out['coll_veh_loss'] = veh_l
+        if plan_l is not None:
+            loss = loss + w['coll_veh_plan'] * plan_l.mean()
+            out['coll_veh_plan_loss'] = plan_l
+        if env_l is not None:
+            loss = loss + w['coll_env'] * env_l.mean()
+            out['coll_env_loss'] = env_l
+        if crash is not None:
+            loss = loss + w['adv_crash'] * crash.mean()
+            out['adv_crash_loss'] = crash
+        out['loss'] = loss
+        if return_mins and cur_min_agt is not None:
+            out['min_agt'] = np.array(cur_min_agt, dtype=int)
+            out['min_t'] = np.array(cur_min_t, dtype=int)
+        return out

@@ -1,0 +1,83 @@
+"""Training-time loss with the reference's names (reference src/losses/traffic_model.py:20-295).
+
+Forward values come from the same HIP collision kernels as the optimisation-time losses.  The HIP
+path does not provide weight gradients (round-1 scope: latent optimisation, d/dz only), so this loss
+is usable for evaluation / monitoring; ``backward()`` through the model raises in TrafficModel.forward.
+"""
+import torch
+from torch import nn
+
+from .common import kl_normal, log_normal
+from . import adv_gen_nusc as _opt
+
+ENV_COLL_THRESH = 0.05
+VEH_COLL_THRESH = 0.02
+
+
+class VehCollLoss(nn.Module):
+    """Every valid in-scene pair contributes (zero when not colliding); returns (penalties, num_pairs)
+    (reference :166-238)."""
+
+    def __init__(self, veh_att, batch, ptr, num_circ=5, buffer_dist=0.0):
+        super(VehCollLoss, self).__init__()
+        self.inner = _opt.VehCollLoss(veh_att, num_circ=num_circ, buffer_dist=buffer_dist, ptr=ptr)
+        sizes = self.inner.info.sizes.to(torch.long)
+        self.num_pairs = torch.sum(sizes * sizes - sizes).to(veh_att.device)
+
+    def forward(self, traj):
+        pen, mask = self.inner.block_penalties(traj)
+        pen = torch.where(mask, pen, torch.zeros_like(pen))
+        return pen[:, self.inner.valid].reshape(-1), self.num_pairs
+
+
+class EnvCollLoss(nn.Module):
+    """Dense (NA,T) penalties, zero where no collision point exists (reference :240-295)."""
+
+    def __init__(self, veh_att, mapixes, map_env, T):
+        super(EnvCollLoss, self).__init__()
+        self.inner = _opt.EnvCollLoss(veh_att, mapixes, map_env)
+        self.T = T
+
+    def forward(self, traj):
+        NA = traj.size(0)
+        assert traj.size(1) == self.T
+        pen, valid = self.inner.valid_penalties(traj)
+        return torch.where(valid, pen, torch.zeros_like(pen)).view(NA, self.T)
+
+
+class TrafficModelLoss(nn.Module):
+    """(reference :20-118)"""
+
+    def __init__(self, loss_weights, state_normalizer=None, att_normalizer=None):
+        super(TrafficModelLoss, self).__init__()
+        self.loss_weights = loss_weights
+        self.state_normalizer = state_normalizer
+        self.att_normalizer = att_normalizer
+
+    def forward(self, scene_graph, pred, map_idx=None, map_env=None):
+        w = self.loss_weights
+        vis = scene_graph.future_vis == 1.0
+        gt = scene_graph.future_gt[vis]
+        pf = pred['future_pred'][vis]
+        recon = -log_normal(pf, gt[:, :4], torch.ones_like(pf))
+        pm, pv = pred['prior_out']
+        qm, qv = pred['posterior_out']
+        kl = kl_normal(qm, qv, pm, pv)
+        loss = w['recon'] * recon.mean() + w['kl'] * kl.mean()
+        out = {'recon_loss': recon, 'kl_loss': kl}
+        if w['coll_veh_prior'] > 0.0 and 'future_samp' in pred:
+            vl = VehCollLoss(self.att_normalizer.unnormalize(scene_graph.lw), scene_graph.batch, scene_graph.ptr)
+            pens, npairs = vl(self.state_normalizer.unnormalize(pred['future_samp']))
+            cv = torch.sum(pens) / npairs
+            loss = loss + w['coll_veh_prior'] * cv
+            out['coll_veh_prior'] = cv.view((1,))
+        if w['coll_env_prior'] > 0.0 and 'future_samp' in pred:
+            assert map_idx is not None and map_env is not None
+            ego = scene_graph.ptr[:-1].to(scene_graph.lw.device)
+            el = EnvCollLoss(self.att_normalizer.unnormalize(scene_graph.lw[ego]), map_idx, map_env,
+                             pred['future_pred'].size(1))
+            ce = el(self.state_normalizer.unnormalize(pred['future_samp'][ego]))
+            loss = loss + w['coll_env_prior'] * ce.mean()
+            out['coll_env_prior'] = ce.view(-1)
+        out['loss'] = loss.view((1,))
+        return out

@@ -1,3 +1,415 @@
-"""placeholder -- filled in below"""
-def mlp_forward(*a, **k): raise NotImplementedError
-def gnn_forward(*a, **k): raise NotImplementedError
+"""Operator layer: torch tensors in, libstrive_hip.so calls, torch tensors out.
+
+Everything here requires ROCm device tensors and the hipcc-built library; a CPU tensor or a missing
+library raises ``StriveHipError`` -- there is deliberately no CPU code path (the CPU restatement of
+the algorithm lives in ``oracle/`` and is test infrastructure only).  PyTorch is used for device
+memory, streams and as the autograd host: the decoder rollout and the vehicle-collision penalty are
+``torch.autograd.Function``s whose forward/backward are single C-ABI calls.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import params
+from ._lib import StriveHipError
+
+__all__ = ['mlp_forward', 'gnn_forward', 'encode_map', 'encode_traj', 'decoder_rollout', 'map_crop', 'coll_point',
+           'veh_coll_penalties', 'scene_info', 'transform2frame']
+
+
+# ------------------------------------------------------------------------------------------------
+# plumbing
+# ------------------------------------------------------------------------------------------------
+
+def _lib_for(*tensors):
+    """The product rule: HIP or nothing."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise StriveHipError('strive_amd operators run on the MI355X through libstrive_hip.so and need ROCm '
+                                 'device tensors; got a %s tensor (no CPU fallback exists -- the CPU restatement '
+                                 'in oracle/ is test infrastructure)' % t.device)
+    return L.get_lib()
+
+
+def _stream(t):
+    return L.stream_ptr(t)
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+_ws_cache = {}
+
+
+def _workspace(device, nbytes, tag='ws'):
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _param_signature(module):
+    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+
+
+def _cached_pack(owner, key, module_for_sig, builder):
+    """Re-pack only when a parameter changed (in-place updates bump ``_version``) or moved."""
+    cache = owner.__dict__.setdefault('_strive_packs', {})
+    sig = _param_signature(module_for_sig)
+    ent = cache.get(key)
+    if ent is None or ent[0] != sig:
+        ent = (sig, builder())
+        cache[key] = ent
+    return ent[1]
+
+
+def _sd_of(module, prefix):
+    return {prefix + '.' + k: v for k, v in module.state_dict().items()}
+
+
+# ------------------------------------------------------------------------------------------------
+# scene structure
+# ------------------------------------------------------------------------------------------------
+
+class SceneInfo(object):
+    def __init__(self, ptr, device):
+        self.ptr = ptr.to(device)
+        self.sizes = (ptr[1:] - ptr[:-1]).cpu()
+        self.B = int(self.sizes.shape[0])
+        self.NA = int(ptr[-1])
+        self.device = device
+        self._packs = {}
+        sz = self.sizes.to(torch.long)
+        self.pair_off = torch.zeros((self.NA,), dtype=torch.int32)
+        if self.NA > 0:
+            per_agent = torch.repeat_interleave(sz, sz)
+            self.pair_off[1:] = torch.cumsum(per_agent, 0)[:-1].to(torch.int32)
+        self.P = int((sz * sz).sum())
+        self.pair_off = self.pair_off.to(device)
+
+    def pack(self, NS):
+        p = self._packs.get(NS)
+        if p is None:
+            p = params.pack_scenes(self.ptr.cpu(), NS, self.device)
+            self._packs[NS] = p
+        return p
+
+
+def _expected_clique_keys(ptr_cpu, NA):
+    keys = []
+    for b in range(ptr_cpu.shape[0] - 1):
+        lo, hi = int(ptr_cpu[b]), int(ptr_cpu[b + 1])
+        n = hi - lo
+        if n <= 1:
+            continue
+        src = torch.arange(lo, hi).view(n, 1).expand(n, n)
+        dst = torch.arange(lo, hi).view(1, n).expand(n, n)
+        keep = src != dst
+        keys.append(src[keep] * NA + dst[keep])
+    return torch.cat(keys) if keys else torch.zeros((0,), dtype=torch.long)
+
+
+def scene_info(scene_graph):
+    """Scene offsets of a batched graph; verifies once that ``edge_index`` is the per-scene clique the
+    kernels assume (reference src/datasets/nuscenes_dataset.py:678-687 always builds exactly that)."""
+    ptr = scene_graph.ptr
+    cached = scene_graph.__dict__.get('_strive_scene_info')
+    if cached is not None and cached.NA == int(ptr[-1]) and cached.B == ptr.shape[0] - 1 and \
+            cached.device == scene_graph.past.device:
+        return cached
+    info = SceneInfo(ptr.cpu(), scene_graph.past.device)
+    if 'edge_index' in scene_graph:
+        ei = scene_graph.edge_index.cpu()
+        exp = _expected_clique_keys(ptr.cpu(), info.NA)
+        got = ei[0] * info.NA + ei[1]
+        if got.shape[0] != exp.shape[0] or not torch.equal(torch.sort(got)[0], torch.sort(exp)[0]):
+            raise NotImplementedError('strive_amd message passing requires per-scene fully connected graphs without '
+                                      'self loops (what the reference dataset builds); got a different edge_index')
+    scene_graph.__dict__['_strive_scene_info'] = info
+    return info
+
+
+# ------------------------------------------------------------------------------------------------
+# small differentiable glue (plain torch; used outside the fused kernels)
+# ------------------------------------------------------------------------------------------------
+
+def transform2frame(frame, poses, inverse=False):
+    """reference src/utils/transforms.py:78-139 for 4-d poses (x,y,hx,hy); plain torch glue."""
+    c = frame[:, 2].unsqueeze(1)
+    s = frame[:, 3].unsqueeze(1)
+    fx = frame[:, 0].unsqueeze(1)
+    fy = frame[:, 1].unsqueeze(1)
+    px, py, pc, ps = poses[..., 0], poses[..., 1], poses[..., 2], poses[..., 3]
+    if inverse:
+        out = [(c * px - s * py) + fx, (s * px + c * py) + fy, pc * c - ps * s, ps * c + pc * s]
+    else:
+        dx, dy = px - fx, py - fy
+        out = [c * dx + s * dy, -s * dx + c * dy, pc * c + ps * s, ps * c - pc * s]
+    return torch.stack(out, dim=-1)
+
+
+# ------------------------------------------------------------------------------------------------
+# MLP / GNN forward (embed-time networks; no gradient)
+# ------------------------------------------------------------------------------------------------
+
+def _no_grad_inputs(what, *tensors):
+    if torch.is_grad_enabled():
+        for t in tensors:
+            if t is not None and t.requires_grad:
+                raise NotImplementedError('%s: the HIP path provides d/dz of the decoder rollout only; gradients '
+                                          'w.r.t. this input are not implemented' % what)
+
+
+def mlp_forward(mlp_module, x):
+    lib = _lib_for(x)
+    _no_grad_inputs('MLP.forward', x)
+    pk = _cached_pack(mlp_module, 'mlp', mlp_module, lambda: params.pack_mlp(_sd_of(mlp_module, 'm'), 'm'))
+    shp = x.shape
+    x2 = _f32c(x).reshape(-1, shp[-1])
+    O = pk.struct.dims[pk.struct.nlayers]
+    y = torch.empty((x2.shape[0], O), dtype=torch.float32, device=x.device)
+    lib.call('strive_mlp_fwd', pk.ref(), L.ptr(x2), x2.shape[0], L.ptr(y), _stream(x))
+    return y.reshape(tuple(shp[:-1]) + (O,))
+
+
+def gnn_forward(net, scene_graph):
+    x, pos, sem = scene_graph.x, scene_graph.pos, scene_graph.sem
+    lib = _lib_for(x, pos, sem)
+    _no_grad_inputs('SceneInteractionNet.forward', x, pos)
+    info = scene_info(scene_graph)
+    multi = x.dim() == 3
+    NS = x.shape[1] if multi else 1
+    NC = sem.shape[1]
+    pk = _cached_pack(net, 'gnn', net, lambda: params.pack_gnn(_sd_of(net, 'g'), 'g', NC))
+    sc = info.pack(NS)
+    R = info.NA * NS
+    x2 = _f32c(x).reshape(R, -1)
+    p2 = _f32c(pos).reshape(R, 4)
+    O = pk.struct.mlp_out.dims[pk.struct.mlp_out.nlayers]
+    out = torch.empty((R, O), dtype=torch.float32, device=x.device)
+    wsb = lib.query('strive_gnn_workspace_bytes', pk.ref(), sc.ref())
+    ws = _workspace(x.device, wsb)
+    lib.call('strive_gnn_fwd', pk.ref(), sc.ref(), L.ptr(x2), L.ptr(p2), L.ptr(_f32c(sem)), L.ptr(out), L.ptr(ws),
+             ws.numel(), _stream(x))
+    return out.reshape(info.NA, NS, O) if multi else out
+
+
+# ------------------------------------------------------------------------------------------------
+# map
+# ------------------------------------------------------------------------------------------------
+
+def _map_pack(map_env, device):
+    cache = map_env.__dict__.setdefault('_strive_map_packs', {})
+    key = (str(device), map_env.nusc_raster.data_ptr(), tuple(map_env.bounds), map_env.L, map_env.W)
+    pk = cache.get(key)
+    if pk is None:
+        pk = params.pack_map(map_env, device)
+        cache.clear()
+        cache[key] = pk
+    return pk
+
+
+def map_crop(map_env, frames, mapixes, pos_mean=(0, 0, 0, 0), pos_std=(1, 1, 1, 1), bounds=None, L_=None, W_=None):
+    """uint8 crop (N,C,L,W) around frames (N,4); get_map_obs semantics, bit-exact."""
+    lib = _lib_for(frames)
+    if bounds is not None or L_ is not None or W_ is not None:
+        env = _OverrideEnv(map_env, bounds, L_, W_)
+    else:
+        env = map_env
+    pk = _map_pack(env, frames.device)
+    N = frames.shape[0]
+    out = torch.empty((N, pk.struct.C, pk.struct.L, pk.struct.Wc), dtype=torch.uint8, device=frames.device)
+    lib.call('strive_map_crop_u8', pk.ref(), L.ptr(_f32c(frames)), L.f4(pos_mean), L.f4(pos_std),
+             L.ptr(mapixes.to(torch.int32).contiguous()), N, L.ptr(out), _stream(frames))
+    return out
+
+
+class _OverrideEnv(object):
+    def __init__(self, env, bounds, L_, W_):
+        self.nusc_raster, self.nusc_dx = env.nusc_raster, env.nusc_dx
+        self.bounds = list(env.bounds if bounds is None else bounds)
+        self.L = env.L if L_ is None else L_
+        self.W = env.W if W_ is None else W_
+
+
+def encode_map(model, pos, batch_of_agent, map_idx, map_env):
+    """Map feature at NORMALISED ``pos`` (NA,4)/(NA,NS,4) -> (NA,[NS,]64): fused crop + CNN, no gradient."""
+    lib = _lib_for(pos)
+    multi = pos.dim() == 3
+    NA = pos.shape[0]
+    NS = pos.shape[1] if multi else 1
+    dev = pos.device
+    mp = _map_pack(map_env, dev)
+    cnn = _cached_pack(model, 'cnn', model.map_conv, lambda: params.pack_cnn(model.state_dict()))
+    mapix = map_idx.to(dev)[batch_of_agent.to(dev)].to(torch.int32)
+    if multi:
+        mapix = mapix.view(NA, 1).expand(NA, NS).reshape(-1)
+    mapix = mapix.contiguous()
+    p2 = _f32c(pos).reshape(NA * NS, 4)
+    feat = torch.empty((NA * NS, 64), dtype=torch.float32, device=dev)
+    wsb = lib.query('strive_map_cnn_workspace_bytes', NA * NS)
+    ws = _workspace(dev, wsb, 'cnn')
+    nm = model.normalizer
+    lib.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(p2), L.f4(nm.mean_vals[:4].tolist()),
+             L.f4(nm.std_vals[:4].tolist()), L.ptr(mapix), NA * NS, L.ptr(feat), L.ptr(ws), ws.numel(), _stream(pos))
+    return feat.reshape(NA, NS, 64) if multi else feat
+
+
+def encode_traj(model, encoder, g, traj, vis):
+    """Past / future trajectory encoder input assembly (torch glue) + HIP MLP.
+    (reference src/models/traffic_model.py:453-523)"""
+    NA, T, _ = traj.shape
+    local = transform2frame(g.past[:, -1, :4], traj[:, :, :4])
+    local = torch.cat([local, traj[:, :, 4:]], dim=2)
+    local = torch.where((vis == 0.0).unsqueeze(-1), torch.zeros_like(local), local)
+    local = torch.cat([local, vis.unsqueeze(-1)], dim=-1)
+    att = g.lw.unsqueeze(1).expand(NA, T, 2)
+    enc_in = torch.cat([torch.cat([local, att], dim=-1).reshape(NA, -1), g.sem], dim=1)
+    return encoder(enc_in.detach())
+
+
+def coll_point(map_env, cars, lw, mapixes, gl, gw):
+    """get_coll_point on layer 0: (N,2) collision points (NaN = none / fully off) and off-pixel counts."""
+    lib = _lib_for(cars)
+    dev = cars.device
+    pk = _map_pack(map_env, dev)
+    N = cars.shape[0]
+    pt = torch.empty((N, 2), dtype=torch.float32, device=dev)
+    cnt = torch.empty((N,), dtype=torch.int32, device=dev)
+    lin_l = torch.linspace(-1.0, 1.0, gl).to(dev)
+    lin_w = torch.linspace(-1.0, 1.0, gw).to(dev)
+    lib.call('strive_coll_point', pk.ref(), L.ptr(_f32c(cars)), L.ptr(_f32c(lw)), L.ptr(mapixes.to(torch.int32).contiguous()),
+             N, int(gl), int(gw), L.ptr(lin_l), L.ptr(lin_w), L.ptr(pt), L.ptr(cnt), _stream(cars))
+    return pt, cnt
+
+
+# ------------------------------------------------------------------------------------------------
+# decoder rollout
+# ------------------------------------------------------------------------------------------------
+
+class _RolloutCtx(object):
+    pass
+
+
+class _RolloutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, h):
+        lib = h.lib
+        dev = z.device
+        zz = _f32c(z).reshape(h.R, 32)
+        traj = torch.empty((h.R, h.FT, 4), dtype=torch.float32, device=dev)
+        tape = torch.empty(h.tape_bytes, dtype=torch.uint8, device=dev)
+        ws = _workspace(dev, h.ws_bytes, 'rollout')
+        lib.call('strive_rollout_fwd', h.dec.ref(), h.sc.ref(), L.ptr(h.past_last), L.ptr(h.lw), L.ptr(h.sem),
+                 L.ptr(h.past_feat), L.ptr(h.map_feat), L.ptr(zz), L.ptr(h.mapix), L.ptr(h.ext), h.FT, L.ptr(traj),
+                 L.ptr(tape), tape.numel(), L.ptr(ws), ws.numel(), _stream(z))
+        ctx.h = h
+        ctx.tape = tape
+        ctx.zz = zz
+        ctx.zshape = z.shape
+        return traj
+
+    @staticmethod
+    def backward(ctx, d_traj):
+        h = ctx.h
+        dev = d_traj.device
+        dz = torch.empty((h.R, 32), dtype=torch.float32, device=dev)
+        ws = _workspace(dev, h.ws_bytes, 'rollout')
+        h.lib.call('strive_rollout_bwd', h.dec.ref(), h.sc.ref(), L.ptr(h.lw), L.ptr(h.sem), L.ptr(ctx.zz), L.ptr(h.ext),
+                   h.FT, L.ptr(_f32c(d_traj)), L.ptr(dz), L.ptr(ctx.tape), ctx.tape.numel(), L.ptr(ws), ws.numel(),
+                   _stream(d_traj))
+        return dz.reshape(ctx.zshape), None
+
+
+def decoder_rollout(model, g, map_feat, past_feat, z, map_idx, map_env, ext_future, FT):
+    """autoregressive_decoder as one fused call; differentiable w.r.t. ``z`` only."""
+    lib = _lib_for(z, map_feat, past_feat, g.past)
+    if model.normalizer is None or model.att_normalizer is None or model.bicycle_params is None:
+        raise RuntimeError('set_normalizer / set_att_normalizer / set_bicycle_params must be called before decoding')
+    _no_grad_inputs('decoder', map_feat, past_feat, ext_future)
+    dev = z.device
+    info = scene_info(g)
+    multi = z.dim() == 3
+    NS = z.shape[1] if multi else 1
+    if ext_future is not None and multi:
+        raise NotImplementedError('ext_future together with multiple samples (the reference crashes there too)')
+    NC = g.sem.shape[1]
+
+    def build():
+        return params.pack_decoder(model.state_dict(), NC, map_env, dev, model.normalizer, model.att_normalizer,
+                                   model.bicycle_params)
+    key = ('dec', str(dev), map_env.nusc_raster.data_ptr(), id(model.normalizer), id(model.att_normalizer))
+    h = _RolloutCtx()
+    h.lib = lib
+    h.dec = _cached_pack(model, key, model, build)
+    h.sc = info.pack(NS)
+    h.R = info.NA * NS
+    h.FT = int(FT)
+    h.past_last = _f32c(g.past[:, -1, :])
+    h.lw = _f32c(g.lw)
+    h.sem = _f32c(g.sem)
+    h.past_feat = _f32c(past_feat)
+    h.map_feat = _f32c(map_feat)
+    h.mapix = map_idx.to(dev)[g.batch.to(dev)].to(torch.int32).contiguous()
+    h.ext = None if ext_future is None else _f32c(ext_future)
+    if h.ext is not None and tuple(h.ext.shape) != (info.B, h.FT, 4):
+        raise ValueError('ext_future must be (B, FT, 4), got %s' % (tuple(h.ext.shape),))
+    h.tape_bytes = lib.query('strive_rollout_tape_bytes', h.dec.ref(), h.sc.ref(), h.FT)
+    h.ws_bytes = lib.query('strive_rollout_workspace_bytes', h.dec.ref(), h.sc.ref(), h.FT)
+    traj = _RolloutFn.apply(z, h)
+    return traj.reshape(info.NA, NS, h.FT, 4) if multi else traj.reshape(info.NA, h.FT, 4)
+
+
+# ------------------------------------------------------------------------------------------------
+# vehicle collision penalties
+# ------------------------------------------------------------------------------------------------
+
+class _VehCollFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, traj, h):
+        lib = h.lib
+        dev = traj.device
+        tr = _f32c(traj)
+        NA, T, _ = tr.shape
+        pen = torch.empty((T, h.P), dtype=torch.float32, device=dev)
+        hit = torch.empty((T, h.P), dtype=torch.uint8, device=dev)
+        amin = torch.empty((T, h.P), dtype=torch.uint8, device=dev)
+        lib.call('strive_veh_coll_fwd', h.sc.ref(), L.ptr(h.pair_off), h.P, L.ptr(tr), T, L.ptr(h.cent_x), L.ptr(h.rad),
+                 C.c_float(h.buffer), L.ptr(pen), L.ptr(hit), L.ptr(amin), _stream(traj))
+        ctx.h = h
+        ctx.save_for_backward(tr, amin)
+        ctx.mark_non_differentiable(hit)
+        return pen, hit
+
+    @staticmethod
+    def backward(ctx, d_pen, _d_hit):
+        h = ctx.h
+        tr, amin = ctx.saved_tensors
+        NA, T, _ = tr.shape
+        d_traj = torch.zeros_like(tr)
+        h.lib.call('strive_veh_coll_bwd', h.sc.ref(), L.ptr(h.pair_off), h.P, L.ptr(tr), T, L.ptr(h.cent_x), L.ptr(h.rad),
+                   C.c_float(h.buffer), L.ptr(_f32c(d_pen)), L.ptr(amin), L.ptr(d_traj), _stream(tr))
+        return d_traj, None
+
+
+class VehCollSetup(object):
+    """Per-batch constants of the circle-approximation penalty."""
+
+    def __init__(self, info, cent_x, rad, buffer):
+        self.lib = _lib_for(cent_x)
+        self.sc = info.pack(1)
+        self.pair_off = info.pair_off
+        self.P = info.P
+        self.cent_x = _f32c(cent_x)
+        self.rad = _f32c(rad)
+        self.buffer = float(buffer)
+
+
+def veh_coll_penalties(traj, setup):
+    """(pen (T,P) differentiable w.r.t. traj, hit (T,P) uint8) over in-scene ordered pairs."""
+    _lib_for(traj)
+    return _VehCollFn.apply(traj[:, :, :4], setup)

@@ -1,0 +1,495 @@
+"""Parity of the HIP product (through the C ABI, via strive_amd's Python mirror of the reference API) against
+the CPU oracle and the committed golden vectors.  Runs on the MI355X box only (-m gpu).
+
+Tolerance policy (normalised units, fp32):
+  * integer / byte outputs (map crops, collision masks, arg-max agents): exact;
+  * single operators and smooth compositions (MLP, GNN, CNN on identical crops, rollouts over a uniform
+    raster, losses on identical trajectories): rtol 1e-4 / atol 2e-5, gradients rtol 1e-3;
+  * full rollouts over a textured raster: the reference algorithm re-samples the raster at every step at
+    poses that depend on the previous step's features; a 1e-7 pose difference can flip a crop pixel and move
+    a map feature by ~4e-3 (measured reference-vs-restatement on CPU).  Those are compared at atol 1e-2 and
+    5 % of gradient scale, and the smooth/discrete parts are pinned separately (tight) by the tests above.
+"""
+import numpy as np
+import pytest
+import torch
+
+import make_golden as mg
+from util import golden, oracle_model, product_model, assert_close
+from test_oracle_golden import check_loop_trace
+from strive_amd import synth, ops
+from strive_amd.constants import NUSC_BIKE_PARAMS
+from oracle import mapenv, losses as olosses, loops as oloops
+from oracle import model as om
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+RT, AT = 1e-4, 2e-5
+
+
+@pytest.fixture(scope='module')
+def model():
+    assert torch.cuda.is_available(), 'gpu tests need the MI355X'
+    m, sd = product_model(device=DEV)
+    return m, sd
+
+
+def dev_env(raster, dx):
+    return synth.SyntheticMapEnv(raster.clone(), dx.clone()).to(DEV)
+
+
+def uniform_env(H=1024):
+    raster = torch.zeros((1, 4, H, H), dtype=torch.uint8)
+    raster[:, 0] = 1
+    dx = torch.tensor([[0.25, 0.25]], dtype=torch.float64)
+    return raster, dx
+
+
+def test_library_is_the_hip_build():
+    from strive_amd import _lib
+    lib = _lib.get_lib()
+    assert lib.path.endswith('strive_amd/libstrive_hip.so') and not lib.missing
+    assert 'gfx950' in torch.cuda.get_device_properties(0).gcnArchName
+
+
+def test_cpu_tensors_are_rejected(model):
+    m, _ = model
+    with pytest.raises(Exception):
+        m.past_encoder(torch.zeros((4, 38)))
+
+
+# ------------------------------------------------------------------------------------------------
+# raster lookups
+# ------------------------------------------------------------------------------------------------
+
+def test_crop_bit_exact():
+    g = golden('g2_crop.npz')
+    raster, dx, frame, mapixes, lw = mg.g2_inputs()
+    env = dev_env(raster, dx)
+    crop = ops.map_crop(env, frame.to(DEV), mapixes.to(DEV)).cpu()
+    ref = mapenv.map_crop(raster, dx, frame, mapixes, env.bounds)
+    assert torch.equal(crop, ref)
+    for i in (0, 1, 7):
+        assert np.array_equal(np.packbits(crop[i].numpy()), g['crop_full_%d' % i])
+    # larger random set incl. normalised inputs
+    n = 96
+    fr = np.zeros((n, 4))
+    fr[:, 0] = synth.counter_uniform((n,), 'gp/x', -10.0, 270.0)
+    fr[:, 1] = synth.counter_uniform((n,), 'gp/y', -10.0, 270.0)
+    ang = synth.counter_uniform((n,), 'gp/h', -np.pi, np.pi)
+    fr[:, 2], fr[:, 3] = np.cos(ang), np.sin(ang)
+    fr = synth.f32(fr)
+    mi = torch.tensor([i % 2 for i in range(n)])
+    crop = ops.map_crop(env, (fr / torch.tensor([15., 15., 1., 1.])).to(DEV), mi.to(DEV), pos_mean=(0, 0, 0, 0),
+                        pos_std=(15, 15, 1, 1)).cpu()
+    ref = mapenv.map_crop(raster, dx, (fr / torch.tensor([15., 15., 1., 1.])) * torch.tensor([15., 15., 1., 1.]), mi, env.bounds)
+    assert torch.equal(crop, ref)
+
+
+def test_coll_point():
+    g = golden('g2_crop.npz')
+    raster, dx, frame, mapixes, lw = mg.g2_inputs()
+    env = dev_env(raster, dx)
+    ok = ~torch.isnan(frame[:, 0])
+    gl, gw = mapenv.coll_grid_size(dx, lw[ok])
+    pt, cnt = ops.coll_point(env, frame[ok].to(DEV), lw[ok].to(DEV), mapixes[ok].to(DEV), gl, gw)
+    np.testing.assert_allclose(pt.cpu().numpy(), g['coll_pt'], rtol=0, atol=1e-3, equal_nan=True)
+    frac = cnt.cpu().float() / (gl * gw)
+    want = np.nan_to_num(g['coll_frac'], nan=-1.0)
+    got = np.where((frac.numpy() == 0) | (frac.numpy() == 1), -1.0, frac.numpy())
+    np.testing.assert_allclose(got, want, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# networks
+# ------------------------------------------------------------------------------------------------
+
+def test_mlp_and_gnn_golden(model):
+    m, sd = model
+    g1, g3 = golden('g1_ops.npz'), golden('g3_gnn.npz')
+    x = synth.f32(synth.counter_uniform((6, 38), 'g1/mlp_in', -1.0, 1.0)).to(DEV)
+    with torch.no_grad():
+        assert_close(m.past_encoder(x), g1['mlp_past_encoder'], RT, AT, 'mlp')
+    batch, map_idx, raster, dx = mg.build_inputs(mg.G3_SIZES, 'g3')
+    batch = batch.to(DEV)
+    NA = batch.past.shape[0]
+    for name, net, fin in (('decoder', m.decoder_net, 164), ('prior', m.prior_net, 130), ('posterior', m.posterior_net, 194)):
+        batch.x = synth.f32(synth.counter_uniform((NA, fin), 'g3/x/' + name, -1.0, 1.0)).to(DEV)
+        pos = batch.past[:, -1, :4].clone()
+        if name == 'prior':
+            pos[1, 0] = float('nan')
+        batch.pos = pos
+        with torch.no_grad():
+            assert_close(net(batch), g3[name + '_out'], RT, AT, name)
+    batch.x = synth.f32(synth.counter_uniform((NA, 2, 164), 'g3/x/ns', -1.0, 1.0)).to(DEV)
+    batch.pos = (batch.past[:, -1, :4].unsqueeze(1).expand(NA, 2, 4)
+                 + 0.01 * synth.f32(synth.counter_uniform((NA, 2, 4), 'g3/p/ns', -1, 1)).to(DEV)).contiguous()
+    with torch.no_grad():
+        assert_close(m.decoder_net(batch), g3['decoder_ns_out'], RT, AT, 'gnn ns')
+
+
+def test_gnn_large_scene(model):
+    """67 agents in one scene (several source chunks per target) + a 1-agent scene, vs the oracle."""
+    m, sd = model
+    batch, map_idx = synth.make_batch([67, 1, 19], key='gp/big')
+    NA = batch.past.shape[0]
+    x = synth.f32(synth.counter_uniform((NA, 164), 'gp/bigx', -1.0, 1.0))
+    pos = batch.past[:, -1, :4].clone()
+    want = om.interaction_net(sd, 'decoder_net', x, pos, batch.sem, batch.edge_index)
+    b = batch.to(DEV)
+    b.x, b.pos = x.to(DEV), pos.to(DEV)
+    with torch.no_grad():
+        assert_close(m.decoder_net(b), want, RT, AT, 'gnn big')
+
+
+def test_map_cnn_vs_oracle(model):
+    m, sd = model
+    raster, dx, frame, mapixes, lw = mg.g2_inputs()
+    env = dev_env(raster, dx)
+    n = 40
+    fr = np.zeros((n, 4))
+    fr[:, 0] = synth.counter_uniform((n,), 'gc/x', 20.0, 236.0)
+    fr[:, 1] = synth.counter_uniform((n,), 'gc/y', 20.0, 236.0)
+    ang = synth.counter_uniform((n,), 'gc/h', -np.pi, np.pi)
+    fr[:, 2], fr[:, 3] = np.cos(ang), np.sin(ang)
+    fr = synth.f32(fr)
+    pos_n = fr / torch.tensor([15., 15., 1., 1.])
+    mi = torch.tensor([i % 2 for i in range(n)])
+    crop = mapenv.map_crop(raster, dx, pos_n * torch.tensor([15., 15., 1., 1.]), mi, env.bounds)
+    want = om.map_cnn(sd, crop.float())
+    got = ops.encode_map(m, pos_n.to(DEV), torch.arange(n).to(DEV), mi.to(DEV), env)
+    assert_close(got, want, RT, AT, 'map cnn')
+    got2 = ops.encode_map(m, pos_n.to(DEV), torch.arange(n).to(DEV), mi.to(DEV), env)
+    assert torch.equal(got, got2), 'CNN must be bitwise reproducible'
+
+
+def test_embed_golden(model):
+    m, sd = model
+    g = golden('g4_rollout.npz')
+    batch, map_idx, raster, dx = mg.build_inputs(mg.G4_SIZES, 'g4')
+    env = dev_env(raster, dx)
+    with torch.no_grad():
+        emb = m.embed(batch.to(DEV), map_idx.to(DEV), env)
+    assert_close(emb['map_feat'], g['map_feat'], RT, AT, 'map_feat')
+    assert_close(emb['past_feat'], g['past_feat'], RT, AT, 'past_feat')
+    assert_close(emb['prior_out'][0], g['prior_mu'], RT, AT, 'prior mu')
+    assert_close(emb['prior_out'][1], g['prior_var'], RT, 1e-4, 'prior var')
+    assert_close(emb['posterior_out'][0], g['post_mu'], RT, AT, 'post mu')
+    assert_close(emb['posterior_out'][1], g['post_var'], RT, 1e-4, 'post var')
+
+
+# ------------------------------------------------------------------------------------------------
+# rollout
+# ------------------------------------------------------------------------------------------------
+
+def _rollout_pair(m, sd, sizes, key, raster, dx, FT, NS=1, ext=False, NC=2):
+    batch, map_idx = synth.make_batch(sizes, key=key, FT=max(FT, 12), NC=NC)
+    env_c = synth.SyntheticMapEnv(raster, dx)
+    orc = oracle_model(sd, NC=NC)
+    with torch.no_grad():
+        emb = orc.embed(batch, map_idx, env_c)
+    z = synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key=key + '/z')
+    if NS > 1:
+        z = torch.stack([z] + [synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='%s/z%d' % (key, i))
+                               for i in range(1, NS)], dim=1)
+    extf = batch.future_gt[batch.ptr[:-1]][:, :FT, :4].contiguous() if ext else None
+    zc = z.clone().requires_grad_(True)
+    pred_c = orc.decode_embedding(zc, emb, batch, map_idx, env_c, ext_future=extf, nfuture=FT)['future_pred']
+    rw = synth.f32(synth.counter_uniform(tuple(pred_c.shape), key + '/rw', -1.0, 1.0))
+    gz_c, = torch.autograd.grad((pred_c * rw).sum(), [zc])
+    env_g = dev_env(raster, dx)
+    bg = batch.clone().to(DEV)
+    emb_g = {'map_feat': emb['map_feat'].to(DEV), 'past_feat': emb['past_feat'].to(DEV)}
+    zg = z.clone().to(DEV).requires_grad_(True)
+    pred_g = m.decode_embedding(zg, emb_g, bg, map_idx.to(DEV), env_g, ext_future=None if extf is None else extf.to(DEV),
+                                nfuture=FT)['future_pred']
+    (pred_g * rw.to(DEV)).sum().backward()
+    return pred_c.detach(), gz_c, pred_g.detach().cpu(), zg.grad.cpu()
+
+
+@pytest.mark.parametrize('sizes,FT,NS,ext', [([1, 2, 5, 16], 12, 1, False), ([3, 9], 16, 1, False), ([4, 1, 7], 12, 1, True),
+                                             ([3, 6], 12, 2, False), ([33], 6, 1, False)])
+def test_rollout_smooth_map_tight(model, sizes, FT, NS, ext):
+    """Uniform raster: the crop does not depend on the pose, so the whole FT-step chain (GNN, bicycle, GRU,
+    CNN, and the reverse sweep) is smooth and must agree tightly."""
+    m, sd = model
+    raster, dx = uniform_env()
+    pc, gc, pg, gg = _rollout_pair(m, sd, sizes, 'gr/%d_%d_%d' % (len(sizes), FT, NS), raster, dx, FT, NS=NS, ext=ext)
+    assert_close(pg, pc, RT, AT, 'future_pred')
+    assert_close(gg, gc, 2e-3, 1e-6 + 1e-4 * float(gc.abs().max()), 'dL/dz')
+
+
+def test_rollout_two_steps_textured(model):
+    """FT=2 over the textured raster: one re-sampling of the map at step-0 poses."""
+    m, sd = model
+    raster, dx = synth.make_raster(mg.RASTER_HW, mg.RASTER_HW)
+    pc, gc, pg, gg = _rollout_pair(m, sd, [3, 5, 1], 'gr/tex2', raster, dx, 2)
+    assert_close(pg, pc, 1e-3, 1e-3, 'future_pred (textured, 2 steps)')
+    assert_close(gg, gc, 5e-2, 5e-2 * float(gc.abs().max()), 'dL/dz (textured, 2 steps)')
+
+
+@pytest.mark.parametrize('case', ['ft12', 'ft16', 'ext', 'ns'])
+def test_rollout_golden_textured(model, case):
+    m, sd = model
+    g = golden('g4_rollout.npz')
+    batch, map_idx, raster, dx = mg.build_inputs(mg.G4_SIZES, 'g4')
+    env = dev_env(raster, dx)
+    bg = batch.clone().to(DEV)
+    emb = {'map_feat': torch.from_numpy(g['map_feat']).to(DEV), 'past_feat': torch.from_numpy(g['past_feat']).to(DEV)}
+    pmu, pvar = torch.from_numpy(g['prior_mu']), torch.from_numpy(g['prior_var'])
+    z = synth.make_latents(pmu, pvar, key='g4/z')
+    kw = {}
+    if case == 'ft12':
+        pk, gk, rk, kw = 'pred_ft12', 'gz_ft12', 'g4/r12', {'nfuture': 12}
+    elif case == 'ft16':
+        pk, gk, rk, kw = 'pred_ft16', 'gz_ft16', 'g4/r16', {'nfuture': 16}
+    elif case == 'ext':
+        pk, gk, rk = 'pred_ext', 'gz_ext', 'g4/rext'
+        kw = {'ext_future': bg.future_gt[bg.ptr[:-1].to(DEV)][:, :, :4].contiguous()}
+    else:
+        pk, gk, rk = 'pred_ns', 'gz_ns', 'g4/rns'
+        z = torch.stack([z, synth.make_latents(pmu, pvar, key='g4/z_b')], dim=1)
+    zg = z.to(DEV).requires_grad_(True)
+    pred = m.decode_embedding(zg, emb, bg, map_idx.to(DEV), env, **kw)['future_pred']
+    rw = synth.f32(synth.counter_uniform(tuple(pred.shape), rk, -1.0, 1.0)).to(DEV)
+    (pred * rw).sum().backward()
+    assert_close(pred, g[pk], 0, 1e-2, pk)
+    assert_close(zg.grad, g[gk], 0, 5e-2 * float(np.abs(g[gk]).max()), gk)
+
+
+# ------------------------------------------------------------------------------------------------
+# losses on identical trajectories
+# ------------------------------------------------------------------------------------------------
+
+@pytest.fixture(scope='module')
+def g5(model):
+    m, sd = model
+    g = golden('g5_losses.npz')
+    batch, map_idx, raster, dx = mg.g5_inputs(None, None)
+    env_c = synth.SyntheticMapEnv(raster, dx)
+    env_g = dev_env(raster, dx)
+    orc = oracle_model(sd)
+    with torch.no_grad():
+        emb = orc.embed(batch, map_idx, env_c)
+    NA = batch.past.shape[0]
+    ego = torch.zeros((NA,), dtype=torch.bool)
+    ego[batch.ptr[:-1]] = True
+    return g, batch, map_idx, env_c, env_g, orc, emb, ego
+
+
+def test_veh_coll_fwd_bwd(model, g5):
+    from strive_amd.losses.adv_gen_nusc import VehCollLoss
+    m, sd = model
+    g, batch, map_idx, env_c, env_g, orc, emb, ego = g5
+    unn = orc.get_normalizer().unnormalize
+    veh_att = orc.get_att_normalizer().unnormalize(batch.lw)
+    traj = olosses.interp_traj(unn(torch.from_numpy(g['adv_pred'])), 3)
+    for buf, single in ((0.1, None), (0.5, 0), (0.0, None)):
+        tc = traj.clone().requires_grad_(True)
+        vc = olosses.VehColl(veh_att, ptr=batch.ptr, buffer_dist=buf, single_veh_idx=single)
+        want = vc(tc)
+        want.sum().backward()
+        tg = traj.clone().to(DEV).requires_grad_(True)
+        vg = VehCollLoss(veh_att.to(DEV), buffer_dist=buf, single_veh_idx=single, ptr=batch.ptr)
+        got = vg(tg)
+        got.sum().backward()
+        assert_close(got, want, 1e-4, 1e-5, 'veh pens buf %.1f' % buf)
+        assert_close(tg.grad, tc.grad, 1e-3, 1e-5, 'veh grad buf %.1f' % buf)
+    vg = VehCollLoss(veh_att.to(DEV), buffer_dist=0.1, ptr=batch.ptr)
+    pens, mask = vg(traj.to(DEV), return_raw=True)
+    NA = traj.shape[0]
+    vc = olosses.VehColl(veh_att, ptr=batch.ptr, buffer_dist=0.1)
+    valid = vc.valid_mask.view(1, NA, NA).expand(pens.shape[0], NA, NA)
+    assert_close(pens.cpu()[valid], g['veh_raw_pens_valid'], 1e-3, 1e-4, 'raw pens')
+    assert np.array_equal(mask.cpu()[valid].numpy(), g['veh_raw_mask_valid'])
+    spread = traj.clone()
+    spread[:, :, 0] += 40.0 * torch.arange(NA).view(NA, 1)
+    assert np.array_equal(vg(spread.to(DEV)).cpu().numpy(), g['veh_nocoll'])
+
+
+def test_loss_modules_vs_oracle(model, g5):
+    from strive_amd.losses.adv_gen_nusc import AvoidCollLoss, AdvGenLoss, TgtMatchingLoss
+    from strive_amd.losses.traffic_model import VehCollLoss as TVeh, EnvCollLoss as TEnv
+    m, sd = model
+    g, batch, map_idx, env_c, env_g, orc, emb, ego = g5
+    unn = orc.get_normalizer().unnormalize
+    veh_att = orc.get_att_normalizer().unnormalize(batch.lw)
+    mapixes = map_idx[batch.batch]
+    z = synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='g5/z')
+    prior = emb['prior_out']
+    # AvoidCollLoss on the golden rollout
+    for tag, buf, single in (('avoid02', 0.2, None), ('avoid05s', 0.5, 0)):
+        pred = torch.from_numpy(g['pred_' + tag])
+        zz = z if single is None else z[ego]
+        pr = prior if single is None else (prior[0][ego], prior[1][ego])
+        pc = pred.clone().requires_grad_(True)
+        zc = zz.clone().requires_grad_(True)
+        lc = olosses.AvoidColl(mg.REFINE_WEIGHTS, veh_att, mapixes, env_c, zz.clone() * 0.9, veh_coll_buffer=buf,
+                               single_veh_idx=single, ptr=batch.ptr if single is not None else None)(unn(pc), zc, pr)
+        lc['loss'].backward()
+        pg = pred.clone().to(DEV).requires_grad_(True)
+        zg = zz.clone().to(DEV).requires_grad_(True)
+        lg = AvoidCollLoss(mg.REFINE_WEIGHTS, veh_att.to(DEV), mapixes.to(DEV), env_g, (zz.clone() * 0.9).to(DEV),
+                           veh_coll_buffer=buf, single_veh_idx=single,
+                           ptr=batch.ptr if single is not None else None)(m.get_normalizer().unnormalize(pg), zg,
+                                                                          (pr[0].to(DEV), pr[1].to(DEV)))
+        lg['loss'].backward()
+        assert set(lg.keys()) == set(lc.keys())
+        for k in lc:
+            assert_close(lg[k], lc[k], 2e-3, 2e-3 if 'env' in k else 1e-4, '%s %s' % (tag, k))
+            assert_close(lg[k], g['%s_%s' % (tag, k)], 2e-3, 2e-3 if 'env' in k else 1e-4, '%s %s (golden)' % (tag, k))
+        assert_close(pg.grad, pc.grad, 2e-3, 1e-4 * float(pc.grad.abs().max()), tag + ' d/dpred')
+        assert_close(zg.grad, zc.grad, 1e-3, 1e-6, tag + ' d/dz')
+    # AdvGenLoss
+    pred = torch.from_numpy(g['adv_pred'])
+    planner = batch.future_gt[ego][:, :, :4]
+    other_z = z[~ego]
+    oprior = (prior[0][~ego], prior[1][~ego])
+    for tag, mt, mi, atk in (('adv', 2, 0.0, None), ('adv2', 0, None, torch.tensor([1, 2, 1]) + batch.ptr[:-1])):
+        pc = pred.clone().requires_grad_(True)
+        zc = other_z.clone().requires_grad_(True)
+        lc = olosses.AdvGen(mg.ADV_WEIGHTS, veh_att, mapixes, env_c, other_z.clone() * 0.9, batch.ptr, veh_coll_buffer=0.1,
+                            crash_loss_min_time=mt, crash_loss_min_infront=mi)(unn(pc), unn(planner), zc, oprior,
+                                                                                return_mins=True, attack_agt_idx=atk)
+        lc['loss'].backward()
+        pg = pred.clone().to(DEV).requires_grad_(True)
+        zg = other_z.clone().to(DEV).requires_grad_(True)
+        lf = AdvGenLoss(mg.ADV_WEIGHTS, veh_att.to(DEV), mapixes.to(DEV), env_g, (other_z.clone() * 0.9).to(DEV), batch.ptr,
+                        veh_coll_buffer=0.1, crash_loss_min_time=mt, crash_loss_min_infront=mi)
+        nu = m.get_normalizer().unnormalize
+        lg = lf(nu(pg), nu(planner.to(DEV)), zg, (oprior[0].to(DEV), oprior[1].to(DEV)), return_mins=True,
+                attack_agt_idx=None if atk is None else atk.to(DEV))
+        lg['loss'].backward()
+        assert set(lg.keys()) == set(lc.keys())
+        for k in lc:
+            if k in ('min_agt', 'min_t'):
+                assert np.array_equal(np.asarray(lg[k]), np.asarray(lc[k]))
+                continue
+            assert_close(lg[k], lc[k], 2e-3, 2e-3 if 'env' in k else 2e-4, '%s %s' % (tag, k))
+            assert_close(lg[k], g['%s_%s' % (tag, k)], 2e-3, 2e-3 if 'env' in k else 2e-4, '%s %s (golden)' % (tag, k))
+        assert_close(pg.grad, pc.grad, 2e-3, 1e-4 * float(pc.grad.abs().max()), tag + ' d/dpred')
+        assert_close(zg.grad, zc.grad, 1e-3, 1e-6, tag + ' d/dz')
+    # all-behind fallback
+    tgt_far = unn(planner).clone()
+    tgt_far[:, :, 0] += 500.0
+    tgt_far[:, :, 2] = 1.0
+    tgt_far[:, :, 3] = 0.0
+    lf = AdvGenLoss(mg.ADV_WEIGHTS, veh_att.to(DEV), mapixes.to(DEV), env_g, (other_z.clone() * 0.9).to(DEV), batch.ptr,
+                    veh_coll_buffer=0.1, crash_loss_min_time=2, crash_loss_min_infront=0.0)
+    pred2 = torch.from_numpy(g['adv_pred'])   # close enough to the fixture's trajectory for the branch check
+    l3 = lf(m.get_normalizer().unnormalize(pred2.to(DEV)), tgt_far.to(DEV), other_z.to(DEV),
+            (oprior[0].to(DEV), oprior[1].to(DEV)), return_mins=True)
+    assert np.array_equal(l3['min_t'], g['advbehind_min_t'])
+    # target matching incl. the prior-term quirk
+    tl = TgtMatchingLoss(mg.ADV_WEIGHTS)
+    tprior = (prior[0][ego].to(DEV), prior[1][ego].to(DEV))
+    lt = tl(m.get_normalizer().unnormalize(pred2[ego].to(DEV)), m.get_normalizer().unnormalize(planner.to(DEV)),
+            z[ego].to(DEV), tprior)
+    ltc = olosses.tgt_matching_loss(mg.ADV_WEIGHTS, unn(pred2[ego]), unn(planner), z[ego], (prior[0][ego], prior[1][ego]))
+    for k in ltc:
+        assert_close(lt[k], ltc[k], 1e-3, 1e-4, 'tgt ' + k)
+    # training variants
+    tp, npairs = TVeh(veh_att.to(DEV), batch.batch.to(DEV), batch.ptr)(m.get_normalizer().unnormalize(pred2.to(DEV)))
+    tpc, npc = olosses.VehColl(veh_att, ptr=batch.ptr, mode='train')(unn(pred2))
+    assert_close(tp, tpc, 1e-3, 1e-4, 'train veh')
+    assert int(npairs) == int(npc)
+    egoi = batch.ptr[:-1]
+    te = TEnv(orc.get_att_normalizer().unnormalize(batch.lw[egoi]).to(DEV), map_idx.to(DEV), env_g, pred2.shape[1])
+    tec = olosses.EnvColl(orc.get_att_normalizer().unnormalize(batch.lw[egoi]), map_idx, env_c, mode='train')
+    assert_close(te(m.get_normalizer().unnormalize(pred2[egoi].to(DEV))), tec(unn(pred2[egoi])), 2e-3, 2e-3, 'train env')
+
+
+# ------------------------------------------------------------------------------------------------
+# closures and loops
+# ------------------------------------------------------------------------------------------------
+
+def test_refine_loop_golden(model):
+    from strive_amd.refine_traffic_optim import refine_traffic_optim
+    m, sd = model
+    g = golden('g6_loop.npz')
+    batch, map_idx, raster, dx = mg.build_inputs(mg.G6_SIZES, 'g6', window=16.0)
+    env_c = synth.SyntheticMapEnv(raster, dx)
+    orc = oracle_model(sd)
+    with torch.no_grad():
+        emb = orc.embed(batch, map_idx, env_c)
+    z0 = synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='g6/z')
+    trace = []
+
+    def log(ld, z):
+        ent = {'z': [z.detach().cpu().clone()], 'grad': z.grad.detach().cpu().clone()}
+        for k, v in ld.items():
+            ent[k] = v.detach().cpu()
+        trace.append(ent)
+    refine_traffic_optim(batch.clone().to(DEV), map_idx.to(DEV), dev_env(raster, dx), m, mg.REFINE_WEIGHTS, 10, 16, 12, True,
+                         0.05, z_init=z0.to(DEV), log=log)
+    check_loop_trace(trace, g)
+
+
+def test_adv_and_sol_loops_run(model):
+    """The two-rollout loops (complementary detach) run end to end and move the latents."""
+    from strive_amd.utils.adv_gen_optim import run_adv_gen_optim
+    from strive_amd.utils.sol_optim import run_find_solution_optim
+    from strive_amd.utils.init_optim import run_init_optim
+    from strive_amd.utils.scenario_gen import detach_embed_info
+    m, sd = model
+    batch, map_idx, raster, dx = mg.g5_inputs(None, None)
+    env = dev_env(raster, dx)
+    bg = batch.clone().to(DEV)
+    mi = map_idx.to(DEV)
+    with torch.no_grad():
+        emb = detach_embed_info(m.embed(bg, mi, env))
+    NA = bg.past.shape[0]
+    ego = torch.zeros((NA,), dtype=torch.bool, device=DEV)
+    ego[bg.ptr[:-1].to(DEV)] = True
+    z0 = emb['posterior_out'][0].clone()
+    w = dict(mg.ADV_WEIGHTS)
+    w.update({'init_motion_prior_ext': 0.01, 'init_match_ext': 10.0, 'sol_motion_prior': 0.005, 'sol_coll_veh': 10.0,
+              'sol_coll_env': 10.0, 'sol_motion_prior_ext': 0.001, 'sol_match_ext': 10.0, 'sol_init_z': 0.0})
+    z1, traj1, _ = run_init_optim(z0, bg.future_gt[:, :, :4], bg.future_vis, 0.05, w, m, bg, env, mi, 3, emb, emb['prior_out'])
+    assert torch.isfinite(z1).all() and (z1 - z0).abs().max() > 0
+    tp = (emb['prior_out'][0][ego], emb['prior_out'][1][ego])
+    op = (emb['prior_out'][0][~ego], emb['prior_out'][1][~ego])
+    z2, fin, _, agt, tt = run_adv_gen_optim(z1.detach(), 0.05, w, m, bg, env, mi, 3, emb, 'ego', tp, op, 2, 0.0)
+    assert torch.isfinite(z2).all() and fin.shape == (NA, 1, 12, 4) and len(agt) == 3
+    z3, sol, _ = run_find_solution_optim(z2, fin, 16, 0.05, w, m, bg, env, mi, 3, emb, tp, op)
+    assert torch.isfinite(z3).all() and sol.shape == (NA, 12, 4)
+
+
+# ------------------------------------------------------------------------------------------------
+# size-independent properties at the headline size (32 scenes x 16 agents)
+# ------------------------------------------------------------------------------------------------
+
+def test_full_size_properties(model):
+    m, sd = model
+    raster, dx = uniform_env(2048)
+    env = dev_env(raster, dx)
+    sizes = [16] * 32
+    batch, map_idx = synth.make_batch(sizes, key='gp/full', map_extent=(512.0, 512.0))
+    bg = batch.to(DEV)
+    mi = map_idx.to(DEV)
+    with torch.no_grad():
+        emb = m.embed(bg, mi, env)
+        z = synth.make_latents(emb['prior_out'][0].cpu(), emb['prior_out'][1].cpu(), key='gp/full/z').to(DEV)
+        full = m.decode_embedding(z, emb, bg, mi, env)['future_pred']
+        again = m.decode_embedding(z, emb, bg, mi, env)['future_pred']
+    assert full.shape == (512, 12, 4) and torch.isfinite(full).all()
+    assert torch.equal(full, again), 'rollout must be bitwise reproducible'
+    # headings stay unit vectors, positions move by at most max_s*dt per step (unnormalised)
+    h = full[:, :, 2:4]
+    assert_close(torch.norm(h, dim=-1), torch.ones((512, 12)), 0, 1e-5, 'unit heading')
+    # per-scene independence: scenes 5 and 17 decoded alone give the same trajectories
+    with torch.no_grad():
+        for b in (5, 17):
+            sub, sub_idx = synth.make_batch([16], key='unused')
+            one = batch.to_data_list()[b]
+            from strive_amd.graph import Batch
+            sb = Batch.from_data_list([one]).to(DEV)
+            lo = 16 * b
+            e1 = {'map_feat': emb['map_feat'][lo:lo + 16].contiguous(), 'past_feat': emb['past_feat'][lo:lo + 16].contiguous()}
+            alone = m.decode_embedding(z[lo:lo + 16].contiguous(), e1, sb, mi[b:b + 1], env)['future_pred']
+            assert_close(alone, full[lo:lo + 16], 0, 1e-6, 'scene %d alone' % b)
+    # multi-sample path with identical samples == 2-D path
+    with torch.no_grad():
+        ns = m.decode_embedding(torch.stack([z, z], dim=1).contiguous(), emb, bg, mi, env)['future_pred']
+    assert_close(ns[:, 0], full, 0, 1e-6, 'NS path sample 0')
+    assert_close(ns[:, 1], full, 0, 1e-6, 'NS path sample 1')

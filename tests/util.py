@@ -1,0 +1,47 @@
+"""Shared builders for the test-suite (inputs regenerated from strive_amd.synth's counter generator)."""
+import os
+
+import numpy as np
+import torch
+
+from strive_amd import synth
+from strive_amd.constants import NUSC_BIKE_PARAMS, state_norm_tensors, att_norm_tensors
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def product_model(NC=2, FT=12, device='cpu', key='weights'):
+    from strive_amd.models.traffic_model import TrafficModel
+    from strive_amd.datasets.utils import MeanStdNormalizer
+    m = TrafficModel(4, FT, 256, NC)
+    sd = synth.fill_state_dict(m.state_dict(), key=key)
+    m.load_state_dict(sd)
+    m.set_normalizer(MeanStdNormalizer(*state_norm_tensors()))
+    m.set_att_normalizer(MeanStdNormalizer(*att_norm_tensors()))
+    m.set_bicycle_params(NUSC_BIKE_PARAMS)
+    m.eval()
+    return m.to(device), sd
+
+
+def oracle_model(sd, NC=2, FT=12):
+    from oracle.model import OracleTrafficModel
+    from oracle.geometry import Normalizer
+    return OracleTrafficModel(sd, Normalizer(*state_norm_tensors()), Normalizer(*att_norm_tensors()), NUSC_BIKE_PARAMS,
+                              FT=FT, NC=NC)
+
+
+def assert_close(a, b, rtol, atol, what=''):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, '%s: shape %s vs %s' % (what, a.shape, b.shape)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    bad = err > tol
+    if bad.any():
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError('%s: %d/%d entries off; worst at %s: got %.8g want %.8g (|d|=%.3g)' %
+                             (what, bad.sum(), bad.size, i, a[i], b[i], err[i]))
