@@ -169,6 +169,8 @@ def mlp_forward(mlp_module, x):
     _no_grad_inputs('MLP.forward', x)
     pk = _cached_pack(mlp_module, 'mlp', mlp_module, lambda: params.pack_mlp(_sd_of(mlp_module, 'm'), 'm'))
     shp = x.shape
+    if shp[-1] != pk.struct.dims[0]:
+        raise ValueError('MLP expects %d input features, got %d' % (pk.struct.dims[0], shp[-1]))
     x2 = _f32c(x).reshape(-1, shp[-1])
     O = pk.struct.dims[pk.struct.nlayers]
     y = torch.empty((x2.shape[0], O), dtype=torch.float32, device=x.device)
@@ -187,6 +189,8 @@ def gnn_forward(net, scene_graph):
     pk = _cached_pack(net, 'gnn', net, lambda: params.pack_gnn(_sd_of(net, 'g'), 'g', NC))
     sc = info.pack(NS)
     R = info.NA * NS
+    if x.shape[-1] != pk.struct.mlp_in.dims[0] or x.shape[0] != info.NA:
+        raise ValueError('interaction net expects (%d, %d) node features, got %s' % (info.NA, pk.struct.mlp_in.dims[0], tuple(x.shape)))
     x2 = _f32c(x).reshape(R, -1)
     p2 = _f32c(pos).reshape(R, 4)
     O = pk.struct.mlp_out.dims[pk.struct.mlp_out.nlayers]

@@ -298,21 +298,21 @@ def test_g6_loop(sd):
     check_loop_trace(trace, g)
 
 
-def check_loop_trace(trace, g):
+def check_loop_trace(trace, g, first=(1e-4, 1e-4, 2e-5)):
     """The optimisation trace is chaotic by construction: Adam's g/(|g|+eps) turns 1e-7 noise in near-zero
     gradient entries into +-lr steps, the rollout re-samples the raster at every step and the collision sets
     are hard-thresholded.  Measured reference-vs-oracle (both CPU fp32): iteration 0 agrees to 1e-6, iteration 1
     to 4e-4, iteration 2 to 2e-2, afterwards individual gradient entries differ by O(1) while every loss term
     stays within 1.5 %.  Hence: tight on the first closure, loose on the next two, loss terms only afterwards."""
     keys = [str(k) for k in g['loss_keys']]
-    gtol = [2e-5, 5e-3, 1e-1]
+    gtol = [first[2], max(5e-3, first[2]), 1e-1]
     for it in range(len(trace)):
         got = [float(torch.mean(trace[it][k])) for k in keys]
-        np.testing.assert_allclose(got, g['losses'][it], rtol=1e-4 if it == 0 else 3e-2, atol=1e-4 if it == 0 else 2e-2)
+        np.testing.assert_allclose(got, g['losses'][it], rtol=first[0] if it == 0 else 3e-2, atol=first[1] if it == 0 else 2e-2)
         if it < 3:
             assert_close(trace[it]['grad'], g['grad'][it], 1e-3, gtol[it], 'grad it%d' % it)
     # z after the first two steps
-    assert_close(trace[1]['z'][0], g['z'][0], 0, 1e-5, 'z after step 1')
+    assert_close(trace[1]['z'][0], g['z'][0], 0, max(1e-5, 50 * first[2]), 'z after step 1')
     assert_close(trace[2]['z'][0], g['z'][1], 0, 5e-3, 'z after step 2')
 
 
