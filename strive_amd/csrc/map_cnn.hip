@@ -76,33 +76,44 @@ __global__ __launch_bounds__(256) void conv1_kernel(StriveMap map, const float* 
     CropFrame fr;
     if (FUSED_CROP) fr = load_crop_frame(map, pos, pmean.v, pstd.v, mapix, n);
     const size_t plane = FUSED_CROP ? (size_t)map.H * map.W : 0;
-    for (int idx = tid; idx < IT * IT; idx += 256) {
-        const int r = idx / IT, c = idx - r * IT;
-        const int l = 2 * oy0 + r, w = 2 * ox0 + c;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        if (l < IH && w < IH) {
-            if (FUSED_CROP) {
-                int px, py;
-                crop_pixel(fr, map.lwise[l], map.wwise[w], true, px, py);
-                const uint8_t* src = fr.base + (size_t)py * map.W + px;
-                v0 = (float)src[0];
-                v1 = (float)src[plane];
-                v2 = (float)src[2 * plane];
-                v3 = (float)src[3 * plane];
-            } else {
-                const uint8_t* src = crop + (size_t)n * CIN * IH * IH + (size_t)l * IH + w;
-                v0 = (float)src[0];
-                v1 = (float)src[(size_t)IH * IH];
-                v2 = (float)src[(size_t)2 * IH * IH];
-                v3 = (float)src[(size_t)3 * IH * IH];
+    // two phases so that the (fp64) coordinate arithmetic of all of a thread's samples is done before any byte
+    // gather is waited for: the 4 x NIT gathers of a thread are then in flight together
+    constexpr int NIT = (IT * IT + 255) / 256;
+    const uint8_t* srcp[NIT];
+    int dsto[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int idx = tid + k * 256;
+        srcp[k] = nullptr;
+        dsto[k] = -1;
+        if (idx < IT * IT) {
+            const int r = idx / IT, c = idx - r * IT;
+            const int l = 2 * oy0 + r, w = 2 * ox0 + c;
+            dsto[k] = r * RS + (c >> 1) + (c & 1) * HALFW;
+            if (l < IH && w < IH) {
+                if (FUSED_CROP) {
+                    int px, py;
+                    crop_pixel(fr, map.lwise[l], map.wwise[w], true, px, py);
+                    srcp[k] = fr.base + (size_t)py * map.W + px;
+                } else {
+                    srcp[k] = crop + (size_t)n * CIN * IH * IH + (size_t)l * IH + w;
+                }
             }
         }
-        const int cc = (c >> 1) + (c & 1) * HALFW;
-        const int o = r * RS + cc;
-        s_in[o] = v0;
-        s_in[PS + o] = v1;
-        s_in[2 * PS + o] = v2;
-        s_in[3 * PS + o] = v3;
+    }
+    const size_t cplane = FUSED_CROP ? plane : (size_t)IH * IH;
+    uint8_t bv[NIT][4];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bv[k][c] = srcp[k] ? srcp[k][c * cplane] : (uint8_t)0;
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        if (dsto[k] >= 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s_in[c * PS + dsto[k]] = (float)bv[k][c];
+        }
     }
     __syncthreads();
 
@@ -170,6 +181,8 @@ struct ConvCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, KS = KS_, IH = IH_, OH = OH_, TH = TH_, TW = TW_, S = S_, CC = CC_;
     static constexpr int NWP = NWP_, NWM = NWM_, NPW = NPW_, MTW = MTW_;
     static constexpr int NW = NWP * NWM, NT = NW * 64;
+    static constexpr int COUT_WG = NWM * MTW * 32;   // output channels owned by one workgroup
+    static constexpr int CSPLIT = COUT / COUT_WG;    // workgroups along the channel axis (grid.x = TILES_X * CSPLIT)
     static constexpr int TILES_Y = (OH + TH - 1) / TH, TILES_X = (OH + TW - 1) / TW;
     static constexpr int ITH = 2 * TH + KS - 2, ITW = 2 * TW + KS - 2;
     static constexpr int HALFW = (ITW + 1) / 2;
@@ -179,17 +192,21 @@ struct ConvCfg {
     static constexpr int SS = CC * PS;             // per-sample block of a chunk
     static constexpr int P = S * TH * TW;
     static constexpr int NTILE = (P + 31) / 32;
-    static constexpr int WCH = (CC / 2) * KS * KS * 2 * COUT;   // weight floats per chunk
+    static constexpr int WROWS = (CC / 2) * KS * KS * 2;        // (channel pair, ky, kx, parity) rows per chunk
+    static constexpr int WCH = WROWS * COUT_WG;                 // weight floats per chunk in LDS
     static constexpr int IN_FLOATS = S * SS;
     static constexpr int GN_FLOATS = S * CIN * 2;
-    static constexpr int NPART_OUT = TILES_X * TILES_Y;   // == 1 whenever S > 1 (whole images per workgroup)
+    static constexpr int NPART_OUT = TILES_X * TILES_Y * CSPLIT;
     static constexpr int RED_DOUBLES = (S == 1) ? 2 * NW : 2 * NW * NPW * 64;
     static constexpr size_t LDS_BYTES = (size_t)(IN_FLOATS + WCH + GN_FLOATS) * 4 + (size_t)RED_DOUBLES * 8 + 64 * 4;
-    static_assert(COUT == NWM * MTW * 32, "channel tiling");
+    static_assert(COUT % COUT_WG == 0, "channel tiling");
     static_assert(NTILE <= NWP * NPW, "pixel tiling");
     static_assert(CC % 2 == 0 && CIN % CC == 0, "channel chunking");
     static_assert(RS >= 2 * HALFW, "row stride");
+    static_assert(S == 1 || (TILES_X == 1 && TILES_Y == 1), "multi-sample workgroups own whole images");
 };
+
+#define STAGE_UB 8   // independent global loads in flight per thread while staging
 
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
@@ -199,6 +216,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
     constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, KS = Cfg::KS, IH = Cfg::IH, OH = Cfg::OH;
     constexpr int TH = Cfg::TH, TW = Cfg::TW, S = Cfg::S, CC = Cfg::CC, RS = Cfg::RS, PS = Cfg::PS, SS = Cfg::SS;
     constexpr int HALFW = Cfg::HALFW, ITH = Cfg::ITH, ITW = Cfg::ITW, NPW = Cfg::NPW, MTW = Cfg::MTW, P = Cfg::P;
+    constexpr int CW = Cfg::COUT_WG, NT = Cfg::NT;
     HIP_DYNAMIC_SHARED(float, smem)
     float* s_in = smem;
     float* s_w = smem + Cfg::IN_FLOATS;
@@ -210,7 +228,9 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
     const int wp = wave % Cfg::NWP, wm = wave / Cfg::NWP;
     const int half = lane >> 5, j = lane & 31;
     const int n0 = blockIdx.z * S;
-    const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    const int tile_x = blockIdx.x % Cfg::TILES_X, cb = blockIdx.x / Cfg::TILES_X;
+    const int c0 = cb * CW;                           // first output channel of this workgroup
+    const int oy0 = blockIdx.y * TH, ox0 = tile_x * TW;
     const int iy0 = 2 * oy0, ix0 = 2 * ox0;
 
     // ---- GroupNorm scale/shift of the producing layer, per (sample, channel) ----
@@ -222,7 +242,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
         s_mr[2 * tid + 1] = rstd;
     }
     __syncthreads();
-    for (int i = tid; i < S * CIN; i += Cfg::NT) {
+    for (int i = tid; i < S * CIN; i += NT) {
         const int s = i / CIN, c = i - s * CIN;
         const float sc = s_mr[2 * s + 1] * gn_g[c];
         s_gn[2 * i] = sc;
@@ -252,31 +272,64 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
 
-    const int abase = half * COUT + wm * MTW * 32 + j;
+    const int abase = half * CW + wm * MTW * 32 + j;
+    constexpr int TOTAL = S * CC * ITH * ITW;
+    constexpr int ITERS = (TOTAL + NT - 1) / NT;
+    constexpr int WQ = Cfg::WCH / 4;                  // float4 units of the weight chunk
+    constexpr int WITERS = (WQ + NT - 1) / NT;
 
     for (int ch = 0; ch < CIN / CC; ++ch) {
         __syncthreads();
-        // ---- stage input chunk with GN + ReLU applied ----
-        for (int idx = tid; idx < S * CC * ITH * ITW; idx += Cfg::NT) {
-            const int col = idx % ITW;
-            int t = idx / ITW;
-            const int r = t % ITH;
-            t /= ITH;
-            const int c = t % CC;
-            const int s = t / CC;
-            const int iy = iy0 + r, ix = ix0 + col;
-            float v = 0.f;
-            const int ci = ch * CC + c;
-            if (n0 + s < N && iy < IH && ix < IH) {
-                const float raw = in[(((size_t)(n0 + s) * CIN + ci) * IH + iy) * IH + ix];
-                v = fmaxf(fmaf(raw, s_gn[2 * (s * CIN + ci)], s_gn[2 * (s * CIN + ci) + 1]), 0.f);
+        // ---- stage input chunk with GN + ReLU applied; loads are issued in batches of STAGE_UB so that each
+        //      thread keeps several global loads in flight (a one-load-at-a-time loop is latency bound) ----
+        for (int k0 = 0; k0 < ITERS; k0 += STAGE_UB) {
+            float raw[STAGE_UB], sc[STAGE_UB], sh[STAGE_UB];
+            int dst[STAGE_UB];
+#pragma unroll
+            for (int u = 0; u < STAGE_UB; ++u) {
+                const int idx = tid + (k0 + u) * NT;
+                raw[u] = 0.f;
+                sc[u] = 0.f;
+                sh[u] = 0.f;
+                dst[u] = -1;
+                if (k0 + u < ITERS && idx < TOTAL) {
+                    const int col = idx % ITW;
+                    int t = idx / ITW;
+                    const int r = t % ITH;
+                    t /= ITH;
+                    const int c = t % CC;
+                    const int s = t / CC;
+                    const int iy = iy0 + r, ix = ix0 + col;
+                    const int ci = ch * CC + c;
+                    dst[u] = s * SS + c * PS + r * RS + (col >> 1) + (col & 1) * HALFW;
+                    if (n0 + s < N && iy < IH && ix < IH) {
+                        raw[u] = in[(((size_t)(n0 + s) * CIN + ci) * IH + iy) * IH + ix];
+                        sc[u] = s_gn[2 * (s * CIN + ci)];
+                        sh[u] = s_gn[2 * (s * CIN + ci) + 1];
+                    }
+                }
             }
-            s_in[s * SS + c * PS + r * RS + (col >> 1) + (col & 1) * HALFW] = v;
+#pragma unroll
+            for (int u = 0; u < STAGE_UB; ++u)
+                if (dst[u] >= 0) s_in[dst[u]] = fmaxf(fmaf(raw[u], sc[u], sh[u]), 0.f);   // sc = sh = 0 -> exact zero padding
         }
-        // ---- stage weight chunk (contiguous in the packed layout) ----
-        {
-            const float* wsrc = wpk + (size_t)ch * Cfg::WCH;
-            for (int i = tid; i < Cfg::WCH; i += Cfg::NT) s_w[i] = wsrc[i];
+        // ---- stage this workgroup's slice of the weight chunk: rows of CW floats out of COUT ----
+        for (int k0 = 0; k0 < WITERS; k0 += 4) {
+            float4 wv[4];
+            int wd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = tid + (k0 + u) * NT;
+                wd[u] = -1;
+                if (k0 + u < WITERS && q < WQ) {
+                    const int row = (q * 4) / CW, c = (q * 4) - row * CW;
+                    wd[u] = q * 4;
+                    wv[u] = *reinterpret_cast<const float4*>(wpk + ((size_t)ch * Cfg::WROWS + row) * COUT + c0 + c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (wd[u] >= 0) *reinterpret_cast<float4*>(s_w + wd[u]) = wv[u];
         }
         __syncthreads();
 #pragma unroll
@@ -288,7 +341,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
                     const int step = (cp * KS + ky) * KS + kx;
                     float a[MTW], b[NPW];
 #pragma unroll
-                    for (int m = 0; m < MTW; ++m) a[m] = s_w[step * 2 * COUT + abase + m * 32];
+                    for (int m = 0; m < MTW; ++m) a[m] = s_w[step * 2 * CW + abase + m * 32];
                     const int off = cp * 2 * PS + ky * RS + (kx >> 1) + (kx & 1) * HALFW;
 #pragma unroll
                     for (int i = 0; i < NPW; ++i) b[i] = s_in[pbase[i] + off];
@@ -319,7 +372,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
         for (int m = 0; m < MTW; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = wm * MTW * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int co = c0 + wm * MTW * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const float v = acc[i][m][r] + bias[co];
                 if (valid) {
                     out[(((size_t)(n0 + s) * COUT + co) * OH + oy) * OH + ox] = v;
@@ -332,7 +385,6 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
             wsum += lsum;
             wsq += lsq;
         } else {
-            // per-lane slot, tagged with its sample through the reduction below
             s_red[2 * ((wave * NPW + i) * 64 + lane)] = valid ? lsum : 0.0;
             s_red[2 * ((wave * NPW + i) * 64 + lane) + 1] = valid ? lsq : 0.0;
         }
@@ -345,7 +397,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
         if (tid == 0 && n0 < N) {
             double a = 0.0, b = 0.0;
             for (int w = 0; w < Cfg::NW; ++w) { a += s_red[2 * w]; b += s_red[2 * w + 1]; }
-            GNStats& o = st_out[(size_t)n0 * Cfg::NPART_OUT + blockIdx.y * Cfg::TILES_X + blockIdx.x];
+            GNStats& o = st_out[(size_t)n0 * Cfg::NPART_OUT + (blockIdx.y * Cfg::TILES_X + tile_x) * Cfg::CSPLIT + cb];
             o.sum = a;
             o.sq = b;
         }
@@ -367,23 +419,24 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
                     }
                 }
             }
-            st_out[n0 + tid].sum = a;
-            st_out[n0 + tid].sq = b;
+            GNStats& o = st_out[(size_t)(n0 + tid) * Cfg::NPART_OUT + cb];
+            o.sum = a;
+            o.sq = b;
         }
     }
 }
 
 // per-layer configurations            CIN COUT KS  IH  OH  TH  TW  S  CC NWP NWM NPW MTW NPART_IN
-typedef ConvCfg< 16,  32, 5, 125, 61, 16, 16,  1,  8,  4,  1,  2,  1, 64> Cfg2;   // 256 px tile, 4 waves
+typedef ConvCfg< 16,  32, 5, 125, 61, 16, 16,  1,  8,  4,  1,  2,  1, 64> Cfg2;   // 16x16 px tile, 4 waves, 4096 WGs / 256 agents
 typedef ConvCfg< 32,  64, 5,  61, 29, 29, 29,  1,  2,  7,  1,  4,  2, 16> Cfg3;   // whole image (841 px), 7 waves
-typedef ConvCfg< 64,  64, 3,  29, 14, 14, 14,  4,  2,  7,  1,  4,  2,  1> Cfg4;   // 4 samples (784 px), 7 waves
-typedef ConvCfg< 64, 128, 3,  14,  6,  6,  6,  8,  4,  3,  2,  3,  2,  1> Cfg5;   // 8 samples (288 px), 6 waves
-typedef ConvCfg<128, 128, 3,   6,  2,  2,  2, 32,  8,  2,  2,  2,  2,  1> Cfg6;   // 32 samples (128 px), 4 waves
+typedef ConvCfg< 64,  64, 3,  29, 14, 14, 14,  1,  8,  4,  1,  2,  2,  1> Cfg4;   // whole image (196 px), 4 waves, 1 WG / agent
+typedef ConvCfg< 64, 128, 3,  14,  6,  6,  6,  2,  8,  3,  2,  1,  1,  1> Cfg5;   // 2 agents (72 px) x 64 of 128 channels, 6 waves
+typedef ConvCfg<128, 128, 3,   6,  2,  2,  2,  8,  8,  1,  4,  1,  1,  2> Cfg6;   // 8 agents (32 px), 4 waves x 32 channels
 
 template <class Cfg>
 static int launch_conv(const float* in, const GNStats* st_in, const float* g, const float* b, const float* w,
                        const float* bias, float* out, GNStats* st_out, int N, hipStream_t stream) {
-    dim3 grid(Cfg::TILES_X, Cfg::TILES_Y, (N + Cfg::S - 1) / Cfg::S);
+    dim3 grid(Cfg::TILES_X * Cfg::CSPLIT, Cfg::TILES_Y, (N + Cfg::S - 1) / Cfg::S);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)conv_mfma_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -410,7 +463,7 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ in, c
         if (n0 + s < N) {
             float mean, rstd;
             const int c = k >> 2;
-            gn_moments(st, n0 + s, 1, 512.0, mean, rstd);
+            gn_moments(st, n0 + s, Cfg6::NPART_OUT, 512.0, mean, rstd);
             const float sc = rstd * gn_g[c];
             v = fmaxf(fmaf(in[(size_t)(n0 + s) * 512 + k], sc, gn_b[c] - mean * sc), 0.f);
         }
@@ -431,8 +484,10 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ in, c
 namespace {
 constexpr size_t L_OUT[6] = {16u * 125 * 125, 32u * 61 * 61, 64u * 29 * 29, 64u * 14 * 14, 128u * 6 * 6, 128u * 2 * 2};
 constexpr int CNN_CHUNK = 256;
-constexpr int NPARTS[6] = {64, 16, 1, 1, 1, 1};   // statistics slots per sample written by each layer
-constexpr int STAT_SLOTS = 64 + 16 + 1 + 1 + 1 + 1;   // agents pushed through the layer stack together (keeps the working set L3-sized)
+constexpr int NPARTS[6] = {64, Cfg2::NPART_OUT, Cfg3::NPART_OUT, Cfg4::NPART_OUT, Cfg5::NPART_OUT, Cfg6::NPART_OUT};
+constexpr int STAT_SLOTS = 64 + Cfg2::NPART_OUT + Cfg3::NPART_OUT + Cfg4::NPART_OUT + Cfg5::NPART_OUT + Cfg6::NPART_OUT;
+static_assert(Cfg3::NPART_IN == Cfg2::NPART_OUT && Cfg4::NPART_IN == Cfg3::NPART_OUT && Cfg5::NPART_IN == Cfg4::NPART_OUT &&
+              Cfg6::NPART_IN == Cfg5::NPART_OUT, "statistics slot chain");   // agents pushed through the layer stack together (keeps the working set L3-sized)
 
 size_t per_agent_floats() {
     size_t t = 0;

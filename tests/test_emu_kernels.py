@@ -1,0 +1,193 @@
+"""Kernel LOGIC on the CPU: the unmodified strive_amd/csrc/*.hip sources compiled as host C++ against
+tests/hipemu (fibers for threads, rendezvous for barriers / shuffles / MFMA) and driven through the same C ABI,
+checked against the oracle and the golden vectors.  This is test infrastructure for a GPU-less build container:
+it validates indexing, LDS staging, MFMA fragment layouts, the reverse-time backward and the ABI plumbing -- it
+says nothing about performance and is never loaded by the product."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import make_golden as mg
+from util import golden, oracle_model, product_model, assert_close
+from strive_amd import _lib as L, params, synth
+from strive_amd.constants import NUSC_BIKE_PARAMS
+from oracle import mapenv, losses as olosses
+from oracle import model as om
+from oracle.geometry import Normalizer
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'hipemu'))
+
+
+@pytest.fixture(scope='module')
+def emu():
+    import build as emu_build
+    return L.StriveLib(emu_build.build(), require_all=True)
+
+
+@pytest.fixture(scope='module')
+def sd():
+    return product_model()[1]
+
+
+def test_crop_and_coll_point(emu):
+    g = golden('g2_crop.npz')
+    raster, dx, frame, mapixes, lw = mg.g2_inputs()
+    env = synth.SyntheticMapEnv(raster, dx)
+    mp = params.pack_map(env, 'cpu')
+    N = frame.shape[0]
+    out = torch.zeros((N, 4, 256, 256), dtype=torch.uint8)
+    mi = mapixes.int()
+    emu.call('strive_map_crop_u8', mp.ref(), L.ptr(frame), L.f4([0] * 4), L.f4([1] * 4), L.ptr(mi), N, L.ptr(out), None)
+    assert torch.equal(out, mapenv.map_crop(raster, dx, frame, mapixes, env.bounds))
+    for i in (0, 1, 7):
+        assert np.array_equal(np.packbits(out[i].numpy()), g['crop_full_%d' % i])
+    ok = ~torch.isnan(frame[:, 0])
+    cars, lws, mis = frame[ok].contiguous(), lw[ok].contiguous(), mi[ok].contiguous()
+    gl, gw = mapenv.coll_grid_size(dx, lws)
+    pt = torch.zeros((cars.shape[0], 2))
+    cnt = torch.zeros((cars.shape[0],), dtype=torch.int32)
+    emu.call('strive_coll_point', mp.ref(), L.ptr(cars), L.ptr(lws), L.ptr(mis), cars.shape[0], gl, gw,
+             L.ptr(torch.linspace(-1, 1, gl)), L.ptr(torch.linspace(-1, 1, gw)), L.ptr(pt), L.ptr(cnt), None)
+    np.testing.assert_allclose(pt.numpy(), g['coll_pt'], rtol=0, atol=1e-3, equal_nan=True)
+
+
+def test_mlp_and_gnn(emu, sd):
+    g1, g3 = golden('g1_ops.npz'), golden('g3_gnn.npz')
+    x = synth.f32(synth.counter_uniform((6, 38), 'g1/mlp_in', -1.0, 1.0))
+    mp = params.pack_mlp(sd, 'past_encoder')
+    y = torch.zeros((6, 64))
+    emu.call('strive_mlp_fwd', mp.ref(), L.ptr(x), 6, L.ptr(y), None)
+    assert_close(y, g1['mlp_past_encoder'], 1e-4, 1e-5, 'mlp')
+    batch, map_idx, raster, dx = mg.build_inputs(mg.G3_SIZES, 'g3')
+    NA = batch.past.shape[0]
+    sc = params.pack_scenes(batch.ptr, 1, 'cpu')
+    for name, prefix, fin in (('decoder', 'decoder_net', 164), ('prior', 'prior_net', 130), ('posterior', 'posterior_net', 194)):
+        x = synth.f32(synth.counter_uniform((NA, fin), 'g3/x/' + name, -1.0, 1.0))
+        pos = batch.past[:, -1, :4].clone().contiguous()
+        if name == 'prior':
+            pos[1, 0] = float('nan')
+        gp = params.pack_gnn(sd, prefix, 2)
+        wsb = emu.query('strive_gnn_workspace_bytes', gp.ref(), sc.ref())
+        ws = torch.zeros(wsb, dtype=torch.uint8)
+        out = torch.zeros((NA, g3[name + '_out'].shape[1]))
+        emu.call('strive_gnn_fwd', gp.ref(), sc.ref(), L.ptr(x), L.ptr(pos), L.ptr(batch.sem.contiguous()), L.ptr(out),
+                 L.ptr(ws), wsb, None)
+        assert_close(out, g3[name + '_out'], 1e-4, 1e-5, name)
+
+
+def test_map_cnn_one_agent(emu, sd):
+    raster, dx, frame, mapixes, lw = mg.g2_inputs()
+    env = synth.SyntheticMapEnv(raster, dx)
+    fr = frame[7:8].contiguous()
+    mi = mapixes[7:8].int().contiguous()
+    crop = mapenv.map_crop(raster, dx, fr, mi.long(), env.bounds)
+    want = om.map_cnn(sd, crop.float())
+    cnn, mp = params.pack_cnn(sd), params.pack_map(env, 'cpu')
+    wsb = emu.query('strive_map_cnn_workspace_bytes', 1)
+    ws = torch.zeros(wsb, dtype=torch.uint8)
+    feat = torch.zeros((1, 64))
+    emu.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(fr), L.f4([0] * 4), L.f4([1] * 4), L.ptr(mi), 1, L.ptr(feat),
+             L.ptr(ws), wsb, None)
+    assert_close(feat, want, 1e-4, 1e-5, 'cnn')
+
+
+def _rollout(emu, sd, sizes, FT, NS=1, ext=False):
+    batch, map_idx, raster, dx = mg.build_inputs(sizes, 'emu')
+    env = synth.SyntheticMapEnv(raster, dx)
+    orc = oracle_model(sd)
+    with torch.no_grad():
+        emb = orc.embed(batch, map_idx, env) if FT > 1 else None
+    NA = batch.past.shape[0]
+    if emb is None:   # FT == 1 needs no map feature from the CNN: use counter-generated features
+        emb = {'map_feat': synth.f32(synth.counter_uniform((NA, 64), 'emu/mf', -1, 1)),
+               'past_feat': synth.f32(synth.counter_uniform((NA, 64), 'emu/pf', -1, 1)),
+               'prior_out': (torch.zeros((NA, 32)), torch.ones((NA, 32)))}
+    z = synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='emu/z')
+    if NS > 1:
+        z = torch.stack([z, synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='emu/z2')], dim=1)
+    z = z.contiguous().requires_grad_(True)
+    extf = batch.future_gt[batch.ptr[:-1]][:, :FT, :4].contiguous() if ext else None
+    pred = orc.decode(batch, emb['map_feat'], emb['past_feat'], z, map_idx, env, ext_future=extf, nfuture=FT)
+    rw = synth.f32(synth.counter_uniform(tuple(pred.shape), 'emu/rw', -1.0, 1.0))
+    gz, = torch.autograd.grad((pred * rw).sum(), [z])
+    sn, an = orc.get_normalizer(), orc.get_att_normalizer()
+    dec = params.pack_decoder(sd, 2, env, 'cpu', sn, an, NUSC_BIKE_PARAMS)
+    sc = params.pack_scenes(batch.ptr, NS, 'cpu')
+    R = NA * NS
+    tb = emu.query('strive_rollout_tape_bytes', dec.ref(), sc.ref(), FT)
+    wb = emu.query('strive_rollout_workspace_bytes', dec.ref(), sc.ref(), FT)
+    tape, ws = torch.zeros(tb, dtype=torch.uint8), torch.zeros(wb, dtype=torch.uint8)
+    traj = torch.zeros((R, FT, 4))
+    zz = z.detach().reshape(R, 32).contiguous()
+    mi = map_idx[batch.batch].int().contiguous()
+    lw, sem = batch.lw.contiguous(), batch.sem.contiguous()
+    emu.call('strive_rollout_fwd', dec.ref(), sc.ref(), L.ptr(batch.past[:, -1, :].contiguous()), L.ptr(lw), L.ptr(sem),
+             L.ptr(emb['past_feat'].contiguous()), L.ptr(emb['map_feat'].contiguous()), L.ptr(zz), L.ptr(mi), L.ptr(extf), FT,
+             L.ptr(traj), L.ptr(tape), tb, L.ptr(ws), wb, None)
+    dz = torch.zeros((R, 32))
+    emu.call('strive_rollout_bwd', dec.ref(), sc.ref(), L.ptr(lw), L.ptr(sem), L.ptr(zz), L.ptr(extf), FT,
+             L.ptr(rw.reshape(R, FT, 4).contiguous()), L.ptr(dz), L.ptr(tape), tb, L.ptr(ws), wb, None)
+    assert_close(traj, pred.detach().reshape(R, FT, 4), 1e-4, 1e-5, 'rollout fwd')
+    assert_close(dz, gz.reshape(R, 32), 2e-3, 1e-6 + 1e-4 * float(gz.abs().max()), 'rollout bwd')
+
+
+@pytest.mark.parametrize('sizes,NS,ext', [([3, 1, 5], 1, False), ([4, 2], 1, True), ([2, 3], 2, False), ([19], 1, False)])
+def test_rollout_single_step(emu, sd, sizes, NS, ext):
+    """FT = 1: GNN + bicycle + local transform and their adjoints (no CNN / GRU in a single step)."""
+    _rollout(emu, sd, sizes, 1, NS=NS, ext=ext)
+
+
+def test_rollout_two_steps(emu, sd):
+    """FT = 2 adds the GRU memory step and one fused crop+CNN evaluation per agent (and their place in the
+    reverse sweep)."""
+    _rollout(emu, sd, [2, 1], 2)
+
+
+@pytest.mark.slow
+def test_rollout_three_steps_ext(emu, sd):
+    _rollout(emu, sd, [3, 1], 3, ext=True)
+
+
+def test_veh_coll_fwd_bwd(emu, sd):
+    g = golden('g5_losses.npz')
+    batch, map_idx, raster, dx = mg.g5_inputs(None, None)
+    orc = oracle_model(sd)
+    veh_att = orc.get_att_normalizer().unnormalize(batch.lw)
+    traj = olosses.interp_traj(orc.get_normalizer().unnormalize(torch.from_numpy(g['adv_pred'])), 3).contiguous()
+    NA, T, _ = traj.shape
+    from strive_amd.ops import SceneInfo
+    from strive_amd.losses.adv_gen_nusc import _linspace5
+    info = SceneInfo(batch.ptr, 'cpu')
+    sc = info.pack(1)
+    rad = (veh_att[:, 1] / 2.).contiguous()
+    cent = _linspace5(-(veh_att[:, 0] / 2.) + rad, (veh_att[:, 0] / 2.) - rad).contiguous()
+    pen = torch.zeros((T, info.P))
+    hit = torch.zeros((T, info.P), dtype=torch.uint8)
+    amin = torch.zeros((T, info.P), dtype=torch.uint8)
+    emu.call('strive_veh_coll_fwd', sc.ref(), L.ptr(info.pair_off), info.P, L.ptr(traj), T, L.ptr(cent), L.ptr(rad), 0.1,
+             L.ptr(pen), L.ptr(hit), L.ptr(amin), None)
+    tc = traj.clone().requires_grad_(True)
+    vc = olosses.VehColl(veh_att, ptr=batch.ptr, buffer_dist=0.1)
+    dense, cmask = vc(tc, return_raw=True)
+    # slot (t, i, j) -> dense[t, i, j]
+    sizes = info.sizes.tolist()
+    si, sj = [], []
+    for b, n in enumerate(sizes):
+        lo = int(batch.ptr[b])
+        for i in range(n):
+            for j in range(n):
+                si.append(lo + i)
+                sj.append(lo + j)
+    si, sj = torch.tensor(si), torch.tensor(sj)
+    assert_close(pen, dense.detach()[:, si, sj], 1e-4, 1e-5, 'pen')
+    assert torch.equal(hit.bool() & (si != sj).view(1, -1), cmask[:, si, sj])
+    wgt = synth.f32(synth.counter_uniform((T, info.P), 'emu/vw', 0.0, 1.0)) * (hit.bool() & (si != sj).view(1, -1))
+    (dense[:, si, sj] * wgt).sum().backward()
+    d_traj = torch.zeros_like(traj)
+    emu.call('strive_veh_coll_bwd', sc.ref(), L.ptr(info.pair_off), info.P, L.ptr(traj), T, L.ptr(cent), L.ptr(rad), 0.1,
+             L.ptr(wgt.contiguous()), L.ptr(amin), L.ptr(d_traj), None)
+    assert_close(d_traj, tc.grad, 1e-3, 1e-5, 'veh bwd')
