@@ -85,6 +85,8 @@ typedef struct StriveMap {
     const float* lwise;      /* (L)  */
     const float* wwise;      /* (Wc) */
     int32_t L, Wc;
+    const uint32_t* raster_px4;   /* optional (M, H, W) copy with the 4 layers of a pixel packed into one little-endian
+                                     word (byte c = layer c), or NULL; lets the fused crop gather 4 layers with ONE load */
 } StriveMap;
 
 /* Map CNN: 6 x [Conv2d(stride 2, pad 0) -> GroupNorm(1 group) -> ReLU] + Linear(512, 64), default

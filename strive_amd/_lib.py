@@ -44,7 +44,7 @@ class StriveGRU(C.Structure):
 class StriveMap(C.Structure):
     _fields_ = [('raster', C.c_void_p), ('dx', C.c_void_p), ('M', C.c_int32), ('C', C.c_int32),
                 ('H', C.c_int32), ('W', C.c_int32), ('lwise', C.c_void_p), ('wwise', C.c_void_p),
-                ('L', C.c_int32), ('Wc', C.c_int32)]
+                ('L', C.c_int32), ('Wc', C.c_int32), ('raster_px4', C.c_void_p)]
 
 
 class StriveCNN(C.Structure):

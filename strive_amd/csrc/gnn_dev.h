@@ -60,6 +60,7 @@ __device__ __forceinline__ int feat_width(const FeatSrc& f) {
 }
 
 // rows r0..r0+RB-1 of the concatenated feature -> LDS [RB][ld] (rows >= R are zero filled)
+template <int RB>
 __device__ __forceinline__ void gather_features(const FeatSrc& f, int r0, int R, int NS, float* dst, int ld, int tid,
                                                 int nthreads) {
     int col0 = 0;

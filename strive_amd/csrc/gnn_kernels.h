@@ -18,16 +18,16 @@ struct Node1Lds {
     float *in, *pre, *act, *xs, *po;
     __device__ Node1Lds(float* base, int in_ld, int xs_ld) {
         in = base;
-        pre = in + RB * in_ld;
-        act = pre + 2 * RB * HLD;
-        xs = act + RB * HLD;
-        po = xs + RB * xs_ld;
+        pre = in + RB_NODE * in_ld;
+        act = pre + 2 * RB_NODE * HLD;
+        xs = act + RB_NODE * HLD;
+        po = xs + RB_NODE * xs_ld;
     }
-    static size_t bytes(int in_ld, int xs_ld) { return (size_t)(RB * in_ld + 4 * RB * HLD + RB * xs_ld) * 4; }
+    static size_t bytes(int in_ld, int xs_ld) { return (size_t)(RB_NODE * in_ld + 4 * RB_NODE * HLD + RB_NODE * xs_ld) * 4; }
 };
 
 // ---------------------------------------------------------------------------------------------
-// node kernel 1: features -> mlp_in -> x ; edge layer-0 partials P, Q.   grid = ceil(R/RB)
+// node kernel 1: features -> mlp_in -> x ; edge layer-0 partials P, Q.   grid = ceil(R/RB_NODE)
 // ---------------------------------------------------------------------------------------------
 static __global__ __launch_bounds__(256) void gnn_node1_kernel(GNNDev g, int NS, FeatSrc f, const float* __restrict__ sem,
                                                                  GnnBuffers gb, int R) {
@@ -35,17 +35,17 @@ static __global__ __launch_bounds__(256) void gnn_node1_kernel(GNNDev g, int NS,
     const int F = g.mlp_in.dims[0], D = g.D, NC = g.NC;
     const int in_ld = ld4(F), xs_ld = ld4(D + NC);
     Node1Lds L(smem, in_ld, xs_ld);
-    const int tid = threadIdx.x, r0 = blockIdx.x * RB;
-    gather_features(f, r0, R, NS, L.in, in_ld, tid, 256);
+    const int tid = threadIdx.x, r0 = blockIdx.x * RB_NODE;
+    gather_features<RB_NODE>(f, r0, R, NS, L.in, in_ld, tid, 256);
     __syncthreads();
-    mlp_forward_lds(g.mlp_in, L.in, in_ld, L.pre, L.act, L.xs, xs_ld, false, tid, 256);
+    mlp_forward_lds<RB_NODE>(g.mlp_in, L.in, in_ld, L.pre, L.act, L.xs, xs_ld, false, tid, 256);
     // append sem, publish x
-    for (int i = tid; i < RB * (xs_ld - D); i += 256) {
+    for (int i = tid; i < RB_NODE * (xs_ld - D); i += 256) {
         const int rr = i / (xs_ld - D), k = i - rr * (xs_ld - D);
         const int r = r0 + rr;
         L.xs[rr * xs_ld + D + k] = (r < R && k < NC) ? sem[(size_t)(r / NS) * NC + k] : 0.f;
     }
-    for (int i = tid; i < RB * D; i += 256) {
+    for (int i = tid; i < RB_NODE * D; i += 256) {
         const int rr = i / D, c = i - rr * D;
         if (r0 + rr < R) gb.X[(size_t)(r0 + rr) * D + c] = L.xs[rr * xs_ld + c];
     }
@@ -53,20 +53,20 @@ static __global__ __launch_bounds__(256) void gnn_node1_kernel(GNNDev g, int NS,
     // edge layer 0, rows of the transposed weight: [x_i (D) | x_j (D) | sem_i (NC) | sem_j (NC) | rel (4)] x 128
     const float* Wt = g.edge.wt[0];
     const int H = STRIVE_HID;
-    dense_lds<false>(L.xs, xs_ld, D, Wt, H, g.edge.b[0], L.po, HLD, H, tid, 256);
+    dense_lds<RB_NODE, false>(L.xs, xs_ld, D, Wt, H, g.edge.b[0], L.po, HLD, H, tid, 256);
     __syncthreads();
-    dense_lds<true>(L.xs + D, xs_ld, NC, Wt + (size_t)(2 * D) * H, H, nullptr, L.po, HLD, H, tid, 256);
+    dense_lds<RB_NODE, true>(L.xs + D, xs_ld, NC, Wt + (size_t)(2 * D) * H, H, nullptr, L.po, HLD, H, tid, 256);
     __syncthreads();
-    for (int i = tid; i < RB * H; i += 256) {
+    for (int i = tid; i < RB_NODE * H; i += 256) {
         const int rr = i / H, c = i - rr * H;
         if (r0 + rr < R) gb.P[(size_t)(r0 + rr) * H + c] = L.po[rr * HLD + c];
     }
     __syncthreads();
-    dense_lds<false>(L.xs, xs_ld, D, Wt + (size_t)D * H, H, nullptr, L.po, HLD, H, tid, 256);
+    dense_lds<RB_NODE, false>(L.xs, xs_ld, D, Wt + (size_t)D * H, H, nullptr, L.po, HLD, H, tid, 256);
     __syncthreads();
-    dense_lds<true>(L.xs + D, xs_ld, NC, Wt + (size_t)(2 * D + NC) * H, H, nullptr, L.po, HLD, H, tid, 256);
+    dense_lds<RB_NODE, true>(L.xs + D, xs_ld, NC, Wt + (size_t)(2 * D + NC) * H, H, nullptr, L.po, HLD, H, tid, 256);
     __syncthreads();
-    for (int i = tid; i < RB * H; i += 256) {
+    for (int i = tid; i < RB_NODE * H; i += 256) {
         const int rr = i / H, c = i - rr * H;
         if (r0 + rr < R) gb.Q[(size_t)(r0 + rr) * H + c] = L.po[rr * HLD + c];
     }
@@ -79,13 +79,13 @@ struct EdgeLds {
     float *rel, *pre, *act, *m;
     int* src;
     __device__ EdgeLds(float* base) {
-        rel = base;                    // [RB][4]
-        pre = rel + RB * 4;            // [2][RB][HLD]
-        act = pre + 2 * RB * HLD;      // [RB][HLD]
-        m = act + RB * HLD;            // [RB][HLD]
-        src = (int*)(m + RB * HLD);    // [RB]
+        rel = base;                    // [RB_EDGE][4]
+        pre = rel + RB_EDGE * 4;            // [2][RB_EDGE][HLD]
+        act = pre + 2 * RB_EDGE * HLD;      // [RB_EDGE][HLD]
+        m = act + RB_EDGE * HLD;            // [RB_EDGE][HLD]
+        src = (int*)(m + RB_EDGE * HLD);    // [RB_EDGE]
     }
-    static size_t bytes() { return (size_t)(RB * 4 + 4 * RB * HLD + RB) * 4; }
+    static size_t bytes() { return (size_t)(RB_EDGE * 4 + 4 * RB_EDGE * HLD + RB_EDGE) * 4; }
 };
 
 // Fill one chunk: source rows, relative poses (NaN -> 0), and the factorised edge layer 0 into pre[0].
@@ -98,9 +98,9 @@ __device__ __forceinline__ int edge_chunk_setup(const GNNDev& g, const ScenesDev
     const int b = sc.scene_of[a];
     const int lo = sc.ptr[b], n = sc.ptr[b + 1] - lo;
     const int nsrc = n - 1;
-    const int j0 = chunk * RB;
-    const int nv = (nsrc - j0) < RB ? (nsrc - j0) : RB;
-    if (tid < RB) {
+    const int j0 = chunk * RB_EDGE;
+    const int nv = (nsrc - j0) < RB_EDGE ? (nsrc - j0) : RB_EDGE;
+    if (tid < RB_EDGE) {
         int srow = -1;
         float rel[4] = {0.f, 0.f, 0.f, 0.f};
         unsigned nm = 0;
@@ -119,7 +119,7 @@ __device__ __forceinline__ int edge_chunk_setup(const GNNDev& g, const ScenesDev
     __syncthreads();
     const int H = STRIVE_HID;
     const float* Wrel = g.edge.wt[0] + (size_t)(2 * g.D + 2 * g.NC) * H;
-    for (int i = tid; i < RB * H; i += 256) {
+    for (int i = tid; i < RB_EDGE * H; i += 256) {
         const int jr = i / H, c = i - jr * H;
         float v = 0.f;
         if (jr < nv) {
@@ -146,10 +146,10 @@ static __global__ __launch_bounds__(256) void gnn_edge_kernel(GNNDev g, ScenesDe
     const int nsrc = sc.ptr[b + 1] - sc.ptr[b] - 1;
     float best = 0.f;
     int arg = -1;
-    const int nchunks = (nsrc + RB - 1) / RB;
+    const int nchunks = (nsrc + RB_EDGE - 1) / RB_EDGE;
     for (int ch = 0; ch < nchunks; ++ch) {
         const int nv = edge_chunk_setup(g, sc, pos, gb, r, ch, L, nullptr, tid);
-        mlp_forward_lds(g.edge, nullptr, 0, L.pre, L.act, L.m, HLD, true, tid, 256);
+        mlp_forward_lds<RB_EDGE>(g.edge, nullptr, 0, L.pre, L.act, L.m, HLD, true, tid, 256);
         if (tid < D) {
             for (int jr = 0; jr < nv; ++jr) {
                 const float v = L.m[jr * HLD + tid];
@@ -170,14 +170,14 @@ static __global__ __launch_bounds__(256) void gnn_edge_kernel(GNNDev g, ScenesDe
 struct Node2Lds {
     float *in, *pre_u, *act, *xp, *pre_o, *out;
     __device__ Node2Lds(float* base, int in_ld) {
-        in = base;                       // [RB][in_ld]   (x | aggr | sem)
-        pre_u = in + RB * in_ld;         // [1][RB][HLD]
-        act = pre_u + RB * HLD;          // [RB][HLD]
-        xp = act + RB * HLD;             // [RB][HLD]    x' (D wide)
-        pre_o = xp + RB * HLD;           // [2][RB][HLD]
-        out = pre_o + 2 * RB * HLD;      // [RB][HLD]
+        in = base;                       // [RB_NODE][in_ld]   (x | aggr | sem)
+        pre_u = in + RB_NODE * in_ld;         // [1][RB_NODE][HLD]
+        act = pre_u + RB_NODE * HLD;          // [RB_NODE][HLD]
+        xp = act + RB_NODE * HLD;             // [RB_NODE][HLD]    x' (D wide)
+        pre_o = xp + RB_NODE * HLD;           // [2][RB_NODE][HLD]
+        out = pre_o + 2 * RB_NODE * HLD;      // [RB_NODE][HLD]
     }
-    static size_t floats(int in_ld) { return (size_t)(RB * in_ld + 6 * RB * HLD); }
+    static size_t floats(int in_ld) { return (size_t)(RB_NODE * in_ld + 6 * RB_NODE * HLD); }
 };
 
 // Leaves update/mlp_out pre-activations and outputs in LDS (the rollout backward re-uses them).
@@ -185,7 +185,7 @@ __device__ __forceinline__ void node2_forward(const GNNDev& g, int NS, const flo
                                               const float* __restrict__ A, const float* __restrict__ sem, int r0, int R,
                                               Node2Lds& L, int in_ld, int tid) {
     const int D = g.D, NC = g.NC;
-    for (int i = tid; i < RB * in_ld; i += 256) {
+    for (int i = tid; i < RB_NODE * in_ld; i += 256) {
         const int rr = i / in_ld, k = i - rr * in_ld;
         const int r = r0 + rr;
         float v = 0.f;
@@ -197,8 +197,8 @@ __device__ __forceinline__ void node2_forward(const GNNDev& g, int NS, const flo
         L.in[i] = v;
     }
     __syncthreads();
-    mlp_forward_lds(g.update, L.in, in_ld, L.pre_u, L.act, L.xp, HLD, false, tid, 256);
-    mlp_forward_lds(g.mlp_out, L.xp, HLD, L.pre_o, L.act, L.out, HLD, false, tid, 256);
+    mlp_forward_lds<RB_NODE>(g.update, L.in, in_ld, L.pre_u, L.act, L.xp, HLD, false, tid, 256);
+    mlp_forward_lds<RB_NODE>(g.mlp_out, L.xp, HLD, L.pre_o, L.act, L.out, HLD, false, tid, 256);
 }
 
 static __global__ __launch_bounds__(256) void gnn_node2_kernel(GNNDev g, int NS, const float* __restrict__ sem, GnnBuffers gb,
@@ -206,10 +206,10 @@ static __global__ __launch_bounds__(256) void gnn_node2_kernel(GNNDev g, int NS,
     HIP_DYNAMIC_SHARED(float, smem)
     const int in_ld = ld4(2 * g.D + g.NC);
     Node2Lds L(smem, in_ld);
-    const int tid = threadIdx.x, r0 = blockIdx.x * RB;
+    const int tid = threadIdx.x, r0 = blockIdx.x * RB_NODE;
     node2_forward(g, NS, gb.X, gb.A, sem, r0, R, L, in_ld, tid);
     const int O = g.mlp_out.dims[g.mlp_out.nlayers];
-    for (int i = tid; i < RB * O; i += 256) {
+    for (int i = tid; i < RB_NODE * O; i += 256) {
         const int rr = i / O, c = i - rr * O;
         if (r0 + rr < R) out[(size_t)(r0 + rr) * O + c] = L.out[rr * HLD + c];
     }
@@ -236,7 +236,7 @@ static inline int gnn_forward_launch(const StriveGNN& g, const StriveScenes& sc,
     const GNNDev gd = gnn_dev(g);
     const ScenesDev sd = scenes_dev(sc);
     const int in_ld = ld4(g.mlp_in.dims[0]), xs_ld = ld4(g.D + g.NC);
-    const int nb = (R + RB - 1) / RB;
+    const int nb = (R + RB_NODE - 1) / RB_NODE;
     hipLaunchKernelGGL(gnn_node1_kernel, dim3(nb), dim3(256), Node1Lds::bytes(in_ld, xs_ld), stream, gd, sc.NS, f, sem, gb, R);
     hipLaunchKernelGGL(gnn_edge_kernel, dim3(R), dim3(256), EdgeLds::bytes(), stream, gd, sd, pos, gb);
     if (out) {

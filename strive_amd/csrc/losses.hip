@@ -32,18 +32,24 @@ __device__ __forceinline__ void circle_centres(const VehArgs& a, int ag, int t, 
     }
 }
 
+// A group of VG consecutive lanes owns one (agent i, time t): lane g of the group handles the scene members
+// jl = g, g + VG, ... so a 16-agent scene is one pass, and the backward reduces the group's partial gradients
+// with shuffles (deterministic, no atomics).
+#define VG 16
+
 __global__ __launch_bounds__(256) void veh_coll_fwd_kernel(VehArgs a, float* __restrict__ pen, uint8_t* __restrict__ hit,
                                                              uint8_t* __restrict__ amin) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.NA * a.T) return;
-    const int i = idx / a.T, t = idx - i * a.T;
+    const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / VG;
+    const int sub = threadIdx.x & (VG - 1);
+    if (gid >= a.NA * a.T) return;
+    const int i = gid / a.T, t = gid - i * a.T;
     const int b = a.scene_of[i];
     const int lo = a.ptr[b], n = a.ptr[b + 1] - lo;
     float ax[NCIRC], ay[NCIRC];
     circle_centres(a, i, t, ax, ay);
     const float ri = a.rad[i];
     const size_t base = (size_t)t * a.P + a.pair_off[i];
-    for (int jl = 0; jl < n; ++jl) {
+    for (int jl = sub; jl < n; jl += VG) {
         const int j = lo + jl;
         float bx[NCIRC], by[NCIRC];
         circle_centres(a, j, t, bx, by);
@@ -65,9 +71,11 @@ __global__ __launch_bounds__(256) void veh_coll_fwd_kernel(VehArgs a, float* __r
 // d_traj[i][t] += sum_j [ d_pen(i,j) * dpen(i,j)/dpose_i  +  d_pen(j,i) * dpen(j,i)/dpose_i ]
 __global__ __launch_bounds__(256) void veh_coll_bwd_kernel(VehArgs a, const float* __restrict__ d_pen,
                                                              const uint8_t* __restrict__ amin, float* __restrict__ d_traj) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.NA * a.T) return;
-    const int i = idx / a.T, t = idx - i * a.T;
+    const int gid_raw = (blockIdx.x * blockDim.x + threadIdx.x) / VG;
+    const int sub = threadIdx.x & (VG - 1);
+    const bool live = gid_raw < a.NA * a.T;      // whole groups are live or not; every lane stays for the shuffles
+    const int gid = live ? gid_raw : 0;
+    const int i = gid / a.T, t = gid - i * a.T;
     const int b = a.scene_of[i];
     const int lo = a.ptr[b], n = a.ptr[b + 1] - lo;
     float ax[NCIRC], ay[NCIRC];
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(256) void veh_coll_bwd_kernel(VehArgs a, const floa
     const float ri = a.rad[i];
     const int il = i - lo;
     float g[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int jl = 0; jl < n; ++jl) {
+    for (int jl = sub; live && jl < n; jl += VG) {
         const int j = lo + jl;
         if (j == i) continue;
         float bx[NCIRC], by[NCIRC];
@@ -116,8 +124,14 @@ __global__ __launch_bounds__(256) void veh_coll_bwd_kernel(VehArgs a, const floa
             }
         }
     }
-    float* o = d_traj + ((size_t)i * a.T + t) * 4;
-    for (int k = 0; k < 4; ++k) o[k] += g[k];
+#pragma unroll
+    for (int m = VG / 2; m >= 1; m >>= 1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] += __shfl_xor(g[k], m);
+    if (live && sub == 0) {
+        float* o = d_traj + ((size_t)i * a.T + t) * 4;
+        for (int k = 0; k < 4; ++k) o[k] += g[k];
+    }
 }
 
 static VehArgs veh_args(const StriveScenes* sc, const int32_t* pair_off, int P, const float* traj, int T,
@@ -133,9 +147,9 @@ extern "C" int strive_veh_coll_fwd(const StriveScenes* sc, const int32_t* pair_o
                                    uint8_t* amin, strive_stream_t stream) {
     STRIVE_CHECK_ARG(sc && pair_off && traj && cent_x && rad && pen && hit && amin, "null argument");
     STRIVE_CHECK_ARG(sc->NS == 1, "collision losses take one trajectory per agent");
-    const int n = sc->NA * T;
+    const long long n = (long long)sc->NA * T * VG;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(veh_coll_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(veh_coll_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        veh_args(sc, pair_off, P, traj, T, cent_x, rad, buffer), pen, hit, amin);
     STRIVE_CHECK_LAUNCH();
     return 0;
@@ -146,9 +160,9 @@ extern "C" int strive_veh_coll_bwd(const StriveScenes* sc, const int32_t* pair_o
                                    const uint8_t* amin, float* d_traj, strive_stream_t stream) {
     STRIVE_CHECK_ARG(sc && pair_off && traj && cent_x && rad && d_pen && amin && d_traj, "null argument");
     STRIVE_CHECK_ARG(sc->NS == 1, "collision losses take one trajectory per agent");
-    const int n = sc->NA * T;
+    const long long n = (long long)sc->NA * T * VG;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(veh_coll_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(veh_coll_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        veh_args(sc, pair_off, P, traj, T, cent_x, rad, buffer), d_pen, amin, d_traj);
     STRIVE_CHECK_LAUNCH();
     return 0;

@@ -10,13 +10,14 @@
 #pragma once
 #include "common.h"
 
-#define RB 16          // rows per workgroup block
+#define RB_EDGE 16     // source rows per chunk in the per-target edge kernels
+#define RB_NODE 8      // rows per workgroup in the per-node kernels (more workgroups: these are latency bound)
 #define RPT 4          // rows per thread item
 #define LN_EPS 1e-5f
 
 // out[r][c] (+)= bias[c] + sum_k in[r][k] * Wt[k*ldw + c],  r < RB, c < OUT.
 // in_ld, out_ld multiples of 4; `in` 16-byte aligned.
-template <bool ACCUM>
+template <int RB, bool ACCUM>
 __device__ __forceinline__ void dense_lds(const float* in, int in_ld, int IN, const float* __restrict__ Wt, int ldw,
                                           const float* __restrict__ bias, float* out, int out_ld, int OUT, int tid,
                                           int nthreads) {
@@ -57,6 +58,7 @@ __device__ __forceinline__ void dense_lds(const float* in, int in_ld, int IN, co
 }
 
 // y = relu(layer_norm(x)) row-wise over N channels (one wave per row, two-pass mean/variance).
+template <int RB>
 __device__ __forceinline__ void ln_relu_rows(const float* x, int x_ld, float* y, int y_ld, int N,
                                              const float* __restrict__ g, const float* __restrict__ b, int tid,
                                              int nthreads) {
@@ -80,6 +82,7 @@ __device__ __forceinline__ void ln_relu_rows(const float* x, int x_ld, float* y,
 
 // Backward of y = relu(layer_norm(x)):  dx from dy, recomputing the normalisation from x (pre-LN).
 // dx may alias dy.
+template <int RB>
 __device__ __forceinline__ void ln_relu_bwd_rows(const float* x, int x_ld, const float* dy, int dy_ld, float* dx,
                                                  int dx_ld, int N, const float* __restrict__ g,
                                                  const float* __restrict__ b, int tid, int nthreads) {
@@ -146,20 +149,21 @@ static inline MLPDev mlp_dev(const StriveMLP& m) {
 //   act : LDS [RB][HLD]   scratch for the post-ReLU activations (overwritten layer by layer)
 //   out : LDS [RB][out_ld]
 // first_done: layer 0's linear output is already in pre[0] (used by the factorised edge layer).
+template <int RB>
 __device__ __forceinline__ void mlp_forward_lds(const MLPDev& m, const float* in, int in_ld, float* pre, float* act,
                                                 float* out, int out_ld, bool first_done, int tid, int nthreads) {
     const int L = m.nlayers;
     if (!first_done) {
-        dense_lds<false>(in, in_ld, m.dims[0], m.wt[0], m.dims[1], m.b[0], (L == 1) ? out : pre, (L == 1) ? out_ld : HLD,
+        dense_lds<RB, false>(in, in_ld, m.dims[0], m.wt[0], m.dims[1], m.b[0], (L == 1) ? out : pre, (L == 1) ? out_ld : HLD,
                          m.dims[1], tid, nthreads);
         __syncthreads();
     }
     for (int l = 1; l < L; ++l) {
         float* p = pre + (size_t)(l - 1) * RB * HLD;
-        ln_relu_rows(p, HLD, act, HLD, m.dims[l], m.ln_g[l - 1], m.ln_b[l - 1], tid, nthreads);
+        ln_relu_rows<RB>(p, HLD, act, HLD, m.dims[l], m.ln_g[l - 1], m.ln_b[l - 1], tid, nthreads);
         __syncthreads();
         const bool last = (l == L - 1);
-        dense_lds<false>(act, HLD, m.dims[l], m.wt[l], m.dims[l + 1], m.b[l], last ? out : pre + (size_t)l * RB * HLD,
+        dense_lds<RB, false>(act, HLD, m.dims[l], m.wt[l], m.dims[l + 1], m.b[l], last ? out : pre + (size_t)l * RB * HLD,
                          last ? out_ld : HLD, m.dims[l + 1], tid, nthreads);
         __syncthreads();
     }
@@ -170,6 +174,7 @@ __device__ __forceinline__ void mlp_forward_lds(const MLPDev& m, const float* in
 //   ga, gb : LDS [RB][HLD] scratch
 //   din  : LDS [RB][din_ld] gradient w.r.t. the layer-0 input; if skip_first, the gradient w.r.t. layer 0's
 //          linear OUTPUT (pre[0]) is left in `ga` instead and din is untouched.
+template <int RB>
 __device__ __forceinline__ void mlp_backward_lds(const MLPDev& m, const float* pre, const float* dout, int dout_ld,
                                                  float* ga, float* gb, float* din, int din_ld, bool skip_first, int tid,
                                                  int nthreads) {
@@ -178,16 +183,16 @@ __device__ __forceinline__ void mlp_backward_lds(const MLPDev& m, const float* p
     int g_ld = dout_ld;
     for (int l = L - 1; l >= 1; --l) {
         // gradient w.r.t. the post-ReLU activation feeding layer l: gb = g * W_l   (W_l torch layout (out,in))
-        dense_lds<false>(g, g_ld, m.dims[l + 1], m.w[l], m.dims[l], nullptr, gb, HLD, m.dims[l], tid, nthreads);
+        dense_lds<RB, false>(g, g_ld, m.dims[l + 1], m.w[l], m.dims[l], nullptr, gb, HLD, m.dims[l], tid, nthreads);
         __syncthreads();
         const float* p = pre + (size_t)(l - 1) * RB * HLD;
-        ln_relu_bwd_rows(p, HLD, gb, HLD, ga, HLD, m.dims[l], m.ln_g[l - 1], m.ln_b[l - 1], tid, nthreads);
+        ln_relu_bwd_rows<RB>(p, HLD, gb, HLD, ga, HLD, m.dims[l], m.ln_g[l - 1], m.ln_b[l - 1], tid, nthreads);
         __syncthreads();
         g = ga;
         g_ld = HLD;
     }
     if (!skip_first) {
-        dense_lds<false>(g, g_ld, m.dims[1], m.w[0], m.dims[0], nullptr, din, din_ld, m.dims[0], tid, nthreads);
+        dense_lds<RB, false>(g, g_ld, m.dims[1], m.w[0], m.dims[0], nullptr, din, din_ld, m.dims[0], tid, nthreads);
         __syncthreads();
     }
 }

@@ -11,19 +11,19 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MLPDev m, const float* __r
     const int F = m.dims[0], O = m.dims[m.nlayers];
     const int in_ld = (F + 3) & ~3;
     float* s_in = smem;
-    float* s_pre = s_in + RB * in_ld;
-    float* s_act = s_pre + (STRIVE_MAX_LAYERS - 1) * RB * HLD;
-    float* s_out = s_act + RB * HLD;
-    const int tid = threadIdx.x, r0 = blockIdx.x * RB;
+    float* s_pre = s_in + RB_NODE * in_ld;
+    float* s_act = s_pre + (STRIVE_MAX_LAYERS - 1) * RB_NODE * HLD;
+    float* s_out = s_act + RB_NODE * HLD;
+    const int tid = threadIdx.x, r0 = blockIdx.x * RB_NODE;
     FeatSrc f;
     f.n = 1;
     f.p[0] = x;
     f.w[0] = F;
     f.per_agent[0] = 0;
-    gather_features(f, r0, rows, 1, s_in, in_ld, tid, 256);
+    gather_features<RB_NODE>(f, r0, rows, 1, s_in, in_ld, tid, 256);
     __syncthreads();
-    mlp_forward_lds(m, s_in, in_ld, s_pre, s_act, s_out, HLD, false, tid, 256);
-    for (int i = tid; i < RB * O; i += 256) {
+    mlp_forward_lds<RB_NODE>(m, s_in, in_ld, s_pre, s_act, s_out, HLD, false, tid, 256);
+    for (int i = tid; i < RB_NODE * O; i += 256) {
         const int rr = i / O, c = i - rr * O;
         if (r0 + rr < rows) y[(size_t)(r0 + rr) * O + c] = s_out[rr * HLD + c];
     }
@@ -36,8 +36,8 @@ extern "C" int strive_mlp_fwd(const StriveMLP* mlp, const float* x, int32_t rows
     STRIVE_CHECK_ARG(mlp->dims[mlp->nlayers] <= STRIVE_HID && mlp->dims[0] <= 512, "layer too wide");
     if (rows <= 0) return 0;
     const int in_ld = (mlp->dims[0] + 3) & ~3;
-    const size_t lds = (size_t)(RB * in_ld + (STRIVE_MAX_LAYERS - 1) * RB * HLD + 2 * RB * HLD) * 4;
-    hipLaunchKernelGGL(mlp_fwd_kernel, dim3((rows + RB - 1) / RB), dim3(256), lds, (hipStream_t)stream, mlp_dev(*mlp), x,
+    const size_t lds = (size_t)(RB_NODE * in_ld + (STRIVE_MAX_LAYERS - 1) * RB_NODE * HLD + 2 * RB_NODE * HLD) * 4;
+    hipLaunchKernelGGL(mlp_fwd_kernel, dim3((rows + RB_NODE - 1) / RB_NODE), dim3(256), lds, (hipStream_t)stream, mlp_dev(*mlp), x,
                        rows, y);
     STRIVE_CHECK_LAUNCH();
     return 0;

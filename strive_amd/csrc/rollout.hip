@@ -127,14 +127,14 @@ __device__ __forceinline__ void bike_backward(const DynParams& p, const BikeFwd&
 #define GLD 192
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// x: LDS [RB][xld] (layer input), h: LDS [RB][64] (layer hidden), gi/gh: LDS [RB][GLD] scratch.
-// Writes the new hidden into hn [RB][64]; if gates != null stores (r,z,n,gh_n) at gates[RB][4*64].
+// x: LDS [RB_NODE][xld] (layer input), h: LDS [RB_NODE][64] (layer hidden), gi/gh: LDS [RB_NODE][GLD] scratch.
+// Writes the new hidden into hn [RB_NODE][64]; if gates != null stores (r,z,n,gh_n) at gates[RB_NODE][4*64].
 __device__ __forceinline__ void gru_layer_lds(const GRUDev& g, int l, const float* x, int xld, int xin, const float* h,
                                               float* gi, float* gh, float* hn, float* gates, int tid) {
-    dense_lds<false>(x, xld, xin, g.wih_t[l], GLD, g.bih[l], gi, GLD, GLD, tid, 256);
-    dense_lds<false>(h, 64, 64, g.whh_t[l], GLD, g.bhh[l], gh, GLD, GLD, tid, 256);
+    dense_lds<RB_NODE, false>(x, xld, xin, g.wih_t[l], GLD, g.bih[l], gi, GLD, GLD, tid, 256);
+    dense_lds<RB_NODE, false>(h, 64, 64, g.whh_t[l], GLD, g.bhh[l], gh, GLD, GLD, tid, 256);
     __syncthreads();
-    for (int i = tid; i < RB * 64; i += 256) {
+    for (int i = tid; i < RB_NODE * 64; i += 256) {
         const int rr = i >> 6, c = i & 63;
         const float r = sigmoidf_(gi[rr * GLD + c] + gh[rr * GLD + c]);
         const float z = sigmoidf_(gi[rr * GLD + 64 + c] + gh[rr * GLD + 64 + c]);
@@ -152,7 +152,7 @@ __device__ __forceinline__ void gru_layer_lds(const GRUDev& g, int l, const floa
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward step kernel: node2 + dynamics + GRU.   grid = ceil(R/RB)
+// forward step kernel: node2 + dynamics + GRU.   grid = ceil(R/RB_NODE)
 // ---------------------------------------------------------------------------------------------
 struct StepArgs {
     int t, FT, R, NS;
@@ -169,15 +169,15 @@ static __global__ __launch_bounds__(256) void rollout_node2_kernel(GNNDev g, GRU
     HIP_DYNAMIC_SHARED(float, smem)
     const int in_ld = ld4(2 * g.D + g.NC);
     Node2Lds L(smem, in_ld);
-    float* s_x = L.out + RB * HLD;        // [RB][4]  GRU input (local pose)
-    float* s_h = s_x + RB * 4;            // [RB][64]    hidden input of the current layer
-    float* s_hn = s_h + RB * 64;          // [2][RB][64] layer outputs, ping-pong (layer l+1 reads layer l's as input)
-    float* s_gi = s_hn + 2 * RB * 64;     // [RB][GLD]
-    float* s_gh = s_gi + RB * GLD;        // [RB][GLD]
-    const int tid = threadIdx.x, r0 = blockIdx.x * RB, t = a.t;
+    float* s_x = L.out + RB_NODE * HLD;        // [RB_NODE][4]  GRU input (local pose)
+    float* s_h = s_x + RB_NODE * 4;            // [RB_NODE][64]    hidden input of the current layer
+    float* s_hn = s_h + RB_NODE * 64;          // [2][RB_NODE][64] layer outputs, ping-pong (layer l+1 reads layer l's as input)
+    float* s_gi = s_hn + 2 * RB_NODE * 64;     // [RB_NODE][GLD]
+    float* s_gh = s_gi + RB_NODE * GLD;        // [RB_NODE][GLD]
+    const int tid = threadIdx.x, r0 = blockIdx.x * RB_NODE, t = a.t;
     node2_forward(g, a.NS, a.X, tp.A_t(t), a.sem, r0, a.R, L, in_ld, tid);
     const bool more = t < a.FT - 1;
-    if (tid < RB) {
+    if (tid < RB_NODE) {
         const int r = r0 + tid;
         float loc[4] = {0.f, 0.f, 0.f, 0.f};
         if (r < a.R) {
@@ -213,15 +213,15 @@ static __global__ __launch_bounds__(256) void rollout_node2_kernel(GNNDev g, GRU
     int xld = 4, xin = 4;
     for (int l = 0; l < 3; ++l) {
         __syncthreads();
-        for (int i = tid; i < RB * 64; i += 256) {
+        for (int i = tid; i < RB_NODE * 64; i += 256) {
             const int rr = i >> 6, c = i & 63;
             const int r = r0 + rr;
             s_h[i] = (r < a.R) ? tp.mem_t(t)[((size_t)r * 3 + l) * 64 + c] : 0.f;
         }
         __syncthreads();
-        float* hn = s_hn + (size_t)(l & 1) * RB * 64;
+        float* hn = s_hn + (size_t)(l & 1) * RB_NODE * 64;
         gru_layer_lds(gru, l, x, xld, xin, s_h, s_gi, s_gh, hn, nullptr, tid);
-        for (int i = tid; i < RB * 64; i += 256) {
+        for (int i = tid; i < RB_NODE * 64; i += 256) {
             const int rr = i >> 6, c = i & 63;
             const int r = r0 + rr;
             if (r < a.R) {
@@ -304,7 +304,7 @@ FeatSrc decoder_features(const Tape& tp, int t, const float* sem, const float* z
     return f;
 }
 
-size_t node2r_lds_bytes(int in_ld) { return (Node2Lds::floats(in_ld) + RB * 4 + 3 * RB * 64 + 2 * RB * GLD) * 4; }
+size_t node2r_lds_bytes(int in_ld) { return (Node2Lds::floats(in_ld) + RB_NODE * 4 + 3 * RB_NODE * 64 + 2 * RB_NODE * GLD) * 4; }
 
 int check_decoder(const StriveDecoder* dec, const StriveScenes* sc, int FT) {
     if (gnn_check(dec->gnn)) return -1;
@@ -351,7 +351,7 @@ extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* 
     const ScenesDev sd = scenes_dev(*sc);
     const int NC = dec->gnn.NC;
     const int in_ld1 = ld4(dec->gnn.mlp_in.dims[0]), xs_ld = ld4(64 + NC), in_ld2 = ld4(128 + NC);
-    const int nb = (int)((R + RB - 1) / RB);
+    const int nb = (int)((R + RB_NODE - 1) / RB_NODE);
 
     hipLaunchKernelGGL(rollout_init_kernel, dim3((unsigned)((R * 64 + 255) / 256)), dim3(256), 0, stream, tp, past_last,
                        past_feat, map_feat, mapix, w.mapix_rows, (int)R, sc->NS);
@@ -382,40 +382,40 @@ extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* 
 // =============================================================================================
 
 // ---- GRU backward for rows r0.. : consumes g_mem (adjoint of mem_{t+1}) and g_pf (adjoint of past_feat_{t+1}),
-//      produces g_mem (adjoint of mem_t) and d_loc (adjoint of the local pose fed to the GRU).  grid = ceil(R/RB)
+//      produces g_mem (adjoint of mem_t) and d_loc (adjoint of the local pose fed to the GRU).  grid = ceil(R/RB_NODE)
 static __global__ __launch_bounds__(256) void gru_bwd_kernel(GRUDev gru, Tape tp, int t, int R, const float* __restrict__ g_pf,
                                                                float* __restrict__ g_mem, float* __restrict__ d_loc) {
     HIP_DYNAMIC_SHARED(float, smem)
-    float* s_x = smem;                      // [RB][4]
-    float* s_h = s_x + RB * 4;              // [3][RB][64]   layer hidden inputs (mem_t)
-    float* s_hn = s_h + 3 * RB * 64;        // [3][RB][64]   layer outputs
-    float* s_gi = s_hn + 3 * RB * 64;       // [RB][GLD]
-    float* s_gh = s_gi + RB * GLD;          // [RB][GLD]
-    float* s_g = s_gh + RB * GLD;           // [3][RB][256]  gates r,z,n,gh_n
-    float* s_dx = s_g + 3 * RB * 256;       // [RB][64]      adjoint flowing to the layer below
-    const int tid = threadIdx.x, r0 = blockIdx.x * RB;
-    for (int i = tid; i < RB * 4; i += 256) {
+    float* s_x = smem;                      // [RB_NODE][4]
+    float* s_h = s_x + RB_NODE * 4;              // [3][RB_NODE][64]   layer hidden inputs (mem_t)
+    float* s_hn = s_h + 3 * RB_NODE * 64;        // [3][RB_NODE][64]   layer outputs
+    float* s_gi = s_hn + 3 * RB_NODE * 64;       // [RB_NODE][GLD]
+    float* s_gh = s_gi + RB_NODE * GLD;          // [RB_NODE][GLD]
+    float* s_g = s_gh + RB_NODE * GLD;           // [3][RB_NODE][256]  gates r,z,n,gh_n
+    float* s_dx = s_g + 3 * RB_NODE * 256;       // [RB_NODE][64]      adjoint flowing to the layer below
+    const int tid = threadIdx.x, r0 = blockIdx.x * RB_NODE;
+    for (int i = tid; i < RB_NODE * 4; i += 256) {
         const int r = r0 + (i >> 2);
         s_x[i] = (r < R) ? tp.loc_t(t)[(size_t)r * 4 + (i & 3)] : 0.f;
     }
-    for (int i = tid; i < 3 * RB * 64; i += 256) {
-        const int l = i / (RB * 64), rem = i - l * RB * 64;
+    for (int i = tid; i < 3 * RB_NODE * 64; i += 256) {
+        const int l = i / (RB_NODE * 64), rem = i - l * RB_NODE * 64;
         const int r = r0 + (rem >> 6), c = rem & 63;
         s_h[i] = (r < R) ? tp.mem_t(t)[((size_t)r * 3 + l) * 64 + c] : 0.f;
     }
     __syncthreads();
     // forward recompute
     for (int l = 0; l < 3; ++l) {
-        const float* x = (l == 0) ? s_x : s_hn + (size_t)(l - 1) * RB * 64;
-        gru_layer_lds(gru, l, x, l == 0 ? 4 : 64, l == 0 ? 4 : 64, s_h + (size_t)l * RB * 64, s_gi, s_gh,
-                      s_hn + (size_t)l * RB * 64, s_g + (size_t)l * RB * 256, tid);
+        const float* x = (l == 0) ? s_x : s_hn + (size_t)(l - 1) * RB_NODE * 64;
+        gru_layer_lds(gru, l, x, l == 0 ? 4 : 64, l == 0 ? 4 : 64, s_h + (size_t)l * RB_NODE * 64, s_gi, s_gh,
+                      s_hn + (size_t)l * RB_NODE * 64, s_g + (size_t)l * RB_NODE * 256, tid);
     }
     // backward, top layer first
     for (int l = 2; l >= 0; --l) {
-        float* gates = s_g + (size_t)l * RB * 256;
-        const float* h = s_h + (size_t)l * RB * 64;
+        float* gates = s_g + (size_t)l * RB_NODE * 256;
+        const float* h = s_h + (size_t)l * RB_NODE * 64;
         // gate pre-activation adjoints into s_gi (d gi) and s_gh (d gh)
-        for (int i = tid; i < RB * 64; i += 256) {
+        for (int i = tid; i < RB_NODE * 64; i += 256) {
             const int rr = i >> 6, c = i & 63;
             const int r = r0 + rr;
             float dh = 0.f;
@@ -439,29 +439,29 @@ static __global__ __launch_bounds__(256) void gru_bwd_kernel(GRUDev gru, Tape tp
             s_gh[rr * GLD + 64 + c] = dpz;
             s_gh[rr * GLD + 128 + c] = dpn * rg;
             // direct path h' = ... + z*h
-            s_hn[(size_t)l * RB * 64 + i] = dh * z;
+            s_hn[(size_t)l * RB_NODE * 64 + i] = dh * z;
         }
         __syncthreads();
         // adjoint of the hidden input: dh*z + dgh * W_hh ; adjoint of the layer input: dgi * W_ih
-        dense_lds<true>(s_gh, GLD, GLD, gru.whh[l], 64, nullptr, s_hn + (size_t)l * RB * 64, 64, 64, tid, 256);
+        dense_lds<RB_NODE, true>(s_gh, GLD, GLD, gru.whh[l], 64, nullptr, s_hn + (size_t)l * RB_NODE * 64, 64, 64, tid, 256);
         const int xin = (l == 0) ? 4 : 64;
-        dense_lds<false>(s_gi, GLD, GLD, gru.wih[l], xin, nullptr, s_dx, 64, xin, tid, 256);
+        dense_lds<RB_NODE, false>(s_gi, GLD, GLD, gru.wih[l], xin, nullptr, s_dx, 64, xin, tid, 256);
         __syncthreads();
-        for (int i = tid; i < RB * 64; i += 256) {
+        for (int i = tid; i < RB_NODE * 64; i += 256) {
             const int r = r0 + (i >> 6), c = i & 63;
-            if (r < R) g_mem[((size_t)r * 3 + l) * 64 + c] = s_hn[(size_t)l * RB * 64 + i];
+            if (r < R) g_mem[((size_t)r * 3 + l) * 64 + c] = s_hn[(size_t)l * RB_NODE * 64 + i];
         }
         __syncthreads();
     }
-    for (int i = tid; i < RB * 4; i += 256) {
+    for (int i = tid; i < RB_NODE * 4; i += 256) {
         const int rr = i >> 2, r = r0 + rr;
         if (r < R) d_loc[(size_t)r * 4 + (i & 3)] = s_dx[rr * 64 + (i & 3)];
     }
 }
 
-static size_t gru_bwd_lds_bytes() { return (size_t)(RB * 4 + 6 * RB * 64 + 2 * RB * GLD + 3 * RB * 256 + RB * 64) * 4; }
+static size_t gru_bwd_lds_bytes() { return (size_t)(RB_NODE * 4 + 6 * RB_NODE * 64 + 2 * RB_NODE * GLD + 3 * RB_NODE * 256 + RB_NODE * 64) * 4; }
 
-// ---- node2 backward: dynamics + mlp_out + update.  grid = ceil(R/RB)
+// ---- node2 backward: dynamics + mlp_out + update.  grid = ceil(R/RB_NODE)
 struct Node2BwdArgs {
     int t, FT, R, NS;
     const float* X;
@@ -482,15 +482,15 @@ static __global__ __launch_bounds__(256) void node2_bwd_kernel(GNNDev g, DynPara
     HIP_DYNAMIC_SHARED(float, smem)
     const int in_ld = ld4(2 * g.D + g.NC);
     Node2Lds L(smem, in_ld);
-    float* s_go = L.out + RB * HLD;      // [RB][4]  gradient w.r.t. decoder output (2 used)
-    float* s_ga = s_go + RB * 4;         // [RB][HLD]
-    float* s_gb = s_ga + RB * HLD;       // [RB][HLD]
-    float* s_gx = s_gb + RB * HLD;       // [RB][HLD] gradient w.r.t. x'
-    float* s_gin = s_gx + RB * HLD;      // [RB][in_ld]
-    const int tid = threadIdx.x, r0 = blockIdx.x * RB, t = a.t;
+    float* s_go = L.out + RB_NODE * HLD;      // [RB_NODE][4]  gradient w.r.t. decoder output (2 used)
+    float* s_ga = s_go + RB_NODE * 4;         // [RB_NODE][HLD]
+    float* s_gb = s_ga + RB_NODE * HLD;       // [RB_NODE][HLD]
+    float* s_gx = s_gb + RB_NODE * HLD;       // [RB_NODE][HLD] gradient w.r.t. x'
+    float* s_gin = s_gx + RB_NODE * HLD;      // [RB_NODE][in_ld]
+    const int tid = threadIdx.x, r0 = blockIdx.x * RB_NODE, t = a.t;
     node2_forward(g, a.NS, a.X, tp.A_t(t), a.sem, r0, a.R, L, in_ld, tid);
     const bool more = t < a.FT - 1;
-    if (tid < RB) {
+    if (tid < RB_NODE) {
         const int r = r0 + tid;
         float gdec[2] = {0.f, 0.f};
         if (r < a.R) {
@@ -532,10 +532,10 @@ static __global__ __launch_bounds__(256) void node2_bwd_kernel(GNNDev g, DynPara
         s_go[tid * 4 + 3] = 0.f;
     }
     __syncthreads();
-    mlp_backward_lds(g.mlp_out, L.pre_o, s_go, 4, s_ga, s_gb, s_gx, HLD, false, tid, 256);
-    mlp_backward_lds(g.update, L.pre_u, s_gx, HLD, s_ga, s_gb, s_gin, in_ld, false, tid, 256);
+    mlp_backward_lds<RB_NODE>(g.mlp_out, L.pre_o, s_go, 4, s_ga, s_gb, s_gx, HLD, false, tid, 256);
+    mlp_backward_lds<RB_NODE>(g.update, L.pre_u, s_gx, HLD, s_ga, s_gb, s_gin, in_ld, false, tid, 256);
     const int D = g.D;
-    for (int i = tid; i < RB * D; i += 256) {
+    for (int i = tid; i < RB_NODE * D; i += 256) {
         const int rr = i / D, c = i - rr * D;
         if (r0 + rr < a.R) {
             a.dX[(size_t)(r0 + rr) * D + c] = s_gin[rr * in_ld + c];
@@ -544,7 +544,7 @@ static __global__ __launch_bounds__(256) void node2_bwd_kernel(GNNDev g, DynPara
     }
 }
 
-static size_t node2_bwd_lds_bytes(int in_ld) { return (Node2Lds::floats(in_ld) + RB * 4 + 3 * RB * HLD + RB * in_ld) * 4; }
+static size_t node2_bwd_lds_bytes(int in_ld) { return (Node2Lds::floats(in_ld) + RB_NODE * 4 + 3 * RB_NODE * HLD + RB_NODE * in_ld) * 4; }
 
 // ---- edge backward: one workgroup per target row.  grid = R
 struct EdgeBwdArgs {
@@ -560,34 +560,34 @@ static __global__ __launch_bounds__(256) void edge_bwd_kernel(GNNDev g, ScenesDe
                                                                 EdgeBwdArgs a) {
     HIP_DYNAMIC_SHARED(float, smem)
     EdgeLds L(smem);
-    float* s_ga = (float*)(L.src + RB);       // [RB][HLD]
-    float* s_gb = s_ga + RB * HLD;            // [RB][HLD]
-    float* s_grel = s_gb + RB * HLD;          // [RB][4]
-    float* s_gfr = s_grel + RB * 4;           // [RB][4]
-    unsigned* s_nan = (unsigned*)(s_gfr + RB * 4);   // [RB]
+    float* s_ga = (float*)(L.src + RB_EDGE);       // [RB_EDGE][HLD]
+    float* s_gb = s_ga + RB_EDGE * HLD;            // [RB_EDGE][HLD]
+    float* s_grel = s_gb + RB_EDGE * HLD;          // [RB_EDGE][4]
+    float* s_gfr = s_grel + RB_EDGE * 4;           // [RB_EDGE][4]
+    unsigned* s_nan = (unsigned*)(s_gfr + RB_EDGE * 4);   // [RB_EDGE]
     const int r = blockIdx.x, tid = threadIdx.x, D = g.D, H = STRIVE_HID;
     const int ag = r / sc.NS;
     const int b = sc.scene_of[ag];
     const int lo = sc.ptr[b];
     const int nsrc = sc.ptr[b + 1] - lo - 1;
-    const int nchunks = (nsrc + RB - 1) / RB;
+    const int nchunks = (nsrc + RB_EDGE - 1) / RB_EDGE;
     const float* Wrel = g.edge.wt[0] + (size_t)(2 * D + 2 * g.NC) * H;
     float dp_acc = 0.f;                  // thread c < 128: sum over sources of d e1[.][c]
     float gfr_acc[4] = {0.f, 0.f, 0.f, 0.f};   // thread 0
     for (int ch = 0; ch < nchunks; ++ch) {
         const int nv = edge_chunk_setup(g, sc, pos, gb, r, ch, L, s_nan, tid);
-        mlp_forward_lds(g.edge, nullptr, 0, L.pre, L.act, L.m, HLD, true, tid, 256);
+        mlp_forward_lds<RB_EDGE>(g.edge, nullptr, 0, L.pre, L.act, L.m, HLD, true, tid, 256);
         // route d(aggregate) to the arg-max edge of every channel
-        for (int i = tid; i < RB * D; i += 256) {
+        for (int i = tid; i < RB_EDGE * D; i += 256) {
             const int jr = i / D, c = i - jr * D;
             float v = 0.f;
             if (jr < nv && a.ARG[(size_t)r * D + c] == L.src[jr]) v = a.dA[(size_t)r * D + c];
             L.m[jr * HLD + c] = v;
         }
         __syncthreads();
-        mlp_backward_lds(g.edge, L.pre, L.m, HLD, s_ga, s_gb, nullptr, 0, true, tid, 256);   // d e1 -> s_ga
+        mlp_backward_lds<RB_EDGE>(g.edge, L.pre, L.m, HLD, s_ga, s_gb, nullptr, 0, true, tid, 256);   // d e1 -> s_ga
         // per-edge outputs
-        for (int i = tid; i < RB * H; i += 256) {
+        for (int i = tid; i < RB_EDGE * H; i += 256) {
             const int jr = i / H, c = i - jr * H;
             if (jr < nv) {
                 const int jl = L.src[jr] / sc.NS - lo;
@@ -600,7 +600,7 @@ static __global__ __launch_bounds__(256) void edge_bwd_kernel(GNNDev g, ScenesDe
         // d rel = d e1 . W_rel^T : one wave per edge row, lanes over channels
         {
             const int wave = tid >> 6, lane = tid & 63;
-            for (int jr = wave; jr < RB; jr += 4) {
+            for (int jr = wave; jr < RB_EDGE; jr += 4) {
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
                 for (int c = lane; c < H; c += 64) {
                     const float ge = s_ga[jr * HLD + c];
@@ -612,7 +612,7 @@ static __global__ __launch_bounds__(256) void edge_bwd_kernel(GNNDev g, ScenesDe
             }
         }
         __syncthreads();
-        if (tid < RB) {
+        if (tid < RB_EDGE) {
             float gfr[4] = {0.f, 0.f, 0.f, 0.f}, gpo[4] = {0.f, 0.f, 0.f, 0.f};
             if (tid < nv) {
                 const int srow = L.src[tid];
@@ -636,9 +636,9 @@ static __global__ __launch_bounds__(256) void edge_bwd_kernel(GNNDev g, ScenesDe
         for (int d = 0; d < 4; ++d) a.gpos_tgt[(size_t)r * 4 + d] = gfr_acc[d];
 }
 
-static size_t edge_bwd_lds_bytes() { return EdgeLds::bytes() + (size_t)(2 * RB * HLD + 2 * RB * 4 + RB) * 4; }
+static size_t edge_bwd_lds_bytes() { return EdgeLds::bytes() + (size_t)(2 * RB_EDGE * HLD + 2 * RB_EDGE * 4 + RB_EDGE) * 4; }
 
-// ---- node1 backward: gather source-side adjoints, back through edge layer 0 partials and mlp_in.  grid = ceil(R/RB)
+// ---- node1 backward: gather source-side adjoints, back through edge layer 0 partials and mlp_in.  grid = ceil(R/RB_NODE)
 struct Node1BwdArgs {
     int t, R;
     const float* dX;        // (R, 64)
@@ -656,18 +656,18 @@ static __global__ __launch_bounds__(256) void node1_bwd_kernel(GNNDev g, ScenesD
     const int F = g.mlp_in.dims[0], D = g.D, H = STRIVE_HID;
     const int in_ld = ld4(F), xs_ld = ld4(D + g.NC);
     Node1Lds L(smem, in_ld, xs_ld);
-    float* s_dp = L.po + RB * HLD;       // [RB][HLD]  dP rows
-    float* s_dq = s_dp + RB * HLD;       // [RB][HLD]  dQ rows
-    float* s_gx = s_dq + RB * HLD;       // [RB][HLD]  adjoint of x (D wide)
-    float* s_gb = s_gx + RB * HLD;       // [RB][HLD]
-    float* s_gin = s_gb + RB * HLD;      // [RB][in_ld]
-    const int tid = threadIdx.x, r0 = blockIdx.x * RB, NS = sc.NS;
+    float* s_dp = L.po + RB_NODE * HLD;       // [RB_NODE][HLD]  dP rows
+    float* s_dq = s_dp + RB_NODE * HLD;       // [RB_NODE][HLD]  dQ rows
+    float* s_gx = s_dq + RB_NODE * HLD;       // [RB_NODE][HLD]  adjoint of x (D wide)
+    float* s_gb = s_gx + RB_NODE * HLD;       // [RB_NODE][HLD]
+    float* s_gin = s_gb + RB_NODE * HLD;      // [RB_NODE][in_ld]
+    const int tid = threadIdx.x, r0 = blockIdx.x * RB_NODE, NS = sc.NS;
     // forward recompute of mlp_in (pre-activations)
-    gather_features(f, r0, a.R, NS, L.in, in_ld, tid, 256);
+    gather_features<RB_NODE>(f, r0, a.R, NS, L.in, in_ld, tid, 256);
     __syncthreads();
-    mlp_forward_lds(g.mlp_in, L.in, in_ld, L.pre, L.act, L.xs, xs_ld, false, tid, 256);
+    mlp_forward_lds<RB_NODE>(g.mlp_in, L.in, in_ld, L.pre, L.act, L.xs, xs_ld, false, tid, 256);
     // gather dP, dQ = sum over targets of the per-edge adjoints, and the source-pose adjoint
-    for (int i = tid; i < RB * H; i += 256) {
+    for (int i = tid; i < RB_NODE * H; i += 256) {
         const int rr = i / H, c = i - rr * H;
         const int r = r0 + rr;
         float vp = 0.f, vq = 0.f;
@@ -685,7 +685,7 @@ static __global__ __launch_bounds__(256) void node1_bwd_kernel(GNNDev g, ScenesD
         s_dp[rr * HLD + c] = vp;
         s_dq[rr * HLD + c] = vq;
     }
-    if (tid < RB * 4) {
+    if (tid < RB_NODE * 4) {
         const int rr = tid >> 2, d = tid & 3;
         const int r = r0 + rr;
         if (r < a.R) {
@@ -704,29 +704,29 @@ static __global__ __launch_bounds__(256) void node1_bwd_kernel(GNNDev g, ScenesD
     __syncthreads();
     // adjoint of x: dP . W_e0[:, 0:D] + dQ . W_e0[:, D:2D] + update-MLP part
     const int EIN = g.edge.dims[0];
-    dense_lds<false>(s_dp, HLD, H, g.edge.w[0], EIN, nullptr, s_gx, HLD, D, tid, 256);
+    dense_lds<RB_NODE, false>(s_dp, HLD, H, g.edge.w[0], EIN, nullptr, s_gx, HLD, D, tid, 256);
     __syncthreads();
-    dense_lds<true>(s_dq, HLD, H, g.edge.w[0] + D, EIN, nullptr, s_gx, HLD, D, tid, 256);
+    dense_lds<RB_NODE, true>(s_dq, HLD, H, g.edge.w[0] + D, EIN, nullptr, s_gx, HLD, D, tid, 256);
     __syncthreads();
-    for (int i = tid; i < RB * D; i += 256) {
+    for (int i = tid; i < RB_NODE * D; i += 256) {
         const int rr = i / D, c = i - rr * D;
         if (r0 + rr < a.R) s_gx[rr * HLD + c] += a.dX[(size_t)(r0 + rr) * D + c];
     }
     __syncthreads();
-    mlp_backward_lds(g.mlp_in, L.pre, s_gx, HLD, s_dp, s_gb, s_gin, in_ld, false, tid, 256);
+    mlp_backward_lds<RB_NODE>(g.mlp_in, L.pre, s_gx, HLD, s_dp, s_gb, s_gin, in_ld, false, tid, 256);
     // scatter: past_feat columns [0,64), z columns [128+NC, 128+NC+32)
-    for (int i = tid; i < RB * 64; i += 256) {
+    for (int i = tid; i < RB_NODE * 64; i += 256) {
         const int rr = i >> 6, c = i & 63;
         if (r0 + rr < a.R) a.g_pf[(size_t)(r0 + rr) * 64 + c] = s_gin[rr * in_ld + c];
     }
     const int zoff = 128 + g.NC;
-    for (int i = tid; i < RB * STRIVE_ZDIM; i += 256) {
+    for (int i = tid; i < RB_NODE * STRIVE_ZDIM; i += 256) {
         const int rr = i / STRIVE_ZDIM, c = i - rr * STRIVE_ZDIM;
         if (r0 + rr < a.R) a.dz[(size_t)(r0 + rr) * STRIVE_ZDIM + c] += s_gin[rr * in_ld + zoff + c];
     }
 }
 
-static size_t node1_bwd_lds_bytes(int in_ld, int xs_ld) { return Node1Lds::bytes(in_ld, xs_ld) + (size_t)(4 * RB * HLD + RB * in_ld) * 4; }
+static size_t node1_bwd_lds_bytes(int in_ld, int xs_ld) { return Node1Lds::bytes(in_ld, xs_ld) + (size_t)(4 * RB_NODE * HLD + RB_NODE * in_ld) * 4; }
 
 // =============================================================================================
 // host orchestration: backward
@@ -792,7 +792,7 @@ extern "C" int strive_rollout_bwd(const StriveDecoder* dec, const StriveScenes* 
     const ScenesDev sd = scenes_dev(*sc);
     const int NC = dec->gnn.NC;
     const int in_ld1 = ld4(dec->gnn.mlp_in.dims[0]), xs_ld = ld4(64 + NC), in_ld2 = ld4(128 + NC);
-    const int nb = (int)((R + RB - 1) / RB);
+    const int nb = (int)((R + RB_NODE - 1) / RB_NODE);
 
     hipMemsetAsync(g_state, 0, R * 8 * 4, stream);
     hipMemsetAsync(g_pos, 0, R * 4 * 4, stream);

@@ -127,7 +127,7 @@ def pack_cnn(sd):
     return p
 
 
-def _fill_map(s, holder, map_env, device):
+def _fill_map(s, holder, map_env, device, with_px4=True):
     raster = map_env.nusc_raster
     dx = map_env.nusc_dx
     if raster.dtype != torch.uint8 or dx.dtype != torch.float64:
@@ -143,6 +143,9 @@ def _fill_map(s, holder, map_env, device):
     s.lwise = holder.hold(torch.linspace(b[0], b[2], map_env.L).to(device))
     s.wwise = holder.hold(torch.linspace(b[1], b[3], map_env.W).to(device))
     s.L, s.Wc = map_env.L, map_env.W
+    if Cc == 4 and with_px4:
+        # pixel-interleaved copy of the raster (one 32-bit word per pixel) for the fused crop -> conv1 gather
+        s.raster_px4 = holder.hold(raster.permute(0, 2, 3, 1).contiguous().view(torch.int32).view(M, H, W))
 
 
 def pack_map(map_env, device):
