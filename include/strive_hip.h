@@ -101,6 +101,9 @@ typedef struct StriveCNN {
     const float* gn_b[6];
     const float* fc_wt;
     const float* fc_b;
+    const uint32_t* w1_frag;   /* layer-0 weights split into three bf16 pieces (w = hi + mid + lo, exact) in MFMA fragment
+                                  order [ky][piece][lane 0..63][8 x bf16], 8 values = window columns 2g,2g+1 x 4 layers for
+                                  lane group g = lane/16, output channel = lane%16; 21504 bytes */
 } StriveCNN;
 
 /* Scene structure of a batch: agents of scene b are rows ptr[b] .. ptr[b+1]-1, ego first

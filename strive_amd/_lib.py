@@ -49,7 +49,7 @@ class StriveMap(C.Structure):
 
 class StriveCNN(C.Structure):
     _fields_ = [('w', C.c_void_p * 6), ('b', C.c_void_p * 6), ('gn_g', C.c_void_p * 6), ('gn_b', C.c_void_p * 6),
-                ('fc_wt', C.c_void_p), ('fc_b', C.c_void_p)]
+                ('fc_wt', C.c_void_p), ('fc_b', C.c_void_p), ('w1_frag', C.c_void_p)]
 
 
 class StriveScenes(C.Structure):

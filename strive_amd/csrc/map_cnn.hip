@@ -15,6 +15,7 @@
 // epilogue of the producing convolution.
 #include "common.h"
 #include "crop_dev.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -183,6 +184,215 @@ __global__ __launch_bounds__(256) void conv1_kernel(StriveMap map, const float* 
 }
 
 // =============================================================================================
+// Layer 1 on the bf16 matrix cores with EXACT fp32 semantics.
+// The crop is uint8 (exactly representable in bf16) and every fp32 weight is the exact sum of three bf16
+// pieces (w = hi + mid + lo, 3 x 8 significand bits), so  sum_k in_k * w_k  ==  sum_k in_k*hi_k + in_k*mid_k +
+// in_k*lo_k  with every product exact in fp32 and fp32 accumulation inside v_mfma_f32_16x16x32_bf16: the result
+// is an fp32 dot product in a different summation order (like any other fp32 implementation), but the matrix
+// pipe runs it at the bf16 rate: 21 MFMAs of 16 cycles per 16-pixel tile instead of 49 of 32 cycles.
+// k is ordered (ky, column pair g = 0..3, column parity, channel): lane group g of an MFMA holds the 8 values
+// of window columns 2g, 2g+1 (x 4 layers) which are 16 contiguous bytes of the [row][col][layer] bf16 LDS
+// tile; the 8th window column is padding with zero weights.
+// Workgroup = 4 waves, 32 (x) x 16 (y) output pixels = 32 pixel tiles of 16, 8 per wave.
+// =============================================================================================
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+namespace l1b {
+constexpr int CIN = 4, COUT = 16, KS = 7, IH = 256, OH = 125;
+constexpr int TOX = 32, TOY = 16;
+constexpr int ITW = 2 * TOX + KS - 2 + 1;   // 70 columns (69 used + the zero-weight pad column of the last pair)
+constexpr int ITH = 2 * TOY + KS - 2;       // 37 rows
+constexpr int TILES_X = (OH + TOX - 1) / TOX, TILES_Y = (OH + TOY - 1) / TOY;   // 4 x 8
+constexpr int NPIX = ITH * ITW;             // 2590 staged pixels (8 bytes each)
+constexpr int WFRAGS = KS * 3;              // (ky, term) fragments, 64 lanes x 16 B each
+constexpr int WBYTES = WFRAGS * 64 * 16;    // 21504
+constexpr int NPART = TILES_X * TILES_Y;    // 32 statistics slots per sample
+}  // namespace l1b
+
+__device__ __forceinline__ uint32_t pack_bf16_pair_from_bytes(uint32_t word, int lo_byte) {
+    // two layers (bytes lo_byte, lo_byte+1 of `word`) -> two bf16 in one dword; integers <= 255 are exact in bf16
+    const float f0 = (float)((word >> (8 * lo_byte)) & 0xffu);
+    const float f1 = (float)((word >> (8 * lo_byte + 8)) & 0xffu);
+    return (__float_as_uint(f0) >> 16) | (__float_as_uint(f1) & 0xffff0000u);
+}
+
+// Persistent over one row of tiles (TILES_X = 4 tiles of 32 x 16 outputs) with two LDS input buffers: while the
+// matrix cores work on tile t, the same waves have already derived the raster pixels of tile t+1 and have its
+// gathers in flight; the gathered words are converted and written to the other buffer after the MFMA phase.
+// The weight fragments are loaded once per workgroup.  8 waves: wave w owns output rows 2w, 2w+1 (4 pixel tiles).
+constexpr int C1_NT = 512;
+
+template <bool FUSED_CROP, int DBG = 0>
+__global__ __launch_bounds__(C1_NT) void conv1b_kernel(StriveMap map, const float* __restrict__ pos, Float4Host pmean,
+                                                         Float4Host pstd, const int32_t* __restrict__ mapix,
+                                                         const uint8_t* __restrict__ crop, const uint32_t* __restrict__ wfrag,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         GNStats* __restrict__ stats) {
+    using namespace l1b;
+    __shared__ __attribute__((aligned(16))) uint32_t s_in[2][NPIX * 2];     // [buffer][row][col][4 x bf16]
+    __shared__ __attribute__((aligned(16))) uint32_t s_w[WBYTES / 4];
+    __shared__ double s_red[2][16];
+    const int n = blockIdx.z;
+    const int ty = blockIdx.x;
+    const int oy0 = ty * TOY;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4;       // k lane group = window column pair
+    const int j = lane & 15;       // pixel within the tile (B) / output channel (A)
+
+    for (int i = tid; i < WBYTES / 16; i += C1_NT)
+        reinterpret_cast<uint4*>(s_w)[i] = reinterpret_cast<const uint4*>(wfrag)[i];
+
+    CropFrame fr;
+    const uint32_t* pk = nullptr;
+    if (FUSED_CROP) {
+        fr = load_crop_frame(map, pos, pmean.v, pstd.v, mapix, n);
+        pk = map.raster_px4 + (size_t)mapix[n] * map.H * map.W;
+    }
+    // Lanes of a wave cover an 8 x 8 patch of crop pixels (not 64 pixels of one row): a patch spans ~10 x 10
+    // raster pixels whatever the heading, i.e. ~10 cache lines per gather instruction instead of up to 64.
+    constexpr int NBX = (ITW + 7) / 8, NBY = (ITH + 7) / 8;       // 9 x 5 patches
+    constexpr int NSLOT = NBX * NBY * 64;
+    constexpr int NIT = (NSLOT + C1_NT - 1) / C1_NT;              // 6 samples per thread per tile
+    uint32_t word[NIT];
+    // per-tile tables of the rounded products l*cos, l*sin (rows) and w*cos, w*sin (columns): the reference's
+    // fl(fl(l*c) - fl(w*s)) + x needs each product once per row / column, not once per pixel
+    __shared__ float s_tab[2][2 * ITH + 2 * ITW];
+
+    auto tables = [&](int tx, int tb) {
+        const int ox0 = tx * TOX;
+        float* T = s_tab[tb];
+        for (int i = tid; i < 2 * ITH + 2 * ITW; i += C1_NT) {
+            float v = 0.f;
+            if (i < 2 * ITH) {
+                const int r = i >> 1, l = 2 * oy0 + r;
+                if (l < IH) v = __fmul_rn(map.lwise[l], (i & 1) ? fr.hs : fr.hc);
+            } else {
+                const int c = (i - 2 * ITH) >> 1, w = 2 * ox0 + c;
+                if (w < IH) v = __fmul_rn(map.wwise[w], (i & 1) ? fr.hs : fr.hc);
+            }
+            T[i] = v;
+        }
+    };
+    auto slot_rc = [&](int k, int& r, int& c) {
+        const int slot = tid + k * C1_NT;
+        const int blk = slot >> 6, li = slot & 63;
+        r = (blk / NBX) * 8 + (li >> 3);
+        c = (blk % NBX) * 8 + (li & 7);
+        return slot < NSLOT && r < ITH && c < ITW;
+    };
+    auto gather = [&](int tx, int tb) {      // derive pixel indices of tile tx and issue the gathers
+        const int ox0 = tx * TOX;
+        const float* T = s_tab[tb];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            int r, c;
+            word[k] = 0u;
+            if (slot_rc(k, r, c)) {
+                const int l = 2 * oy0 + r, w = 2 * ox0 + c;
+                if (l < IH && w < IH) {
+                    if (FUSED_CROP) {
+                        float gx = __fadd_rn(__fsub_rn(T[2 * r], T[2 * ITH + 2 * c + 1]), fr.x);
+                        float gy = __fadd_rn(__fadd_rn(T[2 * r + 1], T[2 * ITH + 2 * c]), fr.y);
+                        gx = (gx != gx) ? 0.0f : gx;
+                        gy = (gy != gy) ? 0.0f : gy;
+                        int px, py;
+                        if (DBG == 2) { px = w + (int)gx % 3; py = l; }                 // timing probe: no fp64 pixel math
+                        else world_to_pixel(fr, gx, gy, px, py);
+                        if (DBG == 1) word[k] = (uint32_t)(px ^ py) & 0x01010101u;      // timing probe: no gather
+                        else word[k] = pk[(size_t)py * map.W + px];
+                    } else {
+                        const uint8_t* src = crop + (size_t)n * CIN * IH * IH + (size_t)l * IH + w;
+                        word[k] = (uint32_t)src[0] | ((uint32_t)src[(size_t)IH * IH] << 8) |
+                                  ((uint32_t)src[(size_t)2 * IH * IH] << 16) | ((uint32_t)src[(size_t)3 * IH * IH] << 24);
+                    }
+                }
+            }
+        }
+    };
+    auto deposit = [&](int buf) {    // gathered words -> 4 x bf16 -> LDS
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            int r, c;
+            if (slot_rc(k, r, c)) {
+                uint2 v;
+                v.x = pack_bf16_pair_from_bytes(word[k], 0);
+                v.y = pack_bf16_pair_from_bytes(word[k], 2);
+                *reinterpret_cast<uint2*>(&s_in[buf][(r * ITW + c) * 2]) = v;
+            }
+        }
+    };
+
+    if (FUSED_CROP) tables(0, 0);
+    __syncthreads();
+    gather(0, 0);
+    if (FUSED_CROP && TILES_X > 1) tables(1, 1);
+    deposit(0);
+    __syncthreads();
+    const bf16x8* wl = reinterpret_cast<const bf16x8*>(s_w) + lane;
+    for (int tx = 0; tx < TILES_X; ++tx) {
+        const int buf = tx & 1;
+        if (tx + 1 < TILES_X) gather(tx + 1, (tx + 1) & 1);
+        // statistics of the previous tile (its per-wave partials were published before the last barrier)
+        if (tx > 0 && tid == 0) {
+            double a = 0.0, b = 0.0;
+            for (int w = 0; w < 8; ++w) { a += s_red[(tx - 1) & 1][2 * w]; b += s_red[(tx - 1) & 1][2 * w + 1]; }
+            GNStats& o = stats[(size_t)n * NPART + ty * TILES_X + (tx - 1)];
+            o.sum = a;
+            o.sq = b;
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            bf16x8 bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int oyl = wave * 2 + (i >> 1), oxl = (i & 1) * 16 + j;
+                const int pix = (2 * oyl + ky) * ITW + 2 * oxl + 2 * g;
+                bfr[i] = *reinterpret_cast<const bf16x8*>(&s_in[buf][pix * 2]);
+            }
+#pragma unroll
+            for (int term = 0; term < (DBG == 3 ? 1 : 3); ++term) {
+                const bf16x8 a = wl[(ky * 3 + term) * 64];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i], acc[i], 0, 0, 0);
+            }
+        }
+        // epilogue: D column = lane&15 = pixel, row = (lane>>4)*4 + r = output channel
+        double lsum = 0.0, lsq = 0.0;
+        const int ox0 = tx * TOX;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int oy = oy0 + wave * 2 + (i >> 1), ox = ox0 + (i & 1) * 16 + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = g * 4 + r;
+                const float v = acc[i][r] + bias[co];
+                if (oy < OH && ox < OH) {
+                    if (DBG != 4) out[(((size_t)n * COUT + co) * OH + oy) * OH + ox] = v;
+                    lsum += (double)v;
+                    lsq += (double)v * (double)v;
+                }
+            }
+        }
+        lsum = wave_sum_d(lsum);
+        lsq = wave_sum_d(lsq);
+        if (lane == 0) { s_red[buf][2 * wave] = lsum; s_red[buf][2 * wave + 1] = lsq; }
+        if (tx + 1 < TILES_X) deposit(buf ^ 1);
+        if (FUSED_CROP && tx + 2 < TILES_X) tables(tx + 2, tx & 1);   // slot tx&1 was last read by gather(tx)
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < 8; ++w) { a += s_red[(TILES_X - 1) & 1][2 * w]; b += s_red[(TILES_X - 1) & 1][2 * w + 1]; }
+        GNStats& o = stats[(size_t)n * NPART + ty * TILES_X + (TILES_X - 1)];
+        o.sum = a;
+        o.sq = b;
+    }
+}
+
+// =============================================================================================
 // Layers 2-6: generic LDS-staged implicit GEMM on v_mfma_f32_32x32x2_f32.
 // A workgroup owns S samples x (TH x TW) output pixels (P = S*TH*TW, linearised) and all COUT channels;
 // waves form an NWP x NWM grid: wave (wp, wm) owns NPW pixel tiles of 32 and MTW channel tiles of 32.
@@ -191,8 +401,9 @@ __global__ __launch_bounds__(256) void conv1_kernel(StriveMap map, const float* 
 // at the same window offset and every LDS address is lane_base + compile-time immediate.
 // =============================================================================================
 template <int CIN_, int COUT_, int KS_, int IH_, int OH_, int TH_, int TW_, int S_, int CC_, int NWP_, int NWM_, int NPW_,
-          int MTW_, int NPART_IN_>
+          int MTW_, int NPART_IN_, int MINW_ = 1>
 struct ConvCfg {
+    static constexpr int MINW = MINW_;               // __launch_bounds__ waves per SIMD (caps the register allocation)
     static constexpr int NPART_IN = NPART_IN_;       // per-sample partial-statistics slots written by the producer
     static constexpr int CIN = CIN_, COUT = COUT_, KS = KS_, IH = IH_, OH = OH_, TH = TH_, TW = TW_, S = S_, CC = CC_;
     static constexpr int NWP = NWP_, NWM = NWM_, NPW = NPW_, MTW = MTW_;
@@ -225,7 +436,7 @@ struct ConvCfg {
 #define STAGE_UB 8   // independent global loads in flight per thread while staging
 
 template <class Cfg>
-__global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
+__global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void conv_mfma_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
                                                              const float* __restrict__ gn_g, const float* __restrict__ gn_b,
                                                              const float* __restrict__ wpk, const float* __restrict__ bias,
                                                              float* __restrict__ out, GNStats* __restrict__ st_out, int N) {
@@ -301,6 +512,8 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
     float raw[ITERS];
     float4 wreg[WITERS];
 
+    const float* in_wg = in + (size_t)n0 * CIN * IH * IH;   // this workgroup's first sample
+    const float* w_wg = wpk + c0;                           // this workgroup's channel slice
     auto issue_loads = [&](int ch) {
 #pragma unroll
         for (int k = 0; k < ITERS; ++k) {
@@ -315,7 +528,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
                 const int s = t / CC;
                 const int iy = iy0 + r, ix = ix0 + col;
                 if (n0 + s < N && iy < IH && ix < IH)
-                    raw[k] = in[(((size_t)(n0 + s) * CIN + ch * CC + c) * IH + iy) * IH + ix];
+                    raw[k] = in_wg[((s * CIN + ch * CC + c) * IH + iy) * IH + ix];   // 32-bit offset from a uniform base
             }
         }
 #pragma unroll
@@ -324,7 +537,7 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
             wreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (q < WQ) {
                 const int row = (q * 4) / CW, c = (q * 4) - row * CW;
-                wreg[k] = *reinterpret_cast<const float4*>(wpk + ((size_t)ch * Cfg::WROWS + row) * COUT + c0 + c);
+                wreg[k] = *reinterpret_cast<const float4*>(w_wg + (ch * Cfg::WROWS + row) * COUT + c);
             }
         }
     };
@@ -455,9 +668,9 @@ __global__ __launch_bounds__(Cfg::NT) void conv_mfma_kernel(const float* __restr
 }
 
 // per-layer configurations            CIN COUT KS  IH  OH  TH  TW  S  CC NWP NWM NPW MTW NPART_IN
-typedef ConvCfg< 16,  32, 5, 125, 61, 16, 16,  1,  4,  4,  1,  2,  1, 64> Cfg2;   // 16x16 px tile, 4 waves, 4096 WGs / 256 agents
+typedef ConvCfg< 16,  32, 5, 125, 61, 16, 16,  1,  4,  4,  1,  2,  1, l1b::NPART, 3> Cfg2;   // 16x16 px tile, 4 waves, 4096 WGs / 256 agents
 typedef ConvCfg< 32,  64, 5,  61, 29, 29, 29,  1,  2,  7,  1,  4,  2, 16> Cfg3;   // whole image (841 px), 7 waves
-typedef ConvCfg< 64,  64, 3,  29, 14, 14, 14,  1,  8,  4,  1,  2,  2,  1> Cfg4;   // whole image (196 px), 4 waves, 1 WG / agent
+typedef ConvCfg< 64,  64, 3,  29, 14, 14, 14,  1,  8,  4,  1,  2,  2,  1, 2> Cfg4;   // whole image (196 px), 4 waves, 1 WG / agent
 typedef ConvCfg< 64, 128, 3,  14,  6,  6,  6,  2,  8,  3,  2,  1,  1,  1> Cfg5;   // 2 agents (72 px) x 64 of 128 channels, 6 waves
 typedef ConvCfg<128, 128, 3,   6,  2,  2,  2,  8,  8,  1,  4,  1,  1,  2> Cfg6;   // 8 agents (32 px), 4 waves x 32 channels
 
@@ -511,9 +724,20 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ in, c
 // =============================================================================================
 namespace {
 constexpr size_t L_OUT[6] = {16u * 125 * 125, 32u * 61 * 61, 64u * 29 * 29, 64u * 14 * 14, 128u * 6 * 6, 128u * 2 * 2};
-constexpr int CNN_CHUNK = 256;
-constexpr int NPARTS[6] = {64, Cfg2::NPART_OUT, Cfg3::NPART_OUT, Cfg4::NPART_OUT, Cfg5::NPART_OUT, Cfg6::NPART_OUT};
-constexpr int STAT_SLOTS = 64 + Cfg2::NPART_OUT + Cfg3::NPART_OUT + Cfg4::NPART_OUT + Cfg5::NPART_OUT + Cfg6::NPART_OUT;
+constexpr int CNN_CHUNK_MAX = 1024;   // workspace is sized for this many agents per pass
+// agents pushed through the layer stack together; STRIVE_CNN_CHUNK overrides (tuning knob, read once)
+static int cnn_chunk() {
+    static int v = 0;
+    if (!v) {
+        const char* e = getenv("STRIVE_CNN_CHUNK");
+        v = e ? atoi(e) : 512;
+        if (v < 8) v = 8;
+        if (v > CNN_CHUNK_MAX) v = CNN_CHUNK_MAX;
+    }
+    return v;
+}
+constexpr int NPARTS[6] = {l1b::NPART, Cfg2::NPART_OUT, Cfg3::NPART_OUT, Cfg4::NPART_OUT, Cfg5::NPART_OUT, Cfg6::NPART_OUT};
+constexpr int STAT_SLOTS = l1b::NPART + Cfg2::NPART_OUT + Cfg3::NPART_OUT + Cfg4::NPART_OUT + Cfg5::NPART_OUT + Cfg6::NPART_OUT;
 static_assert(Cfg3::NPART_IN == Cfg2::NPART_OUT && Cfg4::NPART_IN == Cfg3::NPART_OUT && Cfg5::NPART_IN == Cfg4::NPART_OUT &&
               Cfg6::NPART_IN == Cfg5::NPART_OUT, "statistics slot chain");   // agents pushed through the layer stack together (keeps the working set L3-sized)
 
@@ -525,7 +749,7 @@ size_t per_agent_floats() {
 }  // namespace
 
 extern "C" size_t strive_map_cnn_workspace_bytes(int32_t N) {
-    const size_t ch = (size_t)(N < CNN_CHUNK ? (N > 0 ? N : 1) : CNN_CHUNK);
+    const size_t ch = (size_t)(N < CNN_CHUNK_MAX ? (N > 0 ? N : 1) : CNN_CHUNK_MAX);
     size_t bytes = 0;
     for (int l = 0; l < 6; ++l) bytes += strive_align_up(ch * L_OUT[l] * 4, 256);
     bytes += strive_align_up(ch * STAT_SLOTS * sizeof(GNStats), 256);
@@ -540,7 +764,7 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         strive_set_error("map_cnn: workspace too small (%zu < %zu)", ws_bytes, strive_map_cnn_workspace_bytes(N));
         return -1;
     }
-    const int ch = N < CNN_CHUNK ? N : CNN_CHUNK;
+    const int ch = N < cnn_chunk() ? N : cnn_chunk();
     StriveArena ar(ws, ws_bytes);
     float* act[6];
     for (int l = 0; l < 6; ++l) act[l] = ar.take<float>((size_t)ch * L_OUT[l]);
@@ -564,13 +788,13 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
             size_t off = 0;
             for (int l = 0; l < 6; ++l) { st[l] = stats + off; off += (size_t)ch * NPARTS[l]; }
         }
-        dim3 g1(l1::TILES, l1::TILES, n);
+        dim3 g1(l1b::TILES_Y, 1, n);
         if (map) {
-            hipLaunchKernelGGL(conv1_kernel<true>, g1, dim3(256), 0, stream, mp, pos + (size_t)n0 * 4, m, s, mapix + n0,
-                               (const uint8_t*)nullptr, (const float*)cnn->w[0], (const float*)cnn->b[0], act[0], st[0]);
+            hipLaunchKernelGGL(conv1b_kernel<true>, g1, dim3(C1_NT), 0, stream, mp, pos + (size_t)n0 * 4, m, s, mapix + n0,
+                               (const uint8_t*)nullptr, cnn->w1_frag, (const float*)cnn->b[0], act[0], st[0]);
         } else {
-            hipLaunchKernelGGL(conv1_kernel<false>, g1, dim3(256), 0, stream, mp, (const float*)nullptr, m, s,
-                               (const int32_t*)nullptr, crop + (size_t)n0 * 4 * 256 * 256, (const float*)cnn->w[0],
+            hipLaunchKernelGGL(conv1b_kernel<false>, g1, dim3(C1_NT), 0, stream, mp, (const float*)nullptr, m, s,
+                               (const int32_t*)nullptr, crop + (size_t)n0 * 4 * 256 * 256, cnn->w1_frag,
                                (const float*)cnn->b[0], act[0], st[0]);
         }
         launch_conv<Cfg2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w[1], cnn->b[1], act[1], st[1], n, stream);
@@ -608,7 +832,7 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
                                           const float* pos_mean4_host, const float* pos_std4_host, const int32_t* mapix,
                                           int32_t N, float* feat, void* ws, size_t ws_bytes, strive_stream_t stream_) {
     STRIVE_CHECK_ARG(map && cnn && pos && mapix && feat && ws, "null argument");
-    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK && layer >= 0 && layer <= 6, "bad layer / N");
+    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK_MAX && layer >= 0 && layer <= 14, "bad layer / N");
     STRIVE_CHECK_ARG(ws_bytes >= strive_map_cnn_workspace_bytes(N), "workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
     StriveArena ar(ws, ws_bytes);
@@ -625,9 +849,17 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
     memcpy(s.v, pos_std4_host, 16);
     switch (layer) {
         case 0:
-            hipLaunchKernelGGL(conv1_kernel<true>, dim3(l1::TILES, l1::TILES, N), dim3(256), 0, stream, *map, pos, m, s, mapix,
-                               (const uint8_t*)nullptr, (const float*)cnn->w[0], (const float*)cnn->b[0], act[0], st[0]);
+            hipLaunchKernelGGL(conv1b_kernel<true>, dim3(l1b::TILES_Y, 1, N), dim3(C1_NT), 0, stream, *map, pos, m, s,
+                               mapix, (const uint8_t*)nullptr, cnn->w1_frag, (const float*)cnn->b[0], act[0], st[0]);
             break;
+        case 11: case 12: case 13: case 14: {   // timing probes of the layer-0 kernel (results are NOT valid): no gather / no fp64 / 1/3 MFMA
+            dim3 gg(l1b::TILES_Y, 1, N);
+            if (layer == 11) hipLaunchKernelGGL((conv1b_kernel<true, 1>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, (const float*)cnn->b[0], act[0], st[0]);
+            if (layer == 12) hipLaunchKernelGGL((conv1b_kernel<true, 2>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, (const float*)cnn->b[0], act[0], st[0]);
+            if (layer == 14) hipLaunchKernelGGL((conv1b_kernel<true, 4>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, (const float*)cnn->b[0], act[0], st[0]);
+            if (layer == 13) hipLaunchKernelGGL((conv1b_kernel<true, 3>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, (const float*)cnn->b[0], act[0], st[0]);
+            break;
+        }
         case 1: launch_conv<Cfg2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w[1], cnn->b[1], act[1], st[1], N, stream); break;
         case 2: launch_conv<Cfg3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w[2], cnn->b[2], act[2], st[2], N, stream); break;
         case 3: launch_conv<Cfg4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w[3], cnn->b[3], act[3], st[3], N, stream); break;

@@ -98,6 +98,25 @@ def _fill_gru(s, holder, sd, prefix):
         s.bhh[l] = holder.hold(_c(sd['%s.bias_hh_l%d' % (prefix, l)]))
 
 
+def _conv1_fragments(w):
+    """(16,4,7,7) fp32 -> int32 tensor holding [ky][piece][lane][8 x bf16]: the exact three-way bf16 split of every
+    weight in the k order of conv1b_kernel (lane group g: window columns 2g, 2g+1; element = parity*4 + layer;
+    column 7 is zero padding)."""
+    hi = w.to(torch.bfloat16)
+    r1 = w - hi.to(torch.float32)
+    mid = r1.to(torch.bfloat16)
+    r2 = r1 - mid.to(torch.float32)
+    lo = r2.to(torch.bfloat16)
+    if not torch.equal(hi.float() + mid.float() + lo.float(), w):
+        raise ValueError('conv1 weights are not exactly representable as three bf16 pieces (non-finite or subnormal?)')
+    pieces = torch.stack([hi, mid, lo], dim=0)                       # (3, co, ci, ky, kx)
+    pad = torch.zeros((3, 16, 4, 7, 1), dtype=torch.bfloat16, device=w.device)
+    pk = torch.cat([pieces, pad], dim=4).view(3, 16, 4, 7, 4, 2)     # kx -> (g, parity)
+    # -> [ky][piece][g][co][parity][ci]
+    frag = pk.permute(3, 0, 4, 1, 5, 2).contiguous()                 # (7, 3, 4, 16, 2, 4)
+    return frag.view(torch.int16).view(7, 3, 64, 8).contiguous().view(torch.int32)
+
+
 def _fill_cnn(s, holder, sd):
     expect = [(16, 4, 7), (32, 16, 5), (64, 32, 5), (64, 64, 3), (128, 64, 3), (128, 128, 3)]
     for l in range(6):
@@ -114,6 +133,7 @@ def _fill_cnn(s, holder, sd):
         s.b[l] = holder.hold(_c(sd['map_conv.%d.bias' % (3 * l)]))
         s.gn_g[l] = holder.hold(_c(sd['map_conv.%d.weight' % (3 * l + 1)]))
         s.gn_b[l] = holder.hold(_c(sd['map_conv.%d.bias' % (3 * l + 1)]))
+    s.w1_frag = holder.hold(_conv1_fragments(_c(sd['map_conv.0.weight'])))
     fw = _c(sd['map_feature.weight'])
     if tuple(fw.shape) != (64, 512):
         raise NotImplementedError('map_feature must be Linear(512, 64)')

@@ -36,6 +36,10 @@ struct uint3_emu { unsigned x, y, z; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(8) float2 { float x, y; };
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 
 typedef void* hipStream_t;
 typedef int hipError_t;
@@ -217,5 +221,44 @@ inline hipemu_f32x16 hipemu_mfma_32x32x2(float a, float b, hipemu_f32x16 c, int,
     hipemu::wave_barrier();
     return d;
 }
+// 16x16x32 bf16: lane l holds k = 8*(l>>4) + j (j = 0..7) of row/column l&15 for BOTH operands (verified on
+// gfx950 with tools/mfma_probe.hip); D as for 16x16x4.  Products are exact in fp32 (8 x 8 significand bits);
+// the hardware's internal summation order is not modelled -- plain fp32 adds in k order.
+typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+inline float hipemu_bf16_to_float(__bf16 v) {
+    uint16_t h;
+    memcpy(&h, &v, 2);
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+struct hipemu_bf16_wave { float a[64][8]; float b[64][8]; };
+inline hipemu_bf16_wave& hipemu_bf16_buf() {
+    static std::vector<hipemu_bf16_wave> bufs(16);
+    int lin = (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z));
+    return bufs[lin >> 6];
+}
+inline hipemu_f32x4 hipemu_mfma_16x16x32_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x4 c, int, int, int) {
+    hipemu_bf16_wave& w = hipemu_bf16_buf();
+    int lane = hipemu_lane();
+    for (int j = 0; j < 8; ++j) {
+        w.a[lane][j] = hipemu_bf16_to_float(a[j]);
+        w.b[lane][j] = hipemu_bf16_to_float(b[j]);
+    }
+    hipemu::wave_barrier();
+    hipemu_f32x4 d = c;
+    int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (lane >> 4) * 4 + r;
+        float acc = c[r];
+        for (int g = 0; g < 4; ++g)
+            for (int j = 0; j < 8; ++j) acc += w.a[g * 16 + row][j] * w.b[g * 16 + col][j];
+        d[r] = acc;
+    }
+    hipemu::wave_barrier();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 hipemu_mfma_16x16x32_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_32x32x2
