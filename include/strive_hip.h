@@ -226,6 +226,15 @@ int strive_veh_coll_bwd(const StriveScenes* sc, const int32_t* pair_off, int32_t
                         int32_t T, const float* cent_x, const float* rad, float buffer, const float* d_pen,
                         const uint8_t* amin, float* d_traj, strive_stream_t stream);
 
+/* interp_traj (reference src/losses/adv_gen_nusc.py:625-644): linear x`scale` up-sampling in time of (x,y,hx,hy)
+ * followed by heading renormalisation.  in (N,T,4) -> out (N,TO,4), TO = T*scale.  i0,i1 (TO) int32 and w0,w1 (TO) fp32
+ * are the two taps of every output step as F.interpolate(mode='linear', align_corners=False) computes them. */
+int strive_interp_traj_fwd(const float* in, int32_t N, int32_t T, int32_t TO, const int32_t* i0, const int32_t* i1,
+                           const float* w0, const float* w1, float* out, strive_stream_t stream);
+int strive_interp_traj_bwd(const float* in, const float* d_out, int32_t N, int32_t T, int32_t TO, int32_t scale,
+                           const int32_t* i0, const int32_t* i1, const float* w0, const float* w1, float* d_in,
+                           strive_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

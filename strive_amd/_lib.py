@@ -91,6 +91,8 @@ PROTOTYPES = {
     'strive_rollout_bwd': (C.c_int, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), P, P, P, P, I, P, P,
                                      P, SZ, P, SZ, P]),
     'strive_veh_coll_fwd': (C.c_int, [C.POINTER(StriveScenes), P, I, P, I, P, P, C.c_float, P, P, P, P]),
+    'strive_interp_traj_fwd': (C.c_int, [P, I, I, I, P, P, P, P, P, P]),
+    'strive_interp_traj_bwd': (C.c_int, [P, P, I, I, I, I, P, P, P, P, P, P]),
     'strive_veh_coll_bwd': (C.c_int, [C.POINTER(StriveScenes), P, I, P, I, P, P, C.c_float, P, P, P, P]),
 }
 

@@ -16,7 +16,10 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 
 SOURCES = ['capi.hip', 'map_crop.hip', 'map_cnn.hip', 'mlp_gnn.hip', 'rollout.hip', 'losses.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-fast-math', '-ffp-contract=on',
-         '-fhip-fp32-correctly-rounded-divide-sqrt', '-Wno-unused-result', '-Wno-unused-value']
+         '-fhip-fp32-correctly-rounded-divide-sqrt', '-Wno-unused-result', '-Wno-unused-value',
+         # no auto-formed v_pk_*_f32: see DESIGN.md "packed-fp32 write-after-write" (a half-dead packed result
+         # followed by a scalar write of the same VGPR lost the race for lanes 48-63 when two workgroups shared a CU)
+         '-fno-slp-vectorize']
 
 
 def _sources():

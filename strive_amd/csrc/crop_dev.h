@@ -8,9 +8,28 @@ struct CropFrame {
     float x, y, hc, hs;      // unnormalised pose
     double dx0, dx1;         // metres per pixel for x (dx[m][0]) and y (dx[m][1])
     double inv0, inv1;       // 1/dx, used only to PREDICT the quotient (see world_to_pixel)
+    float finv0, finv1;      // 1/dx in fp32, exact when `pow2`
+    bool pow2;               // both dx are powers of two (pix_per_m = 4 or 8 in the reference): g/dx is exact in fp32
     int H, W;
     const uint8_t* base;     // raster + m*C*H*W (channel 0 of the agent's map)
 };
+
+// dx = 2^e with 2^-100 <= dx <= 2^100: 1/dx is an exact normal fp32 and g * (1/dx) is the exact quotient
+__device__ __forceinline__ bool dx_is_pow2(double dx) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(dx);
+    const int e = (int)((b >> 52) & 0x7ff) - 1023;
+    return (b >> 63) == 0 && (b & 0x000fffffffffffffull) == 0 && e >= -100 && e <= 100;
+}
+
+__device__ __forceinline__ void set_crop_scale(CropFrame& fr, double dx0, double dx1) {
+    fr.dx0 = dx0;
+    fr.dx1 = dx1;
+    fr.inv0 = __ddiv_rn(1.0, dx0);
+    fr.inv1 = __ddiv_rn(1.0, dx1);
+    fr.finv0 = (float)fr.inv0;
+    fr.finv1 = (float)fr.inv1;
+    fr.pow2 = dx_is_pow2(dx0) && dx_is_pow2(dx1);
+}
 
 __device__ __forceinline__ CropFrame load_crop_frame(const StriveMap& map, const float* __restrict__ pos,
                                                      const float* pmean, const float* pstd,
@@ -21,10 +40,7 @@ __device__ __forceinline__ CropFrame load_crop_frame(const StriveMap& map, const
     fr.hc = unnorm1(pos[n * 4 + 2], pmean[2], pstd[2]);
     fr.hs = unnorm1(pos[n * 4 + 3], pmean[3], pstd[3]);
     const int m = mapix[n];
-    fr.dx0 = map.dx[m * 2 + 0];
-    fr.dx1 = map.dx[m * 2 + 1];
-    fr.inv0 = __ddiv_rn(1.0, fr.dx0);
-    fr.inv1 = __ddiv_rn(1.0, fr.dx1);
+    set_crop_scale(fr, map.dx[m * 2 + 0], map.dx[m * 2 + 1]);
     fr.H = map.H;
     fr.W = map.W;
     fr.base = map.raster + (size_t)m * map.C * map.H * map.W;
@@ -51,11 +67,26 @@ __device__ __forceinline__ double quotient_rint(double g, double dx, double inv)
 
 // float64 divide, round half to even, out-of-bounds (either axis) -> pixel (0,0)
 __device__ __forceinline__ void world_to_pixel(const CropFrame& fr, float gx, float gy, int& px, int& py) {
+    if (fr.pow2) {
+        // scaling by a power of two is exact, so rint(fp32 quotient) IS rint(double(g) / dx); overflow to inf and
+        // NaN fail the bounds / ordered tests exactly like the out-of-range doubles do
+        const float qx = rintf(__fmul_rn(gx, fr.finv0)), qy = rintf(__fmul_rn(gy, fr.finv1));
+        const int ix = (int)qx, iy = (int)qy;
+        const bool ordered = (qx == qx) & (qy == qy);
+        const bool inside = ordered & ((unsigned)ix < (unsigned)fr.W) & ((unsigned)iy < (unsigned)fr.H);
+        px = inside ? ix : 0;
+        py = inside ? iy : 0;
+        return;
+    }
     const double qx = quotient_rint((double)gx, fr.dx0, fr.inv0);
     const double qy = quotient_rint((double)gy, fr.dx1, fr.inv1);
-    const bool inside = (qy >= 0.0) && (qy < (double)fr.H) && (qx >= 0.0) && (qx < (double)fr.W);
-    px = inside ? (int)qx : 0;
-    py = inside ? (int)qy : 0;
+    // qx, qy are integer valued (or NaN / inf): test the bounds on the saturating int conversion (NaN -> 0 is
+    // excluded by the explicit ordered test; -0.0 is inside, as `pix >= 0` is in the reference)
+    const int ix = (int)qx, iy = (int)qy;
+    const bool ordered = (qx == qx) & (qy == qy);
+    const bool inside = ordered & ((unsigned)ix < (unsigned)fr.W) & ((unsigned)iy < (unsigned)fr.H);
+    px = inside ? ix : 0;
+    py = inside ? iy : 0;
 }
 
 __device__ __forceinline__ void crop_pixel(const CropFrame& fr, float lwise, float wwise, bool nan_to_zero,

@@ -223,7 +223,7 @@ __device__ __forceinline__ uint32_t pack_bf16_pair_from_bytes(uint32_t word, int
 constexpr int C1_NT = 512;
 
 template <bool FUSED_CROP, int DBG = 0>
-__global__ __launch_bounds__(C1_NT) void conv1b_kernel(StriveMap map, const float* __restrict__ pos, Float4Host pmean,
+__global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const float* __restrict__ pos, Float4Host pmean,
                                                          Float4Host pstd, const int32_t* __restrict__ mapix,
                                                          const uint8_t* __restrict__ crop, const uint32_t* __restrict__ wfrag,
                                                          const float* __restrict__ bias, float* __restrict__ out,

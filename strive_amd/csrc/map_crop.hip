@@ -70,10 +70,7 @@ __global__ __launch_bounds__(256) void coll_point_kernel(StriveMap map, const fl
     fr.hc = cars[n * 4 + 2];
     fr.hs = cars[n * 4 + 3];
     const int m = mapix[n];
-    fr.dx0 = map.dx[m * 2 + 0];
-    fr.dx1 = map.dx[m * 2 + 1];
-    fr.inv0 = __ddiv_rn(1.0, fr.dx0);
-    fr.inv1 = __ddiv_rn(1.0, fr.dx1);
+    set_crop_scale(fr, map.dx[m * 2 + 0], map.dx[m * 2 + 1]);
     fr.H = map.H;
     fr.W = map.W;
     fr.base = map.raster + (size_t)m * map.C * map.H * map.W;   // layer 0

@@ -33,6 +33,24 @@ __device__ __forceinline__ void dense_lds(const float* in, int in_ld, int IN, co
             acc[i] = v;
         }
         int k = 0;
+        // 16 weight loads are issued back to back before any is used: the layers are latency bound on the L2
+        // round trip of the weight stream, not on bandwidth
+        for (; k + 15 < IN; k += 16) {
+            float w[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) w[q] = Wt[(size_t)(k + q) * ldw + c];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const float4 a = *reinterpret_cast<const float4*>(&in[(r0 + i) * in_ld + k + 4 * q4]);
+                    acc[i] = fmaf(a.x, w[4 * q4 + 0], acc[i]);
+                    acc[i] = fmaf(a.y, w[4 * q4 + 1], acc[i]);
+                    acc[i] = fmaf(a.z, w[4 * q4 + 2], acc[i]);
+                    acc[i] = fmaf(a.w, w[4 * q4 + 3], acc[i]);
+                }
+            }
+        }
         for (; k + 3 < IN; k += 4) {
             const float w0 = Wt[(size_t)(k + 0) * ldw + c];
             const float w1 = Wt[(size_t)(k + 1) * ldw + c];

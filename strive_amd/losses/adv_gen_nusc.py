@@ -23,9 +23,9 @@ def interp_traj(future_pred, scale_factor=3):
     if multi:
         NA, NS, T, _ = future_pred.size()
         future_pred = future_pred.reshape(NA * NS, T, 4)
-    up = nn.functional.interpolate(future_pred.transpose(1, 2), scale_factor=scale_factor, mode='linear').transpose(1, 2)
-    h = up[:, :, 2:4]
-    up = torch.cat([up[:, :, :2], h / torch.norm(h, dim=-1, keepdim=True)], dim=-1)
+    if float(scale_factor) != int(scale_factor) or int(scale_factor) < 1:
+        raise NotImplementedError('interp_traj: integer scale factors only')
+    up = ops.interp_traj(future_pred, int(scale_factor))
     if multi:
         up = up.reshape(NA, NS, up.size(1), 4)
     return up

@@ -263,6 +263,23 @@ def encode_map(model, pos, batch_of_agent, map_idx, map_env):
     return feat.reshape(NA, NS, 64) if multi else feat
 
 
+def encode_map_crop(model, crop):
+    """Map feature of PRE-CROPPED uint8 rasters ``(N,4,256,256)`` -> (N,64): the CNN alone, no gradient.
+    (reference src/models/traffic_model.py:104-113 applied to ``map_env.get_map_crop`` output)"""
+    lib = _lib_for(crop)
+    if crop.dtype != torch.uint8 or crop.dim() != 4 or tuple(crop.shape[1:]) != (4, 256, 256):
+        raise StriveHipError('encode_map_crop expects uint8 (N,4,256,256), got %s %s' % (crop.dtype, tuple(crop.shape)))
+    crop = crop.contiguous()
+    N = crop.shape[0]
+    dev = crop.device
+    cnn = _cached_pack(model, 'cnn', model.map_conv, lambda: params.pack_cnn(model.state_dict()))
+    feat = torch.empty((N, 64), dtype=torch.float32, device=dev)
+    wsb = lib.query('strive_map_cnn_workspace_bytes', N)
+    ws = _workspace(dev, wsb, 'cnn')
+    lib.call('strive_map_cnn_fwd_from_crop', cnn.ref(), L.ptr(crop), N, L.ptr(feat), L.ptr(ws), ws.numel(), _stream(crop))
+    return feat
+
+
 def encode_traj(model, encoder, g, traj, vis):
     """Past / future trajectory encoder input assembly (torch glue) + HIP MLP.
     (reference src/models/traffic_model.py:453-523)"""
@@ -417,3 +434,66 @@ def veh_coll_penalties(traj, setup):
     """(pen (T,P) differentiable w.r.t. traj, hit (T,P) uint8) over in-scene ordered pairs."""
     _lib_for(traj)
     return _VehCollFn.apply(traj[:, :, :4], setup)
+
+
+# ------------------------------------------------------------------------------------------------
+# trajectory up-sampling
+# ------------------------------------------------------------------------------------------------
+
+_interp_tables = {}
+
+
+def _interp_taps(T, scale, device):
+    """Taps of F.interpolate(mode='linear', align_corners=False, scale_factor=scale), evaluated in fp32 the way ATen's
+    area_pixel_compute_source_index does: src = max(rscale*(j+0.5)-0.5, 0), i0 = floor(src), i1 = min(i0+1, T-1),
+    w1 = src - i0, w0 = 1 - w1."""
+    key = (T, scale, str(device))
+    t = _interp_tables.get(key)
+    if t is None:
+        import numpy as np
+        rs = np.float32(1.0 / float(scale))
+        j = np.arange(T * scale, dtype=np.float32)
+        src = rs * (j + np.float32(0.5)) - np.float32(0.5)
+        src = np.maximum(src, np.float32(0.0)).astype(np.float32)
+        i0 = np.floor(src).astype(np.int32)
+        i1 = np.minimum(i0 + 1, T - 1).astype(np.int32)
+        w1 = (src - i0.astype(np.float32)).astype(np.float32)
+        w0 = (np.float32(1.0) - w1).astype(np.float32)
+        t = tuple(torch.from_numpy(a).to(device) for a in (i0, i1, w0, w1))
+        _interp_tables[key] = t
+    return t
+
+
+class _InterpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, traj, scale):
+        lib = _lib_for(traj)
+        x = _f32c(traj)
+        N, T, _ = x.shape
+        TO = T * scale
+        i0, i1, w0, w1 = _interp_taps(T, scale, x.device)
+        out = torch.empty((N, TO, 4), dtype=torch.float32, device=x.device)
+        ctx.save_for_backward(x)
+        ctx.scale = scale
+        if N == 0:
+            return out
+        lib.call('strive_interp_traj_fwd', L.ptr(x), N, T, TO, L.ptr(i0), L.ptr(i1), L.ptr(w0), L.ptr(w1), L.ptr(out), _stream(x))
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, = ctx.saved_tensors
+        N, T, _ = x.shape
+        scale = ctx.scale
+        i0, i1, w0, w1 = _interp_taps(T, scale, x.device)
+        d_in = torch.empty_like(x)
+        if N == 0:
+            return d_in, None
+        _lib_for(x).call('strive_interp_traj_bwd', L.ptr(x), L.ptr(_f32c(d_out)), N, T, T * scale, scale, L.ptr(i0), L.ptr(i1),
+                         L.ptr(w0), L.ptr(w1), L.ptr(d_in), _stream(x))
+        return d_in, None
+
+
+def interp_traj(traj, scale):
+    """(N,T,4) -> (N,T*scale,4): linear up-sampling + heading renormalisation, HIP forward and backward."""
+    return _InterpFn.apply(traj[:, :, :4], int(scale))

@@ -39,6 +39,7 @@ inline float4 make_float4(float x, float y, float z, float w) { return float4{x,
 struct alignas(8) uint2 { unsigned x, y; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline long long __double_as_longlong(double d) { long long u; memcpy(&u, &d, 8); return u; }
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 
 typedef void* hipStream_t;

@@ -191,3 +191,33 @@ def test_veh_coll_fwd_bwd(emu, sd):
     emu.call('strive_veh_coll_bwd', sc.ref(), L.ptr(info.pair_off), info.P, L.ptr(traj), T, L.ptr(cent), L.ptr(rad), 0.1,
              L.ptr(wgt.contiguous()), L.ptr(amin), L.ptr(d_traj), None)
     assert_close(d_traj, tc.grad, 1e-3, 1e-5, 'veh bwd')
+
+
+def test_interp_traj_fwd_bwd(emu):
+    """strive_interp_traj_fwd/bwd vs the oracle's F.interpolate + renormalisation (reference
+    src/losses/adv_gen_nusc.py:13-26) and vs the golden vector generated from the reference itself."""
+    from strive_amd.ops import _interp_taps
+    g = golden('g1_ops.npz')
+    N, T, S = 7, 12, 3
+    x = synth.f32(synth.counter_normal((N, T, 4), 'interp/x'))
+    x[:, :, 2:4] = x[:, :, 2:4] / x[:, :, 2:4].norm(dim=-1, keepdim=True)
+    i0, i1, w0, w1 = _interp_taps(T, S, 'cpu')
+    out = torch.zeros((N, T * S, 4))
+    emu.call('strive_interp_traj_fwd', L.ptr(x), N, T, T * S, L.ptr(i0), L.ptr(i1), L.ptr(w0), L.ptr(w1), L.ptr(out), None)
+    xr = x.clone().requires_grad_(True)
+    want = olosses.interp_traj(xr, S)
+    np.testing.assert_allclose(out.numpy(), want.detach().numpy(), rtol=1e-5, atol=2e-6)
+    d_out = synth.f32(synth.counter_normal((N, T * S, 4), 'interp/g'))
+    want.backward(d_out)
+    d_in = torch.zeros_like(x)
+    emu.call('strive_interp_traj_bwd', L.ptr(x), L.ptr(d_out), N, T, T * S, S, L.ptr(i0), L.ptr(i1), L.ptr(w0), L.ptr(w1),
+             L.ptr(d_in), None)
+    np.testing.assert_allclose(d_in.numpy(), xr.grad.numpy(), rtol=2e-5, atol=5e-6)
+    # golden: the reference's interp_traj on the g1 trajectory
+    if True:
+        xi = synth.f32(synth.counter_uniform((5, 12, 4), 'g1/traj', -2.0, 2.0)).contiguous()   # make_golden.py's input
+        Ng, Tg, _ = xi.shape
+        a0, a1, b0, b1 = _interp_taps(Tg, 3, 'cpu')
+        og = torch.zeros((Ng, Tg * 3, 4))
+        emu.call('strive_interp_traj_fwd', L.ptr(xi), Ng, Tg, Tg * 3, L.ptr(a0), L.ptr(a1), L.ptr(b0), L.ptr(b1), L.ptr(og), None)
+        np.testing.assert_allclose(og.numpy(), g['interp'], rtol=1e-5, atol=3e-6)

@@ -298,7 +298,7 @@ def test_g6_loop(sd):
     check_loop_trace(trace, g)
 
 
-def check_loop_trace(trace, g, first=(1e-4, 1e-4, 2e-5), cosine=False):
+def check_loop_trace(trace, g, first=(1e-4, 1e-4, 2e-5), cosine=False, later_rtol=3e-2):
     """The optimisation trace is chaotic by construction: Adam's g/(|g|+eps) turns 1e-7 noise in near-zero
     gradient entries into +-lr steps, the rollout re-samples the raster at every step and the collision sets
     are hard-thresholded.  Measured reference-vs-oracle (both CPU fp32): iteration 0 agrees to 1e-6, iteration 1
@@ -308,7 +308,11 @@ def check_loop_trace(trace, g, first=(1e-4, 1e-4, 2e-5), cosine=False):
     gtol = [first[2], max(5e-3, first[2]), 1e-1]
     for it in range(len(trace)):
         got = [float(torch.mean(trace[it][k])) for k in keys]
-        np.testing.assert_allclose(got, g['losses'][it], rtol=first[0] if it == 0 else 3e-2, atol=first[1] if it == 0 else 2e-2)
+        # `later_rtol`: the collision terms are means over the pairs / agents CURRENTLY in collision, so a borderline
+        # pair entering or leaving the set moves them by ~10 % (golden trace: 0.503 -> 0.564 between iterations 1
+        # and 2); an implementation that is not bit-identical to torch CPU crosses such a threshold an iteration
+        # earlier or later
+        np.testing.assert_allclose(got, g['losses'][it], rtol=first[0] if it == 0 else later_rtol, atol=first[1] if it == 0 else 2e-2)
         if it < 3 and not cosine:
             assert_close(trace[it]['grad'], g['grad'][it], 1e-3, gtol[it], 'grad it%d' % it)
     if cosine:
