@@ -49,7 +49,8 @@ class StriveMap(C.Structure):
 
 class StriveCNN(C.Structure):
     _fields_ = [('w', C.c_void_p * 6), ('b', C.c_void_p * 6), ('gn_g', C.c_void_p * 6), ('gn_b', C.c_void_p * 6),
-                ('fc_wt', C.c_void_p), ('fc_b', C.c_void_p), ('w1_frag', C.c_void_p)]
+                ('fc_wt', C.c_void_p), ('fc_b', C.c_void_p), ('w1_frag', C.c_void_p),
+                ('w2_frag', C.c_void_p), ('w3_frag', C.c_void_p)]
 
 
 class StriveScenes(C.Structure):
@@ -97,6 +98,9 @@ PROTOTYPES = {
 }
 
 
+ABI_VERSION = 2   # include/strive_hip.h STRIVE_ABI_VERSION
+
+
 class StriveLib(object):
     def __init__(self, path=None, require_all=True):
         self.path = DEFAULT_LIB if path is None else path
@@ -121,8 +125,8 @@ class StriveLib(object):
             raise StriveHipError('%s lacks symbols: %s' % (self.path, ', '.join(self.missing)))
         if not self.missing or 'strive_abi_version' not in self.missing:
             v = self._strive_abi_version()
-            if v != 1:
-                raise StriveHipError('ABI version mismatch: library %d, binding 1' % v)
+            if v != ABI_VERSION:
+                raise StriveHipError('ABI version mismatch: library %d, binding %d' % (v, ABI_VERSION))
 
     def call(self, name, *args):
         fn = getattr(self, '_' + name, None)

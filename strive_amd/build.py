@@ -17,9 +17,10 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 SOURCES = ['capi.hip', 'map_crop.hip', 'map_cnn.hip', 'mlp_gnn.hip', 'rollout.hip', 'losses.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-fast-math', '-ffp-contract=on',
          '-fhip-fp32-correctly-rounded-divide-sqrt', '-Wno-unused-result', '-Wno-unused-value',
-         # no auto-formed v_pk_*_f32: see DESIGN.md "packed-fp32 write-after-write" (a half-dead packed result
-         # followed by a scalar write of the same VGPR lost the race for lanes 48-63 when two workgroups shared a CU)
-         '-fno-slp-vectorize']
+         # no auto-formed v_pk_*_f32: on MI355X a v_pk_add_f32 with crossed op_sel halves returned wrong values in
+         # lanes 48-63 whenever >= 4 waves shared the SIMD and a neighbour issued MFMAs (tools/pk_waw_probe.hip,
+         # profiles/r01_pk_add_opsel_probe.txt); audit_packed_ops() checks the built library
+         '-fno-slp-vectorize', '-fno-vectorize']
 
 
 def _sources():
@@ -36,6 +37,32 @@ def _stamp():
                     h.update(f.read())
     h.update(' '.join(FLAGS).encode())
     return h.hexdigest()
+
+
+def audit_packed_ops(lib=LIB):
+    """Disassemble the gfx950 code objects inside `lib`; return {mnemonic: count} of packed-fp32 VALU ops."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        return None
+    counts = {}
+    with tempfile.TemporaryDirectory() as td:
+        cp = os.path.join(td, os.path.basename(lib))
+        shutil.copy(lib, cp)
+        subprocess.run([objdump, '--offloading', cp], cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+        for fn in sorted(os.listdir(td)):
+            if 'amdgcn' not in fn:
+                continue
+            dis = subprocess.run([objdump, '-d', os.path.join(td, fn)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                 check=False).stdout.decode('utf-8', 'replace')
+            for m in re.finditer(r'\b(v_pk_(?:add|mul|fma)_f32)\b', dis):
+                counts[m.group(1)] = counts.get(m.group(1), 0) + 1
+            counts['_code_objects'] = counts.get('_code_objects', 0) + 1
+            counts['_mfma'] = counts.get('_mfma', 0) + len(re.findall(r'\bv_mfma_', dis))
+    return counts
 
 
 def build(force=False, verbose=True):

@@ -2,17 +2,17 @@
 // (reference src/models/traffic_model.py:69-87, 437-440), with the raster crop fused into the
 // first convolution so the (N,4,256,256) crop never exists in HBM.
 //
-// Every convolution is an implicit GEMM on the f32 matrix cores (exact fp32, = an fmaf chain):
-//     D[co][pixel] += W[co][k] * patch[k][pixel],    k = (ci, ky, kx)
-// with A = weights (M = output channels) and B = input patches (N = output pixels), so that the
-// accumulator columns are pixels and the NCHW stores are contiguous along x.
-//   layer 1 (Cout = 16):        v_mfma_f32_16x16x4_f32, the 4 k-lanes are the 4 input channels
-//   layers 2-6 (Cout = 32..128): v_mfma_f32_32x32x2_f32, the 2 k-lanes are an even/odd channel pair
+// Every convolution is an implicit GEMM on the matrix cores,
+//     D[co][pixel] += W[co][k] * patch[k][pixel]
+// with A = weights (M = output channels) and B = input patches (N = output pixels):
+//   layer 1 (u8 crop, Cout 16):  v_mfma_f32_16x16x32_bf16, weights split exactly into 3 bf16 pieces (exact fp32 result)
+//   layers 2-3 (fp32 NHWC in):   v_mfma_f32_16x16x32_bf16, both operands split exactly into 3 bf16 pieces, 6 products
+//   layers 4-6 (fp32 NCHW in):   v_mfma_f32_32x32x2_f32 (exact fp32, = an fmaf chain)
 // Input tiles are staged once per workgroup into LDS with the previous layer's GroupNorm + ReLU applied
 // on the way in (so normalised activations never exist in HBM either); columns are stored
 // de-interleaved by parity so the stride-2 window reads of consecutive output pixels hit consecutive
 // banks.  GroupNorm statistics (sum, sum of squares per sample, float64) are accumulated in the
-// epilogue of the producing convolution.
+// epilogue of the producing convolution, per tile, and added in tile order by the consumer.
 #include "common.h"
 #include "crop_dev.h"
 #include <stdlib.h>
@@ -39,148 +39,6 @@ __device__ __forceinline__ void gn_moments(const GNStats* __restrict__ st, int n
     var = var < 0.0 ? 0.0 : var;
     mean = (float)m;
     rstd = (float)(1.0 / sqrt(var + GN_EPS));
-}
-
-// =============================================================================================
-// Layer 1: (crop u8 4x256x256) -> raw conv output (16x125x125), 7x7 stride 2.
-// Workgroup = 4 waves, output tile 16x16; wave w owns output rows 4w..4w+3 (4 MFMA pixel tiles of 16).
-// =============================================================================================
-namespace l1 {
-constexpr int CIN = 4, COUT = 16, KS = 7, IH = 256, OH = 125;
-constexpr int TO = 16;                 // output tile edge
-constexpr int IT = 2 * TO + KS - 2;    // 37 input rows/cols per tile
-constexpr int HALFW = (IT + 1) / 2;    // 19
-constexpr int RS = 2 * HALFW;          // 38
-constexpr int PS = 1424;               // >= IT*RS = 1406, == 16 (mod 32): ci 0/1 land on disjoint banks
-constexpr int TILES = (OH + TO - 1) / TO;   // 8
-constexpr int WSZ = KS * KS * CIN * COUT;   // 3136 floats
-}  // namespace l1
-
-template <bool FUSED_CROP>
-__global__ __launch_bounds__(256) void conv1_kernel(StriveMap map, const float* __restrict__ pos, Float4Host pmean,
-                                                      Float4Host pstd, const int32_t* __restrict__ mapix,
-                                                      const uint8_t* __restrict__ crop, const float* __restrict__ wpk,
-                                                      const float* __restrict__ bias, float* __restrict__ out,
-                                                      GNStats* __restrict__ stats) {
-    using namespace l1;
-    __shared__ float s_in[CIN * PS];
-    __shared__ float s_w[WSZ];
-    __shared__ double s_red[8];
-    const int n = blockIdx.z;
-    const int oy0 = blockIdx.y * TO, ox0 = blockIdx.x * TO;
-    const int tid = threadIdx.x;
-
-    // ---- stage weights (already packed [ky][kx][ci][co]) ----
-    for (int i = tid; i < WSZ; i += 256) s_w[i] = wpk[i];
-
-    // ---- stage the input window, crop computed on the fly ----
-    CropFrame fr;
-    if (FUSED_CROP) fr = load_crop_frame(map, pos, pmean.v, pstd.v, mapix, n);
-    const size_t plane = FUSED_CROP ? (size_t)map.H * map.W : 0;
-    // two phases so that the (fp64) coordinate arithmetic of all of a thread's samples is done before any byte
-    // gather is waited for: the 4 x NIT gathers of a thread are then in flight together
-    constexpr int NIT = (IT * IT + 255) / 256;
-    const uint8_t* srcp[NIT];
-    size_t pxoff[NIT];
-    int dsto[NIT];
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        const int idx = tid + k * 256;
-        srcp[k] = nullptr;
-        pxoff[k] = 0;
-        dsto[k] = -1;
-        if (idx < IT * IT) {
-            const int r = idx / IT, c = idx - r * IT;
-            const int l = 2 * oy0 + r, w = 2 * ox0 + c;
-            dsto[k] = r * RS + (c >> 1) + (c & 1) * HALFW;
-            if (l < IH && w < IH) {
-                if (FUSED_CROP) {
-                    int px, py;
-                    crop_pixel(fr, map.lwise[l], map.wwise[w], true, px, py);
-                    srcp[k] = fr.base + (size_t)py * map.W + px;
-                    pxoff[k] = (size_t)py * map.W + px;
-                } else {
-                    srcp[k] = crop + (size_t)n * CIN * IH * IH + (size_t)l * IH + w;
-                }
-            }
-        }
-    }
-    const size_t cplane = FUSED_CROP ? plane : (size_t)IH * IH;
-    uint8_t bv[NIT][4];
-    if (FUSED_CROP && map.raster_px4) {
-        // one 32-bit gather per sample from the pixel-interleaved raster copy (4x fewer, 4x wider transactions)
-        const uint32_t* pk = map.raster_px4 + (size_t)mapix[n] * map.H * map.W;
-        uint32_t wv[NIT];
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) wv[k] = srcp[k] ? pk[pxoff[k]] : 0u;
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) bv[k][c] = (uint8_t)((wv[k] >> (8 * c)) & 0xffu);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) bv[k][c] = srcp[k] ? srcp[k][c * cplane] : (uint8_t)0;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        if (dsto[k] >= 0) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) s_in[c * PS + dsto[k]] = (float)bv[k][c];
-        }
-    }
-    __syncthreads();
-
-    const int lane = tid & 63, wave = tid >> 6;
-    const int kq = lane >> 4;      // k lane group = input channel
-    const int j = lane & 15;       // pixel column within the tile / output channel for A
-    f32x4 acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int bbase = kq * PS + (2 * (wave * 4)) * RS + j;
-#pragma unroll
-    for (int ky = 0; ky < KS; ++ky) {
-#pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-            const float a = s_w[((ky * KS + kx) * CIN + kq) * COUT + j];
-            const int off = ky * RS + (kx >> 1) + (kx & 1) * HALFW;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float b = s_in[bbase + i * 2 * RS + off];
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
-            }
-        }
-    }
-    // ---- epilogue: bias, store, GroupNorm statistics ----
-    // D layout: column = lane&15 = pixel x, row = (lane>>4)*4 + r = output channel
-    double lsum = 0.0, lsq = 0.0;
-    const int ox = ox0 + j;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int oy = oy0 + wave * 4 + i;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = kq * 4 + r;
-            const float v = acc[i][r] + bias[co];
-            if (oy < OH && ox < OH) {
-                out[(((size_t)n * COUT + co) * OH + oy) * OH + ox] = v;
-                lsum += (double)v;
-                lsq += (double)v * (double)v;
-            }
-        }
-    }
-    lsum = wave_sum_d(lsum);
-    lsq = wave_sum_d(lsq);
-    if (lane == 0) { s_red[wave * 2] = lsum; s_red[wave * 2 + 1] = lsq; }
-    __syncthreads();
-    if (tid == 0) {
-        GNStats& o = stats[(size_t)n * (TILES * TILES) + blockIdx.y * TILES + blockIdx.x];
-        o.sum = ((s_red[0] + s_red[2]) + s_red[4]) + s_red[6];
-        o.sq = ((s_red[1] + s_red[3]) + s_red[5]) + s_red[7];
-    }
 }
 
 // =============================================================================================
@@ -359,21 +217,23 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
                 for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i], acc[i], 0, 0, 0);
             }
         }
-        // epilogue: D column = lane&15 = pixel, row = (lane>>4)*4 + r = output channel
+        // epilogue: D column = lane&15 = pixel, row = (lane>>4)*4 + r = output channel; NHWC output, one 16-byte
+        // store per lane and pixel tile (the four lane groups complete the pixel's 64 bytes)
         double lsum = 0.0, lsq = 0.0;
         const int ox0 = tx * TOX;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + g * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int oy = oy0 + wave * 2 + (i >> 1), ox = ox0 + (i & 1) * 16 + j;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = g * 4 + r;
-                const float v = acc[i][r] + bias[co];
-                if (oy < OH && ox < OH) {
-                    if (DBG != 4) out[(((size_t)n * COUT + co) * OH + oy) * OH + ox] = v;
-                    lsum += (double)v;
-                    lsq += (double)v * (double)v;
-                }
+            float4 v;
+            v.x = acc[i][0] + bv.x;
+            v.y = acc[i][1] + bv.y;
+            v.z = acc[i][2] + bv.z;
+            v.w = acc[i][3] + bv.w;
+            if (oy < OH && ox < OH) {
+                if (DBG != 4) *reinterpret_cast<float4*>(out + (((size_t)n * OH + oy) * OH + ox) * COUT + g * 4) = v;
+                lsum += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+                lsq += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
             }
         }
         lsum = wave_sum_d(lsum);
@@ -667,10 +527,268 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void conv_mfma_kernel(const flo
     }
 }
 
+// =============================================================================================
+// Layers 2-3 on the bf16 matrix cores at fp32 accuracy ("bf16 x 6").
+// Both operands are split EXACTLY into three bf16 pieces (x = x0 + x1 + x2, 8 mantissa bits each; the weights on
+// the host, the activations while they are staged into LDS, by truncation: x0 = x & 0xffff0000, x1 likewise of
+// x - x0, x2 = the rest) and the six products down to 2^-16 of the leading one are accumulated in fp32 inside
+// v_mfma_f32_16x16x32_bf16:  a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0.  The dropped terms are <= 2^-23 of
+// a product, i.e. the size of one fp32 rounding of that product: the result is an fp32 dot product in another
+// summation order, at 16/6 of the fp32 matrix rate.
+// Activations are NHWC fp32 in HBM; the previous layer's GroupNorm + ReLU is applied on the way into LDS.
+// LDS input layout: [piece 3][channel octet][row][column parity][column/2][8 x bf16]: one 16-byte slot per pixel
+// and octet, consecutive output pixels (stride 2 in the input) in consecutive slots.
+// k order: slot q = (window tap t, channel octet c) = (q / OCT, q % OCT); MFMA step s covers slots 4s..4s+3, lane
+// group g = lane / 16 holds slot 4s + g; slots past the last tap carry zero weights.
+// Workgroup: 4 waves, (4 PT) x 16 output pixels x 32 output channels; wave w owns PT output rows (pixel tiles of 16)
+// and both channel tiles: per MFMA step it reads 3 (PT + 2) fragments from LDS for 12 PT MFMAs.  Input channels are
+// staged PASS_CH at a time (CIN / PASS_CH passes); the weight fragments of one MFMA step (6 KB) are
+// double-buffered through LDS.
+// =============================================================================================
+template <int CIN_, int COUT_, int KS_, int IH_, int OH_, int NPART_IN_, bool OUT_NHWC_, int PT_ = 4, int PASS_CH_ = 8>
+struct BfCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, KS = KS_, IH = IH_, OH = OH_, NPART_IN = NPART_IN_;
+    static constexpr bool OUT_NHWC = OUT_NHWC_;
+    static constexpr int PT = PT_;                                  // pixel tiles (= output rows) per wave
+    static constexpr int NT = 256, NW = 4, TH = NW * PT, TW = 16;
+    static constexpr int COUT_WG = 32, CSPLIT = COUT / COUT_WG;
+    static constexpr int PASS_CH = PASS_CH_, OCT = PASS_CH / 8, NPASS = CIN / PASS_CH;
+    static constexpr int ITH = 2 * TH + KS - 2, ITW = 2 * TW + KS - 2, HW = (ITW + 1) / 2;
+    static constexpr int HALF_B = HW * 16, ROW_B = 2 * HALF_B, OCT_B = ITH * ROW_B, PIECE_B = OCT * OCT_B;
+    static constexpr int IN_B = 3 * PIECE_B;
+    static constexpr int NSLOT = KS * KS * OCT, NKS = (NSLOT + 3) / 4;     // MFMA steps per pass
+    static constexpr int WSTEP_B = 2 * 3 * 64 * 16;                         // [channel tile][piece][lane][16 B]
+    static constexpr int TILES_X = (OH + TW - 1) / TW, TILES_Y = (OH + TH - 1) / TH;
+    static constexpr int NPART_OUT = TILES_X * TILES_Y * CSPLIT;
+    static constexpr int UNITS = ITH * ITW * OCT, UITERS = (UNITS + NT - 1) / NT;
+    static constexpr size_t LDS_BYTES = (size_t)IN_B + 2 * WSTEP_B + (size_t)CIN * 8 + NW * 16 + 16;
+    static constexpr size_t WFRAG_BYTES = (size_t)NPASS * NKS * CSPLIT * WSTEP_B;
+    static_assert(CIN % PASS_CH == 0 && COUT % COUT_WG == 0, "channel tiling");
+    static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+    static_assert(WSTEP_B == 3 * 8 * NT, "weight step = three 8-byte pieces per thread");
+};
+
+__device__ __forceinline__ void split_bf16x3(const float v[8], uint4& p0, uint4& p1, uint4& p2) {
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t b0 = __float_as_uint(v[i]) & 0xffff0000u;
+        const float r1 = v[i] - __uint_as_float(b0);               // exact
+        const uint32_t b1 = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(b1);                 // exact, <= 8 significant bits
+        h[i] = b0;
+        m[i] = b1;
+        l[i] = __float_as_uint(r2);
+    }
+    p0 = make_uint4((h[0] >> 16) | h[1], (h[2] >> 16) | h[3], (h[4] >> 16) | h[5], (h[6] >> 16) | h[7]);
+    p1 = make_uint4((m[0] >> 16) | m[1], (m[2] >> 16) | m[3], (m[4] >> 16) | m[5], (m[6] >> 16) | m[7]);
+    p2 = make_uint4((l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u), (l[4] >> 16) | (l[5] & 0xffff0000u),
+                    (l[6] >> 16) | (l[7] & 0xffff0000u));
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
+                                                                const float* __restrict__ gn_g, const float* __restrict__ gn_b,
+                                                                const uint32_t* __restrict__ wfrag, const float* __restrict__ bias,
+                                                                float* __restrict__ out, GNStats* __restrict__ st_out, int N) {
+    constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, KS = Cfg::KS, IH = Cfg::IH, OH = Cfg::OH, NT = Cfg::NT;
+    constexpr int TH = Cfg::TH, TW = Cfg::TW, ITW = Cfg::ITW, OCT = Cfg::OCT;
+    HIP_DYNAMIC_SHARED(float, smem)
+    unsigned char* s_in = reinterpret_cast<unsigned char*>(smem);
+    unsigned char* s_w = s_in + Cfg::IN_B;
+    float* s_gn = (float*)(s_w + 2 * Cfg::WSTEP_B);              // [CIN][2] scale, shift
+    double* s_red = (double*)(s_gn + 2 * CIN);
+    float* s_mr = (float*)(s_red + 2 * Cfg::NW);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int n = blockIdx.z;
+    const int tile_x = blockIdx.x % Cfg::TILES_X, cb = blockIdx.x / Cfg::TILES_X;
+    const int oy0 = blockIdx.y * TH, ox0 = tile_x * TW;
+    const int iy0 = 2 * oy0, ix0 = 2 * ox0;
+
+    if (tid == 0) {
+        float mean, rstd;
+        gn_moments(st_in, n, Cfg::NPART_IN, (double)CIN * IH * IH, mean, rstd);
+        s_mr[0] = mean;
+        s_mr[1] = rstd;
+    }
+    __syncthreads();
+    for (int c = tid; c < CIN; c += NT) {
+        const float sc = s_mr[1] * gn_g[c];
+        s_gn[2 * c] = sc;
+        s_gn[2 * c + 1] = gn_b[c] - s_mr[0] * sc;
+    }
+
+    constexpr int PT = Cfg::PT;
+    f32x4 acc[PT][2];
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // byte offset of this lane's pixel (window origin) in the wave's first output row; row i is 2*i input rows further
+    const int lane_base = (2 * PT * wave) * Cfg::ROW_B + j * 16;
+
+    const float* in_n = in + (size_t)n * IH * IH * CIN;
+    const uint4* wsrc = reinterpret_cast<const uint4*>(wfrag);
+    constexpr int WQ = Cfg::WSTEP_B / 16;                         // 384 x 16 B per MFMA step
+    auto wstep_src = [&](int pass, int s) { return wsrc + ((size_t)(pass * Cfg::NKS + s) * Cfg::CSPLIT + cb) * WQ; };
+
+    for (int pass = 0; pass < Cfg::NPASS; ++pass) {
+        __syncthreads();        // s_gn ready (pass 0) / every wave is done with the previous pass's tiles
+        // ---- stage 16 input channels of the (2TH+KS-2) x (2TW+KS-2) window: GroupNorm + ReLU, exact 3-way split ----
+#pragma unroll 2
+        for (int k = 0; k < Cfg::UITERS; ++k) {
+            const int idx = tid + k * NT;
+            if (idx < Cfg::UNITS) {
+                const int c = idx % OCT, pix = idx / OCT;
+                const int col = pix % ITW, r = pix / ITW;
+                const int iy = iy0 + r, ix = ix0 + col;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;             // exact zero outside the image
+                if (iy < IH && ix < IH) {
+                    const int ch0 = pass * Cfg::PASS_CH + c * 8;
+                    const float4* src = reinterpret_cast<const float4*>(in_n + ((size_t)iy * IH + ix) * CIN + ch0);
+                    const float4 a = src[0], b = src[1];
+                    const float4* gn = reinterpret_cast<const float4*>(s_gn + 2 * ch0);
+                    const float4 g0 = gn[0], g1 = gn[1], g2 = gn[2], g3 = gn[3];
+                    v[0] = fmaxf(fmaf(a.x, g0.x, g0.y), 0.f);
+                    v[1] = fmaxf(fmaf(a.y, g0.z, g0.w), 0.f);
+                    v[2] = fmaxf(fmaf(a.z, g1.x, g1.y), 0.f);
+                    v[3] = fmaxf(fmaf(a.w, g1.z, g1.w), 0.f);
+                    v[4] = fmaxf(fmaf(b.x, g2.x, g2.y), 0.f);
+                    v[5] = fmaxf(fmaf(b.y, g2.z, g2.w), 0.f);
+                    v[6] = fmaxf(fmaf(b.z, g3.x, g3.y), 0.f);
+                    v[7] = fmaxf(fmaf(b.w, g3.z, g3.w), 0.f);
+                }
+                uint4 p0, p1, p2;
+                split_bf16x3(v, p0, p1, p2);
+                unsigned char* dst = s_in + c * Cfg::OCT_B + r * Cfg::ROW_B + (col & 1) * Cfg::HALF_B + (col >> 1) * 16;
+                *reinterpret_cast<uint4*>(dst) = p0;
+                *reinterpret_cast<uint4*>(dst + Cfg::PIECE_B) = p1;
+                *reinterpret_cast<uint4*>(dst + 2 * Cfg::PIECE_B) = p2;
+            }
+        }
+        // ---- weight fragments of step 0 ----
+        {
+            const uint4* ws = wstep_src(pass, 0);
+            for (int q = tid; q < WQ; q += NT) reinterpret_cast<uint4*>(s_w)[q] = ws[q];
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int s = 0; s < Cfg::NKS; ++s) {
+            const int buf = s & 1;
+            // prefetch the next step's fragments into registers
+            const bool more = s + 1 < Cfg::NKS;
+            // 6144 bytes = 3 x 8 per thread (the last step re-reads its own fragments: no branch)
+            const uint2* ws = reinterpret_cast<const uint2*>(wstep_src(pass, more ? s + 1 : s));
+            const uint2 wn0 = ws[tid], wn1 = ws[tid + NT], wn2 = ws[tid + 2 * NT];
+            __builtin_amdgcn_sched_barrier(0);                        // keep the loads above the matrix work
+            // this lane group's slot: (tap, channel octet)
+            int q = 4 * s + g;
+            q = q < Cfg::NSLOT ? q : 0;                              // padding slots: zero weights, any valid address
+            const int t = q / OCT, c = q - t * OCT;
+            const int ky = t / KS, kx = t - ky * KS;
+            const int off = c * Cfg::OCT_B + ky * Cfg::ROW_B + (kx & 1) * Cfg::HALF_B + (kx >> 1) * 16;
+            bf16x8 a[2][3], b[PT][3];
+            const unsigned char* wb = s_w + buf * Cfg::WSTEP_B + lane * 16;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[ct][pl] = *reinterpret_cast<const bf16x8*>(wb + (ct * 3 + pl) * 1024);
+#pragma unroll
+            for (int i = 0; i < PT; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    b[i][pl] = *reinterpret_cast<const bf16x8*>(s_in + pl * Cfg::PIECE_B + 2 * i * Cfg::ROW_B + lane_base + off);
+#pragma unroll
+            for (int i = 0; i < PT; ++i)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    f32x4 d = acc[i][ct];
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ct][2], b[i][0], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ct][0], b[i][2], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ct][1], b[i][1], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ct][1], b[i][0], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ct][0], b[i][1], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ct][0], b[i][0], d, 0, 0, 0);
+                    acc[i][ct] = d;
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            {   // (after the last step this rewrites the idle buffer with the step's own fragments: harmless, branch-free)
+                uint2* wd = reinterpret_cast<uint2*>(s_w + (buf ^ 1) * Cfg::WSTEP_B);
+                wd[tid] = wn0;
+                wd[tid + NT] = wn1;
+                wd[tid + 2 * NT] = wn2;
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: D column = lane&15 = pixel, row = (lane>>4)*4 + r = channel within the tile ----
+    double lsum = 0.0, lsq = 0.0;
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int oy = oy0 + PT * wave + i, ox = ox0 + j;
+        const bool valid = oy < OH && ox < OH;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int co = cb * Cfg::COUT_WG + ct * 16 + g * 4;
+            const float4 bv = *reinterpret_cast<const float4*>(bias + co);
+            float4 v;
+            v.x = acc[i][ct][0] + bv.x;
+            v.y = acc[i][ct][1] + bv.y;
+            v.z = acc[i][ct][2] + bv.z;
+            v.w = acc[i][ct][3] + bv.w;
+            if (valid) {
+                if (Cfg::OUT_NHWC) {
+                    *reinterpret_cast<float4*>(out + (((size_t)n * OH + oy) * OH + ox) * COUT + co) = v;
+                } else {
+                    float* o = out + (((size_t)n * COUT + co) * OH + oy) * OH + ox;
+                    o[0] = v.x;
+                    o[(size_t)OH * OH] = v.y;
+                    o[(size_t)2 * OH * OH] = v.z;
+                    o[(size_t)3 * OH * OH] = v.w;
+                }
+                lsum += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+                lsq += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+            }
+        }
+    }
+    lsum = wave_sum_d(lsum);
+    lsq = wave_sum_d(lsq);
+    if (lane == 0) { s_red[2 * wave] = lsum; s_red[2 * wave + 1] = lsq; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < Cfg::NW; ++w) { a += s_red[2 * w]; b += s_red[2 * w + 1]; }
+        GNStats& o = st_out[(size_t)n * Cfg::NPART_OUT + (blockIdx.y * Cfg::TILES_X + tile_x) * Cfg::CSPLIT + cb];
+        o.sum = a;
+        o.sq = b;
+    }
+}
+
+typedef BfCfg<16, 32, 5, 125, 61, l1b::NPART, true> Bf2;     // conv2: NHWC in, NHWC out
+typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, false> Bf3;  // conv3: NHWC in, NCHW out (layers 4-6 stay on the fp32 path)
+
+template <class Cfg>
+static int launch_bf6(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
+                      const float* bias, float* out, GNStats* st_out, int N, hipStream_t stream) {
+    dim3 grid(Cfg::TILES_X * Cfg::CSPLIT, Cfg::TILES_Y, N);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_bf6_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_bf6_kernel<Cfg>, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out,
+                       st_out, N);
+    return 0;
+}
+
 // per-layer configurations            CIN COUT KS  IH  OH  TH  TW  S  CC NWP NWM NPW MTW NPART_IN
-typedef ConvCfg< 16,  32, 5, 125, 61, 16, 16,  1,  4,  4,  1,  2,  1, l1b::NPART, 3> Cfg2;   // 16x16 px tile, 4 waves, 4096 WGs / 256 agents
-typedef ConvCfg< 32,  64, 5,  61, 29, 29, 29,  1,  2,  7,  1,  4,  2, 16> Cfg3;   // whole image (841 px), 7 waves
-typedef ConvCfg< 64,  64, 3,  29, 14, 14, 14,  1,  8,  4,  1,  2,  2,  1, 2> Cfg4;   // whole image (196 px), 4 waves, 1 WG / agent
+typedef ConvCfg< 64,  64, 3,  29, 14, 14, 14,  1,  8,  4,  1,  2,  2, Bf3::NPART_OUT, 2> Cfg4;   // whole image (196 px), 4 waves, 1 WG / agent
 typedef ConvCfg< 64, 128, 3,  14,  6,  6,  6,  2,  8,  3,  2,  1,  1,  1> Cfg5;   // 2 agents (72 px) x 64 of 128 channels, 6 waves
 typedef ConvCfg<128, 128, 3,   6,  2,  2,  2,  8,  8,  1,  4,  1,  1,  2> Cfg6;   // 8 agents (32 px), 4 waves x 32 channels
 
@@ -736,9 +854,9 @@ static int cnn_chunk() {
     }
     return v;
 }
-constexpr int NPARTS[6] = {l1b::NPART, Cfg2::NPART_OUT, Cfg3::NPART_OUT, Cfg4::NPART_OUT, Cfg5::NPART_OUT, Cfg6::NPART_OUT};
-constexpr int STAT_SLOTS = l1b::NPART + Cfg2::NPART_OUT + Cfg3::NPART_OUT + Cfg4::NPART_OUT + Cfg5::NPART_OUT + Cfg6::NPART_OUT;
-static_assert(Cfg3::NPART_IN == Cfg2::NPART_OUT && Cfg4::NPART_IN == Cfg3::NPART_OUT && Cfg5::NPART_IN == Cfg4::NPART_OUT &&
+constexpr int NPARTS[6] = {l1b::NPART, Bf2::NPART_OUT, Bf3::NPART_OUT, Cfg4::NPART_OUT, Cfg5::NPART_OUT, Cfg6::NPART_OUT};
+constexpr int STAT_SLOTS = l1b::NPART + Bf2::NPART_OUT + Bf3::NPART_OUT + Cfg4::NPART_OUT + Cfg5::NPART_OUT + Cfg6::NPART_OUT;
+static_assert(Cfg4::NPART_IN == Bf3::NPART_OUT && Cfg5::NPART_IN == Cfg4::NPART_OUT &&
               Cfg6::NPART_IN == Cfg5::NPART_OUT, "statistics slot chain");   // agents pushed through the layer stack together (keeps the working set L3-sized)
 
 size_t per_agent_floats() {
@@ -797,8 +915,8 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
                                (const int32_t*)nullptr, crop + (size_t)n0 * 4 * 256 * 256, cnn->w1_frag,
                                (const float*)cnn->b[0], act[0], st[0]);
         }
-        launch_conv<Cfg2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w[1], cnn->b[1], act[1], st[1], n, stream);
-        launch_conv<Cfg3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w[2], cnn->b[2], act[2], st[2], n, stream);
+        launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], n, stream);
+        launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, stream);
         launch_conv<Cfg4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w[3], cnn->b[3], act[3], st[3], n, stream);
         launch_conv<Cfg5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w[4], cnn->b[4], act[4], st[4], n, stream);
         launch_conv<Cfg6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w[5], cnn->b[5], act[5], st[5], n, stream);
@@ -860,8 +978,8 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
             if (layer == 13) hipLaunchKernelGGL((conv1b_kernel<true, 3>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, (const float*)cnn->b[0], act[0], st[0]);
             break;
         }
-        case 1: launch_conv<Cfg2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w[1], cnn->b[1], act[1], st[1], N, stream); break;
-        case 2: launch_conv<Cfg3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w[2], cnn->b[2], act[2], st[2], N, stream); break;
+        case 1: launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, stream); break;
+        case 2: launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, stream); break;
         case 3: launch_conv<Cfg4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w[3], cnn->b[3], act[3], st[3], N, stream); break;
         case 4: launch_conv<Cfg5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w[4], cnn->b[4], act[4], st[4], N, stream); break;
         case 5: launch_conv<Cfg6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w[5], cnn->b[5], act[5], st[5], N, stream); break;

@@ -102,19 +102,50 @@ def _conv1_fragments(w):
     """(16,4,7,7) fp32 -> int32 tensor holding [ky][piece][lane][8 x bf16]: the exact three-way bf16 split of every
     weight in the k order of conv1b_kernel (lane group g: window columns 2g, 2g+1; element = parity*4 + layer;
     column 7 is zero padding)."""
+    pieces = _bf16_split3(w, 'conv1')                                # (3, co, ci, ky, kx)
+    pad = torch.zeros((3, 16, 4, 7, 1), dtype=torch.bfloat16, device=w.device)
+    pk = torch.cat([pieces, pad], dim=4).view(3, 16, 4, 7, 4, 2)     # kx -> (g, parity)
+    # -> [ky][piece][g][co][parity][ci]
+    frag = pk.permute(3, 0, 4, 1, 5, 2).contiguous()                 # (7, 3, 4, 16, 2, 4)
+    return frag.view(torch.int16).view(7, 3, 64, 8).contiguous().view(torch.int32)
+
+
+def _bf16_split3(w, what):
     hi = w.to(torch.bfloat16)
     r1 = w - hi.to(torch.float32)
     mid = r1.to(torch.bfloat16)
     r2 = r1 - mid.to(torch.float32)
     lo = r2.to(torch.bfloat16)
     if not torch.equal(hi.float() + mid.float() + lo.float(), w):
-        raise ValueError('conv1 weights are not exactly representable as three bf16 pieces (non-finite or subnormal?)')
-    pieces = torch.stack([hi, mid, lo], dim=0)                       # (3, co, ci, ky, kx)
-    pad = torch.zeros((3, 16, 4, 7, 1), dtype=torch.bfloat16, device=w.device)
-    pk = torch.cat([pieces, pad], dim=4).view(3, 16, 4, 7, 4, 2)     # kx -> (g, parity)
-    # -> [ky][piece][g][co][parity][ci]
-    frag = pk.permute(3, 0, 4, 1, 5, 2).contiguous()                 # (7, 3, 4, 16, 2, 4)
-    return frag.view(torch.int16).view(7, 3, 64, 8).contiguous().view(torch.int32)
+        raise ValueError('%s weights are not exactly representable as three bf16 pieces (non-finite or subnormal?)' % what)
+    return torch.stack([hi, mid, lo], dim=0)
+
+
+BF6_PASS_CH = 8     # input channels staged per pass by conv_bf6_kernel (BfCfg::PASS_CH)
+
+
+def _conv_bf6_fragments(w, pass_ch=BF6_PASS_CH):
+    """(co, ci, 5, 5) fp32 -> int32 tensor [pass = ci/pass_ch][step][co/32][co tile][piece][lane][8 x bf16] in the k order
+    of conv_bf6_kernel: lane group g of MFMA step s holds k slot q = 4s + g = (tap q // OCT, channel octet q % OCT),
+    OCT = pass_ch / 8."""
+    co, ci, k, _ = w.shape
+    pieces = _bf16_split3(w, 'conv').permute(0, 1, 3, 4, 2).contiguous()      # (3, co, ky, kx, ci)
+    npass, csplit, oct_ = ci // pass_ch, co // 32, pass_ch // 8
+    nslot = k * k * oct_
+    nks = (nslot + 3) // 4
+    out = torch.zeros((npass, nks, csplit, 2, 3, 4, 16, 8), dtype=torch.bfloat16, device=w.device)
+    for p_ in range(npass):
+        for s_ in range(nks):
+            for g in range(4):
+                q = 4 * s_ + g
+                if q >= nslot:
+                    continue
+                t, c = q // oct_, q % oct_
+                ky, kx = t // k, t % k
+                ch0 = pass_ch * p_ + 8 * c
+                blk = pieces[:, :, ky, kx, ch0:ch0 + 8]                          # (3, co, 8)
+                out[p_, s_, :, :, :, g] = blk.view(3, csplit, 2, 16, 8).permute(1, 2, 0, 3, 4)
+    return out.contiguous().view(torch.int16).view(-1, 8).contiguous().view(torch.int32)
 
 
 def _fill_cnn(s, holder, sd):
@@ -134,6 +165,8 @@ def _fill_cnn(s, holder, sd):
         s.gn_g[l] = holder.hold(_c(sd['map_conv.%d.weight' % (3 * l + 1)]))
         s.gn_b[l] = holder.hold(_c(sd['map_conv.%d.bias' % (3 * l + 1)]))
     s.w1_frag = holder.hold(_conv1_fragments(_c(sd['map_conv.0.weight'])))
+    s.w2_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.3.weight'])))
+    s.w3_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.6.weight'])))
     fw = _c(sd['map_feature.weight'])
     if tuple(fw.shape) != (64, 512):
         raise NotImplementedError('map_feature must be Linear(512, 64)')

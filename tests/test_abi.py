@@ -25,7 +25,7 @@ def test_hip_library_builds_loads_and_exports_everything():
     assert os.path.exists(path)
     lib = L.StriveLib(path)            # raises if any symbol is missing
     assert lib.missing == []
-    assert lib.query('strive_abi_version') == 1
+    assert lib.query("strive_abi_version") == 2
 
 
 def test_every_entry_point_cites_the_reference():
@@ -45,3 +45,16 @@ def test_product_never_imports_the_oracle():
     out = subprocess.run(['grep', '-rln', '--include=*.py', '-E', r'^\s*(from|import)\s+oracle', os.path.join(REPO, 'strive_amd')],
                          capture_output=True, text=True).stdout.strip()
     assert out == '', 'strive_amd imports oracle: %s' % out
+
+
+def test_no_packed_fp32_ops_in_the_device_code():
+    """MI355X returned wrong values in lanes 48-63 for v_pk_add_f32 with crossed op_sel halves when >= 4 waves shared
+    a SIMD with MFMA-issuing neighbours (tools/pk_waw_probe.hip, profiles/r01_pk_add_opsel_probe.txt).  The library
+    is therefore built without auto-formed packed fp32 arithmetic; this checks the disassembly of what was built."""
+    from strive_amd import build
+    counts = build.audit_packed_ops()
+    if counts is None:
+        pytest.skip('llvm-objdump not available')
+    assert counts.get('_code_objects', 0) >= 1 and counts.get('_mfma', 0) > 0, 'no gfx950 code objects found: %r' % (counts,)
+    packed = {k: v for k, v in counts.items() if not k.startswith('_')}
+    assert not packed, 'packed fp32 VALU ops in the device code: %r' % (packed,)

@@ -244,7 +244,10 @@ def test_rollout_smooth_map_tight(model, sizes, FT, NS, ext):
     raster, dx = uniform_env()
     pc, gc, pg, gg = _rollout_pair(m, sd, sizes, 'gr/%d_%d_%d' % (len(sizes), FT, NS), raster, dx, FT, NS=NS, ext=ext)
     assert_close(pg, pc, RT, AT, 'future_pred')
-    assert_close(gg, gc, 2e-3, 1e-6 + 1e-4 * float(gc.abs().max()), 'dL/dz')
+    # map features carry ~1.6x torch-fp32's own rounding noise (tools/cnn_accuracy.py: max 1.4e-6 vs 8.4e-7 against a
+    # float64 evaluation); 12-16 recurrent steps with LayerNorm / max-aggregation kinks amplify that to ~1e-4 of the
+    # gradient scale on isolated entries
+    assert_close(gg, gc, 2e-3, 1e-6 + 2e-4 * float(gc.abs().max()), 'dL/dz')
 
 
 def test_rollout_two_steps_textured(model):
