@@ -32,8 +32,14 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, den
 # algorithmic FLOPs per agent of each map-CNN kernel (2 * Cout * OH * OW * Cin * k * k), SURVEY.md §8(a) a8
 CONV_FLOPS = [2 * 16 * 125 * 125 * 4 * 49, 2 * 32 * 61 * 61 * 16 * 25, 2 * 64 * 29 * 29 * 32 * 25,
               2 * 64 * 14 * 14 * 64 * 9, 2 * 128 * 6 * 6 * 64 * 9, 2 * 128 * 2 * 2 * 128 * 9]
-CONV_NAMES = ['conv1_kernel (fused crop, 16x16x4 f32 MFMA)', 'conv_mfma_kernel<conv2>', 'conv_mfma_kernel<conv3>',
+CONV_NAMES = ['conv1b_kernel<true> (fused crop -> conv1)', 'conv_bf6_kernel<conv2>', 'conv_bf6_kernel<conv3>',
               'conv_mfma_kernel<conv4>', 'conv_mfma_kernel<conv5>', 'conv_mfma_kernel<conv6>']
+# matrix-core work actually issued per algorithmic FLOP and the dense peak it runs against
+# (/opt/skills/guides/MI355X_MICROARCH.md: bf16 dense 2516 TFLOP/s, f32 157.3): conv1 = 3 exact bf16 weight pieces,
+# conv2/conv3 = 6 bf16 products per fp32 product, conv4-6 = the f32 matrix instruction
+PEAK_BF16_MFMA_TFLOPS = 2516.0
+CONV_ISSUE = [(3, PEAK_BF16_MFMA_TFLOPS, 'bf16'), (6, PEAK_BF16_MFMA_TFLOPS, 'bf16'), (6, PEAK_BF16_MFMA_TFLOPS, 'bf16'),
+              (1, PEAK_FP32_MFMA_TFLOPS, 'f32'), (1, PEAK_FP32_MFMA_TFLOPS, 'f32'), (1, PEAK_FP32_MFMA_TFLOPS, 'f32')]
 
 REFINE_WEIGHTS = {'coll_veh': 100.0, 'coll_env': 100.0, 'init_z': 0.01, 'motion_prior': 1.0}   # refine_traffic_optim.cfg:26-29
 
@@ -80,12 +86,24 @@ def gpu_closure_factory(m, env, batch, map_idx, FT, device):
     return step, z, emb, g, mi
 
 
+def _measured_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json, written
+    from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); None if not collected for this kernel."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')) as f:
+            t = json.load(f)
+        ent = t.get(kernel_name)
+        return None if ent is None else ent.get('bytes_per_launch')
+    except Exception:
+        return None
+
+
 def time_dominant_kernel(m, env, g, mi, emb, device, reps=20):
     """Time each CNN kernel in isolation (events on torch's current stream = the launching stream) and return
     the roofline record of the one that takes the most time per rollout step."""
     from strive_amd import ops, _lib as L
     lib = L.get_lib()
-    N = min(256, g.past.shape[0])
+    N = min(512, g.past.shape[0])      # = the size of the launches inside the timed closure (one CNN chunk)
     pos = g.past[:N, -1, :4].contiguous()
     mapix = mi[g.batch][:N].to(torch.int32).contiguous()
     mp = ops._map_pack(env, device)
@@ -113,13 +131,16 @@ def time_dominant_kernel(m, env, g, mi, emb, device, reps=20):
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1) * 1e-3 / reps)
     dom = max(range(6), key=lambda l: times[l])
-    flops = CONV_FLOPS[dom] * N
-    ach = flops / times[dom] / 1e12
-    rec = {'bound': 'mfma', 'kernel': CONV_NAMES[dom], 'achieved': round(ach, 3), 'peak': PEAK_FP32_MFMA_TFLOPS,
-           'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+    mult, peak, mdt = CONV_ISSUE[dom]
+    alg = CONV_FLOPS[dom] * N / times[dom] / 1e12          # algorithmic (fp32-equivalent) TFLOP/s
+    ach = alg * mult                                       # matrix-core FLOP/s actually issued
+    rec = {'bound': 'mfma', 'kernel': CONV_NAMES[dom], 'achieved': round(ach, 3), 'peak': peak,
+           'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': _measured_traffic(CONV_NAMES[dom]),
+           'mfma_dtype': mdt, 'products_per_fp32_product': mult, 'algorithmic_tflops': round(alg, 3),
+           'frac_of_f32_matrix_peak': round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
            'launch_us': round(times[dom] * 1e6, 2), 'agents_per_launch': N,
            'all_layers_us': [round(t * 1e6, 2) for t in times],
-           'all_layers_tflops': [round(CONV_FLOPS[l] * N / times[l] / 1e12, 2) for l in range(6)]}
+           'all_layers_algorithmic_tflops': [round(CONV_FLOPS[l] * N / times[l] / 1e12, 2) for l in range(6)]}
     return rec
 
 

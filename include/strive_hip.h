@@ -105,10 +105,10 @@ typedef struct StriveCNN {
                                   order [ky][piece][lane 0..63][8 x bf16], 8 values = window columns 2g,2g+1 x 4 layers for
                                   lane group g = lane/16, output channel = lane%16; 21504 bytes */
     const uint32_t* w2_frag;   /* layer-1 (16->32, 5x5) and layer-2 (32->64, 5x5) weights, each split exactly into three bf16 */
-    const uint32_t* w3_frag;   /* pieces, in the fragment order of conv_bf6_kernel: [pass = ci/8][step s = 0..6][co/32]
-                                  [co tile 2][piece 3][lane 64][8 x bf16]; lane group g = lane/16 holds window tap 4s+g,
-                                  element e = input channel 8*pass + e, output channel = 32*(co/32) + 16*tile + lane%16;
-                                  taps past 24 are zero.  86016 / 344064 bytes */
+    const uint32_t* w3_frag;   /* pieces, in the fragment order of conv_bf6_kernel: [pass = ci/8][step s = 0..12][co/32]
+                                  [piece 3][lane 64][8 x bf16]; lane half h = lane/32 holds the window tap (s/2, (s&1)+2h)
+                                  for s < 10, (2(s-10)+h, 4) for s = 10, 11, (4, 4) or zero for s = 12; element e = input
+                                  channel 8*pass + e, output channel = 32*(co/32) + lane%32.  79872 / 319488 bytes */
 } StriveCNN;
 
 /* Scene structure of a batch: agents of scene b are rows ptr[b] .. ptr[b+1]-1, ego first

@@ -9,6 +9,9 @@ from collections import defaultdict
 def short(name):
     name = re.sub(r'\(.*$', '', name)
     name = re.sub(r'^void\s+', '', name)
+    m = re.match(r'conv_bf6_kernel<BfCfg<(\d+), (\d+), (\d+), (\d+), (\d+)', name)
+    if m:
+        return 'conv_bf6_kernel<Cin=%s,Cout=%s,k=%s,in=%s,out=%s>' % m.groups()
     m = re.match(r'conv_mfma_kernel<ConvCfg<(\d+), (\d+), (\d+), (\d+), (\d+)', name)
     if m:
         return 'conv<Cin=%s,Cout=%s,k=%s,in=%s,out=%s>' % m.groups()

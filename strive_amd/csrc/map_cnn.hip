@@ -6,7 +6,7 @@
 //     D[co][pixel] += W[co][k] * patch[k][pixel]
 // with A = weights (M = output channels) and B = input patches (N = output pixels):
 //   layer 1 (u8 crop, Cout 16):  v_mfma_f32_16x16x32_bf16, weights split exactly into 3 bf16 pieces (exact fp32 result)
-//   layers 2-3 (fp32 NHWC in):   v_mfma_f32_16x16x32_bf16, both operands split exactly into 3 bf16 pieces, 6 products
+//   layers 2-3 (fp32 in):        v_mfma_f32_32x32x16_bf16, both operands split exactly into 3 bf16 pieces, 6 products
 //   layers 4-6 (fp32 NCHW in):   v_mfma_f32_32x32x2_f32 (exact fp32, = an fmaf chain)
 // Input tiles are staged once per workgroup into LDS with the previous layer's GroupNorm + ReLU applied
 // on the way in (so normalised activations never exist in HBM either); columns are stored
@@ -217,8 +217,9 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
                 for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i], acc[i], 0, 0, 0);
             }
         }
-        // epilogue: D column = lane&15 = pixel, row = (lane>>4)*4 + r = output channel; NHWC output, one 16-byte
-        // store per lane and pixel tile (the four lane groups complete the pixel's 64 bytes)
+        // epilogue: D column = lane&15 = pixel, row = (lane>>4)*4 + r = output channel.  Output layout = channel
+        // octets as planes, [n][c/8][y][x][c%8] ("octet-planar"): the consumer stages 8 channels per pass and reads
+        // 32 contiguous bytes per pixel; one 16-byte store per lane and pixel tile
         double lsum = 0.0, lsq = 0.0;
         const int ox0 = tx * TOX;
         const float4 bv = *reinterpret_cast<const float4*>(bias + g * 4);
@@ -231,7 +232,8 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
             v.z = acc[i][2] + bv.z;
             v.w = acc[i][3] + bv.w;
             if (oy < OH && ox < OH) {
-                if (DBG != 4) *reinterpret_cast<float4*>(out + (((size_t)n * OH + oy) * OH + ox) * COUT + g * 4) = v;
+                if (DBG != 4)
+                    *reinterpret_cast<float4*>(out + ((((size_t)n * (COUT / 8) + (g >> 1)) * OH + oy) * OH + ox) * 8 + (g & 1) * 4) = v;
                 lsum += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
                 lsq += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
             }
@@ -532,40 +534,47 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void conv_mfma_kernel(const flo
 // Both operands are split EXACTLY into three bf16 pieces (x = x0 + x1 + x2, 8 mantissa bits each; the weights on
 // the host, the activations while they are staged into LDS, by truncation: x0 = x & 0xffff0000, x1 likewise of
 // x - x0, x2 = the rest) and the six products down to 2^-16 of the leading one are accumulated in fp32 inside
-// v_mfma_f32_16x16x32_bf16:  a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0.  The dropped terms are <= 2^-23 of
+// v_mfma_f32_32x32x16_bf16:  a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0.  The dropped terms are <= 2^-23 of
 // a product, i.e. the size of one fp32 rounding of that product: the result is an fp32 dot product in another
-// summation order, at 16/6 of the fp32 matrix rate.
-// Activations are NHWC fp32 in HBM; the previous layer's GroupNorm + ReLU is applied on the way into LDS.
-// LDS input layout: [piece 3][channel octet][row][column parity][column/2][8 x bf16]: one 16-byte slot per pixel
-// and octet, consecutive output pixels (stride 2 in the input) in consecutive slots.
-// k order: slot q = (window tap t, channel octet c) = (q / OCT, q % OCT); MFMA step s covers slots 4s..4s+3, lane
-// group g = lane / 16 holds slot 4s + g; slots past the last tap carry zero weights.
-// Workgroup: 4 waves, (4 PT) x 16 output pixels x 32 output channels; wave w owns PT output rows (pixel tiles of 16)
-// and both channel tiles: per MFMA step it reads 3 (PT + 2) fragments from LDS for 12 PT MFMAs.  Input channels are
-// staged PASS_CH at a time (CIN / PASS_CH passes); the weight fragments of one MFMA step (6 KB) are
-// double-buffered through LDS.
+// summation order (measured: 1.6x torch-CPU-fp32's own error against float64, tools/cnn_accuracy.py).
+// The 32x32x16 shape is the one that reaches the bf16 peak on gfx950 (measured 2.29 PFLOP/s; the 16x16x32 shape
+// issues at the same 14 ns for half the work: tools/mfma_rate_probe.hip), i.e. 2.4x the fp32 matrix rate after
+// the factor 6.
+// Activations are fp32 in HBM in octet-planar order [n][c/8][y][x][c%8] (a pass reads 32 contiguous bytes per pixel);
+// the previous layer's GroupNorm + ReLU is applied on the way into LDS.
+// LDS input layout: [piece 3][row][column parity][column/2][8 x bf16]: one 16-byte slot per pixel (8 input channels
+// per pass), consecutive output pixels (stride 2 in the input) in consecutive slots.
+// k order: an MFMA step covers two window taps x 8 channels; lane half h = lane / 32 holds tap h of the step.
+//   steps 0-9:  row ky = s / 2, columns kx = (s & 1) + 2h   (same row, same parity: the two 512-byte windows overlap)
+//   steps 10-11: column 4 of rows 2 (s - 10) + h;   step 12: tap (4, 4) and one zero-weight slot.
+// Workgroup: 4 waves, 8 x 32 output pixels x 32 output channels; wave w owns output rows 2w, 2w+1 (two pixel tiles of
+// 32) : per MFMA step it reads 3 + 6 fragments from LDS for 12 MFMAs.  Input channels are staged 8 at a time
+// (CIN / 8 passes, next pass prefetched into registers); the weight fragments of a pass (13 x 3 KB) are requested up
+// front, parked in registers and fed through three rotating LDS buffers, and the fragment reads of step s+1 are
+// interleaved with the matrix work of step s.
 // =============================================================================================
-template <int CIN_, int COUT_, int KS_, int IH_, int OH_, int NPART_IN_, bool OUT_NHWC_, int PT_ = 4, int PASS_CH_ = 8>
+template <int CIN_, int COUT_, int KS_, int IH_, int OH_, int NPART_IN_, bool OUT_OCT_>
 struct BfCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, KS = KS_, IH = IH_, OH = OH_, NPART_IN = NPART_IN_;
-    static constexpr bool OUT_NHWC = OUT_NHWC_;
-    static constexpr int PT = PT_;                                  // pixel tiles (= output rows) per wave
-    static constexpr int NT = 256, NW = 4, TH = NW * PT, TW = 16;
+    static constexpr bool OUT_OCT = OUT_OCT_;
+    static constexpr int PT = 2;                                    // pixel tiles (= output rows of 32) per wave
+    static constexpr int NT = 256, NW = 4, TH = NW * PT, TW = 32;
     static constexpr int COUT_WG = 32, CSPLIT = COUT / COUT_WG;
-    static constexpr int PASS_CH = PASS_CH_, OCT = PASS_CH / 8, NPASS = CIN / PASS_CH;
+    static constexpr int PASS_CH = 8, NPASS = CIN / PASS_CH;
     static constexpr int ITH = 2 * TH + KS - 2, ITW = 2 * TW + KS - 2, HW = (ITW + 1) / 2;
-    static constexpr int HALF_B = HW * 16, ROW_B = 2 * HALF_B, OCT_B = ITH * ROW_B, PIECE_B = OCT * OCT_B;
-    static constexpr int IN_B = 3 * PIECE_B;
-    static constexpr int NSLOT = KS * KS * OCT, NKS = (NSLOT + 3) / 4;     // MFMA steps per pass
-    static constexpr int WSTEP_B = 2 * 3 * 64 * 16;                         // [channel tile][piece][lane][16 B]
+    static constexpr int HALF_B = HW * 16, ROW_B = 2 * HALF_B, PIECE_B = ITH * ROW_B;
+    static constexpr int IN_B = (3 * PIECE_B + 255) / 256 * 256;              // weight fragments start 256-byte aligned
+    static constexpr int NKS = (KS * KS + 1) / 2;                            // MFMA steps per pass (two taps each)
+    static constexpr int WSTEP_B = 3 * 64 * 16;                              // [piece][lane][16 B]
     static constexpr int TILES_X = (OH + TW - 1) / TW, TILES_Y = (OH + TH - 1) / TH;
     static constexpr int NPART_OUT = TILES_X * TILES_Y * CSPLIT;
-    static constexpr int UNITS = ITH * ITW * OCT, UITERS = (UNITS + NT - 1) / NT;
-    static constexpr size_t LDS_BYTES = (size_t)IN_B + 2 * WSTEP_B + (size_t)CIN * 8 + NW * 16 + 16;
+    static constexpr int UNITS = ITH * ITW, UITERS = (UNITS + NT - 1) / NT;
+    static constexpr size_t LDS_BYTES = (size_t)IN_B + 3 * WSTEP_B + (size_t)CIN * 8 + NW * 16 + 16;
     static constexpr size_t WFRAG_BYTES = (size_t)NPASS * NKS * CSPLIT * WSTEP_B;
-    static_assert(CIN % PASS_CH == 0 && COUT % COUT_WG == 0, "channel tiling");
+    static_assert(CIN % PASS_CH == 0 && COUT % COUT_WG == 0 && CIN <= NT, "channel tiling");
     static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
-    static_assert(WSTEP_B == 3 * 8 * NT, "weight step = three 8-byte pieces per thread");
+    static_assert(KS == 5 && NKS == 13, "the tap order in conv_bf6_kernel is written for 5x5 windows");
+    static_assert(WSTEP_B == 16 * 192, "weight step = one 16-byte piece for each of the first 192 threads");
 };
 
 __device__ __forceinline__ void split_bf16x3(const float v[8], uint4& p0, uint4& p1, uint4& p2) {
@@ -586,73 +595,125 @@ __device__ __forceinline__ void split_bf16x3(const float v[8], uint4& p0, uint4&
                     (l[6] >> 16) | (l[7] & 0xffff0000u));
 }
 
-template <class Cfg>
+// TIMING: phase timestamps (s_memtime) of every workgroup summed into `tprof` (measurement hook only)
+template <class Cfg, bool TIMING = false>
 __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
                                                                 const float* __restrict__ gn_g, const float* __restrict__ gn_b,
                                                                 const uint32_t* __restrict__ wfrag, const float* __restrict__ bias,
-                                                                float* __restrict__ out, GNStats* __restrict__ st_out, int N) {
-    constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, KS = Cfg::KS, IH = Cfg::IH, OH = Cfg::OH, NT = Cfg::NT;
-    constexpr int TH = Cfg::TH, TW = Cfg::TW, ITW = Cfg::ITW, OCT = Cfg::OCT;
+                                                                float* __restrict__ out, GNStats* __restrict__ st_out, int N,
+                                                                unsigned long long* __restrict__ tprof = nullptr) {
+    long long tstamp[8];
+    int nstamp = 0;
+    auto stamp = [&]() { if (TIMING) tstamp[nstamp++] = clock64(); };
+    stamp();
+    constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, IH = Cfg::IH, OH = Cfg::OH, NT = Cfg::NT;
+    constexpr int TH = Cfg::TH, TW = Cfg::TW, ITW = Cfg::ITW, PT = Cfg::PT;
     HIP_DYNAMIC_SHARED(float, smem)
     unsigned char* s_in = reinterpret_cast<unsigned char*>(smem);
     unsigned char* s_w = s_in + Cfg::IN_B;
-    float* s_gn = (float*)(s_w + 2 * Cfg::WSTEP_B);              // [CIN][2] scale, shift
+    float* s_gn = (float*)(s_w + 3 * Cfg::WSTEP_B);              // [CIN][2] scale, shift
     double* s_red = (double*)(s_gn + 2 * CIN);
     float* s_mr = (float*)(s_red + 2 * Cfg::NW);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, j = lane & 15;
+    const int h = lane >> 5, j = lane & 31;
     const int n = blockIdx.z;
     const int tile_x = blockIdx.x % Cfg::TILES_X, cb = blockIdx.x / Cfg::TILES_X;
     const int oy0 = blockIdx.y * TH, ox0 = tile_x * TW;
     const int iy0 = 2 * oy0, ix0 = 2 * ox0;
 
-    if (tid == 0) {
-        float mean, rstd;
-        gn_moments(st_in, n, Cfg::NPART_IN, (double)CIN * IH * IH, mean, rstd);
-        s_mr[0] = mean;
-        s_mr[1] = rstd;
+    // ---- raw input loads of pass 0 go out first: they do not depend on the statistics ----
+    const float* in_n = in + (size_t)n * IH * IH * CIN;          // [c/8][y][x][c%8]
+    float4 raw[Cfg::UITERS][2];
+    auto issue_loads = [&](int pass) {
+#pragma unroll
+        for (int k = 0; k < Cfg::UITERS; ++k) {
+            const int idx = tid + k * NT;
+            raw[k][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            raw[k][1] = raw[k][0];
+            if (idx < Cfg::UNITS) {
+                const int col = idx % ITW, r = idx / ITW;
+                const int iy = iy0 + r, ix = ix0 + col;
+                if (iy < IH && ix < IH) {
+                    const float4* src = reinterpret_cast<const float4*>(in_n + (((size_t)pass * IH + iy) * IH + ix) * 8);
+                    raw[k][0] = src[0];
+                    raw[k][1] = src[1];
+                }
+            }
+        }
+    };
+    issue_loads(0);
+    const float my_g = tid < CIN ? gn_g[tid] : 0.f, my_b = tid < CIN ? gn_b[tid] : 0.f;   // in flight during the reduction
+    float4 bias4[4];                                               // this lane's 16 output channels (epilogue)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) bias4[rg] = *reinterpret_cast<const float4*>(bias + cb * Cfg::COUT_WG + 8 * rg + 4 * h);
+
+    // ---- GroupNorm moments of the input sample: the producer's per-tile partial sums, one per lane, reduced in a
+    // fixed (butterfly) order ----
+    if (wave == 0) {
+        double ps = 0.0, pq = 0.0;
+        for (int i = lane; i < Cfg::NPART_IN; i += 64) {
+            ps += st_in[(size_t)n * Cfg::NPART_IN + i].sum;
+            pq += st_in[(size_t)n * Cfg::NPART_IN + i].sq;
+        }
+        ps = wave_sum_d(ps);
+        pq = wave_sum_d(pq);
+        if (lane == 0) {
+            const double cnt = (double)CIN * IH * IH;
+            const double mu = ps / cnt;
+            double var = pq / cnt - mu * mu;
+            var = var < 0.0 ? 0.0 : var;
+            s_mr[0] = (float)mu;
+            s_mr[1] = (float)(1.0 / sqrt(var + GN_EPS));
+        }
     }
     __syncthreads();
-    for (int c = tid; c < CIN; c += NT) {
-        const float sc = s_mr[1] * gn_g[c];
-        s_gn[2 * c] = sc;
-        s_gn[2 * c + 1] = gn_b[c] - s_mr[0] * sc;
+    if (tid < CIN) {
+        const float sc = s_mr[1] * my_g;
+        s_gn[2 * tid] = sc;
+        s_gn[2 * tid + 1] = my_b - s_mr[0] * sc;
     }
+    stamp();
 
-    constexpr int PT = Cfg::PT;
-    f32x4 acc[PT][2];
+    f32x16 acc[PT];
 #pragma unroll
     for (int i = 0; i < PT; ++i)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     // byte offset of this lane's pixel (window origin) in the wave's first output row; row i is 2*i input rows further
     const int lane_base = (2 * PT * wave) * Cfg::ROW_B + j * 16;
 
-    const float* in_n = in + (size_t)n * IH * IH * CIN;
     const uint4* wsrc = reinterpret_cast<const uint4*>(wfrag);
-    constexpr int WQ = Cfg::WSTEP_B / 16;                         // 384 x 16 B per MFMA step
+    constexpr int WQ = Cfg::WSTEP_B / 16;                         // 192 x 16 B per MFMA step
     auto wstep_src = [&](int pass, int s) { return wsrc + ((size_t)(pass * Cfg::NKS + s) * Cfg::CSPLIT + cb) * WQ; };
+    const bool wmover = tid < WQ;                                 // waves 0-2 move the weight fragments
 
     for (int pass = 0; pass < Cfg::NPASS; ++pass) {
+        // ALL weight fragments of the pass (13 x 16 bytes per moving thread) are requested up front and parked in
+        // registers: an L2 round trip under load (~1 us) is longer than two MFMA steps, a shallower prefetch paces
+        // the whole pipeline at latency / depth (measured with the s_memtime phase profile, tools/conv_phase_profile.py)
+        uint4 wq[Cfg::NKS];
+#pragma unroll
+        for (int t = 0; t < Cfg::NKS; ++t) wq[t] = make_uint4(0u, 0u, 0u, 0u);
+        if (wmover) {
+#pragma unroll
+            for (int t = 0; t < Cfg::NKS; ++t) wq[t] = wstep_src(pass, t)[tid];
+        }
         __syncthreads();        // s_gn ready (pass 0) / every wave is done with the previous pass's tiles
-        // ---- stage 16 input channels of the (2TH+KS-2) x (2TW+KS-2) window: GroupNorm + ReLU, exact 3-way split ----
-#pragma unroll 2
+        // ---- 8 input channels of the (2TH+KS-2) x (2TW+KS-2) window: GroupNorm + ReLU, exact 3-way split ----
+#pragma unroll
         for (int k = 0; k < Cfg::UITERS; ++k) {
             const int idx = tid + k * NT;
             if (idx < Cfg::UNITS) {
-                const int c = idx % OCT, pix = idx / OCT;
-                const int col = pix % ITW, r = pix / ITW;
+                const int col = idx % ITW, r = idx / ITW;
                 const int iy = iy0 + r, ix = ix0 + col;
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = 0.f;             // exact zero outside the image
                 if (iy < IH && ix < IH) {
-                    const int ch0 = pass * Cfg::PASS_CH + c * 8;
-                    const float4* src = reinterpret_cast<const float4*>(in_n + ((size_t)iy * IH + ix) * CIN + ch0);
-                    const float4 a = src[0], b = src[1];
-                    const float4* gn = reinterpret_cast<const float4*>(s_gn + 2 * ch0);
+                    const float4 a = raw[k][0], b = raw[k][1];
+                    const float4* gn = reinterpret_cast<const float4*>(s_gn + 2 * pass * Cfg::PASS_CH);
                     const float4 g0 = gn[0], g1 = gn[1], g2 = gn[2], g3 = gn[3];
                     v[0] = fmaxf(fmaf(a.x, g0.x, g0.y), 0.f);
                     v[1] = fmaxf(fmaf(a.y, g0.z, g0.w), 0.f);
@@ -665,100 +726,101 @@ __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6_kernel(const float* __res
                 }
                 uint4 p0, p1, p2;
                 split_bf16x3(v, p0, p1, p2);
-                unsigned char* dst = s_in + c * Cfg::OCT_B + r * Cfg::ROW_B + (col & 1) * Cfg::HALF_B + (col >> 1) * 16;
+                unsigned char* dst = s_in + r * Cfg::ROW_B + (col & 1) * Cfg::HALF_B + (col >> 1) * 16;
                 *reinterpret_cast<uint4*>(dst) = p0;
                 *reinterpret_cast<uint4*>(dst + Cfg::PIECE_B) = p1;
                 *reinterpret_cast<uint4*>(dst + 2 * Cfg::PIECE_B) = p2;
             }
         }
-        // ---- weight fragments of step 0 ----
-        {
-            const uint4* ws = wstep_src(pass, 0);
-            for (int q = tid; q < WQ; q += NT) reinterpret_cast<uint4*>(s_w)[q] = ws[q];
+        // ---- weight fragments: step t lives in LDS buffer t % 3.  Steps 0 and 1 go straight in; step t is written at the
+        // end of step t-2 (that buffer was last read during step t-4: two barriers earlier) and read into the fragment
+        // registers during step t-1 ----
+        if (wmover) {
+            reinterpret_cast<uint4*>(s_w)[tid] = wq[0];
+            reinterpret_cast<uint4*>(s_w + Cfg::WSTEP_B)[tid] = wq[1];
         }
         __syncthreads();
-#pragma unroll 1
-        for (int s = 0; s < Cfg::NKS; ++s) {
-            const int buf = s & 1;
-            // prefetch the next step's fragments into registers
-            const bool more = s + 1 < Cfg::NKS;
-            // 6144 bytes = 3 x 8 per thread (the last step re-reads its own fragments: no branch)
-            const uint2* ws = reinterpret_cast<const uint2*>(wstep_src(pass, more ? s + 1 : s));
-            const uint2 wn0 = ws[tid], wn1 = ws[tid + NT], wn2 = ws[tid + 2 * NT];
-            __builtin_amdgcn_sched_barrier(0);                        // keep the loads above the matrix work
-            // this lane group's slot: (tap, channel octet)
-            int q = 4 * s + g;
-            q = q < Cfg::NSLOT ? q : 0;                              // padding slots: zero weights, any valid address
-            const int t = q / OCT, c = q - t * OCT;
-            const int ky = t / KS, kx = t - ky * KS;
-            const int off = c * Cfg::OCT_B + ky * Cfg::ROW_B + (kx & 1) * Cfg::HALF_B + (kx >> 1) * 16;
-            bf16x8 a[2][3], b[PT][3];
-            const unsigned char* wb = s_w + buf * Cfg::WSTEP_B + lane * 16;
+        if (pass < 2) stamp();
+        if (pass + 1 < Cfg::NPASS) issue_loads(pass + 1);      // consumed after this pass's matrix work
+
+        // Software pipeline over the MFMA steps: while the matrix cores work on step s, the A/B fragments of step
+        // s+1 are read from LDS into the other register set; one barrier per step.
+        bf16x8 fa[2][3], fb[2][PT][3];
+        auto load_frags = [&](int t, int set) {
+            int ky, kx;
+            if (t < 10) { ky = t >> 1; kx = (t & 1) + 2 * h; }
+            else { ky = 2 * (t - 10) + h; kx = 4; ky = ky > 4 ? 4 : ky; }     // (row 5 does not exist: zero-weight slot)
+            const int off = ky * Cfg::ROW_B + (kx & 1) * Cfg::HALF_B + (kx >> 1) * 16;
+            const unsigned char* wb = s_w + (t % 3) * Cfg::WSTEP_B + lane * 16;
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[ct][pl] = *reinterpret_cast<const bf16x8*>(wb + (ct * 3 + pl) * 1024);
+            for (int pl = 0; pl < 3; ++pl) fa[set][pl] = *reinterpret_cast<const bf16x8*>(wb + pl * 1024);
 #pragma unroll
             for (int i = 0; i < PT; ++i)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    b[i][pl] = *reinterpret_cast<const bf16x8*>(s_in + pl * Cfg::PIECE_B + 2 * i * Cfg::ROW_B + lane_base + off);
+                    fb[set][i][pl] = *reinterpret_cast<const bf16x8*>(s_in + pl * Cfg::PIECE_B + 2 * i * Cfg::ROW_B + lane_base + off);
+        };
+        load_frags(0, 0);
 #pragma unroll
-            for (int i = 0; i < PT; ++i)
+        for (int s = 0; s < Cfg::NKS; ++s) {
+            const int cur = s & 1;
+            if (s + 1 < Cfg::NKS) load_frags(s + 1, cur ^ 1);
+            // six products per pixel tile, smallest first; the two tiles' accumulation chains alternate so that an
+            // MFMA never waits for the one issued just before it
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    f32x4 d = acc[i][ct];
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ct][2], b[i][0], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ct][0], b[i][2], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ct][1], b[i][1], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ct][1], b[i][0], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ct][0], b[i][1], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ct][0], b[i][0], d, 0, 0, 0);
-                    acc[i][ct] = d;
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int i = 0; i < PT; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][TA[term]], fb[cur][i][TB[term]], acc[i], 0, 0, 0);
+            // issue order: one LDS fragment read of step s+1 behind each of the first nine MFMAs of step s (issuing the
+            // nine reads up front stalls the wave on the LDS queue before the matrix pipe gets any work)
+            if (s + 1 < Cfg::NKS) {
+#pragma unroll
+                for (int q = 0; q < 3 + 3 * PT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
                 }
-            __builtin_amdgcn_sched_barrier(0);
-            {   // (after the last step this rewrites the idle buffer with the step's own fragments: harmless, branch-free)
-                uint2* wd = reinterpret_cast<uint2*>(s_w + (buf ^ 1) * Cfg::WSTEP_B);
-                wd[tid] = wn0;
-                wd[tid + NT] = wn1;
-                wd[tid + 2 * NT] = wn2;
+                __builtin_amdgcn_sched_group_barrier(0x008, 6 * PT - (3 + 3 * PT), 0);
             }
-            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 2 < Cfg::NKS && wmover) reinterpret_cast<uint4*>(s_w + ((s + 2) % 3) * Cfg::WSTEP_B)[tid] = wq[s + 2];
+            if (s + 1 < Cfg::NKS) __syncthreads();
         }
+        if (pass < 2) stamp();
     }
 
-    // ---- epilogue: D column = lane&15 = pixel, row = (lane>>4)*4 + r = channel within the tile ----
-    double lsum = 0.0, lsq = 0.0;
+    // ---- epilogue: D column = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel within the tile ----
+    float fsum = 0.f, fsq = 0.f;          // this lane's 16 PT outputs in fp32; everything above that in float64
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
         const int oy = oy0 + PT * wave + i, ox = ox0 + j;
         const bool valid = oy < OH && ox < OH;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const int co = cb * Cfg::COUT_WG + ct * 16 + g * 4;
-            const float4 bv = *reinterpret_cast<const float4*>(bias + co);
+        for (int rg = 0; rg < 4; ++rg) {
+            const int co = cb * Cfg::COUT_WG + 8 * rg + 4 * h;
+            const float4 bv = bias4[rg];
             float4 v;
-            v.x = acc[i][ct][0] + bv.x;
-            v.y = acc[i][ct][1] + bv.y;
-            v.z = acc[i][ct][2] + bv.z;
-            v.w = acc[i][ct][3] + bv.w;
+            v.x = acc[i][4 * rg + 0] + bv.x;
+            v.y = acc[i][4 * rg + 1] + bv.y;
+            v.z = acc[i][4 * rg + 2] + bv.z;
+            v.w = acc[i][4 * rg + 3] + bv.w;
             if (valid) {
-                if (Cfg::OUT_NHWC) {
-                    *reinterpret_cast<float4*>(out + (((size_t)n * OH + oy) * OH + ox) * COUT + co) = v;
-                } else {
+                if (Cfg::OUT_OCT) {     // octet-planar, [n][c/8][y][x][c%8]
+                    *reinterpret_cast<float4*>(out + ((((size_t)n * (COUT / 8) + (co >> 3)) * OH + oy) * OH + ox) * 8 + (co & 7)) = v;
+                } else {                // NCHW
                     float* o = out + (((size_t)n * COUT + co) * OH + oy) * OH + ox;
                     o[0] = v.x;
                     o[(size_t)OH * OH] = v.y;
                     o[(size_t)2 * OH * OH] = v.z;
                     o[(size_t)3 * OH * OH] = v.w;
                 }
-                lsum += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-                lsq += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+                fsum += (v.x + v.y) + (v.z + v.w);
+                fsq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fsq))));
             }
         }
     }
-    lsum = wave_sum_d(lsum);
-    lsq = wave_sum_d(lsq);
+    const double lsum = wave_sum_d((double)fsum), lsq = wave_sum_d((double)fsq);
     if (lane == 0) { s_red[2 * wave] = lsum; s_red[2 * wave + 1] = lsq; }
     __syncthreads();
     if (tid == 0) {
@@ -768,10 +830,17 @@ __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6_kernel(const float* __res
         o.sum = a;
         o.sq = b;
     }
+    stamp();
+    if (TIMING && tid == 0) {
+        // [0] = workgroups, [1 + k] = sum of (stamp k+1 - stamp k): statistics+first loads, staging 0, steps 0,
+        // staging 1, steps 1, (remaining passes +) epilogue
+        atomicAdd(tprof, 1ull);
+        for (int k = 0; k + 1 < nstamp; ++k) atomicAdd(tprof + 1 + k, (unsigned long long)(tstamp[k + 1] - tstamp[k]));
+    }
 }
 
-typedef BfCfg<16, 32, 5, 125, 61, l1b::NPART, true> Bf2;     // conv2: NHWC in, NHWC out
-typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, false> Bf3;  // conv3: NHWC in, NCHW out (layers 4-6 stay on the fp32 path)
+typedef BfCfg<16, 32, 5, 125, 61, l1b::NPART, true> Bf2;     // conv2: octet-planar in and out
+typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, false> Bf3;  // conv3: octet-planar in, NCHW out (layers 4-6 stay on the fp32 path)
 
 template <class Cfg>
 static int launch_bf6(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
@@ -950,7 +1019,7 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
                                           const float* pos_mean4_host, const float* pos_std4_host, const int32_t* mapix,
                                           int32_t N, float* feat, void* ws, size_t ws_bytes, strive_stream_t stream_) {
     STRIVE_CHECK_ARG(map && cnn && pos && mapix && feat && ws, "null argument");
-    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK_MAX && layer >= 0 && layer <= 14, "bad layer / N");
+    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK_MAX && layer >= 0 && layer <= 22, "bad layer / N");
     STRIVE_CHECK_ARG(ws_bytes >= strive_map_cnn_workspace_bytes(N), "workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
     StriveArena ar(ws, ws_bytes);
@@ -970,6 +1039,21 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
             hipLaunchKernelGGL(conv1b_kernel<true>, dim3(l1b::TILES_Y, 1, N), dim3(C1_NT), 0, stream, *map, pos, m, s,
                                mapix, (const uint8_t*)nullptr, cnn->w1_frag, (const float*)cnn->b[0], act[0], st[0]);
             break;
+        case 21: case 22: {   // phase profile of conv2 / conv3: sums of s_memtime deltas land in `feat` (>= 64 bytes, zeroed here)
+            hipMemsetAsync(feat, 0, 64, stream);
+            if (layer == 21) {
+                hipFuncSetAttribute((const void*)conv_bf6_kernel<Bf2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Bf2::LDS_BYTES);
+                hipLaunchKernelGGL((conv_bf6_kernel<Bf2, true>), dim3(Bf2::TILES_X * Bf2::CSPLIT, Bf2::TILES_Y, N), dim3(Bf2::NT), Bf2::LDS_BYTES,
+                                   stream, act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N,
+                                   reinterpret_cast<unsigned long long*>(feat));
+            } else {
+                hipFuncSetAttribute((const void*)conv_bf6_kernel<Bf3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Bf3::LDS_BYTES);
+                hipLaunchKernelGGL((conv_bf6_kernel<Bf3, true>), dim3(Bf3::TILES_X * Bf3::CSPLIT, Bf3::TILES_Y, N), dim3(Bf3::NT), Bf3::LDS_BYTES,
+                                   stream, act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N,
+                                   reinterpret_cast<unsigned long long*>(feat));
+            }
+            break;
+        }
         case 11: case 12: case 13: case 14: {   // timing probes of the layer-0 kernel (results are NOT valid): no gather / no fp64 / 1/3 MFMA
             dim3 gg(l1b::TILES_Y, 1, N);
             if (layer == 11) hipLaunchKernelGGL((conv1b_kernel<true, 1>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, (const float*)cnn->b[0], act[0], st[0]);

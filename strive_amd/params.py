@@ -124,27 +124,33 @@ def _bf16_split3(w, what):
 BF6_PASS_CH = 8     # input channels staged per pass by conv_bf6_kernel (BfCfg::PASS_CH)
 
 
+def conv_tap_order():
+    """Window taps (ky, kx) held by lane halves h = 0, 1 of MFMA step s in conv_bf6_kernel: steps 0-9 = row s // 2,
+    columns (s & 1) + 2h; steps 10-11 = column 4 of rows 2 (s - 10) + h; step 12 = (4, 4) and a zero slot (None)."""
+    order = [[(s_ >> 1, (s_ & 1) + 2 * h) for h in range(2)] for s_ in range(10)]
+    order += [[(0, 4), (1, 4)], [(2, 4), (3, 4)], [(4, 4), None]]
+    return order
+
+
 def _conv_bf6_fragments(w, pass_ch=BF6_PASS_CH):
-    """(co, ci, 5, 5) fp32 -> int32 tensor [pass = ci/pass_ch][step][co/32][co tile][piece][lane][8 x bf16] in the k order
-    of conv_bf6_kernel: lane group g of MFMA step s holds k slot q = 4s + g = (tap q // OCT, channel octet q % OCT),
-    OCT = pass_ch / 8."""
+    """(co, ci, 5, 5) fp32 -> int32 tensor [pass = ci/8][step 13][co/32][piece 3][lane 64][8 x bf16]: the exact three-way
+    bf16 split of every weight in the k order of conv_bf6_kernel (lane = 32 h + output channel % 32, element e = input
+    channel 8 pass + e, window tap = conv_tap_order()[step][h])."""
     co, ci, k, _ = w.shape
+    if k != 5 or pass_ch != 8:
+        raise NotImplementedError('conv_bf6_kernel is written for 5x5 windows staged 8 channels at a time')
     pieces = _bf16_split3(w, 'conv').permute(0, 1, 3, 4, 2).contiguous()      # (3, co, ky, kx, ci)
-    npass, csplit, oct_ = ci // pass_ch, co // 32, pass_ch // 8
-    nslot = k * k * oct_
-    nks = (nslot + 3) // 4
-    out = torch.zeros((npass, nks, csplit, 2, 3, 4, 16, 8), dtype=torch.bfloat16, device=w.device)
+    npass, csplit = ci // pass_ch, co // 32
+    order = conv_tap_order()
+    out = torch.zeros((npass, len(order), csplit, 3, 2, 32, 8), dtype=torch.bfloat16, device=w.device)
     for p_ in range(npass):
-        for s_ in range(nks):
-            for g in range(4):
-                q = 4 * s_ + g
-                if q >= nslot:
+        for s_, taps in enumerate(order):
+            for h, tap in enumerate(taps):
+                if tap is None:
                     continue
-                t, c = q // oct_, q % oct_
-                ky, kx = t // k, t % k
-                ch0 = pass_ch * p_ + 8 * c
-                blk = pieces[:, :, ky, kx, ch0:ch0 + 8]                          # (3, co, 8)
-                out[p_, s_, :, :, :, g] = blk.view(3, csplit, 2, 16, 8).permute(1, 2, 0, 3, 4)
+                ky, kx = tap
+                blk = pieces[:, :, ky, kx, pass_ch * p_:pass_ch * p_ + 8]       # (3, co, 8)
+                out[p_, s_, :, :, h] = blk.view(3, csplit, 32, 8).permute(1, 0, 2, 3)
     return out.contiguous().view(torch.int16).view(-1, 8).contiguous().view(torch.int32)
 
 

@@ -37,7 +37,9 @@ struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(8) float2 { float x, y; };
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 struct alignas(8) uint2 { unsigned x, y; };
+inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
 struct alignas(16) uint4 { unsigned x, y, z, w; };
+inline long long clock64() { return 0; }
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline long long __double_as_longlong(double d) { long long u; memcpy(&u, &d, 8); return u; }
@@ -109,6 +111,7 @@ extern dim3 blockDim, gridDim;
 inline void __syncthreads() { hipemu::block_barrier(); }
 inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 
@@ -261,6 +264,29 @@ inline hipemu_f32x4 hipemu_mfma_16x16x32_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, 
     hipemu::wave_barrier();
     return d;
 }
+// 32x32x16 bf16: lane l holds k = 8*(l>>5) + j (j = 0..7) of row/column l&31 for both operands; D as for 32x32x2
+// (verified on gfx950 with tools/mfma_probe.hip)
+inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x16 c, int, int, int) {
+    hipemu_bf16_wave& w = hipemu_bf16_buf();
+    int lane = hipemu_lane();
+    for (int j = 0; j < 8; ++j) {
+        w.a[lane][j] = hipemu_bf16_to_float(a[j]);
+        w.b[lane][j] = hipemu_bf16_to_float(b[j]);
+    }
+    hipemu::wave_barrier();
+    hipemu_f32x16 d = c;
+    int col = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < 8; ++j) acc += w.a[h * 32 + row][j] * w.b[h * 32 + col][j];
+        d[r] = acc;
+    }
+    hipemu::wave_barrier();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 hipemu_mfma_16x16x32_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_32x32x2
