@@ -19,7 +19,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-fast-math'
          '-fhip-fp32-correctly-rounded-divide-sqrt', '-Wno-unused-result', '-Wno-unused-value',
          # no auto-formed v_pk_*_f32: on MI355X a v_pk_add_f32 with crossed op_sel halves returned wrong values in
          # lanes 48-63 whenever >= 4 waves shared the SIMD and a neighbour issued MFMAs (tools/pk_waw_probe.hip,
-         # profiles/r01_pk_add_opsel_probe.txt, DESIGN.md section 6); audit_packed_ops() checks the built library
+         # profiles/r01_pk_add_opsel_probe.txt, DESIGN.md section 8.1); audit_packed_ops() checks the built library
          '-fno-slp-vectorize', '-fno-vectorize']
 
 

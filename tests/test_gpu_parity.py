@@ -165,7 +165,7 @@ def test_map_cnn_vs_oracle(model):
 
 def test_map_cnn_full_occupancy_reproducible(model):
     """Regression: with > 32 agents two conv1 workgroups share a CU.  A build with auto-formed v_pk_add_f32 lost
-    lanes 48-63 of some gathers there ("packed-fp32 write-after-write"); the fused crop+CNN must equal
+    lanes 48-63 of some gathers there; the fused crop+CNN must equal
     the crop kernel followed by the CNN bit for bit, on every repeat, and match the oracle on a sample."""
     m, sd = model
     raster, dx, frame, mapixes, lw = mg.g2_inputs()
