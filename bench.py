@@ -235,13 +235,20 @@ def main():
         'config': {'workload': 'refine closure: decode_embedding(nfuture=%d) + AvoidCollLoss + backward + Adam, '
                                '%d scenes x %d agents per GPU (BASELINE.json configs[1])' % (args.ft, args.scenes, args.agents),
                    'agents_per_gpu': NA, 'FT': args.ft, 'raster': '%dx%d x4 uint8 @0.25 m' % (args.raster, args.raster),
-                   'parallelism': 'scene-sharded replicas x%d' % world},
+                   'parallelism': 'scene-sharded replicas x%d' % world,
+                   'arithmetic': 'fp32 everywhere; conv1-3 on bf16 matrix cores with exact 3-way operand splits, fp32 accumulate'},
         'final_loss': float(loss.detach().cpu()),
     }
     if rank == 0:
         if not args.no_roofline:
             try:
                 out['roofline'] = time_dominant_kernel(m, env, g, mi, emb, device)
+                # the closure as a whole = 305 MFLOP algorithmic per agent*timestep (map CNN
+                # forward 300.4 + GNN/GRU/dynamics forward+backward), against the fp32 matrix peak
+                per_gpu = out['value'] / world
+                out['roofline']['whole_path'] = {
+                    'algorithmic_tflops': round(per_gpu * 305.0e6 / 1e12, 2),
+                    'frac_of_f32_matrix_peak': round(per_gpu * 305.0e6 / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
             except Exception as e:      # keep the headline number even if the side measurement fails
                 out['roofline'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:
