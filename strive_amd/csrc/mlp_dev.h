@@ -11,31 +11,52 @@
 #include "common.h"
 
 #define RB_EDGE 16     // source rows per chunk in the per-target edge kernels
-#define RB_NODE 8      // rows per workgroup in the per-node kernels (more workgroups: these are latency bound)
+#define RB_NODE 4      // rows per workgroup in the per-node kernels: 128 workgroups for 512 agents (see dense_lds)
 #define RPT 4          // rows per thread item
 #define LN_EPS 1e-5f
 
+// Scratch for the k-split partial sums of dense_lds (one per kernel: not a template).
+#define KSPLIT_CAP (4 * 192)
+__device__ __forceinline__ float* ksplit_buf() {
+    __shared__ float s_part[KSPLIT_CAP];
+    return s_part;
+}
+
 // out[r][c] (+)= bias[c] + sum_k in[r][k] * Wt[k*ldw + c],  r < RB, c < OUT.
-// in_ld, out_ld multiples of 4; `in` 16-byte aligned.
+// in_ld, out_ld multiples of 4; `in` 16-byte aligned; `out` must not alias `in`; called by all threads of the workgroup.
+// Thread item = (output channel c, group of 4 rows, k half).  A workgroup of RB rows has only OUT * RB/4 (channel, row
+// group) items; when that leaves half of the threads idle (RB = 4, OUT <= 128) the k range is split in two and the two
+// partial sums are added through LDS: the per-CU weight traffic (every item streams its weight column through the L1)
+// and the FMA count per thread are both halved -- these layers are bound by exactly those two, on the 64-128 CUs
+// that a batch of 512 agents occupies.
 template <int RB, bool ACCUM>
 __device__ __forceinline__ void dense_lds(const float* in, int in_ld, int IN, const float* __restrict__ Wt, int ldw,
                                           const float* __restrict__ bias, float* out, int out_ld, int OUT, int tid,
                                           int nthreads) {
-    const int items = OUT * (RB / RPT);
+    const int base_items = OUT * (RB / RPT);
+    const bool split = (2 * base_items <= nthreads) && (RB * OUT <= KSPLIT_CAP) && IN >= 32;
+    const int items = split ? 2 * base_items : base_items;
+    const int kmid = split ? ((IN / 2) & ~15) : IN;
+    float* s_part = ksplit_buf();
     for (int item = tid; item < items; item += nthreads) {
-        const int c = item % OUT;
-        const int r0 = (item / OUT) * RPT;
+        const int kh = item / base_items;               // 0, or 1 = upper k half
+        const int it = item - kh * base_items;
+        const int c = it % OUT;
+        const int r0 = (it / OUT) * RPT;
+        const int kbeg = kh ? kmid : 0, kend = kh ? IN : kmid;
         float acc[RPT];
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
-            float v = bias ? bias[c] : 0.f;
-            if (ACCUM) v += out[(r0 + i) * out_ld + c];
+            float v = 0.f;
+            if (kh == 0) {
+                v = bias ? bias[c] : 0.f;
+                if (ACCUM) v += out[(r0 + i) * out_ld + c];
+            }
             acc[i] = v;
         }
-        int k = 0;
-        // 16 weight loads are issued back to back before any is used: the layers are latency bound on the L2
-        // round trip of the weight stream, not on bandwidth
-        for (; k + 15 < IN; k += 16) {
+        int k = kbeg;
+        // 16 weight loads are issued back to back before any is used
+        for (; k + 15 < kend; k += 16) {
             float w[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) w[q] = Wt[(size_t)(k + q) * ldw + c];
@@ -51,7 +72,7 @@ __device__ __forceinline__ void dense_lds(const float* in, int in_ld, int IN, co
                 }
             }
         }
-        for (; k + 3 < IN; k += 4) {
+        for (; k + 3 < kend; k += 4) {
             const float w0 = Wt[(size_t)(k + 0) * ldw + c];
             const float w1 = Wt[(size_t)(k + 1) * ldw + c];
             const float w2 = Wt[(size_t)(k + 2) * ldw + c];
@@ -65,13 +86,28 @@ __device__ __forceinline__ void dense_lds(const float* in, int in_ld, int IN, co
                 acc[i] = fmaf(a.w, w3, acc[i]);
             }
         }
-        for (; k < IN; ++k) {
+        for (; k < kend; ++k) {
             const float w0 = Wt[(size_t)k * ldw + c];
 #pragma unroll
             for (int i = 0; i < RPT; ++i) acc[i] = fmaf(in[(r0 + i) * in_ld + k], w0, acc[i]);
         }
+        if (!split) {
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) out[(r0 + i) * out_ld + c] = acc[i];
+            for (int i = 0; i < RPT; ++i) out[(r0 + i) * out_ld + c] = acc[i];
+        } else if (kh == 1) {
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) s_part[(r0 + i) * OUT + c] = acc[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) out[(r0 + i) * out_ld + c] = acc[i];      // lower half; the upper half is added below
+        }
+    }
+    if (split) {
+        __syncthreads();
+        for (int it = tid; it < RB * OUT; it += nthreads) {
+            const int r = it / OUT, c = it - r * OUT;
+            out[r * out_ld + c] += s_part[it];
+        }
     }
 }
 
