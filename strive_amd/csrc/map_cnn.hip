@@ -877,33 +877,62 @@ static int launch_conv(const float* in, const GNStats* st_in, const float* g, co
 }
 
 // =============================================================================================
-// GroupNorm6 + ReLU + flatten + Linear(512 -> 64): 4 samples per workgroup, thread = (sample, out)
+// GroupNorm6 + ReLU + flatten + Linear(512 -> 64): 4 samples per workgroup.
+// thread = (output o, k quarter): 128 weights per thread in 4 batches of 32 loads (the weight stream from L2 is the
+// critical path: 512 k in batches of 8 cost 64 serial round trips), each weight used for the 4 samples; the four k
+// quarters are added through LDS in a fixed order.
 // =============================================================================================
 __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ in, const GNStats* __restrict__ st,
                                                    const float* __restrict__ gn_g, const float* __restrict__ gn_b,
                                                    const float* __restrict__ wt, const float* __restrict__ bias,
                                                    float* __restrict__ feat, int N) {
-    __shared__ float s_a[4][512];
-    const int n0 = blockIdx.x * 4;
-    for (int i = threadIdx.x; i < 4 * 512; i += 256) {
+    __shared__ __attribute__((aligned(16))) float s_a[4][512];
+    __shared__ float s_p[4][4][64];
+    __shared__ float s_mr[4][2];
+    const int n0 = blockIdx.x * 4, tid = threadIdx.x;
+    if (tid < 4) {
+        float mean = 0.f, rstd = 0.f;
+        if (n0 + tid < N) gn_moments(st, n0 + tid, Cfg6::NPART_OUT, 512.0, mean, rstd);
+        s_mr[tid][0] = mean;
+        s_mr[tid][1] = rstd;
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * 512; i += 256) {
         const int s = i >> 9, k = i & 511;
         float v = 0.f;
         if (n0 + s < N) {
-            float mean, rstd;
             const int c = k >> 2;
-            gn_moments(st, n0 + s, Cfg6::NPART_OUT, 512.0, mean, rstd);
-            const float sc = rstd * gn_g[c];
-            v = fmaxf(fmaf(in[(size_t)(n0 + s) * 512 + k], sc, gn_b[c] - mean * sc), 0.f);
+            const float sc = s_mr[s][1] * gn_g[c];
+            v = fmaxf(fmaf(in[(size_t)(n0 + s) * 512 + k], sc, gn_b[c] - s_mr[s][0] * sc), 0.f);
         }
         s_a[s][k] = v;
     }
     __syncthreads();
-    const int s = threadIdx.x >> 6, o = threadIdx.x & 63;
-    if (n0 + s >= N) return;
-    float acc = bias[o];
-#pragma unroll 8
-    for (int k = 0; k < 512; ++k) acc = fmaf(s_a[s][k], wt[k * 64 + o], acc);
-    feat[(size_t)(n0 + s) * 64 + o] = acc;
+    const int o = tid & 63, kq = tid >> 6;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kb = 0; kb < 4; ++kb) {
+        const int k0 = kq * 128 + kb * 32;
+        float w[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) w[q] = wt[(size_t)(k0 + q) * 64 + o];
+#pragma unroll
+        for (int q4 = 0; q4 < 8; ++q4) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float4 a = *reinterpret_cast<const float4*>(&s_a[s][k0 + 4 * q4]);
+                acc[s] = fmaf(a.x, w[4 * q4 + 0], acc[s]);
+                acc[s] = fmaf(a.y, w[4 * q4 + 1], acc[s]);
+                acc[s] = fmaf(a.z, w[4 * q4 + 2], acc[s]);
+                acc[s] = fmaf(a.w, w[4 * q4 + 3], acc[s]);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) s_p[kq][s][o] = acc[s];
+    __syncthreads();
+    const int s = tid >> 6;
+    if (n0 + s < N) feat[(size_t)(n0 + s) * 64 + o] = ((s_p[0][s][o] + s_p[1][s][o]) + (s_p[2][s][o] + s_p[3][s][o])) + bias[o];
 }
 
 // =============================================================================================
