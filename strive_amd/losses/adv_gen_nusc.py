@@ -139,9 +139,10 @@ class VehCollLoss(nn.Module):
             dense[:, self.slot_i, self.slot_j] = pen
             dmask[:, self.slot_i, self.slot_j] = mask
             return dense, dmask
-        if torch.sum(mask) == 0:
+        v = pen[mask]                       # (one host sync: the compaction itself)
+        if v.numel() == 0:
             return torch.Tensor([0.0]).to(traj.device)
-        return pen[mask]
+        return v
 
     def block_penalties(self, traj):
         """(pen (T,P), colliding&valid mask (T,P)) in slot layout -- what the fused loss modules use."""
@@ -187,9 +188,10 @@ class EnvCollLoss(nn.Module):
 
     def forward(self, traj):
         pen, valid = self.valid_penalties(traj)
-        if torch.sum(valid) == 0:
+        v = pen[valid]
+        if v.numel() == 0:
             return torch.Tensor([0.0]).to(traj.device)
-        return pen[valid]
+        return v
 
 
 class AvoidCollLoss(nn.Module):
