@@ -35,7 +35,9 @@ for n in (40, 96, 300):
         torch.cuda.synchronize()
         return ws[:nb].view(torch.float32).view(n, -1).clone()
 
-    crop = ops.map_crop(env, synth.f32(fr).to(dev), mapix)
+    # the crop kernel gets the poses exactly as the fused kernel un-normalises them (fp32 pos * 15): one ulp in a pose
+    # can move a crop pixel
+    crop = ops.map_crop(env, (pos.cpu() * torch.tensor([15., 15., 1., 1.])).to(dev), mapix)
     lib.call('strive_map_cnn_fwd_from_crop', cnn.ref(), L.ptr(crop), n, L.ptr(feat), L.ptr(ws), wsb, st)
     base = conv1_out()
     bad, rows = 0, set()
