@@ -240,6 +240,12 @@ int strive_interp_traj_bwd(const float* in, const float* d_out, int32_t N, int32
                            const int32_t* i0, const int32_t* i1, const float* w0, const float* w1, float* d_in,
                            strive_stream_t stream);
 
+/* Rotated-rectangle IoU of P box pairs (x, y, hx, hy) + (l, w), float64 out; NaN where a pose contains NaN.
+ * Replaces the shapely polygon loop of check_single_veh_coll / check_pairwise_veh_coll
+ * (reference src/losses/adv_gen_nusc.py:517-623; corners as src/datasets/nuscenes_utils.py:416-428). */
+int strive_rect_iou(const float* box_a, const float* lw_a, const float* box_b, const float* lw_b, int32_t P, double* iou,
+                    strive_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -71,3 +71,52 @@ def bicycle_step(state_u, a, ddh, veh_len, dt, max_hdot, max_s):
     new_y = y + new_s * new_h.sin() * dt
     new_x = x + new_s * new_h.cos() * dt
     return torch.stack([new_x, new_y, new_h.cos(), new_h.sin(), new_s, new_hdot], dim=1)
+
+
+# ------------------------------------------------------------------------------------------------
+# Rotated-rectangle IoU (success / collision-metric tests).  The reference evaluates shapely polygons built from
+# get_corners (reference src/datasets/nuscenes_utils.py:392-428) -- shapely 1.7.1 / GEOS are absent from this image and
+# from /root/reference, so this restates the published geometry (convex polygon intersection area, shoelace formula)
+# in float64 numpy; PARITY UNPINNED for the IoU value itself (no reference output can be generated here); the tests
+# pin it against closed-form cases and a grid-sampling estimate instead.
+# ------------------------------------------------------------------------------------------------
+def rect_corners(box, lw):
+    """(4,2) float64 corners, counter-clockwise, as get_corners builds them: R(atan2(hy, hx)) * (+-l/2, +-w/2) + xy."""
+    import numpy as np
+    l, w = float(lw[0]), float(lw[1])
+    base = np.array([[-l / 2., -w / 2.], [l / 2., -w / 2.], [l / 2., w / 2.], [-l / 2., w / 2.]], dtype=np.float64)
+    h = np.arctan2(float(box[3]), float(box[2]))
+    rot = np.array([[np.cos(h), np.sin(h)], [-np.sin(h), np.cos(h)]])
+    return base @ rot + np.asarray(box[:2], dtype=np.float64)
+
+
+def _poly_area(p):
+    import numpy as np
+    x, y = p[:, 0], p[:, 1]
+    return 0.5 * abs(float(np.dot(x, np.roll(y, -1)) - np.dot(np.roll(x, -1), y)))
+
+
+def rect_iou(box_a, lw_a, box_b, lw_b):
+    """intersection area / union area of two vehicle boxes, float64; NaN if a pose contains NaN."""
+    import numpy as np
+    if np.any(np.isnan(np.asarray(box_a, dtype=np.float64))) or np.any(np.isnan(np.asarray(box_b, dtype=np.float64))):
+        return float('nan')
+    pa, pb = rect_corners(box_a, lw_a), rect_corners(box_b, lw_b)
+    poly = [tuple(v) for v in pa]
+    for e in range(4):                                  # keep the part of `poly` left of every edge of b
+        e0, e1 = pb[e], pb[(e + 1) % 4]
+        d = e1 - e0
+        side = [d[0] * (v[1] - e0[1]) - d[1] * (v[0] - e0[0]) for v in poly]
+        nxt = []
+        for i in range(len(poly)):
+            j = (i + 1) % len(poly)
+            if side[i] >= 0.0:
+                nxt.append(poly[i])
+            if (side[i] >= 0.0) != (side[j] >= 0.0):
+                t = side[i] / (side[i] - side[j])
+                nxt.append((poly[i][0] + t * (poly[j][0] - poly[i][0]), poly[i][1] + t * (poly[j][1] - poly[i][1])))
+        poly = nxt
+        if not poly:
+            break
+    inter = _poly_area(np.array(poly)) if len(poly) >= 3 else 0.0
+    return inter / (_poly_area(pa) + _poly_area(pb) - inter)

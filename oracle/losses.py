@@ -356,3 +356,82 @@ def traffic_model_loss(weights, g, pred, state_norm, att_norm, map_idx=None, map
         out['coll_env_prior'] = ce.view(-1)
     out['loss'] = loss.view((1,))
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Success / feasibility tests around the optimisation loops
+# ------------------------------------------------------------------------------------------------
+VEH_COLL_THRESH = 0.02     # reference src/losses/adv_gen_nusc.py:515
+ENV_COLL_THRESH = 0.05     # reference src/losses/traffic_model.py:17
+
+
+def check_single_veh_coll(traj_tgt, lw_tgt, traj_others, lw_others):
+    """(veh_coll (N,) bool, coll_time (N,) int): first step at which the target box overlaps each other agent's box with
+    IoU > 0.02, FT if never; NaN frames of the others are skipped (reference src/losses/adv_gen_nusc.py:517-565)."""
+    import numpy as np
+    from .geometry import rect_iou
+    tt, lt = traj_tgt.cpu().numpy(), lw_tgt.cpu().numpy()
+    to, lo = traj_others.cpu().numpy(), lw_others.cpu().numpy()
+    N, FT, _ = to.shape
+    coll = np.zeros((N,), dtype=bool)
+    when = np.ones((N,), dtype=int) * FT
+    for j in range(N):
+        for t in range(FT):
+            if np.isnan(to[j, t]).any():
+                continue
+            if rect_iou(tt[t], lt, to[j, t], lo[j]) > VEH_COLL_THRESH:
+                coll[j] = True
+                when[j] = t
+                break
+    return coll, when
+
+
+def check_pairwise_veh_coll(traj, lw):
+    """Agent i counts as collided iff it overlaps (IoU > 0.02) some agent j > i at some step
+    (reference src/losses/adv_gen_nusc.py:567-623)."""
+    import numpy as np
+    from .geometry import rect_iou
+    tr, l = traj.cpu().numpy(), lw.cpu().numpy()
+    N, FT, _ = tr.shape
+    coll = np.zeros((N,), dtype=bool)
+    for i in range(N):
+        for j in range(i + 1, N):
+            if coll[i]:
+                break
+            for t in range(FT):
+                if rect_iou(tr[i, t], l[i], tr[j, t], l[j]) > VEH_COLL_THRESH:
+                    coll[i] = True
+                    break
+    return {'num_coll_veh': float(coll.sum()), 'num_traj_veh': float(N), 'did_collide': coll}
+
+
+def determine_feasibility(samples, normalizer, thresh, time=0, vel=0.0, infront_min=None, check_sep=True, raster=None,
+                          dx=None, map_idx=None):
+    """Restatement of determine_feasibility_nusc (reference src/utils/scenario_gen.py:30-107) for ONE scene:
+    samples (NA,NS,FT,4) normalised, agent 0 = ego.  Returns (feasible (NA-1,), step (NA-1,), dist (NA-1,))."""
+    from . import mapenv
+    if samples.size(0) == 1:
+        return None, None, None
+    s = normalizer.unnormalize(samples)
+    ego, oth = s[0:1], s[1:]
+    NA, NS, FT, _ = oth.shape
+    d = torch.norm(ego[..., :2] - oth[..., :2], dim=-1)[:, :, time:]
+    if infront_min is not None:
+        e2a = oth[:, :, time:, :2] - ego[:, :, time:, :2]
+        e2a = e2a / torch.norm(e2a, dim=-1, keepdim=True)
+        cs = torch.sum(e2a * ego[:, :, time:, 2:4], dim=-1)
+        d = torch.where(cs >= infront_min, d, torch.full_like(d, float('inf')))
+    per_t, which = torch.min(d, dim=1)                         # over samples -> (NA, FT')
+    dist, step = torch.min(per_t, dim=1)
+    step = step + time
+    feasible = (d < thresh).sum(dim=[1, 2]) > 0
+    if check_sep:
+        ar = torch.arange(NA)
+        samp = which[ar, step - time]
+        a_xy = oth[ar, samp, step][:, :2]
+        e_xy = ego.expand(NA, NS, FT, 4)[ar, samp, step][:, :2]
+        cut = mapenv.line_hits_layer(raster[:, 0], dx, a_xy, e_xy, map_idx.expand(NA))
+        feasible = feasible & ~cut
+    v = torch.norm(oth[:, :, 1:, :2] - oth[:, :, :-1, :2], dim=-1)
+    feasible = feasible & (v.amax(dim=(1, 2)) > vel)
+    return feasible, step, dist

@@ -94,6 +94,7 @@ PROTOTYPES = {
     'strive_veh_coll_fwd': (C.c_int, [C.POINTER(StriveScenes), P, I, P, I, P, P, C.c_float, P, P, P, P]),
     'strive_interp_traj_fwd': (C.c_int, [P, I, I, I, P, P, P, P, P, P]),
     'strive_interp_traj_bwd': (C.c_int, [P, P, I, I, I, I, P, P, P, P, P, P]),
+    'strive_rect_iou': (C.c_int, [P, P, P, P, I, P, P]),
     'strive_veh_coll_bwd': (C.c_int, [C.POINTER(StriveScenes), P, I, P, I, P, P, C.c_float, P, P, P, P]),
 }
 

@@ -251,3 +251,85 @@ extern "C" int strive_interp_traj_bwd(const float* in, const float* d_out, int32
     STRIVE_CHECK_LAUNCH();
     return 0;
 }
+
+// =============================================================================================
+// Rotated-rectangle IoU of vehicle boxes (the success / collision-metric tests of the optimisation loops:
+// reference src/losses/adv_gen_nusc.py:517-623 builds shapely polygons from get_corners
+// (src/datasets/nuscenes_utils.py:416-428) and evaluates intersection.area / union.area per (agent, step) in Python).
+// One thread per box pair, float64: corners = R(atan2(hy, hx)) * (+-l/2, +-w/2) + (x, y); the first quadrilateral is
+// clipped against the four edges of the second (Sutherland-Hodgman, <= 8 vertices) and the areas come from the
+// shoelace formula.  A pair with a NaN in either pose yields NaN (the reference skips such frames).
+// =============================================================================================
+__device__ __forceinline__ void box_corners(const float* b, const float* lw, double cx[4], double cy[4]) {
+    const double hl = 0.5 * (double)lw[0], hw = 0.5 * (double)lw[1];
+    const double h = atan2((double)b[3], (double)b[2]);
+    const double c = cos(h), s = sin(h);
+    const double lx[4] = {-hl, hl, hl, -hl}, ly[4] = {-hw, -hw, hw, hw};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        cx[i] = lx[i] * c - ly[i] * s + (double)b[0];
+        cy[i] = lx[i] * s + ly[i] * c + (double)b[1];
+    }
+}
+
+__device__ __forceinline__ double poly_area(const double* x, const double* y, int n) {
+    double a = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int j = (i + 1 == n) ? 0 : i + 1;
+        a += x[i] * y[j] - x[j] * y[i];
+    }
+    return 0.5 * fabs(a);
+}
+
+__global__ __launch_bounds__(256) void rect_iou_kernel(const float* __restrict__ box_a, const float* __restrict__ lw_a,
+                                                         const float* __restrict__ box_b, const float* __restrict__ lw_b, int P,
+                                                         double* __restrict__ iou) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float* a = box_a + (size_t)p * 4;
+    const float* b = box_b + (size_t)p * 4;
+    bool bad = false;
+    for (int i = 0; i < 4; ++i) bad = bad || (a[i] != a[i]) || (b[i] != b[i]);
+    if (bad) {
+        iou[p] = __longlong_as_double(0x7ff8000000000000ll);
+        return;
+    }
+    double ax[4], ay[4], bx[4], by[4];
+    box_corners(a, lw_a + (size_t)p * 2, ax, ay);
+    box_corners(b, lw_b + (size_t)p * 2, bx, by);
+    double px[10], py[10], qx[10], qy[10];
+    int n = 4;
+    for (int i = 0; i < 4; ++i) { px[i] = ax[i]; py[i] = ay[i]; }
+    // both quadrilaterals are counter-clockwise: "inside" of edge (e0 -> e1) is the left side
+    for (int e = 0; e < 4 && n > 0; ++e) {
+        const double ex = bx[e], ey = by[e];
+        const double dx = bx[(e + 1) & 3] - ex, dy = by[(e + 1) & 3] - ey;
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const int j = (i + 1 == n) ? 0 : i + 1;
+            const double si = dx * (py[i] - ey) - dy * (px[i] - ex);
+            const double sj = dx * (py[j] - ey) - dy * (px[j] - ex);
+            if (si >= 0.0) { qx[m] = px[i]; qy[m] = py[i]; ++m; }
+            if ((si >= 0.0) != (sj >= 0.0)) {
+                const double t = si / (si - sj);
+                qx[m] = px[i] + t * (px[j] - px[i]);
+                qy[m] = py[i] + t * (py[j] - py[i]);
+                ++m;
+            }
+        }
+        n = m;
+        for (int i = 0; i < n; ++i) { px[i] = qx[i]; py[i] = qy[i]; }
+    }
+    const double inter = n >= 3 ? poly_area(px, py, n) : 0.0;
+    const double uni = poly_area(ax, ay, 4) + poly_area(bx, by, 4) - inter;
+    iou[p] = inter / uni;
+}
+
+extern "C" int strive_rect_iou(const float* box_a, const float* lw_a, const float* box_b, const float* lw_b, int32_t P,
+                               double* iou, strive_stream_t stream) {
+    STRIVE_CHECK_ARG(box_a && lw_a && box_b && lw_b && iou, "null argument");
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(rect_iou_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, box_a, lw_a, box_b, lw_b, P, iou);
+    STRIVE_CHECK_LAUNCH();
+    return 0;
+}

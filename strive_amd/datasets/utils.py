@@ -48,3 +48,10 @@ def normalize_scene_graph(scene_graph, state_normalizer, att_normalizer, unnorm=
     if 'lw' in scene_graph and len(scene_graph.lw.size()) > 1:
         scene_graph.lw = af(scene_graph.lw)
     return scene_graph
+
+
+def get_ego_inds(scene_graph):
+    """Boolean numpy mask of the first agent of every scene of a batched graph (reference :229-236)."""
+    import numpy as np
+    b = scene_graph.batch.cpu().numpy()
+    return np.append([True], (b[1:] - b[:-1]) == 1)

@@ -375,3 +375,47 @@ class AdvGenLoss(nn.Module):
             out['min_agt'] = np.array(cur_min_agt, dtype=int)
             out['min_t'] = np.array(cur_min_t, dtype=int)
         return out
+
+
+# ------------------------------------------------------------------------------------------------
+# collision metrics used as success tests by the optimisation loops (reference :515-623)
+# ------------------------------------------------------------------------------------------------
+VEH_COLL_THRESH = 0.02   # IoU must be over this to count as a collision for the metric (not the loss)
+
+
+def check_single_veh_coll(traj_tgt, lw_tgt, traj_others, lw_others):
+    """Does the target trajectory (T,4) collide with each of the other trajectories (N,T,4)?  UNNORMALISED inputs;
+    NaN frames of the others are skipped.  Returns numpy ``veh_coll (N,) bool`` and ``coll_time (N,) int`` (first
+    colliding step, T if none) like the reference (:517-565), computed in one HIP launch over all (agent, step) pairs."""
+    import numpy as np
+    N, FT, _ = traj_others.size()
+    if N == 0:
+        return np.zeros((0,), dtype=bool), np.zeros((0,), dtype=int)
+    a = traj_tgt[:, :4].unsqueeze(0).expand(N, FT, 4).reshape(N * FT, 4)
+    la = lw_tgt.view(1, 2).expand(N * FT, 2)
+    b = traj_others[:, :, :4].reshape(N * FT, 4)
+    lb = lw_others.view(N, 1, 2).expand(N, FT, 2).reshape(N * FT, 2)
+    iou = ops.rect_iou(a, la, b, lb).view(N, FT)
+    hit = iou > VEH_COLL_THRESH                                  # NaN compares False: those frames are skipped
+    any_hit = hit.any(dim=1)
+    first = torch.where(any_hit, torch.argmax(hit.to(torch.int32), dim=1), torch.full((N,), FT, device=hit.device, dtype=torch.long))
+    return any_hit.cpu().numpy().astype(bool), first.cpu().numpy().astype(int)
+
+
+def check_pairwise_veh_coll(traj, lw):
+    """Collision bookkeeping over all pairs of the given trajectories (N,T,4), UNNORMALISED (reference :567-623): agent i
+    is marked iff it overlaps some agent j > i at some step."""
+    import numpy as np
+    N, FT, _ = traj.size()
+    ii, jj = torch.triu_indices(N, N, offset=1, device=traj.device)
+    coll = torch.zeros((N,), dtype=torch.bool, device=traj.device)
+    if ii.numel() > 0:
+        Pn = ii.numel()
+        a = traj[ii][:, :, :4].reshape(Pn * FT, 4)
+        b = traj[jj][:, :, :4].reshape(Pn * FT, 4)
+        la = lw[ii].view(Pn, 1, 2).expand(Pn, FT, 2).reshape(Pn * FT, 2)
+        lb = lw[jj].view(Pn, 1, 2).expand(Pn, FT, 2).reshape(Pn * FT, 2)
+        pair_hit = (ops.rect_iou(a, la, b, lb).view(Pn, FT) > VEH_COLL_THRESH).any(dim=1)
+        coll.index_put_((ii[pair_hit],), torch.ones((int(pair_hit.sum()),), dtype=torch.bool, device=traj.device))
+    did = coll.cpu().numpy().astype(bool)
+    return {'num_coll_veh': float(np.sum(did)), 'num_traj_veh': float(N), 'did_collide': did}

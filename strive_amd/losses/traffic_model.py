@@ -81,3 +81,31 @@ class TrafficModelLoss(nn.Module):
             out['coll_env_prior'] = ce.view(-1)
         out['loss'] = loss.view((1,))
         return out
+
+
+ENV_COLL_THRESH = 0.05   # up to 5 % of a vehicle may be off the road (reference :17)
+
+
+def compute_coll_rate_env(scene_graph, map_idx, pred, map_env, state_normalizer, att_normalizer, ego_only=False):
+    """Which sampled rollouts leave the drivable area?  ``pred`` (NA,NS,FT,4) NORMALISED (or a dict holding
+    ``future_pred``); NaN frames never count (reference :366-419).  Returns the reference's dict with
+    ``did_collide`` (NA,NS) bool."""
+    from ..datasets import nuscenes_utils as nutils
+    from ..datasets.utils import get_ego_inds
+    fut = pred if isinstance(pred, torch.Tensor) else pred['future_pred']
+    NA, NS, FT, _ = fut.size()
+    veh_att = scene_graph.lw
+    mapixes = map_idx[scene_graph.batch]
+    if ego_only:
+        ego = torch.from_numpy(get_ego_inds(scene_graph)).to(fut.device)
+        fut, veh_att, mapixes = fut[ego], veh_att[ego], mapixes[ego]
+        NA = fut.size(0)
+    flat = state_normalizer.unnormalize(fut).reshape(NA * NS * FT, 4)
+    att = att_normalizer.unnormalize(veh_att).view(NA, 1, 1, 2).expand(NA, NS, FT, 2).reshape(NA * NS * FT, 2)
+    mix = mapixes.view(NA, 1, 1).expand(NA, NS, FT).reshape(NA * NS * FT)
+    valid = ~torch.isnan(flat.sum(-1))
+    frac = torch.ones((NA * NS * FT,), dtype=torch.float32, device=fut.device)
+    if bool(valid.any()):
+        frac[valid] = nutils.check_on_layer(map_env.nusc_raster[:, 0], map_env.nusc_dx, flat[valid], att[valid], mix[valid])
+    coll = (frac.view(NA, NS, FT) < (1.0 - ENV_COLL_THRESH)).sum(dim=2) >= 1
+    return {'num_coll_map': float(coll.sum().item()), 'num_traj_map': float(NS * NA), 'did_collide': coll}

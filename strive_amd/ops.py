@@ -494,6 +494,20 @@ class _InterpFn(torch.autograd.Function):
         return d_in, None
 
 
+def rect_iou(box_a, lw_a, box_b, lw_b):
+    """IoU of P rotated vehicle boxes: poses (P,4) = (x, y, hx, hy), sizes (P,2) = (l, w) -> float64 (P,), NaN where a pose
+    contains NaN (HIP kernel; the reference loops over shapely polygons, src/losses/adv_gen_nusc.py:517-623)."""
+    lib = _lib_for(box_a, box_b)
+    a, la, b, lb = _f32c(box_a), _f32c(lw_a), _f32c(box_b), _f32c(lw_b)
+    P = a.shape[0]
+    if tuple(a.shape) != (P, 4) or tuple(b.shape) != (P, 4) or tuple(la.shape) != (P, 2) or tuple(lb.shape) != (P, 2):
+        raise ValueError('rect_iou expects (P,4) poses and (P,2) sizes')
+    out = torch.empty((P,), dtype=torch.float64, device=a.device)
+    if P > 0:
+        lib.call('strive_rect_iou', L.ptr(a), L.ptr(la), L.ptr(b), L.ptr(lb), P, L.ptr(out), _stream(a))
+    return out
+
+
 def interp_traj(traj, scale):
     """(N,T,4) -> (N,T*scale,4): linear up-sampling + heading renormalisation, HIP forward and backward."""
     return _InterpFn.apply(traj[:, :, :4], int(scale))

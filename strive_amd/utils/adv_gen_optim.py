@@ -86,3 +86,16 @@ def run_adv_gen_optim(cur_z, lr, loss_weights, model, scene_graph, map_env, map_
     if 'min_t' in fin:
         cur_min_t = fin['min_t']
     return cur_z, final_result_traj, final_decoder_out, cur_min_agt, cur_min_t
+
+
+def compute_adv_gen_success(final_result_traj, model, scene_graph, attack_agt):
+    """Did the scenario make the attacker collide with the planner?  All inputs NORMALISED; ``final_result_traj``
+    (NA,1,FT,4) with agent 0 = the planner's true reaction (reference src/utils/adv_gen_optim.py:214-235)."""
+    from ..losses.adv_gen_nusc import check_single_veh_coll
+    nrm, att = model.get_normalizer(), model.get_att_normalizer()
+    planner_fut = nrm.unnormalize(final_result_traj[0, 0])
+    other_fut = nrm.unnormalize(final_result_traj[1:, 0])
+    planner_lw = att.unnormalize(scene_graph.lw[0])
+    other_lw = att.unnormalize(scene_graph.lw[1:])
+    coll_all, _ = check_single_veh_coll(planner_fut, planner_lw, other_fut, other_lw)
+    return bool(coll_all[attack_agt - 1])

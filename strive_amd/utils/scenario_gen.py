@@ -10,3 +10,43 @@ def detach_embed_info(embed_info_attached):
         elif isinstance(v, tuple):
             out[k] = (v[0].detach(), v[1].detach())
     return out
+
+
+def determine_feasibility_nusc(samples, normalizer, feasibility_thresh, feasibility_time=0, feasibility_vel=0.0,
+                               feasibility_infront_min=None, check_non_drivable_separation=True, map_env=None, map_idx=None):
+    """Is a scene a plausible seed for scenario generation?  (reference src/utils/scenario_gen.py:30-107)
+    ``samples`` (NA,NS,FT,4) NORMALISED futures of ONE scene, agent 0 = ego.  An agent is feasible if, in some sample
+    and step >= ``feasibility_time``, it comes within ``feasibility_thresh`` metres of the ego (optionally only counting
+    steps where it is in front of the ego), the closest approach is not across non-drivable area, and it moves faster
+    than ``feasibility_vel`` per step somewhere.  Returns (feasible, closest step, closest distance), each (NA-1,);
+    three Nones for an ego-only scene."""
+    import torch
+    from ..datasets import nuscenes_utils as nutils
+    if samples.size(0) == 1:
+        return None, None, None
+    if feasibility_infront_min is not None and not (-1 <= feasibility_infront_min <= 1):
+        raise AssertionError('feasibility_infront_min must lie in [-1, 1]')
+    s = normalizer.unnormalize(samples)
+    ego, oth = s[0:1], s[1:]
+    NA, NS, FT, _ = oth.size()
+    t0 = feasibility_time
+    dist = torch.norm(ego[..., :2] - oth[..., :2], dim=-1)[:, :, t0:]                 # (NA, NS, FT')
+    if feasibility_infront_min is not None:
+        to_agent = oth[:, :, t0:, :2] - ego[:, :, t0:, :2]
+        to_agent = to_agent / torch.norm(to_agent, dim=-1, keepdim=True)
+        infront = torch.sum(to_agent * ego[:, :, t0:, 2:4], dim=-1) >= feasibility_infront_min
+        dist = torch.where(infront, dist, torch.full_like(dist, float('inf')))
+    best_over_samples, best_sample = torch.min(dist, dim=1)                           # (NA, FT')
+    feasible_dist, step = torch.min(best_over_samples, dim=1)
+    step = step + t0
+    feasible = (dist < feasibility_thresh).sum(dim=[1, 2]) > 0
+    if check_non_drivable_separation:
+        ar = torch.arange(NA, device=samples.device)
+        samp = best_sample[ar, step - t0]
+        agent_xy = oth[ar, samp, step][:, :2]
+        ego_xy = ego.expand(NA, NS, FT, 4)[ar, samp, step][:, :2]
+        blocked = nutils.check_line_layer(map_env.nusc_raster[:, 0], map_env.nusc_dx, agent_xy, ego_xy, map_idx.expand(NA))
+        feasible = torch.logical_and(feasible, ~blocked)
+    vel = torch.norm(oth[:, :, 1:, :2] - oth[:, :, :-1, :2], dim=-1)
+    feasible = torch.logical_and(feasible, vel.amax(dim=(1, 2)) > feasibility_vel)
+    return feasible, step, feasible_dist

@@ -47,3 +47,20 @@ def run_find_solution_optim(cur_z, final_result_traj, future_len, lr, loss_weigh
     sol_result_traj = sol_decoder_out['future_pred'].clone().detach()
     sol_result_traj[~tgt_mask] = model.get_normalizer().normalize(other_match)
     return cur_z, sol_result_traj, sol_decoder_out
+
+
+def compute_sol_success(final_result_traj, model, scene_graph, map_env, map_idx, use_map_coll=True):
+    """Did the solution optimisation find a collision-free ego future?  All inputs NORMALISED; agent 0 of
+    ``final_result_traj`` (NA,1,FT,4) is the solution (reference src/utils/sol_optim.py:126-165)."""
+    import numpy as np
+    from ..losses.adv_gen_nusc import check_single_veh_coll
+    from ..losses.traffic_model import compute_coll_rate_env
+    nrm, att = model.get_normalizer(), model.get_att_normalizer()
+    sol_fut = nrm.unnormalize(final_result_traj[0, 0])
+    other_fut = nrm.unnormalize(final_result_traj[1:, 0])
+    coll_all, _ = check_single_veh_coll(sol_fut, att.unnormalize(scene_graph.lw[0]), other_fut, att.unnormalize(scene_graph.lw[1:]))
+    impossible = bool(np.sum(coll_all) > 0)
+    if use_map_coll:
+        env = compute_coll_rate_env(scene_graph, map_idx, final_result_traj.contiguous(), map_env, nrm, att, ego_only=True)
+        impossible = impossible or bool(env['did_collide'].cpu().numpy()[0, 0])
+    return not impossible

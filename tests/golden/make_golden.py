@@ -525,10 +525,65 @@ def g7_sample(R):
          z_logprob=npy(so['z_logprob']), z_mdist=npy(so['z_mdist']))
 
 
+def g8_inputs():
+    """One scene of 6 agents x 4 samples x 8 steps (UNNORMALISED world poses on the g2 raster) for the feasibility /
+    drivable-area tests: the ego drives along +x through the map centre, the others start on a ring around it."""
+    raster, dx, _, _, _ = g2_inputs()
+    NA, NS, FT = 6, 4, 8
+    t = torch.arange(FT, dtype=torch.float32).view(1, 1, FT)
+    ang0 = synth.f32(synth.counter_uniform((NA, NS, 1), 'g8/ang', -3.1, 3.1))
+    rad = synth.f32(synth.counter_uniform((NA, NS, 1), 'g8/rad', 2.0, 30.0))
+    spd = synth.f32(synth.counter_uniform((NA, NS, 1), 'g8/spd', 0.0, 3.0))
+    hd = synth.f32(synth.counter_uniform((NA, NS, 1), 'g8/hd', -3.1, 3.1))
+    cx, cy = 128.0, 128.0
+    x = cx + rad * torch.cos(ang0) + spd * t * torch.cos(hd)
+    y = cy + rad * torch.sin(ang0) + spd * t * torch.sin(hd)
+    world = torch.stack([x, y, torch.cos(hd).expand(NA, NS, FT), torch.sin(hd).expand(NA, NS, FT)], dim=-1).contiguous()
+    world[0, :, :, 0] = cx - 6.0 + 2.0 * t[0]          # the ego: same in every sample
+    world[0, :, :, 1] = cy
+    world[0, :, :, 2] = 1.0
+    world[0, :, :, 3] = 0.0
+    world[5, 1, 3:5, :] = float('nan')                  # NaN frames never count in the drivable-area test
+    lw = synth.f32(synth.counter_uniform((NA, 2), 'g8/lw', 0.0, 1.0)) * torch.tensor([1.5, 0.6]) + torch.tensor([4.0, 1.7])
+    return raster, dx, world, lw
+
+
+def g8_checks(R):
+    """determine_feasibility_nusc and compute_coll_rate_env of the reference on the g8 scene."""
+    tm, _ = ref_model(R)
+    raster, dx, world, lw = g8_inputs()
+    env = ref_map_env(R, raster, dx)
+    nrm, att = tm.get_normalizer(), tm.get_att_normalizer()
+    samples = nrm.normalize(torch.nan_to_num(world, nan=0.0))
+    samples = torch.where(torch.isnan(world), world, samples)
+    map_idx = torch.tensor([1])
+    out = {}
+    cases = [(15.0, 0, 0.0, None, False), (15.0, 2, 0.5, None, True), (25.0, 1, 0.0, 0.0, True), (8.0, 0, 1.0, -0.5, False)]
+    clean = torch.nan_to_num(samples, nan=0.0)
+    for ci, (th, t0, vel, front, sep) in enumerate(cases):
+        f, st, ds = R.scenario_gen.determine_feasibility_nusc(clean.clone(), nrm, th, feasibility_time=t0, feasibility_vel=vel,
+                                                              feasibility_infront_min=front, check_non_drivable_separation=sep,
+                                                              map_env=env, map_idx=map_idx)
+        out['feas_%d' % ci] = npy(f)
+        out['step_%d' % ci] = npy(st)
+        out['dist_%d' % ci] = npy(ds)
+    batch, _, _, _ = build_inputs([6], 'g8')
+    batch.lw = att.normalize(lw)
+    for name, ego_only in (('all', False), ('ego', True)):
+        cd = R.tm_losses.compute_coll_rate_env(batch, map_idx, samples.clone(), env, nrm, att, ego_only=ego_only)
+        out['env_did_%s' % name] = npy(cd['did_collide'])
+        out['env_num_%s' % name] = np.array([cd['num_coll_map'], cd['num_traj_map']])
+    save('g8_checks.npz', **out)
+
+
+G8_CASES = [(15.0, 0, 0.0, None, False), (15.0, 2, 0.5, None, True), (25.0, 1, 0.0, 0.0, True), (8.0, 0, 1.0, -0.5, False)]
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     R = import_reference()
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
-    fns = {'g1': g1_ops, 'g2': g2_crop, 'g3': g3_gnn, 'g4': g4_rollout, 'g5': g5_losses, 'g6': g6_loop, 'g7': g7_sample}
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8']
+    fns = {'g1': g1_ops, 'g2': g2_crop, 'g3': g3_gnn, 'g4': g4_rollout, 'g5': g5_losses, 'g6': g6_loop, 'g7': g7_sample,
+           'g8': g8_checks}
     for w in which:
         fns[w](R)

@@ -221,3 +221,27 @@ def test_interp_traj_fwd_bwd(emu):
         og = torch.zeros((Ng, Tg * 3, 4))
         emu.call('strive_interp_traj_fwd', L.ptr(xi), Ng, Tg, Tg * 3, L.ptr(a0), L.ptr(a1), L.ptr(b0), L.ptr(b1), L.ptr(og), None)
         np.testing.assert_allclose(og.numpy(), g['interp'], rtol=1e-5, atol=3e-6)
+
+
+def test_rect_iou_kernel(emu):
+    """strive_rect_iou vs the float64 oracle on random vehicle boxes (overlapping, disjoint, identical, NaN)."""
+    from oracle.geometry import rect_iou
+    P = 96
+    u = synth.counter_uniform((P, 8), 'iouk/u', -1.0, 1.0)
+    a = np.stack([4 * u[:, 0], 4 * u[:, 1], np.cos(3.1 * u[:, 2]), np.sin(3.1 * u[:, 2])], axis=1)
+    b = np.stack([4 * u[:, 3], 4 * u[:, 4], np.cos(3.1 * u[:, 5]), np.sin(3.1 * u[:, 5])], axis=1)
+    la = np.stack([4.5 + u[:, 6], 1.9 + 0.3 * u[:, 7]], axis=1)
+    lb = np.stack([4.0 - 0.5 * u[:, 7], 1.8 + 0.2 * u[:, 6]], axis=1)
+    b[0], lb[0] = a[0], la[0]                       # identical boxes
+    b[1, :2] = a[1, :2] + 40.0                      # far apart
+    b[2, 0] = np.nan                                # NaN pose
+    a[3, 2:] *= 7.5                                 # un-normalised heading vector (atan2 only sees the direction)
+    ta, tb, tla, tlb = (synth.f32(x).contiguous() for x in (a, b, la, lb))
+    out = torch.zeros((P,), dtype=torch.float64)
+    emu.call('strive_rect_iou', L.ptr(ta), L.ptr(tla), L.ptr(tb), L.ptr(tlb), P, L.ptr(out), None)
+    want = np.array([rect_iou(ta[i].numpy(), tla[i].numpy(), tb[i].numpy(), tlb[i].numpy()) for i in range(P)])
+    assert np.isnan(out[2].item()) and np.isnan(want[2])
+    ok = ~np.isnan(want)
+    np.testing.assert_allclose(out.numpy()[ok], want[ok], rtol=0, atol=1e-12)
+    assert abs(out[0].item() - 1.0) < 1e-12 and out[1].item() == 0.0
+    assert (want[ok] > 0.02).sum() > 10 and (want[ok] == 0).sum() > 10      # both outcomes are exercised

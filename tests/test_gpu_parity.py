@@ -328,6 +328,46 @@ def test_interp_traj_fwd_bwd():
     assert ops.interp_traj(torch.zeros((0, 12, 4), device=DEV), 3).shape == (0, 36, 4)
 
 
+def test_success_checks_vs_oracle(model):
+    """check_single_veh_coll / check_pairwise_veh_coll / compute_adv_gen_success / compute_sol_success: the HIP IoU path
+    vs the oracle's restatement of the reference loops (IoU itself: closed-form pinned, see test_oracle_golden.py)."""
+    from strive_amd.losses.adv_gen_nusc import check_single_veh_coll, check_pairwise_veh_coll
+    from strive_amd.utils.adv_gen_optim import compute_adv_gen_success
+    from strive_amd.utils.sol_optim import compute_sol_success
+    m, sd = model
+    raster, dx, world, lw = mg.g8_inputs()
+    NA, NS, FT, _ = world.shape
+    traj = world[:, 0].clone()                                   # (6, 8, 4): one sample per agent
+    traj[2] = traj[0] + torch.tensor([1.0, 0.5, 0.0, 0.0])       # agent 2 overlaps the ego from the start
+    traj[4, 5:] = traj[0, 5:]                                    # agent 4 meets it at step 5
+    traj[4, 5:, 2:] = torch.tensor([0.6, 0.8])
+    traj[3, 2] = float('nan')                                    # a NaN frame is skipped
+    want_c, want_t = olosses.check_single_veh_coll(traj[0], lw[0], traj[1:], lw[1:])
+    got_c, got_t = check_single_veh_coll(traj[0].to(DEV), lw[0].to(DEV), traj[1:].to(DEV), lw[1:].to(DEV))
+    assert np.array_equal(got_c, want_c) and np.array_equal(got_t, want_t)
+    assert want_c[1] and want_t[1] == 0 and want_c[3] and want_t[3] == 5
+    clean = torch.nan_to_num(traj, nan=0.0)
+    want_p = olosses.check_pairwise_veh_coll(clean, lw)
+    got_p = check_pairwise_veh_coll(clean.to(DEV), lw.to(DEV))
+    assert np.array_equal(got_p['did_collide'], want_p['did_collide'])
+    assert got_p['num_coll_veh'] == want_p['num_coll_veh'] and got_p['num_traj_veh'] == float(NA)
+    e0, e1 = check_single_veh_coll(traj[0].to(DEV), lw[0].to(DEV), traj[1:1].to(DEV), lw[1:1].to(DEV))
+    assert e0.shape == (0,) and e1.shape == (0,)
+    # the loop-level success predicates on the same scene (normalised inputs, agent 0 = planner / solution)
+    nrm, att = m.get_normalizer(), m.get_att_normalizer()
+    batch, _, _, _ = mg.build_inputs([6], 'g8')
+    batch.lw = att.normalize(lw)
+    batch = batch.to(DEV)
+    final = nrm.normalize(clean).unsqueeze(1).to(DEV)            # (NA, 1, FT, 4)
+    assert compute_adv_gen_success(final, m, batch, attack_agt=2) is True
+    assert compute_adv_gen_success(final, m, batch, attack_agt=1) is False
+    env = dev_env(raster, dx)
+    assert compute_sol_success(final, m, batch, env, torch.tensor([1]).to(DEV), use_map_coll=True) is False
+    lonely = final.clone()
+    lonely[1:, :, :, :2] += 50.0                                 # move everybody else far away (normalised units)
+    assert compute_sol_success(lonely, m, batch, env, torch.tensor([1]).to(DEV), use_map_coll=False) is True
+
+
 def test_veh_coll_fwd_bwd(model, g5):
     from strive_amd.losses.adv_gen_nusc import VehCollLoss
     m, sd = model
