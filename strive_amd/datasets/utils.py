@@ -55,3 +55,26 @@ def get_ego_inds(scene_graph):
     import numpy as np
     b = scene_graph.batch.cpu().numpy()
     return np.append([True], (b[1:] - b[:-1]) == 1)
+
+
+def read_adv_scenes(scene_path):
+    """Load every ``*.json`` scenario of a directory (sorted by name) written by ``prepare_output_dict`` into the dicts the
+    evaluation tools use: ``name, map, dt, veh_att, scene_past, scene_fut`` (= ``fut_adv``) and, when present,
+    ``attack_t, sem`` (reference src/datasets/utils.py:10-38)."""
+    import glob
+    import json
+    import os
+    scenes = []
+    for path in sorted(glob.glob(os.path.join(scene_path, '*.json'))):
+        with open(path, 'r') as f:
+            jd = json.load(f)
+        if jd is None:
+            continue
+        sc = {'name': os.path.basename(path)[:-5], 'map': jd['map'], 'dt': jd['dt'],
+              'veh_att': torch.tensor(jd['lw']), 'scene_past': torch.tensor(jd['past']), 'scene_fut': torch.tensor(jd['fut_adv'])}
+        if 'attack_t' in jd:
+            sc['attack_t'] = jd['attack_t']
+        if 'sem' in jd:
+            sc['sem'] = torch.tensor(jd['sem'])
+        scenes.append(sc)
+    return scenes

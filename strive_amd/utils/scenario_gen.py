@@ -50,3 +50,42 @@ def determine_feasibility_nusc(samples, normalizer, feasibility_thresh, feasibil
     vel = torch.norm(oth[:, :, 1:, :2] - oth[:, :, :-1, :2], dim=-1)
     feasible = torch.logical_and(feasible, vel.amax(dim=(1, 2)) > feasibility_vel)
     return feasible, step, feasible_dist
+
+
+def prepare_output_dict(scene_graph, map_idx, map_env, dt, model, init_fut_traj, adv_fut_traj, sol_fut_traj=None,
+                        attack_agt=None, attack_t=None, adv_z=None, sol_z=None, prior_distrib=None,
+                        attack_bike_params=None, internal_ego_traj=None):
+    """The scenario wire format consumed by the eval / clustering / viz tools (reference src/utils/scenario_gen.py:189-254):
+    a JSON-ready dict with keys ``N, dt, map, lw, sem, past, fut_init, fut_adv`` and, when given, ``fut_internal_ego,
+    fut_sol, attack_agt, attack_t, z_adv, z_sol, z_prior{mean,var}, attack_bike_prof``.  Trajectories and ``lw`` are
+    stored UNNORMALISED as nested lists."""
+    nrm = model.get_normalizer()
+
+    def world(t):
+        return nrm.unnormalize(t).cpu().numpy().tolist()
+
+    def plain(t):
+        return t.detach().cpu().numpy().tolist()
+    out = {'N': int(init_fut_traj.size(0)), 'dt': dt, 'map': map_env.map_list[map_idx]}
+    out['lw'] = plain(model.get_att_normalizer().unnormalize(scene_graph.lw))
+    out['sem'] = plain(scene_graph.sem)
+    out['past'] = world(scene_graph.past_gt)
+    out['fut_init'] = world(init_fut_traj)
+    out['fut_adv'] = world(adv_fut_traj)
+    if internal_ego_traj is not None:
+        out['fut_internal_ego'] = world(internal_ego_traj)
+    if sol_fut_traj is not None:
+        out['fut_sol'] = world(sol_fut_traj)
+    if attack_agt is not None:
+        out['attack_agt'] = int(attack_agt)
+    if attack_t is not None:
+        out['attack_t'] = int(attack_t)
+    if adv_z is not None:
+        out['z_adv'] = plain(adv_z)
+    if sol_z is not None:
+        out['z_sol'] = plain(sol_z)
+    if prior_distrib is not None:
+        out['z_prior'] = {'mean': plain(prior_distrib[0]), 'var': plain(prior_distrib[1])}
+    if attack_bike_params is not None:
+        out['attack_bike_prof'] = plain(attack_bike_params)
+    return out

@@ -576,14 +576,42 @@ def g8_checks(R):
     save('g8_checks.npz', **out)
 
 
+def g9_inputs():
+    """Scene of 3 agents for the scenario wire format: normalised futures / latents from the counter generator."""
+    batch, map_idx, raster, dx = build_inputs([3], 'g9')
+    f = lambda shape, key: synth.f32(synth.counter_uniform(shape, 'g9/' + key, -1.0, 1.0))
+    return batch, raster, dx, dict(init=f((3, 12, 4), 'init'), adv=f((3, 12, 4), 'adv'), sol=f((3, 12, 4), 'sol'),
+                                   internal=f((1, 12, 4), 'int'), adv_z=f((3, 32), 'zadv'), sol_z=f((3, 32), 'zsol'),
+                                   pm=f((3, 32), 'pm'), pv=f((3, 32), 'pv').abs() + 0.1, bike=f((12, 2), 'bike'))
+
+
+def g9_wire(R):
+    """prepare_output_dict of the reference (full and minimal argument sets) as JSON fixtures."""
+    import json
+    tm, _ = ref_model(R)
+    batch, raster, dx, t = g9_inputs()
+    env = ref_map_env(R, raster, dx)
+    env.map_list = ['synthetic-map-0']
+    full = R.scenario_gen.prepare_output_dict(batch, 0, env, 0.5, tm, t['init'], t['adv'], sol_fut_traj=t['sol'], attack_agt=2,
+                                              attack_t=7, adv_z=t['adv_z'], sol_z=t['sol_z'], prior_distrib=(t['pm'], t['pv']),
+                                              attack_bike_params=t['bike'], internal_ego_traj=t['internal'])
+    mini = R.scenario_gen.prepare_output_dict(batch, 0, env, 0.5, tm, t['init'], t['adv'])
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, 'g9_scenario_full.json'), 'w') as f:
+        json.dump(full, f)
+    with open(os.path.join(here, 'g9_scenario_min.json'), 'w') as f:
+        json.dump(mini, f)
+    print('wrote g9_scenario_{full,min}.json')
+
+
 G8_CASES = [(15.0, 0, 0.0, None, False), (15.0, 2, 0.5, None, True), (25.0, 1, 0.0, 0.0, True), (8.0, 0, 1.0, -0.5, False)]
 
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
     R = import_reference()
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
     fns = {'g1': g1_ops, 'g2': g2_crop, 'g3': g3_gnn, 'g4': g4_rollout, 'g5': g5_losses, 'g6': g6_loop, 'g7': g7_sample,
-           'g8': g8_checks}
+           'g8': g8_checks, 'g9': g9_wire}
     for w in which:
         fns[w](R)
