@@ -29,8 +29,13 @@ struct GRUDev {
 
 struct Tape {
     float *pf, *mf, *pos, *state, *mem, *A, *loc;
+    float *X, *P, *Q;       // node embeddings and edge layer-0 partials of every step (kept: the reverse sweep reads them
+                            // instead of re-running the node-1 kernel)
     int32_t* ARG;
     size_t R;
+    __host__ __device__ float* X_t(int t) const { return X + (size_t)t * R * 64; }
+    __host__ __device__ float* P_t(int t) const { return P + (size_t)t * R * STRIVE_HID; }
+    __host__ __device__ float* Q_t(int t) const { return Q + (size_t)t * R * STRIVE_HID; }
     __host__ __device__ float* pf_t(int t) const { return pf + (size_t)t * R * 64; }
     __host__ __device__ float* mf_t(int t) const { return mf + (size_t)t * R * 64; }
     __host__ __device__ float* pos_t(int t) const { return pos + (size_t)t * R * 4; }
@@ -42,8 +47,8 @@ struct Tape {
 };
 
 static size_t tape_bytes_for(size_t R, int FT) {
-    const size_t per = 64 + 64 + 4 + 8 + 192 + 64 + 4 + 64;
-    return strive_align_up(R * FT * per * 4 + 8 * 256, 256);
+    const size_t per = 64 + 64 + 4 + 8 + 192 + 64 + 4 + 64 + 64 + 2 * STRIVE_HID;
+    return strive_align_up(R * FT * per * 4 + 11 * 256, 256);
 }
 
 static Tape carve_tape(void* p, size_t bytes, size_t R, int FT) {
@@ -58,6 +63,9 @@ static Tape carve_tape(void* p, size_t bytes, size_t R, int FT) {
     t.A = ar.take<float>(R * FT * 64);
     t.loc = ar.take<float>(R * FT * 4);
     t.ARG = ar.take<int32_t>(R * FT * 64);
+    t.X = ar.take<float>(R * FT * 64);
+    t.P = ar.take<float>(R * FT * STRIVE_HID);
+    t.Q = ar.take<float>(R * FT * STRIVE_HID);
     return t;
 }
 
@@ -359,6 +367,9 @@ extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* 
         GnnBuffers gb = w.gb;
         gb.A = tp.A_t(t);
         gb.ARG = tp.ARG_t(t);
+        gb.X = tp.X_t(t);
+        gb.P = tp.P_t(t);
+        gb.Q = tp.Q_t(t);
         FeatSrc f = decoder_features(tp, t, sem, z, lw, NC);
         hipLaunchKernelGGL(gnn_node1_kernel, dim3(nb), dim3(256), Node1Lds::bytes(in_ld1, xs_ld), stream, gd, sc->NS, f, sem,
                            gb, (int)R);
@@ -805,10 +816,10 @@ extern "C" int strive_rollout_bwd(const StriveDecoder* dec, const StriveScenes* 
         GnnBuffers g2 = gb;
         g2.A = tp.A_t(t);
         g2.ARG = tp.ARG_t(t);
+        g2.X = tp.X_t(t);          // x, P, Q of step t as the forward sweep left them in the tape
+        g2.P = tp.P_t(t);
+        g2.Q = tp.Q_t(t);
         FeatSrc f = decoder_features(tp, t, sem, z, lw, NC);
-        // recompute x, P, Q of step t
-        hipLaunchKernelGGL(gnn_node1_kernel, dim3(nb), dim3(256), Node1Lds::bytes(in_ld1, xs_ld), stream, gd, sc->NS, f, sem,
-                           g2, (int)R);
         if (t < FT - 1)
             hipLaunchKernelGGL(gru_bwd_kernel, dim3(nb), dim3(256), gru_bwd_lds_bytes(), stream, gr, tp, t, (int)R, g_pf, g_mem,
                                d_loc);
