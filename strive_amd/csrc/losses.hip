@@ -42,7 +42,9 @@ __global__ __launch_bounds__(256) void veh_coll_fwd_kernel(VehArgs a, float* __r
     const int gid = (blockIdx.x * blockDim.x + threadIdx.x) / VG;
     const int sub = threadIdx.x & (VG - 1);
     if (gid >= a.NA * a.T) return;
-    const int i = gid / a.T, t = gid - i * a.T;
+    // agent fastest: the slots of consecutive agents at one time sample are contiguous in pen / hit / amin, so a wave's
+    // stores (4 groups x 16 lanes) form one contiguous run instead of four runs P floats apart
+    const int t = gid / a.NA, i = gid - t * a.NA;
     const int b = a.scene_of[i];
     const int lo = a.ptr[b], n = a.ptr[b + 1] - lo;
     float ax[NCIRC], ay[NCIRC];
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void veh_coll_bwd_kernel(VehArgs a, const floa
     const int sub = threadIdx.x & (VG - 1);
     const bool live = gid_raw < a.NA * a.T;      // whole groups are live or not; every lane stays for the shuffles
     const int gid = live ? gid_raw : 0;
-    const int i = gid / a.T, t = gid - i * a.T;
+    const int t = gid / a.NA, i = gid - t * a.NA;      // agent fastest (see the forward kernel)
     const int b = a.scene_of[i];
     const int lo = a.ptr[b], n = a.ptr[b + 1] - lo;
     float ax[NCIRC], ay[NCIRC];
