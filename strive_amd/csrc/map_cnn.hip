@@ -553,11 +553,12 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void conv_mfma_kernel(const flo
 // front, parked in registers and fed through three rotating LDS buffers, and the fragment reads of step s+1 are
 // interleaved with the matrix work of step s.
 // =============================================================================================
-template <int CIN_, int COUT_, int KS_, int IH_, int OH_, int NPART_IN_, bool OUT_OCT_>
+template <int CIN_, int COUT_, int KS_, int IH_, int OH_, int NPART_IN_, bool OUT_OCT_, int PT_ = 2, int WGS_PER_CU_ = 2>
 struct BfCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, KS = KS_, IH = IH_, OH = OH_, NPART_IN = NPART_IN_;
     static constexpr bool OUT_OCT = OUT_OCT_;
-    static constexpr int PT = 2;                                    // pixel tiles (= output rows of 32) per wave
+    static constexpr int PT = PT_;                                  // pixel tiles (= output rows of 32) per wave
+    static constexpr int WGS_PER_CU = WGS_PER_CU_;                  // residency target (LDS and register budget)
     static constexpr int NT = 256, NW = 4, TH = NW * PT, TW = 32;
     static constexpr int COUT_WG = 32, CSPLIT = COUT / COUT_WG;
     static constexpr int PASS_CH = 8, NPASS = CIN / PASS_CH;
@@ -572,7 +573,7 @@ struct BfCfg {
     static constexpr size_t LDS_BYTES = (size_t)IN_B + 3 * WSTEP_B + (size_t)CIN * 8 + NW * 16 + 16;
     static constexpr size_t WFRAG_BYTES = (size_t)NPASS * NKS * CSPLIT * WSTEP_B;
     static_assert(CIN % PASS_CH == 0 && COUT % COUT_WG == 0 && CIN <= NT, "channel tiling");
-    static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+    static_assert(LDS_BYTES * WGS_PER_CU <= 160 * 1024, "LDS budget of the residency target");
     static_assert(KS == 5 && NKS == 13, "the tap order in conv_bf6_kernel is written for 5x5 windows");
     static_assert(WSTEP_B == 16 * 192, "weight step = one 16-byte piece for each of the first 192 threads");
 };
@@ -597,7 +598,7 @@ __device__ __forceinline__ void split_bf16x3(const float v[8], uint4& p0, uint4&
 
 // TIMING: phase timestamps (s_memtime) of every workgroup summed into `tprof` (measurement hook only)
 template <class Cfg, bool TIMING = false>
-__global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
+__global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
                                                                 const float* __restrict__ gn_g, const float* __restrict__ gn_b,
                                                                 const uint32_t* __restrict__ wfrag, const float* __restrict__ bias,
                                                                 float* __restrict__ out, GNStats* __restrict__ st_out, int N,
