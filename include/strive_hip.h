@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define STRIVE_ABI_VERSION 2
+#define STRIVE_ABI_VERSION 3
 #define STRIVE_HID 128        /* hidden width of every MLP in the reference (models/common.py, interaction_net.py:32,41) */
 #define STRIVE_MAX_LAYERS 4
 #define STRIVE_ZDIM 32
@@ -104,11 +104,13 @@ typedef struct StriveCNN {
     const uint32_t* w1_frag;   /* layer-0 weights split into three bf16 pieces (w = hi + mid + lo, exact) in MFMA fragment
                                   order [ky][piece][lane 0..63][8 x bf16], 8 values = window columns 2g,2g+1 x 4 layers for
                                   lane group g = lane/16, output channel = lane%16; 21504 bytes */
-    const uint32_t* w2_frag;   /* layer-1 (16->32, 5x5) and layer-2 (32->64, 5x5) weights, each split exactly into three bf16 */
-    const uint32_t* w3_frag;   /* pieces, in the fragment order of conv_bf6_kernel: [pass = ci/8][step s = 0..12][co/32]
-                                  [piece 3][lane 64][8 x bf16]; lane half h = lane/32 holds the window tap (s/2, (s&1)+2h)
-                                  for s < 10, (2(s-10)+h, 4) for s = 10, 11, (4, 4) or zero for s = 12; element e = input
-                                  channel 8*pass + e, output channel = 32*(co/32) + lane%32.  79872 / 319488 bytes */
+    const uint32_t* w2_frag;   /* layer-1 (16->32, 5x5), layer-2 (32->64, 5x5) and layer-3 (64->64, 3x3) weights, each split exactly */
+    const uint32_t* w3_frag;   /* into three bf16 pieces, in the fragment order of conv_bf6_kernel: [pass = ci/8][step s][co/32] */
+    const uint32_t* w4_frag;   /* [piece 3][lane 64][8 x bf16]; lane half h = lane/32 holds one window tap of the step, element
+                                  e = input channel 8*pass + e, output channel = 32*(co/32) + lane%32.
+                                  5x5 (13 steps): tap (s/2, (s&1)+2h) for s < 10, (2(s-10)+h, 4) for s = 10, 11, (4, 4) or zero
+                                  for s = 12.  3x3 (5 steps): (s, 2h) for s < 3, (h, 1) for s = 3, (2, 1) or zero for s = 4.
+                                  79872 / 319488 / 245760 bytes */
 } StriveCNN;
 
 /* Scene structure of a batch: agents of scene b are rows ptr[b] .. ptr[b+1]-1, ego first

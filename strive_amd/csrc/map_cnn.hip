@@ -6,8 +6,8 @@
 //     D[co][pixel] += W[co][k] * patch[k][pixel]
 // with A = weights (M = output channels) and B = input patches (N = output pixels):
 //   layer 1 (u8 crop, Cout 16):  v_mfma_f32_16x16x32_bf16, weights split exactly into 3 bf16 pieces (exact fp32 result)
-//   layers 2-3 (fp32 in):        v_mfma_f32_32x32x16_bf16, both operands split exactly into 3 bf16 pieces, 6 products
-//   layers 4-6 (fp32 NCHW in):   v_mfma_f32_32x32x2_f32 (exact fp32, = an fmaf chain)
+//   layers 2-4 (fp32 in):        v_mfma_f32_32x32x16_bf16, both operands split exactly into 3 bf16 pieces, 6 products
+//   layers 5-6 (fp32 NCHW in):   v_mfma_f32_32x32x2_f32 (exact fp32, = an fmaf chain)
 // Input tiles are staged once per workgroup into LDS with the previous layer's GroupNorm + ReLU applied
 // on the way in (so normalised activations never exist in HBM either); columns are stored
 // de-interleaved by parity so the stride-2 window reads of consecutive output pixels hit consecutive
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void conv_mfma_kernel(const flo
 }
 
 // =============================================================================================
-// Layers 2-3 on the bf16 matrix cores at fp32 accuracy ("bf16 x 6").
+// Layers 2-4 on the bf16 matrix cores at fp32 accuracy ("bf16 x 6").
 // Both operands are split EXACTLY into three bf16 pieces (x = x0 + x1 + x2, 8 mantissa bits each; the weights on
 // the host, the activations while they are staged into LDS, by truncation: x0 = x & 0xffff0000, x1 likewise of
 // x - x0, x2 = the rest) and the six products down to 2^-16 of the leading one are accumulated in fp32 inside
@@ -553,13 +553,16 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void conv_mfma_kernel(const flo
 // front, parked in registers and fed through three rotating LDS buffers, and the fragment reads of step s+1 are
 // interleaved with the matrix work of step s.
 // =============================================================================================
-template <int CIN_, int COUT_, int KS_, int IH_, int OH_, int NPART_IN_, bool OUT_OCT_, int PT_ = 2, int WGS_PER_CU_ = 2>
+template <int CIN_, int COUT_, int KS_, int IH_, int OH_, int NPART_IN_, bool OUT_OCT_, int PT_ = 2, int WGS_PER_CU_ = 2,
+          bool ROWS2_ = false>
 struct BfCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, KS = KS_, IH = IH_, OH = OH_, NPART_IN = NPART_IN_;
     static constexpr bool OUT_OCT = OUT_OCT_;
-    static constexpr int PT = PT_;                                  // pixel tiles (= output rows of 32) per wave
+    static constexpr int PT = PT_;                                  // pixel tiles of 32 per wave
+    static constexpr bool ROWS2 = ROWS2_;                           // pixel tile = 2 rows x 16 columns (small images) instead of 1 x 32
+    static constexpr int TILE_ROWS = ROWS2 ? 2 : 1;
     static constexpr int WGS_PER_CU = WGS_PER_CU_;                  // residency target (LDS and register budget)
-    static constexpr int NT = 256, NW = 4, TH = NW * PT, TW = 32;
+    static constexpr int NT = 256, NW = 4, TH = NW * PT * TILE_ROWS, TW = ROWS2 ? 16 : 32;
     static constexpr int COUT_WG = 32, CSPLIT = COUT / COUT_WG;
     static constexpr int PASS_CH = 8, NPASS = CIN / PASS_CH;
     static constexpr int ITH = 2 * TH + KS - 2, ITW = 2 * TW + KS - 2, HW = (ITW + 1) / 2;
@@ -574,7 +577,7 @@ struct BfCfg {
     static constexpr size_t WFRAG_BYTES = (size_t)NPASS * NKS * CSPLIT * WSTEP_B;
     static_assert(CIN % PASS_CH == 0 && COUT % COUT_WG == 0 && CIN <= NT, "channel tiling");
     static_assert(LDS_BYTES * WGS_PER_CU <= 160 * 1024, "LDS budget of the residency target");
-    static_assert(KS == 5 && NKS == 13, "the tap order in conv_bf6_kernel is written for 5x5 windows");
+    static_assert((KS == 5 && NKS == 13) || (KS == 3 && NKS == 5), "tap orders exist for 5x5 and 3x3 windows");
     static_assert(WSTEP_B == 16 * 192, "weight step = one 16-byte piece for each of the first 192 threads");
 };
 
@@ -682,8 +685,10 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    // byte offset of this lane's pixel (window origin) in the wave's first output row; row i is 2*i input rows further
-    const int lane_base = (2 * PT * wave) * Cfg::ROW_B + j * 16;
+    // this lane's pixel inside a pixel tile (row, column) and the byte offset of its window origin in the wave's first
+    // tile; tile i is 2 * TILE_ROWS * i input rows further
+    const int prow = Cfg::ROWS2 ? (j >> 4) : 0, pcol = Cfg::ROWS2 ? (j & 15) : j;
+    const int lane_base = (2 * (Cfg::TILE_ROWS * PT * wave + prow)) * Cfg::ROW_B + pcol * 16;
 
     const uint4* wsrc = reinterpret_cast<const uint4*>(wfrag);
     constexpr int WQ = Cfg::WSTEP_B / 16;                         // 192 x 16 B per MFMA step
@@ -749,8 +754,14 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
         bf16x8 fa[2][3], fb[2][PT][3];
         auto load_frags = [&](int t, int set) {
             int ky, kx;
-            if (t < 10) { ky = t >> 1; kx = (t & 1) + 2 * h; }
-            else { ky = 2 * (t - 10) + h; kx = 4; ky = ky > 4 ? 4 : ky; }     // (row 5 does not exist: zero-weight slot)
+            if (Cfg::KS == 5) {
+                if (t < 10) { ky = t >> 1; kx = (t & 1) + 2 * h; }
+                else { ky = 2 * (t - 10) + h; kx = 4; ky = ky > 4 ? 4 : ky; }     // (row 5 does not exist: zero-weight slot)
+            } else {        // 3x3: steps 0-2 = row t, columns 0 and 2; step 3 = column 1 of rows 0, 1; step 4 = (2, 1) + zero slot
+                if (t < 3) { ky = t; kx = 2 * h; }
+                else if (t == 3) { ky = h; kx = 1; }
+                else { ky = 2; kx = 1; }
+            }
             const int off = ky * Cfg::ROW_B + (kx & 1) * Cfg::HALF_B + (kx >> 1) * 16;
             const unsigned char* wb = s_w + (t % 3) * Cfg::WSTEP_B + lane * 16;
 #pragma unroll
@@ -759,7 +770,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
             for (int i = 0; i < PT; ++i)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    fb[set][i][pl] = *reinterpret_cast<const bf16x8*>(s_in + pl * Cfg::PIECE_B + 2 * i * Cfg::ROW_B + lane_base + off);
+                    fb[set][i][pl] = *reinterpret_cast<const bf16x8*>(s_in + pl * Cfg::PIECE_B + 2 * Cfg::TILE_ROWS * i * Cfg::ROW_B + lane_base + off);
         };
         load_frags(0, 0);
 #pragma unroll
@@ -795,7 +806,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
     float fsum = 0.f, fsq = 0.f;          // this lane's 16 PT outputs in fp32; everything above that in float64
 #pragma unroll
     for (int i = 0; i < PT; ++i) {
-        const int oy = oy0 + PT * wave + i, ox = ox0 + j;
+        const int oy = oy0 + Cfg::TILE_ROWS * (PT * wave + i) + prow, ox = ox0 + pcol;
         const bool valid = oy < OH && ox < OH;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
@@ -841,7 +852,10 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
 }
 
 typedef BfCfg<16, 32, 5, 125, 61, l1b::NPART, true> Bf2;     // conv2: octet-planar in and out
-typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, false> Bf3;  // conv3: octet-planar in, NCHW out (layers 4-6 stay on the fp32 path)
+typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, true> Bf3;   // conv3: octet-planar in and out
+// conv4 (3x3, 29 -> 14): the whole 14 x 14 image is one workgroup tile of 16 x 16 (pixel tiles of 2 rows x 16 columns);
+// NCHW out: layers 5-6 stay on the fp32 path
+typedef BfCfg<64, 64, 3, 29, 14, Bf3::NPART_OUT, false, 2, 2, true> Bf4;
 
 template <class Cfg>
 static int launch_bf6(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
@@ -858,8 +872,7 @@ static int launch_bf6(const float* in, const GNStats* st_in, const float* g, con
 }
 
 // per-layer configurations            CIN COUT KS  IH  OH  TH  TW  S  CC NWP NWM NPW MTW NPART_IN
-typedef ConvCfg< 64,  64, 3,  29, 14, 14, 14,  1,  8,  4,  1,  2,  2, Bf3::NPART_OUT, 2> Cfg4;   // whole image (196 px), 4 waves, 1 WG / agent
-typedef ConvCfg< 64, 128, 3,  14,  6,  6,  6,  2,  8,  3,  2,  1,  1,  1> Cfg5;   // 2 agents (72 px) x 64 of 128 channels, 6 waves
+typedef ConvCfg< 64, 128, 3,  14,  6,  6,  6,  2,  8,  3,  2,  1,  1, Bf4::NPART_OUT> Cfg5;   // 2 agents (72 px) x 64 of 128 channels, 6 waves
 typedef ConvCfg<128, 128, 3,   6,  2,  2,  2,  8,  8,  1,  4,  1,  1,  2> Cfg6;   // 8 agents (32 px), 4 waves x 32 channels
 
 template <class Cfg>
@@ -953,9 +966,9 @@ static int cnn_chunk() {
     }
     return v;
 }
-constexpr int NPARTS[6] = {l1b::NPART, Bf2::NPART_OUT, Bf3::NPART_OUT, Cfg4::NPART_OUT, Cfg5::NPART_OUT, Cfg6::NPART_OUT};
-constexpr int STAT_SLOTS = l1b::NPART + Bf2::NPART_OUT + Bf3::NPART_OUT + Cfg4::NPART_OUT + Cfg5::NPART_OUT + Cfg6::NPART_OUT;
-static_assert(Cfg4::NPART_IN == Bf3::NPART_OUT && Cfg5::NPART_IN == Cfg4::NPART_OUT &&
+constexpr int NPARTS[6] = {l1b::NPART, Bf2::NPART_OUT, Bf3::NPART_OUT, Bf4::NPART_OUT, Cfg5::NPART_OUT, Cfg6::NPART_OUT};
+constexpr int STAT_SLOTS = l1b::NPART + Bf2::NPART_OUT + Bf3::NPART_OUT + Bf4::NPART_OUT + Cfg5::NPART_OUT + Cfg6::NPART_OUT;
+static_assert(Cfg5::NPART_IN == Bf4::NPART_OUT &&
               Cfg6::NPART_IN == Cfg5::NPART_OUT, "statistics slot chain");   // agents pushed through the layer stack together (keeps the working set L3-sized)
 
 size_t per_agent_floats() {
@@ -1016,7 +1029,7 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         }
         launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], n, stream);
         launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, stream);
-        launch_conv<Cfg4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w[3], cnn->b[3], act[3], st[3], n, stream);
+        launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, stream);
         launch_conv<Cfg5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w[4], cnn->b[4], act[4], st[4], n, stream);
         launch_conv<Cfg6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w[5], cnn->b[5], act[5], st[5], n, stream);
         hipLaunchKernelGGL(fc_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, act[5], st[5], cnn->gn_g[5], cnn->gn_b[5],
@@ -1094,7 +1107,7 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
         }
         case 1: launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, stream); break;
         case 2: launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, stream); break;
-        case 3: launch_conv<Cfg4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w[3], cnn->b[3], act[3], st[3], N, stream); break;
+        case 3: launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], N, stream); break;
         case 4: launch_conv<Cfg5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w[4], cnn->b[4], act[4], st[4], N, stream); break;
         case 5: launch_conv<Cfg6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w[5], cnn->b[5], act[5], st[5], N, stream); break;
         default:

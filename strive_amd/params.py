@@ -124,24 +124,31 @@ def _bf16_split3(w, what):
 BF6_PASS_CH = 8     # input channels staged per pass by conv_bf6_kernel (BfCfg::PASS_CH)
 
 
-def conv_tap_order():
-    """Window taps (ky, kx) held by lane halves h = 0, 1 of MFMA step s in conv_bf6_kernel: steps 0-9 = row s // 2,
-    columns (s & 1) + 2h; steps 10-11 = column 4 of rows 2 (s - 10) + h; step 12 = (4, 4) and a zero slot (None)."""
-    order = [[(s_ >> 1, (s_ & 1) + 2 * h) for h in range(2)] for s_ in range(10)]
-    order += [[(0, 4), (1, 4)], [(2, 4), (3, 4)], [(4, 4), None]]
+def conv_tap_order(k=5):
+    """Window taps (ky, kx) held by lane halves h = 0, 1 of MFMA step s in conv_bf6_kernel (None = zero-weight slot).
+    5x5: steps 0-9 = row s // 2, columns (s & 1) + 2h; steps 10-11 = column 4 of rows 2 (s - 10) + h; step 12 = (4, 4).
+    3x3: steps 0-2 = row s, columns 0 and 2; step 3 = column 1 of rows 0, 1; step 4 = (2, 1)."""
+    if k == 5:
+        order = [[(s_ >> 1, (s_ & 1) + 2 * h) for h in range(2)] for s_ in range(10)]
+        order += [[(0, 4), (1, 4)], [(2, 4), (3, 4)], [(4, 4), None]]
+    elif k == 3:
+        order = [[(s_, 0), (s_, 2)] for s_ in range(3)]
+        order += [[(0, 1), (1, 1)], [(2, 1), None]]
+    else:
+        raise NotImplementedError('conv_bf6_kernel has tap orders for 5x5 and 3x3 windows')
     return order
 
 
 def _conv_bf6_fragments(w, pass_ch=BF6_PASS_CH):
-    """(co, ci, 5, 5) fp32 -> int32 tensor [pass = ci/8][step 13][co/32][piece 3][lane 64][8 x bf16]: the exact three-way
-    bf16 split of every weight in the k order of conv_bf6_kernel (lane = 32 h + output channel % 32, element e = input
-    channel 8 pass + e, window tap = conv_tap_order()[step][h])."""
+    """(co, ci, k, k) fp32, k = 5 or 3 -> int32 tensor [pass = ci/8][step][co/32][piece 3][lane 64][8 x bf16]: the exact
+    three-way bf16 split of every weight in the k order of conv_bf6_kernel (lane = 32 h + output channel % 32, element e =
+    input channel 8 pass + e, window tap = conv_tap_order(k)[step][h])."""
     co, ci, k, _ = w.shape
-    if k != 5 or pass_ch != 8:
-        raise NotImplementedError('conv_bf6_kernel is written for 5x5 windows staged 8 channels at a time')
+    if pass_ch != 8:
+        raise NotImplementedError('conv_bf6_kernel stages 8 channels at a time')
     pieces = _bf16_split3(w, 'conv').permute(0, 1, 3, 4, 2).contiguous()      # (3, co, ky, kx, ci)
     npass, csplit = ci // pass_ch, co // 32
-    order = conv_tap_order()
+    order = conv_tap_order(k)
     out = torch.zeros((npass, len(order), csplit, 3, 2, 32, 8), dtype=torch.bfloat16, device=w.device)
     for p_ in range(npass):
         for s_, taps in enumerate(order):
@@ -173,6 +180,7 @@ def _fill_cnn(s, holder, sd):
     s.w1_frag = holder.hold(_conv1_fragments(_c(sd['map_conv.0.weight'])))
     s.w2_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.3.weight'])))
     s.w3_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.6.weight'])))
+    s.w4_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.9.weight'])))
     fw = _c(sd['map_feature.weight'])
     if tuple(fw.shape) != (64, 512):
         raise NotImplementedError('map_feature must be Linear(512, 64)')
