@@ -851,11 +851,273 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
     }
 }
 
+// =============================================================================================
+// The same bf16 x 6 scheme for a SMALL image (conv5: 64 -> 128 channels, 3x3, 14 x 14 -> 6 x 6): a workgroup takes S whole
+// samples, the 32-pixel MFMA tiles are filled with the linearised pixels (sample, y, x) of those samples (S = 7: 252 of
+// 256 lanes carry a pixel), and every lane keeps the LDS offset of its own window origin.  Input octet-planar, the 8
+// channels of a pass for all S samples staged together ([piece][sample][row][parity][column/2][8 x bf16]); GroupNorm
+// scale / shift per (sample, channel); output statistics per sample reduced in pixel order through LDS.
+// =============================================================================================
+template <int CIN_, int COUT_, int IH_, int OH_, int S_, int NPART_IN_, bool OUT_OCT_>
+struct BfsCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, KS = 3, IH = IH_, OH = OH_, S = S_, NPART_IN = NPART_IN_;
+    static constexpr bool OUT_OCT = OUT_OCT_;
+    static constexpr int NT = 256, NW = 4, PT = 2;
+    static constexpr int PPS = OH * OH, NPIX = S * PPS;                    // pixels per sample / per workgroup
+    static constexpr int COUT_WG = 32, CSPLIT = COUT / COUT_WG;
+    static constexpr int PASS_CH = 8, NPASS = CIN / PASS_CH;
+    static constexpr int HW = (IH + 1) / 2, HALF_B = HW * 16, ROW_B = 2 * HALF_B, SAMPLE_B = IH * ROW_B, PIECE_B = S * SAMPLE_B;
+    static constexpr int IN_B = (3 * PIECE_B + 255) / 256 * 256;
+    static constexpr int NKS = (KS * KS + 1) / 2;
+    static constexpr int WSTEP_B = 3 * 64 * 16;
+    static constexpr int NPART_OUT = CSPLIT;
+    static constexpr int UNITS = S * IH * IH, UITERS = (UNITS + NT - 1) / NT;
+    static constexpr size_t LDS_BYTES = (size_t)IN_B + 3 * WSTEP_B + (size_t)S * CIN * 8 + S * 8 + 16;
+    static_assert(NW * PT * 64 * 8 <= IN_B, "the epilogue's partial sums reuse the input tile");
+    static_assert(NPIX <= NW * PT * 32, "pixel tiles of the workgroup");
+    static_assert(CIN % PASS_CH == 0 && COUT % COUT_WG == 0, "channel tiling");
+    static_assert(LDS_BYTES * 2 <= 160 * 1024, "two workgroups per CU");
+    static_assert(2 * (OH - 1) + KS <= IH, "valid convolution");
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6s_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
+                                                                 const float* __restrict__ gn_g, const float* __restrict__ gn_b,
+                                                                 const uint32_t* __restrict__ wfrag, const float* __restrict__ bias,
+                                                                 float* __restrict__ out, GNStats* __restrict__ st_out, int N) {
+    constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, IH = Cfg::IH, OH = Cfg::OH, NT = Cfg::NT, S = Cfg::S, PT = Cfg::PT;
+    HIP_DYNAMIC_SHARED(float, smem)
+    unsigned char* s_in = reinterpret_cast<unsigned char*>(smem);
+    unsigned char* s_w = s_in + Cfg::IN_B;
+    float* s_gn = (float*)(s_w + 3 * Cfg::WSTEP_B);              // [S][CIN][2] scale, shift
+    float* s_mr = s_gn + S * CIN * 2;                             // [S][2] mean, rstd
+    float* s_part = reinterpret_cast<float*>(s_in);               // [NW*PT*64][2] per-lane partial sums (epilogue: the tile is dead)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int cb = blockIdx.x % Cfg::CSPLIT;
+    const int n0 = (blockIdx.x / Cfg::CSPLIT) * S;
+
+    // ---- raw input loads of pass 0 first ----
+    float4 raw[Cfg::UITERS][2];
+    auto issue_loads = [&](int pass) {
+#pragma unroll
+        for (int k = 0; k < Cfg::UITERS; ++k) {
+            const int idx = tid + k * NT;
+            raw[k][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            raw[k][1] = raw[k][0];
+            if (idx < Cfg::UNITS) {
+                const int a = idx / (IH * IH), r = idx - a * (IH * IH);
+                if (n0 + a < N) {
+                    const float4* src = reinterpret_cast<const float4*>(in + ((((size_t)(n0 + a) * (CIN / 8) + pass) * IH * IH) + r) * 8);
+                    raw[k][0] = src[0];
+                    raw[k][1] = src[1];
+                }
+            }
+        }
+    };
+    issue_loads(0);
+    float4 bias4[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) bias4[rg] = *reinterpret_cast<const float4*>(bias + cb * Cfg::COUT_WG + 8 * rg + 4 * h);
+
+    // ---- GroupNorm moments per sample (partials added in slot order), then scale / shift per (sample, channel) ----
+    if (tid < S) {
+        float mean = 0.f, rstd = 0.f;
+        if (n0 + tid < N) gn_moments(st_in, n0 + tid, Cfg::NPART_IN, (double)CIN * IH * IH, mean, rstd);
+        s_mr[2 * tid] = mean;
+        s_mr[2 * tid + 1] = rstd;
+    }
+    __syncthreads();
+    for (int i = tid; i < S * CIN; i += NT) {
+        const int a = i / CIN, c = i - a * CIN;
+        const float sc = s_mr[2 * a + 1] * gn_g[c];
+        s_gn[2 * i] = sc;
+        s_gn[2 * i + 1] = gn_b[c] - s_mr[2 * a] * sc;
+    }
+
+    // ---- this lane's pixels: tile i of the wave holds linear pixels 32 (PT wave + i) + j ----
+    int lane_base[PT];
+    int pix_a[PT], pix_q[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        int g = 32 * (PT * wave + i) + j;
+        const bool live = g < Cfg::NPIX;
+        g = live ? g : 0;
+        const int a = g / Cfg::PPS, q = g - a * Cfg::PPS;
+        const int oy = q / OH, ox = q - oy * OH;
+        pix_a[i] = live ? a : -1;
+        pix_q[i] = q;
+        lane_base[i] = a * Cfg::SAMPLE_B + (2 * oy) * Cfg::ROW_B + ox * 16;
+    }
+    f32x16 acc[PT];
+#pragma unroll
+    for (int i = 0; i < PT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const uint4* wsrc = reinterpret_cast<const uint4*>(wfrag);
+    constexpr int WQ = Cfg::WSTEP_B / 16;
+    auto wstep_src = [&](int pass, int s) { return wsrc + ((size_t)(pass * Cfg::NKS + s) * Cfg::CSPLIT + cb) * WQ; };
+    const bool wmover = tid < WQ;
+
+    for (int pass = 0; pass < Cfg::NPASS; ++pass) {
+        uint4 wq[Cfg::NKS];
+#pragma unroll
+        for (int t = 0; t < Cfg::NKS; ++t) wq[t] = make_uint4(0u, 0u, 0u, 0u);
+        if (wmover) {
+#pragma unroll
+            for (int t = 0; t < Cfg::NKS; ++t) wq[t] = wstep_src(pass, t)[tid];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < Cfg::UITERS; ++k) {
+            const int idx = tid + k * NT;
+            if (idx < Cfg::UNITS) {
+                const int a = idx / (IH * IH), r = idx - a * (IH * IH);
+                const int row = r / IH, col = r - row * IH;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                if (n0 + a < N) {
+                    const float4 x0 = raw[k][0], x1 = raw[k][1];
+                    const float4* gn = reinterpret_cast<const float4*>(s_gn + 2 * (a * CIN + pass * Cfg::PASS_CH));
+                    const float4 g0 = gn[0], g1 = gn[1], g2 = gn[2], g3 = gn[3];
+                    v[0] = fmaxf(fmaf(x0.x, g0.x, g0.y), 0.f);
+                    v[1] = fmaxf(fmaf(x0.y, g0.z, g0.w), 0.f);
+                    v[2] = fmaxf(fmaf(x0.z, g1.x, g1.y), 0.f);
+                    v[3] = fmaxf(fmaf(x0.w, g1.z, g1.w), 0.f);
+                    v[4] = fmaxf(fmaf(x1.x, g2.x, g2.y), 0.f);
+                    v[5] = fmaxf(fmaf(x1.y, g2.z, g2.w), 0.f);
+                    v[6] = fmaxf(fmaf(x1.z, g3.x, g3.y), 0.f);
+                    v[7] = fmaxf(fmaf(x1.w, g3.z, g3.w), 0.f);
+                }
+                uint4 p0, p1, p2;
+                split_bf16x3(v, p0, p1, p2);
+                unsigned char* dst = s_in + a * Cfg::SAMPLE_B + row * Cfg::ROW_B + (col & 1) * Cfg::HALF_B + (col >> 1) * 16;
+                *reinterpret_cast<uint4*>(dst) = p0;
+                *reinterpret_cast<uint4*>(dst + Cfg::PIECE_B) = p1;
+                *reinterpret_cast<uint4*>(dst + 2 * Cfg::PIECE_B) = p2;
+            }
+        }
+        if (wmover) {
+            reinterpret_cast<uint4*>(s_w)[tid] = wq[0];
+            reinterpret_cast<uint4*>(s_w + Cfg::WSTEP_B)[tid] = wq[1];
+        }
+        __syncthreads();
+        if (pass + 1 < Cfg::NPASS) issue_loads(pass + 1);
+
+        bf16x8 fa[2][3], fb[2][PT][3];
+        auto load_frags = [&](int t, int set) {       // 3x3 tap order of conv_bf6_kernel
+            int ky, kx;
+            if (t < 3) { ky = t; kx = 2 * h; }
+            else if (t == 3) { ky = h; kx = 1; }
+            else { ky = 2; kx = 1; }
+            const int off = ky * Cfg::ROW_B + (kx & 1) * Cfg::HALF_B + (kx >> 1) * 16;
+            const unsigned char* wb = s_w + (t % 3) * Cfg::WSTEP_B + lane * 16;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fa[set][pl] = *reinterpret_cast<const bf16x8*>(wb + pl * 1024);
+#pragma unroll
+            for (int i = 0; i < PT; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    fb[set][i][pl] = *reinterpret_cast<const bf16x8*>(s_in + pl * Cfg::PIECE_B + lane_base[i] + off);
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int s = 0; s < Cfg::NKS; ++s) {
+            const int cur = s & 1;
+            if (s + 1 < Cfg::NKS) load_frags(s + 1, cur ^ 1);
+            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int i = 0; i < PT; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][TA[term]], fb[cur][i][TB[term]], acc[i], 0, 0, 0);
+            if (s + 1 < Cfg::NKS) {
+#pragma unroll
+                for (int q = 0; q < 3 + 3 * PT; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 6 * PT - (3 + 3 * PT), 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 2 < Cfg::NKS && wmover) reinterpret_cast<uint4*>(s_w + ((s + 2) % 3) * Cfg::WSTEP_B)[tid] = wq[s + 2];
+            if (s + 1 < Cfg::NKS) __syncthreads();
+        }
+    }
+
+    // ---- epilogue: D column = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel within the block ----
+    __syncthreads();            // every wave has read its last fragments: the input tile becomes the partial-sum scratch
+#pragma unroll
+    for (int i = 0; i < PT; ++i) {
+        const int a = pix_a[i], q = pix_q[i];
+        const bool valid = a >= 0 && n0 + a < N;
+        const int n = n0 + (a < 0 ? 0 : a);
+        float fsum = 0.f, fsq = 0.f;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int co = cb * Cfg::COUT_WG + 8 * rg + 4 * h;
+            const float4 bv = bias4[rg];
+            float4 v;
+            v.x = acc[i][4 * rg + 0] + bv.x;
+            v.y = acc[i][4 * rg + 1] + bv.y;
+            v.z = acc[i][4 * rg + 2] + bv.z;
+            v.w = acc[i][4 * rg + 3] + bv.w;
+            if (valid) {
+                if (Cfg::OUT_OCT) {
+                    *reinterpret_cast<float4*>(out + (((size_t)n * (COUT / 8) + (co >> 3)) * Cfg::PPS + q) * 8 + (co & 7)) = v;
+                } else {
+                    float* o = out + ((size_t)n * COUT + co) * Cfg::PPS + q;
+                    o[0] = v.x;
+                    o[(size_t)Cfg::PPS] = v.y;
+                    o[(size_t)2 * Cfg::PPS] = v.z;
+                    o[(size_t)3 * Cfg::PPS] = v.w;
+                }
+                fsum += (v.x + v.y) + (v.z + v.w);
+                fsq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fsq))));
+            }
+        }
+        // slot = (linear pixel, channel half): the per-sample reduction below walks them in a fixed order
+        const int slot = (32 * (PT * wave + i) + j) * 2 + h;
+        s_part[2 * slot] = valid ? fsum : 0.f;
+        s_part[2 * slot + 1] = valid ? fsq : 0.f;
+    }
+    __syncthreads();
+    if (tid < S && n0 + tid < N) {
+        double a = 0.0, b = 0.0;
+        for (int q = 0; q < Cfg::PPS; ++q)
+            for (int hh = 0; hh < 2; ++hh) {
+                const int slot = ((tid * Cfg::PPS + q) * 2 + hh);
+                a += (double)s_part[2 * slot];
+                b += (double)s_part[2 * slot + 1];
+            }
+        GNStats& o = st_out[(size_t)(n0 + tid) * Cfg::NPART_OUT + cb];
+        o.sum = a;
+        o.sq = b;
+    }
+}
+
+template <class Cfg>
+static int launch_bf6s(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
+                       const float* bias, float* out, GNStats* st_out, int N, hipStream_t stream) {
+    dim3 grid(((N + Cfg::S - 1) / Cfg::S) * Cfg::CSPLIT);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_bf6s_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_bf6s_kernel<Cfg>, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out,
+                       st_out, N);
+    return 0;
+}
+
 typedef BfCfg<16, 32, 5, 125, 61, l1b::NPART, true> Bf2;     // conv2: octet-planar in and out
 typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, true> Bf3;   // conv3: octet-planar in and out
 // conv4 (3x3, 29 -> 14): the whole 14 x 14 image is one workgroup tile of 16 x 16 (pixel tiles of 2 rows x 16 columns);
-// NCHW out: layers 5-6 stay on the fp32 path
-typedef BfCfg<64, 64, 3, 29, 14, Bf3::NPART_OUT, false, 2, 2, true> Bf4;
+typedef BfCfg<64, 64, 3, 29, 14, Bf3::NPART_OUT, true, 2, 2, true> Bf4;
+typedef BfsCfg<64, 128, 14, 6, 7, Bf4::NPART_OUT, false> Bfs5;      // conv5: 7 samples (252 pixels) x 32 channels per workgroup
 
 template <class Cfg>
 static int launch_bf6(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
@@ -872,8 +1134,7 @@ static int launch_bf6(const float* in, const GNStats* st_in, const float* g, con
 }
 
 // per-layer configurations            CIN COUT KS  IH  OH  TH  TW  S  CC NWP NWM NPW MTW NPART_IN
-typedef ConvCfg< 64, 128, 3,  14,  6,  6,  6,  2,  8,  3,  2,  1,  1, Bf4::NPART_OUT> Cfg5;   // 2 agents (72 px) x 64 of 128 channels, 6 waves
-typedef ConvCfg<128, 128, 3,   6,  2,  2,  2,  8,  8,  1,  4,  1,  1,  2> Cfg6;   // 8 agents (32 px), 4 waves x 32 channels
+typedef ConvCfg<128, 128, 3,   6,  2,  2,  2,  8,  8,  1,  4,  1,  1, Bfs5::NPART_OUT> Cfg6;   // 8 agents (32 px), 4 waves x 32 channels
 
 template <class Cfg>
 static int launch_conv(const float* in, const GNStats* st_in, const float* g, const float* b, const float* w,
@@ -966,10 +1227,10 @@ static int cnn_chunk() {
     }
     return v;
 }
-constexpr int NPARTS[6] = {l1b::NPART, Bf2::NPART_OUT, Bf3::NPART_OUT, Bf4::NPART_OUT, Cfg5::NPART_OUT, Cfg6::NPART_OUT};
-constexpr int STAT_SLOTS = l1b::NPART + Bf2::NPART_OUT + Bf3::NPART_OUT + Bf4::NPART_OUT + Cfg5::NPART_OUT + Cfg6::NPART_OUT;
-static_assert(Cfg5::NPART_IN == Bf4::NPART_OUT &&
-              Cfg6::NPART_IN == Cfg5::NPART_OUT, "statistics slot chain");   // agents pushed through the layer stack together (keeps the working set L3-sized)
+constexpr int NPARTS[6] = {l1b::NPART, Bf2::NPART_OUT, Bf3::NPART_OUT, Bf4::NPART_OUT, Bfs5::NPART_OUT, Cfg6::NPART_OUT};
+constexpr int STAT_SLOTS = l1b::NPART + Bf2::NPART_OUT + Bf3::NPART_OUT + Bf4::NPART_OUT + Bfs5::NPART_OUT + Cfg6::NPART_OUT;
+static_assert(Bfs5::NPART_IN == Bf4::NPART_OUT &&
+              Cfg6::NPART_IN == Bfs5::NPART_OUT, "statistics slot chain");   // agents pushed through the layer stack together (keeps the working set L3-sized)
 
 size_t per_agent_floats() {
     size_t t = 0;
@@ -1030,7 +1291,7 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], n, stream);
         launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, stream);
         launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, stream);
-        launch_conv<Cfg5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w[4], cnn->b[4], act[4], st[4], n, stream);
+        launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], n, stream);
         launch_conv<Cfg6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w[5], cnn->b[5], act[5], st[5], n, stream);
         hipLaunchKernelGGL(fc_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, act[5], st[5], cnn->gn_g[5], cnn->gn_b[5],
                            cnn->fc_wt, cnn->fc_b, feat + (size_t)n0 * 64, n);
@@ -1108,7 +1369,7 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
         case 1: launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, stream); break;
         case 2: launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, stream); break;
         case 3: launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], N, stream); break;
-        case 4: launch_conv<Cfg5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w[4], cnn->b[4], act[4], st[4], N, stream); break;
+        case 4: launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], N, stream); break;
         case 5: launch_conv<Cfg6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w[5], cnn->b[5], act[5], st[5], N, stream); break;
         default:
             hipLaunchKernelGGL(fc_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, act[5], st[5], cnn->gn_g[5], cnn->gn_b[5],

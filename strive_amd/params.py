@@ -181,6 +181,7 @@ def _fill_cnn(s, holder, sd):
     s.w2_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.3.weight'])))
     s.w3_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.6.weight'])))
     s.w4_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.9.weight'])))
+    s.w5_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.12.weight'])))
     fw = _c(sd['map_feature.weight'])
     if tuple(fw.shape) != (64, 512):
         raise NotImplementedError('map_feature must be Linear(512, 64)')

@@ -245,3 +245,26 @@ def test_rect_iou_kernel(emu):
     np.testing.assert_allclose(out.numpy()[ok], want[ok], rtol=0, atol=1e-12)
     assert abs(out[0].item() - 1.0) < 1e-12 and out[1].item() == 0.0
     assert (want[ok] > 0.02).sum() > 10 and (want[ok] == 0).sum() > 10      # both outcomes are exercised
+
+
+def test_map_cnn_eight_agents(emu, sd):
+    """Eight agents: conv5's workgroups take 7 samples each (one full, one with a single sample), conv6 / fc take 8 / 4."""
+    raster, dx, frame, mapixes, lw = mg.g2_inputs()
+    env = synth.SyntheticMapEnv(raster, dx)
+    n = 8
+    fr = np.zeros((n, 4))
+    fr[:, 0] = synth.counter_uniform((n,), 'e8/x', 40.0, 200.0)
+    fr[:, 1] = synth.counter_uniform((n,), 'e8/y', 40.0, 200.0)
+    ang = synth.counter_uniform((n,), 'e8/h', -np.pi, np.pi)
+    fr[:, 2], fr[:, 3] = np.cos(ang), np.sin(ang)
+    fr = synth.f32(fr).contiguous()
+    mi = torch.tensor([i % 2 for i in range(n)], dtype=torch.int32)
+    crop = mapenv.map_crop(raster, dx, fr, mi.long(), env.bounds)
+    want = om.map_cnn(sd, crop.float())
+    cnn, mp = params.pack_cnn(sd), params.pack_map(env, 'cpu')
+    wsb = emu.query('strive_map_cnn_workspace_bytes', n)
+    ws = torch.zeros(wsb, dtype=torch.uint8)
+    feat = torch.zeros((n, 64))
+    emu.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(fr), L.f4([0] * 4), L.f4([1] * 4), L.ptr(mi), n, L.ptr(feat),
+             L.ptr(ws), wsb, None)
+    assert_close(feat, want, 1e-4, 1e-5, 'cnn x8')
