@@ -33,13 +33,13 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, den
 CONV_FLOPS = [2 * 16 * 125 * 125 * 4 * 49, 2 * 32 * 61 * 61 * 16 * 25, 2 * 64 * 29 * 29 * 32 * 25,
               2 * 64 * 14 * 14 * 64 * 9, 2 * 128 * 6 * 6 * 64 * 9, 2 * 128 * 2 * 2 * 128 * 9]
 CONV_NAMES = ['conv1b_kernel<true> (fused crop -> conv1)', 'conv_bf6_kernel<conv2>', 'conv_bf6_kernel<conv3>',
-              'conv_bf6_kernel<conv4>', 'conv_mfma_kernel<conv5>', 'conv_mfma_kernel<conv6>']
+              'conv_bf6_kernel<conv4>', 'conv_bf6s_kernel<conv5>', 'conv_bf6s_kernel<conv6>']
 # matrix-core work actually issued per algorithmic FLOP and the dense peak it runs against
 # (/opt/skills/guides/MI355X_MICROARCH.md: bf16 dense 2516 TFLOP/s, f32 157.3): conv1 = 3 exact bf16 weight pieces,
-# conv2-conv4 = 6 bf16 products per fp32 product, conv5-6 = the f32 matrix instruction
+# conv2-conv6 = 6 bf16 products per fp32 product
 PEAK_BF16_MFMA_TFLOPS = 2516.0
 CONV_ISSUE = [(3, PEAK_BF16_MFMA_TFLOPS, 'bf16'), (6, PEAK_BF16_MFMA_TFLOPS, 'bf16'), (6, PEAK_BF16_MFMA_TFLOPS, 'bf16'),
-              (6, PEAK_BF16_MFMA_TFLOPS, 'bf16'), (1, PEAK_FP32_MFMA_TFLOPS, 'f32'), (1, PEAK_FP32_MFMA_TFLOPS, 'f32')]
+              (6, PEAK_BF16_MFMA_TFLOPS, 'bf16'), (6, PEAK_BF16_MFMA_TFLOPS, 'bf16'), (6, PEAK_BF16_MFMA_TFLOPS, 'bf16')]
 
 REFINE_WEIGHTS = {'coll_veh': 100.0, 'coll_env': 100.0, 'init_z': 0.01, 'motion_prior': 1.0}   # refine_traffic_optim.cfg:26-29
 
@@ -236,7 +236,7 @@ def main():
                                '%d scenes x %d agents per GPU (BASELINE.json configs[1])' % (args.ft, args.scenes, args.agents),
                    'agents_per_gpu': NA, 'FT': args.ft, 'raster': '%dx%d x4 uint8 @0.25 m' % (args.raster, args.raster),
                    'parallelism': 'scene-sharded replicas x%d' % world,
-                   'arithmetic': 'fp32 everywhere; conv1-4 on bf16 matrix cores with exact 3-way operand splits, fp32 accumulate'},
+                   'arithmetic': 'fp32 everywhere; the map CNN on bf16 matrix cores with exact 3-way operand splits, fp32 accumulate'},
         'final_loss': float(loss.detach().cpu()),
     }
     if rank == 0:

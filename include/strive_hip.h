@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define STRIVE_ABI_VERSION 4
+#define STRIVE_ABI_VERSION 5
 #define STRIVE_HID 128        /* hidden width of every MLP in the reference (models/common.py, interaction_net.py:32,41) */
 #define STRIVE_MAX_LAYERS 4
 #define STRIVE_ZDIM 32
@@ -106,12 +106,13 @@ typedef struct StriveCNN {
                                   lane group g = lane/16, output channel = lane%16; 21504 bytes */
     const uint32_t* w2_frag;   /* layer-1 (16->32, 5x5), layer-2 (32->64, 5x5) and layer-3 (64->64, 3x3) weights, each split exactly */
     const uint32_t* w3_frag;   /* into three bf16 pieces, in the fragment order of conv_bf6_kernel: [pass = ci/8][step s][co/32] */
-    const uint32_t* w4_frag;   /* (w5_frag: layer-4, 64->128, 3x3, same format)  [piece 3][lane 64][8 x bf16]; lane half h = lane/32 holds one window tap of the step, element
+    const uint32_t* w4_frag;   /* (w5_frag, w6_frag: layers 4 and 5, 64->128 and 128->128, 3x3, same format)  [piece 3][lane 64][8 x bf16]; lane half h = lane/32 holds one window tap of the step, element
                                   e = input channel 8*pass + e, output channel = 32*(co/32) + lane%32.
                                   5x5 (13 steps): tap (s/2, (s&1)+2h) for s < 10, (2(s-10)+h, 4) for s = 10, 11, (4, 4) or zero
                                   for s = 12.  3x3 (5 steps): (s, 2h) for s < 3, (h, 1) for s = 3, (2, 1) or zero for s = 4.
-                                  79872 / 319488 / 245760 / 491520 bytes */
+                                  79872 / 319488 / 245760 / 491520 / 983040 bytes */
     const uint32_t* w5_frag;
+    const uint32_t* w6_frag;
 } StriveCNN;
 
 /* Scene structure of a batch: agents of scene b are rows ptr[b] .. ptr[b+1]-1, ego first

@@ -6,8 +6,8 @@
 //     D[co][pixel] += W[co][k] * patch[k][pixel]
 // with A = weights (M = output channels) and B = input patches (N = output pixels):
 //   layer 1 (u8 crop, Cout 16):  v_mfma_f32_16x16x32_bf16, weights split exactly into 3 bf16 pieces (exact fp32 result)
-//   layers 2-4 (fp32 in):        v_mfma_f32_32x32x16_bf16, both operands split exactly into 3 bf16 pieces, 6 products
-//   layers 5-6 (fp32 NCHW in):   v_mfma_f32_32x32x2_f32 (exact fp32, = an fmaf chain)
+//   layers 2-6 (fp32 in):        v_mfma_f32_32x32x16_bf16, both operands split exactly into 3 bf16 pieces, 6 products
+//                                (layers 5-6: several whole samples per workgroup)
 // Input tiles are staged once per workgroup into LDS with the previous layer's GroupNorm + ReLU applied
 // on the way in (so normalised activations never exist in HBM either); columns are stored
 // de-interleaved by parity so the stride-2 window reads of consecutive output pixels hit consecutive
@@ -251,281 +251,6 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
         GNStats& o = stats[(size_t)n * NPART + ty * TILES_X + (TILES_X - 1)];
         o.sum = a;
         o.sq = b;
-    }
-}
-
-// =============================================================================================
-// Layers 2-6: generic LDS-staged implicit GEMM on v_mfma_f32_32x32x2_f32.
-// A workgroup owns S samples x (TH x TW) output pixels (P = S*TH*TW, linearised) and all COUT channels;
-// waves form an NWP x NWM grid: wave (wp, wm) owns NPW pixel tiles of 32 and MTW channel tiles of 32.
-// Input channels are streamed through LDS in chunks of CC (even); k is ordered
-// (channel pair, ky, kx, parity) so the two 32-lane halves of a wave always read channel 2cp / 2cp+1
-// at the same window offset and every LDS address is lane_base + compile-time immediate.
-// =============================================================================================
-template <int CIN_, int COUT_, int KS_, int IH_, int OH_, int TH_, int TW_, int S_, int CC_, int NWP_, int NWM_, int NPW_,
-          int MTW_, int NPART_IN_, int MINW_ = 1>
-struct ConvCfg {
-    static constexpr int MINW = MINW_;               // __launch_bounds__ waves per SIMD (caps the register allocation)
-    static constexpr int NPART_IN = NPART_IN_;       // per-sample partial-statistics slots written by the producer
-    static constexpr int CIN = CIN_, COUT = COUT_, KS = KS_, IH = IH_, OH = OH_, TH = TH_, TW = TW_, S = S_, CC = CC_;
-    static constexpr int NWP = NWP_, NWM = NWM_, NPW = NPW_, MTW = MTW_;
-    static constexpr int NW = NWP * NWM, NT = NW * 64;
-    static constexpr int COUT_WG = NWM * MTW * 32;   // output channels owned by one workgroup
-    static constexpr int CSPLIT = COUT / COUT_WG;    // workgroups along the channel axis (grid.x = TILES_X * CSPLIT)
-    static constexpr int TILES_Y = (OH + TH - 1) / TH, TILES_X = (OH + TW - 1) / TW;
-    static constexpr int ITH = 2 * TH + KS - 2, ITW = 2 * TW + KS - 2;
-    static constexpr int HALFW = (ITW + 1) / 2;
-    // row stride == 8 (mod 16) floats: pixels one output row apart (2 input rows) are 16 banks apart
-    static constexpr int RS = ((2 * HALFW + 7) / 16) * 16 + 8;
-    static constexpr int PS = ITH * RS;            // per-channel plane
-    static constexpr int SS = CC * PS;             // per-sample block of a chunk
-    static constexpr int P = S * TH * TW;
-    static constexpr int NTILE = (P + 31) / 32;
-    static constexpr int WROWS = (CC / 2) * KS * KS * 2;        // (channel pair, ky, kx, parity) rows per chunk
-    static constexpr int WCH = WROWS * COUT_WG;                 // weight floats per chunk in LDS
-    static constexpr int IN_FLOATS = S * SS;
-    static constexpr int GN_FLOATS = S * CIN * 2;
-    static constexpr int NPART_OUT = TILES_X * TILES_Y * CSPLIT;
-    static constexpr int RED_DOUBLES = (S == 1) ? 2 * NW : 2 * NW * NPW * 64;
-    static constexpr size_t LDS_BYTES = (size_t)(IN_FLOATS + WCH + GN_FLOATS) * 4 + (size_t)RED_DOUBLES * 8 + 64 * 4;
-    static_assert(COUT % COUT_WG == 0, "channel tiling");
-    static_assert(NTILE <= NWP * NPW, "pixel tiling");
-    static_assert(CC % 2 == 0 && CIN % CC == 0, "channel chunking");
-    static_assert(RS >= 2 * HALFW, "row stride");
-    static_assert(S == 1 || (TILES_X == 1 && TILES_Y == 1), "multi-sample workgroups own whole images");
-};
-
-#define STAGE_UB 8   // independent global loads in flight per thread while staging
-
-template <class Cfg>
-__global__ __launch_bounds__(Cfg::NT, Cfg::MINW) void conv_mfma_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
-                                                             const float* __restrict__ gn_g, const float* __restrict__ gn_b,
-                                                             const float* __restrict__ wpk, const float* __restrict__ bias,
-                                                             float* __restrict__ out, GNStats* __restrict__ st_out, int N) {
-    constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, KS = Cfg::KS, IH = Cfg::IH, OH = Cfg::OH;
-    constexpr int TH = Cfg::TH, TW = Cfg::TW, S = Cfg::S, CC = Cfg::CC, RS = Cfg::RS, PS = Cfg::PS, SS = Cfg::SS;
-    constexpr int HALFW = Cfg::HALFW, ITH = Cfg::ITH, ITW = Cfg::ITW, NPW = Cfg::NPW, MTW = Cfg::MTW, P = Cfg::P;
-    constexpr int CW = Cfg::COUT_WG, NT = Cfg::NT;
-    HIP_DYNAMIC_SHARED(float, smem)
-    float* s_in = smem;
-    float* s_w = smem + Cfg::IN_FLOATS;
-    float* s_gn = s_w + Cfg::WCH;                     // [S][CIN][2] scale, shift
-    double* s_red = (double*)(s_gn + Cfg::GN_FLOATS);   // per-wave (S == 1) or per-lane (S > 1) partial sums
-    float* s_mr = (float*)(s_red + Cfg::RED_DOUBLES);   // [S][2] mean, rstd of the input samples (S <= 32)
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wp = wave % Cfg::NWP, wm = wave / Cfg::NWP;
-    const int half = lane >> 5, j = lane & 31;
-    const int n0 = blockIdx.z * S;
-    const int tile_x = blockIdx.x % Cfg::TILES_X, cb = blockIdx.x / Cfg::TILES_X;
-    const int c0 = cb * CW;                           // first output channel of this workgroup
-    const int oy0 = blockIdx.y * TH, ox0 = tile_x * TW;
-    const int iy0 = 2 * oy0, ix0 = 2 * ox0;
-
-    // ---- GroupNorm scale/shift of the producing layer, per (sample, channel) ----
-    const double cnt_in = (double)CIN * IH * IH;
-    if (tid < S) {
-        float mean = 0.f, rstd = 0.f;
-        if (n0 + tid < N) gn_moments(st_in, n0 + tid, Cfg::NPART_IN, cnt_in, mean, rstd);
-        s_mr[2 * tid] = mean;
-        s_mr[2 * tid + 1] = rstd;
-    }
-    __syncthreads();
-    for (int i = tid; i < S * CIN; i += NT) {
-        const int s = i / CIN, c = i - s * CIN;
-        const float sc = s_mr[2 * s + 1] * gn_g[c];
-        s_gn[2 * i] = sc;
-        s_gn[2 * i + 1] = gn_b[c] - s_mr[2 * s] * sc;
-    }
-
-    // ---- per-lane pixel bases ----
-    int pbase[NPW];
-    int ppix[NPW];
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-        const int tile = wp * NPW + i;
-        int p = tile * 32 + j;
-        ppix[i] = p;
-        if (p >= P) p = 0;
-        const int s = p / (TH * TW);
-        const int q = p - s * (TH * TW);
-        const int oy = q / TW, ox = q - oy * TW;
-        pbase[i] = s * SS + half * PS + (2 * oy) * RS + ox;
-    }
-
-    f32x16 acc[NPW][MTW];
-#pragma unroll
-    for (int i = 0; i < NPW; ++i)
-#pragma unroll
-        for (int m = 0; m < MTW; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
-
-    const int abase = half * CW + wm * MTW * 32 + j;
-    constexpr int TOTAL = S * CC * ITH * ITW;
-    constexpr int ITERS = (TOTAL + NT - 1) / NT;
-    constexpr int WQ = Cfg::WCH / 4;                  // float4 units of the weight chunk
-    constexpr int WITERS = (WQ + NT - 1) / NT;
-    constexpr int NCH = CIN / CC;
-
-    // Register-staged software pipeline: the global loads of chunk ch+1 are issued before the MFMA loop of
-    // chunk ch and only consumed (GroupNorm + ReLU applied, written to LDS) after it, so HBM/L2 latency hides
-    // under the matrix work instead of serialising with it.
-    float raw[ITERS];
-    float4 wreg[WITERS];
-
-    const float* in_wg = in + (size_t)n0 * CIN * IH * IH;   // this workgroup's first sample
-    const float* w_wg = wpk + c0;                           // this workgroup's channel slice
-    auto issue_loads = [&](int ch) {
-#pragma unroll
-        for (int k = 0; k < ITERS; ++k) {
-            const int idx = tid + k * NT;
-            raw[k] = 0.f;
-            if (idx < TOTAL) {
-                const int col = idx % ITW;
-                int t = idx / ITW;
-                const int r = t % ITH;
-                t /= ITH;
-                const int c = t % CC;
-                const int s = t / CC;
-                const int iy = iy0 + r, ix = ix0 + col;
-                if (n0 + s < N && iy < IH && ix < IH)
-                    raw[k] = in_wg[((s * CIN + ch * CC + c) * IH + iy) * IH + ix];   // 32-bit offset from a uniform base
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < WITERS; ++k) {
-            const int q = tid + k * NT;
-            wreg[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q < WQ) {
-                const int row = (q * 4) / CW, c = (q * 4) - row * CW;
-                wreg[k] = *reinterpret_cast<const float4*>(w_wg + (ch * Cfg::WROWS + row) * COUT + c);
-            }
-        }
-    };
-    auto write_lds = [&](int ch) {
-#pragma unroll
-        for (int k = 0; k < ITERS; ++k) {
-            const int idx = tid + k * NT;
-            if (idx < TOTAL) {
-                const int col = idx % ITW;
-                int t = idx / ITW;
-                const int r = t % ITH;
-                t /= ITH;
-                const int c = t % CC;
-                const int s = t / CC;
-                const int iy = iy0 + r, ix = ix0 + col;
-                const int ci = ch * CC + c;
-                float v = 0.f;                                   // exact zero outside the image / batch
-                if (n0 + s < N && iy < IH && ix < IH)
-                    v = fmaxf(fmaf(raw[k], s_gn[2 * (s * CIN + ci)], s_gn[2 * (s * CIN + ci) + 1]), 0.f);
-                s_in[s * SS + c * PS + r * RS + (col >> 1) + (col & 1) * HALFW] = v;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < WITERS; ++k) {
-            const int q = tid + k * NT;
-            if (q < WQ) *reinterpret_cast<float4*>(s_w + q * 4) = wreg[k];
-        }
-    };
-
-    issue_loads(0);
-    for (int ch = 0; ch < NCH; ++ch) {
-        __syncthreads();          // every wave is done reading the previous chunk (and s_gn is ready on ch == 0)
-        write_lds(ch);
-        __syncthreads();
-        if (ch + 1 < NCH) issue_loads(ch + 1);
-#pragma unroll
-        for (int cp = 0; cp < CC / 2; ++cp) {
-#pragma unroll
-            for (int ky = 0; ky < KS; ++ky) {
-#pragma unroll
-                for (int kx = 0; kx < KS; ++kx) {
-                    const int step = (cp * KS + ky) * KS + kx;
-                    float a[MTW], b[NPW];
-#pragma unroll
-                    for (int m = 0; m < MTW; ++m) a[m] = s_w[step * 2 * CW + abase + m * 32];
-                    const int off = cp * 2 * PS + ky * RS + (kx >> 1) + (kx & 1) * HALFW;
-#pragma unroll
-                    for (int i = 0; i < NPW; ++i) b[i] = s_in[pbase[i] + off];
-#pragma unroll
-                    for (int i = 0; i < NPW; ++i)
-#pragma unroll
-                        for (int m = 0; m < MTW; ++m)
-                            acc[i][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[i], acc[i][m], 0, 0, 0);
-                }
-            }
-        }
-    }
-
-    // ---- epilogue ----
-    // D layout: column = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel within the tile
-    double wsum = 0.0, wsq = 0.0;   // S == 1: this wave's running total
-#pragma unroll
-    for (int i = 0; i < NPW; ++i) {
-        const int p = ppix[i];
-        const bool pv = p < P;
-        const int pc = pv ? p : 0;
-        const int s = pc / (TH * TW);
-        const int q = pc - s * (TH * TW);
-        const int oy = oy0 + q / TW, ox = ox0 + q % TW;
-        const bool valid = pv && (n0 + s < N) && oy < OH && ox < OH;
-        double lsum = 0.0, lsq = 0.0;
-#pragma unroll
-        for (int m = 0; m < MTW; ++m) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = c0 + wm * MTW * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float v = acc[i][m][r] + bias[co];
-                if (valid) {
-                    out[(((size_t)(n0 + s) * COUT + co) * OH + oy) * OH + ox] = v;
-                    lsum += (double)v;
-                    lsq += (double)v * (double)v;
-                }
-            }
-        }
-        if (S == 1) {
-            wsum += lsum;
-            wsq += lsq;
-        } else {
-            s_red[2 * ((wave * NPW + i) * 64 + lane)] = valid ? lsum : 0.0;
-            s_red[2 * ((wave * NPW + i) * 64 + lane) + 1] = valid ? lsq : 0.0;
-        }
-    }
-    if (S == 1) {
-        wsum = wave_sum_d(wsum);
-        wsq = wave_sum_d(wsq);
-        if (lane == 0) { s_red[2 * wave] = wsum; s_red[2 * wave + 1] = wsq; }
-        __syncthreads();
-        if (tid == 0 && n0 < N) {
-            double a = 0.0, b = 0.0;
-            for (int w = 0; w < Cfg::NW; ++w) { a += s_red[2 * w]; b += s_red[2 * w + 1]; }
-            GNStats& o = st_out[(size_t)n0 * Cfg::NPART_OUT + (blockIdx.y * Cfg::TILES_X + tile_x) * Cfg::CSPLIT + cb];
-            o.sum = a;
-            o.sq = b;
-        }
-    } else {
-        __syncthreads();
-        // fixed-order reduction: thread s adds the slots whose pixel belongs to sample s
-        if (tid < S && n0 + tid < N) {
-            double a = 0.0, b = 0.0;
-            for (int w = 0; w < Cfg::NW; ++w) {
-                const int wpp = w % Cfg::NWP;
-                for (int i = 0; i < NPW; ++i) {
-                    const int tile = wpp * NPW + i;
-                    for (int l = 0; l < 64; ++l) {
-                        const int p = tile * 32 + (l & 31);
-                        if (p < P && p / (TH * TW) == tid) {
-                            a += s_red[2 * ((w * NPW + i) * 64 + l)];
-                            b += s_red[2 * ((w * NPW + i) * 64 + l) + 1];
-                        }
-                    }
-                }
-            }
-            GNStats& o = st_out[(size_t)(n0 + tid) * Cfg::NPART_OUT + cb];
-            o.sum = a;
-            o.sq = b;
-        }
     }
 }
 
@@ -852,17 +577,17 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
 }
 
 // =============================================================================================
-// The same bf16 x 6 scheme for a SMALL image (conv5: 64 -> 128 channels, 3x3, 14 x 14 -> 6 x 6): a workgroup takes S whole
-// samples, the 32-pixel MFMA tiles are filled with the linearised pixels (sample, y, x) of those samples (S = 7: 252 of
+// The same bf16 x 6 scheme for SMALL images (conv5: 64 -> 128 channels, 14 x 14 -> 6 x 6; conv6: 128 -> 128, 6 x 6 -> 2 x 2;
+// both 3x3): a workgroup takes S whole samples, the 32-pixel MFMA tiles are filled with the linearised pixels (sample, y, x) of those samples (S = 7: 252 of
 // 256 lanes carry a pixel), and every lane keeps the LDS offset of its own window origin.  Input octet-planar, the 8
 // channels of a pass for all S samples staged together ([piece][sample][row][parity][column/2][8 x bf16]); GroupNorm
 // scale / shift per (sample, channel); output statistics per sample reduced in pixel order through LDS.
 // =============================================================================================
-template <int CIN_, int COUT_, int IH_, int OH_, int S_, int NPART_IN_, bool OUT_OCT_>
+template <int CIN_, int COUT_, int IH_, int OH_, int S_, int NPART_IN_, bool OUT_OCT_, int PT_ = 2>
 struct BfsCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, KS = 3, IH = IH_, OH = OH_, S = S_, NPART_IN = NPART_IN_;
     static constexpr bool OUT_OCT = OUT_OCT_;
-    static constexpr int NT = 256, NW = 4, PT = 2;
+    static constexpr int NT = 256, NW = 4, PT = PT_;
     static constexpr int PPS = OH * OH, NPIX = S * PPS;                    // pixels per sample / per workgroup
     static constexpr int COUT_WG = 32, CSPLIT = COUT / COUT_WG;
     static constexpr int PASS_CH = 8, NPASS = CIN / PASS_CH;
@@ -872,7 +597,7 @@ struct BfsCfg {
     static constexpr int WSTEP_B = 3 * 64 * 16;
     static constexpr int NPART_OUT = CSPLIT;
     static constexpr int UNITS = S * IH * IH, UITERS = (UNITS + NT - 1) / NT;
-    static constexpr size_t LDS_BYTES = (size_t)IN_B + 3 * WSTEP_B + (size_t)S * CIN * 8 + S * 8 + 16;
+    static constexpr size_t LDS_BYTES = (size_t)IN_B + 3 * WSTEP_B + (size_t)CIN * 8 + S * 8 + 16;
     static_assert(NW * PT * 64 * 8 <= IN_B, "the epilogue's partial sums reuse the input tile");
     static_assert(NPIX <= NW * PT * 32, "pixel tiles of the workgroup");
     static_assert(CIN % PASS_CH == 0 && COUT % COUT_WG == 0, "channel tiling");
@@ -889,8 +614,8 @@ __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6s_kernel(const float* __re
     HIP_DYNAMIC_SHARED(float, smem)
     unsigned char* s_in = reinterpret_cast<unsigned char*>(smem);
     unsigned char* s_w = s_in + Cfg::IN_B;
-    float* s_gn = (float*)(s_w + 3 * Cfg::WSTEP_B);              // [S][CIN][2] scale, shift
-    float* s_mr = s_gn + S * CIN * 2;                             // [S][2] mean, rstd
+    float* s_gb = (float*)(s_w + 3 * Cfg::WSTEP_B);              // [CIN][2] GroupNorm gamma, beta
+    float* s_mr = s_gb + CIN * 2;                                 // [S][2] mean, rstd of the input samples
     float* s_part = reinterpret_cast<float*>(s_in);               // [NW*PT*64][2] per-lane partial sums (epilogue: the tile is dead)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -928,12 +653,9 @@ __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6s_kernel(const float* __re
         s_mr[2 * tid] = mean;
         s_mr[2 * tid + 1] = rstd;
     }
-    __syncthreads();
-    for (int i = tid; i < S * CIN; i += NT) {
-        const int a = i / CIN, c = i - a * CIN;
-        const float sc = s_mr[2 * a + 1] * gn_g[c];
-        s_gn[2 * i] = sc;
-        s_gn[2 * i + 1] = gn_b[c] - s_mr[2 * a] * sc;
+    for (int c = tid; c < CIN; c += NT) {
+        s_gb[2 * c] = gn_g[c];
+        s_gb[2 * c + 1] = gn_b[c];
     }
 
     // ---- this lane's pixels: tile i of the wave holds linear pixels 32 (PT wave + i) + j ----
@@ -981,16 +703,17 @@ __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6s_kernel(const float* __re
                 for (int e = 0; e < 8; ++e) v[e] = 0.f;
                 if (n0 + a < N) {
                     const float4 x0 = raw[k][0], x1 = raw[k][1];
-                    const float4* gn = reinterpret_cast<const float4*>(s_gn + 2 * (a * CIN + pass * Cfg::PASS_CH));
-                    const float4 g0 = gn[0], g1 = gn[1], g2 = gn[2], g3 = gn[3];
-                    v[0] = fmaxf(fmaf(x0.x, g0.x, g0.y), 0.f);
-                    v[1] = fmaxf(fmaf(x0.y, g0.z, g0.w), 0.f);
-                    v[2] = fmaxf(fmaf(x0.z, g1.x, g1.y), 0.f);
-                    v[3] = fmaxf(fmaf(x0.w, g1.z, g1.w), 0.f);
-                    v[4] = fmaxf(fmaf(x1.x, g2.x, g2.y), 0.f);
-                    v[5] = fmaxf(fmaf(x1.y, g2.z, g2.w), 0.f);
-                    v[6] = fmaxf(fmaf(x1.z, g3.x, g3.y), 0.f);
-                    v[7] = fmaxf(fmaf(x1.w, g3.z, g3.w), 0.f);
+                    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    const float mean = s_mr[2 * a], rstd = s_mr[2 * a + 1];
+                    const float4* gb = reinterpret_cast<const float4*>(s_gb + 2 * pass * Cfg::PASS_CH);
+                    const float4 q0 = gb[0], q1 = gb[1], q2 = gb[2], q3 = gb[3];
+                    const float gam[8] = {q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, q3.x, q3.z};
+                    const float bet[8] = {q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, q3.y, q3.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float sc = rstd * gam[e];                    // scale / shift exactly as the other conv kernels form them
+                        v[e] = fmaxf(fmaf(x[e], sc, bet[e] - mean * sc), 0.f);
+                    }
                 }
                 uint4 p0, p1, p2;
                 split_bf16x3(v, p0, p1, p2);
@@ -1117,7 +840,8 @@ typedef BfCfg<16, 32, 5, 125, 61, l1b::NPART, true> Bf2;     // conv2: octet-pla
 typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, true> Bf3;   // conv3: octet-planar in and out
 // conv4 (3x3, 29 -> 14): the whole 14 x 14 image is one workgroup tile of 16 x 16 (pixel tiles of 2 rows x 16 columns);
 typedef BfCfg<64, 64, 3, 29, 14, Bf3::NPART_OUT, true, 2, 2, true> Bf4;
-typedef BfsCfg<64, 128, 14, 6, 7, Bf4::NPART_OUT, false> Bfs5;      // conv5: 7 samples (252 pixels) x 32 channels per workgroup
+typedef BfsCfg<64, 128, 14, 6, 7, Bf4::NPART_OUT, true> Bfs5;       // conv5: 7 samples (252 pixels) x 32 channels per workgroup
+typedef BfsCfg<128, 128, 6, 2, 32, Bfs5::NPART_OUT, false, 1> Bfs6;  // conv6: 32 samples (128 pixels) x 32 channels per workgroup; NCHW out (fc)
 
 template <class Cfg>
 static int launch_bf6(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
@@ -1134,22 +858,6 @@ static int launch_bf6(const float* in, const GNStats* st_in, const float* g, con
 }
 
 // per-layer configurations            CIN COUT KS  IH  OH  TH  TW  S  CC NWP NWM NPW MTW NPART_IN
-typedef ConvCfg<128, 128, 3,   6,  2,  2,  2,  8,  8,  1,  4,  1,  1, Bfs5::NPART_OUT> Cfg6;   // 8 agents (32 px), 4 waves x 32 channels
-
-template <class Cfg>
-static int launch_conv(const float* in, const GNStats* st_in, const float* g, const float* b, const float* w,
-                       const float* bias, float* out, GNStats* st_out, int N, hipStream_t stream) {
-    dim3 grid(Cfg::TILES_X * Cfg::CSPLIT, Cfg::TILES_Y, (N + Cfg::S - 1) / Cfg::S);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_mfma_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)Cfg::LDS_BYTES);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(conv_mfma_kernel<Cfg>, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, stream, in, st_in, g, b, w, bias, out,
-                       st_out, N);
-    return 0;
-}
 
 // =============================================================================================
 // GroupNorm6 + ReLU + flatten + Linear(512 -> 64): 4 samples per workgroup.
@@ -1167,7 +875,7 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ in, c
     const int n0 = blockIdx.x * 4, tid = threadIdx.x;
     if (tid < 4) {
         float mean = 0.f, rstd = 0.f;
-        if (n0 + tid < N) gn_moments(st, n0 + tid, Cfg6::NPART_OUT, 512.0, mean, rstd);
+        if (n0 + tid < N) gn_moments(st, n0 + tid, Bfs6::NPART_OUT, 512.0, mean, rstd);
         s_mr[tid][0] = mean;
         s_mr[tid][1] = rstd;
     }
@@ -1227,10 +935,10 @@ static int cnn_chunk() {
     }
     return v;
 }
-constexpr int NPARTS[6] = {l1b::NPART, Bf2::NPART_OUT, Bf3::NPART_OUT, Bf4::NPART_OUT, Bfs5::NPART_OUT, Cfg6::NPART_OUT};
-constexpr int STAT_SLOTS = l1b::NPART + Bf2::NPART_OUT + Bf3::NPART_OUT + Bf4::NPART_OUT + Bfs5::NPART_OUT + Cfg6::NPART_OUT;
+constexpr int NPARTS[6] = {l1b::NPART, Bf2::NPART_OUT, Bf3::NPART_OUT, Bf4::NPART_OUT, Bfs5::NPART_OUT, Bfs6::NPART_OUT};
+constexpr int STAT_SLOTS = l1b::NPART + Bf2::NPART_OUT + Bf3::NPART_OUT + Bf4::NPART_OUT + Bfs5::NPART_OUT + Bfs6::NPART_OUT;
 static_assert(Bfs5::NPART_IN == Bf4::NPART_OUT &&
-              Cfg6::NPART_IN == Bfs5::NPART_OUT, "statistics slot chain");   // agents pushed through the layer stack together (keeps the working set L3-sized)
+              Bfs6::NPART_IN == Bfs5::NPART_OUT, "statistics slot chain");
 
 size_t per_agent_floats() {
     size_t t = 0;
@@ -1292,7 +1000,7 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, stream);
         launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, stream);
         launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], n, stream);
-        launch_conv<Cfg6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w[5], cnn->b[5], act[5], st[5], n, stream);
+        launch_bf6s<Bfs6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w6_frag, cnn->b[5], act[5], st[5], n, stream);
         hipLaunchKernelGGL(fc_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, act[5], st[5], cnn->gn_g[5], cnn->gn_b[5],
                            cnn->fc_wt, cnn->fc_b, feat + (size_t)n0 * 64, n);
     }
@@ -1370,7 +1078,7 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
         case 2: launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, stream); break;
         case 3: launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], N, stream); break;
         case 4: launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], N, stream); break;
-        case 5: launch_conv<Cfg6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w[5], cnn->b[5], act[5], st[5], N, stream); break;
+        case 5: launch_bf6s<Bfs6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w6_frag, cnn->b[5], act[5], st[5], N, stream); break;
         default:
             hipLaunchKernelGGL(fc_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, act[5], st[5], cnn->gn_g[5], cnn->gn_b[5],
                                cnn->fc_wt, cnn->fc_b, feat, N);

@@ -182,6 +182,7 @@ def _fill_cnn(s, holder, sd):
     s.w3_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.6.weight'])))
     s.w4_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.9.weight'])))
     s.w5_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.12.weight'])))
+    s.w6_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.15.weight'])))
     fw = _c(sd['map_feature.weight'])
     if tuple(fw.shape) != (64, 512):
         raise NotImplementedError('map_feature must be Linear(512, 64)')
