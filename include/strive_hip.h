@@ -92,7 +92,8 @@ typedef struct StriveMap {
 /* Map CNN: 6 x [Conv2d(stride 2, pad 0) -> GroupNorm(1 group) -> ReLU] + Linear(512, 64), default
  * architecture only (kernels 7,5,5,3,3,3; channels 4->16->32->64->64->128->128; 256x256 input);
  * reference src/models/traffic_model.py:69-87, 437-440.
- * w[l]: packed for the MFMA kernels, layout [ci/2][ky][kx][ci&1][co] (l = 0: [ky][kx][ci][co]);
+ * w[l]: fp32 weights as [ci/2][ky][kx][ci&1][co] (l = 0: [ky][kx][ci][co]) -- not read by the kernels any more (all six
+ * convolutions take the bf16 fragment tables w1_frag .. w6_frag below); kept so that the struct layout stays put;
  * fc_wt: (512, 64) transposed Linear weight. */
 typedef struct StriveCNN {
     const float* w[6];
