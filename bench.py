@@ -1,25 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- adv-optim agent*timesteps/s of STRIVE's latent-optimisation closure on MI355X.
 
-A "step" is one optimisation closure of the reference's refine loop (reference
-src/refine_traffic_optim.py:186-218) over one scene batch:
-    zero_grad -> TrafficModel.decode_embedding(z, nfuture=FT)        (FT autoregressive decoder steps)
-              -> AvoidCollLoss (vehicle + environment collision, prior NLL, init-z)
-              -> backward to z.grad -> Adam step on z
-and advances NA*FT agent*timesteps.  Workload (BASELINE.json configs[1]): 32 synthetic scenes x 16 agents
-(NA = 512), fp32, synthetic 4096^2 4-layer raster, counter-generated weights (no checkpoint / dataset is
-available offline).  With N GPUs every rank owns its own 32 scenes (scenes are independent: weak scaling, no
-data-path collective) and the reported value is the whole-job aggregate.
+A "step" is one optimisation closure of one of the reference's loops over one scene batch, followed by its Adam
+step.  Workloads (``--workload``):
 
-Output: ONE JSON line on rank 0 (see README of the task for the contract) with two extra objects:
-  roofline     -- the dominant kernel (a map-CNN convolution, MFMA fp32 bound), timed live with events on the
-                  launching stream; achieved = algorithmic FLOPs per launch / average launch duration.
-  cpu_baseline -- the CPU oracle (a port of the reference's algorithm, oracle/) timed on this host on a bounded
-                  sample of the same workload.
+  refine       (default; BASELINE.json configs[1], the headline) the refine loop's closure (reference
+               src/refine_traffic_optim.py:186-218): zero_grad -> TrafficModel.decode_embedding(z, nfuture=FT) ->
+               AvoidCollLoss -> backward -> Adam, on 32 synthetic scenes x 16 agents per GPU (NA = 512), fp32.  With N
+               GPUs every rank owns its own 32 scenes (scenes are independent: weak scaling, no data-path collective).
+  adv          (configs[2]) the adversarial loop's closure (reference src/utils/adv_gen_optim.py:107-171, planner 'ego'):
+               two rollouts with complementary detach + TgtMatchingLoss + AdvGenLoss + backward + Adam on ~512 agents in
+               scenes of 2..30 agents; advances 2*NA*FT agent*timesteps.  Weak scaling like `refine`.
+  sharded4096  (configs[4]) ONE batch of ~4096 agents with NC = 5 classes (reduce_cats), split over the ranks by
+               strive_amd.distributed.shard_scenes; every rank runs the adversarial closure on its scenes.  The job is
+               fixed, so this is strong scaling.
+
+``python bench.py --gpus N`` launches the N ranks itself (re-executing under torch.distributed.run on 127.0.0.1) when it
+was not started by a launcher; under a launcher (WORLD_SIZE set) it is one rank of the job.
+
+Output: ONE JSON line on rank 0 with two extra objects:
+  roofline     -- the dominant kernel (a map-CNN convolution on the bf16 matrix cores), timed live with events on the
+                  launching stream: achieved = algorithmic FLOPs per launch x issued products / average launch duration;
+                  `bandwidth_kernels` = achieved GB/s of the byte-bound kernels (algorithmic bytes / live duration).
+  cpu_baseline -- the CPU oracle (a port of the reference's algorithm, oracle/) timed on this host: 1 warm-up + 3 timed
+                  closures on a bounded sample of the same workload, autograd incl. weight gradients like the reference.
+Any failure while collecting either makes the run exit non-zero (after printing the line with the error recorded).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,11 +40,15 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 matrix peak
+PEAK_HBM_GBS = 8000.0              # same guide: HBM3E ~8 TB/s
 # algorithmic FLOPs per agent of each map-CNN kernel (2 * Cout * OH * OW * Cin * k * k), SURVEY.md §8(a) a8
 CONV_FLOPS = [2 * 16 * 125 * 125 * 4 * 49, 2 * 32 * 61 * 61 * 16 * 25, 2 * 64 * 29 * 29 * 32 * 25,
               2 * 64 * 14 * 14 * 64 * 9, 2 * 128 * 6 * 6 * 64 * 9, 2 * 128 * 2 * 2 * 128 * 9]
 CONV_NAMES = ['conv1b_kernel<true> (fused crop -> conv1)', 'conv_bf6_kernel<conv2>', 'conv_bf6_kernel<conv3>',
               'conv_bf6_kernel<conv4>', 'conv_bf6s_kernel<conv5>', 'conv_bf6s_kernel<conv6>']
+# algorithmic HBM bytes per agent of the CNN kernels: input read once + output written once (fp32 activations, uint8 raster)
+CONV_BYTES = [4 * 256 * 256 + 16 * 125 * 125 * 4, (16 * 125 * 125 + 32 * 61 * 61) * 4, (32 * 61 * 61 + 64 * 29 * 29) * 4,
+              (64 * 29 * 29 + 64 * 14 * 14) * 4, (64 * 14 * 14 + 128 * 6 * 6) * 4, (128 * 6 * 6 + 128 * 2 * 2) * 4]
 # matrix-core work actually issued per algorithmic FLOP and the dense peak it runs against
 # (/opt/skills/guides/MI355X_MICROARCH.md: bf16 dense 2516 TFLOP/s, f32 157.3): conv1 = 3 exact bf16 weight pieces,
 # conv2-conv6 = 6 bf16 products per fp32 product
@@ -42,27 +57,81 @@ CONV_ISSUE = [(3, PEAK_BF16_MFMA_TFLOPS, 'bf16'), (6, PEAK_BF16_MFMA_TFLOPS, 'bf
               (6, PEAK_BF16_MFMA_TFLOPS, 'bf16'), (6, PEAK_BF16_MFMA_TFLOPS, 'bf16'), (6, PEAK_BF16_MFMA_TFLOPS, 'bf16')]
 
 REFINE_WEIGHTS = {'coll_veh': 100.0, 'coll_env': 100.0, 'init_z': 0.01, 'motion_prior': 1.0}   # refine_traffic_optim.cfg:26-29
+ADV_WEIGHTS = {'coll_veh': 20.0, 'coll_veh_plan': 20.0, 'coll_env': 20.0, 'init_z': 0.5, 'init_z_atk': 0.05,
+               'motion_prior': 1.0, 'motion_prior_atk': 0.005, 'motion_prior_ext': 0.0001, 'match_ext': 10.0,
+               'adv_crash': 2.0}                                                               # adv_gen_rule_based.cfg:33-42
 
 
-def build_workload(device, scenes, agents, FT, seed_key, raster_px):
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+
+def variable_scene_sizes(total, key, lo=2, hi=30):
+    """Scene sizes n_b in [lo, hi] summing to `total` (the last scene takes the remainder), deterministic."""
+    from strive_amd import synth
+    draws = synth.counter_uniform((4 * total // (lo + hi) + 64,), key + '/sizes', lo, hi + 1).astype(int).tolist()
+    sizes, acc = [], 0
+    for n in draws:
+        n = min(max(int(n), lo), hi)
+        if acc + n > total - lo:
+            break
+        sizes.append(n)
+        acc += n
+    rest = total - acc
+    while rest > hi:
+        sizes.append(hi)
+        rest -= hi
+    if rest >= 1:
+        sizes.append(rest)
+    assert sum(sizes) == total
+    return sizes
+
+
+def workload_scenes(args, rank, world):
+    """-> (list of (scene size, scene key) owned by this rank, description, scaling)."""
+    if args.workload == 'refine':
+        own = [(args.agents, 'bench/r%d/%d' % (rank, b)) for b in range(args.scenes)]
+        return own, '%d scenes x %d agents per GPU' % (args.scenes, args.agents), 'weak'
+    if args.workload == 'adv':
+        sizes = variable_scene_sizes(args.total_agents or 512, 'bench/adv/r%d' % rank)
+        own = [(n, 'bench/adv/r%d/%d' % (rank, b)) for b, n in enumerate(sizes)]
+        return own, '%d agents per GPU in %d scenes of 2..30' % (sum(sizes), len(sizes)), 'weak'
+    from strive_amd.distributed import shard_scenes
+    sizes = variable_scene_sizes(args.total_agents or 4096, 'bench/sharded')
+    part = shard_scenes(sizes, world)
+    own = [(sizes[i], 'bench/sharded/%d' % i) for i in part[rank]]
+    return own, 'one batch of %d agents in %d scenes of 2..30, scene-sharded over %d ranks' % (sum(sizes), len(sizes), world), 'strong'
+
+
+def build_model(device, NC):
     from strive_amd import synth
     from strive_amd.constants import NUSC_BIKE_PARAMS, state_norm_tensors, att_norm_tensors
     from strive_amd.models.traffic_model import TrafficModel
     from strive_amd.datasets.utils import MeanStdNormalizer
-    m = TrafficModel(4, 12, 256, 2)
+    m = TrafficModel(4, 12, 256, NC)
     m.load_state_dict(synth.fill_state_dict(m.state_dict()))
     m.set_normalizer(MeanStdNormalizer(*state_norm_tensors()))
     m.set_att_normalizer(MeanStdNormalizer(*att_norm_tensors()))
     m.set_bicycle_params(NUSC_BIKE_PARAMS)
-    m = m.eval().to(device)
-    raster, dx = synth.make_raster(raster_px, raster_px)
+    return m.eval().to(device)
+
+
+def build_batch(own, NC, raster_px, FT_data=12):
+    from strive_amd import synth
+    from strive_amd.graph import Batch
     extent = raster_px * 0.25
-    env = synth.SyntheticMapEnv(raster, dx).to(device)
-    batch, map_idx = synth.make_batch([agents] * scenes, key=seed_key, FT=12, map_extent=(extent, extent))
-    return m, env, batch, map_idx
+    scenes = [synth.make_scene(n, key, FT=FT_data, NC=NC, map_extent=(extent, extent)) for n, key in own]
+    batch = Batch.from_data_list(scenes)
+    return batch, torch.zeros((len(own),), dtype=torch.long)
 
 
-def gpu_closure_factory(m, env, batch, map_idx, FT, device):
+def build_env(raster_px, device):
+    from strive_amd import synth
+    raster, dx = synth.make_raster(raster_px, raster_px)
+    return synth.SyntheticMapEnv(raster, dx).to(device)
+
+
+def refine_closure_factory(m, env, batch, map_idx, FT, device):
     from strive_amd import synth
     from strive_amd.losses.adv_gen_nusc import AvoidCollLoss
     from strive_amd.utils.scenario_gen import detach_embed_info
@@ -83,19 +152,57 @@ def gpu_closure_factory(m, env, batch, map_idx, FT, device):
         ld['loss'].backward()
         opt.step()
         return ld['loss']
-    return step, z, emb, g, mi
+    return step, emb, g, mi, 1
 
+
+def adv_closure_factory(m, env, batch, map_idx, FT, device):
+    """reference src/utils/adv_gen_optim.py:39-171 in 'ego' planner mode, latents initialised at the posterior mean like
+    adv_scenario_gen.py:297-312 does after the init optimisation."""
+    from strive_amd.utils.adv_gen_optim import AdvClosure
+    from strive_amd.utils.scenario_gen import detach_embed_info
+    g = batch.to(device)
+    mi = map_idx.to(device)
+    with torch.no_grad():
+        emb = detach_embed_info(m.embed(g, mi, env))
+    NA = g.past.shape[0]
+    ego = torch.zeros((NA,), dtype=torch.bool, device=device)
+    ego[g.ptr[:-1].to(device)] = True
+    pm, pv = emb['prior_out']
+    c = AdvClosure(emb['posterior_out'][0].clone(), 0.05, ADV_WEIGHTS, m, g, env, mi, emb, (pm[ego], pv[ego]),
+                   (pm[~ego], pv[~ego]), 2, 0.0, planner_fut=g.future_gt[ego][:, :FT, :4].contiguous(), future_len=FT,
+                   veh_coll_buffer=0.1)
+    return (lambda: c.step()), emb, g, mi, 2
+
+
+# ------------------------------------------------------------------------------------------------
+# side measurements
+# ------------------------------------------------------------------------------------------------
 
 def _measured_traffic(kernel_name):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json, written
-    from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); None if not collected for this kernel."""
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_traffic.json')) as f:
-            t = json.load(f)
-        ent = t.get(kernel_name)
-        return None if ent is None else ent.get('bytes_per_launch')
-    except Exception:
-        return None
+    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/r0N_traffic.json, written from
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); None if not collected for this kernel."""
+    for name in ('r02_traffic.json', 'r01_traffic.json'):
+        try:
+            with open(os.path.join(REPO, 'profiles', name)) as f:
+                ent = json.load(f).get(kernel_name)
+            if ent is not None:
+                return ent.get('bytes_per_launch')
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def _event_time(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
 
 
 def time_dominant_kernel(m, env, g, mi, emb, device, reps=20):
@@ -107,7 +214,7 @@ def time_dominant_kernel(m, env, g, mi, emb, device, reps=20):
     pos = g.past[:N, -1, :4].contiguous()
     mapix = mi[g.batch][:N].to(torch.int32).contiguous()
     mp = ops._map_pack(env, device)
-    cnn = ops._cached_pack(m, 'cnn', m.map_conv, lambda: None)
+    cnn = ops.cnn_pack(m)
     wsb = lib.query('strive_map_cnn_workspace_bytes', N)
     ws = torch.empty(wsb, dtype=torch.uint8, device=device)
     feat = torch.empty((N, 64), device=device)
@@ -118,18 +225,8 @@ def time_dominant_kernel(m, env, g, mi, emb, device, reps=20):
     torch.cuda.synchronize()
     times = []
     for layer in range(6):
-        for _ in range(3):
-            lib.call('strive_map_cnn_bench_layer', mp.ref(), cnn.ref(), layer, L.ptr(pos), mean4, std4, L.ptr(mapix), N,
-                     L.ptr(feat), L.ptr(ws), wsb, st)
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            lib.call('strive_map_cnn_bench_layer', mp.ref(), cnn.ref(), layer, L.ptr(pos), mean4, std4, L.ptr(mapix), N,
-                     L.ptr(feat), L.ptr(ws), wsb, st)
-        e1.record()
-        torch.cuda.synchronize()
-        times.append(e0.elapsed_time(e1) * 1e-3 / reps)
+        times.append(_event_time(lambda: lib.call('strive_map_cnn_bench_layer', mp.ref(), cnn.ref(), layer, L.ptr(pos), mean4,
+                                                  std4, L.ptr(mapix), N, L.ptr(feat), L.ptr(ws), wsb, st), reps))
     dom = max(range(6), key=lambda l: times[l])
     mult, peak, mdt = CONV_ISSUE[dom]
     alg = CONV_FLOPS[dom] * N / times[dom] / 1e12          # algorithmic (fp32-equivalent) TFLOP/s
@@ -141,72 +238,207 @@ def time_dominant_kernel(m, env, g, mi, emb, device, reps=20):
            'launch_us': round(times[dom] * 1e6, 2), 'agents_per_launch': N,
            'all_layers_us': [round(t * 1e6, 2) for t in times],
            'all_layers_algorithmic_tflops': [round(CONV_FLOPS[l] * N / times[l] / 1e12, 2) for l in range(6)]}
+    # byte-bound view of the same launches: algorithmic bytes (input once + output once) / live duration
+    bw = {}
+    for l in range(6):
+        gbs = CONV_BYTES[l] * N / times[l] / 1e9
+        bw[CONV_NAMES[l]] = {'algorithmic_bytes': CONV_BYTES[l] * N, 'us': round(times[l] * 1e6, 2), 'GBps': round(gbs, 1),
+                             'frac_of_hbm_peak': round(gbs / PEAK_HBM_GBS, 4), 'traffic': _measured_traffic(CONV_NAMES[l])}
+    rec['bandwidth_kernels'] = bw
     return rec
 
 
-def cpu_baseline(FT, scenes=4, agents=16, raster_px=4096):
-    """The oracle's refine closure (decode + AvoidCollLoss + backward) on `scenes` scenes of the same workload."""
+def time_bandwidth_kernels(m, env, g, mi, device, reps=20):
+    """Achieved GB/s of the byte-bound kernels outside the CNN: the stand-alone raster crop, the
+    vehicle-collision penalty and the off-road collision point, each on this batch's own sizes."""
+    from strive_amd import ops
+    from strive_amd.losses.adv_gen_nusc import VehCollLoss
+    out = {}
+    N = min(512, g.past.shape[0])
+    unn = m.get_normalizer().unnormalize
+    pos = unn(g.past[:N, -1, :])[:, :4].contiguous()
+    mapix = mi[g.batch][:N]
+    t = _event_time(lambda: ops.map_crop(env, pos, mapix), reps)
+    by = N * 4 * 256 * 256 * 2          # gather 1 B per crop pixel, write 1 B
+    out['map_crop_u8_kernel'] = {'algorithmic_bytes': by, 'us': round(t * 1e6, 2), 'GBps': round(by / t / 1e9, 1),
+                                 'frac_of_hbm_peak': round(by / t / 1e9 / PEAK_HBM_GBS, 4)}
+    NA = g.past.shape[0]
+    T = 48
+    traj = unn(g.future_gt[:, :12, :])[:, :, :4].repeat(1, 4, 1).contiguous()
+    veh_att = m.get_att_normalizer().unnormalize(g.lw)
+    vl = VehCollLoss(veh_att, buffer_dist=0.2, ptr=g.ptr)
+    t = _event_time(lambda: ops.veh_coll_penalties(traj, vl.setup), reps)
+    P = int(((g.ptr[1:] - g.ptr[:-1]) ** 2).sum())
+    by = NA * T * 16 + T * P * 6        # trajectories read once; pen (4 B) + hit + amin (1 B each) written per pair slot
+    out['veh_coll_fwd_kernel'] = {'algorithmic_bytes': by, 'us': round(t * 1e6, 2), 'GBps': round(by / t / 1e9, 1),
+                                  'frac_of_hbm_peak': round(by / t / 1e9 / PEAK_HBM_GBS, 4), 'pairs': P, 'T': T}
+    cars = traj.reshape(NA * T, 4)
+    lw = veh_att.unsqueeze(1).expand(NA, T, 2).reshape(NA * T, 2).contiguous()
+    mp = mi[g.batch].unsqueeze(1).expand(NA, T).reshape(-1)
+    gl, gw = 39, 16
+    t = _event_time(lambda: ops.coll_point(env, cars, lw, mp, gl, gw), reps)
+    by = NA * T * (gl * gw + 16 + 8 + 12)
+    out['coll_point_kernel'] = {'algorithmic_bytes': by, 'us': round(t * 1e6, 2), 'GBps': round(by / t / 1e9, 1),
+                                'frac_of_hbm_peak': round(by / t / 1e9 / PEAK_HBM_GBS, 4)}
+    return out
+
+
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _one_socket_threads():
+    """Hardware threads of one socket (what the reference's single-socket CPU run would use)."""
+    try:
+        sockets, cpus = set(), 0
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('physical id'):
+                    sockets.add(line.split(':', 1)[1].strip())
+                elif line.startswith('processor'):
+                    cpus += 1
+        if sockets and cpus:
+            return max(1, cpus // len(sockets))
+    except OSError:
+        pass
+    return torch.get_num_threads()
+
+
+def cpu_baseline(FT, scenes=4, agents=16, raster_px=4096, timed=3):
+    """The oracle's refine closure (decode + AvoidCollLoss + backward) on `scenes` scenes of the same workload, in the
+    reference's structure: materialised fp32/fp64/int64 coordinate tensors per crop, per-edge MLP, and -- because the
+    reference's parameters require grad and encode_map runs with grad enabled -- autograd through the map CNN including its
+    (unused) weight gradients.  1 warm-up closure + `timed` timed closures."""
     from strive_amd import synth
     from strive_amd.constants import NUSC_BIKE_PARAMS, state_norm_tensors, att_norm_tensors
     from strive_amd.models.traffic_model import TrafficModel
     from oracle.model import OracleTrafficModel
     from oracle.geometry import Normalizer
     from oracle.losses import AvoidColl
-    m = TrafficModel(4, 12, 256, 2)
-    sd = synth.fill_state_dict(m.state_dict())
-    orc = OracleTrafficModel(sd, Normalizer(*state_norm_tensors()), Normalizer(*att_norm_tensors()), NUSC_BIKE_PARAMS)
-    raster, dx = synth.make_raster(raster_px, raster_px)
-    extent = raster_px * 0.25
-    env = synth.SyntheticMapEnv(raster, dx)
-    batch, map_idx = synth.make_batch([agents] * scenes, key='bench/r0', FT=12, map_extent=(extent, extent))
-    with torch.no_grad():
-        emb = orc.embed(batch, map_idx, env)
-    z0 = synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='bench/z')
-    z = z0.clone().requires_grad_(True)
-    lf = AvoidColl(REFINE_WEIGHTS, orc.get_att_normalizer().unnormalize(batch.lw), map_idx[batch.batch], env, z0.clone(),
-                   veh_coll_buffer=0.2)
-    t0 = time.time()
-    pred = orc.decode_embedding(z, emb, batch, map_idx, env, nfuture=FT)['future_pred']
-    ld = lf(orc.get_normalizer().unnormalize(pred), z, emb['prior_out'])
-    ld['loss'].backward()
-    dt = time.time() - t0
+    threads = _one_socket_threads()
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        m = TrafficModel(4, 12, 256, 2)
+        sd = synth.fill_state_dict(m.state_dict())
+        for v in sd.values():
+            v.requires_grad_(True)          # reference: model parameters require grad during the optimisation loops
+        orc = OracleTrafficModel(sd, Normalizer(*state_norm_tensors()), Normalizer(*att_norm_tensors()), NUSC_BIKE_PARAMS)
+        raster, dx = synth.make_raster(raster_px, raster_px)
+        extent = raster_px * 0.25
+        env = synth.SyntheticMapEnv(raster, dx)
+        batch, map_idx = build_batch([(agents, 'bench/r0/%d' % b) for b in range(scenes)], 2, raster_px)
+        with torch.no_grad():
+            emb = orc.embed(batch, map_idx, env)
+        z0 = synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='bench/z')
+        z = z0.clone().requires_grad_(True)
+        opt = torch.optim.Adam([z], lr=0.05)
+        lf = AvoidColl(REFINE_WEIGHTS, orc.get_att_normalizer().unnormalize(batch.lw), map_idx[batch.batch], env, z0.clone(),
+                       veh_coll_buffer=0.2)
+
+        def closure():
+            opt.zero_grad()
+            for v in sd.values():
+                v.grad = None
+            pred = orc.decode_embedding(z, emb, batch, map_idx, env, nfuture=FT)['future_pred']
+            ld = lf(orc.get_normalizer().unnormalize(pred), z, emb['prior_out'])
+            ld['loss'].backward()
+            opt.step()
+        closure()
+        t0 = time.perf_counter()
+        for _ in range(timed):
+            closure()
+        dt = (time.perf_counter() - t0) / timed
+    finally:
+        torch.set_num_threads(old_threads)
     n = scenes * agents * FT
-    return {'value': round(n / dt, 2), 'unit': 'agent*timesteps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d scenes x %d agents, FT=%d, 1 closure (decode + AvoidCollLoss + backward) of the CPU oracle, '
-                      '%.1f s' % (scenes, agents, FT, dt)}
+    return {'value': round(n / dt, 2), 'unit': 'agent*timesteps/s', 'cores': threads, 'kind': 'port', 'cpu': _cpu_model(),
+            'sample': '%d scenes x %d agents, FT=%d: 1 warm-up + %d timed refine closures (decode + AvoidCollLoss + backward '
+                      'incl. the CNN weight gradients the reference computes + Adam) of the CPU oracle, %.1f s per closure; '
+                      'threads = one socket' % (scenes, agents, FT, timed, dt)}
 
 
-def main():
+# ------------------------------------------------------------------------------------------------
+# launch
+# ------------------------------------------------------------------------------------------------
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', choices=['refine', 'adv', 'sharded4096'], default='refine')
     ap.add_argument('--scenes', type=int, default=32)
     ap.add_argument('--agents', type=int, default=16)
-    ap.add_argument('--ft', type=int, default=16, help='rollout steps per closure (refine_traffic_optim.cfg: samp_future_len 16)')
+    ap.add_argument('--total-agents', type=int, default=0, help='adv / sharded4096: agents in the batch (default 512 / 4096)')
+    ap.add_argument('--nc', type=int, default=0, help='semantic classes (default 2; 5 for sharded4096 = reduce_cats)')
+    ap.add_argument('--ft', type=int, default=0, help='rollout steps per closure (default: 16 for refine = '
+                                                      'refine_traffic_optim.cfg samp_future_len, 12 otherwise)')
     ap.add_argument('--raster', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    args = ap.parse_args()
+    ap.add_argument('--dry-run', action='store_true', help='CPU/gloo: join the ranks, build the scene partition, no kernels')
+    args = ap.parse_args(argv)
+    if not args.nc:
+        args.nc = 5 if args.workload == 'sharded4096' else 2
+    if not args.ft:
+        args.ft = 16 if args.workload == 'refine' else 12
+    return args
 
+
+def main():
+    args = parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # not under a launcher: start the N ranks ourselves, one process per GPU, rendezvous on 127.0.0.1
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started %d ranks' % (args.gpus, world))
+    use_dist = world > 1
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path)')
+    if local >= torch.cuda.device_count():
+        raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
-    use_dist = world > 1
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     import __graft_entry__ as ge
-    ge.build(verbose=False)
+    if rank == 0:
+        ge.build(verbose=False)
+    if use_dist:
+        dist.barrier()
 
-    m, env, batch, map_idx = build_workload(device, args.scenes, args.agents, args.ft, 'bench/r%d' % rank, args.raster)
-    step, z, emb, g, mi = gpu_closure_factory(m, env, batch, map_idx, args.ft, device)
+    own, desc, scaling = workload_scenes(args, rank, world)
+    m = build_model(device, args.nc)
+    env = build_env(args.raster, device)
+    batch, map_idx = build_batch(own, args.nc, args.raster)
+    factory = refine_closure_factory if args.workload == 'refine' else adv_closure_factory
+    step, emb, g, mi, rollouts = factory(m, env, batch, map_idx, args.ft, device)
     for _ in range(args.warmup):
         step()
 
@@ -220,44 +452,93 @@ def main():
     for _ in range(args.steps):
         loss = step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt = dt_local
+    NA = int(g.past.shape[0])
+    units_local = rollouts * NA * args.ft * args.steps
+    units = units_local
+    per_rank = [[rank, NA, round(dt_local / args.steps * 1e3, 3)]]
     if use_dist:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt_local], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    NA = args.scenes * args.agents
-    units = NA * args.ft * args.steps * world
+        uu = torch.tensor([units_local], device=device, dtype=torch.float64)
+        dist.all_reduce(uu, op=dist.ReduceOp.SUM)
+        units = int(uu.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
+    closure = {'refine': 'refine closure: decode_embedding(nfuture=%d) + AvoidCollLoss + backward + Adam',
+               'adv': 'adversarial closure: 2 x decode_embedding(nfuture=%d, ext_future) with complementary detach + '
+                      'TgtMatchingLoss + AdvGenLoss + backward + Adam',
+               'sharded4096': 'adversarial closure: 2 x decode_embedding(nfuture=%d, ext_future) + TgtMatchingLoss + '
+                              'AdvGenLoss + backward + Adam'}[args.workload] % args.ft
+    cfg_ref = {'refine': 'BASELINE.json configs[1]', 'adv': 'BASELINE.json configs[2]', 'sharded4096': 'BASELINE.json configs[4]'}
     out = {
         'metric': 'adv-optim agent*timesteps/sec (decoder fwd+bwd)',
         'value': round(units / dt, 1), 'unit': 'agent*timesteps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'refine closure: decode_embedding(nfuture=%d) + AvoidCollLoss + backward + Adam, '
-                               '%d scenes x %d agents per GPU (BASELINE.json configs[1])' % (args.ft, args.scenes, args.agents),
-                   'agents_per_gpu': NA, 'FT': args.ft, 'raster': '%dx%d x4 uint8 @0.25 m' % (args.raster, args.raster),
+        'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s, %s (%s)' % (closure, desc, cfg_ref[args.workload]),
+                   'agents_per_gpu': NA, 'FT': args.ft, 'NC': args.nc, 'rollouts_per_closure': rollouts,
+                   'raster': '%dx%d x4 uint8 @0.25 m' % (args.raster, args.raster),
                    'parallelism': 'scene-sharded replicas x%d' % world,
                    'arithmetic': 'fp32 everywhere; the map CNN on bf16 matrix cores with exact 3-way operand splits, fp32 accumulate'},
         'final_loss': float(loss.detach().cpu()),
+        'per_rank': [{'rank': r, 'agents': a, 'ms_per_step': t} for r, a, t in per_rank],
     }
+    failed = False
     if rank == 0:
         if not args.no_roofline:
             try:
                 out['roofline'] = time_dominant_kernel(m, env, g, mi, emb, device)
+                out['roofline']['bandwidth_kernels'].update(time_bandwidth_kernels(m, env, g, mi, device))
                 # the closure as a whole = 305 MFLOP algorithmic per agent*timestep (map CNN
                 # forward 300.4 + GNN/GRU/dynamics forward+backward), against the fp32 matrix peak
                 per_gpu = out['value'] / world
                 out['roofline']['whole_path'] = {
                     'algorithmic_tflops': round(per_gpu * 305.0e6 / 1e12, 2),
                     'frac_of_f32_matrix_peak': round(per_gpu * 305.0e6 / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
-            except Exception as e:      # keep the headline number even if the side measurement fails
+            except Exception as e:      # keep the headline number, but the run fails
                 out['roofline'] = {'error': repr(e)}
+                failed = True
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(args.ft)
             except Exception as e:
                 out['cpu_baseline'] = {'error': repr(e)}
+                failed = True
         print(json.dumps(out), flush=True)
     if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if failed:
+        sys.exit(3)
+
+
+def dry_run(args, rank, world):
+    """No GPU: the ranks join a gloo group, build their part of the workload and rank 0 checks that the union of the
+    per-rank scene lists is exactly the job (disjoint + complete for `sharded4096`)."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    own, desc, scaling = workload_scenes(args, rank, world)
+    mine = {'rank': rank, 'scenes': [k for _, k in own], 'agents': sum(n for n, _ in own)}
+    everyone = [mine]
+    if world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+    if rank == 0:
+        keys = [k for e in everyone for k in e['scenes']]
+        rec = {'dry_run': True, 'n_gpus': world, 'ranks_joined': sorted(e['rank'] for e in everyone), 'scaling': scaling,
+               'workload': desc, 'agents_per_rank': [e['agents'] for e in everyone], 'total_agents': sum(e['agents'] for e in everyone),
+               'scenes_per_rank': [len(e['scenes']) for e in everyone], 'disjoint': len(keys) == len(set(keys))}
+        if args.workload == 'sharded4096':
+            sizes = variable_scene_sizes(args.total_agents or 4096, 'bench/sharded')
+            rec['complete'] = sorted(keys) == sorted('bench/sharded/%d' % i for i in range(len(sizes)))
+        print(json.dumps(rec), flush=True)
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 

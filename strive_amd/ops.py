@@ -44,7 +44,9 @@ _ws_cache = {}
 
 
 def _workspace(device, nbytes, tag='ws'):
-    key = (str(device), tag)
+    """Scratch buffer per (device, tag, current stream): launches on different streams never share one."""
+    stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == 'cuda' else 0
+    key = (str(device), tag, stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
@@ -52,14 +54,16 @@ def _workspace(device, nbytes, tag='ws'):
     return buf
 
 
-def _param_signature(module):
-    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+def _param_signature(*modules):
+    return tuple((p.data_ptr(), p._version) for m in modules for p in m.parameters())
 
 
-def _cached_pack(owner, key, module_for_sig, builder):
-    """Re-pack only when a parameter changed (in-place updates bump ``_version``) or moved."""
+def _cached_pack(owner, key, module_for_sig, builder, extra_sig=()):
+    """Re-pack only when a parameter changed (in-place updates bump ``_version``) or moved, or when ``extra_sig``
+    (plain values the pack also depends on) changed.  ``module_for_sig`` is a module or a tuple of modules."""
     cache = owner.__dict__.setdefault('_strive_packs', {})
-    sig = _param_signature(module_for_sig)
+    mods = module_for_sig if isinstance(module_for_sig, (tuple, list)) else (module_for_sig,)
+    sig = (_param_signature(*mods), extra_sig)
     ent = cache.get(key)
     if ent is None or ent[0] != sig:
         ent = (sig, builder())
@@ -78,6 +82,8 @@ def _sd_of(module, prefix):
 class SceneInfo(object):
     def __init__(self, ptr, device):
         self.ptr = ptr.to(device)
+        self.ptr_cpu = ptr.cpu().clone()
+        self.ei_sig = None
         self.sizes = (ptr[1:] - ptr[:-1]).cpu()
         self.B = int(self.sizes.shape[0])
         self.NA = int(ptr[-1])
@@ -118,10 +124,13 @@ def scene_info(scene_graph):
     kernels assume (reference src/datasets/nuscenes_dataset.py:678-687 always builds exactly that)."""
     ptr = scene_graph.ptr
     cached = scene_graph.__dict__.get('_strive_scene_info')
-    if cached is not None and cached.NA == int(ptr[-1]) and cached.B == ptr.shape[0] - 1 and \
-            cached.device == scene_graph.past.device:
+    ei = scene_graph.edge_index if 'edge_index' in scene_graph else None
+    ei_sig = None if ei is None else (ei.data_ptr(), ei._version, tuple(ei.shape))
+    if cached is not None and cached.device == scene_graph.past.device and cached.ei_sig == ei_sig and \
+            cached.ptr_cpu.shape == ptr.shape and torch.equal(cached.ptr_cpu, ptr.cpu()):
         return cached
     info = SceneInfo(ptr.cpu(), scene_graph.past.device)
+    info.ei_sig = ei_sig
     if 'edge_index' in scene_graph:
         ei = scene_graph.edge_index.cpu()
         exp = _expected_clique_keys(ptr.cpu(), info.NA)
@@ -240,6 +249,11 @@ class _OverrideEnv(object):
         self.W = env.W if W_ is None else W_
 
 
+def cnn_pack(model):
+    """Packed map-CNN weights (bf16 fragment tables + fc), re-packed when any map_conv / map_feature parameter changes."""
+    return _cached_pack(model, 'cnn', (model.map_conv, model.map_feature), lambda: params.pack_cnn(model.state_dict()))
+
+
 def encode_map(model, pos, batch_of_agent, map_idx, map_env):
     """Map feature at NORMALISED ``pos`` (NA,4)/(NA,NS,4) -> (NA,[NS,]64): fused crop + CNN, no gradient."""
     lib = _lib_for(pos)
@@ -248,7 +262,7 @@ def encode_map(model, pos, batch_of_agent, map_idx, map_env):
     NS = pos.shape[1] if multi else 1
     dev = pos.device
     mp = _map_pack(map_env, dev)
-    cnn = _cached_pack(model, 'cnn', model.map_conv, lambda: params.pack_cnn(model.state_dict()))
+    cnn = cnn_pack(model)
     mapix = map_idx.to(dev)[batch_of_agent.to(dev)].to(torch.int32)
     if multi:
         mapix = mapix.view(NA, 1).expand(NA, NS).reshape(-1)
@@ -272,7 +286,7 @@ def encode_map_crop(model, crop):
     crop = crop.contiguous()
     N = crop.shape[0]
     dev = crop.device
-    cnn = _cached_pack(model, 'cnn', model.map_conv, lambda: params.pack_cnn(model.state_dict()))
+    cnn = cnn_pack(model)
     feat = torch.empty((N, 64), dtype=torch.float32, device=dev)
     wsb = lib.query('strive_map_cnn_workspace_bytes', N)
     ws = _workspace(dev, wsb, 'cnn')
@@ -363,10 +377,15 @@ def decoder_rollout(model, g, map_feat, past_feat, z, map_idx, map_env, ext_futu
     def build():
         return params.pack_decoder(model.state_dict(), NC, map_env, dev, model.normalizer, model.att_normalizer,
                                    model.bicycle_params)
-    key = ('dec', str(dev), map_env.nusc_raster.data_ptr(), id(model.normalizer), id(model.att_normalizer))
+    key = ('dec', str(dev), map_env.nusc_raster.data_ptr())
+    # plain values the pack copies: normaliser statistics and the bicycle parameters (not object identities)
+    nm, an, bp = model.normalizer, model.att_normalizer, model.bicycle_params
+    extra = (tuple(nm.mean_vals.tolist()), tuple(nm.std_vals.tolist()), tuple(an.mean_vals.tolist()), tuple(an.std_vals.tolist()),
+             tuple(sorted((k, tuple(v) if isinstance(v, (tuple, list)) else v) for k, v in bp.items())),
+             tuple(map_env.bounds), map_env.L, map_env.W)
     h = _RolloutCtx()
     h.lib = lib
-    h.dec = _cached_pack(model, key, model, build)
+    h.dec = _cached_pack(model, key, model, build, extra_sig=extra)
     h.sc = info.pack(NS)
     h.R = info.NA * NS
     h.FT = int(FT)

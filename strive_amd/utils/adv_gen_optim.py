@@ -21,57 +21,85 @@ def collate_tgt_other_z(scene_graph, tgt_z, other_z):
     return torch.cat([tgt_z, other_z], dim=0).index_select(0, src)
 
 
-def run_adv_gen_optim(cur_z, lr, loss_weights, model, scene_graph, map_env, map_idx, num_iters, embed_info,
-                      planner_name, tgt_prior_distrib, other_prior_distrib, feasibility_time, feasibility_infront_min,
-                      planner=None, planner_viz_out=None, attack_agt_idx=None, future_len=None, veh_coll_buffer=0.1,
-                      log=None):
-    from ..losses.adv_gen_nusc import TgtMatchingLoss, AdvGenLoss
-    if planner_name != 'ego':
-        raise NotImplementedError("only planner_name='ego' (open loop) is implemented; the rule-based planner is "
-                                  "a CPU component outside the HIP hot path")
-    dev = cur_z.device
-    NA = cur_z.size(0)
-    ego_inds = scene_graph.ptr[:-1].to(dev)
-    ego_mask = torch.zeros((NA,), dtype=torch.bool, device=dev)
-    ego_mask[ego_inds] = True
-    if attack_agt_idx is not None:
-        attack_agt_idx = torch.as_tensor(attack_agt_idx).to(ego_inds) + ego_inds
-    if future_len is None:
-        future_len = model.FT
-    tgt_z = cur_z[ego_mask].clone().detach()
-    tgt_z.requires_grad = True
-    other_z_all = cur_z[~ego_mask].clone().detach()
-    other_z_all.requires_grad = True
-    cur_z = collate_tgt_other_z(scene_graph, tgt_z, other_z_all)
-    adv_optim = optim.Adam([tgt_z, other_z_all], lr=lr)
-    unn = model.get_normalizer().unnormalize
-    tgt_loss = TgtMatchingLoss(loss_weights)
-    adv_loss = AdvGenLoss(loss_weights, model.get_att_normalizer().unnormalize(scene_graph.lw),
-                          map_idx[scene_graph.batch], map_env, cur_z[~ego_mask].clone().detach(), scene_graph.ptr,
-                          veh_coll_buffer=veh_coll_buffer, crash_loss_min_time=feasibility_time,
-                          crash_loss_min_infront=feasibility_infront_min)
-    planner_fut = scene_graph.future_gt[ego_mask][:, :, :4]
-    assert planner_fut.size(1) == future_len
-    for _ in range(num_iters):
-        adv_optim.zero_grad()
-        z_a = collate_tgt_other_z(scene_graph, tgt_z, other_z_all.clone().detach())
-        z_b = collate_tgt_other_z(scene_graph, tgt_z.clone().detach(), other_z_all)
-        out_a = model.decode_embedding(z_a, embed_info, scene_graph, map_idx, map_env, ext_future=planner_fut,
-                                       nfuture=future_len)
-        out_b = model.decode_embedding(z_b, embed_info, scene_graph, map_idx, map_env, ext_future=planner_fut,
-                                       nfuture=future_len)
-        lt = tgt_loss(unn(out_a['future_pred'][ego_mask]), unn(planner_fut), tgt_z, tgt_prior_distrib)
-        la = adv_loss(unn(out_b['future_pred']), unn(planner_fut), other_z_all, other_prior_distrib,
-                      attack_agt_idx=attack_agt_idx)
+class AdvClosure(object):
+    """State + one iteration of the adversarial optimisation (reference src/utils/adv_gen_optim.py:39-171):
+    the two leaf latent groups, Adam over both, the two loss modules and ``step()`` = one closure (zero_grad, two
+    rollouts with complementary detach, TgtMatchingLoss + AdvGenLoss, backward) followed by one ``Adam.step()``.
+    ``run_adv_gen_optim`` and bench.py's ``--workload adv`` both drive this object."""
+
+    def __init__(self, cur_z, lr, loss_weights, model, scene_graph, map_env, map_idx, embed_info, tgt_prior_distrib,
+                 other_prior_distrib, feasibility_time, feasibility_infront_min, planner_fut=None, attack_agt_idx=None,
+                 future_len=None, veh_coll_buffer=0.1):
+        from ..losses.adv_gen_nusc import TgtMatchingLoss, AdvGenLoss
+        dev = cur_z.device
+        NA = cur_z.size(0)
+        self.model, self.scene_graph, self.map_env, self.map_idx, self.embed_info = model, scene_graph, map_env, map_idx, embed_info
+        self.ego_inds = scene_graph.ptr[:-1].to(dev)
+        self.ego_mask = torch.zeros((NA,), dtype=torch.bool, device=dev)
+        self.ego_mask[self.ego_inds] = True
+        if attack_agt_idx is not None:
+            attack_agt_idx = torch.as_tensor(attack_agt_idx).to(self.ego_inds) + self.ego_inds
+        self.attack_agt_idx = attack_agt_idx
+        self.future_len = model.FT if future_len is None else future_len
+        self.tgt_z = cur_z[self.ego_mask].clone().detach()
+        self.tgt_z.requires_grad = True
+        self.other_z = cur_z[~self.ego_mask].clone().detach()
+        self.other_z.requires_grad = True
+        self.optim = optim.Adam([self.tgt_z, self.other_z], lr=lr)
+        self.unn = model.get_normalizer().unnormalize
+        self.tgt_prior, self.other_prior = tgt_prior_distrib, other_prior_distrib
+        self.tgt_loss = TgtMatchingLoss(loss_weights)
+        self.adv_loss = AdvGenLoss(loss_weights, model.get_att_normalizer().unnormalize(scene_graph.lw),
+                                   map_idx[scene_graph.batch], map_env, self.collated()[~self.ego_mask].clone().detach(),
+                                   scene_graph.ptr, veh_coll_buffer=veh_coll_buffer, crash_loss_min_time=feasibility_time,
+                                   crash_loss_min_infront=feasibility_infront_min)
+        self.planner_fut = scene_graph.future_gt[self.ego_mask][:, :, :4] if planner_fut is None else planner_fut
+        assert self.planner_fut.size(1) == self.future_len
+
+    def collated(self, detach_tgt=False, detach_other=False):
+        t = self.tgt_z.clone().detach() if detach_tgt else self.tgt_z
+        o = self.other_z.clone().detach() if detach_other else self.other_z
+        return collate_tgt_other_z(self.scene_graph, t, o)
+
+    def step(self, log=None):
+        """(reference src/utils/adv_gen_optim.py:107-171)"""
+        m, g = self.model, self.scene_graph
+        self.optim.zero_grad()
+        z_a = self.collated(detach_other=True)      # ego latents get the matching loss only
+        z_b = self.collated(detach_tgt=True)        # the others get the adversarial loss only
+        out_a = m.decode_embedding(z_a, self.embed_info, g, self.map_idx, self.map_env, ext_future=self.planner_fut,
+                                   nfuture=self.future_len)
+        out_b = m.decode_embedding(z_b, self.embed_info, g, self.map_idx, self.map_env, ext_future=self.planner_fut,
+                                   nfuture=self.future_len)
+        lt = self.tgt_loss(self.unn(out_a['future_pred'][self.ego_mask]), self.unn(self.planner_fut), self.tgt_z,
+                           self.tgt_prior)
+        la = self.adv_loss(self.unn(out_b['future_pred']), self.unn(self.planner_fut), self.other_z, self.other_prior,
+                           attack_agt_idx=self.attack_agt_idx)
         loss_dict = {'tgt_match_' + k: v for k, v in lt.items()}
         loss_dict.update({'adv_' + k: v for k, v in la.items()})
         loss = loss_dict['tgt_match_loss'] + loss_dict['adv_loss']
         loss.backward()
         if log is not None:
-            log(loss_dict)
-        adv_optim.step()
+            log(loss_dict, self.tgt_z, self.other_z)
+        self.optim.step()
+        return loss
 
-    cur_z = collate_tgt_other_z(scene_graph, tgt_z, other_z_all)
+
+def run_adv_gen_optim(cur_z, lr, loss_weights, model, scene_graph, map_env, map_idx, num_iters, embed_info,
+                      planner_name, tgt_prior_distrib, other_prior_distrib, feasibility_time, feasibility_infront_min,
+                      planner=None, planner_viz_out=None, attack_agt_idx=None, future_len=None, veh_coll_buffer=0.1,
+                      log=None):
+    if planner_name != 'ego':
+        raise NotImplementedError("only planner_name='ego' (open loop) is implemented; the rule-based planner is "
+                                  "a CPU component outside the HIP hot path")
+    c = AdvClosure(cur_z, lr, loss_weights, model, scene_graph, map_env, map_idx, embed_info, tgt_prior_distrib,
+                   other_prior_distrib, feasibility_time, feasibility_infront_min, attack_agt_idx=attack_agt_idx,
+                   future_len=future_len, veh_coll_buffer=veh_coll_buffer)
+    for _ in range(num_iters):
+        c.step(log=log)
+    ego_inds, ego_mask, unn, adv_loss, future_len = c.ego_inds, c.ego_mask, c.unn, c.adv_loss, c.future_len
+
+    cur_z = c.collated()
     with torch.no_grad():
         final_decoder_out = model.decode_embedding(cur_z, embed_info, scene_graph, map_idx, map_env, nfuture=future_len)
     final_result_traj = final_decoder_out['future_pred'].unsqueeze(1).clone().detach()

@@ -20,7 +20,7 @@ def run_init_optim(cur_z, init_traj, traj_vis, lr, loss_weights, model, scene_gr
         loss_dict = match_loss(pred, init_traj, cur_z, prior_distrib)
         loss_dict['loss'].backward()
         if log is not None:
-            log(loss_dict)
+            log(loss_dict, cur_z)
         init_optim.step()
     with torch.no_grad():
         init_decoder_out = model.decode_embedding(cur_z, embed_info, scene_graph, map_idx, map_env)

@@ -39,7 +39,7 @@ def run_find_solution_optim(cur_z, final_result_traj, future_len, lr, loss_weigh
         loss = loss_dict['tgt_loss'] + loss_dict['other_loss']
         loss.backward()
         if log is not None:
-            log(loss_dict)
+            log(loss_dict, tgt_z, other_z_all)
         sol_optim.step()
     cur_z = collate_tgt_other_z(scene_graph, tgt_z, other_z_all)
     with torch.no_grad():
