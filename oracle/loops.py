@@ -25,7 +25,8 @@ def collate_tgt_other_z(ptr, tgt_z, other_z):
 
 
 def _trace_entry(z_list, loss_dict):
-    ent = {'z': [z.detach().clone() for z in z_list]}
+    ent = {'z': [z.detach().clone() for z in z_list],
+           'grad': [z.grad.detach().clone() if z.grad is not None else torch.zeros_like(z) for z in z_list]}
     for k, v in loss_dict.items():
         if torch.is_tensor(v):
             ent[k] = v.detach().clone()

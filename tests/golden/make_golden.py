@@ -507,8 +507,125 @@ def g6_loop(R):
         zs.append(npy(z).copy())
     save('g6_loop.npz', z=np.stack(zs), grad=np.stack(grads), losses=np.asarray(losses), loss_keys=np.asarray(keys))
 
-    # the reference's own refine_traffic_optim() function is exercised by tests/test_dropin_reference.py
-    # (build-container only); it draws its starting sample unseeded so it cannot be a fixture.
+    # the reference's own refine_traffic_optim() draws its starting sample unseeded, so it cannot be a fixture; its
+    # init / adv / sol loop functions are run as they are by g6_loops() below, and tests/test_dropin_reference.py
+    # (build container only) executes the reference's loop functions on top of this package's modules.
+
+
+LOOP_WEIGHTS = dict(ADV_WEIGHTS)
+LOOP_WEIGHTS.update({'init_motion_prior_ext': 0.01, 'init_match_ext': 10.0, 'sol_motion_prior': 0.005, 'sol_coll_veh': 10.0,
+                     'sol_coll_env': 10.0, 'sol_motion_prior_ext': 0.001, 'sol_match_ext': 10.0, 'sol_init_z': 0.0})
+LOOP_ITERS = {'u': 10, 't': 5}      # uniform raster (smooth chain, compared tightly) / textured raster (chaotic, loose)
+LOOP_LR = 0.05
+
+
+def loop_rasters(kind):
+    """'u': every pixel drivable, no dividers -> the crop (hence the CNN feature) does not depend on the pose and the whole
+    optimisation chain is smooth; 't': the textured raster of the other fixtures."""
+    if kind == 'u':
+        raster = torch.zeros((1, 4, RASTER_HW, RASTER_HW), dtype=torch.uint8)
+        raster[:, 0] = 1
+        return raster, torch.tensor([[0.25, 0.25]], dtype=torch.float64)
+    return synth.make_raster(RASTER_HW, RASTER_HW)
+
+
+class _LoopRecorder(object):
+    """Harness around the reference's OWN loop functions (they expose no hook): while active, every ``Adam.step`` call
+    records the leaf latents and their gradients as they are BEFORE the update, together with the loss dicts the
+    reference's loss modules returned during that closure."""
+
+    def __init__(self, R, prefixes):
+        self.R, self.prefixes, self.trace, self._cur = R, prefixes, [], {}
+
+    def __enter__(self):
+        rec = self
+        self._orig_step = torch.optim.Adam.step
+        self._orig_fwd = {}
+
+        def step(opt, closure=None):
+            ps = [p for g in opt.param_groups for p in g['params']]
+            ent = {'z': [p.detach().clone() for p in ps], 'grad': [p.grad.detach().clone() for p in ps]}
+            ent.update(rec._cur)
+            rec._cur = {}
+            rec.trace.append(ent)
+            return rec._orig_step(opt, closure)
+        torch.optim.Adam.step = step
+        for cls_name, prefix in self.prefixes.items():
+            cls = getattr(self.R.adv_losses, cls_name)
+            orig = cls.forward
+            self._orig_fwd[cls_name] = orig
+
+            def fwd(mod, *a, _orig=orig, _prefix=prefix, **k):
+                out = _orig(mod, *a, **k)
+                for key, v in out.items():
+                    if torch.is_tensor(v):
+                        rec._cur[_prefix + key] = v.detach().clone()
+                return out
+            cls.forward = fwd
+        return self
+
+    def __exit__(self, *exc):
+        torch.optim.Adam.step = self._orig_step
+        for cls_name, orig in self._orig_fwd.items():
+            getattr(self.R.adv_losses, cls_name).forward = orig
+
+
+def _store_trace(out, tag, trace):
+    keys = sorted(k for k in trace[0] if k not in ('z', 'grad'))
+    out[tag + '/loss_keys'] = np.asarray(keys)
+    out[tag + '/losses'] = np.asarray([[float(torch.mean(e[k])) for k in keys] for e in trace])
+    for i in range(len(trace[0]['z'])):
+        out['%s/z%d' % (tag, i)] = np.stack([npy(e['z'][i]) for e in trace])
+        out['%s/grad%d' % (tag, i)] = np.stack([npy(e['grad'][i]) for e in trace])
+
+
+def g6_loops(R):
+    """The reference's own run_init_optim -> run_adv_gen_optim(planner 'ego') -> run_find_solution_optim on the G5 scene,
+    over the uniform raster (10 iterations each) and the textured one (5 iterations): per iteration the leaf latents,
+    their gradients and the mean of every loss-dict entry; plus each loop's inputs so a test can start any loop from
+    the reference's own state."""
+    import contextlib
+    import io
+    out = {}
+    for kind in ('u', 't'):
+        tm, _ = ref_model(R)
+        batch, map_idx, _, _ = g5_inputs(R, None)
+        raster, dx = loop_rasters(kind)
+        env = ref_map_env(R, raster, dx)
+        n = LOOP_ITERS[kind]
+        with torch.no_grad():
+            emb = R.scenario_gen.detach_embed_info(tm.embed(batch, map_idx, env))
+        NA = batch.past.shape[0]
+        ego = torch.zeros((NA,), dtype=torch.bool)
+        ego[batch.ptr[:-1]] = True
+        pm, pv = emb['prior_out']
+        tp, op = (pm[ego], pv[ego]), (pm[~ego], pv[~ego])
+        z0 = synth.make_latents(pm, pv, key='g6l/z')
+        sink = io.StringIO()
+        with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+            with _LoopRecorder(R, {'TgtMatchingLoss': ''}) as rec:
+                z1, traj1, _ = R.init_optim.run_init_optim(z0, batch.future_gt[:, :, :4], batch.future_vis, LOOP_LR, LOOP_WEIGHTS, tm,
+                                                           batch, env, map_idx, n, emb, emb['prior_out'])
+            _store_trace(out, kind + '/init', rec.trace)
+            z1 = z1.detach()
+            with _LoopRecorder(R, {'TgtMatchingLoss': 'tgt_match_', 'AdvGenLoss': 'adv_'}) as rec:
+                z2, fin, _, agt, tt = R.adv_optim.run_adv_gen_optim(z1, LOOP_LR, LOOP_WEIGHTS, tm, batch, env, map_idx, n, emb, 'ego',
+                                                                    tp, op, 2, 0.0)
+            _store_trace(out, kind + '/adv', rec.trace)
+            z2 = z2.detach()
+            with _LoopRecorder(R, {'AvoidCollLoss': 'tgt_', 'TgtMatchingLoss': 'other_'}) as rec:
+                z3, sol, _ = R.sol_optim.run_find_solution_optim(z2, fin, 16, LOOP_LR, LOOP_WEIGHTS, tm, batch, env, map_idx, n, emb,
+                                                                 tp, op)
+            _store_trace(out, kind + '/sol', rec.trace)
+        out[kind + '/init/z_out'] = npy(z1)
+        out[kind + '/init/traj_out'] = npy(traj1)
+        out[kind + '/adv/z_out'] = npy(z2)
+        out[kind + '/adv/final_result_traj'] = npy(fin)
+        out[kind + '/adv/min_agt'] = np.asarray(agt)
+        out[kind + '/adv/min_t'] = np.asarray(tt)
+        out[kind + '/sol/z_out'] = npy(z3)
+        out[kind + '/sol/traj_out'] = npy(sol)
+    save('g6_loops.npz', **out)
 
 
 def g7_sample(R):
@@ -610,8 +727,8 @@ G8_CASES = [(15.0, 0, 0.0, None, False), (15.0, 2, 0.5, None, True), (25.0, 1, 0
 if __name__ == '__main__':
     torch.set_num_threads(8)
     R = import_reference()
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g6l', 'g7', 'g8', 'g9']
     fns = {'g1': g1_ops, 'g2': g2_crop, 'g3': g3_gnn, 'g4': g4_rollout, 'g5': g5_losses, 'g6': g6_loop, 'g7': g7_sample,
-           'g8': g8_checks, 'g9': g9_wire}
+           'g8': g8_checks, 'g9': g9_wire, 'g6l': g6_loops}
     for w in which:
         fns[w](R)

@@ -1,0 +1,144 @@
+"""Shared by the loop-parity tests: drive the init / adversarial / solution loops of the oracle (CPU) or of the product
+(HIP) from the states stored in tests/golden/g6_loops.npz -- which the reference's OWN loop functions produced
+(make_golden.py::g6_loops) -- and compare the per-iteration traces.
+
+Why two rasters: over the uniform raster ('u') the crop, hence the map feature, does not depend on the pose, so the whole
+chain rollout -> losses -> backward -> Adam is smooth and an independent fp32 implementation must track the reference
+tightly for many iterations.  Over the textured raster ('t') every rollout step re-samples the raster at poses that depend
+on the previous step: a 1e-7 pose difference can flip crop pixels and move a map feature by ~4e-3, and the hard collision
+thresholds amplify further, so only the first closure is comparable entry-wise and later iterations by their loss terms."""
+import numpy as np
+import torch
+
+import make_golden as mg
+from strive_amd import synth
+
+
+def loop_inputs(kind):
+    batch, map_idx, _, _ = mg.g5_inputs(None, None)
+    raster, dx = mg.loop_rasters(kind)
+    return batch, map_idx, raster, dx
+
+
+def loop_start(g, kind, name, emb_prior, ego):
+    """Starting latents of loop `name` = what the reference's previous loop returned (init starts from the injected z0)."""
+    pm, pv = emb_prior
+    if name == 'init':
+        return synth.make_latents(pm, pv, key='g6l/z')
+    if name == 'adv':
+        return torch.from_numpy(g[kind + '/init/z_out'])
+    return torch.from_numpy(g[kind + '/adv/z_out'])
+
+
+def trace_logger(trace):
+    def log(ld, *zs):
+        ent = {'z': [z.detach().cpu().clone() for z in zs], 'grad': [z.grad.detach().cpu().clone() for z in zs]}
+        for k, v in ld.items():
+            if torch.is_tensor(v):
+                ent[k] = v.detach().cpu()
+        trace.append(ent)
+    return log
+
+
+def frac_within(a, b, atol, rtol=0.0):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.mean(np.abs(a - b) <= atol + rtol * np.abs(b)))
+
+
+def compare_trace(trace, g, tag, loss_rtol, loss_atol, grad_rtol, z_atol, z_frac=0.99, n_iters=None, report=None):
+    """`trace[it]` = {'z': [..], 'grad': [..], loss entries} of iteration `it` BEFORE its Adam step, like the fixture.
+
+    * every loss-dict entry (mean) within loss_rtol / loss_atol at every iteration;
+    * gradients: relative L2 error of each leaf's gradient <= grad_rtol;
+    * latents: at least `z_frac` of the entries within z_atol.  (Adam's first steps are lr*g/(|g|+eps): an entry whose
+      gradient is at the noise level can take a +-lr step in either direction, so a small fraction of entries may differ by
+      up to 2*lr while everything else agrees; those entries are near-irrelevant to the loss by construction.)
+    Returns the worst observed figures (for the calibration log)."""
+    keys = [str(k) for k in g[tag + '/loss_keys']]
+    want_losses = g[tag + '/losses']
+    n = len(trace) if n_iters is None else n_iters
+    assert len(trace) >= n and want_losses.shape[0] >= n
+    worst = {'loss_rel': 0.0, 'grad_rel': 0.0, 'z_frac': 1.0, 'z_max': 0.0}
+    nz = len(trace[0]['z'])
+    for it in range(n):
+        assert set(keys) <= set(trace[it].keys()), 'iteration %d: missing loss entries %s' % (it, sorted(set(keys) - set(trace[it])))
+        got = np.array([float(torch.mean(trace[it][k])) for k in keys])
+        want = want_losses[it]
+        rel = np.abs(got - want) / (loss_atol / max(loss_rtol, 1e-30) + np.abs(want))
+        worst['loss_rel'] = max(worst['loss_rel'], float(rel.max()))
+        bad = np.abs(got - want) > loss_atol + loss_rtol * np.abs(want)
+        assert not bad.any(), '%s iteration %d: loss entries off: %s' % (
+            tag, it, ', '.join('%s got %.6g want %.6g' % (keys[i], got[i], want[i]) for i in np.nonzero(bad)[0]))
+        for i in range(nz):
+            gg = trace[it]['grad'][i].double().numpy().reshape(-1)
+            gw = g['%s/grad%d' % (tag, i)][it].astype(np.float64).reshape(-1)
+            gr = float(np.linalg.norm(gg - gw) / max(np.linalg.norm(gw), 1e-30))
+            worst['grad_rel'] = max(worst['grad_rel'], gr)
+            assert gr <= grad_rtol, '%s iteration %d: gradient of leaf %d off by %.3g (relative L2)' % (tag, it, i, gr)
+            zg = trace[it]['z'][i].double().numpy().reshape(-1)
+            zw = g['%s/z%d' % (tag, i)][it].astype(np.float64).reshape(-1)
+            fr = frac_within(zg, zw, z_atol)
+            worst['z_frac'] = min(worst['z_frac'], fr)
+            worst['z_max'] = max(worst['z_max'], float(np.abs(zg - zw).max()))
+            assert fr >= z_frac, '%s iteration %d: only %.4f of the latent entries of leaf %d within %.1e' % (tag, it, fr, i, z_atol)
+    if report is not None:
+        report.append((tag, n, worst))
+    return worst
+
+
+def run_oracle_loop(name, kind, g, orc, n):
+    from oracle import loops
+    batch, map_idx, raster, dx = loop_inputs(kind)
+    env = synth.SyntheticMapEnv(raster, dx)
+    with torch.no_grad():
+        emb = orc.embed(batch, map_idx, env)
+    NA = batch.past.shape[0]
+    ego = torch.zeros((NA,), dtype=torch.bool)
+    ego[batch.ptr[:-1]] = True
+    pm, pv = emb['prior_out']
+    tp, op = (pm[ego], pv[ego]), (pm[~ego], pv[~ego])
+    z = loop_start(g, kind, name, emb['prior_out'], ego)
+    trace = []
+    if name == 'init':
+        loops.init_loop(orc, batch, map_idx, env, emb, z, batch.future_gt[:, :, :4], batch.future_vis, mg.LOOP_WEIGHTS, n, mg.LOOP_LR,
+                        emb['prior_out'], trace=trace)
+    elif name == 'adv':
+        loops.adv_loop(orc, batch, map_idx, env, emb, z, mg.LOOP_WEIGHTS, n, mg.LOOP_LR, tp, op, feasibility_time=2,
+                       feasibility_infront_min=0.0, trace=trace)
+    else:
+        fin = torch.from_numpy(g[kind + '/adv/final_result_traj'])
+        loops.sol_loop(orc, batch, map_idx, env, emb, z, fin, 16, mg.LOOP_WEIGHTS, n, mg.LOOP_LR, tp, op, trace=trace)
+    return trace
+
+
+def run_product_loop(name, kind, g, m, n, device, embed_from=None):
+    """The product's loop functions (strive_amd.utils.*_optim) on `device`; the embed outputs come from the product's own
+    embed() unless `embed_from` (an oracle) is given."""
+    from strive_amd.utils.init_optim import run_init_optim
+    from strive_amd.utils.adv_gen_optim import run_adv_gen_optim
+    from strive_amd.utils.sol_optim import run_find_solution_optim
+    from strive_amd.utils.scenario_gen import detach_embed_info
+    batch, map_idx, raster, dx = loop_inputs(kind)
+    env = synth.SyntheticMapEnv(raster.clone(), dx.clone()).to(device)
+    bg = batch.clone().to(device)
+    mi = map_idx.to(device)
+    with torch.no_grad():
+        emb = detach_embed_info(m.embed(bg, mi, env))
+    NA = bg.past.shape[0]
+    ego = torch.zeros((NA,), dtype=torch.bool, device=device)
+    ego[bg.ptr[:-1].to(device)] = True
+    pm, pv = emb['prior_out']
+    tp, op = (pm[ego], pv[ego]), (pm[~ego], pv[~ego])
+    z = loop_start(g, kind, name, (pm.cpu(), pv.cpu()), ego.cpu()).to(device)
+    trace = []
+    log = trace_logger(trace)
+    if name == 'init':
+        res = run_init_optim(z, bg.future_gt[:, :, :4], bg.future_vis, mg.LOOP_LR, mg.LOOP_WEIGHTS, m, bg, env, mi, n, emb,
+                             emb['prior_out'], log=log)
+    elif name == 'adv':
+        res = run_adv_gen_optim(z, mg.LOOP_LR, mg.LOOP_WEIGHTS, m, bg, env, mi, n, emb, 'ego', tp, op, 2, 0.0, log=log)
+    else:
+        fin = torch.from_numpy(g[kind + '/adv/final_result_traj']).to(device)
+        res = run_find_solution_optim(z, fin, 16, mg.LOOP_LR, mg.LOOP_WEIGHTS, m, bg, env, mi, n, emb, tp, op, log=log)
+    return trace, res
