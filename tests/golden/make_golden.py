@@ -338,6 +338,45 @@ def g4_rollout(R):
     save('g4_rollout.npz', **out)
 
 
+G4B_SIZES = [4, 2, 1]
+
+
+def g4b_nc5(R):
+    """NC = 5 semantic classes (reduce_cats, reference configs/adv_gen_replay_cyclist.cfg:15-16): every sem-bearing input
+    of the networks grows (decoder node input 167, edge input 142).  embed + FT = 12 rollout forward and d/dz."""
+    out = {}
+    tm, _ = ref_model(R, NC=5, key='weights5')
+    batch, map_idx, raster, dx = build_inputs(G4B_SIZES, 'g4b', NC=5)
+    env = ref_map_env(R, raster, dx)
+    with torch.no_grad():
+        emb = R.scenario_gen.detach_embed_info(tm.embed(batch, map_idx, env))
+    out['map_feat'] = npy(emb['map_feat'])
+    out['past_feat'] = npy(emb['past_feat'])
+    out['prior_mu'] = npy(emb['prior_out'][0])
+    out['prior_var'] = npy(emb['prior_out'][1])
+    out['post_mu'] = npy(emb['posterior_out'][0])
+    out['post_var'] = npy(emb['posterior_out'][1])
+    z = synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='g4b/z').requires_grad_(True)
+    pred = tm.decode_embedding(z, emb, batch, map_idx, env)['future_pred']
+    rw = synth.f32(synth.counter_uniform(tuple(pred.shape), 'g4b/r', -1.0, 1.0))
+    gz, = torch.autograd.grad((pred * rw).sum(), [z])
+    out['pred'] = npy(pred)
+    out['gz'] = npy(gz)
+    # the same over the uniform raster (smooth chain: compared tightly on the GPU)
+    uraster, udx = loop_rasters('u')
+    uenv = ref_map_env(R, uraster, udx)
+    with torch.no_grad():
+        uemb = R.scenario_gen.detach_embed_info(tm.embed(batch, map_idx, uenv))
+    out['u_map_feat'] = npy(uemb['map_feat'])
+    out['u_past_feat'] = npy(uemb['past_feat'])
+    z = synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='g4b/z').requires_grad_(True)
+    pred = tm.decode_embedding(z, uemb, batch, map_idx, uenv)['future_pred']
+    gz, = torch.autograd.grad((pred * rw).sum(), [z])
+    out['u_pred'] = npy(pred)
+    out['u_gz'] = npy(gz)
+    save('g4b_nc5.npz', **out)
+
+
 G5_SIZES = [4, 6, 2]
 ADV_WEIGHTS = {'coll_veh': 20.0, 'coll_veh_plan': 20.0, 'coll_env': 20.0, 'init_z': 0.5, 'init_z_atk': 0.05,
                'motion_prior': 1.0, 'motion_prior_atk': 0.005, 'motion_prior_ext': 0.0001, 'match_ext': 10.0,
@@ -727,8 +766,8 @@ G8_CASES = [(15.0, 0, 0.0, None, False), (15.0, 2, 0.5, None, True), (25.0, 1, 0
 if __name__ == '__main__':
     torch.set_num_threads(8)
     R = import_reference()
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g6l', 'g7', 'g8', 'g9']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g4b', 'g5', 'g6', 'g6l', 'g7', 'g8', 'g9']
     fns = {'g1': g1_ops, 'g2': g2_crop, 'g3': g3_gnn, 'g4': g4_rollout, 'g5': g5_losses, 'g6': g6_loop, 'g7': g7_sample,
-           'g8': g8_checks, 'g9': g9_wire, 'g6l': g6_loops}
+           'g8': g8_checks, 'g9': g9_wire, 'g6l': g6_loops, 'g4b': g4b_nc5}
     for w in which:
         fns[w](R)

@@ -95,10 +95,10 @@ def test_map_cnn_one_agent(emu, sd):
     assert_close(feat, want, 1e-4, 1e-5, 'cnn')
 
 
-def _rollout(emu, sd, sizes, FT, NS=1, ext=False):
-    batch, map_idx, raster, dx = mg.build_inputs(sizes, 'emu')
+def _rollout(emu, sd, sizes, FT, NS=1, ext=False, NC=2):
+    batch, map_idx, raster, dx = mg.build_inputs(sizes, 'emu', NC=NC)
     env = synth.SyntheticMapEnv(raster, dx)
-    orc = oracle_model(sd)
+    orc = oracle_model(sd, NC=NC)
     with torch.no_grad():
         emb = orc.embed(batch, map_idx, env) if FT > 1 else None
     NA = batch.past.shape[0]
@@ -115,7 +115,7 @@ def _rollout(emu, sd, sizes, FT, NS=1, ext=False):
     rw = synth.f32(synth.counter_uniform(tuple(pred.shape), 'emu/rw', -1.0, 1.0))
     gz, = torch.autograd.grad((pred * rw).sum(), [z])
     sn, an = orc.get_normalizer(), orc.get_att_normalizer()
-    dec = params.pack_decoder(sd, 2, env, 'cpu', sn, an, NUSC_BIKE_PARAMS)
+    dec = params.pack_decoder(sd, NC, env, 'cpu', sn, an, NUSC_BIKE_PARAMS)
     sc = params.pack_scenes(batch.ptr, NS, 'cpu')
     R = NA * NS
     tb = emu.query('strive_rollout_tape_bytes', dec.ref(), sc.ref(), FT)
@@ -139,6 +139,13 @@ def _rollout(emu, sd, sizes, FT, NS=1, ext=False):
 def test_rollout_single_step(emu, sd, sizes, NS, ext):
     """FT = 1: GNN + bicycle + local transform and their adjoints (no CNN / GRU in a single step)."""
     _rollout(emu, sd, sizes, 1, NS=NS, ext=ext)
+
+
+def test_rollout_single_step_five_classes(emu):
+    """NC = 5 (reduce_cats): node input 167, edge input 142 -- every sem-bearing offset of the kernels moves."""
+    sd5 = product_model(NC=5, key='weights5')[1]
+    _rollout(emu, sd5, [3, 1, 4], 1, NC=5)
+    _rollout(emu, sd5, [2, 3], 1, NS=2, NC=5)
 
 
 def test_rollout_two_steps(emu, sd):

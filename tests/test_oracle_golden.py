@@ -159,6 +159,29 @@ def test_g4_rollout(g4_setup, case):
     assert_close(gz, g[gk], 1e-3, 1e-6, gk)
 
 
+def test_g4b_nc5():
+    """NC = 5 (reduce_cats): embed + rollout forward / d/dz of the oracle vs the reference, textured and uniform raster."""
+    g = golden('g4b_nc5.npz')
+    sd5 = product_model(NC=5, key='weights5')[1]
+    orc = oracle_model(sd5, NC=5)
+    batch, map_idx, raster, dx = mg.build_inputs(mg.G4B_SIZES, 'g4b', NC=5)
+    for pre, (ra, dxx) in (('', (raster, dx)), ('u_', mg.loop_rasters('u'))):
+        env = synth.SyntheticMapEnv(ra, dxx)
+        with torch.no_grad():
+            emb = orc.embed(batch, map_idx, env)
+        assert_close(emb['map_feat'], g[pre + 'map_feat'], RT, AT, 'map_feat')
+        assert_close(emb['past_feat'], g[pre + 'past_feat'], RT, AT, 'past_feat')
+        if not pre:
+            assert_close(emb['prior_out'][0], g['prior_mu'], RT, AT, 'prior mu')
+            assert_close(emb['posterior_out'][1], g['post_var'], RT, AT, 'post var')
+        z = synth.make_latents(torch.from_numpy(g['prior_mu']), torch.from_numpy(g['prior_var']), key='g4b/z').requires_grad_(True)
+        pred = orc.decode_embedding(z, emb, batch, map_idx, env)['future_pred']
+        rw = synth.f32(synth.counter_uniform(tuple(pred.shape), 'g4b/r', -1.0, 1.0))
+        gz, = torch.autograd.grad((pred * rw).sum(), [z])
+        assert_close(pred, g[pre + 'pred'], RT, AT, pre + 'pred')
+        assert_close(gz, g[pre + 'gz'], 1e-3, 1e-6, pre + 'gz')
+
+
 @pytest.fixture(scope='module')
 def g5_setup(sd):
     batch, map_idx, raster, dx = mg.g5_inputs(None, None)
