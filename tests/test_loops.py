@@ -9,7 +9,7 @@ gradients and every loss-dict entry, over a uniform raster (10 iterations, smoot
     bit for bit for all iterations, the init loop to 1e-5: this pins Adam's hyper-parameters, zero_grad, the
     complementary-detach two-rollout scheme and the nfuture choices of the restatement.
   * GPU (-m gpu): the product's loop functions (HIP rollouts + HIP losses) against the same fixture -- tight on the uniform
-    raster for all 10 iterations including the latents (no tolerance above 3 %), loose on the textured raster -- and the
+    raster for all 10 iterations including the latents (no tolerance above 2 %), loose on the textured raster -- and the
     refine loop against the oracle's on the uniform raster.
 """
 import json
@@ -80,27 +80,27 @@ def _dump_report():
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', ['init', 'adv', 'sol'])
 def test_product_loops_uniform_raster_tight(fixture, model, name):
-    """10 iterations of the product's loop against the reference's own, smooth chain: every loss entry within 3 %
-    (+1e-3 abs for entries that are ~0), every gradient within 3 % (relative L2), >= 99 % of the latent entries within
-    2e-3 after every step."""
+    """10 iterations of the product's loop against the reference's own, smooth chain: every loss entry within 0.2 %
+    (+1e-4 abs for entries that are ~0), every gradient within 2 % (relative L2), >= 99.5 % of the latent entries within
+    1e-3 after every step.  (Measured on the MI355X, r02: losses 6e-5, gradients 3e-3, latents 2e-4 at worst.)"""
     m, _ = model
     n = mg.LOOP_ITERS['u']
     trace, res = lu.run_product_loop(name, 'u', fixture, m, n, DEV)
-    w = lu.compare_trace(trace, fixture, 'u/' + name, 3e-2, 1e-3, 3e-2, 2e-3, z_frac=0.99, report=REPORT)
+    w = lu.compare_trace(trace, fixture, 'u/' + name, 2e-3, 1e-4, 2e-2, 1e-3, z_frac=0.995, report=REPORT)
     print('loop u/%s: %s' % (name, w))
     _dump_report()
     if name == 'adv':
         z, fin, _, agt, tt = res
         assert np.array_equal(np.asarray(agt), fixture['u/adv/min_agt']) and np.array_equal(np.asarray(tt), fixture['u/adv/min_t'])
-        assert lu.frac_within(z.cpu().numpy(), fixture['u/adv/z_out'], 2e-3) >= 0.99
+        assert lu.frac_within(z.detach().cpu().numpy(), fixture['u/adv/z_out'], 1e-3) >= 0.995
         assert_close(fin, fixture['u/adv/final_result_traj'], 0, 2e-3, 'final_result_traj')
     elif name == 'sol':
         z, sol, _ = res
-        assert lu.frac_within(z.cpu().numpy().reshape(-1), fixture['u/sol/z_out'].reshape(-1), 2e-3) >= 0.99
+        assert lu.frac_within(z.detach().cpu().numpy().reshape(-1), fixture['u/sol/z_out'].reshape(-1), 1e-3) >= 0.995
         assert_close(sol, fixture['u/sol/traj_out'], 0, 2e-3, 'sol_result_traj')
     else:
         z, traj, _ = res
-        assert lu.frac_within(z.cpu().numpy(), fixture['u/init/z_out'], 2e-3) >= 0.99
+        assert lu.frac_within(z.detach().cpu().numpy(), fixture['u/init/z_out'], 1e-3) >= 0.995
         assert_close(traj, fixture['u/init/traj_out'], 0, 2e-3, 'init_result_traj')
 
 
@@ -142,6 +142,6 @@ def test_refine_loop_uniform_raster_tight(model):
     env_g = synth.SyntheticMapEnv(raster.clone(), dx.clone()).to(DEV)
     _, z_fin, _, _ = refine_traffic_optim(batch.clone().to(DEV), map_idx.to(DEV), env_g, m, mg.REFINE_WEIGHTS, 10, 16, 12, True, 0.05,
                                           z_init=z0.to(DEV), log=lu.trace_logger(trace))
-    w = lu.compare_trace(trace, g, 'r', 3e-2, 1e-3, 3e-2, 2e-3, z_frac=0.99, report=REPORT)
+    w = lu.compare_trace(trace, g, 'r', 2e-3, 1e-4, 2e-2, 1e-3, z_frac=0.995, report=REPORT)
     print('loop refine (uniform): %s' % w)
     _dump_report()

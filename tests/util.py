@@ -45,3 +45,16 @@ def assert_close(a, b, rtol, atol, what=''):
         i = np.unravel_index(np.argmax(err - tol), err.shape)
         raise AssertionError('%s: %d/%d entries off; worst at %s: got %.8g want %.8g (|d|=%.3g)' %
                              (what, bad.sum(), bad.size, i, a[i], b[i], err[i]))
+
+
+def assert_close_frac(a, b, rtol, atol, frac, hard_atol, what=''):
+    """Gradients through max-aggregation / LayerNorm-ReLU kinks: a 1e-6 difference can move an arg-max between two
+    near-tied messages and change a handful of gradient entries at O(1) relative level while everything else agrees.
+    At least `frac` of the entries must be within (rtol, atol) and every entry within hard_atol."""
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, '%s: shape %s vs %s' % (what, a.shape, b.shape)
+    err = np.abs(a - b)
+    ok = float(np.mean(err <= atol + rtol * np.abs(b)))
+    assert ok >= frac, '%s: only %.4f of the entries within rtol %.1e / atol %.1e' % (what, ok, rtol, atol)
+    assert float(err.max()) <= hard_atol, '%s: worst entry off by %.3g (> %.3g)' % (what, float(err.max()), hard_atol)
