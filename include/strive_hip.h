@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define STRIVE_ABI_VERSION 5
+#define STRIVE_ABI_VERSION 6
 #define STRIVE_HID 128        /* hidden width of every MLP in the reference (models/common.py, interaction_net.py:32,41) */
 #define STRIVE_MAX_LAYERS 4
 #define STRIVE_ZDIM 32
@@ -114,6 +114,8 @@ typedef struct StriveCNN {
                                   79872 / 319488 / 245760 / 491520 / 983040 bytes */
     const uint32_t* w5_frag;
     const uint32_t* w6_frag;
+    const float* w_torch[6];   /* the convolution weights in torch layout (co, ci, ky, kx): read by the training backward's
+                                  data-gradient kernel only (may be NULL on the latent-optimisation path) */
 } StriveCNN;
 
 /* Scene structure of a batch: agents of scene b are rows ptr[b] .. ptr[b+1]-1, ego first
@@ -250,6 +252,55 @@ int strive_interp_traj_bwd(const float* in, const float* d_out, int32_t N, int32
  * (reference src/losses/adv_gen_nusc.py:517-623; corners as src/datasets/nuscenes_utils.py:416-428). */
 int strive_rect_iou(const float* box_a, const float* lw_a, const float* box_b, const float* lw_b, int32_t P, double* iou,
                     strive_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training backward (weight gradients) -- reference src/train_traffic.py:103-131 calls loss.backward() through
+ * TrafficModel.forward (src/models/traffic_model.py:178-225).
+ *
+ * Gradient buffers are flat fp32 arrays in the parameter order of the reference module (torch named_parameters()),
+ * ACCUMULATED into (the caller zeroes them):
+ *   MLP  (models/common.py:8-44):      per layer l:  W_l (dims[l+1], dims[l]) | b_l | and for hidden layers LN gamma_l | beta_l
+ *   GNN  (models/interaction_net.py):  mlp_in | msg.0.edge_mlp | msg.0.update_mlp | mlp_out
+ *   GRU  (nn.GRU(4, 64, 3)):           per layer: weight_ih (192, in_l) | weight_hh (192, 64) | bias_ih | bias_hh
+ *   CNN  (traffic_model.py:69-87):     per layer: conv W (co, ci, k, k) | conv b | GroupNorm gamma | beta;  then Linear W (64, 512) | b
+ * Weight gradients are summed with fp32 atomics (their summation order is not fixed run to run); input gradients are
+ * deterministic.
+ * ---------------------------------------------------------------------------------------------- */
+size_t strive_mlp_param_count(const StriveMLP* mlp);
+size_t strive_gnn_param_count(const StriveGNN* gnn);
+size_t strive_gru_param_count(void);
+size_t strive_map_cnn_param_count(void);
+
+/* MLP.forward under autograd (reference src/models/common.py:41-44): dy (rows, out) -> d_params (+=) and, if dx != NULL,
+ * dx (rows, in).  The forward is recomputed from x. */
+int strive_mlp_bwd(const StriveMLP* mlp, const float* x, const float* dy, int32_t rows, float* dx, float* d_params,
+                   strive_stream_t stream);
+
+size_t strive_gnn_bwd_workspace_bytes(const StriveGNN* gnn, const StriveScenes* sc);
+
+/* SceneInteractionNet.forward under autograd (reference src/models/interaction_net.py:52-77): d_out (R, out) ->
+ * dx (R, mlp_in.dims[0]) and d_params (+=).  pos carries no gradient here (the encoders are called at data poses). */
+int strive_gnn_bwd(const StriveGNN* gnn, const StriveScenes* sc, const float* x, const float* pos, const float* sem,
+                   const float* d_out, float* dx, float* d_params, void* ws, size_t ws_bytes, strive_stream_t stream);
+
+size_t strive_map_cnn_bwd_workspace_bytes(int32_t N);
+
+/* encode_map under autograd (reference src/models/traffic_model.py:416-451; the crop is data): d_feat (N,64) at the N
+ * poses `pos` -> d_params (+=).  The forward is recomputed in chunks inside. */
+int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, const float* pos, const float* pos_mean4_host,
+                       const float* pos_std4_host, const int32_t* mapix, int32_t N, const float* d_feat, float* d_params,
+                       void* ws, size_t ws_bytes, strive_stream_t stream);
+
+size_t strive_rollout_train_workspace_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT);
+
+/* autoregressive_decoder under autograd with parameter gradients (reference src/models/traffic_model.py:589-704 as used
+ * by forward(), :178-225): like strive_rollout_bwd, plus d_past_feat, d_map_feat (NA,64) -- the adjoints of the encoder
+ * outputs the rollout starts from -- and the gradients of decoder_net (d_gnn), decoder_memory (d_gru) and of the map CNN
+ * (d_cnn: every step t >= 1 re-encodes the map at the detached pose, :694-695), all (+=).  NS must be 1. */
+int strive_rollout_bwd_train(const StriveDecoder* dec, const StriveScenes* sc, const float* lw, const float* sem,
+                             const float* z, const float* ext_future, const int32_t* mapix, int32_t FT, const float* d_traj,
+                             float* dz, float* d_past_feat, float* d_map_feat, float* d_gnn, float* d_gru, float* d_cnn,
+                             const void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, strive_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -50,7 +50,8 @@ class StriveMap(C.Structure):
 class StriveCNN(C.Structure):
     _fields_ = [('w', C.c_void_p * 6), ('b', C.c_void_p * 6), ('gn_g', C.c_void_p * 6), ('gn_b', C.c_void_p * 6),
                 ('fc_wt', C.c_void_p), ('fc_b', C.c_void_p), ('w1_frag', C.c_void_p),
-                ('w2_frag', C.c_void_p), ('w3_frag', C.c_void_p), ('w4_frag', C.c_void_p), ('w5_frag', C.c_void_p), ('w6_frag', C.c_void_p)]
+                ('w2_frag', C.c_void_p), ('w3_frag', C.c_void_p), ('w4_frag', C.c_void_p), ('w5_frag', C.c_void_p), ('w6_frag', C.c_void_p),
+                ('w_torch', C.c_void_p * 6)]
 
 
 class StriveScenes(C.Structure):
@@ -96,10 +97,22 @@ PROTOTYPES = {
     'strive_interp_traj_bwd': (C.c_int, [P, P, I, I, I, I, P, P, P, P, P, P]),
     'strive_rect_iou': (C.c_int, [P, P, P, P, I, P, P]),
     'strive_veh_coll_bwd': (C.c_int, [C.POINTER(StriveScenes), P, I, P, I, P, P, C.c_float, P, P, P, P]),
+    'strive_mlp_param_count': (SZ, [C.POINTER(StriveMLP)]),
+    'strive_gnn_param_count': (SZ, [C.POINTER(StriveGNN)]),
+    'strive_gru_param_count': (SZ, []),
+    'strive_map_cnn_param_count': (SZ, []),
+    'strive_mlp_bwd': (C.c_int, [C.POINTER(StriveMLP), P, P, I, P, P, P]),
+    'strive_gnn_bwd_workspace_bytes': (SZ, [C.POINTER(StriveGNN), C.POINTER(StriveScenes)]),
+    'strive_gnn_bwd': (C.c_int, [C.POINTER(StriveGNN), C.POINTER(StriveScenes), P, P, P, P, P, P, P, SZ, P]),
+    'strive_map_cnn_bwd_workspace_bytes': (SZ, [I]),
+    'strive_map_cnn_bwd': (C.c_int, [C.POINTER(StriveMap), C.POINTER(StriveCNN), P, F4, F4, P, I, P, P, P, SZ, P]),
+    'strive_rollout_train_workspace_bytes': (SZ, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), I]),
+    'strive_rollout_bwd_train': (C.c_int, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), P, P, P, P, P, I, P, P, P, P, P, P, P,
+                                           P, SZ, P, SZ, P]),
 }
 
 
-ABI_VERSION = 5   # include/strive_hip.h STRIVE_ABI_VERSION
+ABI_VERSION = 6   # include/strive_hip.h STRIVE_ABI_VERSION
 
 
 class StriveLib(object):

@@ -1086,3 +1086,5 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
     STRIVE_CHECK_LAUNCH();
     return 0;
 }
+
+#include "map_cnn_bwd.h"

@@ -1,0 +1,448 @@
+// Map CNN backward for the TRAINING path (reference src/train_traffic.py:103-131 back-propagates the reconstruction / KL /
+// collision losses into map_conv.* and map_feature.*; the latent-optimisation loops never come here: the reference crops at
+// pos.detach(), traffic_model.py:694, so dL/dz needs no CNN backward).
+//
+// Included at the end of map_cnn.hip (it re-uses the forward's workspace carve-up, GroupNorm statistics and layer table).
+// The forward of a chunk of samples is re-run to regenerate the raw convolution outputs y_l and their GroupNorm moments
+// (nothing is kept from the rollout's forward sweep: 1.76 MB per agent and step), then per layer, top down:
+//     GroupNorm(1)+ReLU backward in place on G_l   (moments from the forward's float64 partial sums)
+//     weight gradient   dW_l[co][ci][ky][kx] += sum_{n,oy,ox} dy_l[n][co][oy][ox] * a_{l-1}[n][ci][2 oy + ky][2 ox + kx]
+//     data gradient     G_{l-1}[n][ci][iy][ix] = sum_{co,ky,kx} dy_l[n][co][(iy-ky)/2][(ix-kx)/2] * W_l[co][ci][ky][kx]
+// Both convolution gradients are implicit GEMMs on one fp32 64 x 64 x 16 LDS-tiled kernel whose operand tiles are fetched
+// through small functors (im2col indexing, GroupNorm + ReLU of the layer input applied on the way in, like the forward does);
+// the stride-2 data gradient is split into the 4 input-pixel parity classes so that no multiply is spent on structurally
+// zero taps.  Weight gradients are split over K (samples x output pixels) and accumulated with fp32 atomics into the flat
+// gradient buffer (parameter order of the reference module).  This path is correct-first: fp32 FMA, not yet on the matrix
+// cores (DESIGN.md lists it under "next").
+#pragma once
+
+namespace cnnbwd {
+
+constexpr int LC_IN[6] = {4, 16, 32, 64, 64, 128};
+constexpr int LC_OUT[6] = {16, 32, 64, 64, 128, 128};
+constexpr int LKS[6] = {7, 5, 5, 3, 3, 3};
+constexpr int LIH[6] = {256, 125, 61, 29, 14, 6};
+constexpr int LOH[6] = {125, 61, 29, 14, 6, 2};
+constexpr bool LOCT[6] = {true, true, true, true, true, false};   // layout of the forward's raw output of layer l
+
+struct LayerDesc {
+    int cin, cout, ks, ih, oh;
+    bool in_oct, out_oct;    // layouts of the forward's activations: layer input (= output of l-1) and output
+};
+
+static inline LayerDesc layer_desc(int l) {
+    LayerDesc d;
+    d.cin = LC_IN[l]; d.cout = LC_OUT[l]; d.ks = LKS[l]; d.ih = LIH[l]; d.oh = LOH[l];
+    d.in_oct = l > 0 ? LOCT[l - 1] : false;
+    d.out_oct = LOCT[l];
+    return d;
+}
+
+// element (n, c, y, x) of a forward activation tensor with C channels and H x H pixels
+__device__ __forceinline__ size_t act_index(bool oct, int C, int H, int n, int c, int y, int x) {
+    if (oct) return ((((size_t)n * (C >> 3) + (c >> 3)) * H + y) * H + x) * 8 + (c & 7);
+    return (((size_t)n * C + c) * H + y) * H + x;
+}
+
+// ---- per-sample GroupNorm moments of one layer: MR[n] = (mean, rstd) ----
+static __global__ void moments_kernel(const GNStats* __restrict__ st, int nparts, double count, float2* __restrict__ mr, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float mean, rstd;
+    gn_moments(st, n, nparts, count, mean, rstd);
+    mr[n] = make_float2(mean, rstd);
+}
+
+// ---- Linear(512, 64) + GroupNorm6/ReLU input: G5 <- d a6 = W^T d feat;  dW += d feat^T a6;  db += sum d feat ----
+// grid = ceil(N / 8); 8 samples per workgroup so that every weight-gradient atomic carries 8 samples
+static __global__ __launch_bounds__(256) void fc_bwd_kernel(const float* __restrict__ y6, const float2* __restrict__ mr,
+                                                              const float* __restrict__ gn_g, const float* __restrict__ gn_b,
+                                                              const float* __restrict__ wt /* (512,64) */, const float* __restrict__ d_feat,
+                                                              float* __restrict__ G5, float* __restrict__ dW /* (64,512) */,
+                                                              float* __restrict__ db, int N) {
+    __shared__ float s_a[8][512];
+    __shared__ float s_d[8][64];
+    const int n0 = blockIdx.x * 8, tid = threadIdx.x;
+    const int ns = (N - n0) < 8 ? (N - n0) : 8;
+    for (int i = tid; i < 8 * 512; i += 256) {
+        const int s = i >> 9, k = i & 511;
+        float v = 0.f;
+        if (s < ns) {
+            const int c = k >> 2;
+            const float2 m = mr[n0 + s];
+            const float xh = (y6[(size_t)(n0 + s) * 512 + k] - m.x) * m.y;
+            v = fmaxf(xh * gn_g[c] + gn_b[c], 0.f);
+        }
+        s_a[s][k] = v;
+    }
+    for (int i = tid; i < 8 * 64; i += 256) {
+        const int s = i >> 6, o = i & 63;
+        s_d[s][o] = s < ns ? d_feat[(size_t)(n0 + s) * 64 + o] : 0.f;
+    }
+    __syncthreads();
+    // data gradient (w.r.t. the post-ReLU activation a6; the ReLU / GroupNorm part follows in the layer-5 GN backward)
+    for (int i = tid; i < 8 * 512; i += 256) {
+        const int s = i >> 9, k = i & 511;
+        if (s < ns) {
+            float acc = 0.f;
+            for (int o = 0; o < 64; ++o) acc = fmaf(s_d[s][o], wt[(size_t)k * 64 + o], acc);
+            G5[(size_t)(n0 + s) * 512 + k] = acc;
+        }
+    }
+    // weight gradient: lanes over k (consecutive addresses of one output row)
+    for (int i = tid; i < 64 * 512; i += 256) {
+        const int o = i >> 9, k = i & 511;
+        float acc = 0.f;
+        for (int s = 0; s < ns; ++s) acc = fmaf(s_d[s][o], s_a[s][k], acc);
+        if (acc != 0.f) unsafeAtomicAdd(&dW[i], acc);
+    }
+    if (tid < 64) {
+        float acc = 0.f;
+        for (int s = 0; s < ns; ++s) acc += s_d[s][tid];
+        if (acc != 0.f) unsafeAtomicAdd(&db[tid], acc);
+    }
+}
+
+// ---- GroupNorm(1) + ReLU backward, pass 1: G <- dn = da * [pre > 0];  S[n] += (sum dn*gamma, sum dn*gamma*xhat);
+//      dgamma[c] += sum dn*xhat, dbeta[c] += sum dn.   grid = (blocks per sample, N); G is NCHW.
+static __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(LayerDesc d, const float* __restrict__ y, const float2* __restrict__ mr,
+                                                                     const float* __restrict__ gam, const float* __restrict__ bet,
+                                                                     float* __restrict__ G, double* __restrict__ S,
+                                                                     float* __restrict__ dgam, float* __restrict__ dbet) {
+    __shared__ float s_dg[128], s_db[128];
+    __shared__ double s_s[2][4];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int HW = d.oh * d.oh, M = d.cout * HW;
+    const int per = (M + gridDim.x - 1) / gridDim.x;
+    const int e0 = blockIdx.x * per, e1 = (e0 + per) < M ? (e0 + per) : M;
+    if (tid < 128) { s_dg[tid] = 0.f; s_db[tid] = 0.f; }
+    __syncthreads();
+    const float2 m = mr[n];
+    double s1 = 0.0, s2 = 0.0;
+    for (int e = e0 + tid; e < e1; e += 256) {
+        const int c = e / HW, p = e - c * HW;
+        const int yy = p / d.oh, xx = p - yy * d.oh;
+        const float xh = (y[act_index(d.out_oct, d.cout, d.oh, n, c, yy, xx)] - m.x) * m.y;
+        const float pre = xh * gam[c] + bet[c];
+        const size_t gi = (size_t)n * M + e;
+        const float dn = pre > 0.f ? G[gi] : 0.f;
+        G[gi] = dn;
+        if (dn != 0.f) {
+            const float dg = dn * gam[c];
+            s1 += (double)dg;
+            s2 += (double)dg * (double)xh;
+            atomicAdd(&s_dg[c], dn * xh);
+            atomicAdd(&s_db[c], dn);
+        }
+    }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if ((tid & 63) == 0) { s_s[0][tid >> 6] = s1; s_s[1][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        unsafeAtomicAdd(&S[2 * n + 0], (s_s[0][0] + s_s[0][1]) + (s_s[0][2] + s_s[0][3]));
+        unsafeAtomicAdd(&S[2 * n + 1], (s_s[1][0] + s_s[1][1]) + (s_s[1][2] + s_s[1][3]));
+    }
+    if (tid < d.cout) {
+        if (s_dg[tid] != 0.f) unsafeAtomicAdd(&dgam[tid], s_dg[tid]);
+        if (s_db[tid] != 0.f) unsafeAtomicAdd(&dbet[tid], s_db[tid]);
+    }
+}
+
+// ---- pass 2: G <- dy = rstd * (dn*gamma - S1/M - xhat*S2/M);  conv bias gradient db[c] += sum dy ----
+static __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(LayerDesc d, const float* __restrict__ y, const float2* __restrict__ mr,
+                                                                    const float* __restrict__ gam, float* __restrict__ G,
+                                                                    const double* __restrict__ S, float* __restrict__ dbias) {
+    __shared__ float s_db[128];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int HW = d.oh * d.oh, M = d.cout * HW;
+    const int per = (M + gridDim.x - 1) / gridDim.x;
+    const int e0 = blockIdx.x * per, e1 = (e0 + per) < M ? (e0 + per) : M;
+    if (tid < 128) s_db[tid] = 0.f;
+    __syncthreads();
+    const float2 m = mr[n];
+    const float a1 = (float)(S[2 * n + 0] / (double)M), a2 = (float)(S[2 * n + 1] / (double)M);
+    for (int e = e0 + tid; e < e1; e += 256) {
+        const int c = e / HW, p = e - c * HW;
+        const int yy = p / d.oh, xx = p - yy * d.oh;
+        const float xh = (y[act_index(d.out_oct, d.cout, d.oh, n, c, yy, xx)] - m.x) * m.y;
+        const size_t gi = (size_t)n * M + e;
+        const float dy = m.y * (G[gi] * gam[c] - a1 - xh * a2);
+        G[gi] = dy;
+        atomicAdd(&s_db[c], dy);
+    }
+    __syncthreads();
+    if (tid < d.cout && s_db[tid] != 0.f) unsafeAtomicAdd(&dbias[tid], s_db[tid]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 implicit GEMM:  C[m][j] (+)= sum_k A(m, k) * B(k, j),  64 x 64 tile per workgroup, K in steps of 16, 256 threads,
+// 4 x 4 outputs per thread (rows ty + 16 i, columns tx + 16 j).  P supplies M, N, the K range of this workgroup and the
+// element functors; out-of-range elements read as 0.
+// ---------------------------------------------------------------------------------------------
+template <class P>
+static __global__ __launch_bounds__(256) void igemm64_kernel(P p) {
+    __shared__ float As[16][68];
+    __shared__ float Bs[16][68];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    typename P::Ctx cx = p.context(blockIdx.z);
+    if (j0 >= cx.N) return;          // block-uniform
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = cx.k_begin; k0 < cx.k_end; k0 += 16) {
+        // A tile: lanes over k (A is contiguous along k for the weight gradient)
+        for (int e = tid; e < 64 * 16; e += 256) {
+            const int kk = e & 15, mm = e >> 4;
+            const int m = m0 + mm, k = k0 + kk;
+            As[kk][mm] = (m < p.M && k < cx.k_end) ? p.loadA(cx, m, k) : 0.f;
+        }
+        // B tile: lanes over j
+        for (int e = tid; e < 64 * 16; e += 256) {
+            const int jj = e & 63, kk = e >> 6;
+            const int j = j0 + jj, k = k0 + kk;
+            Bs[kk][jj] = (j < cx.N && k < cx.k_end) ? p.loadB(cx, k, j) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[kk][ty + 16 * i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx + 16 * j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty + 16 * i;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int jg = j0 + tx + 16 * j;
+            if (jg < cx.N) p.store(cx, m, jg, acc[i][j]);
+        }
+    }
+}
+
+// ---- weight gradient of layer l:  M = cout, N = cin*ks*ks, K = samples * oh*oh, split over grid.z ----
+struct WgradProb {
+    LayerDesc d;
+    int M, NS, kchunk;
+    const float* dy;            // G_l, NCHW (NS, cout, oh, oh)
+    const float* act_in;        // forward raw output of layer l-1 (l > 0) ...
+    const uint8_t* crop;        // ... or the uint8 crop (NS, 4, 256, 256) for l = 0
+    const float2* mr_in;        // moments of layer l-1
+    const float* gam_in;
+    const float* bet_in;
+    float* dW;                  // (cout, cin, ks, ks), accumulated
+    struct Ctx { int k_begin, k_end, N; };
+    __device__ Ctx context(int z) const {
+        Ctx c;
+        const int K = NS * d.oh * d.oh;
+        c.k_begin = z * kchunk;
+        c.k_end = (c.k_begin + kchunk) < K ? (c.k_begin + kchunk) : K;
+        c.N = d.cin * d.ks * d.ks;
+        return c;
+    }
+    __device__ float loadA(const Ctx&, int m, int k) const {
+        const int HW = d.oh * d.oh;
+        const int n = k / HW, rem = k - n * HW;
+        return dy[((size_t)n * d.cout + m) * HW + rem];
+    }
+    __device__ float loadB(const Ctx&, int k, int j) const {
+        const int HW = d.oh * d.oh, KK = d.ks * d.ks;
+        const int n = k / HW, rem = k - n * HW;
+        const int oy = rem / d.oh, ox = rem - oy * d.oh;
+        const int ci = j / KK, t = j - ci * KK;
+        const int ky = t / d.ks, kx = t - ky * d.ks;
+        const int iy = 2 * oy + ky, ix = 2 * ox + kx;
+        if (crop) return (float)crop[(((size_t)n * 4 + ci) * 256 + iy) * 256 + ix];
+        const float2 m = mr_in[n];
+        const float v = act_in[act_index(d.in_oct, d.cin, d.ih, n, ci, iy, ix)];
+        return fmaxf((v - m.x) * m.y * gam_in[ci] + bet_in[ci], 0.f);
+    }
+    __device__ void store(const Ctx& c, int m, int j, float v) const {
+        if (v != 0.f) unsafeAtomicAdd(&dW[(size_t)m * c.N + j], v);
+    }
+};
+
+// ---- data gradient of layer l (l > 0): per sample and input-pixel parity class (grid.z = 4 n + class) ----
+//      M = cin, N = pixels of the class, K = cout * taps of the class
+struct DgradProb {
+    LayerDesc d;
+    int M;
+    const float* dy;            // G_l, NCHW
+    const float* w;             // torch layout (cout, cin, ks, ks)
+    float* gin;                 // G_{l-1}, NCHW (NS, cin, ih, ih): every element is written exactly once
+    struct Ctx { int k_begin, k_end, N, n, py, px, ny, nx, na, nb; };
+    __device__ Ctx context(int z) const {
+        Ctx c;
+        c.n = z >> 2;
+        c.py = (z >> 1) & 1;
+        c.px = z & 1;
+        c.ny = (d.ih - c.py + 1) / 2;
+        c.nx = (d.ih - c.px + 1) / 2;
+        c.na = (d.ks - c.py + 1) / 2;
+        c.nb = (d.ks - c.px + 1) / 2;
+        c.N = c.ny * c.nx;
+        c.k_begin = 0;
+        c.k_end = d.cout * c.na * c.nb;
+        return c;
+    }
+    __device__ float loadA(const Ctx& c, int m, int k) const {
+        const int T = c.na * c.nb;
+        const int co = k / T, t = k - co * T;
+        const int a = t / c.nb, b = t - a * c.nb;
+        return w[(((size_t)co * d.cin + m) * d.ks + (c.py + 2 * a)) * d.ks + (c.px + 2 * b)];
+    }
+    __device__ float loadB(const Ctx& c, int k, int j) const {
+        const int T = c.na * c.nb;
+        const int co = k / T, t = k - co * T;
+        const int a = t / c.nb, b = t - a * c.nb;
+        const int iy2 = j / c.nx, ix2 = j - iy2 * c.nx;
+        const int oy = iy2 - a, ox = ix2 - b;
+        if (oy < 0 || oy >= d.oh || ox < 0 || ox >= d.oh) return 0.f;
+        return dy[(((size_t)c.n * d.cout + co) * d.oh + oy) * d.oh + ox];
+    }
+    __device__ void store(const Ctx& c, int m, int j, float v) const {
+        const int iy2 = j / c.nx, ix2 = j - iy2 * c.nx;
+        gin[(((size_t)c.n * d.cin + m) * d.ih + (2 * iy2 + c.py)) * d.ih + (2 * ix2 + c.px)] = v;
+    }
+};
+
+constexpr int BWD_CHUNK = 64;     // samples pushed through forward-recompute + backward together
+
+static inline size_t grad_floats_per_sample() {
+    size_t t = 0;
+    for (int l = 0; l < 6; ++l) t += L_OUT[l];
+    return t;
+}
+
+// flat gradient layout: per layer conv W (co,ci,k,k) | conv b | GN gamma | GN beta ; then fc W (64,512) | fc b
+struct CnnGradPtrs {
+    float *w[6], *b[6], *g[6], *be[6], *fcw, *fcb;
+};
+static inline size_t cnn_param_count() {
+    size_t n = 0;
+    for (int l = 0; l < 6; ++l) n += (size_t)LC_OUT[l] * LC_IN[l] * LKS[l] * LKS[l] + 3 * (size_t)LC_OUT[l];
+    return n + 64 * 512 + 64;
+}
+static inline CnnGradPtrs cnn_grad_ptrs(float* flat) {
+    CnnGradPtrs p;
+    for (int l = 0; l < 6; ++l) {
+        p.w[l] = flat; flat += (size_t)LC_OUT[l] * LC_IN[l] * LKS[l] * LKS[l];
+        p.b[l] = flat; flat += LC_OUT[l];
+        p.g[l] = flat; flat += LC_OUT[l];
+        p.be[l] = flat; flat += LC_OUT[l];
+    }
+    p.fcw = flat; flat += 64 * 512;
+    p.fcb = flat;
+    return p;
+}
+
+}  // namespace cnnbwd
+
+extern "C" size_t strive_map_cnn_param_count(void) { return cnnbwd::cnn_param_count(); }
+
+extern "C" size_t strive_map_cnn_bwd_workspace_bytes(int32_t N) {
+    const size_t ch = (size_t)(N < cnnbwd::BWD_CHUNK ? (N > 0 ? N : 1) : cnnbwd::BWD_CHUNK);
+    size_t b = 0;
+    b += strive_align_up(strive_map_cnn_workspace_bytes((int32_t)ch), 256);     // forward activations + statistics
+    b += strive_align_up(ch * cnnbwd::grad_floats_per_sample() * 4, 256);       // G_0 .. G_5
+    b += strive_align_up(ch * 4 * 256 * 256, 256);                              // uint8 crop (conv1's input)
+    b += strive_align_up(ch * 6 * sizeof(float2), 256);                         // moments
+    b += strive_align_up(ch * 2 * sizeof(double), 256);                         // GroupNorm backward sums
+    b += strive_align_up(ch * 64 * 4, 256);                                     // feature scratch of the recomputed forward
+    return b + 1024;
+}
+
+// d_feat (N,64) -> CNN weight gradients at the N poses `pos`, ACCUMULATED into d_params (flat, see strive_hip.h).
+extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, const float* pos, const float* pos_mean4_host,
+                                  const float* pos_std4_host, const int32_t* mapix, int32_t N, const float* d_feat,
+                                  float* d_params, void* ws, size_t ws_bytes, strive_stream_t stream_) {
+    using namespace cnnbwd;
+    STRIVE_CHECK_ARG(map && cnn && pos && mapix && d_feat && d_params && ws && pos_mean4_host && pos_std4_host, "null argument");
+    STRIVE_CHECK_ARG(map->C == 4 && map->L == 256 && map->Wc == 256, "the HIP map CNN supports the default 4x256x256 crop only");
+    STRIVE_CHECK_ARG(cnn->w_torch[0] && cnn->fc_wt, "map_cnn_bwd needs the torch-layout weights (StriveCNN.w_torch)");
+    if (N <= 0) return 0;
+    STRIVE_CHECK_ARG(ws_bytes >= strive_map_cnn_bwd_workspace_bytes(N), "workspace too small");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int ch = N < BWD_CHUNK ? N : BWD_CHUNK;
+    StriveArena ar(ws, ws_bytes);
+    const size_t fwd_bytes = strive_map_cnn_workspace_bytes(ch);
+    char* fwd_ws = ar.take<char>(fwd_bytes);
+    float* G[6];
+    for (int l = 0; l < 6; ++l) G[l] = ar.take<float>((size_t)ch * L_OUT[l]);
+    uint8_t* crop = ar.take<uint8_t>((size_t)ch * 4 * 256 * 256);
+    float2* mr = ar.take<float2>((size_t)ch * 6);
+    double* S = ar.take<double>((size_t)ch * 2);
+    float* feat = ar.take<float>((size_t)ch * 64);
+    STRIVE_CHECK_ARG(ar.ok(), "workspace arena overflow");
+    const CnnGradPtrs gp = cnn_grad_ptrs(d_params);
+
+    for (int n0 = 0; n0 < N; n0 += ch) {
+        const int n = (N - n0) < ch ? (N - n0) : ch;
+        // forward recompute of this chunk: raw convolution outputs and GroupNorm partial sums land in fwd_ws
+        int rc = cnn_run(map, cnn, pos + (size_t)n0 * 4, pos_mean4_host, pos_std4_host, mapix + n0, nullptr, n, feat, fwd_ws,
+                         fwd_bytes, stream);
+        if (rc) return rc;
+        rc = strive_map_crop_u8(map, pos + (size_t)n0 * 4, pos_mean4_host, pos_std4_host, mapix + n0, n, crop, stream_);
+        if (rc) return rc;
+        // the same carve-up cnn_run used for n samples
+        StriveArena fa(fwd_ws, fwd_bytes);
+        float* act[6];
+        for (int l = 0; l < 6; ++l) act[l] = fa.take<float>((size_t)n * L_OUT[l]);
+        GNStats* stats = fa.take<GNStats>((size_t)n * STAT_SLOTS);
+        GNStats* st[6];
+        {
+            size_t off = 0;
+            for (int l = 0; l < 6; ++l) { st[l] = stats + off; off += (size_t)n * NPARTS[l]; }
+        }
+        for (int l = 0; l < 6; ++l)
+            hipLaunchKernelGGL(moments_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, st[l], NPARTS[l], (double)L_OUT[l],
+                               mr + (size_t)l * ch, n);
+        hipLaunchKernelGGL(fc_bwd_kernel, dim3((n + 7) / 8), dim3(256), 0, stream, act[5], mr + (size_t)5 * ch, cnn->gn_g[5],
+                           cnn->gn_b[5], cnn->fc_wt, d_feat + (size_t)n0 * 64, G[5], gp.fcw, gp.fcb, n);
+        for (int l = 5; l >= 0; --l) {
+            const LayerDesc d = layer_desc(l);
+            const int M = d.cout * d.oh * d.oh;
+            int nblk = (M + 8191) / 8192;
+            if (nblk < 1) nblk = 1;
+            hipMemsetAsync(S, 0, (size_t)n * 2 * sizeof(double), stream);
+            hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nblk, n), dim3(256), 0, stream, d, act[l], mr + (size_t)l * ch, cnn->gn_g[l],
+                               cnn->gn_b[l], G[l], S, gp.g[l], gp.be[l]);
+            hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nblk, n), dim3(256), 0, stream, d, act[l], mr + (size_t)l * ch, cnn->gn_g[l],
+                               G[l], S, gp.b[l]);
+            // weight gradient
+            WgradProb wp;
+            wp.d = d; wp.M = d.cout; wp.NS = n; wp.dy = G[l];
+            wp.act_in = l > 0 ? act[l - 1] : nullptr;
+            wp.crop = l > 0 ? nullptr : crop;
+            wp.mr_in = l > 0 ? mr + (size_t)(l - 1) * ch : nullptr;
+            wp.gam_in = l > 0 ? cnn->gn_g[l - 1] : nullptr;
+            wp.bet_in = l > 0 ? cnn->gn_b[l - 1] : nullptr;
+            wp.dW = gp.w[l];
+            const int K = n * d.oh * d.oh, NN = d.cin * d.ks * d.ks;
+            wp.kchunk = 2048;
+            hipLaunchKernelGGL(igemm64_kernel<WgradProb>, dim3((NN + 63) / 64, (d.cout + 63) / 64, (K + wp.kchunk - 1) / wp.kchunk),
+                               dim3(256), 0, stream, wp);
+            if (l > 0) {
+                DgradProb dp;
+                dp.d = d; dp.M = d.cin; dp.dy = G[l]; dp.w = cnn->w_torch[l]; dp.gin = G[l - 1];
+                const int nmax = ((d.ih + 1) / 2) * ((d.ih + 1) / 2);
+                hipLaunchKernelGGL(igemm64_kernel<DgradProb>, dim3((nmax + 63) / 64, (d.cin + 63) / 64, 4 * n), dim3(256), 0, stream, dp);
+            }
+        }
+    }
+    STRIVE_CHECK_LAUNCH();
+    return 0;
+}

@@ -136,10 +136,13 @@ __device__ __forceinline__ void ln_relu_rows(const float* x, int x_ld, float* y,
 
 // Backward of y = relu(layer_norm(x)):  dx from dy, recomputing the normalisation from x (pre-LN).
 // dx may alias dy.
+// dgam / dbet (optional, global memory): LayerNorm weight / bias gradients, accumulated with atomics over the first
+// `nrows` rows (training path only; the latent-optimisation path passes nullptr).
 template <int RB>
 __device__ __forceinline__ void ln_relu_bwd_rows(const float* x, int x_ld, const float* dy, int dy_ld, float* dx,
                                                  int dx_ld, int N, const float* __restrict__ g,
-                                                 const float* __restrict__ b, int tid, int nthreads) {
+                                                 const float* __restrict__ b, int tid, int nthreads,
+                                                 float* dgam = nullptr, float* dbet = nullptr, int nrows = RB) {
     const int wave = tid >> 6, lane = tid & 63, nw = nthreads >> 6;
     for (int r = wave; r < RB; r += nw) {
         float s = 0.f;
@@ -155,9 +158,14 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const float* x, int x_ld, const
         for (int c = lane; c < N; c += 64) {
             const float xh = (x[r * x_ld + c] - mean) * rstd;
             const float pre = xh * g[c] + b[c];
-            const float gg = (pre > 0.f ? dy[r * dy_ld + c] : 0.f) * g[c];
+            const float dn = pre > 0.f ? dy[r * dy_ld + c] : 0.f;
+            const float gg = dn * g[c];
             m1 += gg;
             m2 = fmaf(gg, xh, m2);
+            if (dgam && r < nrows && dn != 0.f) {
+                unsafeAtomicAdd(&dgam[c], dn * xh);
+                unsafeAtomicAdd(&dbet[c], dn);
+            }
         }
         m1 = wave_sum(m1) / (float)N;
         m2 = wave_sum(m2) / (float)N;
@@ -223,30 +231,102 @@ __device__ __forceinline__ void mlp_forward_lds(const MLPDev& m, const float* in
     }
 }
 
-// Backward (input gradient only) through the same MLP, given the `pre` buffers of a forward pass.
+// Weight gradients of one MLP as device pointers into a flat fp32 buffer laid out in the parameter order of the
+// reference module (torch named_parameters()): for every layer  W_l (dims[l+1], dims[l]) | b_l | and, for hidden layers,
+// LayerNorm gamma_l | beta_l.  All null = the latent-optimisation path (no weight gradients).
+struct MLPGradDev {
+    float* w[STRIVE_MAX_LAYERS];
+    float* b[STRIVE_MAX_LAYERS];
+    float* ln_g[STRIVE_MAX_LAYERS];
+    float* ln_b[STRIVE_MAX_LAYERS];
+};
+
+static inline size_t mlp_param_count(const StriveMLP& m) {
+    size_t n = 0;
+    for (int l = 0; l < m.nlayers; ++l) {
+        n += (size_t)m.dims[l + 1] * m.dims[l] + m.dims[l + 1];
+        if (l < m.nlayers - 1) n += 2 * (size_t)m.dims[l + 1];
+    }
+    return n;
+}
+
+// carve `flat` (may be null: all-null result); advances *flat past this MLP's parameters
+static inline MLPGradDev mlp_grad_dev(const StriveMLP& m, float** flat) {
+    MLPGradDev g;
+    for (int l = 0; l < STRIVE_MAX_LAYERS; ++l) g.w[l] = g.b[l] = g.ln_g[l] = g.ln_b[l] = nullptr;
+    if (!flat || !*flat) return g;
+    float* p = *flat;
+    for (int l = 0; l < m.nlayers; ++l) {
+        g.w[l] = p; p += (size_t)m.dims[l + 1] * m.dims[l];
+        g.b[l] = p; p += m.dims[l + 1];
+        if (l < m.nlayers - 1) {
+            g.ln_g[l] = p; p += m.dims[l + 1];
+            g.ln_b[l] = p; p += m.dims[l + 1];
+        }
+    }
+    *flat = p;
+    return g;
+}
+
+// dW[o * ldw + i] += sum_{r < nrows} g[r][o] * a[r][i]   (o < OUT, i < IN; dW in torch (out, in) layout, possibly a column
+// block of a wider matrix: ldw = its full row length);  db[o] += sum_r g[r][o]  (db may be null).
+// Lanes run over consecutive i of one output row, so the atomics of a wave hit consecutive addresses.
+__device__ __forceinline__ void wgrad_lds(const float* g, int g_ld, int OUT, const float* a, int a_ld, int IN, float* dW,
+                                          int ldw, float* db, int nrows, int tid, int nthreads) {
+    for (int item = tid; item < OUT * IN; item += nthreads) {
+        const int o = item / IN, i = item - o * IN;
+        float s = 0.f;
+        for (int r = 0; r < nrows; ++r) s = fmaf(g[r * g_ld + o], a[r * a_ld + i], s);
+        if (s != 0.f) unsafeAtomicAdd(&dW[(size_t)o * ldw + i], s);
+    }
+    if (db) {
+        for (int o = tid; o < OUT; o += nthreads) {
+            float s = 0.f;
+            for (int r = 0; r < nrows; ++r) s += g[r * g_ld + o];
+            if (s != 0.f) unsafeAtomicAdd(&db[o], s);
+        }
+    }
+}
+
+// Backward through the same MLP, given the `pre` buffers of a forward pass.
 //   dout : LDS [RB][dout_ld] gradient w.r.t. the MLP output
 //   ga, gb : LDS [RB][HLD] scratch
 //   din  : LDS [RB][din_ld] gradient w.r.t. the layer-0 input; if skip_first, the gradient w.r.t. layer 0's
 //          linear OUTPUT (pre[0]) is left in `ga` instead and din is untouched.
+// Weight gradients (training path): pass `grads` (+ `act`: LDS [RB][HLD] scratch for the re-derived layer inputs, `in`:
+// the layer-0 input rows, and `nrows` = valid rows of the block); they are accumulated with atomics.  With skip_first the
+// layer-0 weight gradient is the caller's business (factorised edge layer).
 template <int RB>
 __device__ __forceinline__ void mlp_backward_lds(const MLPDev& m, const float* pre, const float* dout, int dout_ld,
                                                  float* ga, float* gb, float* din, int din_ld, bool skip_first, int tid,
-                                                 int nthreads) {
+                                                 int nthreads, const MLPGradDev* grads = nullptr, float* act = nullptr,
+                                                 const float* in = nullptr, int in_ld = 0, int nrows = RB) {
     const int L = m.nlayers;
     const float* g = dout;
     int g_ld = dout_ld;
+    const bool wg = grads && grads->w[L - 1];
     for (int l = L - 1; l >= 1; --l) {
+        const float* p = pre + (size_t)(l - 1) * RB * HLD;
+        if (wg) {
+            // this layer's input = relu(layer_norm(pre[l-1])), re-derived into `act`
+            ln_relu_rows<RB>(p, HLD, act, HLD, m.dims[l], m.ln_g[l - 1], m.ln_b[l - 1], tid, nthreads);
+            __syncthreads();
+            wgrad_lds(g, g_ld, m.dims[l + 1], act, HLD, m.dims[l], grads->w[l], m.dims[l], grads->b[l], nrows, tid, nthreads);
+        }
         // gradient w.r.t. the post-ReLU activation feeding layer l: gb = g * W_l   (W_l torch layout (out,in))
         dense_lds<RB, false>(g, g_ld, m.dims[l + 1], m.w[l], m.dims[l], nullptr, gb, HLD, m.dims[l], tid, nthreads);
         __syncthreads();
-        const float* p = pre + (size_t)(l - 1) * RB * HLD;
-        ln_relu_bwd_rows<RB>(p, HLD, gb, HLD, ga, HLD, m.dims[l], m.ln_g[l - 1], m.ln_b[l - 1], tid, nthreads);
+        ln_relu_bwd_rows<RB>(p, HLD, gb, HLD, ga, HLD, m.dims[l], m.ln_g[l - 1], m.ln_b[l - 1], tid, nthreads,
+                             wg ? grads->ln_g[l - 1] : nullptr, wg ? grads->ln_b[l - 1] : nullptr, nrows);
         __syncthreads();
         g = ga;
         g_ld = HLD;
     }
     if (!skip_first) {
-        dense_lds<RB, false>(g, g_ld, m.dims[1], m.w[0], m.dims[0], nullptr, din, din_ld, m.dims[0], tid, nthreads);
-        __syncthreads();
+        if (wg) wgrad_lds(g, g_ld, m.dims[1], in, in_ld, m.dims[0], grads->w[0], m.dims[0], grads->b[0], nrows, tid, nthreads);
+        if (din) {
+            dense_lds<RB, false>(g, g_ld, m.dims[1], m.w[0], m.dims[0], nullptr, din, din_ld, m.dims[0], tid, nthreads);
+            __syncthreads();
+        }
     }
 }

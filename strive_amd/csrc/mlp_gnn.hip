@@ -1,6 +1,6 @@
 // Stand-alone MLP forward and scene-interaction-network forward (used by embed(): past/future encoders,
 // prior and posterior networks), plus the three forward kernels the decoder rollout shares.
-#include "gnn_kernels.h"
+#include "gnn_bwd_kernels.h"
 
 // ---------------------------------------------------------------------------------------------
 // MLP forward on a (rows, F) matrix
@@ -44,6 +44,67 @@ extern "C" int strive_mlp_fwd(const StriveMLP* mlp, const float* x, int32_t rows
 }
 
 // ---------------------------------------------------------------------------------------------
+// MLP backward on a (rows, F) matrix: weight gradients (accumulated, flat named_parameters() order) and, optionally,
+// the input gradient.  The forward is recomputed in LDS from x (nothing was saved).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mlp_bwd_kernel(MLPDev m, MLPGradDev gr, const float* __restrict__ x,
+                                                        const float* __restrict__ dy, int rows, float* __restrict__ dx) {
+    HIP_DYNAMIC_SHARED(float, smem)
+    const int F = m.dims[0], O = m.dims[m.nlayers];
+    const int in_ld = (F + 3) & ~3;
+    float* s_in = smem;
+    float* s_pre = s_in + RB_NODE * in_ld;
+    float* s_act = s_pre + (STRIVE_MAX_LAYERS - 1) * RB_NODE * HLD;
+    float* s_out = s_act + RB_NODE * HLD;
+    float* s_go = s_out + RB_NODE * HLD;
+    float* s_ga = s_go + RB_NODE * HLD;
+    float* s_gb = s_ga + RB_NODE * HLD;
+    float* s_din = s_gb + RB_NODE * HLD;     // [RB_NODE][in_ld]
+    const int tid = threadIdx.x, r0 = blockIdx.x * RB_NODE;
+    const int nrows = (rows - r0) < RB_NODE ? (rows - r0) : RB_NODE;
+    FeatSrc f;
+    f.n = 1;
+    f.p[0] = x;
+    f.w[0] = F;
+    f.per_agent[0] = 0;
+    gather_features<RB_NODE>(f, r0, rows, 1, s_in, in_ld, tid, 256);
+    __syncthreads();
+    mlp_forward_lds<RB_NODE>(m, s_in, in_ld, s_pre, s_act, s_out, HLD, false, tid, 256);
+    for (int i = tid; i < RB_NODE * HLD; i += 256) {
+        const int rr = i / HLD, c = i - rr * HLD;
+        s_go[i] = (rr < nrows && c < O) ? dy[(size_t)(r0 + rr) * O + c] : 0.f;
+    }
+    __syncthreads();
+    mlp_backward_lds<RB_NODE>(m, s_pre, s_go, HLD, s_ga, s_gb, dx ? s_din : nullptr, in_ld, false, tid, 256, &gr, s_act, s_in, in_ld,
+                              nrows);
+    if (dx) {
+        for (int i = tid; i < RB_NODE * F; i += 256) {
+            const int rr = i / F, c = i - rr * F;
+            if (rr < nrows) dx[(size_t)(r0 + rr) * F + c] = s_din[rr * in_ld + c];
+        }
+    }
+}
+
+extern "C" size_t strive_mlp_param_count(const StriveMLP* mlp) { return mlp ? mlp_param_count(*mlp) : 0; }
+
+extern "C" int strive_mlp_bwd(const StriveMLP* mlp, const float* x, const float* dy, int32_t rows, float* dx, float* d_params,
+                              strive_stream_t stream) {
+    STRIVE_CHECK_ARG(mlp && x && dy && d_params, "null argument");
+    STRIVE_CHECK_ARG(mlp->nlayers >= 2 && mlp->nlayers <= STRIVE_MAX_LAYERS, "unsupported layer count");
+    for (int l = 1; l < mlp->nlayers; ++l) STRIVE_CHECK_ARG(mlp->dims[l] == STRIVE_HID, "hidden width must be 128");
+    STRIVE_CHECK_ARG(mlp->dims[mlp->nlayers] <= STRIVE_HID && mlp->dims[0] <= 512, "layer too wide");
+    if (rows <= 0) return 0;
+    const int in_ld = (mlp->dims[0] + 3) & ~3;
+    const size_t lds = (size_t)(2 * RB_NODE * in_ld + (STRIVE_MAX_LAYERS - 1) * RB_NODE * HLD + 5 * RB_NODE * HLD) * 4;
+    float* p = d_params;
+    const MLPGradDev gr = mlp_grad_dev(*mlp, &p);
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3((rows + RB_NODE - 1) / RB_NODE), dim3(256), lds, (hipStream_t)stream, mlp_dev(*mlp), gr,
+                       x, dy, rows, dx);
+    STRIVE_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // SceneInteractionNet forward
 // ---------------------------------------------------------------------------------------------
 extern "C" size_t strive_gnn_workspace_bytes(const StriveGNN* gnn, const StriveScenes* sc) {
@@ -77,6 +138,62 @@ extern "C" int strive_gnn_fwd(const StriveGNN* gnn, const StriveScenes* sc, cons
     f.per_agent[0] = 0;
     int rc = gnn_forward_launch(*gnn, *sc, f, pos, sem, gb, out, (hipStream_t)stream);
     if (rc) return rc;
+    STRIVE_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SceneInteractionNet backward: d_out -> dx (input features) and the weight gradients (accumulated, flat
+// named_parameters() order).  The forward is recomputed (node embeddings, partials, aggregates) into the workspace.
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t strive_gnn_bwd_workspace_bytes(const StriveGNN* gnn, const StriveScenes* sc) {
+    if (!gnn || !sc) return 0;
+    const size_t R = (size_t)sc->NA * sc->NS;
+    return strive_gnn_workspace_bytes(gnn, sc) + gnn_bwd_buffers_bytes(R, gnn->D, sc->max_n > 0 ? sc->max_n : 1) +
+           strive_align_up(R * 4 * 4, 256) + 4096;
+}
+
+extern "C" int strive_gnn_bwd(const StriveGNN* gnn, const StriveScenes* sc, const float* x, const float* pos, const float* sem,
+                              const float* d_out, float* dx, float* d_params, void* ws, size_t ws_bytes,
+                              strive_stream_t stream_) {
+    STRIVE_CHECK_ARG(gnn && sc && x && pos && sem && d_out && dx && d_params && ws, "null argument");
+    STRIVE_CHECK_ARG(ws_bytes >= strive_gnn_bwd_workspace_bytes(gnn, sc), "workspace too small");
+    STRIVE_CHECK_ARG(sc->max_n >= 1, "max_n not set");
+    if (gnn_check(*gnn)) return -1;
+    const int R = sc->NA * sc->NS;
+    if (R == 0) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    StriveArena ar(ws, ws_bytes);
+    GnnBuffers gb;
+    gb.X = ar.take<float>((size_t)R * gnn->D);
+    gb.P = ar.take<float>((size_t)R * STRIVE_HID);
+    gb.Q = ar.take<float>((size_t)R * STRIVE_HID);
+    gb.A = ar.take<float>((size_t)R * gnn->D);
+    gb.ARG = ar.take<int32_t>((size_t)R * gnn->D);
+    GnnBwdBuffers bw = gnn_bwd_buffers_take(ar, (size_t)R, gnn->D, sc->max_n);
+    float* g_pos = ar.take<float>((size_t)R * 4);
+    STRIVE_CHECK_ARG(ar.ok(), "workspace arena overflow");
+    FeatSrc f;
+    f.n = 1;
+    f.p[0] = x;
+    f.w[0] = gnn->mlp_in.dims[0];
+    f.per_agent[0] = 0;
+    int rc = gnn_forward_launch(*gnn, *sc, f, pos, sem, gb, nullptr, stream);      // node1 + edge: X, P, Q, A, ARG
+    if (rc) return rc;
+    const GNNDev gd = gnn_dev(*gnn);
+    const GNNGradDev gr = gnn_grad_dev(*gnn, d_params);
+    const ScenesDev sd = scenes_dev(*sc);
+    const int in_ld1 = ld4(gnn->mlp_in.dims[0]), xs_ld = ld4(gnn->D + gnn->NC), in_ld2 = ld4(2 * gnn->D + gnn->NC);
+    const int nb = (R + RB_NODE - 1) / RB_NODE;
+    hipLaunchKernelGGL(gnn_node2_bwd_kernel, dim3(nb), dim3(256), gnn_node2_bwd_lds_bytes(in_ld2), stream, gd, gr, sc->NS, sem, gb,
+                       d_out, bw.dX, bw.dA, R);
+    EdgeBwdArgs ae;
+    ae.dA = bw.dA; ae.ARG = gb.ARG; ae.dP = bw.dP; ae.DE1 = bw.DE1; ae.DPJ = bw.DPJ; ae.gpos_tgt = bw.gpos_tgt;
+    hipLaunchKernelGGL(edge_bwd_kernel, dim3((unsigned)R), dim3(256), edge_bwd_lds_bytes(), stream, gd, gr, sd, pos, gb, ae);
+    Node1BwdArgs a1;
+    a1.t = 0; a1.R = R; a1.dX = bw.dX; a1.dP = bw.dP; a1.DE1 = bw.DE1; a1.DPJ = bw.DPJ; a1.gpos_tgt = bw.gpos_tgt;
+    a1.sem = sem; a1.g_pos = g_pos; a1.g_full = dx; a1.g_pf = nullptr; a1.g_mf = nullptr; a1.dz = nullptr;
+    hipLaunchKernelGGL(node1_bwd_kernel, dim3(nb), dim3(256), node1_bwd_lds_bytes(in_ld1, xs_ld), stream, gd, gr, sd, f, a1);
     STRIVE_CHECK_LAUNCH();
     return 0;
 }

@@ -10,7 +10,7 @@
 // (cheap: the GNN/GRU are ~1.6 MFLOP per agent-step against 300 MFLOP for the CNN, which needs no backward
 // at all because the reference crops at pos.detach()).  The backward is four launches per step:
 // node1 (recompute), gru_bwd, node2_bwd, edge_bwd, node1_bwd.
-#include "gnn_kernels.h"
+#include "gnn_bwd_kernels.h"
 
 struct DynParams {
     float smean[6], sstd[6];
@@ -26,6 +26,36 @@ struct GRUDev {
     const float* bih[3];
     const float* bhh[3];
 };
+
+// Weight gradients of the GRU memory (training path): flat buffer in named_parameters() order, per layer
+// weight_ih (192, in_l) | weight_hh (192, 64) | bias_ih (192) | bias_hh (192); null = no weight gradients.
+struct GRUGradDev {
+    float* wih[3];
+    float* whh[3];
+    float* bih[3];
+    float* bhh[3];
+    bool on;
+};
+
+static inline size_t gru_param_count() {
+    size_t n = 0;
+    for (int l = 0; l < 3; ++l) n += (size_t)192 * (l == 0 ? 4 : 64) + (size_t)192 * 64 + 2 * 192;
+    return n;
+}
+
+static inline GRUGradDev gru_grad_dev(float* flat) {
+    GRUGradDev d;
+    d.on = flat != nullptr;
+    float* p = flat;
+    for (int l = 0; l < 3; ++l) {
+        const int in = l == 0 ? 4 : 64;
+        d.wih[l] = p; if (p) p += (size_t)192 * in;
+        d.whh[l] = p; if (p) p += (size_t)192 * 64;
+        d.bih[l] = p; if (p) p += 192;
+        d.bhh[l] = p; if (p) p += 192;
+    }
+    return d;
+}
 
 struct Tape {
     float *pf, *mf, *pos, *state, *mem, *A, *loc;
@@ -394,8 +424,9 @@ extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* 
 
 // ---- GRU backward for rows r0.. : consumes g_mem (adjoint of mem_{t+1}) and g_pf (adjoint of past_feat_{t+1}),
 //      produces g_mem (adjoint of mem_t) and d_loc (adjoint of the local pose fed to the GRU).  grid = ceil(R/RB_NODE)
-static __global__ __launch_bounds__(256) void gru_bwd_kernel(GRUDev gru, Tape tp, int t, int R, const float* __restrict__ g_pf,
-                                                               float* __restrict__ g_mem, float* __restrict__ d_loc) {
+static __global__ __launch_bounds__(256) void gru_bwd_kernel(GRUDev gru, GRUGradDev gg, Tape tp, int t, int R,
+                                                               const float* __restrict__ g_pf, float* __restrict__ g_mem,
+                                                               float* __restrict__ d_loc) {
     HIP_DYNAMIC_SHARED(float, smem)
     float* s_x = smem;                      // [RB_NODE][4]
     float* s_h = s_x + RB_NODE * 4;              // [3][RB_NODE][64]   layer hidden inputs (mem_t)
@@ -453,9 +484,17 @@ static __global__ __launch_bounds__(256) void gru_bwd_kernel(GRUDev gru, Tape tp
             s_hn[(size_t)l * RB_NODE * 64 + i] = dh * z;
         }
         __syncthreads();
+        const int xin = (l == 0) ? 4 : 64;
+        if (gg.on) {
+            // dW_ih = d gi^T . x_l,  dW_hh = d gh^T . h_l  (x_l = the layer below's forward output, still intact in s_hn[l-1])
+            const int nrows = (R - r0) < RB_NODE ? (R - r0) : RB_NODE;
+            const float* xl = (l == 0) ? s_x : s_hn + (size_t)(l - 1) * RB_NODE * 64;
+            wgrad_lds(s_gi, GLD, GLD, xl, l == 0 ? 4 : 64, xin, gg.wih[l], xin, gg.bih[l], nrows, tid, 256);
+            wgrad_lds(s_gh, GLD, GLD, h, 64, 64, gg.whh[l], 64, gg.bhh[l], nrows, tid, 256);
+        }
         // adjoint of the hidden input: dh*z + dgh * W_hh ; adjoint of the layer input: dgi * W_ih
         dense_lds<RB_NODE, true>(s_gh, GLD, GLD, gru.whh[l], 64, nullptr, s_hn + (size_t)l * RB_NODE * 64, 64, 64, tid, 256);
-        const int xin = (l == 0) ? 4 : 64;
+        __syncthreads();     // both calls split k and share dense_lds' partial-sum buffer: the first must have drained it
         dense_lds<RB_NODE, false>(s_gi, GLD, GLD, gru.wih[l], xin, nullptr, s_dx, 64, xin, tid, 256);
         __syncthreads();
         for (int i = tid; i < RB_NODE * 64; i += 256) {
@@ -489,7 +528,7 @@ struct Node2BwdArgs {
     float* dA;               // (R, 64) out: dL/d(aggregated message)
 };
 
-static __global__ __launch_bounds__(256) void node2_bwd_kernel(GNNDev g, DynParams dp, Node2BwdArgs a, Tape tp) {
+static __global__ __launch_bounds__(256) void node2_bwd_kernel(GNNDev g, GNNGradDev gr, DynParams dp, Node2BwdArgs a, Tape tp) {
     HIP_DYNAMIC_SHARED(float, smem)
     const int in_ld = ld4(2 * g.D + g.NC);
     Node2Lds L(smem, in_ld);
@@ -543,8 +582,11 @@ static __global__ __launch_bounds__(256) void node2_bwd_kernel(GNNDev g, DynPara
         s_go[tid * 4 + 3] = 0.f;
     }
     __syncthreads();
-    mlp_backward_lds<RB_NODE>(g.mlp_out, L.pre_o, s_go, 4, s_ga, s_gb, s_gx, HLD, false, tid, 256);
-    mlp_backward_lds<RB_NODE>(g.update, L.pre_u, s_gx, HLD, s_ga, s_gb, s_gin, in_ld, false, tid, 256);
+    const int nrows = (a.R - r0) < RB_NODE ? (a.R - r0) : RB_NODE;
+    mlp_backward_lds<RB_NODE>(g.mlp_out, L.pre_o, s_go, 4, s_ga, s_gb, s_gx, HLD, false, tid, 256,
+                              gr.on ? &gr.mlp_out : nullptr, L.act, L.xp, HLD, nrows);
+    mlp_backward_lds<RB_NODE>(g.update, L.pre_u, s_gx, HLD, s_ga, s_gb, s_gin, in_ld, false, tid, 256,
+                              gr.on ? &gr.update : nullptr, L.act, L.in, in_ld, nrows);
     const int D = g.D;
     for (int i = tid; i < RB_NODE * D; i += 256) {
         const int rr = i / D, c = i - rr * D;
@@ -557,206 +599,114 @@ static __global__ __launch_bounds__(256) void node2_bwd_kernel(GNNDev g, DynPara
 
 static size_t node2_bwd_lds_bytes(int in_ld) { return (Node2Lds::floats(in_ld) + RB_NODE * 4 + 3 * RB_NODE * HLD + RB_NODE * in_ld) * 4; }
 
-// ---- edge backward: one workgroup per target row.  grid = R
-struct EdgeBwdArgs {
-    const float* dA;       // (R, D)
-    const int32_t* ARG;    // (R, D)
-    float* dP;             // (R, 128)
-    float* DE1;            // (R*max_n, 128)  per-edge layer-0 adjoint, slot = target_row*max_n + local source index
-    float* DPJ;            // (R*max_n, 4)    per-edge adjoint of the SOURCE pose
-    float* gpos_tgt;       // (R, 4)          adjoint of the TARGET pose (frame), summed over its edges
-};
-
-static __global__ __launch_bounds__(256) void edge_bwd_kernel(GNNDev g, ScenesDev sc, const float* __restrict__ pos, GnnBuffers gb,
-                                                                EdgeBwdArgs a) {
-    HIP_DYNAMIC_SHARED(float, smem)
-    EdgeLds L(smem);
-    float* s_ga = (float*)(L.src + RB_EDGE);       // [RB_EDGE][HLD]
-    float* s_gb = s_ga + RB_EDGE * HLD;            // [RB_EDGE][HLD]
-    float* s_grel = s_gb + RB_EDGE * HLD;          // [RB_EDGE][4]
-    float* s_gfr = s_grel + RB_EDGE * 4;           // [RB_EDGE][4]
-    unsigned* s_nan = (unsigned*)(s_gfr + RB_EDGE * 4);   // [RB_EDGE]
-    const int r = blockIdx.x, tid = threadIdx.x, D = g.D, H = STRIVE_HID;
-    const int ag = r / sc.NS;
-    const int b = sc.scene_of[ag];
-    const int lo = sc.ptr[b];
-    const int nsrc = sc.ptr[b + 1] - lo - 1;
-    const int nchunks = (nsrc + RB_EDGE - 1) / RB_EDGE;
-    const float* Wrel = g.edge.wt[0] + (size_t)(2 * D + 2 * g.NC) * H;
-    float dp_acc = 0.f;                  // thread c < 128: sum over sources of d e1[.][c]
-    float gfr_acc[4] = {0.f, 0.f, 0.f, 0.f};   // thread 0
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int nv = edge_chunk_setup(g, sc, pos, gb, r, ch, L, s_nan, tid);
-        mlp_forward_lds<RB_EDGE>(g.edge, nullptr, 0, L.pre, L.act, L.m, HLD, true, tid, 256);
-        // route d(aggregate) to the arg-max edge of every channel
-        for (int i = tid; i < RB_EDGE * D; i += 256) {
-            const int jr = i / D, c = i - jr * D;
-            float v = 0.f;
-            if (jr < nv && a.ARG[(size_t)r * D + c] == L.src[jr]) v = a.dA[(size_t)r * D + c];
-            L.m[jr * HLD + c] = v;
-        }
-        __syncthreads();
-        mlp_backward_lds<RB_EDGE>(g.edge, L.pre, L.m, HLD, s_ga, s_gb, nullptr, 0, true, tid, 256);   // d e1 -> s_ga
-        // per-edge outputs
-        for (int i = tid; i < RB_EDGE * H; i += 256) {
-            const int jr = i / H, c = i - jr * H;
-            if (jr < nv) {
-                const int jl = L.src[jr] / sc.NS - lo;
-                a.DE1[((size_t)r * sc.max_n + jl) * H + c] = s_ga[jr * HLD + c];
-            }
-        }
-        if (tid < H) {
-            for (int jr = 0; jr < nv; ++jr) dp_acc += s_ga[jr * HLD + tid];
-        }
-        // d rel = d e1 . W_rel^T : one wave per edge row, lanes over channels
-        {
-            const int wave = tid >> 6, lane = tid & 63;
-            for (int jr = wave; jr < RB_EDGE; jr += 4) {
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int c = lane; c < H; c += 64) {
-                    const float ge = s_ga[jr * HLD + c];
-                    for (int d = 0; d < 4; ++d) v[d] = fmaf(ge, Wrel[d * H + c], v[d]);
-                }
-                for (int d = 0; d < 4; ++d) v[d] = wave_sum(v[d]);
-                if (lane == 0)
-                    for (int d = 0; d < 4; ++d) s_grel[jr * 4 + d] = v[d];
-            }
-        }
-        __syncthreads();
-        if (tid < RB_EDGE) {
-            float gfr[4] = {0.f, 0.f, 0.f, 0.f}, gpo[4] = {0.f, 0.f, 0.f, 0.f};
-            if (tid < nv) {
-                const int srow = L.src[tid];
-                float gr[4];
-                for (int d = 0; d < 4; ++d) gr[d] = (s_nan[tid] >> d) & 1u ? 0.f : s_grel[tid * 4 + d];
-                rel_pose_bwd(pos + (size_t)r * 4, pos + (size_t)srow * 4, gr, gfr, gpo);
-                const int jl = srow / sc.NS - lo;
-                float* o = a.DPJ + ((size_t)r * sc.max_n + jl) * 4;
-                for (int d = 0; d < 4; ++d) o[d] = gpo[d];
-            }
-            for (int d = 0; d < 4; ++d) s_gfr[tid * 4 + d] = gfr[d];
-        }
-        __syncthreads();
-        if (tid == 0)
-            for (int jr = 0; jr < nv; ++jr)
-                for (int d = 0; d < 4; ++d) gfr_acc[d] += s_gfr[jr * 4 + d];
-        __syncthreads();
-    }
-    if (tid < H) a.dP[(size_t)r * H + tid] = dp_acc;
-    if (tid == 0)
-        for (int d = 0; d < 4; ++d) a.gpos_tgt[(size_t)r * 4 + d] = gfr_acc[d];
-}
-
-static size_t edge_bwd_lds_bytes() { return EdgeLds::bytes() + (size_t)(2 * RB_EDGE * HLD + 2 * RB_EDGE * 4 + RB_EDGE) * 4; }
-
-// ---- node1 backward: gather source-side adjoints, back through edge layer 0 partials and mlp_in.  grid = ceil(R/RB_NODE)
-struct Node1BwdArgs {
-    int t, R;
-    const float* dX;        // (R, 64)
-    const float* dP;        // (R, 128)
-    const float* DE1;
-    const float* DPJ;
-    const float* gpos_tgt;
-    float* g_pf;            // (R, 64) out: adjoint of past_feat_t
-    float* g_pos;           // (R, 4)  out: adjoint of pos_t
-    float* dz;              // (R, 32) accumulated
-};
-
-static __global__ __launch_bounds__(256) void node1_bwd_kernel(GNNDev g, ScenesDev sc, FeatSrc f, Node1BwdArgs a) {
-    HIP_DYNAMIC_SHARED(float, smem)
-    const int F = g.mlp_in.dims[0], D = g.D, H = STRIVE_HID;
-    const int in_ld = ld4(F), xs_ld = ld4(D + g.NC);
-    Node1Lds L(smem, in_ld, xs_ld);
-    float* s_dp = L.po + RB_NODE * HLD;       // [RB_NODE][HLD]  dP rows
-    float* s_dq = s_dp + RB_NODE * HLD;       // [RB_NODE][HLD]  dQ rows
-    float* s_gx = s_dq + RB_NODE * HLD;       // [RB_NODE][HLD]  adjoint of x (D wide)
-    float* s_gb = s_gx + RB_NODE * HLD;       // [RB_NODE][HLD]
-    float* s_gin = s_gb + RB_NODE * HLD;      // [RB_NODE][in_ld]
-    const int tid = threadIdx.x, r0 = blockIdx.x * RB_NODE, NS = sc.NS;
-    // forward recompute of mlp_in (pre-activations)
-    gather_features<RB_NODE>(f, r0, a.R, NS, L.in, in_ld, tid, 256);
-    __syncthreads();
-    mlp_forward_lds<RB_NODE>(g.mlp_in, L.in, in_ld, L.pre, L.act, L.xs, xs_ld, false, tid, 256);
-    // gather dP, dQ = sum over targets of the per-edge adjoints, and the source-pose adjoint
-    for (int i = tid; i < RB_NODE * H; i += 256) {
-        const int rr = i / H, c = i - rr * H;
-        const int r = r0 + rr;
-        float vp = 0.f, vq = 0.f;
-        if (r < a.R) {
-            vp = a.dP[(size_t)r * H + c];
-            const int ag = r / NS, s = r - ag * NS;
-            const int b = sc.scene_of[ag];
-            const int lo = sc.ptr[b], hi = sc.ptr[b + 1];
-            const int jl = ag - lo;
-            for (int ia = lo; ia < hi; ++ia) {
-                if (ia == ag) continue;
-                vq += a.DE1[((size_t)(ia * NS + s) * sc.max_n + jl) * H + c];
-            }
-        }
-        s_dp[rr * HLD + c] = vp;
-        s_dq[rr * HLD + c] = vq;
-    }
-    if (tid < RB_NODE * 4) {
-        const int rr = tid >> 2, d = tid & 3;
-        const int r = r0 + rr;
-        if (r < a.R) {
-            float v = a.gpos_tgt[(size_t)r * 4 + d];
-            const int ag = r / NS, s = r - ag * NS;
-            const int b = sc.scene_of[ag];
-            const int lo = sc.ptr[b], hi = sc.ptr[b + 1];
-            const int jl = ag - lo;
-            for (int ia = lo; ia < hi; ++ia) {
-                if (ia == ag) continue;
-                v += a.DPJ[((size_t)(ia * NS + s) * sc.max_n + jl) * 4 + d];
-            }
-            a.g_pos[(size_t)r * 4 + d] = v;
-        }
-    }
-    __syncthreads();
-    // adjoint of x: dP . W_e0[:, 0:D] + dQ . W_e0[:, D:2D] + update-MLP part
-    const int EIN = g.edge.dims[0];
-    dense_lds<RB_NODE, false>(s_dp, HLD, H, g.edge.w[0], EIN, nullptr, s_gx, HLD, D, tid, 256);
-    __syncthreads();
-    dense_lds<RB_NODE, true>(s_dq, HLD, H, g.edge.w[0] + D, EIN, nullptr, s_gx, HLD, D, tid, 256);
-    __syncthreads();
-    for (int i = tid; i < RB_NODE * D; i += 256) {
-        const int rr = i / D, c = i - rr * D;
-        if (r0 + rr < a.R) s_gx[rr * HLD + c] += a.dX[(size_t)(r0 + rr) * D + c];
-    }
-    __syncthreads();
-    mlp_backward_lds<RB_NODE>(g.mlp_in, L.pre, s_gx, HLD, s_dp, s_gb, s_gin, in_ld, false, tid, 256);
-    // scatter: past_feat columns [0,64), z columns [128+NC, 128+NC+32)
-    for (int i = tid; i < RB_NODE * 64; i += 256) {
-        const int rr = i >> 6, c = i & 63;
-        if (r0 + rr < a.R) a.g_pf[(size_t)(r0 + rr) * 64 + c] = s_gin[rr * in_ld + c];
-    }
-    const int zoff = 128 + g.NC;
-    for (int i = tid; i < RB_NODE * STRIVE_ZDIM; i += 256) {
-        const int rr = i / STRIVE_ZDIM, c = i - rr * STRIVE_ZDIM;
-        if (r0 + rr < a.R) a.dz[(size_t)(r0 + rr) * STRIVE_ZDIM + c] += s_gin[rr * in_ld + zoff + c];
-    }
-}
-
-static size_t node1_bwd_lds_bytes(int in_ld, int xs_ld) { return Node1Lds::bytes(in_ld, xs_ld) + (size_t)(4 * RB_NODE * HLD + RB_NODE * in_ld) * 4; }
-
 // =============================================================================================
 // host orchestration: backward
 // =============================================================================================
 namespace {
 size_t bwd_ws_bytes(size_t R, int max_n) {
     size_t b = 0;
-    b += strive_align_up(R * 64 * 4, 256);                 // X
-    b += 2 * strive_align_up(R * STRIVE_HID * 4, 256);     // P, Q
     b += strive_align_up(R * 8 * 4, 256);                  // g_state
     b += 2 * strive_align_up(R * 4 * 4, 256);              // g_pos, d_loc
-    b += strive_align_up(R * 64 * 4, 256);                 // g_pf
+    b += 2 * strive_align_up(R * 64 * 4, 256);             // g_pf, g_mf
     b += strive_align_up(R * 192 * 4, 256);                // g_mem
-    b += 2 * strive_align_up(R * 64 * 4, 256);             // dX, dA
-    b += strive_align_up(R * STRIVE_HID * 4, 256);         // dP
-    b += strive_align_up(R * 4 * 4, 256);                  // gpos_tgt
-    b += strive_align_up(R * (size_t)max_n * STRIVE_HID * 4, 256);   // DE1
-    b += strive_align_up(R * (size_t)max_n * 4 * 4, 256);            // DPJ
+    b += gnn_bwd_buffers_bytes(R, 64, max_n);
     return b;
+}
+
+// What the training path wants on top of dL/dz (all device pointers; reference src/train_traffic.py:103-131 needs the
+// gradients of every parameter the rollout touches and of the encoder outputs it starts from).
+struct TrainOut {
+    float* d_past_feat;    // (NA, 64)
+    float* d_map_feat;     // (NA, 64)
+    float* d_gnn;          // flat decoder_net gradients, accumulated
+    float* d_gru;          // flat decoder_memory gradients, accumulated
+    float* d_cnn;          // flat map_conv + map_feature gradients, accumulated
+    const int32_t* mapix;  // (NA)
+    void* cnn_ws;
+    size_t cnn_ws_bytes;
+};
+
+static __global__ void rollout_init_bwd_kernel(const float* __restrict__ g_pf, const float* __restrict__ g_mem,
+                                               const float* __restrict__ g_mf, float* __restrict__ d_past_feat,
+                                               float* __restrict__ d_map_feat, int R) {
+    // past_feat feeds past_feat_0 and all three GRU layers' initial memory (reference traffic_model.py:625)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * 64) return;
+    const int r = i >> 6, c = i & 63;
+    float v = g_pf[i];
+    for (int l = 0; l < 3; ++l) v += g_mem[((size_t)r * 3 + l) * 64 + c];
+    d_past_feat[i] = v;
+    d_map_feat[i] = g_mf[i];
+}
+
+int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const float* lw, const float* sem, const float* z,
+                     const float* ext_future, int32_t FT, const float* d_traj, float* dz, const void* tape, size_t tape_bytes,
+                     void* ws, size_t ws_bytes, strive_stream_t stream_, const TrainOut* tr) {
+    const size_t R = (size_t)sc->NA * sc->NS;
+    hipStream_t stream = (hipStream_t)stream_;
+    Tape tp = carve_tape(const_cast<void*>(tape), tape_bytes, R, FT);
+    StriveArena ar(ws, ws_bytes);
+    float* g_state = ar.take<float>(R * 8);
+    float* g_pos = ar.take<float>(R * 4);
+    float* d_loc = ar.take<float>(R * 4);
+    float* g_pf = ar.take<float>(R * 64);
+    float* g_mf = ar.take<float>(R * 64);
+    float* g_mem = ar.take<float>(R * 192);
+    GnnBwdBuffers bw = gnn_bwd_buffers_take(ar, R, 64, sc->max_n);
+    if (!ar.ok()) { strive_set_error("rollout_bwd: workspace arena overflow"); return -1; }
+
+    const GNNDev gd = gnn_dev(dec->gnn);
+    const GRUDev gr = gru_dev(dec->gru);
+    const GNNGradDev ggn = gnn_grad_dev(dec->gnn, tr ? tr->d_gnn : nullptr);
+    const GRUGradDev ggr = gru_grad_dev(tr ? tr->d_gru : nullptr);
+    const DynParams dp = dyn_params(*dec);
+    const ScenesDev sd = scenes_dev(*sc);
+    const int NC = dec->gnn.NC;
+    const int in_ld1 = ld4(dec->gnn.mlp_in.dims[0]), xs_ld = ld4(64 + NC), in_ld2 = ld4(128 + NC);
+    const int nb = (int)((R + RB_NODE - 1) / RB_NODE);
+
+    hipMemsetAsync(g_state, 0, R * 8 * 4, stream);
+    hipMemsetAsync(g_pos, 0, R * 4 * 4, stream);
+    hipMemsetAsync(d_loc, 0, R * 4 * 4, stream);
+    hipMemsetAsync(g_pf, 0, R * 64 * 4, stream);
+    hipMemsetAsync(g_mem, 0, R * 192 * 4, stream);
+    hipMemsetAsync(dz, 0, R * STRIVE_ZDIM * 4, stream);
+
+    for (int t = FT - 1; t >= 0; --t) {
+        GnnBuffers g2;
+        g2.A = tp.A_t(t);
+        g2.ARG = tp.ARG_t(t);
+        g2.X = tp.X_t(t);          // x, P, Q of step t as the forward sweep left them in the tape
+        g2.P = tp.P_t(t);
+        g2.Q = tp.Q_t(t);
+        FeatSrc f = decoder_features(tp, t, sem, z, lw, NC);
+        if (t < FT - 1)
+            hipLaunchKernelGGL(gru_bwd_kernel, dim3(nb), dim3(256), gru_bwd_lds_bytes(), stream, gr, ggr, tp, t, (int)R, g_pf,
+                               g_mem, d_loc);
+        Node2BwdArgs a2;
+        a2.t = t; a2.FT = FT; a2.R = (int)R; a2.NS = sc->NS; a2.X = g2.X; a2.sem = sem; a2.lw = lw; a2.ext = ext_future;
+        a2.ptr = sc->ptr; a2.scene_of = sc->scene_of; a2.g_traj = d_traj; a2.g_pos = g_pos; a2.d_loc = d_loc;
+        a2.g_state = g_state; a2.dX = bw.dX; a2.dA = bw.dA;
+        hipLaunchKernelGGL(node2_bwd_kernel, dim3(nb), dim3(256), node2_bwd_lds_bytes(in_ld2), stream, gd, ggn, dp, a2, tp);
+        EdgeBwdArgs ae;
+        ae.dA = bw.dA; ae.ARG = tp.ARG_t(t); ae.dP = bw.dP; ae.DE1 = bw.DE1; ae.DPJ = bw.DPJ; ae.gpos_tgt = bw.gpos_tgt;
+        hipLaunchKernelGGL(edge_bwd_kernel, dim3((unsigned)R), dim3(256), edge_bwd_lds_bytes(), stream, gd, ggn, sd, tp.pos_t(t),
+                           g2, ae);
+        Node1BwdArgs a1;
+        a1.t = t; a1.R = (int)R; a1.dX = bw.dX; a1.dP = bw.dP; a1.DE1 = bw.DE1; a1.DPJ = bw.DPJ; a1.gpos_tgt = bw.gpos_tgt;
+        a1.sem = sem; a1.g_pos = g_pos; a1.g_full = nullptr; a1.g_pf = g_pf; a1.g_mf = tr ? g_mf : nullptr; a1.dz = dz;
+        hipLaunchKernelGGL(node1_bwd_kernel, dim3(nb), dim3(256), node1_bwd_lds_bytes(in_ld1, xs_ld), stream, gd, ggn, sd, f, a1);
+        if (tr && t > 0) {
+            // map_feat_t = CNN(crop(pos_t.detach())) (reference traffic_model.py:694-695): its adjoint reaches the CNN weights
+            int rc = strive_map_cnn_bwd(&dec->map, &dec->cnn, tp.pos_t(t), dec->state_mean, dec->state_std, tr->mapix, (int32_t)R,
+                                        g_mf, tr->d_cnn, tr->cnn_ws, tr->cnn_ws_bytes, stream_);
+            if (rc) return rc;
+        }
+    }
+    if (tr)
+        hipLaunchKernelGGL(rollout_init_bwd_kernel, dim3((unsigned)((R * 64 + 255) / 256)), dim3(256), 0, stream, g_pf, g_mem, g_mf,
+                           tr->d_past_feat, tr->d_map_feat, (int)R);
+    return 0;
 }
 }  // namespace
 
@@ -777,65 +727,42 @@ extern "C" int strive_rollout_bwd(const StriveDecoder* dec, const StriveScenes* 
     STRIVE_CHECK_ARG(tape_bytes >= tape_bytes_for(R, FT), "tape too small");
     STRIVE_CHECK_ARG(ws_bytes >= strive_rollout_workspace_bytes(dec, sc, FT), "workspace too small");
     STRIVE_CHECK_ARG(sc->max_n >= 1, "max_n not set");
-    hipStream_t stream = (hipStream_t)stream_;
-    Tape tp = carve_tape(const_cast<void*>(tape), tape_bytes, R, FT);
-    StriveArena ar(ws, ws_bytes);
-    GnnBuffers gb;
-    gb.X = ar.take<float>(R * 64);
-    gb.P = ar.take<float>(R * STRIVE_HID);
-    gb.Q = ar.take<float>(R * STRIVE_HID);
-    float* g_state = ar.take<float>(R * 8);
-    float* g_pos = ar.take<float>(R * 4);
-    float* d_loc = ar.take<float>(R * 4);
-    float* g_pf = ar.take<float>(R * 64);
-    float* g_mem = ar.take<float>(R * 192);
-    float* dX = ar.take<float>(R * 64);
-    float* dA = ar.take<float>(R * 64);
-    float* dP = ar.take<float>(R * STRIVE_HID);
-    float* gpos_tgt = ar.take<float>(R * 4);
-    float* DE1 = ar.take<float>(R * (size_t)sc->max_n * STRIVE_HID);
-    float* DPJ = ar.take<float>(R * (size_t)sc->max_n * 4);
-    STRIVE_CHECK_ARG(ar.ok(), "workspace arena overflow");
+    int rc = rollout_backward(dec, sc, lw, sem, z, ext_future, FT, d_traj, dz, tape, tape_bytes, ws, ws_bytes, stream_, nullptr);
+    if (rc) return rc;
+    STRIVE_CHECK_LAUNCH();
+    return 0;
+}
 
-    const GNNDev gd = gnn_dev(dec->gnn);
-    const GRUDev gr = gru_dev(dec->gru);
-    const DynParams dp = dyn_params(*dec);
-    const ScenesDev sd = scenes_dev(*sc);
-    const int NC = dec->gnn.NC;
-    const int in_ld1 = ld4(dec->gnn.mlp_in.dims[0]), xs_ld = ld4(64 + NC), in_ld2 = ld4(128 + NC);
-    const int nb = (int)((R + RB_NODE - 1) / RB_NODE);
+extern "C" size_t strive_rollout_train_workspace_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT) {
+    if (!sc) return 0;
+    return strive_rollout_workspace_bytes(dec, sc, FT) + strive_align_up(strive_map_cnn_bwd_workspace_bytes(sc->NA * sc->NS), 256);
+}
 
-    hipMemsetAsync(g_state, 0, R * 8 * 4, stream);
-    hipMemsetAsync(g_pos, 0, R * 4 * 4, stream);
-    hipMemsetAsync(d_loc, 0, R * 4 * 4, stream);
-    hipMemsetAsync(g_pf, 0, R * 64 * 4, stream);
-    hipMemsetAsync(g_mem, 0, R * 192 * 4, stream);
-    hipMemsetAsync(dz, 0, R * STRIVE_ZDIM * 4, stream);
+extern "C" size_t strive_gnn_param_count(const StriveGNN* gnn) { return gnn ? gnn_param_count(*gnn) : 0; }
+extern "C" size_t strive_gru_param_count(void) { return gru_param_count(); }
 
-    for (int t = FT - 1; t >= 0; --t) {
-        GnnBuffers g2 = gb;
-        g2.A = tp.A_t(t);
-        g2.ARG = tp.ARG_t(t);
-        g2.X = tp.X_t(t);          // x, P, Q of step t as the forward sweep left them in the tape
-        g2.P = tp.P_t(t);
-        g2.Q = tp.Q_t(t);
-        FeatSrc f = decoder_features(tp, t, sem, z, lw, NC);
-        if (t < FT - 1)
-            hipLaunchKernelGGL(gru_bwd_kernel, dim3(nb), dim3(256), gru_bwd_lds_bytes(), stream, gr, tp, t, (int)R, g_pf, g_mem,
-                               d_loc);
-        Node2BwdArgs a2;
-        a2.t = t; a2.FT = FT; a2.R = (int)R; a2.NS = sc->NS; a2.X = g2.X; a2.sem = sem; a2.lw = lw; a2.ext = ext_future;
-        a2.ptr = sc->ptr; a2.scene_of = sc->scene_of; a2.g_traj = d_traj; a2.g_pos = g_pos; a2.d_loc = d_loc;
-        a2.g_state = g_state; a2.dX = dX; a2.dA = dA;
-        hipLaunchKernelGGL(node2_bwd_kernel, dim3(nb), dim3(256), node2_bwd_lds_bytes(in_ld2), stream, gd, dp, a2, tp);
-        EdgeBwdArgs ae;
-        ae.dA = dA; ae.ARG = tp.ARG_t(t); ae.dP = dP; ae.DE1 = DE1; ae.DPJ = DPJ; ae.gpos_tgt = gpos_tgt;
-        hipLaunchKernelGGL(edge_bwd_kernel, dim3((unsigned)R), dim3(256), edge_bwd_lds_bytes(), stream, gd, sd, tp.pos_t(t), g2, ae);
-        Node1BwdArgs a1;
-        a1.t = t; a1.R = (int)R; a1.dX = dX; a1.dP = dP; a1.DE1 = DE1; a1.DPJ = DPJ; a1.gpos_tgt = gpos_tgt;
-        a1.g_pf = g_pf; a1.g_pos = g_pos; a1.dz = dz;
-        hipLaunchKernelGGL(node1_bwd_kernel, dim3(nb), dim3(256), node1_bwd_lds_bytes(in_ld1, xs_ld), stream, gd, sd, f, a1);
-    }
+extern "C" int strive_rollout_bwd_train(const StriveDecoder* dec, const StriveScenes* sc, const float* lw, const float* sem,
+                                        const float* z, const float* ext_future, const int32_t* mapix, int32_t FT,
+                                        const float* d_traj, float* dz, float* d_past_feat, float* d_map_feat, float* d_gnn,
+                                        float* d_gru, float* d_cnn, const void* tape, size_t tape_bytes, void* ws,
+                                        size_t ws_bytes, strive_stream_t stream_) {
+    STRIVE_CHECK_ARG(dec && sc && lw && sem && z && mapix && d_traj && dz && d_past_feat && d_map_feat && d_gnn && d_gru && d_cnn &&
+                     tape && ws, "null argument");
+    if (check_decoder(dec, sc, FT)) return -1;
+    STRIVE_CHECK_ARG(sc->NS == 1, "the training backward takes 2-D latents (one sample per agent)");
+    const size_t R = (size_t)sc->NA;
+    if (R == 0) return 0;
+    STRIVE_CHECK_ARG(tape_bytes >= tape_bytes_for(R, FT), "tape too small");
+    STRIVE_CHECK_ARG(ws_bytes >= strive_rollout_train_workspace_bytes(dec, sc, FT), "workspace too small");
+    STRIVE_CHECK_ARG(sc->max_n >= 1, "max_n not set");
+    const size_t base = strive_rollout_workspace_bytes(dec, sc, FT);
+    TrainOut tr;
+    tr.d_past_feat = d_past_feat; tr.d_map_feat = d_map_feat; tr.d_gnn = d_gnn; tr.d_gru = d_gru; tr.d_cnn = d_cnn;
+    tr.mapix = mapix;
+    tr.cnn_ws = (char*)ws + base;
+    tr.cnn_ws_bytes = ws_bytes - base;
+    int rc = rollout_backward(dec, sc, lw, sem, z, ext_future, FT, d_traj, dz, tape, tape_bytes, ws, base, stream_, &tr);
+    if (rc) return rc;
     STRIVE_CHECK_LAUNCH();
     return 0;
 }

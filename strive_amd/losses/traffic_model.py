@@ -1,8 +1,9 @@
 """Training-time loss with the reference's names (reference src/losses/traffic_model.py:20-295).
 
-Forward values come from the same HIP collision kernels as the optimisation-time losses.  The HIP
-path does not provide weight gradients (round-1 scope: latent optimisation, d/dz only), so this loss
-is usable for evaluation / monitoring; ``backward()`` through the model raises in TrafficModel.forward.
+Values and gradients w.r.t. the predictions come from the same HIP collision kernels as the optimisation-time
+losses (autograd Functions in strive_amd.ops) plus elementwise torch glue; together with ``TrafficModel.forward``
+(which builds the parameter-gradient graph) ``loss_dict['loss'][0].backward()`` trains the model like the reference's
+loop (src/train_traffic.py:103-131).
 """
 import torch
 from torch import nn
@@ -81,6 +82,22 @@ class TrafficModelLoss(nn.Module):
             out['coll_env_prior'] = ce.view(-1)
         out['loss'] = loss.view((1,))
         return out
+
+
+    def compute_err(self, scene_graph, pred, normalizer):
+        """Interpretable errors the training / test loops log (reference :120-164): position error (m) and heading error
+        (degrees) per visible frame, NLL and Mahalanobis distance of the posterior mean under the prior per agent."""
+        vis = scene_graph.future_vis == 1.0
+        gt = normalizer.unnormalize(scene_graph.future_gt)[vis]
+        pf = normalizer.unnormalize(pred['future_pred'])[vis]
+        pos_err = torch.norm(gt[:, :2] - pf[:, :2], dim=-1)
+        gh = gt[:, 2:4] / torch.norm(gt[:, 2:4], dim=-1, keepdim=True)
+        ph = pf[:, 2:4] / torch.norm(pf[:, 2:4], dim=-1, keepdim=True)
+        ang_err = torch.rad2deg(torch.acos(torch.sum(gh * ph, dim=-1).clamp(-1, 1)))
+        pm, pv = pred['prior_out']
+        qm = pred['posterior_out'][0]
+        return {'pos_err': pos_err, 'ang_err': ang_err, 'z_logprob': log_normal(qm, pm, pv),
+                'z_mdist': torch.norm((qm - pm) / torch.sqrt(pv), dim=-1)}
 
 
 ENV_COLL_THRESH = 0.05   # up to 5 % of a vehicle may be off the road (reference :17)

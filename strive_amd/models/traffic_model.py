@@ -7,7 +7,8 @@ and the same 174-tensor ``state_dict`` layout, so the ref
 drivers and checkpoints work unchanged.  The arithmetic is not torch: every method hands tensors to
 the C ABI (include/strive_hip.h) through strive_amd.ops -- the decoder rollout is ONE call that
 enqueues the whole FT-step kernel sequence, and its backward is an explicit reverse-time sweep that
-yields d/dz only (what the latent-optimisation loops need).
+yields d/dz only when the loops call ``decode_embedding`` (what the latent optimisation needs, SURVEY.md
+Appendix A) and, inside ``forward()`` (training), also the gradients of every parameter.
 
 Not supported (raise NotImplementedError): ``traj_encoder='gru'``, ``output_bicycle=False`` and
 non-default map-CNN shapes -- no shipped config uses them (last paragraph).
@@ -209,16 +210,20 @@ class TrafficModel(nn.Module):
                 'future_pred': self.decoder(scene_graph, emb['map_feat'], emb['past_feat'], mu, map_idx, map_env)}
 
     def forward(self, scene_graph, map_idx, map_env, use_post_mean=False, future_sample=False):
-        """Training-time forward (reference src/models/traffic_model.py:178-225).  Values are produced by
-        the HIP path; weight gradients are not (see strive_amd/ops.py: training backward is out of the
-        round-1 scope and raises if requested)."""
-        emb = self.embed(scene_graph, map_idx, map_env)
-        pmu, pvar = emb['prior_out']
-        qmu, qvar = emb['posterior_out']
-        z = qmu if use_post_mean else self.rsample(qmu, qvar)
-        out = {'prior_out': (pmu, pvar), 'posterior_out': (qmu, qvar),
-               'future_pred': self.decoder(scene_graph, emb['map_feat'], emb['past_feat'], z, map_idx, map_env)}
-        if future_sample:
-            zp = self.rsample(pmu, pvar)
-            out['future_samp'] = self.decoder(scene_graph, emb['map_feat'], emb['past_feat'], zp, map_idx, map_env)
+        """Training-time forward (reference src/models/traffic_model.py:178-225): posterior-sample rollout (+ prior-sample
+        rollout with ``future_sample``).  This is the one entry point that builds an autograd graph with PARAMETER
+        gradients: while it runs (with grad enabled and trainable parameters) every HIP operator -- map CNN, trajectory
+        encoders, prior / posterior networks, decoder rollout -- is an autograd Function whose backward is the matching
+        ``strive_*_bwd`` call, so ``loss.backward()`` fills ``p.grad`` of all 174 tensors like the reference."""
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        with ops.weight_grad_mode(train):
+            emb = self.embed(scene_graph, map_idx, map_env)
+            pmu, pvar = emb['prior_out']
+            qmu, qvar = emb['posterior_out']
+            z = qmu if use_post_mean else self.rsample(qmu, qvar)
+            out = {'prior_out': (pmu, pvar), 'posterior_out': (qmu, qvar),
+                   'future_pred': self.decoder(scene_graph, emb['map_feat'], emb['past_feat'], z, map_idx, map_env)}
+            if future_sample:
+                zp = self.rsample(pmu, pvar)
+                out['future_samp'] = self.decoder(scene_graph, emb['map_feat'], emb['past_feat'], zp, map_idx, map_env)
         return out

@@ -76,6 +76,47 @@ def _sd_of(module, prefix):
 
 
 # ------------------------------------------------------------------------------------------------
+# weight-gradient mode (the training path)
+# ------------------------------------------------------------------------------------------------
+
+class _WeightGradMode(object):
+    """The latent-optimisation loops differentiate w.r.t. the latents only, and that is all the HIP path computes when its
+    operators are called directly (embed / decode_embedding / sample_batched).  ``TrafficModel.forward`` -- the training
+    entry point (reference src/train_traffic.py:103-118) -- switches this mode on, and the same operators then run as
+    autograd Functions that also return the gradients of every parameter they read."""
+    on = False
+
+    def __init__(self, enable):
+        self.enable = bool(enable)
+
+    def __enter__(self):
+        self.prev = _WeightGradMode.on
+        _WeightGradMode.on = self.enable
+        return self
+
+    def __exit__(self, *exc):
+        _WeightGradMode.on = self.prev
+
+
+def weight_grad_mode(enable=True):
+    return _WeightGradMode(enable)
+
+
+def _wgrad():
+    return _WeightGradMode.on and torch.is_grad_enabled()
+
+
+def _split_like(flat, params):
+    out, off = [], 0
+    for p in params:
+        n = p.numel()
+        out.append(flat[off:off + n].view(p.shape))
+        off += n
+    assert off == flat.numel(), 'flat gradient size %d does not match the parameters (%d)' % (flat.numel(), off)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
 # scene structure
 # ------------------------------------------------------------------------------------------------
 
@@ -173,24 +214,79 @@ def _no_grad_inputs(what, *tensors):
                                           'w.r.t. this input are not implemented' % what)
 
 
+class _MLPFn(torch.autograd.Function):
+    """MLP with parameter gradients (training path): forward = strive_mlp_fwd, backward = strive_mlp_bwd."""
+
+    @staticmethod
+    def forward(ctx, x2, h, *ps):
+        y = torch.empty((x2.shape[0], h.O), dtype=torch.float32, device=x2.device)
+        h.lib.call('strive_mlp_fwd', h.pk.ref(), L.ptr(x2), x2.shape[0], L.ptr(y), _stream(x2))
+        ctx.h, ctx.x2, ctx.ps = h, x2, ps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, x2 = ctx.h, ctx.x2
+        n = h.lib.query('strive_mlp_param_count', h.pk.ref())
+        dp = torch.zeros((n,), dtype=torch.float32, device=x2.device)
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        h.lib.call('strive_mlp_bwd', h.pk.ref(), L.ptr(x2), L.ptr(_f32c(dy)), x2.shape[0], L.ptr(dx), L.ptr(dp), _stream(x2))
+        return (dx, None) + tuple(_split_like(dp, ctx.ps))
+
+
 def mlp_forward(mlp_module, x):
     lib = _lib_for(x)
-    _no_grad_inputs('MLP.forward', x)
     pk = _cached_pack(mlp_module, 'mlp', mlp_module, lambda: params.pack_mlp(_sd_of(mlp_module, 'm'), 'm'))
     shp = x.shape
     if shp[-1] != pk.struct.dims[0]:
         raise ValueError('MLP expects %d input features, got %d' % (pk.struct.dims[0], shp[-1]))
-    x2 = _f32c(x).reshape(-1, shp[-1])
     O = pk.struct.dims[pk.struct.nlayers]
+    if _wgrad():
+        h = _RolloutCtx()
+        h.lib, h.pk, h.O = lib, pk, O
+        x2 = x.to(torch.float32).contiguous().reshape(-1, shp[-1])
+        return _MLPFn.apply(x2, h, *list(mlp_module.parameters())).reshape(tuple(shp[:-1]) + (O,))
+    _no_grad_inputs('MLP.forward', x)
+    x2 = _f32c(x).reshape(-1, shp[-1])
     y = torch.empty((x2.shape[0], O), dtype=torch.float32, device=x.device)
     lib.call('strive_mlp_fwd', pk.ref(), L.ptr(x2), x2.shape[0], L.ptr(y), _stream(x))
     return y.reshape(tuple(shp[:-1]) + (O,))
 
 
+class _GNNFn(torch.autograd.Function):
+    """SceneInteractionNet with parameter gradients (training path): strive_gnn_fwd / strive_gnn_bwd."""
+
+    @staticmethod
+    def forward(ctx, x2, h, *ps):
+        out = torch.empty((h.R, h.O), dtype=torch.float32, device=x2.device)
+        wsb = h.lib.query('strive_gnn_workspace_bytes', h.pk.ref(), h.sc.ref())
+        ws = _workspace(x2.device, wsb)
+        h.lib.call('strive_gnn_fwd', h.pk.ref(), h.sc.ref(), L.ptr(x2), L.ptr(h.pos), L.ptr(h.sem), L.ptr(out), L.ptr(ws),
+                   ws.numel(), _stream(x2))
+        ctx.h, ctx.x2, ctx.ps = h, x2, ps
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        h, x2 = ctx.h, ctx.x2
+        n = h.lib.query('strive_gnn_param_count', h.pk.ref())
+        dp = torch.zeros((n,), dtype=torch.float32, device=x2.device)
+        dx = torch.empty_like(x2)
+        wsb = h.lib.query('strive_gnn_bwd_workspace_bytes', h.pk.ref(), h.sc.ref())
+        ws = _workspace(x2.device, wsb, 'gnn_bwd')
+        h.lib.call('strive_gnn_bwd', h.pk.ref(), h.sc.ref(), L.ptr(x2), L.ptr(h.pos), L.ptr(h.sem), L.ptr(_f32c(d_out)), L.ptr(dx),
+                   L.ptr(dp), L.ptr(ws), ws.numel(), _stream(x2))
+        return (dx, None) + tuple(_split_like(dp, ctx.ps))
+
+
 def gnn_forward(net, scene_graph):
     x, pos, sem = scene_graph.x, scene_graph.pos, scene_graph.sem
     lib = _lib_for(x, pos, sem)
-    _no_grad_inputs('SceneInteractionNet.forward', x, pos)
+    train = _wgrad()
+    if train:
+        _no_grad_inputs('SceneInteractionNet.forward (poses)', pos)
+    else:
+        _no_grad_inputs('SceneInteractionNet.forward', x, pos)
     info = scene_info(scene_graph)
     multi = x.dim() == 3
     NS = x.shape[1] if multi else 1
@@ -200,9 +296,14 @@ def gnn_forward(net, scene_graph):
     R = info.NA * NS
     if x.shape[-1] != pk.struct.mlp_in.dims[0] or x.shape[0] != info.NA:
         raise ValueError('interaction net expects (%d, %d) node features, got %s' % (info.NA, pk.struct.mlp_in.dims[0], tuple(x.shape)))
-    x2 = _f32c(x).reshape(R, -1)
     p2 = _f32c(pos).reshape(R, 4)
     O = pk.struct.mlp_out.dims[pk.struct.mlp_out.nlayers]
+    if train:
+        h = _RolloutCtx()
+        h.lib, h.pk, h.sc, h.R, h.O, h.pos, h.sem = lib, pk, sc, R, O, p2, _f32c(sem)
+        out = _GNNFn.apply(x.to(torch.float32).contiguous().reshape(R, -1), h, *list(net.parameters()))
+        return out.reshape(info.NA, NS, O) if multi else out
+    x2 = _f32c(x).reshape(R, -1)
     out = torch.empty((R, O), dtype=torch.float32, device=x.device)
     wsb = lib.query('strive_gnn_workspace_bytes', pk.ref(), sc.ref())
     ws = _workspace(x.device, wsb)
@@ -254,8 +355,38 @@ def cnn_pack(model):
     return _cached_pack(model, 'cnn', (model.map_conv, model.map_feature), lambda: params.pack_cnn(model.state_dict()))
 
 
+def _cnn_params(model):
+    return list(model.map_conv.parameters()) + list(model.map_feature.parameters())
+
+
+class _CNNFn(torch.autograd.Function):
+    """encode_map with parameter gradients (training path): strive_map_cnn_fwd / strive_map_cnn_bwd (the crop is data)."""
+
+    @staticmethod
+    def forward(ctx, h, *ps):
+        feat = torch.empty((h.N, 64), dtype=torch.float32, device=h.p2.device)
+        wsb = h.lib.query('strive_map_cnn_workspace_bytes', h.N)
+        ws = _workspace(h.p2.device, wsb, 'cnn')
+        h.lib.call('strive_map_cnn_fwd', h.mp.ref(), h.cnn.ref(), L.ptr(h.p2), h.mean4, h.std4, L.ptr(h.mapix), h.N, L.ptr(feat),
+                   L.ptr(ws), ws.numel(), _stream(h.p2))
+        ctx.h, ctx.ps = h, ps
+        return feat
+
+    @staticmethod
+    def backward(ctx, d_feat):
+        h = ctx.h
+        dev = h.p2.device
+        dp = torch.zeros((h.lib.query('strive_map_cnn_param_count'),), dtype=torch.float32, device=dev)
+        wsb = h.lib.query('strive_map_cnn_bwd_workspace_bytes', h.N)
+        ws = _workspace(dev, wsb, 'cnn_bwd')
+        h.lib.call('strive_map_cnn_bwd', h.mp.ref(), h.cnn.ref(), L.ptr(h.p2), h.mean4, h.std4, L.ptr(h.mapix), h.N,
+                   L.ptr(_f32c(d_feat)), L.ptr(dp), L.ptr(ws), ws.numel(), _stream(h.p2))
+        return (None,) + tuple(_split_like(dp, ctx.ps))
+
+
 def encode_map(model, pos, batch_of_agent, map_idx, map_env):
-    """Map feature at NORMALISED ``pos`` (NA,4)/(NA,NS,4) -> (NA,[NS,]64): fused crop + CNN, no gradient."""
+    """Map feature at NORMALISED ``pos`` (NA,4)/(NA,NS,4) -> (NA,[NS,]64): fused crop + CNN.  No gradient w.r.t. the pose
+    (the crop is a lookup); parameter gradients on the training path only."""
     lib = _lib_for(pos)
     multi = pos.dim() == 3
     NA = pos.shape[0]
@@ -268,10 +399,16 @@ def encode_map(model, pos, batch_of_agent, map_idx, map_env):
         mapix = mapix.view(NA, 1).expand(NA, NS).reshape(-1)
     mapix = mapix.contiguous()
     p2 = _f32c(pos).reshape(NA * NS, 4)
+    nm = model.normalizer
+    if _wgrad():
+        h = _RolloutCtx()
+        h.lib, h.mp, h.cnn, h.p2, h.mapix, h.N = lib, mp, cnn, p2, mapix, NA * NS
+        h.mean4, h.std4 = L.f4(nm.mean_vals[:4].tolist()), L.f4(nm.std_vals[:4].tolist())
+        feat = _CNNFn.apply(h, *_cnn_params(model))
+        return feat.reshape(NA, NS, 64) if multi else feat
     feat = torch.empty((NA * NS, 64), dtype=torch.float32, device=dev)
     wsb = lib.query('strive_map_cnn_workspace_bytes', NA * NS)
     ws = _workspace(dev, wsb, 'cnn')
-    nm = model.normalizer
     lib.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(p2), L.f4(nm.mean_vals[:4].tolist()),
              L.f4(nm.std_vals[:4].tolist()), L.ptr(mapix), NA * NS, L.ptr(feat), L.ptr(ws), ws.numel(), _stream(pos))
     return feat.reshape(NA, NS, 64) if multi else feat
@@ -360,15 +497,61 @@ class _RolloutFn(torch.autograd.Function):
         return dz.reshape(ctx.zshape), None
 
 
+class _RolloutTrainFn(torch.autograd.Function):
+    """autoregressive_decoder with parameter gradients (training path): strive_rollout_fwd / strive_rollout_bwd_train.
+    Differentiable inputs: z, past_feat, map_feat; parameters: decoder_net, decoder_memory, map_conv, map_feature."""
+
+    @staticmethod
+    def forward(ctx, z, past_feat, map_feat, h, *ps):
+        lib = h.lib
+        dev = z.device
+        zz = z.to(torch.float32).contiguous().reshape(h.R, 32)
+        pf = past_feat.to(torch.float32).contiguous()
+        mf = map_feat.to(torch.float32).contiguous()
+        traj = torch.empty((h.R, h.FT, 4), dtype=torch.float32, device=dev)
+        tape = torch.empty(h.tape_bytes, dtype=torch.uint8, device=dev)
+        ws = _workspace(dev, h.ws_bytes, 'rollout')
+        lib.call('strive_rollout_fwd', h.dec.ref(), h.sc.ref(), L.ptr(h.past_last), L.ptr(h.lw), L.ptr(h.sem), L.ptr(pf), L.ptr(mf),
+                 L.ptr(zz), L.ptr(h.mapix), L.ptr(h.ext), h.FT, L.ptr(traj), L.ptr(tape), tape.numel(), L.ptr(ws), ws.numel(),
+                 _stream(z))
+        ctx.h, ctx.tape, ctx.zz, ctx.zshape, ctx.ps = h, tape, zz, z.shape, ps
+        return traj
+
+    @staticmethod
+    def backward(ctx, d_traj):
+        h = ctx.h
+        lib = h.lib
+        dev = d_traj.device
+        dz = torch.empty((h.R, 32), dtype=torch.float32, device=dev)
+        dpf = torch.empty((h.R, 64), dtype=torch.float32, device=dev)
+        dmf = torch.empty((h.R, 64), dtype=torch.float32, device=dev)
+        ng = lib.query('strive_gnn_param_count', C.byref(h.dec.struct.gnn))
+        nr = lib.query('strive_gru_param_count')
+        nc = lib.query('strive_map_cnn_param_count')
+        dp = torch.zeros((ng + nr + nc,), dtype=torch.float32, device=dev)
+        wsb = lib.query('strive_rollout_train_workspace_bytes', h.dec.ref(), h.sc.ref(), h.FT)
+        ws = _workspace(dev, wsb, 'rollout_train')
+        lib.call('strive_rollout_bwd_train', h.dec.ref(), h.sc.ref(), L.ptr(h.lw), L.ptr(h.sem), L.ptr(ctx.zz), L.ptr(h.ext),
+                 L.ptr(h.mapix), h.FT, L.ptr(_f32c(d_traj)), L.ptr(dz), L.ptr(dpf), L.ptr(dmf), L.ptr(dp[:ng]), L.ptr(dp[ng:ng + nr]),
+                 L.ptr(dp[ng + nr:]), L.ptr(ctx.tape), ctx.tape.numel(), L.ptr(ws), ws.numel(), _stream(d_traj))
+        return (dz.reshape(ctx.zshape), dpf, dmf, None) + tuple(_split_like(dp, ctx.ps))
+
+
 def decoder_rollout(model, g, map_feat, past_feat, z, map_idx, map_env, ext_future, FT):
     """autoregressive_decoder as one fused call; differentiable w.r.t. ``z`` only."""
     lib = _lib_for(z, map_feat, past_feat, g.past)
     if model.normalizer is None or model.att_normalizer is None or model.bicycle_params is None:
         raise RuntimeError('set_normalizer / set_att_normalizer / set_bicycle_params must be called before decoding')
-    _no_grad_inputs('decoder', map_feat, past_feat, ext_future)
+    train = _wgrad()
+    if train:
+        _no_grad_inputs('decoder (ext_future)', ext_future)
+    else:
+        _no_grad_inputs('decoder', map_feat, past_feat, ext_future)
     dev = z.device
     info = scene_info(g)
     multi = z.dim() == 3
+    if train and multi:
+        raise NotImplementedError('the training backward takes 2-D latents (reference TrafficModel.forward never passes samples)')
     NS = z.shape[1] if multi else 1
     if ext_future is not None and multi:
         raise NotImplementedError('ext_future together with multiple samples (the reference crashes there too)')
@@ -400,6 +583,10 @@ def decoder_rollout(model, g, map_feat, past_feat, z, map_idx, map_env, ext_futu
         raise ValueError('ext_future must be (B, FT, 4), got %s' % (tuple(h.ext.shape),))
     h.tape_bytes = lib.query('strive_rollout_tape_bytes', h.dec.ref(), h.sc.ref(), h.FT)
     h.ws_bytes = lib.query('strive_rollout_workspace_bytes', h.dec.ref(), h.sc.ref(), h.FT)
+    if train:
+        ps = list(model.decoder_net.parameters()) + list(model.decoder_memory.parameters()) + _cnn_params(model)
+        traj = _RolloutTrainFn.apply(z, past_feat, map_feat, h, *ps)
+        return traj.reshape(info.NA, h.FT, 4)
     traj = _RolloutFn.apply(z, h)
     return traj.reshape(info.NA, NS, h.FT, 4) if multi else traj.reshape(info.NA, h.FT, 4)
 

@@ -174,6 +174,7 @@ def _fill_cnn(s, holder, sd):
         else:
             pk = w.view(co, ci // 2, 2, k, k).permute(1, 3, 4, 2, 0).contiguous()   # [ci/2][ky][kx][ci&1][co]
         s.w[l] = holder.hold(pk)
+        s.w_torch[l] = holder.hold(w)                                     # (co, ci, ky, kx): the training backward's data gradient
         s.b[l] = holder.hold(_c(sd['map_conv.%d.bias' % (3 * l)]))
         s.gn_g[l] = holder.hold(_c(sd['map_conv.%d.weight' % (3 * l + 1)]))
         s.gn_b[l] = holder.hold(_c(sd['map_conv.%d.bias' % (3 * l + 1)]))

@@ -36,6 +36,7 @@ struct uint3_emu { unsigned x, y, z; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(8) float2 { float x, y; };
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
 struct alignas(8) uint2 { unsigned x, y; };
 inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
 struct alignas(16) uint4 { unsigned x, y, z, w; };
@@ -182,6 +183,7 @@ inline unsigned long long __ballot(int pred) {
 
 // ---- atomics (single OS thread: plain read-modify-write) ----
 template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <typename T> inline T unsafeAtomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
 inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }

@@ -275,3 +275,139 @@ def test_map_cnn_eight_agents(emu, sd):
     emu.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(fr), L.f4([0] * 4), L.f4([1] * 4), L.ptr(mi), n, L.ptr(feat),
              L.ptr(ws), wsb, None)
     assert_close(feat, want, 1e-4, 1e-5, 'cnn x8')
+
+
+# ------------------------------------------------------------------------------------------------
+# training backward: weight gradients (flat buffers in named_parameters() order) vs torch autograd of the oracle
+# ------------------------------------------------------------------------------------------------
+
+def _grad_sd(sd):
+    return {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+
+
+def _flat_grads(sdg, prefix):
+    return torch.cat([(v.grad if v.grad is not None else torch.zeros_like(v)).reshape(-1) for k, v in sdg.items()
+                      if k.startswith(prefix + '.')])
+
+
+def _check_flat(got, want, sdg, prefix, rtol=2e-3, what=''):
+    """per-parameter comparison so a failure names the tensor"""
+    off = 0
+    for k, v in sdg.items():
+        if not k.startswith(prefix + '.'):
+            continue
+        n = v.numel()
+        w = want[off:off + n]
+        g = got[off:off + n]
+        scale = float(w.abs().max())
+        assert_close(g, w, rtol, 1e-6 + 2e-4 * scale, '%s grad %s' % (what, k))
+        off += n
+    assert off == got.numel() == want.numel()
+
+
+def test_mlp_bwd_weight_and_input_gradients(emu, sd):
+    sdg = _grad_sd(sd)
+    x = synth.f32(synth.counter_uniform((7, 38), 'emu/mlpb/x', -1.0, 1.0)).requires_grad_(True)
+    y = om.mlp(sdg, 'past_encoder', x)
+    rw = synth.f32(synth.counter_uniform(tuple(y.shape), 'emu/mlpb/r', -1.0, 1.0))
+    (y * rw).sum().backward()
+    mp = params.pack_mlp(sd, 'past_encoder')
+    n = emu.query('strive_mlp_param_count', mp.ref())
+    want = _flat_grads(sdg, 'past_encoder')
+    assert n == want.numel()
+    dp = torch.zeros(n)
+    dx = torch.zeros((7, 38))
+    emu.call('strive_mlp_bwd', mp.ref(), L.ptr(x.detach().contiguous()), L.ptr(rw.contiguous()), 7, L.ptr(dx), L.ptr(dp), None)
+    assert_close(dx, x.grad, 2e-3, 1e-6, 'mlp dx')
+    _check_flat(dp, want, sdg, 'past_encoder', what='mlp')
+    # accumulation + no input gradient requested
+    emu.call('strive_mlp_bwd', mp.ref(), L.ptr(x.detach().contiguous()), L.ptr(rw.contiguous()), 7, None, L.ptr(dp), None)
+    _check_flat(dp, 2 * want, sdg, 'past_encoder', what='mlp (accumulated)')
+
+
+@pytest.mark.parametrize('name,prefix,fin', [('decoder', 'decoder_net', 164), ('posterior', 'posterior_net', 194)])
+def test_gnn_bwd_weight_and_input_gradients(emu, sd, name, prefix, fin):
+    sdg = _grad_sd(sd)
+    batch, map_idx, raster, dx_ = mg.build_inputs([3, 5, 1, 2], 'emu/gnnb')
+    NA = batch.past.shape[0]
+    x = synth.f32(synth.counter_uniform((NA, fin), 'emu/gnnb/x/' + name, -1.0, 1.0)).requires_grad_(True)
+    pos = batch.past[:, -1, :4].clone().contiguous()
+    y = om.interaction_net(sdg, prefix, x, pos, batch.sem, batch.edge_index)
+    rw = synth.f32(synth.counter_uniform(tuple(y.shape), 'emu/gnnb/r/' + name, -1.0, 1.0))
+    (y * rw).sum().backward()
+    gp = params.pack_gnn(sd, prefix, 2)
+    sc = params.pack_scenes(batch.ptr, 1, 'cpu')
+    n = emu.query('strive_gnn_param_count', gp.ref())
+    want = _flat_grads(sdg, prefix)
+    assert n == want.numel()
+    wsb = emu.query('strive_gnn_bwd_workspace_bytes', gp.ref(), sc.ref())
+    ws = torch.zeros(wsb, dtype=torch.uint8)
+    dp = torch.zeros(n)
+    dxo = torch.zeros((NA, fin))
+    emu.call('strive_gnn_bwd', gp.ref(), sc.ref(), L.ptr(x.detach().contiguous()), L.ptr(pos), L.ptr(batch.sem.contiguous()),
+             L.ptr(rw.contiguous()), L.ptr(dxo), L.ptr(dp), L.ptr(ws), wsb, None)
+    assert_close(dxo, x.grad, 2e-3, 1e-6 + 2e-4 * float(x.grad.abs().max()), name + ' dx')
+    _check_flat(dp, want, sdg, prefix, what=name)
+
+
+def _rollout_train(emu, sd, sizes, FT):
+    sdg = _grad_sd(sd)
+    batch, map_idx, raster, dx_ = mg.build_inputs(sizes, 'emu/rt')
+    env = synth.SyntheticMapEnv(raster, dx_)
+    NA = batch.past.shape[0]
+    orc = oracle_model(sdg)
+    mf = synth.f32(synth.counter_uniform((NA, 64), 'emu/rt/mf', -1, 1)).requires_grad_(True)
+    pf = synth.f32(synth.counter_uniform((NA, 64), 'emu/rt/pf', -1, 1)).requires_grad_(True)
+    z = synth.f32(synth.counter_normal((NA, 32), 'emu/rt/z')).requires_grad_(True)
+    pred = orc.decode(batch, mf, pf, z, map_idx, env, nfuture=FT)
+    rw = synth.f32(synth.counter_uniform(tuple(pred.shape), 'emu/rt/rw', -1.0, 1.0))
+    (pred * rw).sum().backward()
+    sn, an = orc.get_normalizer(), orc.get_att_normalizer()
+    dec = params.pack_decoder(sd, 2, env, 'cpu', sn, an, NUSC_BIKE_PARAMS)
+    sc = params.pack_scenes(batch.ptr, 1, 'cpu')
+    tb = emu.query('strive_rollout_tape_bytes', dec.ref(), sc.ref(), FT)
+    wb = emu.query('strive_rollout_train_workspace_bytes', dec.ref(), sc.ref(), FT)
+    tape, ws = torch.zeros(tb, dtype=torch.uint8), torch.zeros(wb, dtype=torch.uint8)
+    traj = torch.zeros((NA, FT, 4))
+    zz = z.detach().contiguous()
+    mi = map_idx[batch.batch].int().contiguous()
+    lw, sem = batch.lw.contiguous(), batch.sem.contiguous()
+    emu.call('strive_rollout_fwd', dec.ref(), sc.ref(), L.ptr(batch.past[:, -1, :].contiguous()), L.ptr(lw), L.ptr(sem),
+             L.ptr(pf.detach().contiguous()), L.ptr(mf.detach().contiguous()), L.ptr(zz), L.ptr(mi), None, FT,
+             L.ptr(traj), L.ptr(tape), tb, L.ptr(ws), wb, None)
+    assert_close(traj, pred.detach(), 1e-4, 1e-5, 'rollout fwd')
+    ng, nr, nc = emu.query('strive_gnn_param_count', dec.struct.gnn), emu.query('strive_gru_param_count'), \
+        emu.query('strive_map_cnn_param_count')
+    dz, dpf, dmf = torch.zeros((NA, 32)), torch.zeros((NA, 64)), torch.zeros((NA, 64))
+    dg, dr, dc = torch.zeros(ng), torch.zeros(nr), torch.zeros(nc)
+    emu.call('strive_rollout_bwd_train', dec.ref(), sc.ref(), L.ptr(lw), L.ptr(sem), L.ptr(zz), None, L.ptr(mi), FT,
+             L.ptr(rw.contiguous()), L.ptr(dz), L.ptr(dpf), L.ptr(dmf), L.ptr(dg), L.ptr(dr), L.ptr(dc), L.ptr(tape), tb,
+             L.ptr(ws), wb, None)
+    at = 1e-4 if FT == 1 else 3e-3      # FT > 1: the step-1 map feature comes from two different fp32 CNN evaluations
+    assert_close(dz, z.grad, 2e-3, 1e-6 + at * float(z.grad.abs().max()), 'dz')
+    assert_close(dpf, pf.grad, 2e-3, 1e-6 + at * float(pf.grad.abs().max()), 'd past_feat')
+    assert_close(dmf, mf.grad, 2e-3, 1e-6 + at * float(mf.grad.abs().max()), 'd map_feat')
+    _check_flat(dg, _flat_grads(sdg, 'decoder_net'), sdg, 'decoder_net', what='rollout')
+    if FT > 1:
+        _check_flat(dr, _flat_grads(sdg, 'decoder_memory'), sdg, 'decoder_memory', what='rollout')
+        want_c = torch.cat([_flat_grads(sdg, 'map_conv'), _flat_grads(sdg, 'map_feature')])
+        off = 0
+        for k, v in sdg.items():
+            if k.startswith('map_conv.') or k.startswith('map_feature.'):
+                n = v.numel()
+                w = want_c[off:off + n]
+                assert_close(dc[off:off + n], w, 5e-3, 1e-6 + 5e-4 * float(w.abs().max()), 'rollout grad ' + k)
+                off += n
+        assert off == nc
+    else:
+        assert float(dr.abs().max()) == 0.0 and float(dc.abs().max()) == 0.0
+
+
+def test_rollout_train_backward_single_step(emu, sd):
+    """FT = 1: decoder_net weight gradients + the adjoints of past_feat / map_feat / z."""
+    _rollout_train(emu, sd, [3, 1, 4], 1)
+
+
+def test_rollout_train_backward_two_steps(emu, sd):
+    """FT = 2: adds the GRU memory's weight gradients and one map-CNN backward (crop at the detached step-0 pose)."""
+    _rollout_train(emu, sd, [2], 2)

@@ -1,0 +1,150 @@
+"""The training path (BASELINE.json configs[3]): TrafficModel.forward as an autograd graph of HIP
+Functions with PARAMETER gradients, TrafficModelLoss on it, and the data-parallel gradient exchange.
+
+  * CPU (-m "not gpu"): the product's forward -> loss -> backward on a tiny scene through the host-emulation build of the
+    same .hip sources, all 174 parameter gradients against torch autograd of the oracle; the gloo world-size-2
+    data-parallel step against the single-process step.
+  * GPU (-m gpu): the G5 scene (reference fixture: loss terms + 8 weight-gradient tensors produced by the reference's own
+    TrafficModel / TrafficModelLoss / backward) and all 174 gradients against the oracle.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import make_golden as mg
+from util import golden, oracle_model, product_model, assert_close
+from strive_amd import synth
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'hipemu'))
+
+TW = {'recon': 1.0, 'kl': 0.004, 'coll_veh_prior': 0.05, 'coll_env_prior': 0.1}     # train_traffic.cfg:17-21
+
+
+def _oracle_step(sd, batch, map_idx, env, eps_post, eps_prior, FT=12):
+    from oracle import losses as ol
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    orc = oracle_model(sdg, FT=FT)
+    out = orc.forward(batch, map_idx, env, eps_post=eps_post, eps_prior=eps_prior)
+    ld = ol.traffic_model_loss(TW, batch, out, orc.get_normalizer(), orc.get_att_normalizer(), map_idx, env)
+    ld['loss'].sum().backward()
+    return out, ld, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sdg.items()}
+
+
+def _product_step(m, batch, map_idx, env, eps_post, eps_prior):
+    from strive_amd.losses.traffic_model import TrafficModelLoss
+    m.train()
+    for p in m.parameters():
+        p.grad = None
+    seq = [eps_post, eps_prior]
+    saved = m.rsample
+    m.rsample = lambda mean, var: mean + seq.pop(0).to(mean.device) * torch.sqrt(var)      # the reference draws eps unseeded
+    try:
+        out = m(batch, map_idx, env, future_sample=True)
+    finally:
+        m.rsample = saved
+    lf = TrafficModelLoss(TW, m.get_normalizer(), m.get_att_normalizer())
+    ld = lf(batch, out, map_idx=map_idx, map_env=env)
+    ld['loss'][0].backward()
+    err = lf.compute_err(batch, out, m.get_normalizer())
+    return out, ld, {n: p.grad for n, p in m.named_parameters()}, err
+
+
+def _compare_grads(got, want, rtol, frac_atol, what):
+    assert set(got) == set(want) and len(got) == 174
+    worst = ('', 0.0)
+    for n in want:
+        assert got[n] is not None, 'no gradient for %s' % n
+        w = want[n]
+        scale = float(w.abs().max())
+        g = got[n].detach().cpu()
+        rel = float((g - w).norm() / max(float(w.norm()), 1e-30))
+        if rel > worst[1]:
+            worst = (n, rel)
+        assert_close(g, w, rtol, 1e-7 + frac_atol * scale, '%s: grad %s' % (what, n))
+    return worst
+
+
+@pytest.fixture(scope='module')
+def emu_ops():
+    import build as emu_build
+    from strive_amd import _lib as L, ops
+    emu = L.StriveLib(emu_build.build(), require_all=True)
+    orig = (ops._lib_for, L.get_lib)
+    ops._lib_for = lambda *tensors: emu           # CPU tensors + the emulated library: test infrastructure only
+    L.get_lib = lambda: emu
+    yield emu
+    ops._lib_for, L.get_lib = orig
+
+
+def test_training_step_all_gradients_emulated(emu_ops):
+    """forward(future_sample=True) -> TrafficModelLoss -> backward on 3 agents with FT = 2, every one of the 174 parameter
+    gradients against autograd of the oracle."""
+    m, sd = product_model(FT=2)
+    batch, map_idx = synth.make_batch([2, 1], key='train/emu', FT=2)
+    raster, dx = synth.make_raster(1024, 1024)
+    env = synth.SyntheticMapEnv(raster, dx)
+    NA = batch.past.shape[0]
+    eps_post = synth.f32(synth.counter_normal((NA, 32), 'train/eps_post'))
+    eps_prior = synth.f32(synth.counter_normal((NA, 32), 'train/eps_prior'))
+    out_o, ld_o, g_o = _oracle_step(sd, batch, map_idx, env, eps_post, eps_prior, FT=2)
+    out, ld, g, err = _product_step(m, batch.clone(), map_idx, env, eps_post, eps_prior)
+    assert_close(out['future_pred'], out_o['future_pred'], 1e-4, 2e-5, 'future_pred')
+    assert_close(out['future_samp'], out_o['future_samp'], 1e-4, 2e-5, 'future_samp')
+    for k in ('loss', 'recon_loss', 'kl_loss', 'coll_veh_prior', 'coll_env_prior'):
+        assert_close(ld[k], ld_o[k], 2e-3, 2e-3 if 'env' in k else 1e-5, k)
+    worst = _compare_grads(g, g_o, 5e-3, 2e-3, 'emulated training step')
+    print('worst relative L2 gradient error: %s %.3g' % worst)
+    assert set(err) == {'pos_err', 'ang_err', 'z_logprob', 'z_mdist'} and err['pos_err'].shape == (NA * 2,)
+    # the optimisation entry points still give d/dz only and never touch parameter gradients
+    for p in m.parameters():
+        p.grad = None
+    with torch.no_grad():
+        emb = m.embed(batch.clone(), map_idx, env)
+    z = emb['prior_out'][0].clone().requires_grad_(True)
+    m.decode_embedding(z, emb, batch.clone(), map_idx, env)['future_pred'].sum().backward()
+    assert z.grad is not None and all(p.grad is None for p in m.parameters())
+    m.eval()
+
+
+@pytest.mark.gpu
+def test_training_step_golden_and_all_gradients():
+    """The G5 scene on the MI355X: loss terms and 8 weight-gradient tensors of the REFERENCE's own training step (fixture),
+    and all 174 gradients against the oracle."""
+    DEV = 'cuda:0'
+    g = golden('g5_losses.npz')
+    m, sd = product_model(device=DEV)
+    batch, map_idx, raster, dx = mg.g5_inputs(None, None)
+    NA = batch.past.shape[0]
+    eps_post = synth.f32(synth.counter_normal((NA, 32), 'g5/eps_post'))
+    eps_prior = synth.f32(synth.counter_normal((NA, 32), 'g5/eps_prior'))
+    env_g = synth.SyntheticMapEnv(raster.clone(), dx.clone()).to(DEV)
+    out, ld, grads, err = _product_step(m, batch.clone().to(DEV), map_idx.to(DEV), env_g, eps_post, eps_prior)
+    # textured raster, 11 re-sampled steps: loose on the trajectories (like the rollout goldens), terms of the loss accordingly
+    assert_close(out['future_pred'], g['train_future_pred'], 0, 1e-2, 'train future_pred')
+    assert_close(out['future_samp'], g['train_future_samp'], 0, 1e-2, 'train future_samp')
+    for k in ('loss', 'recon_loss', 'kl_loss'):
+        assert_close(ld[k], g['train_' + k], 2e-2, 1e-3, 'train ' + k)
+    assert int(g['train_ngrads']) == 174 and all(v is not None for v in grads.values())
+    for n in ('decoder_net.mlp_out.net.6.weight', 'decoder_memory.weight_hh_l0', 'map_conv.0.weight', 'map_feature.weight',
+              'prior_net.msg.0.edge_mlp.net.0.weight', 'past_encoder.net.0.weight', 'posterior_net.mlp_in.net.0.weight',
+              'future_encoder.net.9.bias'):
+        w = g['train_grad/' + n]
+        got = grads[n].detach().cpu().reshape(-1)[:w.size].numpy().reshape(w.shape) if w.size < grads[n].numel() else \
+            grads[n].detach().cpu().numpy()
+        rel = float(np.linalg.norm(got - w) / max(np.linalg.norm(w), 1e-30))
+        assert rel < 0.1, 'reference gradient %s: relative L2 error %.3g' % (n, rel)
+    # tight: uniform raster (smooth chain) against the oracle, all 174 gradients
+    ur, udx = mg.loop_rasters('u')
+    env_c = synth.SyntheticMapEnv(ur, udx)
+    out_o, ld_o, g_o = _oracle_step(sd, batch, map_idx, env_c, eps_post, eps_prior)
+    env_u = synth.SyntheticMapEnv(ur.clone(), udx.clone()).to(DEV)
+    out, ld, grads, err = _product_step(m, batch.clone().to(DEV), map_idx.to(DEV), env_u, eps_post, eps_prior)
+    assert_close(out['future_pred'], out_o['future_pred'], 1e-4, 2e-5, 'future_pred (uniform)')
+    for k in ('loss', 'recon_loss', 'kl_loss', 'coll_veh_prior', 'coll_env_prior'):
+        assert_close(ld[k], ld_o[k], 2e-3, 2e-3 if 'env' in k else 1e-5, k + ' (uniform)')
+    worst = _compare_grads(grads, g_o, 1e-2, 5e-3, 'training step (uniform raster)')
+    print('worst relative L2 gradient error: %s %.3g' % worst)
+    m.eval()
