@@ -50,3 +50,95 @@ class GlobalMean(object):
         gcount = torch.clamp(stat[1], min=1.0)
         # value = global mean; gradient flows through the local sum only
         return (local_sum - local_sum.detach() + stat[0]) / gcount
+
+
+# ------------------------------------------------------------------------------------------------
+# data-parallel training (BASELINE.json configs[3]: train_traffic.cfg over 8 x MI355X)
+# ------------------------------------------------------------------------------------------------
+
+class DataParallelTrainer(object):
+    """One optimisation step of the reference's training loop (src/train_traffic.py:103-131) with the scenes of a batch
+    sharded over the ranks -- one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU box,
+    "gloo" in the CPU tests).
+
+    The reference's loss is a sum of batch-wide means with DIFFERENT denominators (reconstruction over visible frames,
+    KL over agents, vehicle collisions over ordered in-scene pairs, environment collisions over ego frames:
+    src/losses/traffic_model.py:55-105), so averaging per-rank gradients would not reproduce the single-process step.
+    Here every rank forms its part of the GLOBAL loss -- local sums over global counts -- and the gradients are then
+    simply summed:
+      1. all_reduce(SUM) of the four data-dependent counts (they depend on the batch only, not on the forward);
+      2. forward -> TrafficModelLoss -> backward of the rank's share of the global loss (a RuntimeError is caught like the
+         reference's per-batch try/except);
+      3. ONE all_reduce(SUM) of the flat gradient bucket (1.09 M fp32 = 4.37 MB for NC = 2) whose last element is the
+         rank's "I failed" flag: if any rank failed, every rank skips the optimiser step (the skip vote), otherwise the
+         bucket is scattered back into ``p.grad`` and ``optimizer.step()`` runs -- identical parameters on every rank.
+    """
+
+    def __init__(self, model, loss_fn, optimizer, group=None):
+        self.model, self.loss_fn, self.optimizer, self.group = model, loss_fn, optimizer, group
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        self.last_error = None
+
+    def _all_reduce(self, t):
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    @staticmethod
+    def batch_counts(scene_graph, FT):
+        """(visible frames, agents, ordered in-scene pairs, ego frames) of this rank's scenes."""
+        sizes = (scene_graph.ptr[1:] - scene_graph.ptr[:-1]).to(torch.float64)
+        return torch.stack([(scene_graph.future_vis == 1.0).sum().to(torch.float64).cpu(), sizes.sum().cpu(),
+                            (sizes * sizes - sizes).sum().cpu(), torch.tensor(float(sizes.numel() * FT), dtype=torch.float64)])
+
+    def global_loss_share(self, loss_dict, local, glob):
+        """This rank's additive share of the global-batch loss from the per-element outputs of TrafficModelLoss."""
+        w = self.loss_fn.loss_weights
+        loss = w['recon'] * loss_dict['recon_loss'].sum() / glob[0] + w['kl'] * loss_dict['kl_loss'].sum() / glob[1]
+        if 'coll_veh_prior' in loss_dict and local[2] > 0:      # a rank without pairs (one-agent scenes) has 0/0 locally
+            loss = loss + w['coll_veh_prior'] * loss_dict['coll_veh_prior'].sum() * (local[2] / glob[2])
+        if 'coll_env_prior' in loss_dict:
+            loss = loss + w['coll_env_prior'] * loss_dict['coll_env_prior'].sum() / glob[3]
+        return loss
+
+    def step(self, scene_graph, map_idx, map_env, future_sample=None):
+        dev = self.params[0].device
+        local = self.batch_counts(scene_graph, self.model.FT)
+        glob = self._all_reduce(local.clone().to(dev)).cpu()
+        w = self.loss_fn.loss_weights
+        if future_sample is None:
+            future_sample = w['coll_veh_prior'] > 0.0 or w['coll_env_prior'] > 0.0
+        self.optimizer.zero_grad()
+        failed, loss_dict, share = 0.0, None, None
+        try:
+            pred = self.model(scene_graph, map_idx, map_env, future_sample=future_sample)
+            loss_dict = self.loss_fn(scene_graph, pred, map_idx=map_idx, map_env=map_env)
+            share = self.global_loss_share(loss_dict, [float(v) for v in local], [float(v) for v in glob])
+            share.backward()
+        except RuntimeError as e:          # like the reference's per-batch try/except: skip, everywhere
+            self.last_error = e
+            failed = 1.0
+        bucket = torch.zeros((self.numel + 1,), dtype=torch.float32, device=dev)
+        if not failed:
+            off = 0
+            for p in self.params:
+                n = p.numel()
+                if p.grad is not None:
+                    bucket[off:off + n] = p.grad.reshape(-1)
+                off += n
+        bucket[-1] = failed
+        self._all_reduce(bucket)
+        if float(bucket[-1]) > 0.0:
+            for p in self.params:
+                p.grad = None
+            return None
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = bucket[off:off + n].view_as(p).clone()
+            off += n
+        self.optimizer.step()
+        out = dict(loss_dict)
+        out['global_loss'] = self._all_reduce(share.detach().clone().reshape(1))
+        return out

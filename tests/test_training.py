@@ -148,3 +148,88 @@ def test_training_step_golden_and_all_gradients():
     worst = _compare_grads(grads, g_o, 1e-2, 5e-3, 'training step (uniform raster)')
     print('worst relative L2 gradient error: %s %.3g' % worst)
     m.eval()
+
+
+# ------------------------------------------------------------------------------------------------
+# data parallel: two gloo ranks, scenes sharded, against the single-process step on the whole batch
+# ------------------------------------------------------------------------------------------------
+
+def _dp_worker(rank, world, port, sizes, out_path):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'hipemu'))
+    import build as emu_build
+    from strive_amd import _lib as L, ops
+    from strive_amd.distributed import DataParallelTrainer, shard_scenes
+    from strive_amd.losses.traffic_model import TrafficModelLoss
+    from strive_amd.graph import Batch
+    torch.set_num_threads(2)
+    emu = L.StriveLib(emu_build.build(), require_all=True)
+    ops._lib_for = lambda *tensors: emu
+    L.get_lib = lambda: emu
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    m, sd = product_model(FT=2)
+    m.train()
+    scenes = [synth.make_scene(n, 'train/dp/%d' % b, FT=2) for b, n in enumerate(sizes)]
+    # one scene loses a future frame so that the visible-frame counts differ between ranks
+    scenes[0].future_vis[0, 1] = 0.0
+    mine = shard_scenes(sizes, world)[rank]
+    batch = Batch.from_data_list([scenes[i] for i in mine])
+    map_idx = torch.zeros((len(mine),), dtype=torch.long)
+    raster, dx = synth.make_raster(1024, 1024)
+    env = synth.SyntheticMapEnv(raster, dx)
+    NA_all = sum(sizes)
+    eps = synth.f32(synth.counter_normal((2, NA_all, 32), 'train/dp/eps'))
+    offs = np.cumsum([0] + list(sizes))
+    rows = torch.cat([torch.arange(offs[i], offs[i + 1]) for i in mine])
+    seq = []
+    m.rsample = lambda mean, var: mean + seq.pop(0) * torch.sqrt(var)
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    tr = DataParallelTrainer(m, TrafficModelLoss(TW, m.get_normalizer(), m.get_att_normalizer()), opt)
+    seq[:] = [eps[0][rows], eps[1][rows]]
+    out = tr.step(batch, map_idx, env)
+    res = {'loss': float(out['global_loss']), 'params': {n: p.detach().clone() for n, p in m.named_parameters()}}
+    # second step: rank 1 raises inside its forward -> nobody may step (skip vote)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    if world > 1:
+        seq[:] = [eps[0][rows], eps[1][rows]]
+        if rank == 1:
+            def boom(mean, var):
+                raise RuntimeError('injected failure')
+            m.rsample = boom
+        out2 = tr.step(batch, map_idx, env)
+        res['skipped'] = out2 is None
+        res['unchanged'] = all(torch.equal(before[n], p.detach()) for n, p in m.named_parameters())
+    torch.save(res, out_path % rank)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_equals_single_process(tmp_path):
+    """Scenes [2, 1] on two gloo ranks (one scene each) vs both scenes in one process: same global loss, same parameters
+    after the step (gradients of terms with different denominators are combined exactly), and the skip vote."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    sizes = [2, 1]
+    single = str(tmp_path / 'single_%d.pt')
+    _dp_worker(0, 1, port, sizes, single)
+    from strive_amd import _lib as L, ops          # the in-process run patched these: restore for the other tests
+    import importlib
+    importlib.reload(L)
+    importlib.reload(ops)
+    multi = str(tmp_path / 'dp_%d.pt')
+    mp.spawn(_dp_worker, args=(2, port, sizes, multi), nprocs=2, join=True)
+    ref = torch.load(single % 0)
+    r0, r1 = torch.load(multi % 0), torch.load(multi % 1)
+    assert abs(r0['loss'] - ref['loss']) < 1e-5 * max(1.0, abs(ref['loss'])), (r0['loss'], ref['loss'])
+    for n, p in ref['params'].items():
+        assert torch.equal(r0['params'][n], r1['params'][n]), 'ranks diverged on ' + n
+        assert_close(r0['params'][n], p, 1e-4, 1e-6, 'parameter after the step: ' + n)
+    assert r0['skipped'] and r1['skipped'] and r0['unchanged'] and r1['unchanged']
