@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define STRIVE_ABI_VERSION 6
+#define STRIVE_ABI_VERSION 7
 #define STRIVE_HID 128        /* hidden width of every MLP in the reference (models/common.py, interaction_net.py:32,41) */
 #define STRIVE_MAX_LAYERS 4
 #define STRIVE_ZDIM 32
@@ -93,7 +93,7 @@ typedef struct StriveMap {
  * architecture only (kernels 7,5,5,3,3,3; channels 4->16->32->64->64->128->128; 256x256 input);
  * reference src/models/traffic_model.py:69-87, 437-440.
  * w[l]: fp32 weights as [ci/2][ky][kx][ci&1][co] (l = 0: [ky][kx][ci][co]) -- not read by the kernels any more (all six
- * convolutions take the bf16 fragment tables w1_frag .. w6_frag below); kept so that the struct layout stays put;
+ * convolutions take the fp16 fragment tables w1_frag .. w6_frag below); kept so that the struct layout stays put;
  * fc_wt: (512, 64) transposed Linear weight. */
 typedef struct StriveCNN {
     const float* w[6];
@@ -102,20 +102,25 @@ typedef struct StriveCNN {
     const float* gn_b[6];
     const float* fc_wt;
     const float* fc_b;
-    const uint32_t* w1_frag;   /* layer-0 weights split into three bf16 pieces (w = hi + mid + lo, exact) in MFMA fragment
-                                  order [ky][piece][lane 0..63][8 x bf16], 8 values = window columns 2g,2g+1 x 4 layers for
-                                  lane group g = lane/16, output channel = lane%16; 21504 bytes */
-    const uint32_t* w2_frag;   /* layer-1 (16->32, 5x5), layer-2 (32->64, 5x5) and layer-3 (64->64, 3x3) weights, each split exactly */
-    const uint32_t* w3_frag;   /* into three bf16 pieces, in the fragment order of conv_bf6_kernel: [pass = ci/8][step s][co/32] */
-    const uint32_t* w4_frag;   /* (w5_frag, w6_frag: layers 4 and 5, 64->128 and 128->128, 3x3, same format)  [piece 3][lane 64][8 x bf16]; lane half h = lane/32 holds one window tap of the step, element
+    const uint32_t* w1_frag;   /* layer-0 weights * wscale[0] split into two fp16 pieces (w0 = fp16(w) rounded to nearest,
+                                  w1 = fp16(w - w0): w0 + w1 = w up to 2^-24 |w|) in MFMA fragment order
+                                  [ky][piece][lane 0..63][8 x fp16], 8 values = window columns 2g,2g+1 x 4 layers for
+                                  lane group g = lane/16, output channel = lane%16; 14336 bytes */
+    const uint32_t* w2_frag;   /* layer-1 (16->32, 5x5), layer-2 (32->64, 5x5) and layer-3 (64->64, 3x3) weights, each * wscale[l] */
+    const uint32_t* w3_frag;   /* and split into two fp16 pieces, in the fragment order of conv_bf6_kernel: [pass = ci/8][step s][co/32] */
+    const uint32_t* w4_frag;   /* (w5_frag, w6_frag: layers 4 and 5, 64->128 and 128->128, 3x3, same format)  [piece 2][lane 64][8 x fp16]; lane half h = lane/32 holds one window tap of the step, element
                                   e = input channel 8*pass + e, output channel = 32*(co/32) + lane%32.
                                   5x5 (13 steps): tap (s/2, (s&1)+2h) for s < 10, (2(s-10)+h, 4) for s = 10, 11, (4, 4) or zero
                                   for s = 12.  3x3 (5 steps): (s, 2h) for s < 3, (h, 1) for s = 3, (2, 1) or zero for s = 4.
-                                  79872 / 319488 / 245760 / 491520 / 983040 bytes */
+                                  53248 / 212992 / 163840 / 327680 / 655360 bytes */
     const uint32_t* w5_frag;
     const uint32_t* w6_frag;
     const float* w_torch[6];   /* the convolution weights in torch layout (co, ci, ky, kx): read by the training backward's
                                   data-gradient kernel only (may be NULL on the latent-optimisation path) */
+    float wscale[6];           /* power of two the fp16 weight pieces of layer l were multiplied by (so that both pieces sit
+                                  in fp16's normal range) */
+    float xscale[6];           /* power of two the GroupNorm+ReLU input of layer l (l >= 1) is multiplied by before its fp16
+                                  split; chosen from the bound |gamma| sqrt(C H W) + |beta| so that it cannot overflow */
 } StriveCNN;
 
 /* Scene structure of a batch: agents of scene b are rows ptr[b] .. ptr[b+1]-1, ego first

@@ -51,7 +51,7 @@ class StriveCNN(C.Structure):
     _fields_ = [('w', C.c_void_p * 6), ('b', C.c_void_p * 6), ('gn_g', C.c_void_p * 6), ('gn_b', C.c_void_p * 6),
                 ('fc_wt', C.c_void_p), ('fc_b', C.c_void_p), ('w1_frag', C.c_void_p),
                 ('w2_frag', C.c_void_p), ('w3_frag', C.c_void_p), ('w4_frag', C.c_void_p), ('w5_frag', C.c_void_p), ('w6_frag', C.c_void_p),
-                ('w_torch', C.c_void_p * 6)]
+                ('w_torch', C.c_void_p * 6), ('wscale', C.c_float * 6), ('xscale', C.c_float * 6)]
 
 
 class StriveScenes(C.Structure):
@@ -112,7 +112,7 @@ PROTOTYPES = {
 }
 
 
-ABI_VERSION = 6   # include/strive_hip.h STRIVE_ABI_VERSION
+ABI_VERSION = 7   # include/strive_hip.h STRIVE_ABI_VERSION
 
 
 class StriveLib(object):

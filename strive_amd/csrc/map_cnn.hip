@@ -53,7 +53,7 @@ __device__ __forceinline__ void gn_moments(const GNStats* __restrict__ st, int n
 // tile; the 8th window column is padding with zero weights.
 // Workgroup = 4 waves, 32 (x) x 16 (y) output pixels = 32 pixel tiles of 16, 8 per wave.
 // =============================================================================================
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 namespace l1b {
 constexpr int CIN = 4, COUT = 16, KS = 7, IH = 256, OH = 125;
@@ -62,16 +62,23 @@ constexpr int ITW = 2 * TOX + KS - 2 + 1;   // 70 columns (69 used + the zero-we
 constexpr int ITH = 2 * TOY + KS - 2;       // 37 rows
 constexpr int TILES_X = (OH + TOX - 1) / TOX, TILES_Y = (OH + TOY - 1) / TOY;   // 4 x 8
 constexpr int NPIX = ITH * ITW;             // 2590 staged pixels (8 bytes each)
-constexpr int WFRAGS = KS * 3;              // (ky, term) fragments, 64 lanes x 16 B each
-constexpr int WBYTES = WFRAGS * 64 * 16;    // 21504
+constexpr int WFRAGS = KS * 2;              // (ky, piece) fragments, 64 lanes x 16 B each
+constexpr int WBYTES = WFRAGS * 64 * 16;    // 14336
 constexpr int NPART = TILES_X * TILES_Y;    // 32 statistics slots per sample
 }  // namespace l1b
 
-__device__ __forceinline__ uint32_t pack_bf16_pair_from_bytes(uint32_t word, int lo_byte) {
-    // two layers (bytes lo_byte, lo_byte+1 of `word`) -> two bf16 in one dword; integers <= 255 are exact in bf16
+__device__ __forceinline__ uint32_t f16_bits(float v) {
+    const _Float16 h = (_Float16)v;             // round to nearest even
+    uint16_t b;
+    __builtin_memcpy(&b, &h, 2);
+    return (uint32_t)b;
+}
+
+__device__ __forceinline__ uint32_t pack_f16_pair_from_bytes(uint32_t word, int lo_byte) {
+    // two layers (bytes lo_byte, lo_byte+1 of `word`) -> two fp16 in one dword; integers <= 255 are exact in fp16
     const float f0 = (float)((word >> (8 * lo_byte)) & 0xffu);
     const float f1 = (float)((word >> (8 * lo_byte + 8)) & 0xffu);
-    return (__float_as_uint(f0) >> 16) | (__float_as_uint(f1) & 0xffff0000u);
+    return f16_bits(f0) | (f16_bits(f1) << 16);
 }
 
 // Persistent over one row of tiles (TILES_X = 4 tiles of 32 x 16 outputs) with two LDS input buffers: while the
@@ -84,10 +91,10 @@ template <bool FUSED_CROP, int DBG = 0>
 __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const float* __restrict__ pos, Float4Host pmean,
                                                          Float4Host pstd, const int32_t* __restrict__ mapix,
                                                          const uint8_t* __restrict__ crop, const uint32_t* __restrict__ wfrag,
-                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         float unscale, const float* __restrict__ bias, float* __restrict__ out,
                                                          GNStats* __restrict__ stats) {
     using namespace l1b;
-    __shared__ __attribute__((aligned(16))) uint32_t s_in[2][NPIX * 2];     // [buffer][row][col][4 x bf16]
+    __shared__ __attribute__((aligned(16))) uint32_t s_in[2][NPIX * 2];     // [buffer][row][col][4 x fp16]
     __shared__ __attribute__((aligned(16))) uint32_t s_w[WBYTES / 4];
     __shared__ double s_red[2][16];
     const int n = blockIdx.z;
@@ -167,14 +174,14 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
             }
         }
     };
-    auto deposit = [&](int buf) {    // gathered words -> 4 x bf16 -> LDS
+    auto deposit = [&](int buf) {    // gathered words -> 4 x fp16 -> LDS
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             int r, c;
             if (slot_rc(k, r, c)) {
                 uint2 v;
-                v.x = pack_bf16_pair_from_bytes(word[k], 0);
-                v.y = pack_bf16_pair_from_bytes(word[k], 2);
+                v.x = pack_f16_pair_from_bytes(word[k], 0);
+                v.y = pack_f16_pair_from_bytes(word[k], 2);
                 *reinterpret_cast<uint2*>(&s_in[buf][(r * ITW + c) * 2]) = v;
             }
         }
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
     if (FUSED_CROP && TILES_X > 1) tables(1, 1);
     deposit(0);
     __syncthreads();
-    const bf16x8* wl = reinterpret_cast<const bf16x8*>(s_w) + lane;
+    const f16x8* wl = reinterpret_cast<const f16x8*>(s_w) + lane;
     for (int tx = 0; tx < TILES_X; ++tx) {
         const int buf = tx & 1;
         if (tx + 1 < TILES_X) gather(tx + 1, (tx + 1) & 1);
@@ -203,18 +210,18 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
         for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky) {
-            bf16x8 bfr[4];
+            f16x8 bfr[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int oyl = wave * 2 + (i >> 1), oxl = (i & 1) * 16 + j;
                 const int pix = (2 * oyl + ky) * ITW + 2 * oxl + 2 * g;
-                bfr[i] = *reinterpret_cast<const bf16x8*>(&s_in[buf][pix * 2]);
+                bfr[i] = *reinterpret_cast<const f16x8*>(&s_in[buf][pix * 2]);
             }
 #pragma unroll
-            for (int term = 0; term < (DBG == 3 ? 1 : 3); ++term) {
-                const bf16x8 a = wl[(ky * 3 + term) * 64];
+            for (int term = (DBG == 3 ? 0 : 1); term >= 0; --term) {      // the small piece first
+                const f16x8 a = wl[(ky * 2 + term) * 64];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i], acc[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bfr[i], acc[i], 0, 0, 0);
             }
         }
         // epilogue: D column = lane&15 = pixel, row = (lane>>4)*4 + r = output channel.  Output layout = channel
@@ -227,10 +234,10 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
         for (int i = 0; i < 4; ++i) {
             const int oy = oy0 + wave * 2 + (i >> 1), ox = ox0 + (i & 1) * 16 + j;
             float4 v;
-            v.x = acc[i][0] + bv.x;
-            v.y = acc[i][1] + bv.y;
-            v.z = acc[i][2] + bv.z;
-            v.w = acc[i][3] + bv.w;
+            v.x = fmaf(acc[i][0], unscale, bv.x);      // unscale = 2^-k exactly: one rounding, like acc + bias
+            v.y = fmaf(acc[i][1], unscale, bv.y);
+            v.z = fmaf(acc[i][2], unscale, bv.z);
+            v.w = fmaf(acc[i][3], unscale, bv.w);
             if (oy < OH && ox < OH) {
                 if (DBG != 4)
                     *reinterpret_cast<float4*>(out + ((((size_t)n * (COUT / 8) + (g >> 1)) * OH + oy) * OH + ox) * 8 + (g & 1) * 4) = v;
@@ -292,9 +299,10 @@ struct BfCfg {
     static constexpr int PASS_CH = 8, NPASS = CIN / PASS_CH;
     static constexpr int ITH = 2 * TH + KS - 2, ITW = 2 * TW + KS - 2, HW = (ITW + 1) / 2;
     static constexpr int HALF_B = HW * 16, ROW_B = 2 * HALF_B, PIECE_B = ITH * ROW_B;
-    static constexpr int IN_B = (3 * PIECE_B + 255) / 256 * 256;              // weight fragments start 256-byte aligned
+    static constexpr int NPIECE = 2;                                          // fp16 pieces per value
+    static constexpr int IN_B = (NPIECE * PIECE_B + 255) / 256 * 256;         // weight fragments start 256-byte aligned
     static constexpr int NKS = (KS * KS + 1) / 2;                            // MFMA steps per pass (two taps each)
-    static constexpr int WSTEP_B = 3 * 64 * 16;                              // [piece][lane][16 B]
+    static constexpr int WSTEP_B = 2 * 64 * 16;                              // [piece][lane][16 B]
     static constexpr int TILES_X = (OH + TW - 1) / TW, TILES_Y = (OH + TH - 1) / TH;
     static constexpr int NPART_OUT = TILES_X * TILES_Y * CSPLIT;
     static constexpr int UNITS = ITH * ITW, UITERS = (UNITS + NT - 1) / NT;
@@ -303,25 +311,25 @@ struct BfCfg {
     static_assert(CIN % PASS_CH == 0 && COUT % COUT_WG == 0 && CIN <= NT, "channel tiling");
     static_assert(LDS_BYTES * WGS_PER_CU <= 160 * 1024, "LDS budget of the residency target");
     static_assert((KS == 5 && NKS == 13) || (KS == 3 && NKS == 5), "tap orders exist for 5x5 and 3x3 windows");
-    static_assert(WSTEP_B == 16 * 192, "weight step = one 16-byte piece for each of the first 192 threads");
+    static_assert(WSTEP_B == 16 * 128, "weight step = one 16-byte piece for each of the first 128 threads");
 };
 
-__device__ __forceinline__ void split_bf16x3(const float v[8], uint4& p0, uint4& p1, uint4& p2) {
-    uint32_t h[8], m[8], l[8];
+// v = p0 + p1 up to 2^-24 |v| (p0 = fp16(v) rounded to nearest, p1 = fp16(v - p0)); v is pre-scaled into fp16's range.
+__device__ __forceinline__ void split_f16x2(const float v[8], uint4& p0, uint4& p1) {
+    uint32_t h[8], l[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const uint32_t b0 = __float_as_uint(v[i]) & 0xffff0000u;
-        const float r1 = v[i] - __uint_as_float(b0);               // exact
-        const uint32_t b1 = __float_as_uint(r1) & 0xffff0000u;
-        const float r2 = r1 - __uint_as_float(b1);                 // exact, <= 8 significant bits
-        h[i] = b0;
-        m[i] = b1;
-        l[i] = __float_as_uint(r2);
+        const _Float16 a = (_Float16)v[i];
+        const float r = v[i] - (float)a;                 // exact
+        const _Float16 c = (_Float16)r;
+        uint16_t ab, cb;
+        __builtin_memcpy(&ab, &a, 2);
+        __builtin_memcpy(&cb, &c, 2);
+        h[i] = ab;
+        l[i] = cb;
     }
-    p0 = make_uint4((h[0] >> 16) | h[1], (h[2] >> 16) | h[3], (h[4] >> 16) | h[5], (h[6] >> 16) | h[7]);
-    p1 = make_uint4((m[0] >> 16) | m[1], (m[2] >> 16) | m[3], (m[4] >> 16) | m[5], (m[6] >> 16) | m[7]);
-    p2 = make_uint4((l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u), (l[4] >> 16) | (l[5] & 0xffff0000u),
-                    (l[6] >> 16) | (l[7] & 0xffff0000u));
+    p0 = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    p1 = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
 // TIMING: phase timestamps (s_memtime) of every workgroup summed into `tprof` (measurement hook only)
@@ -330,6 +338,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
                                                                 const float* __restrict__ gn_g, const float* __restrict__ gn_b,
                                                                 const uint32_t* __restrict__ wfrag, const float* __restrict__ bias,
                                                                 float* __restrict__ out, GNStats* __restrict__ st_out, int N,
+                                                                float xscale, float unscale,
                                                                 unsigned long long* __restrict__ tprof = nullptr) {
     long long tstamp[8];
     int nstamp = 0;
@@ -398,9 +407,10 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
     }
     __syncthreads();
     if (tid < CIN) {
+        // xscale = 2^k folded into the affine map: relu(2^k (a x + b)) = 2^k relu(a x + b), exact
         const float sc = s_mr[1] * my_g;
-        s_gn[2 * tid] = sc;
-        s_gn[2 * tid + 1] = my_b - s_mr[0] * sc;
+        s_gn[2 * tid] = sc * xscale;
+        s_gn[2 * tid + 1] = (my_b - s_mr[0] * sc) * xscale;
     }
     stamp();
 
@@ -416,9 +426,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
     const int lane_base = (2 * (Cfg::TILE_ROWS * PT * wave + prow)) * Cfg::ROW_B + pcol * 16;
 
     const uint4* wsrc = reinterpret_cast<const uint4*>(wfrag);
-    constexpr int WQ = Cfg::WSTEP_B / 16;                         // 192 x 16 B per MFMA step
+    constexpr int WQ = Cfg::WSTEP_B / 16;                         // 128 x 16 B per MFMA step
     auto wstep_src = [&](int pass, int s) { return wsrc + ((size_t)(pass * Cfg::NKS + s) * Cfg::CSPLIT + cb) * WQ; };
-    const bool wmover = tid < WQ;                                 // waves 0-2 move the weight fragments
+    const bool wmover = tid < WQ;                                 // waves 0-1 move the weight fragments
 
     for (int pass = 0; pass < Cfg::NPASS; ++pass) {
         // ALL weight fragments of the pass (13 x 16 bytes per moving thread) are requested up front and parked in
@@ -432,7 +442,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
             for (int t = 0; t < Cfg::NKS; ++t) wq[t] = wstep_src(pass, t)[tid];
         }
         __syncthreads();        // s_gn ready (pass 0) / every wave is done with the previous pass's tiles
-        // ---- 8 input channels of the (2TH+KS-2) x (2TW+KS-2) window: GroupNorm + ReLU, exact 3-way split ----
+        // ---- 8 input channels of the (2TH+KS-2) x (2TW+KS-2) window: GroupNorm + ReLU (pre-scaled), two-piece fp16 split ----
 #pragma unroll
         for (int k = 0; k < Cfg::UITERS; ++k) {
             const int idx = tid + k * NT;
@@ -455,12 +465,11 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
                     v[6] = fmaxf(fmaf(b.z, g3.x, g3.y), 0.f);
                     v[7] = fmaxf(fmaf(b.w, g3.z, g3.w), 0.f);
                 }
-                uint4 p0, p1, p2;
-                split_bf16x3(v, p0, p1, p2);
+                uint4 p0, p1;
+                split_f16x2(v, p0, p1);
                 unsigned char* dst = s_in + r * Cfg::ROW_B + (col & 1) * Cfg::HALF_B + (col >> 1) * 16;
                 *reinterpret_cast<uint4*>(dst) = p0;
                 *reinterpret_cast<uint4*>(dst + Cfg::PIECE_B) = p1;
-                *reinterpret_cast<uint4*>(dst + 2 * Cfg::PIECE_B) = p2;
             }
         }
         // ---- weight fragments: step t lives in LDS buffer t % 3.  Steps 0 and 1 go straight in; step t is written at the
@@ -476,7 +485,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
 
         // Software pipeline over the MFMA steps: while the matrix cores work on step s, the A/B fragments of step
         // s+1 are read from LDS into the other register set; one barrier per step.
-        bf16x8 fa[2][3], fb[2][PT][3];
+        f16x8 fa[2][2], fb[2][PT][2];
         auto load_frags = [&](int t, int set) {
             int ky, kx;
             if (Cfg::KS == 5) {
@@ -490,35 +499,37 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
             const int off = ky * Cfg::ROW_B + (kx & 1) * Cfg::HALF_B + (kx >> 1) * 16;
             const unsigned char* wb = s_w + (t % 3) * Cfg::WSTEP_B + lane * 16;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) fa[set][pl] = *reinterpret_cast<const bf16x8*>(wb + pl * 1024);
+            for (int pl = 0; pl < 2; ++pl) fa[set][pl] = *reinterpret_cast<const f16x8*>(wb + pl * 1024);
 #pragma unroll
             for (int i = 0; i < PT; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    fb[set][i][pl] = *reinterpret_cast<const bf16x8*>(s_in + pl * Cfg::PIECE_B + 2 * Cfg::TILE_ROWS * i * Cfg::ROW_B + lane_base + off);
+                for (int pl = 0; pl < 2; ++pl)
+                    fb[set][i][pl] = *reinterpret_cast<const f16x8*>(s_in + pl * Cfg::PIECE_B + 2 * Cfg::TILE_ROWS * i * Cfg::ROW_B + lane_base + off);
         };
         load_frags(0, 0);
 #pragma unroll
         for (int s = 0; s < Cfg::NKS; ++s) {
             const int cur = s & 1;
             if (s + 1 < Cfg::NKS) load_frags(s + 1, cur ^ 1);
-            // six products per pixel tile, smallest first; the two tiles' accumulation chains alternate so that an
-            // MFMA never waits for the one issued just before it
-            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+            // three products per pixel tile (w1 x0, w0 x1, w0 x0: the small ones first; w1 x1 is below 2^-24 of the leading
+            // product); the tiles' accumulation chains alternate so that an MFMA never waits for the one issued just before it
+            constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
 #pragma unroll
-            for (int term = 0; term < 6; ++term)
+            for (int term = 0; term < 3; ++term)
 #pragma unroll
                 for (int i = 0; i < PT; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][TA[term]], fb[cur][i][TB[term]], acc[i], 0, 0, 0);
-            // issue order: one LDS fragment read of step s+1 behind each of the first nine MFMAs of step s (issuing the
-            // nine reads up front stalls the wave on the LDS queue before the matrix pipe gets any work)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][TA[term]], fb[cur][i][TB[term]], acc[i], 0, 0, 0);
+            // issue order: one LDS fragment read of step s+1 behind each MFMA of step s (issuing the reads up front stalls
+            // the wave on the LDS queue before the matrix pipe gets any work)
             if (s + 1 < Cfg::NKS) {
+                constexpr int NRD = 2 + 2 * PT, NMF = 3 * PT;
 #pragma unroll
-                for (int q = 0; q < 3 + 3 * PT; ++q) {
+                for (int q = 0; q < (NRD < NMF ? NRD : NMF); ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 6 * PT - (3 + 3 * PT), 0);
+                if (NMF > NRD) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
+                if (NRD > NMF) __builtin_amdgcn_sched_group_barrier(0x100, NRD - NMF, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (s + 2 < Cfg::NKS && wmover) reinterpret_cast<uint4*>(s_w + ((s + 2) % 3) * Cfg::WSTEP_B)[tid] = wq[s + 2];
@@ -538,10 +549,10 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
             const int co = cb * Cfg::COUT_WG + 8 * rg + 4 * h;
             const float4 bv = bias4[rg];
             float4 v;
-            v.x = acc[i][4 * rg + 0] + bv.x;
-            v.y = acc[i][4 * rg + 1] + bv.y;
-            v.z = acc[i][4 * rg + 2] + bv.z;
-            v.w = acc[i][4 * rg + 3] + bv.w;
+            v.x = fmaf(acc[i][4 * rg + 0], unscale, bv.x);     // unscale = 2^-k exactly: one rounding, like acc + bias
+            v.y = fmaf(acc[i][4 * rg + 1], unscale, bv.y);
+            v.z = fmaf(acc[i][4 * rg + 2], unscale, bv.z);
+            v.w = fmaf(acc[i][4 * rg + 3], unscale, bv.w);
             if (valid) {
                 if (Cfg::OUT_OCT) {     // octet-planar, [n][c/8][y][x][c%8]
                     *reinterpret_cast<float4*>(out + ((((size_t)n * (COUT / 8) + (co >> 3)) * OH + oy) * OH + ox) * 8 + (co & 7)) = v;
@@ -592,9 +603,9 @@ struct BfsCfg {
     static constexpr int COUT_WG = 32, CSPLIT = COUT / COUT_WG;
     static constexpr int PASS_CH = 8, NPASS = CIN / PASS_CH;
     static constexpr int HW = (IH + 1) / 2, HALF_B = HW * 16, ROW_B = 2 * HALF_B, SAMPLE_B = IH * ROW_B, PIECE_B = S * SAMPLE_B;
-    static constexpr int IN_B = (3 * PIECE_B + 255) / 256 * 256;
+    static constexpr int IN_B = (2 * PIECE_B + 255) / 256 * 256;
     static constexpr int NKS = (KS * KS + 1) / 2;
-    static constexpr int WSTEP_B = 3 * 64 * 16;
+    static constexpr int WSTEP_B = 2 * 64 * 16;
     static constexpr int NPART_OUT = CSPLIT;
     static constexpr int UNITS = S * IH * IH, UITERS = (UNITS + NT - 1) / NT;
     static constexpr size_t LDS_BYTES = (size_t)IN_B + 3 * WSTEP_B + (size_t)CIN * 8 + S * 8 + 16;
@@ -609,7 +620,8 @@ template <class Cfg>
 __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6s_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
                                                                  const float* __restrict__ gn_g, const float* __restrict__ gn_b,
                                                                  const uint32_t* __restrict__ wfrag, const float* __restrict__ bias,
-                                                                 float* __restrict__ out, GNStats* __restrict__ st_out, int N) {
+                                                                 float* __restrict__ out, GNStats* __restrict__ st_out, int N,
+                                                                 float xscale, float unscale) {
     constexpr int CIN = Cfg::CIN, COUT = Cfg::COUT, IH = Cfg::IH, OH = Cfg::OH, NT = Cfg::NT, S = Cfg::S, PT = Cfg::PT;
     HIP_DYNAMIC_SHARED(float, smem)
     unsigned char* s_in = reinterpret_cast<unsigned char*>(smem);
@@ -712,15 +724,14 @@ __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6s_kernel(const float* __re
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float sc = rstd * gam[e];                    // scale / shift exactly as the other conv kernels form them
-                        v[e] = fmaxf(fmaf(x[e], sc, bet[e] - mean * sc), 0.f);
+                        v[e] = fmaxf(fmaf(x[e], sc * xscale, (bet[e] - mean * sc) * xscale), 0.f);
                     }
                 }
-                uint4 p0, p1, p2;
-                split_bf16x3(v, p0, p1, p2);
+                uint4 p0, p1;
+                split_f16x2(v, p0, p1);
                 unsigned char* dst = s_in + a * Cfg::SAMPLE_B + row * Cfg::ROW_B + (col & 1) * Cfg::HALF_B + (col >> 1) * 16;
                 *reinterpret_cast<uint4*>(dst) = p0;
                 *reinterpret_cast<uint4*>(dst + Cfg::PIECE_B) = p1;
-                *reinterpret_cast<uint4*>(dst + 2 * Cfg::PIECE_B) = p2;
             }
         }
         if (wmover) {
@@ -730,7 +741,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6s_kernel(const float* __re
         __syncthreads();
         if (pass + 1 < Cfg::NPASS) issue_loads(pass + 1);
 
-        bf16x8 fa[2][3], fb[2][PT][3];
+        f16x8 fa[2][2], fb[2][PT][2];
         auto load_frags = [&](int t, int set) {       // 3x3 tap order of conv_bf6_kernel
             int ky, kx;
             if (t < 3) { ky = t; kx = 2 * h; }
@@ -739,31 +750,33 @@ __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6s_kernel(const float* __re
             const int off = ky * Cfg::ROW_B + (kx & 1) * Cfg::HALF_B + (kx >> 1) * 16;
             const unsigned char* wb = s_w + (t % 3) * Cfg::WSTEP_B + lane * 16;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) fa[set][pl] = *reinterpret_cast<const bf16x8*>(wb + pl * 1024);
+            for (int pl = 0; pl < 2; ++pl) fa[set][pl] = *reinterpret_cast<const f16x8*>(wb + pl * 1024);
 #pragma unroll
             for (int i = 0; i < PT; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    fb[set][i][pl] = *reinterpret_cast<const bf16x8*>(s_in + pl * Cfg::PIECE_B + lane_base[i] + off);
+                for (int pl = 0; pl < 2; ++pl)
+                    fb[set][i][pl] = *reinterpret_cast<const f16x8*>(s_in + pl * Cfg::PIECE_B + lane_base[i] + off);
         };
         load_frags(0, 0);
 #pragma unroll
         for (int s = 0; s < Cfg::NKS; ++s) {
             const int cur = s & 1;
             if (s + 1 < Cfg::NKS) load_frags(s + 1, cur ^ 1);
-            constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
 #pragma unroll
-            for (int term = 0; term < 6; ++term)
+            for (int term = 0; term < 3; ++term)
 #pragma unroll
                 for (int i = 0; i < PT; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][TA[term]], fb[cur][i][TB[term]], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][TA[term]], fb[cur][i][TB[term]], acc[i], 0, 0, 0);
             if (s + 1 < Cfg::NKS) {
+                constexpr int NRD = 2 + 2 * PT, NMF = 3 * PT;
 #pragma unroll
-                for (int q = 0; q < 3 + 3 * PT; ++q) {
+                for (int q = 0; q < (NRD < NMF ? NRD : NMF); ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 6 * PT - (3 + 3 * PT), 0);
+                if (NMF > NRD) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
+                if (NRD > NMF) __builtin_amdgcn_sched_group_barrier(0x100, NRD - NMF, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (s + 2 < Cfg::NKS && wmover) reinterpret_cast<uint4*>(s_w + ((s + 2) % 3) * Cfg::WSTEP_B)[tid] = wq[s + 2];
@@ -784,10 +797,10 @@ __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6s_kernel(const float* __re
             const int co = cb * Cfg::COUT_WG + 8 * rg + 4 * h;
             const float4 bv = bias4[rg];
             float4 v;
-            v.x = acc[i][4 * rg + 0] + bv.x;
-            v.y = acc[i][4 * rg + 1] + bv.y;
-            v.z = acc[i][4 * rg + 2] + bv.z;
-            v.w = acc[i][4 * rg + 3] + bv.w;
+            v.x = fmaf(acc[i][4 * rg + 0], unscale, bv.x);     // unscale = 2^-k exactly: one rounding, like acc + bias
+            v.y = fmaf(acc[i][4 * rg + 1], unscale, bv.y);
+            v.z = fmaf(acc[i][4 * rg + 2], unscale, bv.z);
+            v.w = fmaf(acc[i][4 * rg + 3], unscale, bv.w);
             if (valid) {
                 if (Cfg::OUT_OCT) {
                     *reinterpret_cast<float4*>(out + (((size_t)n * (COUT / 8) + (co >> 3)) * Cfg::PPS + q) * 8 + (co & 7)) = v;
@@ -824,7 +837,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6s_kernel(const float* __re
 
 template <class Cfg>
 static int launch_bf6s(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
-                       const float* bias, float* out, GNStats* st_out, int N, hipStream_t stream) {
+                       const float* bias, float* out, GNStats* st_out, int N, float xscale, float wscale, hipStream_t stream) {
     dim3 grid(((N + Cfg::S - 1) / Cfg::S) * Cfg::CSPLIT);
     static bool attr_set = false;
     if (!attr_set) {
@@ -832,7 +845,7 @@ static int launch_bf6s(const float* in, const GNStats* st_in, const float* g, co
         attr_set = true;
     }
     hipLaunchKernelGGL(conv_bf6s_kernel<Cfg>, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out,
-                       st_out, N);
+                       st_out, N, xscale, 1.0f / (xscale * wscale));
     return 0;
 }
 
@@ -845,7 +858,7 @@ typedef BfsCfg<128, 128, 6, 2, 32, Bfs5::NPART_OUT, false, 1> Bfs6;  // conv6: 3
 
 template <class Cfg>
 static int launch_bf6(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
-                      const float* bias, float* out, GNStats* st_out, int N, hipStream_t stream) {
+                      const float* bias, float* out, GNStats* st_out, int N, float xscale, float wscale, hipStream_t stream) {
     dim3 grid(Cfg::TILES_X * Cfg::CSPLIT, Cfg::TILES_Y, N);
     static bool attr_set = false;
     if (!attr_set) {
@@ -853,7 +866,7 @@ static int launch_bf6(const float* in, const GNStats* st_in, const float* g, con
         attr_set = true;
     }
     hipLaunchKernelGGL(conv_bf6_kernel<Cfg>, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out,
-                       st_out, N);
+                       st_out, N, xscale, 1.0f / (xscale * wscale));
     return 0;
 }
 
@@ -990,17 +1003,17 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         dim3 g1(l1b::TILES_Y, 1, n);
         if (map) {
             hipLaunchKernelGGL(conv1b_kernel<true>, g1, dim3(C1_NT), 0, stream, mp, pos + (size_t)n0 * 4, m, s, mapix + n0,
-                               (const uint8_t*)nullptr, cnn->w1_frag, (const float*)cnn->b[0], act[0], st[0]);
+                               (const uint8_t*)nullptr, cnn->w1_frag, 1.0f / cnn->wscale[0], (const float*)cnn->b[0], act[0], st[0]);
         } else {
             hipLaunchKernelGGL(conv1b_kernel<false>, g1, dim3(C1_NT), 0, stream, mp, (const float*)nullptr, m, s,
-                               (const int32_t*)nullptr, crop + (size_t)n0 * 4 * 256 * 256, cnn->w1_frag,
+                               (const int32_t*)nullptr, crop + (size_t)n0 * 4 * 256 * 256, cnn->w1_frag, 1.0f / cnn->wscale[0],
                                (const float*)cnn->b[0], act[0], st[0]);
         }
-        launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], n, stream);
-        launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, stream);
-        launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, stream);
-        launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], n, stream);
-        launch_bf6s<Bfs6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w6_frag, cnn->b[5], act[5], st[5], n, stream);
+        launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], n, cnn->xscale[1], cnn->wscale[1], stream);
+        launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
+        launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, cnn->xscale[3], cnn->wscale[3], stream);
+        launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], n, cnn->xscale[4], cnn->wscale[4], stream);
+        launch_bf6s<Bfs6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w6_frag, cnn->b[5], act[5], st[5], n, cnn->xscale[5], cnn->wscale[5], stream);
         hipLaunchKernelGGL(fc_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, act[5], st[5], cnn->gn_g[5], cnn->gn_b[5],
                            cnn->fc_wt, cnn->fc_b, feat + (size_t)n0 * 64, n);
     }
@@ -1049,7 +1062,7 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
     switch (layer) {
         case 0:
             hipLaunchKernelGGL(conv1b_kernel<true>, dim3(l1b::TILES_Y, 1, N), dim3(C1_NT), 0, stream, *map, pos, m, s,
-                               mapix, (const uint8_t*)nullptr, cnn->w1_frag, (const float*)cnn->b[0], act[0], st[0]);
+                               mapix, (const uint8_t*)nullptr, cnn->w1_frag, 1.0f / cnn->wscale[0], (const float*)cnn->b[0], act[0], st[0]);
             break;
         case 21: case 22: {   // phase profile of conv2 / conv3: sums of s_memtime deltas land in `feat` (>= 64 bytes, zeroed here)
             hipMemsetAsync(feat, 0, 64, stream);
@@ -1057,28 +1070,28 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
                 hipFuncSetAttribute((const void*)conv_bf6_kernel<Bf2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Bf2::LDS_BYTES);
                 hipLaunchKernelGGL((conv_bf6_kernel<Bf2, true>), dim3(Bf2::TILES_X * Bf2::CSPLIT, Bf2::TILES_Y, N), dim3(Bf2::NT), Bf2::LDS_BYTES,
                                    stream, act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N,
-                                   reinterpret_cast<unsigned long long*>(feat));
+                                   cnn->xscale[1], 1.0f / (cnn->xscale[1] * cnn->wscale[1]), reinterpret_cast<unsigned long long*>(feat));
             } else {
                 hipFuncSetAttribute((const void*)conv_bf6_kernel<Bf3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Bf3::LDS_BYTES);
                 hipLaunchKernelGGL((conv_bf6_kernel<Bf3, true>), dim3(Bf3::TILES_X * Bf3::CSPLIT, Bf3::TILES_Y, N), dim3(Bf3::NT), Bf3::LDS_BYTES,
                                    stream, act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N,
-                                   reinterpret_cast<unsigned long long*>(feat));
+                                   cnn->xscale[2], 1.0f / (cnn->xscale[2] * cnn->wscale[2]), reinterpret_cast<unsigned long long*>(feat));
             }
             break;
         }
         case 11: case 12: case 13: case 14: {   // timing probes of the layer-0 kernel (results are NOT valid): no gather / no fp64 / 1/3 MFMA
             dim3 gg(l1b::TILES_Y, 1, N);
-            if (layer == 11) hipLaunchKernelGGL((conv1b_kernel<true, 1>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, (const float*)cnn->b[0], act[0], st[0]);
-            if (layer == 12) hipLaunchKernelGGL((conv1b_kernel<true, 2>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, (const float*)cnn->b[0], act[0], st[0]);
-            if (layer == 14) hipLaunchKernelGGL((conv1b_kernel<true, 4>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, (const float*)cnn->b[0], act[0], st[0]);
-            if (layer == 13) hipLaunchKernelGGL((conv1b_kernel<true, 3>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, (const float*)cnn->b[0], act[0], st[0]);
+            if (layer == 11) hipLaunchKernelGGL((conv1b_kernel<true, 1>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, 1.0f / cnn->wscale[0], (const float*)cnn->b[0], act[0], st[0]);
+            if (layer == 12) hipLaunchKernelGGL((conv1b_kernel<true, 2>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, 1.0f / cnn->wscale[0], (const float*)cnn->b[0], act[0], st[0]);
+            if (layer == 14) hipLaunchKernelGGL((conv1b_kernel<true, 4>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, 1.0f / cnn->wscale[0], (const float*)cnn->b[0], act[0], st[0]);
+            if (layer == 13) hipLaunchKernelGGL((conv1b_kernel<true, 3>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, 1.0f / cnn->wscale[0], (const float*)cnn->b[0], act[0], st[0]);
             break;
         }
-        case 1: launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, stream); break;
-        case 2: launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, stream); break;
-        case 3: launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], N, stream); break;
-        case 4: launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], N, stream); break;
-        case 5: launch_bf6s<Bfs6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w6_frag, cnn->b[5], act[5], st[5], N, stream); break;
+        case 1: launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
+        case 2: launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, cnn->xscale[2], cnn->wscale[2], stream); break;
+        case 3: launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], N, cnn->xscale[3], cnn->wscale[3], stream); break;
+        case 4: launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], N, cnn->xscale[4], cnn->wscale[4], stream); break;
+        case 5: launch_bf6s<Bfs6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w6_frag, cnn->b[5], act[5], st[5], N, cnn->xscale[5], cnn->wscale[5], stream); break;
         default:
             hipLaunchKernelGGL(fc_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, act[5], st[5], cnn->gn_g[5], cnn->gn_b[5],
                                cnn->fc_wt, cnn->fc_b, feat, N);

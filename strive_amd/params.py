@@ -98,27 +98,34 @@ def _fill_gru(s, holder, sd, prefix):
         s.bhh[l] = holder.hold(_c(sd['%s.bias_hh_l%d' % (prefix, l)]))
 
 
-def _conv1_fragments(w):
-    """(16,4,7,7) fp32 -> int32 tensor holding [ky][piece][lane][8 x bf16]: the exact three-way bf16 split of every
+def _pow2_scale(bound, target=32768.0):
+    """largest power of two S with bound * S <= target (fp16's largest finite value is 65504)"""
+    import math
+    if not (bound > 0.0) or not math.isfinite(bound):
+        return 1.0
+    return float(2.0 ** math.floor(math.log2(target / bound)))
+
+
+def _f16_split2(w, scale, what):
+    """w * scale = w0 + w1 up to 2^-24 |w|: w0 = fp16 (round to nearest even), w1 = fp16 of the exact remainder."""
+    ws = w.to(torch.float32) * scale
+    w0 = ws.to(torch.float16)
+    w1 = (ws - w0.to(torch.float32)).to(torch.float16)
+    if not bool(torch.isfinite(w0.float()).all()) or not bool(torch.isfinite(w1.float()).all()):
+        raise ValueError('%s weights do not fit fp16 after scaling by %g (non-finite values?)' % (what, scale))
+    return torch.stack([w0, w1], dim=0)
+
+
+def _conv1_fragments(w, scale):
+    """(16,4,7,7) fp32 -> int32 tensor holding [ky][piece][lane][8 x fp16]: the two-piece fp16 split of every (scaled)
     weight in the k order of conv1b_kernel (lane group g: window columns 2g, 2g+1; element = parity*4 + layer;
     column 7 is zero padding)."""
-    pieces = _bf16_split3(w, 'conv1')                                # (3, co, ci, ky, kx)
-    pad = torch.zeros((3, 16, 4, 7, 1), dtype=torch.bfloat16, device=w.device)
-    pk = torch.cat([pieces, pad], dim=4).view(3, 16, 4, 7, 4, 2)     # kx -> (g, parity)
+    pieces = _f16_split2(w, scale, 'conv1')                          # (2, co, ci, ky, kx)
+    pad = torch.zeros((2, 16, 4, 7, 1), dtype=torch.float16, device=w.device)
+    pk = torch.cat([pieces, pad], dim=4).view(2, 16, 4, 7, 4, 2)     # kx -> (g, parity)
     # -> [ky][piece][g][co][parity][ci]
-    frag = pk.permute(3, 0, 4, 1, 5, 2).contiguous()                 # (7, 3, 4, 16, 2, 4)
-    return frag.view(torch.int16).view(7, 3, 64, 8).contiguous().view(torch.int32)
-
-
-def _bf16_split3(w, what):
-    hi = w.to(torch.bfloat16)
-    r1 = w - hi.to(torch.float32)
-    mid = r1.to(torch.bfloat16)
-    r2 = r1 - mid.to(torch.float32)
-    lo = r2.to(torch.bfloat16)
-    if not torch.equal(hi.float() + mid.float() + lo.float(), w):
-        raise ValueError('%s weights are not exactly representable as three bf16 pieces (non-finite or subnormal?)' % what)
-    return torch.stack([hi, mid, lo], dim=0)
+    frag = pk.permute(3, 0, 4, 1, 5, 2).contiguous()                 # (7, 2, 4, 16, 2, 4)
+    return frag.view(torch.int16).view(7, 2, 64, 8).contiguous().view(torch.int32)
 
 
 BF6_PASS_CH = 8     # input channels staged per pass by conv_bf6_kernel (BfCfg::PASS_CH)
@@ -139,25 +146,25 @@ def conv_tap_order(k=5):
     return order
 
 
-def _conv_bf6_fragments(w, pass_ch=BF6_PASS_CH):
-    """(co, ci, k, k) fp32, k = 5 or 3 -> int32 tensor [pass = ci/8][step][co/32][piece 3][lane 64][8 x bf16]: the exact
-    three-way bf16 split of every weight in the k order of conv_bf6_kernel (lane = 32 h + output channel % 32, element e =
+def _conv_bf6_fragments(w, scale, pass_ch=BF6_PASS_CH):
+    """(co, ci, k, k) fp32, k = 5 or 3 -> int32 tensor [pass = ci/8][step][co/32][piece 2][lane 64][8 x fp16]: the two-piece
+    fp16 split of every (scaled) weight in the k order of conv_bf6_kernel (lane = 32 h + output channel % 32, element e =
     input channel 8 pass + e, window tap = conv_tap_order(k)[step][h])."""
     co, ci, k, _ = w.shape
     if pass_ch != 8:
         raise NotImplementedError('conv_bf6_kernel stages 8 channels at a time')
-    pieces = _bf16_split3(w, 'conv').permute(0, 1, 3, 4, 2).contiguous()      # (3, co, ky, kx, ci)
+    pieces = _f16_split2(w, scale, 'conv').permute(0, 1, 3, 4, 2).contiguous()      # (2, co, ky, kx, ci)
     npass, csplit = ci // pass_ch, co // 32
     order = conv_tap_order(k)
-    out = torch.zeros((npass, len(order), csplit, 3, 2, 32, 8), dtype=torch.bfloat16, device=w.device)
+    out = torch.zeros((npass, len(order), csplit, 2, 2, 32, 8), dtype=torch.float16, device=w.device)
     for p_ in range(npass):
         for s_, taps in enumerate(order):
             for h, tap in enumerate(taps):
                 if tap is None:
                     continue
                 ky, kx = tap
-                blk = pieces[:, :, ky, kx, pass_ch * p_:pass_ch * p_ + 8]       # (3, co, 8)
-                out[p_, s_, :, :, h] = blk.view(3, csplit, 32, 8).permute(1, 0, 2, 3)
+                blk = pieces[:, :, ky, kx, pass_ch * p_:pass_ch * p_ + 8]       # (2, co, 8)
+                out[p_, s_, :, :, h] = blk.view(2, csplit, 32, 8).permute(1, 0, 2, 3)
     return out.contiguous().view(torch.int16).view(-1, 8).contiguous().view(torch.int32)
 
 
@@ -178,12 +185,24 @@ def _fill_cnn(s, holder, sd):
         s.b[l] = holder.hold(_c(sd['map_conv.%d.bias' % (3 * l)]))
         s.gn_g[l] = holder.hold(_c(sd['map_conv.%d.weight' % (3 * l + 1)]))
         s.gn_b[l] = holder.hold(_c(sd['map_conv.%d.bias' % (3 * l + 1)]))
-    s.w1_frag = holder.hold(_conv1_fragments(_c(sd['map_conv.0.weight'])))
-    s.w2_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.3.weight'])))
-    s.w3_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.6.weight'])))
-    s.w4_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.9.weight'])))
-    s.w5_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.12.weight'])))
-    s.w6_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.15.weight'])))
+    # power-of-two scales: weights so that max |w| * wscale <= 32768; layer inputs (l >= 1) from the bound
+    # relu(gamma * xhat + beta) <= max|gamma| * sqrt(C H W) + max|beta|  (|xhat| <= sqrt(#elements) for any sample)
+    in_elems = [0, 16 * 125 * 125, 32 * 61 * 61, 64 * 29 * 29, 64 * 14 * 14, 128 * 6 * 6]
+    for l in range(6):
+        w = _c(sd['map_conv.%d.weight' % (3 * l)])
+        s.wscale[l] = _pow2_scale(float(w.abs().max()))
+        if l == 0:
+            s.xscale[l] = 1.0
+        else:
+            g = float(_c(sd['map_conv.%d.weight' % (3 * l - 2)]).abs().max())
+            b = float(_c(sd['map_conv.%d.bias' % (3 * l - 2)]).abs().max())
+            s.xscale[l] = min(_pow2_scale(g * in_elems[l] ** 0.5 + b, 60000.0), 1024.0)
+    s.w1_frag = holder.hold(_conv1_fragments(_c(sd['map_conv.0.weight']), s.wscale[0]))
+    s.w2_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.3.weight']), s.wscale[1]))
+    s.w3_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.6.weight']), s.wscale[2]))
+    s.w4_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.9.weight']), s.wscale[3]))
+    s.w5_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.12.weight']), s.wscale[4]))
+    s.w6_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.15.weight']), s.wscale[5]))
     fw = _c(sd['map_feature.weight'])
     if tuple(fw.shape) != (64, 512):
         raise NotImplementedError('map_feature must be Linear(512, 64)')

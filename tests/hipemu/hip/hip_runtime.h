@@ -305,6 +305,51 @@ inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b,
     hipemu::wave_barrier();
     return d;
 }
+// fp16 variants: same fragment layout as the bf16 ones (verified on gfx950 with tools/mfma_f16_probe.hip; fp16 subnormals
+// are kept, products of two fp16 values are exact in fp32)
+typedef _Float16 hipemu_f16x8 __attribute__((ext_vector_type(8)));
+inline hipemu_f32x4 hipemu_mfma_16x16x32_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x4 c, int, int, int) {
+    hipemu_bf16_wave& w = hipemu_bf16_buf();
+    int lane = hipemu_lane();
+    for (int j = 0; j < 8; ++j) {
+        w.a[lane][j] = (float)a[j];
+        w.b[lane][j] = (float)b[j];
+    }
+    hipemu::wave_barrier();
+    hipemu_f32x4 d = c;
+    int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (lane >> 4) * 4 + r;
+        float acc = c[r];
+        for (int g = 0; g < 4; ++g)
+            for (int j = 0; j < 8; ++j) acc += w.a[g * 16 + row][j] * w.b[g * 16 + col][j];
+        d[r] = acc;
+    }
+    hipemu::wave_barrier();
+    return d;
+}
+inline hipemu_f32x16 hipemu_mfma_32x32x16_f16(hipemu_f16x8 a, hipemu_f16x8 b, hipemu_f32x16 c, int, int, int) {
+    hipemu_bf16_wave& w = hipemu_bf16_buf();
+    int lane = hipemu_lane();
+    for (int j = 0; j < 8; ++j) {
+        w.a[lane][j] = (float)a[j];
+        w.b[lane][j] = (float)b[j];
+    }
+    hipemu::wave_barrier();
+    hipemu_f32x16 d = c;
+    int col = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < 8; ++j) acc += w.a[h * 32 + row][j] * w.b[h * 32 + col][j];
+        d[r] = acc;
+    }
+    hipemu::wave_barrier();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16 hipemu_mfma_32x32x16_f16
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16 hipemu_mfma_16x16x32_f16
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 hipemu_mfma_16x16x32_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_16x16x4
