@@ -286,7 +286,7 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
 // interleaved with the matrix work of step s.
 // =============================================================================================
 template <int CIN_, int COUT_, int KS_, int IH_, int OH_, int NPART_IN_, bool OUT_OCT_, int PT_ = 2, int WGS_PER_CU_ = 2,
-          bool ROWS2_ = false>
+          bool ROWS2_ = false, int CBW_ = 1>
 struct BfCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, KS = KS_, IH = IH_, OH = OH_, NPART_IN = NPART_IN_;
     static constexpr bool OUT_OCT = OUT_OCT_;
@@ -295,23 +295,25 @@ struct BfCfg {
     static constexpr int TILE_ROWS = ROWS2 ? 2 : 1;
     static constexpr int WGS_PER_CU = WGS_PER_CU_;                  // residency target (LDS and register budget)
     static constexpr int NT = 256, NW = 4, TH = NW * PT * TILE_ROWS, TW = ROWS2 ? 16 : 32;
-    static constexpr int COUT_WG = 32, CSPLIT = COUT / COUT_WG;
+    // a workgroup computes CBW blocks of 32 output channels from ONE staging of the input tile (the matrix steps of a pass
+    // run once per block): the input is fetched, normalised and split COUT / (32 CBW) times instead of COUT / 32 times
+    static constexpr int CBW = CBW_, COUT_WG = 32 * CBW, CSPLIT = COUT / COUT_WG;
     static constexpr int PASS_CH = 8, NPASS = CIN / PASS_CH;
     static constexpr int ITH = 2 * TH + KS - 2, ITW = 2 * TW + KS - 2, HW = (ITW + 1) / 2;
     static constexpr int HALF_B = HW * 16, ROW_B = 2 * HALF_B, PIECE_B = ITH * ROW_B;
     static constexpr int NPIECE = 2;                                          // fp16 pieces per value
     static constexpr int IN_B = (NPIECE * PIECE_B + 255) / 256 * 256;         // weight fragments start 256-byte aligned
     static constexpr int NKS = (KS * KS + 1) / 2;                            // MFMA steps per pass (two taps each)
-    static constexpr int WSTEP_B = 2 * 64 * 16;                              // [piece][lane][16 B]
+    static constexpr int WSTEP_B = CBW * 2 * 64 * 16;                        // one matrix step: [block][piece][lane][16 B]
     static constexpr int TILES_X = (OH + TW - 1) / TW, TILES_Y = (OH + TH - 1) / TH;
     static constexpr int NPART_OUT = TILES_X * TILES_Y * CSPLIT;
     static constexpr int UNITS = ITH * ITW, UITERS = (UNITS + NT - 1) / NT;
     static constexpr size_t LDS_BYTES = (size_t)IN_B + 3 * WSTEP_B + (size_t)CIN * 8 + NW * 16 + 16;
-    static constexpr size_t WFRAG_BYTES = (size_t)NPASS * NKS * CSPLIT * WSTEP_B;
+    static constexpr size_t WFRAG_BYTES = (size_t)NPASS * NKS * (COUT / 32) * 2048;
     static_assert(CIN % PASS_CH == 0 && COUT % COUT_WG == 0 && CIN <= NT, "channel tiling");
     static_assert(LDS_BYTES * WGS_PER_CU <= 160 * 1024, "LDS budget of the residency target");
     static_assert((KS == 5 && NKS == 13) || (KS == 3 && NKS == 5), "tap orders exist for 5x5 and 3x3 windows");
-    static_assert(WSTEP_B == 16 * 128, "weight step = one 16-byte piece for each of the first 128 threads");
+    static_assert(WSTEP_B == 16 * 128 * CBW && WSTEP_B / 16 <= NT, "weight step = one 16-byte piece for each of the first 128 CBW threads");
 };
 
 // v = p0 + p1 up to 2^-24 |v| (p0 = fp16(v) rounded to nearest, p1 = fp16(v - p0)); v is pre-scaled into fp16's range.
@@ -382,9 +384,6 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
     };
     issue_loads(0);
     const float my_g = tid < CIN ? gn_g[tid] : 0.f, my_b = tid < CIN ? gn_b[tid] : 0.f;   // in flight during the reduction
-    float4 bias4[4];                                               // this lane's 16 output channels (epilogue)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) bias4[rg] = *reinterpret_cast<const float4*>(bias + cb * Cfg::COUT_WG + 8 * rg + 4 * h);
 
     // ---- GroupNorm moments of the input sample: the producer's per-tile partial sums, one per lane, reduced in a
     // fixed (butterfly) order ----
@@ -414,11 +413,14 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
     }
     stamp();
 
-    f32x16 acc[PT];
+    constexpr int CBW = Cfg::CBW, NKS = Cfg::NKS;
+    f32x16 acc[CBW][PT];
 #pragma unroll
-    for (int i = 0; i < PT; ++i)
+    for (int c = 0; c < CBW; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
 
     // this lane's pixel inside a pixel tile (row, column) and the byte offset of its window origin in the wave's first
     // tile; tile i is 2 * TILE_ROWS * i input rows further
@@ -426,20 +428,21 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
     const int lane_base = (2 * (Cfg::TILE_ROWS * PT * wave + prow)) * Cfg::ROW_B + pcol * 16;
 
     const uint4* wsrc = reinterpret_cast<const uint4*>(wfrag);
-    constexpr int WQ = Cfg::WSTEP_B / 16;                         // 128 x 16 B per MFMA step
-    auto wstep_src = [&](int pass, int s) { return wsrc + ((size_t)(pass * Cfg::NKS + s) * Cfg::CSPLIT + cb) * WQ; };
-    const bool wmover = tid < WQ;                                 // waves 0-1 move the weight fragments
+    constexpr int WQ = Cfg::WSTEP_B / 16;                         // 128 CBW x 16 B per matrix step
+    // fragments are stored [pass][tap pair][co / 32][piece][lane]: the CBW blocks of this workgroup are adjacent
+    auto wstep_src = [&](int pass, int t) { return wsrc + ((size_t)(pass * NKS + t) * (COUT / 32) + cb * CBW) * 128; };
+    const bool wmover = tid < WQ;                                 // the first 2 CBW waves move the weight fragments
 
     for (int pass = 0; pass < Cfg::NPASS; ++pass) {
         // ALL weight fragments of the pass (13 x 16 bytes per moving thread) are requested up front and parked in
         // registers: an L2 round trip under load (~1 us) is longer than two MFMA steps, a shallower prefetch paces
         // the whole pipeline at latency / depth (measured with the s_memtime phase profile, tools/conv_phase_profile.py)
-        uint4 wq[Cfg::NKS];
+        uint4 wq[NKS];
 #pragma unroll
-        for (int t = 0; t < Cfg::NKS; ++t) wq[t] = make_uint4(0u, 0u, 0u, 0u);
+        for (int t = 0; t < NKS; ++t) wq[t] = make_uint4(0u, 0u, 0u, 0u);
         if (wmover) {
 #pragma unroll
-            for (int t = 0; t < Cfg::NKS; ++t) wq[t] = wstep_src(pass, t)[tid];
+            for (int t = 0; t < NKS; ++t) wq[t] = wstep_src(pass, t)[tid];
         }
         __syncthreads();        // s_gn ready (pass 0) / every wave is done with the previous pass's tiles
         // ---- 8 input channels of the (2TH+KS-2) x (2TW+KS-2) window: GroupNorm + ReLU (pre-scaled), two-piece fp16 split ----
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
 
         // Software pipeline over the MFMA steps: while the matrix cores work on step s, the A/B fragments of step
         // s+1 are read from LDS into the other register set; one barrier per step.
-        f16x8 fa[2][2], fb[2][PT][2];
+        f16x8 fa[2][CBW][2], fb[2][PT][2];
         auto load_frags = [&](int t, int set) {
             int ky, kx;
             if (Cfg::KS == 5) {
@@ -499,7 +502,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
             const int off = ky * Cfg::ROW_B + (kx & 1) * Cfg::HALF_B + (kx >> 1) * 16;
             const unsigned char* wb = s_w + (t % 3) * Cfg::WSTEP_B + lane * 16;
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) fa[set][pl] = *reinterpret_cast<const f16x8*>(wb + pl * 1024);
+            for (int c = 0; c < CBW; ++c)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) fa[set][c][pl] = *reinterpret_cast<const f16x8*>(wb + (c * 2 + pl) * 1024);
 #pragma unroll
             for (int i = 0; i < PT; ++i)
 #pragma unroll
@@ -508,21 +513,24 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
         };
         load_frags(0, 0);
 #pragma unroll
-        for (int s = 0; s < Cfg::NKS; ++s) {
+        for (int s = 0; s < NKS; ++s) {
             const int cur = s & 1;
-            if (s + 1 < Cfg::NKS) load_frags(s + 1, cur ^ 1);
-            // three products per pixel tile (w1 x0, w0 x1, w0 x0: the small ones first; w1 x1 is below 2^-24 of the leading
-            // product); the tiles' accumulation chains alternate so that an MFMA never waits for the one issued just before it
+            if (s + 1 < NKS) load_frags(s + 1, cur ^ 1);
+            // three products per (channel block, pixel tile) (w1 x0, w0 x1, w0 x0: the small ones first; w1 x1 is below 2^-24
+            // of the leading product); the accumulation chains alternate so that an MFMA never waits for the one issued just
+            // before it
             constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
 #pragma unroll
             for (int term = 0; term < 3; ++term)
 #pragma unroll
-                for (int i = 0; i < PT; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][TA[term]], fb[cur][i][TB[term]], acc[i], 0, 0, 0);
+                for (int c = 0; c < CBW; ++c)
+#pragma unroll
+                    for (int i = 0; i < PT; ++i)
+                        acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][c][TA[term]], fb[cur][i][TB[term]], acc[c][i], 0, 0, 0);
             // issue order: one LDS fragment read of step s+1 behind each MFMA of step s (issuing the reads up front stalls
             // the wave on the LDS queue before the matrix pipe gets any work)
-            if (s + 1 < Cfg::NKS) {
-                constexpr int NRD = 2 + 2 * PT, NMF = 3 * PT;
+            if (s + 1 < NKS) {
+                constexpr int NRD = 2 * CBW + 2 * PT, NMF = 3 * PT * CBW;
 #pragma unroll
                 for (int q = 0; q < (NRD < NMF ? NRD : NMF); ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
@@ -532,39 +540,42 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
                 if (NRD > NMF) __builtin_amdgcn_sched_group_barrier(0x100, NRD - NMF, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 2 < Cfg::NKS && wmover) reinterpret_cast<uint4*>(s_w + ((s + 2) % 3) * Cfg::WSTEP_B)[tid] = wq[s + 2];
-            if (s + 1 < Cfg::NKS) __syncthreads();
+            if (s + 2 < NKS && wmover) reinterpret_cast<uint4*>(s_w + ((s + 2) % 3) * Cfg::WSTEP_B)[tid] = wq[s + 2];
+            if (s + 1 < NKS) __syncthreads();
         }
         if (pass < 2) stamp();
     }
 
-    // ---- epilogue: D column = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel within the tile ----
-    float fsum = 0.f, fsq = 0.f;          // this lane's 16 PT outputs in fp32; everything above that in float64
+    // ---- epilogue: D column = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel within the block ----
+    float fsum = 0.f, fsq = 0.f;          // this lane's 16 CBW PT outputs in fp32; everything above that in float64
 #pragma unroll
-    for (int i = 0; i < PT; ++i) {
-        const int oy = oy0 + Cfg::TILE_ROWS * (PT * wave + i) + prow, ox = ox0 + pcol;
-        const bool valid = oy < OH && ox < OH;
+    for (int c = 0; c < CBW; ++c) {
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int co = cb * Cfg::COUT_WG + 8 * rg + 4 * h;
-            const float4 bv = bias4[rg];
-            float4 v;
-            v.x = fmaf(acc[i][4 * rg + 0], unscale, bv.x);     // unscale = 2^-k exactly: one rounding, like acc + bias
-            v.y = fmaf(acc[i][4 * rg + 1], unscale, bv.y);
-            v.z = fmaf(acc[i][4 * rg + 2], unscale, bv.z);
-            v.w = fmaf(acc[i][4 * rg + 3], unscale, bv.w);
-            if (valid) {
-                if (Cfg::OUT_OCT) {     // octet-planar, [n][c/8][y][x][c%8]
-                    *reinterpret_cast<float4*>(out + ((((size_t)n * (COUT / 8) + (co >> 3)) * OH + oy) * OH + ox) * 8 + (co & 7)) = v;
-                } else {                // NCHW
-                    float* o = out + (((size_t)n * COUT + co) * OH + oy) * OH + ox;
-                    o[0] = v.x;
-                    o[(size_t)OH * OH] = v.y;
-                    o[(size_t)2 * OH * OH] = v.z;
-                    o[(size_t)3 * OH * OH] = v.w;
+        for (int i = 0; i < PT; ++i) {
+            const int oy = oy0 + Cfg::TILE_ROWS * (PT * wave + i) + prow, ox = ox0 + pcol;
+            const bool valid = oy < OH && ox < OH;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int co = (cb * CBW + c) * 32 + 8 * rg + 4 * h;
+                const float4 bv = *reinterpret_cast<const float4*>(bias + co);
+                float4 v;
+                v.x = fmaf(acc[c][i][4 * rg + 0], unscale, bv.x);     // unscale = 2^-k exactly: one rounding, like acc + bias
+                v.y = fmaf(acc[c][i][4 * rg + 1], unscale, bv.y);
+                v.z = fmaf(acc[c][i][4 * rg + 2], unscale, bv.z);
+                v.w = fmaf(acc[c][i][4 * rg + 3], unscale, bv.w);
+                if (valid) {
+                    if (Cfg::OUT_OCT) {     // octet-planar, [n][c/8][y][x][c%8]
+                        *reinterpret_cast<float4*>(out + ((((size_t)n * (COUT / 8) + (co >> 3)) * OH + oy) * OH + ox) * 8 + (co & 7)) = v;
+                    } else {                // NCHW
+                        float* o = out + (((size_t)n * COUT + co) * OH + oy) * OH + ox;
+                        o[0] = v.x;
+                        o[(size_t)OH * OH] = v.y;
+                        o[(size_t)2 * OH * OH] = v.z;
+                        o[(size_t)3 * OH * OH] = v.w;
+                    }
+                    fsum += (v.x + v.y) + (v.z + v.w);
+                    fsq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fsq))));
                 }
-                fsum += (v.x + v.y) + (v.z + v.w);
-                fsq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fsq))));
             }
         }
     }
@@ -850,7 +861,7 @@ static int launch_bf6s(const float* in, const GNStats* st_in, const float* g, co
 }
 
 typedef BfCfg<16, 32, 5, 125, 61, l1b::NPART, true> Bf2;     // conv2: octet-planar in and out
-typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, true> Bf3;   // conv3: octet-planar in and out
+typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, true, 2, 2, false, 2> Bf3;   // conv3: octet-planar in and out; both 32-channel blocks from one staging
 // conv4 (3x3, 29 -> 14): the whole 14 x 14 image is one workgroup tile of 16 x 16 (pixel tiles of 2 rows x 16 columns);
 typedef BfCfg<64, 64, 3, 29, 14, Bf3::NPART_OUT, true, 2, 2, true> Bf4;
 typedef BfsCfg<64, 128, 14, 6, 7, Bf4::NPART_OUT, true> Bfs5;       // conv5: 7 samples (252 pixels) x 32 channels per workgroup

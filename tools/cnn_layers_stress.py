@@ -21,7 +21,7 @@ for n in (40, 96, 300):
     mi = torch.tensor([i % 2 for i in range(n)]).to(dev)
     ops.encode_map(m, pos, torch.arange(n).to(dev), mi, env)
     mp = ops._map_pack(env, dev)
-    cnn = ops._cached_pack(m, 'cnn', m.map_conv, lambda: None)
+    cnn = ops.cnn_pack(m)
     mapix = mi.to(torch.int32).contiguous()
     wsb = lib.query('strive_map_cnn_workspace_bytes', n)
     ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)

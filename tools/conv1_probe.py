@@ -13,7 +13,7 @@ lib = L.get_lib()
 N = 256
 pos = g.past[:N, -1, :4].contiguous()
 mapix = mi[g.batch][:N].to(torch.int32).contiguous()
-mp = ops._map_pack(env, dev); cnn = ops._cached_pack(m, 'cnn', m.map_conv, lambda: None)
+mp = ops._map_pack(env, dev); cnn = ops.cnn_pack(m)
 wsb = lib.query('strive_map_cnn_workspace_bytes', N); ws = torch.empty(wsb, dtype=torch.uint8, device=dev); feat = torch.empty((N, 64), device=dev)
 nm = m.normalizer; mean4, std4 = L.f4(nm.mean_vals[:4].tolist()), L.f4(nm.std_vals[:4].tolist()); st = L.stream_ptr(pos)
 def t(layer, reps=20):

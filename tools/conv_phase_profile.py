@@ -17,7 +17,7 @@ pos = (synth.f32(fr) / torch.tensor([15., 15., 1., 1.])).to(dev).contiguous()
 mi = torch.tensor([i % 2 for i in range(n)]).to(dev)
 ops.encode_map(m, pos, torch.arange(n).to(dev), mi, env)
 lib = L.get_lib()
-mp = ops._map_pack(env, dev); cnn = ops._cached_pack(m, 'cnn', m.map_conv, lambda: None)
+mp = ops._map_pack(env, dev); cnn = ops.cnn_pack(m)
 mapix = mi.to(torch.int32).contiguous()
 wsb = lib.query('strive_map_cnn_workspace_bytes', n)
 ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
