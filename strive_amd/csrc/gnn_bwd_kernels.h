@@ -52,10 +52,10 @@ static __global__ __launch_bounds__(256) void gnn_node2_bwd_kernel(GNNDev g, GNN
         s_go[i] = (rr < nrows && c < O) ? d_out[(size_t)(r0 + rr) * O + c] : 0.f;
     }
     __syncthreads();
-    mlp_backward_lds<RB_NODE>(g.mlp_out, L.pre_o, s_go, HLD, s_ga, s_gb, s_gx, HLD, false, tid, 256,
-                              gr.on ? &gr.mlp_out : nullptr, L.act, L.xp, HLD, nrows);
-    mlp_backward_lds<RB_NODE>(g.update, L.pre_u, s_gx, HLD, s_ga, s_gb, s_gin, in_ld, false, tid, 256,
-                              gr.on ? &gr.update : nullptr, L.act, L.in, in_ld, nrows);
+    mlp_backward_lds<RB_NODE, true>(g.mlp_out, L.pre_o, s_go, HLD, s_ga, s_gb, s_gx, HLD, false, tid, 256,
+                                    gr.on ? &gr.mlp_out : nullptr, L.act, L.xp, HLD, nrows);
+    mlp_backward_lds<RB_NODE, true>(g.update, L.pre_u, s_gx, HLD, s_ga, s_gb, s_gin, in_ld, false, tid, 256,
+                                    gr.on ? &gr.update : nullptr, L.act, L.in, in_ld, nrows);
     const int D = g.D;
     for (int i = tid; i < RB_NODE * D; i += 256) {
         const int rr = i / D, c = i - rr * D;
@@ -80,6 +80,7 @@ struct EdgeBwdArgs {
     float* gpos_tgt;       // (R, 4)          adjoint of the TARGET pose (frame), summed over its edges
 };
 
+template <bool WG>
 static __global__ __launch_bounds__(256) void edge_bwd_kernel(GNNDev g, GNNGradDev gr, ScenesDev sc, const float* __restrict__ pos,
                                                                 GnnBuffers gb, EdgeBwdArgs a) {
     HIP_DYNAMIC_SHARED(float, smem)
@@ -110,9 +111,9 @@ static __global__ __launch_bounds__(256) void edge_bwd_kernel(GNNDev g, GNNGradD
             L.m[jr * HLD + c] = v;
         }
         __syncthreads();
-        mlp_backward_lds<RB_EDGE>(g.edge, L.pre, L.m, HLD, s_ga, s_gb, nullptr, 0, true, tid, 256,
-                                  gr.on ? &gr.edge : nullptr, L.act, nullptr, 0, nv);   // d e1 -> s_ga
-        if (gr.on) {
+        mlp_backward_lds<RB_EDGE, WG>(g.edge, L.pre, L.m, HLD, s_ga, s_gb, nullptr, 0, true, tid, 256,
+                                      WG ? &gr.edge : nullptr, L.act, nullptr, 0, nv);   // d e1 -> s_ga
+        if (WG) {
             // layer 0 is factorised: the relative-pose columns of its weight get d e1^T . rel here (NaN components were
             // replaced by 0 in L.rel, like the forward); the node columns and the bias follow in node1_bwd from dP / dQ
             wgrad_lds(s_ga, HLD, H, L.rel, 4, 4, gr.edge.w[0] + (2 * D + 2 * g.NC), EIN, nullptr, nv, tid, 256);
@@ -188,6 +189,7 @@ struct Node1BwdArgs {
     float* dz;              // (R, 32) columns [128+NC, 128+NC+32), ACCUMULATED   (rollout: the latents)
 };
 
+template <bool WG>
 static __global__ __launch_bounds__(256) void node1_bwd_kernel(GNNDev g, GNNGradDev gr, ScenesDev sc, FeatSrc f, Node1BwdArgs a) {
     HIP_DYNAMIC_SHARED(float, smem)
     const int F = g.mlp_in.dims[0], D = g.D, H = STRIVE_HID;
@@ -240,7 +242,7 @@ static __global__ __launch_bounds__(256) void node1_bwd_kernel(GNNDev g, GNNGrad
         }
     }
     const int EIN = g.edge.dims[0];
-    if (gr.on) {
+    if (WG) {
         // node columns and bias of the factorised edge layer 0:  e1_ij = W[:, x_i] x_i + W[:, x_j] x_j + W[:, s_i] sem_i +
         // W[:, s_j] sem_j + W[:, rel] rel_ij + b,  so  dW[:, x_i] = sum_i dP_i x_i^T,  dW[:, x_j] = sum_j dQ_j x_j^T, ...
         for (int i = tid; i < RB_NODE * (xs_ld - D); i += 256) {
@@ -266,8 +268,8 @@ static __global__ __launch_bounds__(256) void node1_bwd_kernel(GNNDev g, GNNGrad
         if (r0 + rr < a.R) s_gx[rr * HLD + c] += a.dX[(size_t)(r0 + rr) * D + c];
     }
     __syncthreads();
-    mlp_backward_lds<RB_NODE>(g.mlp_in, L.pre, s_gx, HLD, s_dp, s_gb, s_gin, in_ld, false, tid, 256,
-                              gr.on ? &gr.mlp_in : nullptr, L.act, L.in, in_ld, nrows);
+    mlp_backward_lds<RB_NODE, WG>(g.mlp_in, L.pre, s_gx, HLD, s_dp, s_gb, s_gin, in_ld, false, tid, 256,
+                                  WG ? &gr.mlp_in : nullptr, L.act, L.in, in_ld, nrows);
     if (a.g_full) {
         for (int i = tid; i < RB_NODE * F; i += 256) {
             const int rr = i / F, c = i - rr * F;

@@ -296,7 +296,9 @@ __device__ __forceinline__ void wgrad_lds(const float* g, int g_ld, int OUT, con
 // Weight gradients (training path): pass `grads` (+ `act`: LDS [RB][HLD] scratch for the re-derived layer inputs, `in`:
 // the layer-0 input rows, and `nrows` = valid rows of the block); they are accumulated with atomics.  With skip_first the
 // layer-0 weight gradient is the caller's business (factorised edge layer).
-template <int RB>
+// WG is a compile-time switch: the latent-optimisation kernels instantiate WG = false and carry none of the weight-gradient
+// code (it costs registers and time in these latency-bound kernels even when it is branched over).
+template <int RB, bool WG = false>
 __device__ __forceinline__ void mlp_backward_lds(const MLPDev& m, const float* pre, const float* dout, int dout_ld,
                                                  float* ga, float* gb, float* din, int din_ld, bool skip_first, int tid,
                                                  int nthreads, const MLPGradDev* grads = nullptr, float* act = nullptr,
@@ -304,7 +306,7 @@ __device__ __forceinline__ void mlp_backward_lds(const MLPDev& m, const float* p
     const int L = m.nlayers;
     const float* g = dout;
     int g_ld = dout_ld;
-    const bool wg = grads && grads->w[L - 1];
+    const bool wg = WG && grads && grads->w[L - 1];
     for (int l = L - 1; l >= 1; --l) {
         const float* p = pre + (size_t)(l - 1) * RB * HLD;
         if (wg) {

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MLPDev m, MLPGradDev gr, c
         s_go[i] = (rr < nrows && c < O) ? dy[(size_t)(r0 + rr) * O + c] : 0.f;
     }
     __syncthreads();
-    mlp_backward_lds<RB_NODE>(m, s_pre, s_go, HLD, s_ga, s_gb, dx ? s_din : nullptr, in_ld, false, tid, 256, &gr, s_act, s_in, in_ld,
+    mlp_backward_lds<RB_NODE, true>(m, s_pre, s_go, HLD, s_ga, s_gb, dx ? s_din : nullptr, in_ld, false, tid, 256, &gr, s_act, s_in, in_ld,
                               nrows);
     if (dx) {
         for (int i = tid; i < RB_NODE * F; i += 256) {
@@ -189,11 +189,11 @@ extern "C" int strive_gnn_bwd(const StriveGNN* gnn, const StriveScenes* sc, cons
                        d_out, bw.dX, bw.dA, R);
     EdgeBwdArgs ae;
     ae.dA = bw.dA; ae.ARG = gb.ARG; ae.dP = bw.dP; ae.DE1 = bw.DE1; ae.DPJ = bw.DPJ; ae.gpos_tgt = bw.gpos_tgt;
-    hipLaunchKernelGGL(edge_bwd_kernel, dim3((unsigned)R), dim3(256), edge_bwd_lds_bytes(), stream, gd, gr, sd, pos, gb, ae);
+    hipLaunchKernelGGL(edge_bwd_kernel<true>, dim3((unsigned)R), dim3(256), edge_bwd_lds_bytes(), stream, gd, gr, sd, pos, gb, ae);
     Node1BwdArgs a1;
     a1.t = 0; a1.R = R; a1.dX = bw.dX; a1.dP = bw.dP; a1.DE1 = bw.DE1; a1.DPJ = bw.DPJ; a1.gpos_tgt = bw.gpos_tgt;
     a1.sem = sem; a1.g_pos = g_pos; a1.g_full = dx; a1.g_pf = nullptr; a1.g_mf = nullptr; a1.dz = nullptr;
-    hipLaunchKernelGGL(node1_bwd_kernel, dim3(nb), dim3(256), node1_bwd_lds_bytes(in_ld1, xs_ld), stream, gd, gr, sd, f, a1);
+    hipLaunchKernelGGL(node1_bwd_kernel<true>, dim3(nb), dim3(256), node1_bwd_lds_bytes(in_ld1, xs_ld), stream, gd, gr, sd, f, a1);
     STRIVE_CHECK_LAUNCH();
     return 0;
 }

@@ -424,6 +424,7 @@ extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* 
 
 // ---- GRU backward for rows r0.. : consumes g_mem (adjoint of mem_{t+1}) and g_pf (adjoint of past_feat_{t+1}),
 //      produces g_mem (adjoint of mem_t) and d_loc (adjoint of the local pose fed to the GRU).  grid = ceil(R/RB_NODE)
+template <bool WG>
 static __global__ __launch_bounds__(256) void gru_bwd_kernel(GRUDev gru, GRUGradDev gg, Tape tp, int t, int R,
                                                                const float* __restrict__ g_pf, float* __restrict__ g_mem,
                                                                float* __restrict__ d_loc) {
@@ -485,7 +486,7 @@ static __global__ __launch_bounds__(256) void gru_bwd_kernel(GRUDev gru, GRUGrad
         }
         __syncthreads();
         const int xin = (l == 0) ? 4 : 64;
-        if (gg.on) {
+        if (WG) {
             // dW_ih = d gi^T . x_l,  dW_hh = d gh^T . h_l  (x_l = the layer below's forward output, still intact in s_hn[l-1])
             const int nrows = (R - r0) < RB_NODE ? (R - r0) : RB_NODE;
             const float* xl = (l == 0) ? s_x : s_hn + (size_t)(l - 1) * RB_NODE * 64;
@@ -528,6 +529,7 @@ struct Node2BwdArgs {
     float* dA;               // (R, 64) out: dL/d(aggregated message)
 };
 
+template <bool WG>
 static __global__ __launch_bounds__(256) void node2_bwd_kernel(GNNDev g, GNNGradDev gr, DynParams dp, Node2BwdArgs a, Tape tp) {
     HIP_DYNAMIC_SHARED(float, smem)
     const int in_ld = ld4(2 * g.D + g.NC);
@@ -583,10 +585,10 @@ static __global__ __launch_bounds__(256) void node2_bwd_kernel(GNNDev g, GNNGrad
     }
     __syncthreads();
     const int nrows = (a.R - r0) < RB_NODE ? (a.R - r0) : RB_NODE;
-    mlp_backward_lds<RB_NODE>(g.mlp_out, L.pre_o, s_go, 4, s_ga, s_gb, s_gx, HLD, false, tid, 256,
-                              gr.on ? &gr.mlp_out : nullptr, L.act, L.xp, HLD, nrows);
-    mlp_backward_lds<RB_NODE>(g.update, L.pre_u, s_gx, HLD, s_ga, s_gb, s_gin, in_ld, false, tid, 256,
-                              gr.on ? &gr.update : nullptr, L.act, L.in, in_ld, nrows);
+    mlp_backward_lds<RB_NODE, WG>(g.mlp_out, L.pre_o, s_go, 4, s_ga, s_gb, s_gx, HLD, false, tid, 256,
+                                  WG ? &gr.mlp_out : nullptr, L.act, L.xp, HLD, nrows);
+    mlp_backward_lds<RB_NODE, WG>(g.update, L.pre_u, s_gx, HLD, s_ga, s_gb, s_gin, in_ld, false, tid, 256,
+                                  WG ? &gr.update : nullptr, L.act, L.in, in_ld, nrows);
     const int D = g.D;
     for (int i = tid; i < RB_NODE * D; i += 256) {
         const int rr = i / D, c = i - rr * D;
@@ -639,6 +641,7 @@ static __global__ void rollout_init_bwd_kernel(const float* __restrict__ g_pf, c
     d_map_feat[i] = g_mf[i];
 }
 
+template <bool WG>
 int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const float* lw, const float* sem, const float* z,
                      const float* ext_future, int32_t FT, const float* d_traj, float* dz, const void* tape, size_t tape_bytes,
                      void* ws, size_t ws_bytes, strive_stream_t stream_, const TrainOut* tr) {
@@ -681,21 +684,21 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
         g2.Q = tp.Q_t(t);
         FeatSrc f = decoder_features(tp, t, sem, z, lw, NC);
         if (t < FT - 1)
-            hipLaunchKernelGGL(gru_bwd_kernel, dim3(nb), dim3(256), gru_bwd_lds_bytes(), stream, gr, ggr, tp, t, (int)R, g_pf,
+            hipLaunchKernelGGL(gru_bwd_kernel<WG>, dim3(nb), dim3(256), gru_bwd_lds_bytes(), stream, gr, ggr, tp, t, (int)R, g_pf,
                                g_mem, d_loc);
         Node2BwdArgs a2;
         a2.t = t; a2.FT = FT; a2.R = (int)R; a2.NS = sc->NS; a2.X = g2.X; a2.sem = sem; a2.lw = lw; a2.ext = ext_future;
         a2.ptr = sc->ptr; a2.scene_of = sc->scene_of; a2.g_traj = d_traj; a2.g_pos = g_pos; a2.d_loc = d_loc;
         a2.g_state = g_state; a2.dX = bw.dX; a2.dA = bw.dA;
-        hipLaunchKernelGGL(node2_bwd_kernel, dim3(nb), dim3(256), node2_bwd_lds_bytes(in_ld2), stream, gd, ggn, dp, a2, tp);
+        hipLaunchKernelGGL(node2_bwd_kernel<WG>, dim3(nb), dim3(256), node2_bwd_lds_bytes(in_ld2), stream, gd, ggn, dp, a2, tp);
         EdgeBwdArgs ae;
         ae.dA = bw.dA; ae.ARG = tp.ARG_t(t); ae.dP = bw.dP; ae.DE1 = bw.DE1; ae.DPJ = bw.DPJ; ae.gpos_tgt = bw.gpos_tgt;
-        hipLaunchKernelGGL(edge_bwd_kernel, dim3((unsigned)R), dim3(256), edge_bwd_lds_bytes(), stream, gd, ggn, sd, tp.pos_t(t),
+        hipLaunchKernelGGL(edge_bwd_kernel<WG>, dim3((unsigned)R), dim3(256), edge_bwd_lds_bytes(), stream, gd, ggn, sd, tp.pos_t(t),
                            g2, ae);
         Node1BwdArgs a1;
         a1.t = t; a1.R = (int)R; a1.dX = bw.dX; a1.dP = bw.dP; a1.DE1 = bw.DE1; a1.DPJ = bw.DPJ; a1.gpos_tgt = bw.gpos_tgt;
         a1.sem = sem; a1.g_pos = g_pos; a1.g_full = nullptr; a1.g_pf = g_pf; a1.g_mf = tr ? g_mf : nullptr; a1.dz = dz;
-        hipLaunchKernelGGL(node1_bwd_kernel, dim3(nb), dim3(256), node1_bwd_lds_bytes(in_ld1, xs_ld), stream, gd, ggn, sd, f, a1);
+        hipLaunchKernelGGL(node1_bwd_kernel<WG>, dim3(nb), dim3(256), node1_bwd_lds_bytes(in_ld1, xs_ld), stream, gd, ggn, sd, f, a1);
         if (tr && t > 0) {
             // map_feat_t = CNN(crop(pos_t.detach())) (reference traffic_model.py:694-695): its adjoint reaches the CNN weights
             int rc = strive_map_cnn_bwd(&dec->map, &dec->cnn, tp.pos_t(t), dec->state_mean, dec->state_std, tr->mapix, (int32_t)R,
@@ -727,7 +730,7 @@ extern "C" int strive_rollout_bwd(const StriveDecoder* dec, const StriveScenes* 
     STRIVE_CHECK_ARG(tape_bytes >= tape_bytes_for(R, FT), "tape too small");
     STRIVE_CHECK_ARG(ws_bytes >= strive_rollout_workspace_bytes(dec, sc, FT), "workspace too small");
     STRIVE_CHECK_ARG(sc->max_n >= 1, "max_n not set");
-    int rc = rollout_backward(dec, sc, lw, sem, z, ext_future, FT, d_traj, dz, tape, tape_bytes, ws, ws_bytes, stream_, nullptr);
+    int rc = rollout_backward<false>(dec, sc, lw, sem, z, ext_future, FT, d_traj, dz, tape, tape_bytes, ws, ws_bytes, stream_, nullptr);
     if (rc) return rc;
     STRIVE_CHECK_LAUNCH();
     return 0;
@@ -761,7 +764,7 @@ extern "C" int strive_rollout_bwd_train(const StriveDecoder* dec, const StriveSc
     tr.mapix = mapix;
     tr.cnn_ws = (char*)ws + base;
     tr.cnn_ws_bytes = ws_bytes - base;
-    int rc = rollout_backward(dec, sc, lw, sem, z, ext_future, FT, d_traj, dz, tape, tape_bytes, ws, base, stream_, &tr);
+    int rc = rollout_backward<true>(dec, sc, lw, sem, z, ext_future, FT, d_traj, dz, tape, tape_bytes, ws, base, stream_, &tr);
     if (rc) return rc;
     STRIVE_CHECK_LAUNCH();
     return 0;

@@ -17,6 +17,59 @@ from .common import log_normal
 from .. import ops
 
 
+class LossDict(dict):
+    """The reference's loss dicts hold, besides the scalar ``'loss'``, the COMPACTED 1-D lists of the penalties currently
+    in collision (``pen[mask]``): tensors whose length depends on the data, so producing them costs a device->host
+    synchronisation.  The optimisation loops only back-propagate ``'loss'``; the lists are read for logging.  This dict has
+    the same keys and yields the same tensors, but compacts a list only when it is actually read -- a closure that reads
+    nothing but ``'loss'`` never stalls the GPU queue."""
+
+    def __init__(self):
+        super(LossDict, self).__init__()
+        self._thunks = {}
+
+    def set_lazy(self, key, thunk):
+        dict.__setitem__(self, key, None)
+        self._thunks[key] = thunk
+
+    def _resolve(self, key):
+        th = self._thunks.pop(key, None)
+        if th is not None:
+            dict.__setitem__(self, key, th())
+
+    def __getitem__(self, key):
+        self._resolve(key)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        if key in self:
+            return self[key]
+        return default
+
+    def items(self):
+        for k in list(self._thunks):
+            self._resolve(k)
+        return dict.items(self)
+
+    def values(self):
+        for k in list(self._thunks):
+            self._resolve(k)
+        return dict.values(self)
+
+
+def _masked_mean(pen, mask):
+    """mean of pen[mask], 0 when nothing is selected (= the reference's ``[0.]`` sentinel), without compaction."""
+    cnt = mask.sum()
+    return torch.where(mask, pen, torch.zeros_like(pen)).sum() / torch.clamp(cnt, min=1).to(pen.dtype)
+
+
+def _compact_or_zero(pen, mask):
+    v = pen[mask]
+    if v.numel() == 0:
+        return torch.Tensor([0.0]).to(pen.device)
+    return v
+
+
 def interp_traj(future_pred, scale_factor=3):
     """Linear up-sampling in time + heading renormalisation (reference :625-644)."""
     multi = future_pred.dim() == 4
@@ -36,13 +89,16 @@ def _expand_targets(tgt, sizes_minus_one):
     return torch.repeat_interleave(tgt, sizes_minus_one.to(tgt.device), dim=0)
 
 
+def _behind(attacker_fut, tgt_expanded, crash_min_infront):
+    d = attacker_fut[:, :, :2] - tgt_expanded[:, :, :2]
+    d = d / torch.norm(d, dim=-1, keepdim=True)
+    return torch.sum(d * tgt_expanded[:, :, 2:4], dim=-1) < crash_min_infront
+
+
 def check_behind(attacker_fut, tgt_fut, ptr, crash_min_infront):
     """(NA-B,T) bool, True where the attacker is behind the target (reference :646-673)."""
     sizes = (ptr[1:] - ptr[:-1]) - 1
-    tgt = _expand_targets(tgt_fut, sizes)
-    d = attacker_fut[:, :, :2] - tgt[:, :, :2]
-    d = d / torch.norm(d, dim=-1, keepdim=True)
-    return torch.sum(d * tgt[:, :, 2:4], dim=-1) < crash_min_infront
+    return _behind(attacker_fut, _expand_targets(tgt_fut, sizes), crash_min_infront)
 
 
 class MotionPriorLoss(nn.Module):
@@ -210,6 +266,7 @@ class AvoidCollLoss(nn.Module):
             assert ptr is not None
             self.single_mask = torch.zeros((veh_att.size(0),), dtype=torch.bool, device=veh_att.device)
             self.single_mask[(ptr[:-1] + single_veh_idx).to(veh_att.device)] = True
+            self.single_idx = torch.nonzero(self.single_mask).flatten()
             veh_att = veh_att[self.single_mask]
             mapixes = mapixes[self.single_mask]
         self.env_coll_loss = EnvCollLoss(veh_att, mapixes, map_env)
@@ -217,16 +274,16 @@ class AvoidCollLoss(nn.Module):
     def forward(self, future_pred, z, prior_out):
         w = self.loss_weights
         loss = 0.0
-        out = {}
+        out = LossDict()
         fine = interp_traj(future_pred, scale_factor=3)
         if w['coll_veh'] > 0.0:
-            v = self.veh_coll_loss(fine)
-            loss = loss + w['coll_veh'] * v.mean()
-            out['coll_veh_loss'] = v
+            pen, m = self.veh_coll_loss.block_penalties(fine)
+            loss = loss + w['coll_veh'] * _masked_mean(pen, m)
+            out.set_lazy('coll_veh_loss', lambda: _compact_or_zero(pen, m))
         if w['coll_env'] > 0.0:
-            e = self.env_coll_loss(fine if not self.use_single_agt else fine[self.single_mask])
-            loss = loss + w['coll_env'] * e.mean()
-            out['coll_env_loss'] = e
+            epen, ev = self.env_coll_loss.valid_penalties(fine if not self.use_single_agt else fine.index_select(0, self.single_idx))
+            loss = loss + w['coll_env'] * _masked_mean(epen, ev)
+            out.set_lazy('coll_env_loss', lambda: _compact_or_zero(epen, ev))
         if w['motion_prior'] > 0.0:
             p = self.motion_prior_loss(z, prior_out)
             loss = loss + w['motion_prior'] * p.mean()
@@ -256,6 +313,9 @@ class AdvGenLoss(nn.Module):
         self.B = self.graph_sizes.size(0)
         self.ego_mask = torch.zeros((NA,), dtype=torch.bool, device=dev)
         self.ego_mask[ptr_c[:-1].to(dev)] = True
+        # index tensors instead of boolean-mask indexing in forward(): x[mask] has a data-dependent shape and costs a
+        # device->host synchronisation on every call
+        self.nonego_idx = torch.nonzero(~self.ego_mask).flatten()
         self.nonego_ptr = ptr_c - torch.arange(len(ptr_c))
         self.veh_coll_loss = VehCollLoss(veh_att, buffer_dist=veh_coll_buffer, ptr=ptr)
         self.env_coll_loss = EnvCollLoss(veh_att[~self.ego_mask], mapixes[~self.ego_mask], map_env)
@@ -290,14 +350,14 @@ class AdvGenLoss(nn.Module):
         crash = soft = None
         cur_min_agt = cur_min_t = None
         if w.get('adv_crash', 0.0) > 0.0:
-            atk = future_pred[~self.ego_mask][:, self.crash_min_t:, :]
+            atk = future_pred.index_select(0, self.nonego_idx)[:, self.crash_min_t:, :]
             tgt = tgt_traj[:, self.crash_min_t:, :4]
-            tgt_e = _expand_targets(tgt, self.graph_sizes - 1)
+            tgt_e = tgt[self.seg]                         # every attacker's own target row (index built once: no host sync)
             dist = torch.norm(atk[:, :, :2] - tgt_e[:, :, :2], dim=-1)
             din = dist
             inf = torch.full_like(din, float('inf'))
             if self.crash_min_infront is not None:
-                behind = check_behind(atk.detach(), tgt.detach(), self.ptr.cpu(), self.crash_min_infront)
+                behind = _behind(atk.detach(), tgt_e.detach(), self.crash_min_infront)
                 always = (torch.sum(behind, dim=1, keepdim=True) == behind.size(1)).expand_as(behind)
                 all_behind = torch.sum(always) == always.numel()
                 always = always & ~all_behind
@@ -305,7 +365,7 @@ class AdvGenLoss(nn.Module):
             if attack_agt_idx is not None:
                 am = torch.zeros((NA,), dtype=torch.bool, device=dev)
                 am[attack_agt_idx.to(dev)] = True
-                am = am[~self.ego_mask].unsqueeze(1).expand_as(din)
+                am = am.index_select(0, self.nonego_idx).unsqueeze(1).expand_as(din)
                 din = torch.where(~am, inf, din)
             NT = future_pred.size(1) - self.crash_min_t
             soft = self._segment_softmin(din)
@@ -330,8 +390,8 @@ class AdvGenLoss(nn.Module):
         if ('coll_veh' in w or 'coll_veh_plan' in w) and (w['coll_veh'] > 0.0 or w['coll_veh_plan'] > 0.0):
             pen, cmask = self.veh_coll_loss.block_penalties(fine)
             if w['coll_veh'] > 0.0:
-                m = cmask & (~self.slot_ego).view(1, -1)
-                veh_l = torch.Tensor([0.0]).to(dev) if torch.sum(m) == 0 else pen[m]
+                m_veh = cmask & (~self.slot_ego).view(1, -1)
+                veh_l = (pen, m_veh)
             if w['coll_veh_plan'] > 0.0:
                 # weight of a planner-involving pair = prior_reweight of its non-ego member (reference :192-204)
                 one = torch.ones((1,), device=dev)
@@ -339,34 +399,36 @@ class AdvGenLoss(nn.Module):
                 wi = torch.where(self.slot_j_ego & ~self.slot_i_ego, rew1[self.slot_i_ne.clamp(min=0)], one)
                 wj = torch.where(self.slot_i_ego & ~self.slot_j_ego, rew1[self.slot_j_ne.clamp(min=0)], one)
                 pw = torch.where(self.slot_j_ego, wi, wj)
-                m = cmask & self.slot_ego.view(1, -1)
-                plan_l = torch.Tensor([0.0]).to(dev) if torch.sum(m) == 0 else (pen * pw.view(1, -1))[m]
+                m_plan = cmask & self.slot_ego.view(1, -1)
+                plan_l = (pen * pw.view(1, -1), m_plan)
 
         env_l = None
         if w.get('coll_env', 0.0) > 0.0:
-            env_l = self.env_coll_loss(fine[~self.ego_mask])
+            env_l = self.env_coll_loss.valid_penalties(fine.index_select(0, self.nonego_idx))
         init_l = None
         if w.get('init_z', 0.0) > 0.0:
             coeff = rew * w['init_z'] + (1.0 - rew) * w['init_z_atk']
             init_l = torch.sum(torch.sum((self.init_z - z) ** 2, dim=1) * coeff)
 
         loss = 0.0
-        out = {}
+        out = LossDict()
         if init_l is not None:
             loss = loss + init_l.mean()
             out['init_loss'] = init_l
         if prior_l is not None:
             loss = loss + prior_l.mean()
             out['motion_prior_loss'] = prior_l
+        # the three collision terms are means over the entries currently in collision ([0.] if none): formed as masked
+        # sums / counts on the device; the compacted lists themselves are produced only if somebody reads them
         if veh_l is not None:
-            loss = loss + w['coll_veh'] * veh_l.mean()
-            out['coll_veh_loss'] = veh_l
+            loss = loss + w['coll_veh'] * _masked_mean(*veh_l)
+            out.set_lazy('coll_veh_loss', lambda: _compact_or_zero(*veh_l))
         if plan_l is not None:
-            loss = loss + w['coll_veh_plan'] * plan_l.mean()
-            out['coll_veh_plan_loss'] = plan_l
+            loss = loss + w['coll_veh_plan'] * _masked_mean(*plan_l)
+            out.set_lazy('coll_veh_plan_loss', lambda: _compact_or_zero(*plan_l))
         if env_l is not None:
-            loss = loss + w['coll_env'] * env_l.mean()
-            out['coll_env_loss'] = env_l
+            loss = loss + w['coll_env'] * _masked_mean(*env_l)
+            out.set_lazy('coll_env_loss', lambda: _compact_or_zero(*env_l))
         if crash is not None:
             loss = loss + w['adv_crash'] * crash.mean()
             out['adv_crash_loss'] = crash

@@ -125,6 +125,7 @@ class SceneInfo(object):
         self.ptr = ptr.to(device)
         self.ptr_cpu = ptr.cpu().clone()
         self.ei_sig = None
+        self.ptr_sig = None
         self.sizes = (ptr[1:] - ptr[:-1]).cpu()
         self.B = int(self.sizes.shape[0])
         self.NA = int(ptr[-1])
@@ -166,12 +167,20 @@ def scene_info(scene_graph):
     ptr = scene_graph.ptr
     cached = scene_graph.__dict__.get('_strive_scene_info')
     ei = scene_graph.edge_index if 'edge_index' in scene_graph else None
+    # identity + in-place version of the two structure tensors: a cheap check that never touches the device (comparing
+    # ptr by value would be a device->host copy, i.e. a synchronisation, on every rollout).  Re-collated or edited graphs
+    # carry new tensors / bumped versions and are re-validated.
     ei_sig = None if ei is None else (ei.data_ptr(), ei._version, tuple(ei.shape))
+    ptr_sig = (ptr.data_ptr(), ptr._version, tuple(ptr.shape))
+    if cached is not None and cached.device == scene_graph.past.device and cached.ei_sig == ei_sig and cached.ptr_sig == ptr_sig:
+        return cached
     if cached is not None and cached.device == scene_graph.past.device and cached.ei_sig == ei_sig and \
             cached.ptr_cpu.shape == ptr.shape and torch.equal(cached.ptr_cpu, ptr.cpu()):
+        cached.ptr_sig = ptr_sig          # same offsets in a new tensor
         return cached
     info = SceneInfo(ptr.cpu(), scene_graph.past.device)
     info.ei_sig = ei_sig
+    info.ptr_sig = ptr_sig
     if 'edge_index' in scene_graph:
         ei = scene_graph.edge_index.cpu()
         exp = _expected_clique_keys(ptr.cpu(), info.NA)
@@ -444,6 +453,20 @@ def encode_traj(model, encoder, g, traj, vis):
     return encoder(enc_in.detach())
 
 
+_lin_tables = {}
+
+
+def _linspace_pair(gl, gw, dev):
+    """the two fp32 linspace(-1, 1, .) tables of get_coll_point, uploaded once per (size, device): a host->device copy per
+    call would make the host wait for the stream to drain"""
+    key = (gl, gw, str(dev))
+    t = _lin_tables.get(key)
+    if t is None:
+        t = (torch.linspace(-1.0, 1.0, gl).to(dev), torch.linspace(-1.0, 1.0, gw).to(dev))
+        _lin_tables[key] = t
+    return t
+
+
 def coll_point(map_env, cars, lw, mapixes, gl, gw):
     """get_coll_point on layer 0: (N,2) collision points (NaN = none / fully off) and off-pixel counts."""
     lib = _lib_for(cars)
@@ -452,8 +475,7 @@ def coll_point(map_env, cars, lw, mapixes, gl, gw):
     N = cars.shape[0]
     pt = torch.empty((N, 2), dtype=torch.float32, device=dev)
     cnt = torch.empty((N,), dtype=torch.int32, device=dev)
-    lin_l = torch.linspace(-1.0, 1.0, gl).to(dev)
-    lin_w = torch.linspace(-1.0, 1.0, gw).to(dev)
+    lin_l, lin_w = _linspace_pair(int(gl), int(gw), dev)
     lib.call('strive_coll_point', pk.ref(), L.ptr(_f32c(cars)), L.ptr(_f32c(lw)), L.ptr(mapixes.to(torch.int32).contiguous()),
              N, int(gl), int(gw), L.ptr(lin_l), L.ptr(lin_w), L.ptr(pt), L.ptr(cnt), _stream(cars))
     return pt, cnt

@@ -5,19 +5,32 @@ import torch
 import torch.optim as optim
 
 
+def _collate_index(scene_graph, device):
+    """Row of cat([tgt_z, other_z]) that belongs to each agent of the batched graph (ego first in every scene); built once
+    per graph and device (boolean-mask assignment synchronises with the host, the loops call this twice per closure)."""
+    ptr = scene_graph.ptr
+    cache = scene_graph.__dict__.get('_strive_collate')
+    sig = (str(device), ptr.data_ptr(), ptr._version, tuple(ptr.shape))     # identity check: no device->host copy per call
+    if cache is not None and cache[0] == sig:
+        return cache[2], cache[3], cache[4]
+    B = ptr.shape[0] - 1
+    NA = int(ptr[-1])
+    ego = ptr[:-1].to(device)
+    is_ego = torch.zeros((NA,), dtype=torch.bool, device=device)
+    is_ego[ego] = True
+    src = torch.empty((NA,), dtype=torch.long, device=device)
+    src[is_ego] = torch.arange(B, device=device)
+    src[~is_ego] = torch.arange(NA - B, device=device) + B
+    ego_idx = torch.nonzero(is_ego).flatten()
+    other_idx = torch.nonzero(~is_ego).flatten()
+    scene_graph.__dict__['_strive_collate'] = (sig, None, src, ego_idx, other_idx)
+    return src, ego_idx, other_idx
+
+
 def collate_tgt_other_z(scene_graph, tgt_z, other_z):
     """Interleave ego latents (B,[NS,]D) and the others' (NA-B,[NS,]D) into graph order (reference :19-36),
     as one index_select instead of a per-scene concatenation loop."""
-    ptr = scene_graph.ptr
-    B = tgt_z.size(0)
-    NA = int(ptr[-1])
-    dev = other_z.device
-    ego = ptr[:-1].to(dev)
-    is_ego = torch.zeros((NA,), dtype=torch.bool, device=dev)
-    is_ego[ego] = True
-    src = torch.empty((NA,), dtype=torch.long, device=dev)
-    src[is_ego] = torch.arange(B, device=dev)
-    src[~is_ego] = torch.arange(NA - B, device=dev) + B
+    src, _, _ = _collate_index(scene_graph, other_z.device)
     return torch.cat([tgt_z, other_z], dim=0).index_select(0, src)
 
 
@@ -37,6 +50,7 @@ class AdvClosure(object):
         self.ego_inds = scene_graph.ptr[:-1].to(dev)
         self.ego_mask = torch.zeros((NA,), dtype=torch.bool, device=dev)
         self.ego_mask[self.ego_inds] = True
+        _, self.ego_idx, self.other_idx = _collate_index(scene_graph, dev)
         if attack_agt_idx is not None:
             attack_agt_idx = torch.as_tensor(attack_agt_idx).to(self.ego_inds) + self.ego_inds
         self.attack_agt_idx = attack_agt_idx
@@ -71,15 +85,16 @@ class AdvClosure(object):
                                    nfuture=self.future_len)
         out_b = m.decode_embedding(z_b, self.embed_info, g, self.map_idx, self.map_env, ext_future=self.planner_fut,
                                    nfuture=self.future_len)
-        lt = self.tgt_loss(self.unn(out_a['future_pred'][self.ego_mask]), self.unn(self.planner_fut), self.tgt_z,
+        lt = self.tgt_loss(self.unn(out_a['future_pred'].index_select(0, self.ego_idx)), self.unn(self.planner_fut), self.tgt_z,
                            self.tgt_prior)
         la = self.adv_loss(self.unn(out_b['future_pred']), self.unn(self.planner_fut), self.other_z, self.other_prior,
                            attack_agt_idx=self.attack_agt_idx)
-        loss_dict = {'tgt_match_' + k: v for k, v in lt.items()}
-        loss_dict.update({'adv_' + k: v for k, v in la.items()})
-        loss = loss_dict['tgt_match_loss'] + loss_dict['adv_loss']
+        loss = lt['loss'] + la['loss']
         loss.backward()
         if log is not None:
+            # (reading the dict entries compacts the collision lists = host synchronisations: only when somebody looks)
+            loss_dict = {'tgt_match_' + k: v for k, v in lt.items()}
+            loss_dict.update({'adv_' + k: v for k, v in la.items()})
             log(loss_dict, self.tgt_z, self.other_z)
         self.optim.step()
         return loss

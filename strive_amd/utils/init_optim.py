@@ -8,7 +8,8 @@ import torch.optim as optim
 def run_init_optim(cur_z, init_traj, traj_vis, lr, loss_weights, model, scene_graph, map_env, map_idx, num_iters,
                    embed_info, prior_distrib, log=None):
     from ..losses.adv_gen_nusc import TgtMatchingLoss
-    init_traj = model.get_normalizer().unnormalize(init_traj)[traj_vis == 1.0]
+    vis_idx = torch.nonzero((traj_vis == 1.0).reshape(-1)).flatten()        # once: x[mask] would synchronise every iteration
+    init_traj = model.get_normalizer().unnormalize(init_traj).reshape(-1, init_traj.size(-1)).index_select(0, vis_idx)
     cur_z = cur_z.clone().detach()
     cur_z.requires_grad = True
     init_optim = optim.Adam([cur_z], lr=lr)
@@ -16,7 +17,7 @@ def run_init_optim(cur_z, init_traj, traj_vis, lr, loss_weights, model, scene_gr
     for _ in range(num_iters):
         init_optim.zero_grad()
         pred = model.decode_embedding(cur_z, embed_info, scene_graph, map_idx, map_env)['future_pred']
-        pred = model.get_normalizer().unnormalize(pred)[traj_vis == 1.0]
+        pred = model.get_normalizer().unnormalize(pred).reshape(-1, pred.size(-1)).index_select(0, vis_idx)
         loss_dict = match_loss(pred, init_traj, cur_z, prior_distrib)
         loss_dict['loss'].backward()
         if log is not None:

@@ -2,7 +2,7 @@
 import torch
 import torch.optim as optim
 
-from .adv_gen_optim import collate_tgt_other_z
+from .adv_gen_optim import collate_tgt_other_z, _collate_index
 
 
 def run_find_solution_optim(cur_z, final_result_traj, future_len, lr, loss_weights, model, scene_graph, map_env,
@@ -21,6 +21,7 @@ def run_find_solution_optim(cur_z, final_result_traj, future_len, lr, loss_weigh
     other_z_all = cur_z[~tgt_mask].view(NA - B, 1, -1).clone().detach()
     other_z_all.requires_grad = True
     sol_optim = optim.Adam([tgt_z, other_z_all], lr=lr)
+    _, _, other_idx = _collate_index(scene_graph, dev)
     w = {k[4:]: v for k, v in loss_weights.items() if k[:4] == 'sol_'}
     avoid_loss = AvoidCollLoss(w, model.get_att_normalizer().unnormalize(scene_graph.lw), map_idx[scene_graph.batch],
                                map_env, tgt_z.clone().detach(), veh_coll_buffer=0.5, single_veh_idx=0, ptr=scene_graph.ptr)
@@ -33,12 +34,12 @@ def run_find_solution_optim(cur_z, final_result_traj, future_len, lr, loss_weigh
         out_b = model.decode_embedding(z_b, embed_info, scene_graph, map_idx, map_env)
         tgt_pred = unn(out_a['future_pred']).transpose(0, 1).reshape(NA, future_len, 4)
         lt = avoid_loss(tgt_pred, tgt_z, tgt_prior_distrib)
-        loss_dict = {'tgt_' + k: v for k, v in lt.items()}
-        lo = match_loss(unn(out_b['future_pred'])[~tgt_mask], other_match, other_z_all, other_prior_distrib)
-        loss_dict.update({'other_' + k: v for k, v in lo.items()})
-        loss = loss_dict['tgt_loss'] + loss_dict['other_loss']
+        lo = match_loss(unn(out_b['future_pred']).index_select(0, other_idx), other_match, other_z_all, other_prior_distrib)
+        loss = lt['loss'] + lo['loss']
         loss.backward()
         if log is not None:
+            loss_dict = {'tgt_' + k: v for k, v in lt.items()}
+            loss_dict.update({'other_' + k: v for k, v in lo.items()})
             log(loss_dict, tgt_z, other_z_all)
         sol_optim.step()
     cur_z = collate_tgt_other_z(scene_graph, tgt_z, other_z_all)
