@@ -1,0 +1,22 @@
+# rocprofv3 evidence for round 2 (run on the GPU box through gpurun): kernel trace + separate PMC passes
+set -x
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r02prof
+rm -rf $O; mkdir -p $O
+B="python bench.py --no-cpu-baseline --no-roofline"
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/kt -- $B --steps 7 --warmup 2 > $O/kt.log 2>&1
+DB=$(find $O/kt -name "*.db" | head -1)
+python profiles/summarize_rocpd.py $DB > $O/kernel_stats.txt 2>&1
+python profiles/gap_report.py $DB 5 rollout_init_kernel 2 > $O/gaps.txt 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B --steps 2 --warmup 1 > $O/fetch.log 2>&1
+python profiles/summarize_pmc.py $(find $O/fetch -name "*counter_collection.csv" | head -1) > $O/pmc_fetch_size.txt 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B --steps 2 --warmup 1 > $O/write.log 2>&1
+python profiles/summarize_pmc.py $(find $O/write -name "*counter_collection.csv" | head -1) > $O/pmc_write_size.txt 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/sq -- $B --steps 1 --warmup 1 > $O/sq.log 2>&1
+python profiles/summarize_pmc.py $(find $O/sq -name "*counter_collection.csv" | head -1) > $O/pmc_sq_waits.txt 2>&1
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d $O/sq2 -- $B --steps 1 --warmup 1 > $O/sq2.log 2>&1
+python profiles/summarize_pmc.py $(find $O/sq2 -name "*counter_collection.csv" | head -1) > $O/pmc_sq_mfma.txt 2>&1
+find $O -type f -size +1M -delete
+python bench.py > $O/bench_line.json 2> $O/bench.err
+tail -c 400 $O/bench_line.json
