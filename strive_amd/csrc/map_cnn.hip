@@ -605,18 +605,18 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
 // channels of a pass for all S samples staged together ([piece][sample][row][parity][column/2][8 x bf16]); GroupNorm
 // scale / shift per (sample, channel); output statistics per sample reduced in pixel order through LDS.
 // =============================================================================================
-template <int CIN_, int COUT_, int IH_, int OH_, int S_, int NPART_IN_, bool OUT_OCT_, int PT_ = 2>
+template <int CIN_, int COUT_, int IH_, int OH_, int S_, int NPART_IN_, bool OUT_OCT_, int PT_ = 2, int CBW_ = 1>
 struct BfsCfg {
     static constexpr int CIN = CIN_, COUT = COUT_, KS = 3, IH = IH_, OH = OH_, S = S_, NPART_IN = NPART_IN_;
     static constexpr bool OUT_OCT = OUT_OCT_;
     static constexpr int NT = 256, NW = 4, PT = PT_;
     static constexpr int PPS = OH * OH, NPIX = S * PPS;                    // pixels per sample / per workgroup
-    static constexpr int COUT_WG = 32, CSPLIT = COUT / COUT_WG;
+    static constexpr int CBW = CBW_, COUT_WG = 32 * CBW, CSPLIT = COUT / COUT_WG;      // CBW 32-channel blocks from one staging
     static constexpr int PASS_CH = 8, NPASS = CIN / PASS_CH;
     static constexpr int HW = (IH + 1) / 2, HALF_B = HW * 16, ROW_B = 2 * HALF_B, SAMPLE_B = IH * ROW_B, PIECE_B = S * SAMPLE_B;
     static constexpr int IN_B = (2 * PIECE_B + 255) / 256 * 256;
     static constexpr int NKS = (KS * KS + 1) / 2;
-    static constexpr int WSTEP_B = 2 * 64 * 16;
+    static constexpr int WSTEP_B = CBW * 2 * 64 * 16;
     static constexpr int NPART_OUT = CSPLIT;
     static constexpr int UNITS = S * IH * IH, UITERS = (UNITS + NT - 1) / NT;
     static constexpr size_t LDS_BYTES = (size_t)IN_B + 3 * WSTEP_B + (size_t)CIN * 8 + S * 8 + 16;
@@ -625,6 +625,7 @@ struct BfsCfg {
     static_assert(CIN % PASS_CH == 0 && COUT % COUT_WG == 0, "channel tiling");
     static_assert(LDS_BYTES * 2 <= 160 * 1024, "two workgroups per CU");
     static_assert(2 * (OH - 1) + KS <= IH, "valid convolution");
+    static_assert(WSTEP_B / 16 <= NT, "one 16-byte weight piece per thread and matrix step");
 };
 
 template <class Cfg>
@@ -665,9 +666,6 @@ __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6s_kernel(const float* __re
         }
     };
     issue_loads(0);
-    float4 bias4[4];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) bias4[rg] = *reinterpret_cast<const float4*>(bias + cb * Cfg::COUT_WG + 8 * rg + 4 * h);
 
     // ---- GroupNorm moments per sample (partials added in slot order), then scale / shift per (sample, channel) ----
     if (tid < S) {
@@ -695,15 +693,18 @@ __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6s_kernel(const float* __re
         pix_q[i] = q;
         lane_base[i] = a * Cfg::SAMPLE_B + (2 * oy) * Cfg::ROW_B + ox * 16;
     }
-    f32x16 acc[PT];
+    constexpr int CBW = Cfg::CBW;
+    f32x16 acc[CBW][PT];
 #pragma unroll
-    for (int i = 0; i < PT; ++i)
+    for (int c = 0; c < CBW; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int i = 0; i < PT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
 
     const uint4* wsrc = reinterpret_cast<const uint4*>(wfrag);
     constexpr int WQ = Cfg::WSTEP_B / 16;
-    auto wstep_src = [&](int pass, int s) { return wsrc + ((size_t)(pass * Cfg::NKS + s) * Cfg::CSPLIT + cb) * WQ; };
+    auto wstep_src = [&](int pass, int s) { return wsrc + ((size_t)(pass * Cfg::NKS + s) * (COUT / 32) + cb * CBW) * 128; };
     const bool wmover = tid < WQ;
 
     for (int pass = 0; pass < Cfg::NPASS; ++pass) {
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6s_kernel(const float* __re
         __syncthreads();
         if (pass + 1 < Cfg::NPASS) issue_loads(pass + 1);
 
-        f16x8 fa[2][2], fb[2][PT][2];
+        f16x8 fa[2][CBW][2], fb[2][PT][2];
         auto load_frags = [&](int t, int set) {       // 3x3 tap order of conv_bf6_kernel
             int ky, kx;
             if (t < 3) { ky = t; kx = 2 * h; }
@@ -761,7 +762,9 @@ __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6s_kernel(const float* __re
             const int off = ky * Cfg::ROW_B + (kx & 1) * Cfg::HALF_B + (kx >> 1) * 16;
             const unsigned char* wb = s_w + (t % 3) * Cfg::WSTEP_B + lane * 16;
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) fa[set][pl] = *reinterpret_cast<const f16x8*>(wb + pl * 1024);
+            for (int c = 0; c < CBW; ++c)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) fa[set][c][pl] = *reinterpret_cast<const f16x8*>(wb + (c * 2 + pl) * 1024);
 #pragma unroll
             for (int i = 0; i < PT; ++i)
 #pragma unroll
@@ -777,10 +780,12 @@ __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6s_kernel(const float* __re
 #pragma unroll
             for (int term = 0; term < 3; ++term)
 #pragma unroll
-                for (int i = 0; i < PT; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][TA[term]], fb[cur][i][TB[term]], acc[i], 0, 0, 0);
+                for (int c = 0; c < CBW; ++c)
+#pragma unroll
+                    for (int i = 0; i < PT; ++i)
+                        acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][c][TA[term]], fb[cur][i][TB[term]], acc[c][i], 0, 0, 0);
             if (s + 1 < Cfg::NKS) {
-                constexpr int NRD = 2 + 2 * PT, NMF = 3 * PT;
+                constexpr int NRD = 2 * CBW + 2 * PT, NMF = 3 * PT * CBW;
 #pragma unroll
                 for (int q = 0; q < (NRD < NMF ? NRD : NMF); ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -804,26 +809,29 @@ __global__ __launch_bounds__(Cfg::NT, 2) void conv_bf6s_kernel(const float* __re
         const int n = n0 + (a < 0 ? 0 : a);
         float fsum = 0.f, fsq = 0.f;
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int co = cb * Cfg::COUT_WG + 8 * rg + 4 * h;
-            const float4 bv = bias4[rg];
-            float4 v;
-            v.x = fmaf(acc[i][4 * rg + 0], unscale, bv.x);     // unscale = 2^-k exactly: one rounding, like acc + bias
-            v.y = fmaf(acc[i][4 * rg + 1], unscale, bv.y);
-            v.z = fmaf(acc[i][4 * rg + 2], unscale, bv.z);
-            v.w = fmaf(acc[i][4 * rg + 3], unscale, bv.w);
-            if (valid) {
-                if (Cfg::OUT_OCT) {
-                    *reinterpret_cast<float4*>(out + (((size_t)n * (COUT / 8) + (co >> 3)) * Cfg::PPS + q) * 8 + (co & 7)) = v;
-                } else {
-                    float* o = out + ((size_t)n * COUT + co) * Cfg::PPS + q;
-                    o[0] = v.x;
-                    o[(size_t)Cfg::PPS] = v.y;
-                    o[(size_t)2 * Cfg::PPS] = v.z;
-                    o[(size_t)3 * Cfg::PPS] = v.w;
+        for (int c = 0; c < CBW; ++c) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int co = (cb * CBW + c) * 32 + 8 * rg + 4 * h;
+                const float4 bv = *reinterpret_cast<const float4*>(bias + co);
+                float4 v;
+                v.x = fmaf(acc[c][i][4 * rg + 0], unscale, bv.x);     // unscale = 2^-k exactly: one rounding, like acc + bias
+                v.y = fmaf(acc[c][i][4 * rg + 1], unscale, bv.y);
+                v.z = fmaf(acc[c][i][4 * rg + 2], unscale, bv.z);
+                v.w = fmaf(acc[c][i][4 * rg + 3], unscale, bv.w);
+                if (valid) {
+                    if (Cfg::OUT_OCT) {
+                        *reinterpret_cast<float4*>(out + (((size_t)n * (COUT / 8) + (co >> 3)) * Cfg::PPS + q) * 8 + (co & 7)) = v;
+                    } else {
+                        float* o = out + ((size_t)n * COUT + co) * Cfg::PPS + q;
+                        o[0] = v.x;
+                        o[(size_t)Cfg::PPS] = v.y;
+                        o[(size_t)2 * Cfg::PPS] = v.z;
+                        o[(size_t)3 * Cfg::PPS] = v.w;
+                    }
+                    fsum += (v.x + v.y) + (v.z + v.w);
+                    fsq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fsq))));
                 }
-                fsum += (v.x + v.y) + (v.z + v.w);
-                fsq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fsq))));
             }
         }
         // slot = (linear pixel, channel half): the per-sample reduction below walks them in a fixed order
@@ -863,9 +871,9 @@ static int launch_bf6s(const float* in, const GNStats* st_in, const float* g, co
 typedef BfCfg<16, 32, 5, 125, 61, l1b::NPART, true> Bf2;     // conv2: octet-planar in and out
 typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, true, 2, 2, false, 2> Bf3;   // conv3: octet-planar in and out; both 32-channel blocks from one staging
 // conv4 (3x3, 29 -> 14): the whole 14 x 14 image is one workgroup tile of 16 x 16 (pixel tiles of 2 rows x 16 columns);
-typedef BfCfg<64, 64, 3, 29, 14, Bf3::NPART_OUT, true, 2, 2, true> Bf4;
-typedef BfsCfg<64, 128, 14, 6, 7, Bf4::NPART_OUT, true> Bfs5;       // conv5: 7 samples (252 pixels) x 32 channels per workgroup
-typedef BfsCfg<128, 128, 6, 2, 32, Bfs5::NPART_OUT, false, 1> Bfs6;  // conv6: 32 samples (128 pixels) x 32 channels per workgroup; NCHW out (fc)
+typedef BfCfg<64, 64, 3, 29, 14, Bf3::NPART_OUT, true, 2, 2, true, 2> Bf4;
+typedef BfsCfg<64, 128, 14, 6, 7, Bf4::NPART_OUT, true, 2, 2> Bfs5;       // conv5: 7 samples (252 pixels) x 32 channels per workgroup
+typedef BfsCfg<128, 128, 6, 2, 32, Bfs5::NPART_OUT, false, 1, 2> Bfs6;  // conv6: 32 samples (128 pixels) x 32 channels per workgroup; NCHW out (fc)
 
 template <class Cfg>
 static int launch_bf6(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
