@@ -868,7 +868,7 @@ static int launch_bf6s(const float* in, const GNStats* st_in, const float* g, co
     return 0;
 }
 
-typedef BfCfg<16, 32, 5, 125, 61, l1b::NPART, true> Bf2;     // conv2: octet-planar in and out
+typedef BfCfg<16, 32, 5, 125, 61, l1b::NPART, true, 2, 3> Bf2;     // conv2: octet-planar in and out
 typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, true, 2, 2, false, 2> Bf3;   // conv3: octet-planar in and out; both 32-channel blocks from one staging
 // conv4 (3x3, 29 -> 14): the whole 14 x 14 image is one workgroup tile of 16 x 16 (pixel tiles of 2 rows x 16 columns);
 typedef BfCfg<64, 64, 3, 29, 14, Bf3::NPART_OUT, true, 2, 2, true, 2> Bf4;
