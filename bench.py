@@ -14,6 +14,10 @@ step.  Workloads (``--workload``):
   sharded4096  (configs[4]) ONE batch of ~4096 agents with NC = 5 classes (reduce_cats), split over the ranks by
                strive_amd.distributed.shard_scenes; every rank runs the adversarial closure on its scenes.  The job is
                fixed, so this is strong scaling.
+  train        (configs[3]) one training step of train_traffic.cfg (reference src/train_traffic.py:103-131): batch of 4
+               scenes x 16 agents per GPU, TrafficModel.forward(future_sample=True) = posterior-sample + prior-sample rollout,
+               TrafficModelLoss, backward to all 174 parameter tensors, flat-bucket gradient all-reduce (RCCL) with the skip
+               vote, Adam(lr 1e-5); advances 2*NA*FT agent*timesteps.  Weak scaling (data parallel).
 
 ``python bench.py --gpus N`` launches the N ranks itself (re-executing under torch.distributed.run on 127.0.0.1) when it
 was not started by a launcher; under a launcher (WORLD_SIZE set) it is one rank of the job.
@@ -97,6 +101,10 @@ def workload_scenes(args, rank, world):
         sizes = variable_scene_sizes(args.total_agents or 512, 'bench/adv/r%d' % rank)
         own = [(n, 'bench/adv/r%d/%d' % (rank, b)) for b, n in enumerate(sizes)]
         return own, '%d agents per GPU in %d scenes of 2..30' % (sum(sizes), len(sizes)), 'weak'
+    if args.workload == 'train':
+        nsc = 4 if args.scenes == 32 else args.scenes          # train_traffic.cfg: batch_size 4 (scenes per GPU)
+        own = [(args.agents, 'bench/train/r%d/%d' % (rank, b)) for b in range(nsc)]
+        return own, '%d scenes x %d agents per GPU' % (nsc, args.agents), 'weak'
     from strive_amd.distributed import shard_scenes
     sizes = variable_scene_sizes(args.total_agents or 4096, 'bench/sharded')
     part = shard_scenes(sizes, world)
@@ -173,6 +181,27 @@ def adv_closure_factory(m, env, batch, map_idx, FT, device):
                    (pm[~ego], pv[~ego]), 2, 0.0, planner_fut=g.future_gt[ego][:, :FT, :4].contiguous(), future_len=FT,
                    veh_coll_buffer=0.1)
     return (lambda: c.step()), emb, g, mi, 2
+
+
+TRAIN_WEIGHTS = {'recon': 1.0, 'kl': 0.004, 'coll_veh_prior': 0.05, 'coll_env_prior': 0.1}      # train_traffic.cfg:17-21
+
+
+def train_step_factory(m, env, batch, map_idx, FT, device):
+    """reference src/train_traffic.py:103-131 through strive_amd.distributed.DataParallelTrainer (one rank = plain step)."""
+    from strive_amd.distributed import DataParallelTrainer
+    from strive_amd.losses.traffic_model import TrafficModelLoss
+    g = batch.to(device)
+    mi = map_idx.to(device)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-5)
+    tr = DataParallelTrainer(m, TrafficModelLoss(TRAIN_WEIGHTS, m.get_normalizer(), m.get_att_normalizer()), opt)
+
+    def step():
+        out = tr.step(g, mi, env)
+        if out is None:
+            raise RuntimeError('training step was skipped: %r' % (tr.last_error,))
+        return out['global_loss'][0]
+    return step, None, g, mi, 2
 
 
 # ------------------------------------------------------------------------------------------------
@@ -398,7 +427,7 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', choices=['refine', 'adv', 'sharded4096'], default='refine')
+    ap.add_argument('--workload', choices=['refine', 'adv', 'sharded4096', 'train'], default='refine')
     ap.add_argument('--scenes', type=int, default=32)
     ap.add_argument('--agents', type=int, default=16)
     ap.add_argument('--total-agents', type=int, default=0, help='adv / sharded4096: agents in the batch (default 512 / 4096)')
@@ -453,7 +482,7 @@ def main():
     m = build_model(device, args.nc)
     env = build_env(args.raster, device)
     batch, map_idx = build_batch(own, args.nc, args.raster)
-    factory = refine_closure_factory if args.workload == 'refine' else adv_closure_factory
+    factory = {'refine': refine_closure_factory, 'train': train_step_factory}.get(args.workload, adv_closure_factory)
     step, emb, g, mi, rollouts = factory(m, env, batch, map_idx, args.ft, device)
     for _ in range(args.warmup):
         step()
@@ -488,8 +517,11 @@ def main():
                'adv': 'adversarial closure: 2 x decode_embedding(nfuture=%d, ext_future) with complementary detach + '
                       'TgtMatchingLoss + AdvGenLoss + backward + Adam',
                'sharded4096': 'adversarial closure: 2 x decode_embedding(nfuture=%d, ext_future) + TgtMatchingLoss + '
-                              'AdvGenLoss + backward + Adam'}[args.workload] % args.ft
-    cfg_ref = {'refine': 'BASELINE.json configs[1]', 'adv': 'BASELINE.json configs[2]', 'sharded4096': 'BASELINE.json configs[4]'}
+                              'AdvGenLoss + backward + Adam',
+               'train': 'training step: TrafficModel.forward(future_sample=True) (2 rollouts of %d steps) + TrafficModelLoss + '
+                        'backward to 174 parameter tensors + gradient all-reduce + Adam'}[args.workload] % args.ft
+    cfg_ref = {'refine': 'BASELINE.json configs[1]', 'adv': 'BASELINE.json configs[2]', 'sharded4096': 'BASELINE.json configs[4]',
+               'train': 'BASELINE.json configs[3]'}
     out = {
         'metric': 'adv-optim agent*timesteps/sec (decoder fwd+bwd)',
         'value': round(units / dt, 1), 'unit': 'agent*timesteps/s', 'n_gpus': world, 'steps': args.steps,
@@ -506,7 +538,7 @@ def main():
     }
     failed = False
     if rank == 0:
-        if not args.no_roofline:
+        if not args.no_roofline and args.workload != 'train':
             try:
                 out['roofline'] = time_dominant_kernel(m, env, g, mi, emb, device)
                 out['roofline']['bandwidth_kernels'].update(time_bandwidth_kernels(m, env, g, mi, device))
@@ -519,7 +551,7 @@ def main():
             except Exception as e:      # keep the headline number, but the run fails
                 out['roofline'] = {'error': repr(e)}
                 failed = True
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload != 'train':
             try:
                 out['cpu_baseline'] = cpu_baseline(args.ft)
             except Exception as e:
