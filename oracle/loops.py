@@ -76,7 +76,7 @@ def init_loop(model, g, map_idx, map_env, embed_info, z_init, init_traj, traj_vi
 
 def adv_loop(model, g, map_idx, map_env, embed_info, z_init, weights, num_iters, lr, tgt_prior, other_prior,
              feasibility_time=0, feasibility_infront_min=None, attack_agt_idx=None, future_len=None,
-             veh_coll_buffer=0.1, trace=None):
+             veh_coll_buffer=0.1, trace=None, planner=None):
     """Adversarial optimisation in open-loop ('ego' planner) mode: the planner trajectory is the
     ego's ground-truth future, injected into both rollouts as ``ext_future``; two rollouts with
     complementary detach so each latent group only sees its own loss.
@@ -99,14 +99,30 @@ def adv_loop(model, g, map_idx, map_env, embed_info, z_init, weights, num_iters,
                  crash_loss_min_time=feasibility_time, crash_loss_min_infront=feasibility_infront_min)
     planner_fut = g.future_gt[ego_mask][:, :, :4]
     unn = model.get_normalizer().unnormalize
+    if planner is not None:
+        # closed loop (reference :90-103, 133-139, planner_name == 'hardcode'): `planner` is any object with the
+        # reference's reset / rollout protocol; it reacts to the current rollout of the other agents in every
+        # iteration, nothing is injected into the decoder and the adversarial loss sees the model's own ego prediction
+        import numpy as np
+        B = ptr.shape[0] - 1
+        planner.reset(unn(g.past_gt[:, -1, :]), model.get_att_normalizer().unnormalize(g.lw), g.batch, B, map_idx)
+        agt_ptr = (ptr - torch.arange(B + 1)).numpy()
+        plan_t = np.linspace(model.dt, model.dt * FT, FT)
     for _ in range(num_iters):
         opt.zero_grad()
         z_a = collate_tgt_other_z(ptr, tgt_z, other_z.clone().detach())
         z_b = collate_tgt_other_z(ptr, tgt_z.clone().detach(), other_z)
-        pa = model.decode_embedding(z_a, embed_info, g, map_idx, map_env, ext_future=planner_fut, nfuture=FT)
-        pb = model.decode_embedding(z_b, embed_info, g, map_idx, map_env, ext_future=planner_fut, nfuture=FT)
+        ext = planner_fut if planner is None else None
+        pa = model.decode_embedding(z_a, embed_info, g, map_idx, map_env, ext_future=ext, nfuture=FT)
+        pb = model.decode_embedding(z_b, embed_info, g, map_idx, map_env, ext_future=ext, nfuture=FT)
+        if planner is not None:
+            agt = unn(pa['future_pred'][~ego_mask]).detach().cpu().numpy()
+            planner_fut = model.get_normalizer().normalize(planner.rollout(agt, plan_t, agt_ptr, plan_t, control_all=False).to(g.future_gt))
+            adv_tgt = pb['future_pred'][ego_mask]
+        else:
+            adv_tgt = planner_fut
         lt = tgt_matching_loss(weights, unn(pa['future_pred'][ego_mask]), unn(planner_fut), tgt_z, tgt_prior)
-        la = adv(unn(pb['future_pred']), unn(planner_fut), other_z, other_prior, attack_agt_idx=attack_agt_idx)
+        la = adv(unn(pb['future_pred']), unn(adv_tgt), other_z, other_prior, attack_agt_idx=attack_agt_idx)
         ld = {'tgt_match_' + k: v for k, v in lt.items()}
         ld.update({'adv_' + k: v for k, v in la.items()})
         loss = ld['tgt_match_loss'] + ld['adv_loss']

@@ -44,6 +44,9 @@ _ALIASES = {
     'datasets.utils': 'strive_amd.datasets.utils',
     'datasets.nuscenes_utils': 'strive_amd.datasets.nuscenes_utils',
     'datasets.map_env': 'strive_amd.datasets.map_env',
+    'planners': 'strive_amd.planners',
+    'planners.planner': 'strive_amd.planners.planner',
+    'planners.hardcode_goalcond_nusc': 'strive_amd.planners.hardcode_goalcond_nusc',
 }
 
 # next to a reference checkout: fully replaced / overlaid / loop modules

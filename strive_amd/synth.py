@@ -96,7 +96,8 @@ class SyntheticMapEnv(object):
     no ``get_map_crop``: the product's TrafficModel reads the raster tensors directly through the HIP
     crop kernel, and the oracle uses its own restatement."""
 
-    def __init__(self, raster, dx, bounds=(-17.0, -38.5, 60.0, 38.5), L=256, W=256):
+    def __init__(self, raster, dx, bounds=(-17.0, -38.5, 60.0, 38.5), L=256, W=256, lane_graph=None):
+        self.lane_graphs = None if lane_graph is None else {'synthetic-%d' % i: lane_graph for i in range(raster.shape[0])}
         self.nusc_raster = raster
         self.nusc_dx = dx
         self.bounds = list(bounds)
@@ -116,8 +117,9 @@ class SyntheticMapEnv(object):
 # --------------------------------------------------------------------------------------------
 
 def make_scene(n, key, PT=4, FT=12, NC=2, map_extent=(256.0, 256.0), dt=0.5, window=120.0,
-               with_future=True):
-    """One scene of ``n`` agents as a :class:`Data` (NORMALISED), ego at node 0."""
+               with_future=True, poses=None):
+    """One scene of ``n`` agents as a :class:`Data` (NORMALISED), ego at node 0.  ``poses`` = (px, py, h, s) arrays
+    override the drawn positions / headings / speeds (e.g. agents placed on a lane graph)."""
     Hm, Wm = map_extent
     cx = counter_uniform((), key + '/cx', 0.35 * Wm, 0.65 * Wm)
     cy = counter_uniform((), key + '/cy', 0.35 * Hm, 0.65 * Hm)
@@ -128,6 +130,9 @@ def make_scene(n, key, PT=4, FT=12, NC=2, map_extent=(256.0, 256.0), dt=0.5, win
     h = counter_uniform((n,), key + '/h', -math.pi, math.pi)
     s = counter_uniform((n,), key + '/s', 0.0, 5.0)
     hdot = counter_uniform((n,), key + '/hd', -0.05, 0.05)
+    if poses is not None:
+        px, py, h, s = [np.asarray(a, dtype=np.float64) for a in poses]
+        hdot = np.zeros((n,))
     T = PT + FT
     ts = (np.arange(T) - (PT - 1)) * dt  # t=0 at last past step
     hh = h[:, None] + hdot[:, None] * ts[None, :]
@@ -224,3 +229,117 @@ def make_latents(prior_mu, prior_var, key='z', scale=0.5):
     src/models/traffic_model.py:706-712, so parity tests always inject z explicitly)."""
     eps = f32(counter_normal(tuple(prior_mu.shape), key)).to(prior_mu.device)
     return prior_mu + scale * torch.sqrt(prior_var) * eps
+
+
+# --------------------------------------------------------------------------------------------
+# lane graph (the rule-based planner's map input)
+# --------------------------------------------------------------------------------------------
+
+def assemble_lane_graph(lanes, outgoing):
+    """Lane polylines + lane-level connectivity -> the lane-graph dict the reference's map environment holds per map
+    (reference src/datasets/nuscenes_utils.py:50-123, built there from the nuScenes devkit): ``xy (n,2)`` node positions,
+    ``in_edges`` / ``out_edges`` (lists of node lists), ``edges (m,5)`` = (x0, y0, unit direction, length) of every directed
+    node pair, ``edgeixes (m,2)`` and ``ee2ix`` {(v0,v1): edge index}.  ``lanes``: list of (k_i, 2) arrays (k_i >= 2);
+    ``outgoing[i]``: ids of the lanes that continue lane i (its last node connects to their first node)."""
+    start, xys = [], []
+    for ln in lanes:
+        start.append(len(xys))
+        xys.extend(np.asarray(ln, dtype=np.float64).tolist())
+    n = len(xys)
+    out_edges = [[] for _ in range(n)]
+    in_edges = [[] for _ in range(n)]
+    for i, ln in enumerate(lanes):
+        for k in range(len(ln) - 1):
+            out_edges[start[i] + k].append(start[i] + k + 1)
+            in_edges[start[i] + k + 1].append(start[i] + k)
+        for j in outgoing[i]:
+            out_edges[start[i] + len(ln) - 1].append(start[j])
+    for i, ln in enumerate(lanes):                 # incoming connections in lane order, like the devkit's connectivity
+        for j in range(len(lanes)):
+            if i in outgoing[j]:
+                in_edges[start[i]].append(start[j] + len(lanes[j]) - 1)
+    xy = np.asarray(xys, dtype=np.float64)
+    edges, edgeixes, ee2ix = [], [], {}
+    for v0 in range(n):
+        for v1 in out_edges[v0]:
+            d = xy[v1] - xy[v0]
+            ln_ = float(np.linalg.norm(d))
+            ee2ix[(v0, v1)] = len(edges)
+            edges.append([xy[v0, 0], xy[v0, 1], d[0] / ln_, d[1] / ln_, ln_])
+            edgeixes.append([v0, v1])
+    return {'xy': xy, 'in_edges': in_edges, 'out_edges': out_edges, 'edges': np.asarray(edges),
+            'edgeixes': np.asarray(edgeixes, dtype=np.int64), 'ee2ix': ee2ix}
+
+
+def make_lane_graph(extent=256.0, period=40.0, centre=9.0, lane_off=3.0, step=2.0):
+    """Lane graph of the synthetic raster (`make_raster`, map 0: roads of width 18 m every 40 m in both directions): one
+    lane per direction on every road, cut into segments at the crossings; at a crossing every arriving segment continues
+    straight (first connection) and turns right (second connection), so node out-degrees of 2 and in-degrees of 2 occur."""
+    cs = [c for c in np.arange(centre, extent, period)]
+    cuts = [0.0] + cs + [extent]            # segment borders along a road: the crossing road centres
+
+    def seg(p0, p1):
+        L = float(np.linalg.norm(np.asarray(p1) - np.asarray(p0)))
+        k = max(2, int(round(L / step)) + 1)
+        t = np.linspace(0.0, 1.0, k)[:, None]
+        return (1 - t) * np.asarray(p0, dtype=np.float64)[None] + t * np.asarray(p1, dtype=np.float64)[None]
+
+    lanes, meta = [], []                     # meta: (orientation 'h'/'v', road index, direction +-1, segment index)
+    for ri, c in enumerate(cs):
+        for d in (+1, -1):
+            for si in range(len(cuts) - 1):
+                a, b = (cuts[si], cuts[si + 1]) if d > 0 else (cuts[si + 1], cuts[si])
+                # keep segment ends 0.5 m away from the crossing centre so that consecutive lanes do not share a point
+                a2 = a + 0.5 * np.sign(b - a)
+                b2 = b - 0.5 * np.sign(b - a)
+                y = c - d * lane_off           # drive on the right: eastbound lane below the centre line
+                lanes.append(seg((a2, y), (b2, y)))
+                meta.append(('h', ri, d, si))
+                x = c + d * lane_off           # northbound lane to the right of the centre line
+                lanes.append(seg((x, a2), (x, b2)))
+                meta.append(('v', ri, d, si))
+    index = {m: i for i, m in enumerate(meta)}
+    nseg = len(cuts) - 1
+    outgoing = [[] for _ in lanes]
+    for i, (o, ri, d, si) in enumerate(meta):
+        nxt = si + 1 if d > 0 else si - 1
+        if 0 <= nxt < nseg:
+            outgoing[i].append(index[(o, ri, d, nxt)])          # straight on
+            # right turn at the crossing this segment ends at: crossing road index = the cut between si and nxt
+            ci = si if d > 0 else si - 1                         # index into cs of that crossing road
+            if 0 <= ci < len(cs):
+                if o == 'h':
+                    # heading +x turns right to -y (southbound, d = -1); heading -x turns right to +y
+                    td = -1 if d > 0 else +1
+                    tseg = ri if td < 0 else ri + 1              # southbound: the segment below road ri; northbound: above
+                    key = ('v', ci, td, tseg)
+                else:
+                    td = +1 if d > 0 else -1                     # heading +y turns right to +x; heading -y to -x
+                    tseg = ri + 1 if td > 0 else ri
+                    key = ('h', ci, td, tseg)
+                if key in index:
+                    outgoing[i].append(index[key])
+    return assemble_lane_graph(lanes, outgoing)
+
+
+def lane_scene_poses(lane_graph, n, key, radius=35.0, centre=(128.0, 128.0)):
+    """(px, py, h, s) of ``n`` agents sitting on lane nodes within ``radius`` of ``centre`` (ego = the node closest to the
+    centre), headed along their lane, speeds 2..8 m/s, no two closer than 6 m."""
+    xy = lane_graph['xy']
+    d = np.linalg.norm(xy - np.asarray(centre)[None], axis=1)
+    cand = [int(i) for i in np.argsort(d) if d[i] <= radius and len(lane_graph['out_edges'][int(i)]) > 0]
+    pick = [cand[0]]
+    order = np.argsort(counter_uniform((len(cand),), key + '/pick'))
+    for k in order:
+        c = cand[int(k)]
+        if len(pick) >= n:
+            break
+        if all(np.linalg.norm(xy[c] - xy[q]) >= 6.0 for q in pick):
+            pick.append(c)
+    assert len(pick) == n, 'not enough lane nodes for %d agents' % n
+    px, py = xy[pick, 0].copy(), xy[pick, 1].copy()
+    nxt = [lane_graph['out_edges'][c][0] for c in pick]
+    hd = xy[nxt] - xy[pick]
+    h = np.arctan2(hd[:, 1], hd[:, 0])
+    s = counter_uniform((n,), key + '/ls', 2.0, 8.0)
+    return px, py, h, s

@@ -96,6 +96,8 @@ def _install_stubs():
     for alias, typ in (('int', int), ('bool', bool), ('float', float)):
         if not hasattr(np, alias):
             setattr(np, alias, typ)
+    if not hasattr(np, 'product'):          # removed in numpy 2 (the planner calls it)
+        np.product = np.prod
 
 
 def import_reference():
@@ -121,6 +123,8 @@ def import_reference():
     R.init_optim = importlib.import_module('utils.init_optim')
     R.adv_optim = importlib.import_module('utils.adv_gen_optim')
     R.sol_optim = importlib.import_module('utils.sol_optim')
+    R.planner_base = importlib.import_module('planners.planner')
+    R.planner = importlib.import_module('planners.hardcode_goalcond_nusc')
     return R
 
 
@@ -667,6 +671,106 @@ def g6_loops(R):
     save('g6_loops.npz', **out)
 
 
+G6H_SIZES = [4, 3]
+G6H_ITERS = 5
+
+
+def g6h_inputs():
+    """Scenes whose agents sit on the synthetic lane graph (so that the rule-based planner has lanes to follow), uniform
+    raster (smooth chain), one map."""
+    lg = synth.make_lane_graph()
+    scenes = []
+    for b, n in enumerate(G6H_SIZES):
+        poses = synth.lane_scene_poses(lg, n, 'g6h/%d' % b, radius=25.0, centre=(128.0 + 40.0 * b, 128.0))
+        scenes.append(synth.make_scene(n, 'g6h/%d' % b, poses=poses))
+    batch = Batch.from_data_list(scenes)
+    map_idx = torch.zeros((len(G6H_SIZES),), dtype=torch.long)
+    raster, dx = loop_rasters('u')
+    return lg, batch, map_idx, raster, dx
+
+
+def g6h_hardcode(R):
+    """The reference's run_adv_gen_optim in CLOSED LOOP against its own rule-based planner (planner_name='hardcode',
+    adv_gen_rule_based.cfg: planner 'hardcode'), 5 iterations: per-iteration latents / gradients / loss entries + results."""
+    import contextlib
+    import io
+    tm, _ = ref_model(R)
+    lg, batch, map_idx, raster, dx = g6h_inputs()
+    env = ref_map_env(R, raster, dx)
+    env.lane_graphs = {m: lg for m in env.map_list}
+    with torch.no_grad():
+        emb = R.scenario_gen.detach_embed_info(tm.embed(batch, map_idx, env))
+    NA = batch.past.shape[0]
+    ego = torch.zeros((NA,), dtype=torch.bool)
+    ego[batch.ptr[:-1]] = True
+    pm, pv = emb['prior_out']
+    tp, op = (pm[ego], pv[ego]), (pm[~ego], pv[~ego])
+    z0 = synth.make_latents(pm, pv, key='g6h/z')
+    planner = R.planner.HardcodeNuscPlanner(env, R.planner_base.PlannerConfig(**R.planner.CONFIG_DICT['default']))
+    out = {}
+    sink = io.StringIO()
+    with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+        with _LoopRecorder(R, {'TgtMatchingLoss': 'tgt_match_', 'AdvGenLoss': 'adv_'}) as rec:
+            z2, fin, _, agt, tt = R.adv_optim.run_adv_gen_optim(z0, LOOP_LR, LOOP_WEIGHTS, tm, batch, env, map_idx, G6H_ITERS, emb,
+                                                                'hardcode', tp, op, 2, 0.0, planner=planner)
+    _store_trace(out, 'h/adv', rec.trace)
+    out['h/adv/z_out'] = npy(z2)
+    out['h/adv/final_result_traj'] = npy(fin)
+    out['h/adv/min_agt'] = np.asarray(agt)
+    out['h/adv/min_t'] = np.asarray(tt)
+    save('g6h_hardcode.npz', **out)
+
+
+G10_SIZES = [5, 3]
+
+
+def g10_inputs():
+    """Two scenes on the synthetic lane graph for the rule-based planner: agents on lane nodes (one moved off every lane,
+    one standing still), unnormalised initial states, constant-velocity futures of the non-ego agents with a NaN tail."""
+    lg = synth.make_lane_graph()
+    states, atts, mask, obs = [], [], [], []
+    t = np.linspace(0.5, 6.0, 12)
+    for b, n in enumerate(G10_SIZES):
+        px, py, h, s = synth.lane_scene_poses(lg, n, 'g10/%d' % b, centre=(128.0 + 40.0 * b, 128.0))
+        if b == 0:
+            px[3] += 9.0; py[3] += 7.0; h[3] += 0.9            # off every lane: constant-heading prediction
+            s[2] = 0.0                                         # parked on its lane
+        lw = np.stack([4.2 + 0.4 * synth.counter_uniform((n,), 'g10/l%d' % b), 1.9 + 0.2 * synth.counter_uniform((n,), 'g10/w%d' % b)], -1)
+        st = np.stack([px, py, np.cos(h), np.sin(h), s, np.zeros(n)], -1)
+        states.append(st); atts.append(lw); mask += [b] * n
+        fut = np.stack([px[1:, None] + s[1:, None] * np.cos(h[1:, None]) * t[None], py[1:, None] + s[1:, None] * np.sin(h[1:, None]) * t[None],
+                        np.broadcast_to(np.cos(h[1:, None]), (n - 1, 12)), np.broadcast_to(np.sin(h[1:, None]), (n - 1, 12))], -1)
+        if b == 1:
+            fut[1, 7:] = np.nan                                # this agent's observations end after 3.5 s
+        obs.append(fut)
+    ptr = np.concatenate([[0], np.cumsum([n - 1 for n in G10_SIZES])])
+    return (lg, synth.f32(np.concatenate(states)), synth.f32(np.concatenate(atts)), torch.tensor(mask), np.concatenate(obs).astype(np.float64),
+            t, ptr)
+
+
+class _LaneEnv(object):
+    def __init__(self, lg, n=1):
+        self.map_list = ['synthetic-%d' % i for i in range(n)]
+        self.lane_graphs = {m: lg for m in self.map_list}
+
+
+def g10_planner(R):
+    """HardcodeNuscPlanner.rollout of the reference (both shipped configurations) on the g10 scenes."""
+    import contextlib
+    import io
+    lg, st, att, mask, obs, t, ptr = g10_inputs()
+    out = {}
+    for name in ('default', 'final_tuned_val_1'):
+        pl = R.planner.HardcodeNuscPlanner(_LaneEnv(lg), R.planner_base.PlannerConfig(**R.planner.CONFIG_DICT[name]))
+        pl.reset(st, att, mask, len(G10_SIZES), torch.zeros((len(G10_SIZES),), dtype=torch.long))
+        with contextlib.redirect_stdout(io.StringIO()):
+            plan = pl.rollout(obs.copy(), t, ptr, t, control_all=False)
+            plan2 = pl.rollout(obs.copy(), t, ptr, t, control_all=False)        # rollouts do not mutate the reset state
+        assert torch.equal(plan, plan2)
+        out['plan_' + name] = plan.numpy()
+    save('g10_planner.npz', **out)
+
+
 def g7_sample(R):
     """sample_batched NS=3 with injected eps + feasibility-style outputs."""
     tm, _ = ref_model(R)
@@ -766,8 +870,8 @@ G8_CASES = [(15.0, 0, 0.0, None, False), (15.0, 2, 0.5, None, True), (25.0, 1, 0
 if __name__ == '__main__':
     torch.set_num_threads(8)
     R = import_reference()
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g4b', 'g5', 'g6', 'g6l', 'g7', 'g8', 'g9']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g4b', 'g5', 'g6', 'g6l', 'g6h', 'g7', 'g8', 'g9', 'g10']
     fns = {'g1': g1_ops, 'g2': g2_crop, 'g3': g3_gnn, 'g4': g4_rollout, 'g5': g5_losses, 'g6': g6_loop, 'g7': g7_sample,
-           'g8': g8_checks, 'g9': g9_wire, 'g6l': g6_loops, 'g4b': g4b_nc5}
+           'g8': g8_checks, 'g9': g9_wire, 'g6l': g6_loops, 'g4b': g4b_nc5, 'g10': g10_planner, 'g6h': g6h_hardcode}
     for w in which:
         fns[w](R)

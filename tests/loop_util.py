@@ -142,3 +142,54 @@ def run_product_loop(name, kind, g, m, n, device, embed_from=None):
         fin = torch.from_numpy(g[kind + '/adv/final_result_traj']).to(device)
         res = run_find_solution_optim(z, fin, 16, mg.LOOP_LR, mg.LOOP_WEIGHTS, m, bg, env, mi, n, emb, tp, op, log=log)
     return trace, res
+
+
+def hardcode_inputs():
+    lg, batch, map_idx, raster, dx = mg.g6h_inputs()
+    return lg, batch, map_idx, raster, dx
+
+
+def run_oracle_hardcode_loop(g, orc, n):
+    """oracle rollouts / losses + THIS package's rule-based planner in closed loop (the oracle itself never imports product
+    code: the planner object is handed to it)"""
+    from oracle import loops
+    from strive_amd.planners.planner import PlannerConfig
+    from strive_amd.planners.hardcode_goalcond_nusc import HardcodeNuscPlanner, CONFIG_DICT
+    lg, batch, map_idx, raster, dx = hardcode_inputs()
+    env = synth.SyntheticMapEnv(raster, dx, lane_graph=lg)
+    with torch.no_grad():
+        emb = orc.embed(batch, map_idx, env)
+    NA = batch.past.shape[0]
+    ego = torch.zeros((NA,), dtype=torch.bool)
+    ego[batch.ptr[:-1]] = True
+    pm, pv = emb['prior_out']
+    z0 = synth.make_latents(pm, pv, key='g6h/z')
+    planner = HardcodeNuscPlanner(env, PlannerConfig(**CONFIG_DICT['default']))
+    trace = []
+    orc.dt = 0.5
+    loops.adv_loop(orc, batch, map_idx, env, emb, z0, mg.LOOP_WEIGHTS, n, mg.LOOP_LR, (pm[ego], pv[ego]), (pm[~ego], pv[~ego]),
+                   feasibility_time=2, feasibility_infront_min=0.0, trace=trace, planner=planner)
+    return trace
+
+
+def run_product_hardcode_loop(g, m, n, device):
+    from strive_amd.utils.adv_gen_optim import run_adv_gen_optim
+    from strive_amd.utils.scenario_gen import detach_embed_info
+    from strive_amd.planners.planner import PlannerConfig
+    from strive_amd.planners.hardcode_goalcond_nusc import HardcodeNuscPlanner, CONFIG_DICT
+    lg, batch, map_idx, raster, dx = hardcode_inputs()
+    env = synth.SyntheticMapEnv(raster.clone(), dx.clone(), lane_graph=lg).to(device)
+    bg = batch.clone().to(device)
+    mi = map_idx.to(device)
+    with torch.no_grad():
+        emb = detach_embed_info(m.embed(bg, mi, env))
+    NA = bg.past.shape[0]
+    ego = torch.zeros((NA,), dtype=torch.bool, device=device)
+    ego[bg.ptr[:-1].to(device)] = True
+    pm, pv = emb['prior_out']
+    z0 = synth.make_latents(pm.cpu(), pv.cpu(), key='g6h/z').to(device)
+    planner = HardcodeNuscPlanner(env, PlannerConfig(**CONFIG_DICT['default']))
+    trace = []
+    res = run_adv_gen_optim(z0, mg.LOOP_LR, mg.LOOP_WEIGHTS, m, bg, env, mi, n, emb, 'hardcode', (pm[ego], pv[ego]), (pm[~ego], pv[~ego]),
+                            2, 0.0, planner=planner, log=trace_logger(trace))
+    return trace, res

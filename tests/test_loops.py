@@ -60,6 +60,17 @@ def test_oracle_loops_match_reference(fixture, sd, kind, name):
         lu.compare_trace(trace, fixture, tag, 1e-6, 1e-7, 1e-6, 1e-7, z_frac=1.0)
 
 
+def test_oracle_closed_loop_with_the_rule_based_planner(sd):
+    """adv_gen_rule_based.cfg's mode (planner 'hardcode'): the oracle's rollouts and losses with THIS package's planner in
+    the loop against the reference's run_adv_gen_optim with ITS planner (fixture g6h): pins the closed-loop plumbing
+    (nothing injected into the decoder, planner reaction as the matching target, own ego prediction as the adversarial
+    target) and the planner inside it."""
+    g = golden('g6h_hardcode.npz')
+    orc = oracle_model(sd)
+    trace = lu.run_oracle_hardcode_loop(g, orc, mg.G6H_ITERS)
+    lu.compare_trace(trace, g, 'h/adv', 1e-5, 1e-6, 1e-4, 1e-5, z_frac=1.0)
+
+
 # ------------------------------------------------------------------------------------------------
 # GPU: the product's loops
 # ------------------------------------------------------------------------------------------------
@@ -118,6 +129,21 @@ def test_product_loops_textured_raster(fixture, model, name):
     w = lu.compare_trace(trace, fixture, tag, 0.15, 5e-2, 10.0, 0.11, z_frac=0.9, report=REPORT)
     print('loop %s: first %s all %s' % (tag, w0, w))
     _dump_report()
+
+
+@pytest.mark.gpu
+def test_product_closed_loop_with_the_rule_based_planner(model):
+    """run_adv_gen_optim(planner_name='hardcode') -- HIP rollouts and losses, host planner -- against the reference's own
+    closed-loop run (fixture g6h, uniform raster, 5 iterations)."""
+    m, _ = model
+    g = golden('g6h_hardcode.npz')
+    trace, res = lu.run_product_hardcode_loop(g, m, mg.G6H_ITERS, DEV)
+    w = lu.compare_trace(trace, g, 'h/adv', 2e-3, 1e-4, 2e-2, 1e-3, z_frac=0.995, report=REPORT)
+    print('loop h/adv (closed loop, rule-based planner): %s' % w)
+    _dump_report()
+    z, fin, _, agt, tt = res
+    assert np.array_equal(np.asarray(agt), g['h/adv/min_agt']) and np.array_equal(np.asarray(tt), g['h/adv/min_t'])
+    assert_close(fin, g['h/adv/final_result_traj'], 0, 2e-3, 'final_result_traj (ego = the reaction of the planner)')
 
 
 @pytest.mark.gpu
