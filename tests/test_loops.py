@@ -169,8 +169,13 @@ def test_refine_loop_uniform_raster_tight(model):
     env_g = synth.SyntheticMapEnv(raster.clone(), dx.clone()).to(DEV)
     _, z_fin, _, _ = refine_traffic_optim(batch.clone().to(DEV), map_idx.to(DEV), env_g, m, mg.REFINE_WEIGHTS, 10, 16, 12, True, 0.05,
                                           z_init=z0.to(DEV), log=lu.trace_logger(trace))
-    # (gradient 3 %: the refine objective has the hard-thresholded collision set; a borderline pair entering it one iteration
-    # earlier or later moves the gradient by ~2 % while losses and latents stay within 0.2 % / 1e-3)
-    w = lu.compare_trace(trace, g, 'r', 2e-3, 1e-4, 3e-2, 1e-3, z_frac=0.995, report=REPORT)
+    # The refine objective divides by the NUMBER of pairs currently in collision: when a borderline pair (penalty ~ 0) is
+    # inside the set in one run and outside in the other, the loss barely moves but every collision gradient is rescaled by
+    # k / (k + 1).  Gradients are therefore compared entry-wise at the iterations where both runs see the same set size (all
+    # but at most two of the ten), losses and latents at every iteration.
+    differ = {it for it in range(10) if trace[it]['coll_veh_loss'].numel() != want[it]['coll_veh_loss'].numel()}
+    print('iterations with a different number of colliding pairs:', sorted(differ))
+    assert len(differ) <= 2
+    w = lu.compare_trace(trace, g, 'r', 2e-3, 1e-4, 2e-2, 1e-3, z_frac=0.995, report=REPORT, grad_skip=differ)
     print('loop refine (uniform): %s' % w)
     _dump_report()
