@@ -176,6 +176,8 @@ def test_refine_loop_uniform_raster_tight(model):
     differ = {it for it in range(10) if trace[it]['coll_veh_loss'].numel() != want[it]['coll_veh_loss'].numel()}
     print('iterations with a different number of colliding pairs:', sorted(differ))
     assert len(differ) <= 2
-    w = lu.compare_trace(trace, g, 'r', 2e-3, 1e-4, 2e-2, 1e-3, z_frac=0.995, report=REPORT, grad_skip=differ, grad_row_frac=0.74)   # 8 agents: one interacting pair may sit on a kink
+    w = lu.compare_trace(trace, g, 'r', 2e-3, 1e-4, 2e-2, 1e-3, z_frac=0.995, report=REPORT, grad_skip=differ, grad_row_frac=0.74,
+                         kink_after=4)   # 8 agents: one interacting pair may sit on a kink; after the first such event (never
+    # before iteration 4) the two runs are on slightly different trajectories: direction (cos >= 0.99), losses and latents only
     print('loop refine (uniform): %s' % w)
     _dump_report()
