@@ -101,8 +101,9 @@ static __global__ __launch_bounds__(256) void edge_bwd_kernel(GNNDev g, GNNGradD
     float dp_acc = 0.f;                  // thread c < 128: sum over sources of d e1[.][c]
     float gfr_acc[4] = {0.f, 0.f, 0.f, 0.f};   // thread 0
     for (int ch = 0; ch < nchunks; ++ch) {
-        const int nv = edge_chunk_setup(g, sc, pos, gb, r, ch, L, s_nan, tid);
-        mlp_forward_lds<RB_EDGE>(g.edge, nullptr, 0, L.pre, L.act, L.m, HLD, true, tid, 256);
+        // the hidden layers' pre-activations come from the forward pass's table when it kept one (no recompute)
+        const int nv = edge_chunk_setup(g, sc, pos, gb, r, ch, L, s_nan, tid, gb.PRE_E);
+        if (!gb.PRE_E) mlp_forward_lds<RB_EDGE>(g.edge, nullptr, 0, L.pre, L.act, L.m, HLD, true, tid, 256);
         // route d(aggregate) to the arg-max edge of every channel
         for (int i = tid; i < RB_EDGE * D; i += 256) {
             const int jr = i / D, c = i - jr * D;
@@ -181,6 +182,8 @@ struct Node1BwdArgs {
     const float* DPJ;
     const float* gpos_tgt;
     const float* sem;       // (NA, NC)   needed for the weight gradients only
+    const float* PRE_IN;    // (R, 2, 128) mlp_in pre-activations kept by the forward pass, or null (then recomputed)
+    const float* X;         // (R, D) node embeddings (needed with PRE_IN for nothing but the weight gradients)
     float* g_pos;           // (R, 4)  out: adjoint of pos
     // adjoint of the node features: any of these may be null
     float* g_full;          // (R, F)  the whole feature row (stand-alone network)
@@ -202,10 +205,19 @@ static __global__ __launch_bounds__(256) void node1_bwd_kernel(GNNDev g, GNNGrad
     float* s_gin = s_gb + RB_NODE * HLD;      // [RB_NODE][in_ld]
     const int tid = threadIdx.x, r0 = blockIdx.x * RB_NODE, NS = sc.NS;
     const int nrows = (a.R - r0) < RB_NODE ? (a.R - r0) : RB_NODE;
-    // forward recompute of mlp_in (pre-activations)
-    gather_features<RB_NODE>(f, r0, a.R, NS, L.in, in_ld, tid, 256);
-    __syncthreads();
-    mlp_forward_lds<RB_NODE>(g.mlp_in, L.in, in_ld, L.pre, L.act, L.xs, xs_ld, false, tid, 256);
+    if (!WG && a.PRE_IN) {
+        // the forward pass kept mlp_in's pre-activations: nothing to recompute (features and x are only needed for the
+        // weight gradients)
+        for (int i = tid; i < RB_NODE * 2 * H; i += 256) {
+            const int rr = i / (2 * H), rem = i - rr * 2 * H, l = rem / H, c = rem - l * H;
+            L.pre[(size_t)l * RB_NODE * HLD + rr * HLD + c] = (r0 + rr < a.R) ? a.PRE_IN[(size_t)(r0 + rr) * 2 * H + rem] : 0.f;
+        }
+    } else {
+        // forward recompute of mlp_in (pre-activations)
+        gather_features<RB_NODE>(f, r0, a.R, NS, L.in, in_ld, tid, 256);
+        __syncthreads();
+        mlp_forward_lds<RB_NODE>(g.mlp_in, L.in, in_ld, L.pre, L.act, L.xs, xs_ld, false, tid, 256);
+    }
     // gather dP, dQ = sum over targets of the per-edge adjoints, and the source-pose adjoint
     for (int i = tid; i < RB_NODE * H; i += 256) {
         const int rr = i / H, c = i - rr * H;

@@ -9,6 +9,10 @@ struct GnnBuffers {
     float* Q;       // (R, 128) source-side partial of edge layer 0
     float* A;       // (R, D)   max-aggregated messages
     int32_t* ARG;   // (R, D)   source row that attained the max (-1: no incoming edge)
+    // optional (null = not kept): pre-LayerNorm outputs of the hidden layers, kept for the backward instead of being
+    // recomputed there (HBM is 288 GB; these are 1 KB per node and 1 KB per edge)
+    float* PRE_IN;  // (R, 2, 128)          mlp_in layers 0, 1
+    float* PRE_E;   // (R * max_n, 2, 128)  edge MLP layers 0, 1; slot = target_row * max_n + local source index
 };
 
 // LDS carve-ups (floats)
@@ -39,6 +43,12 @@ static __global__ __launch_bounds__(256) void gnn_node1_kernel(GNNDev g, int NS,
     gather_features<RB_NODE>(f, r0, R, NS, L.in, in_ld, tid, 256);
     __syncthreads();
     mlp_forward_lds<RB_NODE>(g.mlp_in, L.in, in_ld, L.pre, L.act, L.xs, xs_ld, false, tid, 256);
+    if (gb.PRE_IN) {
+        for (int i = tid; i < RB_NODE * 2 * STRIVE_HID; i += 256) {
+            const int rr = i / (2 * STRIVE_HID), rem = i - rr * 2 * STRIVE_HID, l = rem / STRIVE_HID, c = rem - l * STRIVE_HID;
+            if (r0 + rr < R) gb.PRE_IN[(size_t)(r0 + rr) * 2 * STRIVE_HID + rem] = L.pre[(size_t)l * RB_NODE * HLD + rr * HLD + c];
+        }
+    }
     // append sem, publish x
     for (int i = tid; i < RB_NODE * (xs_ld - D); i += 256) {
         const int rr = i / (xs_ld - D), k = i - rr * (xs_ld - D);
@@ -90,9 +100,11 @@ struct EdgeLds {
 
 // Fill one chunk: source rows, relative poses (NaN -> 0), and the factorised edge layer 0 into pre[0].
 // Returns the number of valid sources in the chunk (block-uniform).
+// `stored` (optional): the PRE_E table a forward pass kept -- then BOTH hidden layers' pre-activations of the chunk are
+// loaded into L.pre and the caller skips the edge MLP forward.
 __device__ __forceinline__ int edge_chunk_setup(const GNNDev& g, const ScenesDev& sc, const float* __restrict__ pos,
                                                 const GnnBuffers& gb, int r, int chunk, EdgeLds& L, unsigned* nanmask_out,
-                                                int tid) {
+                                                int tid, const float* __restrict__ stored = nullptr) {
     const int NS = sc.NS;
     const int a = r / NS, s = r - a * NS;
     const int b = sc.scene_of[a];
@@ -118,6 +130,16 @@ __device__ __forceinline__ int edge_chunk_setup(const GNNDev& g, const ScenesDev
     }
     __syncthreads();
     const int H = STRIVE_HID;
+    if (stored) {
+        for (int i = tid; i < RB_EDGE * 2 * H; i += 256) {
+            const int jr = i / (2 * H), rem = i - jr * 2 * H, l = rem / H, c = rem - l * H;
+            float v = 0.f;
+            if (jr < nv) v = stored[((size_t)r * sc.max_n + (L.src[jr] / NS - lo)) * 2 * H + rem];
+            L.pre[(size_t)l * RB_EDGE * HLD + jr * HLD + c] = v;
+        }
+        __syncthreads();
+        return nv;
+    }
     const float* Wrel = g.edge.wt[0] + (size_t)(2 * g.D + 2 * g.NC) * H;
     for (int i = tid; i < RB_EDGE * H; i += 256) {
         const int jr = i / H, c = i - jr * H;
@@ -150,6 +172,16 @@ static __global__ __launch_bounds__(256) void gnn_edge_kernel(GNNDev g, ScenesDe
     for (int ch = 0; ch < nchunks; ++ch) {
         const int nv = edge_chunk_setup(g, sc, pos, gb, r, ch, L, nullptr, tid);
         mlp_forward_lds<RB_EDGE>(g.edge, nullptr, 0, L.pre, L.act, L.m, HLD, true, tid, 256);
+        if (gb.PRE_E) {
+            const int lo = sc.ptr[b];
+            for (int i = tid; i < RB_EDGE * 2 * STRIVE_HID; i += 256) {
+                const int jr = i / (2 * STRIVE_HID), rem = i - jr * 2 * STRIVE_HID, l = rem / STRIVE_HID, c = rem - l * STRIVE_HID;
+                if (jr < nv) {
+                    const int jl = L.src[jr] / sc.NS - lo;
+                    gb.PRE_E[((size_t)r * sc.max_n + jl) * 2 * STRIVE_HID + rem] = L.pre[(size_t)l * RB_EDGE * HLD + jr * HLD + c];
+                }
+            }
+        }
         if (tid < D) {
             for (int jr = 0; jr < nv; ++jr) {
                 const float v = L.m[jr * HLD + tid];

@@ -131,6 +131,8 @@ extern "C" int strive_gnn_fwd(const StriveGNN* gnn, const StriveScenes* sc, cons
     gb.Q = ar.take<float>((size_t)R * STRIVE_HID);
     gb.A = ar.take<float>((size_t)R * gnn->D);
     gb.ARG = ar.take<int32_t>((size_t)R * gnn->D);
+    gb.PRE_IN = nullptr;
+    gb.PRE_E = nullptr;
     FeatSrc f;
     f.n = 1;
     f.p[0] = x;
@@ -170,6 +172,8 @@ extern "C" int strive_gnn_bwd(const StriveGNN* gnn, const StriveScenes* sc, cons
     gb.Q = ar.take<float>((size_t)R * STRIVE_HID);
     gb.A = ar.take<float>((size_t)R * gnn->D);
     gb.ARG = ar.take<int32_t>((size_t)R * gnn->D);
+    gb.PRE_IN = nullptr;
+    gb.PRE_E = nullptr;
     GnnBwdBuffers bw = gnn_bwd_buffers_take(ar, (size_t)R, gnn->D, sc->max_n);
     float* g_pos = ar.take<float>((size_t)R * 4);
     STRIVE_CHECK_ARG(ar.ok(), "workspace arena overflow");
@@ -192,7 +196,7 @@ extern "C" int strive_gnn_bwd(const StriveGNN* gnn, const StriveScenes* sc, cons
     hipLaunchKernelGGL(edge_bwd_kernel<true>, dim3((unsigned)R), dim3(256), edge_bwd_lds_bytes(), stream, gd, gr, sd, pos, gb, ae);
     Node1BwdArgs a1;
     a1.t = 0; a1.R = R; a1.dX = bw.dX; a1.dP = bw.dP; a1.DE1 = bw.DE1; a1.DPJ = bw.DPJ; a1.gpos_tgt = bw.gpos_tgt;
-    a1.sem = sem; a1.g_pos = g_pos; a1.g_full = dx; a1.g_pf = nullptr; a1.g_mf = nullptr; a1.dz = nullptr;
+    a1.sem = sem; a1.PRE_IN = nullptr; a1.X = gb.X; a1.g_pos = g_pos; a1.g_full = dx; a1.g_pf = nullptr; a1.g_mf = nullptr; a1.dz = nullptr;
     hipLaunchKernelGGL(node1_bwd_kernel<true>, dim3(nb), dim3(256), node1_bwd_lds_bytes(in_ld1, xs_ld), stream, gd, gr, sd, f, a1);
     STRIVE_CHECK_LAUNCH();
     return 0;

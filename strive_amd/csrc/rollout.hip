@@ -61,8 +61,19 @@ struct Tape {
     float *pf, *mf, *pos, *state, *mem, *A, *loc;
     float *X, *P, *Q;       // node embeddings and edge layer-0 partials of every step (kept: the reverse sweep reads them
                             // instead of re-running the node-1 kernel)
+    // pre-LayerNorm outputs of every hidden layer, decoder outputs and GRU gates of every step: what the reverse sweep used
+    // to recompute (5 + 3 + 2 dense layers per node, 2 per edge, 6 GRU products).  1.9 KB per node-step + 1 KB per
+    // edge-step: 150 MB for the 512-agent, 16-step closure -- nothing next to 288 GB, and a third of the backward's time
+    float *PRE_IN, *PRE_E, *PRE_U, *PRE_O, *DEC, *GATES;
     int32_t* ARG;
     size_t R;
+    int max_n;
+    __host__ __device__ float* PRE_IN_t(int t) const { return PRE_IN + (size_t)t * R * 2 * STRIVE_HID; }
+    __host__ __device__ float* PRE_E_t(int t) const { return PRE_E + (size_t)t * R * max_n * 2 * STRIVE_HID; }
+    __host__ __device__ float* PRE_U_t(int t) const { return PRE_U + (size_t)t * R * STRIVE_HID; }
+    __host__ __device__ float* PRE_O_t(int t) const { return PRE_O + (size_t)t * R * 2 * STRIVE_HID; }
+    __host__ __device__ float* DEC_t(int t) const { return DEC + (size_t)t * R * 4; }
+    __host__ __device__ float* GATES_t(int t) const { return GATES + (size_t)t * R * 3 * 256; }
     __host__ __device__ float* X_t(int t) const { return X + (size_t)t * R * 64; }
     __host__ __device__ float* P_t(int t) const { return P + (size_t)t * R * STRIVE_HID; }
     __host__ __device__ float* Q_t(int t) const { return Q + (size_t)t * R * STRIVE_HID; }
@@ -76,15 +87,17 @@ struct Tape {
     __host__ __device__ int32_t* ARG_t(int t) const { return ARG + (size_t)t * R * 64; }
 };
 
-static size_t tape_bytes_for(size_t R, int FT) {
-    const size_t per = 64 + 64 + 4 + 8 + 192 + 64 + 4 + 64 + 64 + 2 * STRIVE_HID;
-    return strive_align_up(R * FT * per * 4 + 11 * 256, 256);
+static size_t tape_bytes_for(size_t R, int FT, int max_n) {
+    const size_t per = 64 + 64 + 4 + 8 + 192 + 64 + 4 + 64 + 64 + 2 * STRIVE_HID +
+                       2 * STRIVE_HID + (size_t)max_n * 2 * STRIVE_HID + STRIVE_HID + 2 * STRIVE_HID + 4 + 3 * 256;
+    return strive_align_up(R * FT * per * 4 + 17 * 256, 256);
 }
 
-static Tape carve_tape(void* p, size_t bytes, size_t R, int FT) {
+static Tape carve_tape(void* p, size_t bytes, size_t R, int FT, int max_n) {
     StriveArena ar(p, bytes);
     Tape t;
     t.R = R;
+    t.max_n = max_n;
     t.pf = ar.take<float>(R * FT * 64);
     t.mf = ar.take<float>(R * FT * 64);
     t.pos = ar.take<float>(R * FT * 4);
@@ -96,6 +109,12 @@ static Tape carve_tape(void* p, size_t bytes, size_t R, int FT) {
     t.X = ar.take<float>(R * FT * 64);
     t.P = ar.take<float>(R * FT * STRIVE_HID);
     t.Q = ar.take<float>(R * FT * STRIVE_HID);
+    t.PRE_IN = ar.take<float>(R * FT * 2 * STRIVE_HID);
+    t.PRE_E = ar.take<float>(R * FT * (size_t)max_n * 2 * STRIVE_HID);
+    t.PRE_U = ar.take<float>(R * FT * STRIVE_HID);
+    t.PRE_O = ar.take<float>(R * FT * 2 * STRIVE_HID);
+    t.DEC = ar.take<float>(R * FT * 4);
+    t.GATES = ar.take<float>(R * FT * 3 * 256);
     return t;
 }
 
@@ -167,8 +186,11 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 // x: LDS [RB_NODE][xld] (layer input), h: LDS [RB_NODE][64] (layer hidden), gi/gh: LDS [RB_NODE][GLD] scratch.
 // Writes the new hidden into hn [RB_NODE][64]; if gates != null stores (r,z,n,gh_n) at gates[RB_NODE][4*64].
+// ggates (optional, global [RB_NODE rows][256] of THIS layer, row stride gstride floats): the same four values kept for the
+// reverse sweep; rows >= nrows are not written.
 __device__ __forceinline__ void gru_layer_lds(const GRUDev& g, int l, const float* x, int xld, int xin, const float* h,
-                                              float* gi, float* gh, float* hn, float* gates, int tid) {
+                                              float* gi, float* gh, float* hn, float* gates, int tid,
+                                              float* ggates = nullptr, int gstride = 0, int nrows = 0) {
     dense_lds<RB_NODE, false>(x, xld, xin, g.wih_t[l], GLD, g.bih[l], gi, GLD, GLD, tid, 256);
     dense_lds<RB_NODE, false>(h, 64, 64, g.whh_t[l], GLD, g.bhh[l], gh, GLD, GLD, tid, 256);
     __syncthreads();
@@ -184,6 +206,13 @@ __device__ __forceinline__ void gru_layer_lds(const GRUDev& g, int l, const floa
             gates[rr * 256 + 64 + c] = z;
             gates[rr * 256 + 128 + c] = n;
             gates[rr * 256 + 192 + c] = ghn;
+        }
+        if (ggates && rr < nrows) {
+            float* gq = ggates + (size_t)rr * gstride;
+            gq[c] = r;
+            gq[64 + c] = z;
+            gq[128 + c] = n;
+            gq[192 + c] = ghn;
         }
     }
     __syncthreads();
@@ -215,6 +244,17 @@ static __global__ __launch_bounds__(256) void rollout_node2_kernel(GNNDev g, GRU
     const int tid = threadIdx.x, r0 = blockIdx.x * RB_NODE, t = a.t;
     node2_forward(g, a.NS, a.X, tp.A_t(t), a.sem, r0, a.R, L, in_ld, tid);
     const bool more = t < a.FT - 1;
+    // keep the pre-activations of update (1 layer) and mlp_out (2 layers) for the reverse sweep
+    for (int i = tid; i < RB_NODE * 3 * STRIVE_HID; i += 256) {
+        const int rr = i / (3 * STRIVE_HID), rem = i - rr * 3 * STRIVE_HID;
+        if (r0 + rr < a.R) {
+            if (rem < STRIVE_HID) tp.PRE_U_t(t)[(size_t)(r0 + rr) * STRIVE_HID + rem] = L.pre_u[rr * HLD + rem];
+            else {
+                const int q = rem - STRIVE_HID, l = q / STRIVE_HID, c = q - l * STRIVE_HID;
+                tp.PRE_O_t(t)[(size_t)(r0 + rr) * 2 * STRIVE_HID + q] = L.pre_o[(size_t)l * RB_NODE * HLD + rr * HLD + c];
+            }
+        }
+    }
     if (tid < RB_NODE) {
         const int r = r0 + tid;
         float loc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -223,6 +263,8 @@ static __global__ __launch_bounds__(256) void rollout_node2_kernel(GNNDev g, GRU
             const float* st = tp.state_t(t) + (size_t)r * 8;
             BikeFwd b;
             bike_forward(dp, st, L.out[tid * HLD + 0], L.out[tid * HLD + 1], a.lw[ag * 2], b);
+            tp.DEC_t(t)[(size_t)r * 4 + 0] = L.out[tid * HLD + 0];
+            tp.DEC_t(t)[(size_t)r * 4 + 1] = L.out[tid * HLD + 1];
             float* tr = a.traj + ((size_t)r * a.FT + t) * 4;
             for (int i = 0; i < 4; ++i) tr[i] = b.out[i];
             float gin[4] = {b.out[0], b.out[1], b.out[2], b.out[3]};
@@ -258,7 +300,9 @@ static __global__ __launch_bounds__(256) void rollout_node2_kernel(GNNDev g, GRU
         }
         __syncthreads();
         float* hn = s_hn + (size_t)(l & 1) * RB_NODE * 64;
-        gru_layer_lds(gru, l, x, xld, xin, s_h, s_gi, s_gh, hn, nullptr, tid);
+        const int nrows = (a.R - r0) < RB_NODE ? (a.R - r0) : RB_NODE;
+        gru_layer_lds(gru, l, x, xld, xin, s_h, s_gi, s_gh, hn, nullptr, tid, tp.GATES_t(t) + ((size_t)r0 * 3 + l) * 256, 3 * 256,
+                      nrows);
         for (int i = tid; i < RB_NODE * 64; i += 256) {
             const int rr = i >> 6, c = i & 63;
             const int r = r0 + rr;
@@ -356,7 +400,7 @@ int check_decoder(const StriveDecoder* dec, const StriveScenes* sc, int FT) {
 
 extern "C" size_t strive_rollout_tape_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT) {
     if (!sc) return 0;
-    return tape_bytes_for((size_t)sc->NA * sc->NS, FT);
+    return tape_bytes_for((size_t)sc->NA * sc->NS, FT, sc->max_n > 0 ? sc->max_n : 1);
 }
 
 extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* sc, const float* past_last,
@@ -369,10 +413,10 @@ extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* 
     STRIVE_CHECK_ARG(!(ext_future && sc->NS != 1), "ext_future with multiple samples is not supported");
     const size_t R = (size_t)sc->NA * sc->NS;
     if (R == 0) return 0;
-    STRIVE_CHECK_ARG(tape_bytes >= tape_bytes_for(R, FT), "tape too small");
+    STRIVE_CHECK_ARG(tape_bytes >= tape_bytes_for(R, FT, sc->max_n > 0 ? sc->max_n : 1), "tape too small");
     STRIVE_CHECK_ARG(ws_bytes >= strive_rollout_workspace_bytes(dec, sc, FT), "workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
-    Tape tp = carve_tape(tape, tape_bytes, R, FT);
+    Tape tp = carve_tape(tape, tape_bytes, R, FT, sc->max_n > 0 ? sc->max_n : 1);
     StriveArena ar(ws, ws_bytes);
     FwdWs w;
     w.gb.X = ar.take<float>(R * 64);
@@ -400,6 +444,8 @@ extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* 
         gb.X = tp.X_t(t);
         gb.P = tp.P_t(t);
         gb.Q = tp.Q_t(t);
+        gb.PRE_IN = tp.PRE_IN_t(t);
+        gb.PRE_E = tp.PRE_E_t(t);
         FeatSrc f = decoder_features(tp, t, sem, z, lw, NC);
         hipLaunchKernelGGL(gnn_node1_kernel, dim3(nb), dim3(256), Node1Lds::bytes(in_ld1, xs_ld), stream, gd, sc->NS, f, sem,
                            gb, (int)R);
@@ -447,11 +493,20 @@ static __global__ __launch_bounds__(256) void gru_bwd_kernel(GRUDev gru, GRUGrad
         s_h[i] = (r < R) ? tp.mem_t(t)[((size_t)r * 3 + l) * 64 + c] : 0.f;
     }
     __syncthreads();
-    // forward recompute
-    for (int l = 0; l < 3; ++l) {
-        const float* x = (l == 0) ? s_x : s_hn + (size_t)(l - 1) * RB_NODE * 64;
-        gru_layer_lds(gru, l, x, l == 0 ? 4 : 64, l == 0 ? 4 : 64, s_h + (size_t)l * RB_NODE * 64, s_gi, s_gh,
-                      s_hn + (size_t)l * RB_NODE * 64, s_g + (size_t)l * RB_NODE * 256, tid);
+    if (!WG) {
+        // the forward sweep kept the gates (r, z, n, W_hn h + b_hn) of this step: nothing to recompute
+        for (int i = tid; i < 3 * RB_NODE * 256; i += 256) {
+            const int l = i / (RB_NODE * 256), rem = i - l * RB_NODE * 256, rr = rem >> 8, c = rem & 255;
+            s_g[i] = (r0 + rr < R) ? tp.GATES_t(t)[((size_t)(r0 + rr) * 3 + l) * 256 + c] : 0.f;
+        }
+        __syncthreads();
+    } else {
+        // forward recompute (the weight gradients also need the layer outputs)
+        for (int l = 0; l < 3; ++l) {
+            const float* x = (l == 0) ? s_x : s_hn + (size_t)(l - 1) * RB_NODE * 64;
+            gru_layer_lds(gru, l, x, l == 0 ? 4 : 64, l == 0 ? 4 : 64, s_h + (size_t)l * RB_NODE * 64, s_gi, s_gh,
+                          s_hn + (size_t)l * RB_NODE * 64, s_g + (size_t)l * RB_NODE * 256, tid);
+        }
     }
     // backward, top layer first
     for (int l = 2; l >= 0; --l) {
@@ -540,7 +595,26 @@ static __global__ __launch_bounds__(256) void node2_bwd_kernel(GNNDev g, GNNGrad
     float* s_gx = s_gb + RB_NODE * HLD;       // [RB_NODE][HLD] gradient w.r.t. x'
     float* s_gin = s_gx + RB_NODE * HLD;      // [RB_NODE][in_ld]
     const int tid = threadIdx.x, r0 = blockIdx.x * RB_NODE, t = a.t;
-    node2_forward(g, a.NS, a.X, tp.A_t(t), a.sem, r0, a.R, L, in_ld, tid);
+    if (!WG) {
+        // pre-activations and decoder outputs of this step come from the tape (the weight gradients would also need the
+        // layer inputs: that instantiation recomputes the forward)
+        for (int i = tid; i < RB_NODE * 3 * STRIVE_HID; i += 256) {
+            const int rr = i / (3 * STRIVE_HID), rem = i - rr * 3 * STRIVE_HID;
+            const bool live = r0 + rr < a.R;
+            if (rem < STRIVE_HID) L.pre_u[rr * HLD + rem] = live ? tp.PRE_U_t(t)[(size_t)(r0 + rr) * STRIVE_HID + rem] : 0.f;
+            else {
+                const int q = rem - STRIVE_HID, l = q / STRIVE_HID, c = q - l * STRIVE_HID;
+                L.pre_o[(size_t)l * RB_NODE * HLD + rr * HLD + c] = live ? tp.PRE_O_t(t)[(size_t)(r0 + rr) * 2 * STRIVE_HID + q] : 0.f;
+            }
+        }
+        if (tid < RB_NODE * 2) {
+            const int rr = tid >> 1, c = tid & 1;
+            L.out[rr * HLD + c] = (r0 + rr < a.R) ? tp.DEC_t(t)[(size_t)(r0 + rr) * 4 + c] : 0.f;
+        }
+        __syncthreads();
+    } else {
+        node2_forward(g, a.NS, a.X, tp.A_t(t), a.sem, r0, a.R, L, in_ld, tid);
+    }
     const bool more = t < a.FT - 1;
     if (tid < RB_NODE) {
         const int r = r0 + tid;
@@ -647,7 +721,7 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
                      void* ws, size_t ws_bytes, strive_stream_t stream_, const TrainOut* tr) {
     const size_t R = (size_t)sc->NA * sc->NS;
     hipStream_t stream = (hipStream_t)stream_;
-    Tape tp = carve_tape(const_cast<void*>(tape), tape_bytes, R, FT);
+    Tape tp = carve_tape(const_cast<void*>(tape), tape_bytes, R, FT, sc->max_n > 0 ? sc->max_n : 1);
     StriveArena ar(ws, ws_bytes);
     float* g_state = ar.take<float>(R * 8);
     float* g_pos = ar.take<float>(R * 4);
@@ -682,6 +756,8 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
         g2.X = tp.X_t(t);          // x, P, Q of step t as the forward sweep left them in the tape
         g2.P = tp.P_t(t);
         g2.Q = tp.Q_t(t);
+        g2.PRE_IN = tp.PRE_IN_t(t);
+        g2.PRE_E = tp.PRE_E_t(t);
         FeatSrc f = decoder_features(tp, t, sem, z, lw, NC);
         if (t < FT - 1)
             hipLaunchKernelGGL(gru_bwd_kernel<WG>, dim3(nb), dim3(256), gru_bwd_lds_bytes(), stream, gr, ggr, tp, t, (int)R, g_pf,
@@ -697,7 +773,7 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
                            g2, ae);
         Node1BwdArgs a1;
         a1.t = t; a1.R = (int)R; a1.dX = bw.dX; a1.dP = bw.dP; a1.DE1 = bw.DE1; a1.DPJ = bw.DPJ; a1.gpos_tgt = bw.gpos_tgt;
-        a1.sem = sem; a1.g_pos = g_pos; a1.g_full = nullptr; a1.g_pf = g_pf; a1.g_mf = tr ? g_mf : nullptr; a1.dz = dz;
+        a1.sem = sem; a1.PRE_IN = tp.PRE_IN_t(t); a1.X = g2.X; a1.g_pos = g_pos; a1.g_full = nullptr; a1.g_pf = g_pf; a1.g_mf = tr ? g_mf : nullptr; a1.dz = dz;
         hipLaunchKernelGGL(node1_bwd_kernel<WG>, dim3(nb), dim3(256), node1_bwd_lds_bytes(in_ld1, xs_ld), stream, gd, ggn, sd, f, a1);
         if (tr && t > 0) {
             // map_feat_t = CNN(crop(pos_t.detach())) (reference traffic_model.py:694-695): its adjoint reaches the CNN weights
@@ -727,7 +803,7 @@ extern "C" int strive_rollout_bwd(const StriveDecoder* dec, const StriveScenes* 
     if (check_decoder(dec, sc, FT)) return -1;
     const size_t R = (size_t)sc->NA * sc->NS;
     if (R == 0) return 0;
-    STRIVE_CHECK_ARG(tape_bytes >= tape_bytes_for(R, FT), "tape too small");
+    STRIVE_CHECK_ARG(tape_bytes >= tape_bytes_for(R, FT, sc->max_n > 0 ? sc->max_n : 1), "tape too small");
     STRIVE_CHECK_ARG(ws_bytes >= strive_rollout_workspace_bytes(dec, sc, FT), "workspace too small");
     STRIVE_CHECK_ARG(sc->max_n >= 1, "max_n not set");
     int rc = rollout_backward<false>(dec, sc, lw, sem, z, ext_future, FT, d_traj, dz, tape, tape_bytes, ws, ws_bytes, stream_, nullptr);
@@ -755,7 +831,7 @@ extern "C" int strive_rollout_bwd_train(const StriveDecoder* dec, const StriveSc
     STRIVE_CHECK_ARG(sc->NS == 1, "the training backward takes 2-D latents (one sample per agent)");
     const size_t R = (size_t)sc->NA;
     if (R == 0) return 0;
-    STRIVE_CHECK_ARG(tape_bytes >= tape_bytes_for(R, FT), "tape too small");
+    STRIVE_CHECK_ARG(tape_bytes >= tape_bytes_for(R, FT, sc->max_n > 0 ? sc->max_n : 1), "tape too small");
     STRIVE_CHECK_ARG(ws_bytes >= strive_rollout_train_workspace_bytes(dec, sc, FT), "workspace too small");
     STRIVE_CHECK_ARG(sc->max_n >= 1, "max_n not set");
     const size_t base = strive_rollout_workspace_bytes(dec, sc, FT);
