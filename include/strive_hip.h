@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define STRIVE_ABI_VERSION 7
+#define STRIVE_ABI_VERSION 8
 #define STRIVE_HID 128        /* hidden width of every MLP in the reference (models/common.py, interaction_net.py:32,41) */
 #define STRIVE_MAX_LAYERS 4
 #define STRIVE_ZDIM 32
@@ -251,6 +251,58 @@ int strive_interp_traj_fwd(const float* in, int32_t N, int32_t T, int32_t TO, co
 int strive_interp_traj_bwd(const float* in, const float* d_out, int32_t N, int32_t T, int32_t TO, int32_t scale,
                            const int32_t* i0, const int32_t* i1, const float* w0, const float* w1, float* d_in,
                            strive_stream_t stream);
+
+/* AvoidCollLoss (reference src/losses/adv_gen_nusc.py:264-341) as ONE call per direction: up-sampling (:625-644), the
+ * in-scene circle penalties (:405-512), the off-road collision points and their penalty (:366-403), the prior NLL
+ * (:343-364), the init-z distance and the weighted masked means -- what the reference evaluates with ~60 elementwise
+ * torch operators per closure.  Constants of one batch: */
+typedef struct StriveAvoidColl {
+    const int32_t* pair_off;     /* (NA)  first in-scene pair slot of every agent, P slots in all */
+    int32_t P;
+    const float* cent_x;         /* (NA,5) circle offsets along the heading */
+    const float* rad;            /* (NA)   circle radii */
+    float buffer;                /* veh_coll_buffer */
+    const uint8_t* pair_valid;   /* (P)    1 = the slot counts (i != j, and the single-agent filter of :281-286) */
+    const int32_t* i0;           /* (TO)   up-sampling taps as for strive_interp_traj_fwd */
+    const int32_t* i1;
+    const float* w0;
+    const float* w1;
+    int32_t scale;               /* TO = T * scale */
+    int32_t NE;                  /* agents that take the environment term (all, or one per scene) */
+    const int32_t* env_agent;    /* (NE)   their agent index */
+    const int32_t* env_of_agent; /* (NA)   inverse: row e of an agent, -1 if it takes no environment term */
+    const float* env_lw;         /* (NE,2) unnormalised length, width */
+    const int32_t* env_mapix;    /* (NE)   */
+    const float* env_pdist;      /* (NE)   sqrt(l^2/4 + w^2/4) (:373) */
+    int32_t gl, gw;              /* collision-point grid (nuscenes_utils.py:351-354) */
+    const float* lin_l;          /* (gl) linspace(-1,1,gl) */
+    const float* lin_w;          /* (gw) */
+    const float* init_z;         /* (NZ,D) */
+    int32_t NZ, D;               /* latent rows (NA, or one per scene when only the first agent of a scene is optimised) */
+    float prior_den, init_den;   /* denominators of the two latent means: NZ and NZ for a (NZ,D) latent; NZ and NZ*D for a
+                                    (NZ,1,D) one, where the reference's sum(dim=1) runs over the singleton axis (:327-330) */
+    float w_veh, w_env, w_prior, w_init;   /* loss weights; a term with weight <= 0 is skipped like the reference does */
+} StriveAvoidColl;
+
+size_t strive_avoid_coll_workspace_bytes(const StriveScenes* sc, const StriveAvoidColl* h, int32_t T);
+
+/* traj (NA,T,4) unnormalised, z / mu / var (NZ,D).  out (8 floats): loss, mean colliding-pair penalty, mean off-road
+ * penalty, mean prior NLL, mean init-z distance, #colliding valid slots, #rows with a collision point, 0.
+ * `ws` keeps what the backward needs and must stay untouched until it ran. */
+int strive_avoid_coll_fwd(const StriveScenes* sc, const StriveMap* map, const StriveAvoidColl* h, const float* traj,
+                          int32_t T, const float* z, const float* mu, const float* var, float* out, void* ws,
+                          size_t ws_bytes, strive_stream_t stream);
+
+/* d_loss: one float ON THE DEVICE.  d_traj (NA,T,4) and d_z (NZ,D) are overwritten. */
+int strive_avoid_coll_bwd(const StriveScenes* sc, const StriveAvoidColl* h, const float* traj, int32_t T, const float* z,
+                          const float* mu, const float* var, const float* d_loss, void* ws, size_t ws_bytes,
+                          float* d_traj, float* d_z, strive_stream_t stream);
+
+/* strive_coll_point over the rows (e, t) of an up-sampled trajectory tensor without expanding the per-agent attributes:
+ * car = fine[agent_of[e]*TO + t], size lw[e], map mapix[e]; out_pt (NE*TO,2), out_cnt (NE*TO). */
+int strive_coll_point_rows(const StriveMap* map, const float* fine, int32_t TO, const int32_t* agent_of, const float* lw,
+                           const int32_t* mapix, int32_t NE, int32_t gl, int32_t gw, const float* lin_l,
+                           const float* lin_w, float* out_pt, int32_t* out_cnt, strive_stream_t stream);
 
 /* Rotated-rectangle IoU of P box pairs (x, y, hx, hy) + (l, w), float64 out; NaN where a pose contains NaN.
  * Replaces the shapely polygon loop of check_single_veh_coll / check_pairwise_veh_coll

@@ -59,6 +59,16 @@ class StriveScenes(C.Structure):
                 ('scene_of', C.c_void_p)]
 
 
+class StriveAvoidColl(C.Structure):
+    _fields_ = [('pair_off', C.c_void_p), ('P', C.c_int32), ('cent_x', C.c_void_p), ('rad', C.c_void_p), ('buffer', C.c_float),
+                ('pair_valid', C.c_void_p), ('i0', C.c_void_p), ('i1', C.c_void_p), ('w0', C.c_void_p), ('w1', C.c_void_p),
+                ('scale', C.c_int32), ('NE', C.c_int32), ('env_agent', C.c_void_p), ('env_of_agent', C.c_void_p),
+                ('env_lw', C.c_void_p), ('env_mapix', C.c_void_p), ('env_pdist', C.c_void_p), ('gl', C.c_int32),
+                ('gw', C.c_int32), ('lin_l', C.c_void_p), ('lin_w', C.c_void_p), ('init_z', C.c_void_p), ('NZ', C.c_int32), ('D', C.c_int32),
+                ('prior_den', C.c_float), ('init_den', C.c_float),
+                ('w_veh', C.c_float), ('w_env', C.c_float), ('w_prior', C.c_float), ('w_init', C.c_float)]
+
+
 class StriveDecoder(C.Structure):
     _fields_ = [('gnn', StriveGNN), ('gru', StriveGRU), ('cnn', StriveCNN), ('map', StriveMap),
                 ('state_mean', C.c_float * 6), ('state_std', C.c_float * 6),
@@ -97,6 +107,11 @@ PROTOTYPES = {
     'strive_interp_traj_bwd': (C.c_int, [P, P, I, I, I, I, P, P, P, P, P, P]),
     'strive_rect_iou': (C.c_int, [P, P, P, P, I, P, P]),
     'strive_veh_coll_bwd': (C.c_int, [C.POINTER(StriveScenes), P, I, P, I, P, P, C.c_float, P, P, P, P]),
+    'strive_avoid_coll_workspace_bytes': (SZ, [C.POINTER(StriveScenes), C.POINTER(StriveAvoidColl), I]),
+    'strive_avoid_coll_fwd': (C.c_int, [C.POINTER(StriveScenes), C.POINTER(StriveMap), C.POINTER(StriveAvoidColl), P, I, P, P, P,
+                                        P, P, SZ, P]),
+    'strive_avoid_coll_bwd': (C.c_int, [C.POINTER(StriveScenes), C.POINTER(StriveAvoidColl), P, I, P, P, P, P, P, SZ, P, P, P]),
+    'strive_coll_point_rows': (C.c_int, [C.POINTER(StriveMap), P, I, P, P, P, I, I, I, P, P, P, P, P]),
     'strive_mlp_param_count': (SZ, [C.POINTER(StriveMLP)]),
     'strive_gnn_param_count': (SZ, [C.POINTER(StriveGNN)]),
     'strive_gru_param_count': (SZ, []),
@@ -112,7 +127,7 @@ PROTOTYPES = {
 }
 
 
-ABI_VERSION = 7   # include/strive_hip.h STRIVE_ABI_VERSION
+ABI_VERSION = 8   # include/strive_hip.h STRIVE_ABI_VERSION
 
 
 class StriveLib(object):

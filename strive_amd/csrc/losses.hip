@@ -70,9 +70,21 @@ __global__ __launch_bounds__(256) void veh_coll_fwd_kernel(VehArgs a, float* __r
     }
 }
 
+// Gradient of the masked MEAN of the penalties without a d_pen tensor (fused AvoidCollLoss): d_pen(slot) = g for the
+// slots that are colliding and valid, g = d_loss * w / max(#such slots, 1) read from the forward's sums.
+struct VehImplicit {
+    const uint8_t* hit;       // (T,P)
+    const uint8_t* valid;     // (P)
+    const double* sums;       // [1] = number of colliding valid slots
+    const float* d_loss;      // device scalar
+    float w;
+};
+
 // d_traj[i][t] += sum_j [ d_pen(i,j) * dpen(i,j)/dpose_i  +  d_pen(j,i) * dpen(j,i)/dpose_i ]
+template <bool IMPL>
 __global__ __launch_bounds__(256) void veh_coll_bwd_kernel(VehArgs a, const float* __restrict__ d_pen,
-                                                             const uint8_t* __restrict__ amin, float* __restrict__ d_traj) {
+                                                             const uint8_t* __restrict__ amin, float* __restrict__ d_traj,
+                                                             VehImplicit im) {
     const int gid_raw = (blockIdx.x * blockDim.x + threadIdx.x) / VG;
     const int sub = threadIdx.x & (VG - 1);
     const bool live = gid_raw < a.NA * a.T;      // whole groups are live or not; every lane stays for the shuffles
@@ -85,6 +97,11 @@ __global__ __launch_bounds__(256) void veh_coll_bwd_kernel(VehArgs a, const floa
     const float ri = a.rad[i];
     const int il = i - lo;
     float g[4] = {0.f, 0.f, 0.f, 0.f};
+    float gs = 0.f;
+    if (IMPL) {
+        const double c = im.sums[1];
+        gs = (float)((double)im.d_loss[0] * (double)im.w / (c < 1.0 ? 1.0 : c));
+    }
     for (int jl = sub; live && jl < n; jl += VG) {
         const int j = lo + jl;
         if (j == i) continue;
@@ -94,7 +111,7 @@ __global__ __launch_bounds__(256) void veh_coll_bwd_kernel(VehArgs a, const floa
         // pair (i, j): i is the first member
         {
             const size_t s = (size_t)t * a.P + a.pair_off[i] + jl;
-            const float gp = d_pen[s];
+            const float gp = IMPL ? ((im.hit[s] && im.valid[a.pair_off[i] + jl]) ? gs : 0.f) : d_pen[s];
             if (gp != 0.f) {
                 const int am = amin[s];
                 const int p = am / NCIRC, q = am - p * NCIRC;
@@ -111,7 +128,7 @@ __global__ __launch_bounds__(256) void veh_coll_bwd_kernel(VehArgs a, const floa
         // pair (j, i): i is the second member
         {
             const size_t s = (size_t)t * a.P + a.pair_off[j] + il;
-            const float gp = d_pen[s];
+            const float gp = IMPL ? ((im.hit[s] && im.valid[a.pair_off[j] + il]) ? gs : 0.f) : d_pen[s];
             if (gp != 0.f) {
                 const int am = amin[s];
                 const int p = am / NCIRC, q = am - p * NCIRC;   // p indexes j's circles, q indexes i's
@@ -164,8 +181,8 @@ extern "C" int strive_veh_coll_bwd(const StriveScenes* sc, const int32_t* pair_o
     STRIVE_CHECK_ARG(sc->NS == 1, "collision losses take one trajectory per agent");
     const long long n = (long long)sc->NA * T * VG;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(veh_coll_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       veh_args(sc, pair_off, P, traj, T, cent_x, rad, buffer), d_pen, amin, d_traj);
+    hipLaunchKernelGGL(veh_coll_bwd_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       veh_args(sc, pair_off, P, traj, T, cent_x, rad, buffer), d_pen, amin, d_traj, VehImplicit());
     STRIVE_CHECK_LAUNCH();
     return 0;
 }
@@ -334,4 +351,296 @@ extern "C" int strive_rect_iou(const float* box_a, const float* lw_a, const floa
     hipLaunchKernelGGL(rect_iou_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, box_a, lw_a, box_b, lw_b, P, iou);
     STRIVE_CHECK_LAUNCH();
     return 0;
+}
+
+
+// =============================================================================================
+// AvoidCollLoss in one call per direction (reference src/losses/adv_gen_nusc.py:264-341).
+//   forward : interp_traj_fwd -> veh_coll_fwd -> coll_point (rows) -> avoid_partial -> avoid_final     (5 launches)
+//   backward: avoid_grad (environment term, d_z) -> veh_coll_bwd<implicit> -> interp_traj_bwd            (3 launches)
+// against ~60 + ~45 elementwise torch operators.  All sums are float64 partials per workgroup added in a fixed order
+// (deterministic); the means divide by max(count, 1) like the reference's "[0.] when nothing collides" sentinel does.
+// =============================================================================================
+extern "C" int strive_coll_point_rows(const StriveMap* map, const float* fine, int32_t TO, const int32_t* agent_of,
+                                      const float* lw, const int32_t* mapix, int32_t NE, int32_t gl, int32_t gw,
+                                      const float* lin_l, const float* lin_w, float* out_pt, int32_t* out_cnt,
+                                      strive_stream_t stream);
+
+#define AV_BLOCKS 240
+#define AV_TERMS 6          // veh sum, veh count, env sum, env count, prior NLL sum, init-z sum
+
+struct AvoidWs {
+    float* fine;            // (NA,TO,4)
+    float* pen;             // (TO,P)
+    uint8_t* hit;           // (TO,P)
+    uint8_t* amin;          // (TO,P)
+    float* pt;              // (NE*TO,2)
+    int32_t* cnt;           // (NE*TO)
+    double* partial;        // (AV_BLOCKS, AV_TERMS)
+    double* sums;           // (AV_TERMS)
+    float* d_fine;          // (NA,TO,4) backward scratch
+};
+
+static size_t avoid_ws_bytes(size_t NA, size_t TO, size_t P, size_t NE) {
+    size_t b = 0;
+    b += strive_align_up(NA * TO * 16, 256) * 2;
+    b += strive_align_up(TO * P * 4, 256) + 2 * strive_align_up(TO * P, 256);
+    b += strive_align_up(NE * TO * 8, 256) + strive_align_up(NE * TO * 4, 256);
+    b += strive_align_up((size_t)AV_BLOCKS * AV_TERMS * 8, 256) + 256;
+    return b + 256;
+}
+
+static AvoidWs avoid_carve(void* p, size_t bytes, size_t NA, size_t TO, size_t P, size_t NE) {
+    StriveArena ar(p, bytes);
+    AvoidWs w;
+    w.fine = ar.take<float>(NA * TO * 4);
+    w.d_fine = ar.take<float>(NA * TO * 4);
+    w.pen = ar.take<float>(TO * P);
+    w.hit = ar.take<uint8_t>(TO * P);
+    w.amin = ar.take<uint8_t>(TO * P);
+    w.pt = ar.take<float>(NE * TO * 2);
+    w.cnt = ar.take<int32_t>(NE * TO);
+    w.partial = ar.take<double>((size_t)AV_BLOCKS * AV_TERMS);
+    w.sums = ar.take<double>(AV_TERMS);
+    return w;
+}
+
+struct AvoidArgs {
+    int NA, TO, P, NE, NZ, D;
+    float prior_den, init_den;
+    const float* fine;
+    const float* pen;
+    const uint8_t* hit;
+    const uint8_t* valid;
+    const int32_t* env_agent;
+    const float* pt;
+    const float* pdist;
+    const float *z, *mu, *var, *init_z;
+    float w_veh, w_env, w_prior, w_init;
+};
+
+// off-road penalty of row (e, t): 1 - |c - p| / r for rows with a collision point (reference :384-403)
+__device__ __forceinline__ bool env_row(const AvoidArgs& a, int row, float& dx, float& dy, float& d, float& pd) {
+    const float px = a.pt[(size_t)row * 2], py = a.pt[(size_t)row * 2 + 1];
+    if (!(px + py == px + py)) return false;      // NaN point = no collision point
+    const int e = row / a.TO, t = row - e * a.TO;
+    const float* c = a.fine + ((size_t)a.env_agent[e] * a.TO + t) * 4;
+    dx = c[0] - px;
+    dy = c[1] - py;
+    d = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+    pd = a.pdist[e];
+    return true;
+}
+
+__global__ __launch_bounds__(256) void avoid_partial_kernel(AvoidArgs a, double* __restrict__ partial) {
+    __shared__ double s_red[4][AV_TERMS];
+    const int tid = threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long g0 = (long long)blockIdx.x * blockDim.x + tid;
+    double acc[AV_TERMS] = {0, 0, 0, 0, 0, 0};
+    if (a.w_veh > 0.f) {
+        const long long n = (long long)a.TO * a.P;
+        for (long long i = g0; i < n; i += stride) {
+            const int slot = (int)(i % a.P);
+            if (a.hit[i] && a.valid[slot]) { acc[0] += (double)a.pen[i]; acc[1] += 1.0; }
+        }
+    }
+    if (a.w_env > 0.f) {
+        const long long n = (long long)a.NE * a.TO;
+        for (long long i = g0; i < n; i += stride) {
+            float dx, dy, d, pd;
+            if (env_row(a, (int)i, dx, dy, d, pd)) { acc[2] += (double)(1.0f - d / pd); acc[3] += 1.0; }
+        }
+    }
+    if (a.w_prior > 0.f || a.w_init > 0.f) {
+        const long long n = (long long)a.NZ * a.D;
+        for (long long i = g0; i < n; i += stride) {
+            const float z = a.z[i];
+            if (a.w_prior > 0.f) {
+                // -log N(z; mu, var) per element as losses/common.py:26-41 evaluates it in fp32
+                const float m = a.mu[i], v = a.var[i];
+                const float dz = z - m;
+                const float lp = -logf(sqrtf(v)) - 0.91893853320467267f - (dz * dz) / (2.0f * v);
+                acc[4] -= (double)lp;
+            }
+            if (a.w_init > 0.f) {
+                const float di = a.init_z[i] - z;
+                acc[5] += (double)(di * di);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < AV_TERMS; ++k) acc[k] = wave_sum_d(acc[k]);
+    if ((tid & 63) == 0)
+        for (int k = 0; k < AV_TERMS; ++k) s_red[tid >> 6][k] = acc[k];
+    __syncthreads();
+    if (tid < AV_TERMS) partial[(size_t)blockIdx.x * AV_TERMS + tid] = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+}
+
+__global__ __launch_bounds__(64) void avoid_final_kernel(AvoidArgs a, const double* __restrict__ partial, int nblocks,
+                                                           double* __restrict__ sums, float* __restrict__ out) {
+    __shared__ double s[AV_TERMS];
+    const int tid = threadIdx.x;
+    if (tid < AV_TERMS) {
+        double v = 0.0;
+        for (int b = 0; b < nblocks; ++b) v += partial[(size_t)b * AV_TERMS + tid];
+        s[tid] = v;
+        sums[tid] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double veh = s[0] / (s[1] < 1.0 ? 1.0 : s[1]);
+        const double env = s[2] / (s[3] < 1.0 ? 1.0 : s[3]);
+        const double pri = a.prior_den > 0.f ? s[4] / (double)a.prior_den : 0.0;
+        const double ini = a.init_den > 0.f ? s[5] / (double)a.init_den : 0.0;
+        double loss = 0.0;
+        if (a.w_veh > 0.f) loss += (double)a.w_veh * veh;
+        if (a.w_env > 0.f) loss += (double)a.w_env * env;
+        if (a.w_prior > 0.f) loss += (double)a.w_prior * pri;
+        if (a.w_init > 0.f) loss += (double)a.w_init * ini;
+        out[0] = (float)loss;
+        out[1] = (float)veh;
+        out[2] = (float)env;
+        out[3] = (float)pri;
+        out[4] = (float)ini;
+        out[5] = (float)s[1];
+        out[6] = (float)s[3];
+        out[7] = 0.f;
+    }
+}
+
+// d_fine of the environment term -- every (agent, t) row is written, zeros where the agent takes no environment term or
+// has no collision point, so the vehicle term can accumulate on top without a memset -- and d_z
+__global__ __launch_bounds__(256) void avoid_grad_kernel(AvoidArgs a, const int32_t* __restrict__ env_of_agent,
+                                                           const double* __restrict__ sums, const float* __restrict__ d_loss,
+                                                           float* __restrict__ d_fine, float* __restrict__ d_z) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n_rows = (long long)a.NA * a.TO;
+    const float gl = d_loss[0];
+    if (idx < n_rows) {
+        const int ag = (int)(idx / a.TO), t = (int)(idx - (long long)ag * a.TO);
+        float gx = 0.f, gy = 0.f;
+        const int e = (a.w_env > 0.f && env_of_agent) ? env_of_agent[ag] : -1;
+        if (e >= 0) {
+            float dx, dy, d, pd;
+            if (env_row(a, e * a.TO + t, dx, dy, d, pd) && d > 0.f) {
+                const double c = sums[3];
+                const float gs = (float)((double)gl * (double)a.w_env / (c < 1.0 ? 1.0 : c));
+                const float k = -gs / (d * pd);      // pen = 1 - d / pd  ->  d pen / d c = -(c - p) / (d * pd)
+                gx = k * dx;
+                gy = k * dy;
+            }
+        }
+        float* o = d_fine + (size_t)idx * 4;
+        o[0] = gx; o[1] = gy; o[2] = 0.f; o[3] = 0.f;
+        return;
+    }
+    const long long i = idx - n_rows;
+    if (i < (long long)a.NZ * a.D) {
+        const float z = a.z[i];
+        float g = 0.f;
+        if (a.w_prior > 0.f) g += gl * a.w_prior / a.prior_den * ((z - a.mu[i]) / a.var[i]);
+        if (a.w_init > 0.f) g += gl * a.w_init / a.init_den * (2.0f * (z - a.init_z[i]));
+        d_z[i] = g;
+    }
+}
+
+static AvoidArgs avoid_args(const StriveScenes* sc, const StriveAvoidColl* h, const AvoidWs& w, int TO, const float* z,
+                            const float* mu, const float* var) {
+    AvoidArgs a;
+    a.NA = sc->NA; a.TO = TO; a.P = h->P; a.NE = h->NE; a.NZ = h->NZ; a.D = h->D;
+    a.prior_den = h->prior_den; a.init_den = h->init_den;
+    a.fine = w.fine; a.pen = w.pen; a.hit = w.hit; a.valid = h->pair_valid;
+    a.env_agent = h->env_agent; a.pt = w.pt; a.pdist = h->env_pdist;
+    a.z = z; a.mu = mu; a.var = var; a.init_z = h->init_z;
+    a.w_veh = h->w_veh; a.w_env = h->w_env; a.w_prior = h->w_prior; a.w_init = h->w_init;
+    return a;
+}
+
+static int avoid_check(const StriveScenes* sc, const StriveAvoidColl* h, int T) {
+    STRIVE_CHECK_ARG(sc && h, "null argument");
+    STRIVE_CHECK_ARG(sc->NS == 1, "collision losses take one trajectory per agent");
+    STRIVE_CHECK_ARG(T > 0 && h->scale >= 1 && h->P >= 0 && h->NE >= 0 && h->NZ >= 0 && h->D >= 0, "bad sizes");
+    STRIVE_CHECK_ARG(h->i0 && h->i1 && h->w0 && h->w1, "null interpolation taps");
+    if (h->w_veh > 0.f) STRIVE_CHECK_ARG(h->pair_off && h->cent_x && h->rad && h->pair_valid, "null vehicle-term constants");
+    if (h->w_env > 0.f && h->NE > 0)
+        STRIVE_CHECK_ARG(h->env_agent && h->env_of_agent && h->env_lw && h->env_mapix && h->env_pdist && h->lin_l && h->lin_w &&
+                             h->gl > 0 && h->gw > 0,
+                         "null environment-term constants");
+    if (h->w_init > 0.f) STRIVE_CHECK_ARG(h->init_z, "null init_z");
+    return 0;
+}
+
+extern "C" size_t strive_avoid_coll_workspace_bytes(const StriveScenes* sc, const StriveAvoidColl* h, int32_t T) {
+    if (!sc || !h || T <= 0 || h->scale < 1) return 0;
+    return avoid_ws_bytes((size_t)sc->NA, (size_t)T * h->scale, (size_t)h->P, (size_t)h->NE);
+}
+
+extern "C" int strive_avoid_coll_fwd(const StriveScenes* sc, const StriveMap* map, const StriveAvoidColl* h, const float* traj,
+                                     int32_t T, const float* z, const float* mu, const float* var, float* out, void* ws,
+                                     size_t ws_bytes, strive_stream_t stream) {
+    if (int rc = avoid_check(sc, h, T)) return rc;
+    STRIVE_CHECK_ARG(traj && out && ws, "null argument");
+    if (h->w_prior > 0.f) STRIVE_CHECK_ARG(z && mu && var, "null latent tensors");
+    if (h->w_init > 0.f) STRIVE_CHECK_ARG(z, "null latent tensors");
+    if (h->w_env > 0.f && h->NE > 0) STRIVE_CHECK_ARG(map, "null map");
+    const int NA = sc->NA, TO = T * h->scale;
+    STRIVE_CHECK_ARG(ws_bytes >= avoid_ws_bytes(NA, TO, h->P, h->NE), "workspace too small");
+    AvoidWs w = avoid_carve(ws, ws_bytes, NA, TO, h->P, h->NE);
+    hipStream_t st = (hipStream_t)stream;
+    if (NA > 0) {
+        if (int rc = strive_interp_traj_fwd(traj, NA, T, TO, h->i0, h->i1, h->w0, h->w1, w.fine, stream)) return rc;
+        if (h->w_veh > 0.f && h->P > 0)
+            if (int rc = strive_veh_coll_fwd(sc, h->pair_off, h->P, w.fine, TO, h->cent_x, h->rad, h->buffer, w.pen, w.hit, w.amin,
+                                             stream))
+                return rc;
+        if (h->w_env > 0.f && h->NE > 0)
+            if (int rc = strive_coll_point_rows(map, w.fine, TO, h->env_agent, h->env_lw, h->env_mapix, h->NE, h->gl, h->gw,
+                                                h->lin_l, h->lin_w, w.pt, w.cnt, stream))
+                return rc;
+    }
+    AvoidArgs a = avoid_args(sc, h, w, TO, z, mu, var);
+    if (h->P == 0) a.w_veh = 0.f;          // nothing to sum; the weight is re-applied below (mean of nothing = 0)
+    if (h->NE == 0) a.w_env = 0.f;
+    long long work = (long long)TO * h->P;
+    if ((long long)h->NE * TO > work) work = (long long)h->NE * TO;
+    if ((long long)h->NZ * h->D > work) work = (long long)h->NZ * h->D;
+    int nb = (int)((work + 1023) / 1024);
+    nb = nb < 1 ? 1 : (nb > AV_BLOCKS ? AV_BLOCKS : nb);
+    hipLaunchKernelGGL(avoid_partial_kernel, dim3(nb), dim3(256), 0, st, a, w.partial);
+    STRIVE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(avoid_final_kernel, dim3(1), dim3(64), 0, st, a, (const double*)w.partial, nb, w.sums, out);
+    STRIVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int strive_avoid_coll_bwd(const StriveScenes* sc, const StriveAvoidColl* h, const float* traj, int32_t T,
+                                     const float* z, const float* mu, const float* var, const float* d_loss, void* ws,
+                                     size_t ws_bytes, float* d_traj, float* d_z, strive_stream_t stream) {
+    if (int rc = avoid_check(sc, h, T)) return rc;
+    STRIVE_CHECK_ARG(traj && d_loss && ws && d_traj, "null argument");
+    const int NA = sc->NA, TO = T * h->scale;
+    STRIVE_CHECK_ARG(ws_bytes >= avoid_ws_bytes(NA, TO, h->P, h->NE), "workspace too small");
+    if (NA == 0) return 0;
+    AvoidWs w = avoid_carve(ws, ws_bytes, NA, TO, h->P, h->NE);
+    hipStream_t st = (hipStream_t)stream;
+    AvoidArgs a = avoid_args(sc, h, w, TO, z, mu, var);
+    if (h->NE == 0) a.w_env = 0.f;
+    const bool latent = (h->w_prior > 0.f || h->w_init > 0.f) && h->D > 0;
+    if (latent) STRIVE_CHECK_ARG(z && d_z && (h->w_prior <= 0.f || (mu && var)), "null latent tensors");
+    if (!latent) a.D = 0;
+    const long long n = (long long)NA * TO + (long long)a.NZ * a.D;
+    hipLaunchKernelGGL(avoid_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, h->env_of_agent,
+                       (const double*)w.sums, d_loss, w.d_fine, d_z);
+    STRIVE_CHECK_LAUNCH();
+    if (h->w_veh > 0.f && h->P > 0) {
+        VehImplicit im;
+        im.hit = w.hit; im.valid = h->pair_valid; im.sums = w.sums; im.d_loss = d_loss; im.w = h->w_veh;
+        const long long nv = (long long)NA * TO * VG;
+        hipLaunchKernelGGL(veh_coll_bwd_kernel<true>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st,
+                           veh_args(sc, h->pair_off, h->P, w.fine, TO, h->cent_x, h->rad, h->buffer), (const float*)nullptr,
+                           (const uint8_t*)w.amin, w.d_fine, im);
+        STRIVE_CHECK_LAUNCH();
+    }
+    return strive_interp_traj_bwd(traj, w.d_fine, NA, T, TO, h->scale, h->i0, h->i1, h->w0, h->w1, d_traj, stream);
 }

@@ -60,21 +60,29 @@ __global__ __launch_bounds__(256) void coll_point_kernel(StriveMap map, const fl
                                                            const float* __restrict__ lw, const int32_t* __restrict__ mapix,
                                                            int gl, int gw, const float* __restrict__ lin_l,
                                                            const float* __restrict__ lin_w, float* __restrict__ out_pt,
-                                                           int32_t* __restrict__ out_cnt) {
+                                                           int32_t* __restrict__ out_cnt, int TO,
+                                                           const int32_t* __restrict__ agent_of) {
     __shared__ double s_x[4], s_y[4];
     __shared__ int s_n[4];
     const int n = blockIdx.x;
+    // agent_of: rows are (e, t) of an up-sampled trajectory tensor; the car sits at fine[agent_of[e]*TO + t] and the
+    // attributes are per e (strive_coll_point_rows)
+    int crow = n, arow = n;
+    if (agent_of) {
+        arow = n / TO;
+        crow = agent_of[arow] * TO + (n - arow * TO);
+    }
     CropFrame fr;
-    fr.x = cars[n * 4 + 0];
-    fr.y = cars[n * 4 + 1];
-    fr.hc = cars[n * 4 + 2];
-    fr.hs = cars[n * 4 + 3];
-    const int m = mapix[n];
+    fr.x = cars[(size_t)crow * 4 + 0];
+    fr.y = cars[(size_t)crow * 4 + 1];
+    fr.hc = cars[(size_t)crow * 4 + 2];
+    fr.hs = cars[(size_t)crow * 4 + 3];
+    const int m = mapix[arow];
     set_crop_scale(fr, map.dx[m * 2 + 0], map.dx[m * 2 + 1]);
     fr.H = map.H;
     fr.W = map.W;
     fr.base = map.raster + (size_t)m * map.C * map.H * map.W;   // layer 0
-    const float ls = lw[n * 2 + 0], ws = lw[n * 2 + 1];
+    const float ls = lw[arow * 2 + 0], ws = lw[arow * 2 + 1];
     double sx = 0.0, sy = 0.0;
     int cnt = 0;
     for (int i = threadIdx.x; i < gl * gw; i += blockDim.x) {
@@ -120,7 +128,20 @@ extern "C" int strive_coll_point(const StriveMap* map, const float* cars, const 
     STRIVE_CHECK_ARG(N >= 0 && gl > 0 && gw > 0, "bad sizes");
     if (N == 0) return 0;
     hipLaunchKernelGGL(coll_point_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, *map, cars, lw, mapix, gl, gw,
-                       lin_l, lin_w, out_pt, out_cnt);
+                       lin_l, lin_w, out_pt, out_cnt, 1, (const int32_t*)nullptr);
+    STRIVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int strive_coll_point_rows(const StriveMap* map, const float* fine, int32_t TO, const int32_t* agent_of,
+                                      const float* lw, const int32_t* mapix, int32_t NE, int32_t gl, int32_t gw,
+                                      const float* lin_l, const float* lin_w, float* out_pt, int32_t* out_cnt,
+                                      strive_stream_t stream) {
+    STRIVE_CHECK_ARG(map && fine && agent_of && lw && mapix && lin_l && lin_w && out_pt && out_cnt, "null argument");
+    STRIVE_CHECK_ARG(NE >= 0 && TO > 0 && gl > 0 && gw > 0, "bad sizes");
+    if (NE == 0) return 0;
+    hipLaunchKernelGGL(coll_point_kernel, dim3(NE * TO), dim3(256), 0, (hipStream_t)stream, *map, fine, lw, mapix, gl, gw,
+                       lin_l, lin_w, out_pt, out_cnt, TO, agent_of);
     STRIVE_CHECK_LAUNCH();
     return 0;
 }

@@ -270,8 +270,50 @@ class AvoidCollLoss(nn.Module):
             veh_att = veh_att[self.single_mask]
             mapixes = mapixes[self.single_mask]
         self.env_coll_loss = EnvCollLoss(veh_att, mapixes, map_env)
+        self._fused = None
+
+    def _setup(self):
+        if self._fused is None:
+            w = self.loss_weights
+            env = self.env_coll_loss
+            NA = self.veh_coll_loss.veh_att.size(0)
+            dev = self.veh_coll_loss.veh_att.device
+            env_agent = self.single_idx if self.use_single_agt else torch.arange(NA, device=dev)
+            NE = env_agent.numel()
+            self._fused = ops.AvoidCollSetup(
+                self.veh_coll_loss.info, self.veh_coll_loss.setup, self.veh_coll_loss.valid, env_agent, env.veh_att, env.mapixes,
+                env.penalty_dists, env.map_env, lambda TO: env._grid_size(NE, TO), self.init_z,
+                (w['coll_veh'], w['coll_env'], w['motion_prior'], w['init_z']))
+        return self._fused
 
     def forward(self, future_pred, z, prior_out):
+        """One HIP call forward, one backward (strive_avoid_coll_fwd/bwd) for the objective; the per-term entries of the
+        reference's dict are evaluated by ``forward_terms`` only when somebody reads them (logging)."""
+        if future_pred.dim() != 3 or not (z.dim() == 2 or (z.dim() == 3 and z.size(1) == 1)) or prior_out[0].dim() != 2 or \
+                prior_out[0].requires_grad or prior_out[1].requires_grad:
+            return self.forward_terms(future_pred, z, prior_out)
+        out = LossDict()
+        loss, _ = ops.avoid_coll_loss(future_pred, z, prior_out[0], prior_out[1], self._setup())
+        out['loss'] = loss
+        terms = {}
+
+        def term(key):
+            def thunk():
+                if not terms:
+                    ft = self.forward_terms(future_pred, z, prior_out)
+                    for k in list(ft.keys()):
+                        terms[k] = ft[k]              # (resolves the lazy lists of that dict)
+                return terms[key]
+            return thunk
+        w = self.loss_weights
+        for key, wk in (('coll_veh_loss', 'coll_veh'), ('coll_env_loss', 'coll_env'), ('motion_prior_loss', 'motion_prior'),
+                        ('init_loss', 'init_z')):
+            if w[wk] > 0.0:
+                out.set_lazy(key, term(key))
+        return out
+
+    def forward_terms(self, future_pred, z, prior_out):
+        """The same objective term by term with torch glue between the HIP kernels (reference :290-341)."""
         w = self.loss_weights
         loss = 0.0
         out = LossDict()

@@ -722,6 +722,104 @@ class _InterpFn(torch.autograd.Function):
         return d_in, None
 
 
+# ------------------------------------------------------------------------------------------------
+# AvoidCollLoss in one call per direction
+# ------------------------------------------------------------------------------------------------
+
+class AvoidCollSetup(object):
+    """Constants of one batch for strive_avoid_coll_fwd/bwd (include/strive_hip.h StriveAvoidColl).  ``veh`` is the
+    VehCollSetup of the batch, ``pair_valid`` (P,) bool, ``env_agent`` (NE,) long, ``env_lw`` (NE,2), ``env_mapix`` (NE,),
+    ``env_pdist`` (NE,), ``grid`` = callable T_fine -> (gl, gw), ``init_z`` (NA,D) or None, ``weights`` the four loss weights
+    in the order (coll_veh, coll_env, motion_prior, init_z)."""
+
+    def __init__(self, info, veh, pair_valid, env_agent, env_lw, env_mapix, env_pdist, map_env, grid, init_z, weights, scale=3):
+        dev = veh.cent_x.device
+        self.lib = veh.lib
+        self.info, self.veh, self.map_env, self.grid, self.scale = info, veh, map_env, grid, int(scale)
+        self.sc = info.pack(1)
+        self.pair_valid = pair_valid.to(torch.uint8).contiguous()
+        self.env_agent = env_agent.to(device=dev, dtype=torch.int32).contiguous()
+        inv = torch.full((info.NA,), -1, dtype=torch.int32, device=dev)
+        inv[env_agent.to(dev).long()] = torch.arange(self.env_agent.numel(), dtype=torch.int32, device=dev)
+        self.env_of_agent = inv
+        self.env_lw = _f32c(env_lw)
+        self.env_mapix = env_mapix.to(device=dev, dtype=torch.int32).contiguous()
+        self.env_pdist = _f32c(env_pdist)
+        self.init_z = None if init_z is None else _f32c(init_z.detach())
+        self.weights = tuple(float(w) for w in weights)
+        self._structs = {}
+
+    def struct_for(self, T, NZ, D, singleton):
+        key = (T, NZ, D, singleton)
+        st = self._structs.get(key)
+        if st is None:
+            dev = self.veh.cent_x.device
+            TO = T * self.scale
+            i0, i1, w0, w1 = _interp_taps(T, self.scale, dev)
+            gl, gw = self.grid(TO) if self.weights[1] > 0.0 and self.env_agent.numel() > 0 else (1, 1)
+            lin_l, lin_w = _linspace_pair(int(gl), int(gw), dev)
+            h = L.StriveAvoidColl()
+            h.pair_off, h.P = self.veh.pair_off.data_ptr(), self.veh.P
+            h.cent_x, h.rad, h.buffer = self.veh.cent_x.data_ptr(), self.veh.rad.data_ptr(), self.veh.buffer
+            h.pair_valid = self.pair_valid.data_ptr()
+            h.i0, h.i1, h.w0, h.w1, h.scale = i0.data_ptr(), i1.data_ptr(), w0.data_ptr(), w1.data_ptr(), self.scale
+            h.NE = self.env_agent.numel()
+            h.env_agent, h.env_of_agent = self.env_agent.data_ptr(), self.env_of_agent.data_ptr()
+            h.env_lw, h.env_mapix, h.env_pdist = self.env_lw.data_ptr(), self.env_mapix.data_ptr(), self.env_pdist.data_ptr()
+            h.gl, h.gw, h.lin_l, h.lin_w = int(gl), int(gw), lin_l.data_ptr(), lin_w.data_ptr()
+            h.init_z = None if self.init_z is None else self.init_z.data_ptr()
+            h.NZ, h.D = NZ, D
+            h.prior_den, h.init_den = float(NZ), float(NZ * D if singleton else NZ)
+            h.w_veh, h.w_env, h.w_prior, h.w_init = self.weights
+            nbytes = self.lib.query('strive_avoid_coll_workspace_bytes', self.sc.ref(), C.byref(h), T)
+            st = (h, (i0, i1, w0, w1, lin_l, lin_w), int(nbytes))
+            self._structs[key] = st
+        return st
+
+
+class _AvoidCollFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, traj, z, mu, var, h):
+        lib = h.lib
+        singleton = z.dim() == 3
+        tr, zc, muc, varc = _f32c(traj), _f32c(z).reshape(z.shape[0], -1), _f32c(mu), _f32c(var)
+        NA, T, _ = tr.shape
+        if zc.shape != muc.shape or zc.shape != varc.shape or (h.init_z is not None and h.init_z.numel() != zc.numel()):
+            raise ValueError('avoid_coll_loss: latent %s, prior %s / %s, init_z %s do not match' % (
+                tuple(z.shape), tuple(mu.shape), tuple(var.shape), None if h.init_z is None else tuple(h.init_z.shape)))
+        ctx.key = (T, zc.shape[0], zc.shape[1], singleton)
+        ctx.zshape = z.shape
+        st, _keep, nbytes = h.struct_for(*ctx.key)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=tr.device)
+        out = torch.empty((8,), dtype=torch.float32, device=tr.device)
+        pk = _map_pack(h.map_env, tr.device)
+        lib.call('strive_avoid_coll_fwd', h.sc.ref(), pk.ref(), C.byref(st), L.ptr(tr), T, L.ptr(zc), L.ptr(muc), L.ptr(varc),
+                 L.ptr(out), L.ptr(ws), nbytes, _stream(tr))
+        ctx.h = h
+        ctx.save_for_backward(tr, zc, muc, varc, ws)
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, d_loss, _d_out):
+        h = ctx.h
+        tr, zc, muc, varc, ws = ctx.saved_tensors
+        NA, T, _ = tr.shape
+        st, _keep, nbytes = h.struct_for(*ctx.key)
+        d_traj = torch.empty_like(tr)
+        d_z = torch.zeros_like(zc)
+        h.lib.call('strive_avoid_coll_bwd', h.sc.ref(), C.byref(st), L.ptr(tr), T, L.ptr(zc), L.ptr(muc), L.ptr(varc),
+                   L.ptr(_f32c(d_loss).reshape(1)), L.ptr(ws), nbytes, L.ptr(d_traj), L.ptr(d_z), _stream(tr))
+        return d_traj, d_z.view(ctx.zshape), None, None, None
+
+
+def avoid_coll_loss(traj, z, mu, var, setup):
+    """-> (loss 0-dim, differentiable w.r.t. traj and z; out (8,) = loss, the four means, the two counts)."""
+    if mu.requires_grad or var.requires_grad:
+        raise NotImplementedError('the fused AvoidCollLoss treats the prior as a constant (the optimisation loops detach it)')
+    return _AvoidCollFn.apply(traj[:, :, :4], z, mu, var, setup)
+
+
 def rect_iou(box_a, lw_a, box_b, lw_b):
     """IoU of P rotated vehicle boxes: poses (P,4) = (x, y, hx, hy), sizes (P,2) = (l, w) -> float64 (P,), NaN where a pose
     contains NaN (HIP kernel; the reference loops over shapely polygons, src/losses/adv_gen_nusc.py:517-623)."""

@@ -411,3 +411,69 @@ def test_rollout_train_backward_single_step(emu, sd):
 def test_rollout_train_backward_two_steps(emu, sd):
     """FT = 2: adds the GRU memory's weight gradients and one map-CNN backward (crop at the detached step-0 pose)."""
     _rollout_train(emu, sd, [2], 2)
+
+
+@pytest.mark.parametrize('single', [False, True])
+def test_avoid_coll_loss_fused(emu, sd, single, monkeypatch):
+    """strive_avoid_coll_fwd/bwd (AvoidCollLoss as one call per direction) against the oracle's term-by-term loss: objective,
+    d/d trajectory and d/d latent; all agents with a (NA,D) latent, and the solution loop's form (environment term and
+    latents for the first agent of each scene only, latent (B,1,D): the init term divides by B*D there)."""
+    from strive_amd import ops
+    from strive_amd.losses.adv_gen_nusc import AvoidCollLoss
+    monkeypatch.setattr(ops, '_lib_for', lambda *tensors: emu)
+    g = golden('g5_losses.npz')
+    batch, map_idx, raster, dx = mg.g5_inputs(None, None)
+    orc = oracle_model(sd)
+    env_p = synth.SyntheticMapEnv(raster, dx)
+    env_o = env_p            # the oracle reads nusc_raster / nusc_dx only
+    veh_att = orc.get_att_normalizer().unnormalize(batch.lw)
+    traj = orc.get_normalizer().unnormalize(torch.from_numpy(g['adv_pred'])).contiguous()
+    NA, B = traj.shape[0], batch.ptr.shape[0] - 1
+    D = 32
+    NZ = B if single else NA
+    shape = (NZ, 1, D) if single else (NZ, D)
+    z0 = synth.f32(synth.counter_uniform((NZ, D), 'emu/avz', -1.0, 1.0))
+    mu = synth.f32(synth.counter_uniform((NZ, D), 'emu/avm', -0.5, 0.5))
+    var = synth.f32(synth.counter_uniform((NZ, D), 'emu/avv', 0.3, 2.0))
+    init = synth.f32(synth.counter_uniform((NZ, D), 'emu/avi', -1.0, 1.0)).view(shape)
+    w = {'coll_veh': 1.5, 'coll_env': 0.7, 'motion_prior': 0.02, 'init_z': 0.3}
+    kw = dict(veh_coll_buffer=0.3)
+    if single:
+        kw.update(single_veh_idx=0, ptr=batch.ptr)
+    else:
+        kw.update(ptr=batch.ptr)
+    mapixes = map_idx[batch.batch]
+
+    def run(loss_fn):
+        tr = traj.clone().requires_grad_(True)
+        z = z0.clone().view(shape).requires_grad_(True)
+        out = loss_fn(tr, z, (mu, var))
+        out['loss'].backward()
+        return out, tr.grad, z.grad
+
+    oo, otr, oz = run(olosses.AvoidColl(w, veh_att, mapixes, env_o, init, **kw))
+    fused = AvoidCollLoss(w, veh_att, mapixes, env_p, init, **kw)
+    po, ptr_, pz = run(fused)
+    assert fused._fused is not None, 'the fused call was not taken'
+    assert len(oo['coll_veh_loss']) > 3 and len(oo['coll_env_loss']) > 3, 'the case must have collisions of both kinds'
+    assert_close(po['loss'].detach(), oo['loss'].detach(), 2e-5, 1e-6, 'loss')
+    # (the collision point is a float64 mean here and an fp32 torch.sum in the oracle: 1e-4 m apart at map coordinates of
+    # 1e3 m, i.e. up to a few 1e-3 of a 0.1 m distance and of its gradient)
+    assert_close(ptr_, otr, 5e-3, 1e-6, 'd traj')
+    assert_close(pz, oz, 1e-4, 1e-7, 'd z')
+    for k in ('coll_veh_loss', 'coll_env_loss', 'motion_prior_loss', 'init_loss'):
+        assert_close(po[k].detach(), oo[k].detach(), 1e-4, 1e-5, k)
+    # one weight at a time (skipped terms must not contribute), and an empty selection
+    for k in w:
+        w1 = {q: (w[q] if q == k else 0.0) for q in w}
+        o1 = run(olosses.AvoidColl(w1, veh_att, mapixes, env_o, init, **kw))
+        p1 = run(AvoidCollLoss(w1, veh_att, mapixes, env_p, init, **kw))
+        assert_close(p1[0]['loss'].detach(), o1[0]['loss'].detach(), 2e-5, 1e-6, 'loss ' + k)
+        if o1[1] is not None:
+            assert_close(p1[1], o1[1], 5e-3, 1e-6, 'd traj ' + k)
+        else:
+            assert float(p1[1].abs().max()) == 0.0
+        if o1[2] is not None:
+            assert_close(p1[2], o1[2], 1e-4, 1e-7, 'd z ' + k)
+        else:
+            assert float(p1[2].abs().max()) == 0.0
