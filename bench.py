@@ -47,19 +47,22 @@ sys.path.insert(0, REPO)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 matrix peak
 PEAK_HBM_GBS = 8000.0              # same guide: HBM3E ~8 TB/s
 # algorithmic FLOPs per agent of each map-CNN kernel (2 * Cout * OH * OW * Cin * k * k), SURVEY.md §8(a) a8
+# (the fifth kernel is the fused tail: conv5 + conv6 + Linear(512, 64) in one launch)
 CONV_FLOPS = [2 * 16 * 125 * 125 * 4 * 49, 2 * 32 * 61 * 61 * 16 * 25, 2 * 64 * 29 * 29 * 32 * 25,
-              2 * 64 * 14 * 14 * 64 * 9, 2 * 128 * 6 * 6 * 64 * 9, 2 * 128 * 2 * 2 * 128 * 9]
+              2 * 64 * 14 * 14 * 64 * 9, 2 * 128 * 6 * 6 * 64 * 9 + 2 * 128 * 2 * 2 * 128 * 9 + 2 * 512 * 64]
 CONV_NAMES = ['conv1b_kernel<true> (fused crop -> conv1)', 'conv_bf6_kernel<conv2>', 'conv_bf6_kernel<conv3>',
-              'conv_bf6_kernel<conv4>', 'conv_bf6s_kernel<conv5>', 'conv_bf6s_kernel<conv6>']
+              'conv_bf6_kernel<conv4>', 'cnn_tail_kernel (conv5 + conv6 + Linear)']
+CONV_LAYER_IDS = [0, 1, 2, 3, 7]      # strive_map_cnn_bench_layer ids of the kernels strive_map_cnn_fwd launches
 # algorithmic HBM bytes per agent of the CNN kernels: input read once + output written once (fp32 activations, uint8 raster)
 CONV_BYTES = [4 * 256 * 256 + 16 * 125 * 125 * 4, (16 * 125 * 125 + 32 * 61 * 61) * 4, (32 * 61 * 61 + 64 * 29 * 29) * 4,
-              (64 * 29 * 29 + 64 * 14 * 14) * 4, (64 * 14 * 14 + 128 * 6 * 6) * 4, (128 * 6 * 6 + 128 * 2 * 2) * 4]
+              (64 * 29 * 29 + 64 * 14 * 14) * 4, (64 * 14 * 14 + 64) * 4]
 # matrix-core work actually issued per algorithmic FLOP and the dense peak it runs against
 # (/opt/skills/guides/MI355X_MICROARCH.md: bf16 / fp16 dense 2516 TFLOP/s, f32 157.3): conv1 = 2 fp16 weight pieces x the
 # uint8 crop, conv2-conv6 = 3 fp16 products per fp32 product (two-piece round-to-nearest split of both operands)
 PEAK_F16_MFMA_TFLOPS = 2516.0
 CONV_ISSUE = [(2, PEAK_F16_MFMA_TFLOPS, 'f16'), (3, PEAK_F16_MFMA_TFLOPS, 'f16'), (3, PEAK_F16_MFMA_TFLOPS, 'f16'),
-              (3, PEAK_F16_MFMA_TFLOPS, 'f16'), (3, PEAK_F16_MFMA_TFLOPS, 'f16'), (3, PEAK_F16_MFMA_TFLOPS, 'f16')]
+              (3, PEAK_F16_MFMA_TFLOPS, 'f16'), (3, PEAK_F16_MFMA_TFLOPS, 'f16')]
+NK = len(CONV_NAMES)
 
 REFINE_WEIGHTS = {'coll_veh': 100.0, 'coll_env': 100.0, 'init_z': 0.01, 'motion_prior': 1.0}   # refine_traffic_optim.cfg:26-29
 ADV_WEIGHTS = {'coll_veh': 20.0, 'coll_veh_plan': 20.0, 'coll_env': 20.0, 'init_z': 0.5, 'init_z_atk': 0.05,
@@ -254,10 +257,10 @@ def time_dominant_kernel(m, env, g, mi, emb, device, reps=20):
     lib.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(pos), mean4, std4, L.ptr(mapix), N, L.ptr(feat), L.ptr(ws), wsb, st)
     torch.cuda.synchronize()
     times = []
-    for layer in range(6):
+    for layer in CONV_LAYER_IDS:
         times.append(_event_time(lambda: lib.call('strive_map_cnn_bench_layer', mp.ref(), cnn.ref(), layer, L.ptr(pos), mean4,
                                                   std4, L.ptr(mapix), N, L.ptr(feat), L.ptr(ws), wsb, st), reps))
-    dom = max(range(6), key=lambda l: times[l])
+    dom = max(range(NK), key=lambda l: times[l])
     mult, peak, mdt = CONV_ISSUE[dom]
     alg = CONV_FLOPS[dom] * N / times[dom] / 1e12          # algorithmic (fp32-equivalent) TFLOP/s
     ach = alg * mult                                       # matrix-core FLOP/s actually issued
@@ -282,10 +285,10 @@ def time_dominant_kernel(m, env, g, mi, emb, device, reps=20):
                 'frac_of_f32_matrix_peak': round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
                 'launch_us': round(times[dom] * 1e6, 2), 'agents_per_launch': N,
                 'all_layers_us': [round(t * 1e6, 2) for t in times],
-                'all_layers_algorithmic_tflops': [round(CONV_FLOPS[l] * N / times[l] / 1e12, 2) for l in range(6)]})
+                'all_layers_algorithmic_tflops': [round(CONV_FLOPS[l] * N / times[l] / 1e12, 2) for l in range(NK)]})
     # byte-bound view of the same launches: algorithmic bytes (input once + output once) / live duration
     bw = {}
-    for l in range(6):
+    for l in range(NK):
         gbs = CONV_BYTES[l] * N / times[l] / 1e9
         bw[CONV_NAMES[l]] = {'algorithmic_bytes': CONV_BYTES[l] * N, 'us': round(times[l] * 1e6, 2), 'GBps': round(gbs, 1),
                              'frac_of_hbm_peak': round(gbs / PEAK_HBM_GBS, 4), 'traffic': _measured_traffic(CONV_NAMES[l])}

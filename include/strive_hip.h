@@ -178,9 +178,11 @@ int strive_map_cnn_fwd(const StriveMap* map, const StriveCNN* cnn, const float* 
 int strive_map_cnn_fwd_from_crop(const StriveCNN* cnn, const uint8_t* crop, int32_t N, float* feat,
                                  void* ws, size_t ws_bytes, strive_stream_t stream);
 
-/* Measurement hook for bench.py: launch ONE kernel of the stack (layer 0 = fused crop+conv1, 1..5 =
- * conv2..6, 6 = GroupNorm+Linear) on the activations a previous strive_map_cnn_fwd over the same N <= 256
- * poses left in `ws`, so a single kernel can be timed with events on the launching stream. */
+/* Measurement hook for bench.py: launch ONE kernel of the stack (layer 0 = fused crop+conv1, 1..3 = conv2..4,
+ * 7 = the fused conv5 + conv6 + Linear kernel strive_map_cnn_fwd runs; 4, 5, 6 = the separate conv5 / conv6 /
+ * GroupNorm+Linear kernels of the training recompute, in that order) on the activations a previous
+ * strive_map_cnn_fwd over the same N poses left in `ws`, so a single kernel can be timed with events on the
+ * launching stream. */
 int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN* cnn, int32_t layer, const float* pos,
                                const float* pos_mean4_host, const float* pos_std4_host, const int32_t* mapix,
                                int32_t N, float* feat, void* ws, size_t ws_bytes, strive_stream_t stream);

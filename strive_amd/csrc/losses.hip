@@ -55,14 +55,28 @@ __global__ __launch_bounds__(256) void veh_coll_fwd_kernel(VehArgs a, float* __r
         const int j = lo + jl;
         float bx[NCIRC], by[NCIRC];
         circle_centres(a, j, t, bx, by);
-        float dmin = 3.0e38f;
-        int am = 0;
+        // min over the 25 centre distances, first index on ties like torch.min.  The correctly rounded square root is
+        // monotonic, so min sqrt(d2) = sqrt(min d2): one square root instead of 25.  Two different d2 can round to the same
+        // distance, and the reference then reports the EARLIER index: the (rare) candidates within 2 ulp of the minimum are
+        // re-checked with their own square root.
+        float d2[NCIRC * NCIRC];
+        float m2 = 3.0e38f;
+#pragma unroll
         for (int p = 0; p < NCIRC; ++p)
+#pragma unroll
             for (int q = 0; q < NCIRC; ++q) {
                 const float dx = ax[p] - bx[q], dy = ay[p] - by[q];
-                const float d = sqrtf(dx * dx + dy * dy);
-                if (d < dmin) { dmin = d; am = p * NCIRC + q; }
+                const float v = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+                d2[p * NCIRC + q] = v;
+                m2 = fminf(m2, v);
             }
+        const float dmin = m2 < 3.0e38f ? sqrtf(m2) : 3.0e38f;      // NaN poses: nothing compares below the sentinel
+        const float thr = m2 * 1.0000005f;
+        int am = NCIRC * NCIRC;
+#pragma unroll
+        for (int k = NCIRC * NCIRC - 1; k >= 0; --k)
+            if (d2[k] <= thr && (d2[k] == m2 || sqrtf(d2[k]) == dmin)) am = k;
+        if (am == NCIRC * NCIRC) am = 0;
         const float pd = (ri + a.rad[j]) + a.buffer;
         pen[base + jl] = 1.0f - dmin / pd;
         hit[base + jl] = (j != i && dmin <= pd) ? 1 : 0;

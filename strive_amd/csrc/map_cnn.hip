@@ -950,6 +950,8 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ in, c
     if (n0 + s < N) feat[(size_t)(n0 + s) * 64 + o] = ((s_p[0][s][o] + s_p[1][s][o]) + (s_p[2][s][o] + s_p[3][s][o])) + bias[o];
 }
 
+#include "map_cnn_tail.h"
+
 // =============================================================================================
 // host side
 // =============================================================================================
@@ -989,7 +991,9 @@ extern "C" size_t strive_map_cnn_workspace_bytes(int32_t N) {
 
 static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos, const float* pmean, const float* pstd,
                    const int32_t* mapix, const uint8_t* crop, int32_t N, float* feat, void* ws, size_t ws_bytes,
-                   hipStream_t stream) {
+                   hipStream_t stream, bool keep_tail_activations = false) {
+    // keep_tail_activations: run conv5, conv6 and the Linear layer as separate kernels that leave their outputs and moments
+    // in `ws` (the training backward reads them); otherwise the fused tail kernel (map_cnn_tail.h)
     if (N == 0) return 0;
     if (ws_bytes < strive_map_cnn_workspace_bytes(N)) {
         strive_set_error("map_cnn: workspace too small (%zu < %zu)", ws_bytes, strive_map_cnn_workspace_bytes(N));
@@ -1031,6 +1035,10 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], n, cnn->xscale[1], cnn->wscale[1], stream);
         launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
         launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, cnn->xscale[3], cnn->wscale[3], stream);
+        if (!keep_tail_activations) {
+            launch_cnn_tail(cnn, act[3], st[3], NPARTS[3], feat + (size_t)n0 * 64, n, stream);
+            continue;
+        }
         launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], n, cnn->xscale[4], cnn->wscale[4], stream);
         launch_bf6s<Bfs6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w6_frag, cnn->b[5], act[5], st[5], n, cnn->xscale[5], cnn->wscale[5], stream);
         hipLaunchKernelGGL(fc_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, act[5], st[5], cnn->gn_g[5], cnn->gn_b[5],
@@ -1057,13 +1065,15 @@ extern "C" int strive_map_cnn_fwd_from_crop(const StriveCNN* cnn, const uint8_t*
 // ---------------------------------------------------------------------------------------------
 // Measurement hook: launch ONE layer of the stack on activations left in `ws` by a previous
 // strive_map_cnn_fwd over the same N (<= 256) poses, so bench.py can time a single kernel with events
-// on the launching stream.  layer 0 = fused crop + conv1, 1..5 = conv2..conv6, 6 = GroupNorm + Linear.
+// on the launching stream.  layer 0 = fused crop + conv1, 1..3 = conv2..conv4, 7 = the fused tail (conv5 + conv6 + Linear: what
+// strive_map_cnn_fwd runs); 4, 5, 6 = the separate conv5 / conv6 / GroupNorm + Linear kernels of the training recompute (4 first:
+// 5 and 6 read what the previous one wrote).
 // ---------------------------------------------------------------------------------------------
 extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN* cnn, int32_t layer, const float* pos,
                                           const float* pos_mean4_host, const float* pos_std4_host, const int32_t* mapix,
                                           int32_t N, float* feat, void* ws, size_t ws_bytes, strive_stream_t stream_) {
     STRIVE_CHECK_ARG(map && cnn && pos && mapix && feat && ws, "null argument");
-    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK_MAX && layer >= 0 && layer <= 22, "bad layer / N");
+    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK_MAX && layer >= 0 && layer <= 27, "bad layer / N");
     STRIVE_CHECK_ARG(ws_bytes >= strive_map_cnn_workspace_bytes(N), "workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
     StriveArena ar(ws, ws_bytes);
@@ -1111,6 +1121,14 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
         case 3: launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], N, cnn->xscale[3], cnn->wscale[3], stream); break;
         case 4: launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], N, cnn->xscale[4], cnn->wscale[4], stream); break;
         case 5: launch_bf6s<Bfs6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w6_frag, cnn->b[5], act[5], st[5], N, cnn->xscale[5], cnn->wscale[5], stream); break;
+        case 7: launch_cnn_tail(cnn, act[3], st[3], NPARTS[3], feat, N, stream); break;      // conv5 + conv6 + Linear, fused
+        case 27: {  // its phase profile: clock sums land in `ws` beyond the activations conv4 left (results in feat stay valid)
+            unsigned long long* tp = reinterpret_cast<unsigned long long*>(act[4]);
+            hipMemsetAsync(tp, 0, 64, stream);
+            launch_cnn_tail(cnn, act[3], st[3], NPARTS[3], feat, N, stream, tp);
+            hipMemcpyAsync(feat, tp, 64, hipMemcpyDeviceToDevice, stream);
+            break;
+        }
         default:
             hipLaunchKernelGGL(fc_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, act[5], st[5], cnn->gn_g[5], cnn->gn_b[5],
                                cnn->fc_wt, cnn->fc_b, feat, N);

@@ -393,7 +393,7 @@ extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, co
         const int n = (N - n0) < ch ? (N - n0) : ch;
         // forward recompute of this chunk: raw convolution outputs and GroupNorm partial sums land in fwd_ws
         int rc = cnn_run(map, cnn, pos + (size_t)n0 * 4, pos_mean4_host, pos_std4_host, mapix + n0, nullptr, n, feat, fwd_ws,
-                         fwd_bytes, stream);
+                         fwd_bytes, stream, /*keep_tail_activations=*/true);
         if (rc) return rc;
         rc = strive_map_crop_u8(map, pos + (size_t)n0 * 4, pos_mean4_host, pos_std4_host, mapix + n0, n, crop, stream_);
         if (rc) return rc;

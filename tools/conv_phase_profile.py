@@ -9,7 +9,7 @@ dev = torch.device('cuda:0')
 m, sd = product_model(device=dev)
 raster, dx = synth.make_raster(1024, 1024, M=2)
 env = synth.SyntheticMapEnv(raster, dx).to(dev)
-n = 256
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 fr = np.zeros((n, 4))
 fr[:, 0] = synth.counter_uniform((n,), 'st/x', 20.0, 236.0); fr[:, 1] = synth.counter_uniform((n,), 'st/y', 20.0, 236.0)
 ang = synth.counter_uniform((n,), 'st/h', -np.pi, np.pi); fr[:, 2], fr[:, 3] = np.cos(ang), np.sin(ang)
@@ -27,7 +27,8 @@ mean4, std4 = L.f4(nm.mean_vals[:4].tolist()), L.f4(nm.std_vals[:4].tolist())
 st = L.stream_ptr(pos)
 lib.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(pos), mean4, std4, L.ptr(mapix), n, L.ptr(feat), L.ptr(ws), wsb, st)
 names = ['stats + first loads', 'staging pass 0', 'MFMA steps pass 0', 'staging pass 1', 'MFMA steps pass 1', 'remaining passes + epilogue']
-for layer, nm_ in ((21, 'conv2'), (22, 'conv3')):
+tail_names = ['prologue (moments, first staging)', 'conv5 passes', 'conv5 epilogue (GN + split)', 'conv6 passes', 'conv6 epilogue', 'Linear']
+for layer, nm_ in ((21, 'conv2'), (22, 'conv3'), (27, 'tail')):
     for rep in range(2):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -37,5 +38,5 @@ for layer, nm_ in ((21, 'conv2'), (22, 'conv3')):
     wgs = int(t[0]); d = t[1:7].astype(np.float64) / max(wgs, 1)
     print('%s: %d workgroups, kernel %.1f us; mean s_memtime ticks per workgroup by phase:' % (nm_, wgs, e0.elapsed_time(e1) * 1e3))
     for k in range(6):
-        print('   %-28s %9.0f ticks  (%4.1f %%)' % (names[k], d[k], 100 * d[k] / d.sum()))
+        print('   %-34s %9.0f ticks  (%4.1f %%)' % ((tail_names if layer == 27 else names)[k], d[k], 100 * d[k] / d.sum()))
     print('   total %.0f ticks per workgroup' % d.sum())
