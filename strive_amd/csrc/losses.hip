@@ -380,7 +380,8 @@ extern "C" int strive_coll_point_rows(const StriveMap* map, const float* fine, i
                                       const float* lin_l, const float* lin_w, float* out_pt, int32_t* out_cnt,
                                       strive_stream_t stream);
 
-#define AV_BLOCKS 240
+#define AV_BLOCKS 1024
+#define NT_AV 256
 #define AV_TERMS 6          // veh sum, veh count, env sum, env count, prior NLL sum, init-z sum
 
 struct AvoidWs {
@@ -453,10 +454,15 @@ __global__ __launch_bounds__(256) void avoid_partial_kernel(AvoidArgs a, double*
     const long long g0 = (long long)blockIdx.x * blockDim.x + tid;
     double acc[AV_TERMS] = {0, 0, 0, 0, 0, 0};
     if (a.w_veh > 0.f) {
-        const long long n = (long long)a.TO * a.P;
-        for (long long i = g0; i < n; i += stride) {
-            const int slot = (int)(i % a.P);
-            if (a.hit[i] && a.valid[slot]) { acc[0] += (double)a.pen[i]; acc[1] += 1.0; }
+        // (t, slot) walked with 32-bit indices: slot fastest, so pen / hit reads are contiguous and `valid` stays in L1
+        const int per_t = (a.P + NT_AV - 1) / NT_AV;                 // slot chunks of one time sample
+        const long long nchunk = (long long)a.TO * per_t;
+        for (long long ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+            const int t = (int)(ch / per_t), slot = (int)(ch - (long long)t * per_t) * NT_AV + tid;
+            if (slot < a.P) {
+                const size_t i = (size_t)t * a.P + slot;
+                if (a.hit[i] && a.valid[slot]) { acc[0] += (double)a.pen[i]; acc[1] += 1.0; }
+            }
         }
     }
     if (a.w_env > 0.f) {
@@ -495,11 +501,12 @@ __global__ __launch_bounds__(64) void avoid_final_kernel(AvoidArgs a, const doub
                                                            double* __restrict__ sums, float* __restrict__ out) {
     __shared__ double s[AV_TERMS];
     const int tid = threadIdx.x;
-    if (tid < AV_TERMS) {
+    // lanes stride over the workgroup partials, then a shuffle tree: a fixed order (deterministic), 16 steps instead of 1024
+    for (int k = 0; k < AV_TERMS; ++k) {
         double v = 0.0;
-        for (int b = 0; b < nblocks; ++b) v += partial[(size_t)b * AV_TERMS + tid];
-        s[tid] = v;
-        sums[tid] = v;
+        for (int b = tid; b < nblocks; b += 64) v += partial[(size_t)b * AV_TERMS + k];
+        v = wave_sum_d(v);
+        if (tid == 0) { s[k] = v; sums[k] = v; }
     }
     __syncthreads();
     if (tid == 0) {
@@ -619,7 +626,7 @@ extern "C" int strive_avoid_coll_fwd(const StriveScenes* sc, const StriveMap* ma
     long long work = (long long)TO * h->P;
     if ((long long)h->NE * TO > work) work = (long long)h->NE * TO;
     if ((long long)h->NZ * h->D > work) work = (long long)h->NZ * h->D;
-    int nb = (int)((work + 1023) / 1024);
+    int nb = (int)((work + 2047) / 2048);
     nb = nb < 1 ? 1 : (nb > AV_BLOCKS ? AV_BLOCKS : nb);
     hipLaunchKernelGGL(avoid_partial_kernel, dim3(nb), dim3(256), 0, st, a, w.partial);
     STRIVE_CHECK_LAUNCH();
