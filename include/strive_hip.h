@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define STRIVE_ABI_VERSION 8
+#define STRIVE_ABI_VERSION 9
 #define STRIVE_HID 128        /* hidden width of every MLP in the reference (models/common.py, interaction_net.py:32,41) */
 #define STRIVE_MAX_LAYERS 4
 #define STRIVE_ZDIM 32
@@ -53,6 +53,14 @@ typedef struct StriveMLP {
     const float* b[STRIVE_MAX_LAYERS];
     const float* ln_g[STRIVE_MAX_LAYERS];
     const float* ln_b[STRIVE_MAX_LAYERS];
+    /* optional (NULL = the layer runs on the vector ALUs from w / wt): W_l * wsc[l] (wf) and its transpose (wbf) split into two
+     * fp16 pieces (w0 = fp16(w) to nearest, w1 = fp16(w - w0)) in the operand order of v_mfma_f32_16x16x32_f16:
+     * [row tile = row / 16][k-step = k / 32][piece][lane 0..63][8 x fp16], lane l = row 16 tile + (l & 15),
+     * k = 32 step + 8 (l >> 4) + j, zero beyond the matrix; rows = outputs and k = inputs for wf, the reverse for wbf.
+     * wsc[l] is a power of two. */
+    const void* wf[STRIVE_MAX_LAYERS];
+    const void* wbf[STRIVE_MAX_LAYERS];
+    float wsc[STRIVE_MAX_LAYERS];
 } StriveMLP;
 
 /* One message-passing round over per-scene cliques; reference src/models/interaction_net.py:16-218

@@ -28,7 +28,8 @@ dp = C.POINTER(C.c_double)
 class StriveMLP(C.Structure):
     _fields_ = [('nlayers', C.c_int32), ('dims', C.c_int32 * (MAXL + 1)),
                 ('w', C.c_void_p * MAXL), ('wt', C.c_void_p * MAXL), ('b', C.c_void_p * MAXL),
-                ('ln_g', C.c_void_p * MAXL), ('ln_b', C.c_void_p * MAXL)]
+                ('ln_g', C.c_void_p * MAXL), ('ln_b', C.c_void_p * MAXL),
+                ('wf', C.c_void_p * MAXL), ('wbf', C.c_void_p * MAXL), ('wsc', C.c_float * MAXL)]
 
 
 class StriveGNN(C.Structure):
@@ -127,7 +128,7 @@ PROTOTYPES = {
 }
 
 
-ABI_VERSION = 8   # include/strive_hip.h STRIVE_ABI_VERSION
+ABI_VERSION = 9   # include/strive_hip.h STRIVE_ABI_VERSION
 
 
 class StriveLib(object):

@@ -111,6 +111,159 @@ __device__ __forceinline__ void dense_lds(const float* in, int in_ld, int IN, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product on the matrix cores, fp32-accurate: out[r][c] (+)= bias[c] + sum_k in[r][k] * W[c][k].
+//
+// Measured (tools/dense_probe.hip, 10 chained 128x128 layers on 4 rows, 128 workgroups): 2.5 us per layer with dense_lds,
+// 0.97 us here.  The VALU form is bound by its weight stream -- 64 dependent-latency 4-byte loads per thread and layer --
+// not by arithmetic; as matrix operands the same 64 KB arrive as 16 coalesced 16-byte loads per lane, all in flight at
+// once, and the multiply-adds cost 24 instructions per wave.
+//
+// Both operands are split into two fp16 pieces (x = x0 + x1 up to 2^-22 |x|, x0 = fp16(x) to nearest, x1 = fp16(x - x0))
+// and three products are accumulated in fp32 by v_mfma_f32_16x16x32_f16 (x0 w0 + x0 w1 + x1 w0; x1 w1 <= 2^-22 is dropped).
+// The weights are split and laid out in fragment order on the host (`frag`, scaled by the power of two `wscale`); every
+// activation ROW is scaled by its own power of two (largest magnitude into [2^14, 2^15)) before the split, so rows of any
+// magnitude -- loss gradients of 1e-9 next to 1e+3 in the backward kernels -- keep 22 significant bits relative to their own
+// largest entry, which is what an fp32 dot product keeps.
+//   frag: [n-tile nt = c / 16][k-step ks = k / 32][piece][lane][8 x fp16]; lane l holds channel 16 nt + (l & 15),
+//         k = 32 ks + 8 (l >> 4) + j; rows / columns beyond (OUT, IN) are zero.
+//   D of one instruction: lane l holds channels 16 nt + 4 (l >> 4) + {0..3} of activation row l & 15.
+// Called by all threads; `out` must not alias `in`; the caller synchronises afterwards (as for dense_lds).
+typedef __attribute__((ext_vector_type(8))) _Float16 mf_f16x8;
+typedef float mf_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int RB>
+struct MfmaScratch {
+    static constexpr int MAXK = RB <= 4 ? 288 : 128;             // padded K the scratch is sized for
+    static constexpr int BYTES = 2 * RB * (2 * MAXK + 16);
+};
+template <int RB>
+__device__ __forceinline__ unsigned char* mfma_scratch() {
+    __shared__ __attribute__((aligned(16))) unsigned char s_mf[MfmaScratch<RB>::BYTES + RB * 4];
+    return s_mf;
+}
+
+__device__ __forceinline__ bool dense_mfma_ok(const void* frag, int RB, int IN, int OUT) {
+    return frag != nullptr && IN >= 32 && OUT >= 32 && ((IN + 31) & ~31) <= (RB <= 4 ? 288 : 128);
+}
+
+template <int RB, bool ACCUM>
+__device__ __forceinline__ void dense_mfma(const float* in, int in_ld, int IN, const uint4* __restrict__ frag, float wscale,
+                                           const float* __restrict__ bias, float* out, int out_ld, int OUT, int tid,
+                                           int nthreads) {
+    static_assert(RB <= 16, "one 16-row tile");
+    const int KS = (IN + 31) >> 5, KP = KS * 32, NTL = (OUT + 15) >> 4;
+    const int BROW = 2 * KP + 16;                                 // bytes per row and piece (+16: rows land in distinct banks)
+    unsigned char* sb = mfma_scratch<RB>();
+    float* s_rs = reinterpret_cast<float*>(sb + MfmaScratch<RB>::BYTES);
+    const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
+    // the weight fragments do not depend on the activations: the first batch (two 16-channel tiles x 4 k-steps = 16 loads per
+    // lane -- the whole layer when it is 128 x 128 and the workgroup has 4 waves) is requested BEFORE the split, so the L2 round
+    // trip runs under it
+    auto load_a = [&](int nt0, int nt1, int ks0, uint4 (&a)[2][4][2]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ks = ks0 + q < KS ? ks0 + q : KS - 1;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                a[0][q][pl] = frag[((size_t)(nt0 * KS + ks) * 2 + pl) * 64 + lane];
+                a[1][q][pl] = frag[((size_t)(nt1 * KS + ks) * 2 + pl) * 64 + lane];
+            }
+        }
+    };
+    uint4 a[2][4][2];
+    {
+        const int f0 = 2 * wave < NTL ? 2 * wave : 0;
+        load_a(f0, f0 + 1 < NTL ? f0 + 1 : f0, 0, a);
+    }
+    // ---- 1. per-row power-of-two scale, split into the two pieces ----
+    for (int r = wave; r < RB; r += nw) {
+        float mx = 0.f;
+        for (int k = lane; k < IN; k += 64) mx = fmaxf(mx, fabsf(in[r * in_ld + k]));
+        mx = wave_max(mx);
+        float sc = 1.f;
+        if (mx > 0.f && mx < 3.0e38f) {
+            int e = 127 + 14 - ((__float_as_int(mx) >> 23) & 255) + 127;       // biased exponent of 2^(14 - floor(log2 mx))
+            e = e < 1 ? 1 : (e > 254 ? 254 : e);
+            sc = __int_as_float(e << 23);
+        }
+        for (int k2 = 2 * lane; k2 < KP; k2 += 128) {
+            const float v0 = k2 < IN ? in[r * in_ld + k2] * sc : 0.f;
+            const float v1 = k2 + 1 < IN ? in[r * in_ld + k2 + 1] * sc : 0.f;
+            const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+            const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
+            uint16_t a0, a1, b0, b1;
+            __builtin_memcpy(&a0, &h0, 2);
+            __builtin_memcpy(&a1, &h1, 2);
+            __builtin_memcpy(&b0, &l0, 2);
+            __builtin_memcpy(&b1, &l1, 2);
+            *reinterpret_cast<uint32_t*>(sb + r * BROW + k2 * 2) = a0 | ((uint32_t)a1 << 16);
+            *reinterpret_cast<uint32_t*>(sb + (RB + r) * BROW + k2 * 2) = b0 | ((uint32_t)b1 << 16);
+        }
+        if (lane == 0) s_rs[r] = 1.0f / (sc * wscale);            // powers of two: exact
+    }
+    __syncthreads();
+    // ---- 2. two 16-channel tiles per wave at a time ----
+    const int row = lane & 15, g = lane >> 4;
+    const int row_eff = row < RB ? row : 0;                       // the D columns of the rows that do not exist are never stored
+    const unsigned char* bp0 = sb + row_eff * BROW + g * 16;
+    const float rs = s_rs[row_eff];
+    bool first = true;
+    for (int nt0 = 2 * wave; nt0 < NTL; nt0 += 2 * nw) {
+        const bool two = nt0 + 1 < NTL;
+        const int nt1 = two ? nt0 + 1 : nt0;
+        mf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int ks0 = 0; ks0 < KS; ks0 += 4) {
+            if (!first) load_a(nt0, nt1, ks0, a);
+            first = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (ks0 + q < KS) {
+                    const unsigned char* bp = bp0 + (ks0 + q) * 64;
+                    const mf_f16x8 b0 = *reinterpret_cast<const mf_f16x8*>(bp);
+                    const mf_f16x8 b1 = *reinterpret_cast<const mf_f16x8*>(bp + RB * BROW);
+                    mf_f16x8 w0, w1;
+                    __builtin_memcpy(&w0, &a[0][q][0], 16);
+                    __builtin_memcpy(&w1, &a[0][q][1], 16);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, b0, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, b1, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, b0, acc0, 0, 0, 0);
+                    __builtin_memcpy(&w0, &a[1][q][0], 16);
+                    __builtin_memcpy(&w1, &a[1][q][1], 16);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, b0, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, b1, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, b0, acc1, 0, 0, 0);
+                }
+            }
+        }
+        if (row < RB) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (t == 1 && !two) break;
+                const mf_f32x4 acc = t ? acc1 : acc0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * (t ? nt1 : nt0) + 4 * g + r;
+                    if (c < OUT) {
+                        float v = fmaf(acc[r], rs, bias ? bias[c] : 0.f);
+                        if (ACCUM) v += out[row * out_ld + c];
+                        out[row * out_ld + c] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// dense_mfma when the layer has fragments and fits, dense_lds (fp32 VALU on Wt) otherwise
+template <int RB, bool ACCUM>
+__device__ __forceinline__ void dense_any(const float* in, int in_ld, int IN, const float* __restrict__ Wt, int ldw,
+                                          const uint4* __restrict__ frag, float wscale, const float* __restrict__ bias,
+                                          float* out, int out_ld, int OUT, int tid, int nthreads) {
+    if (dense_mfma_ok(frag, RB, IN, OUT)) dense_mfma<RB, ACCUM>(in, in_ld, IN, frag, wscale, bias, out, out_ld, OUT, tid, nthreads);
+    else dense_lds<RB, ACCUM>(in, in_ld, IN, Wt, ldw, bias, out, out_ld, OUT, tid, nthreads);
+}
+
 // y = relu(layer_norm(x)) row-wise over N channels (one wave per row, two-pass mean/variance).
 template <int RB>
 __device__ __forceinline__ void ln_relu_rows(const float* x, int x_ld, float* y, int y_ld, int N,
@@ -187,6 +340,9 @@ struct MLPDev {
     const float* b[STRIVE_MAX_LAYERS];
     const float* ln_g[STRIVE_MAX_LAYERS];
     const float* ln_b[STRIVE_MAX_LAYERS];
+    const uint4* wf[STRIVE_MAX_LAYERS];      // matrix-core fragments of W_l (forward) and of W_l^T (input gradient), or null
+    const uint4* wbf[STRIVE_MAX_LAYERS];
+    float wsc[STRIVE_MAX_LAYERS];            // their power-of-two scale
 };
 
 static inline MLPDev mlp_dev(const StriveMLP& m) {
@@ -199,6 +355,9 @@ static inline MLPDev mlp_dev(const StriveMLP& m) {
         d.b[i] = m.b[i];
         d.ln_g[i] = m.ln_g[i];
         d.ln_b[i] = m.ln_b[i];
+        d.wf[i] = reinterpret_cast<const uint4*>(m.wf[i]);
+        d.wbf[i] = reinterpret_cast<const uint4*>(m.wbf[i]);
+        d.wsc[i] = m.wsc[i];
     }
     return d;
 }
@@ -216,8 +375,8 @@ __device__ __forceinline__ void mlp_forward_lds(const MLPDev& m, const float* in
                                                 float* out, int out_ld, bool first_done, int tid, int nthreads) {
     const int L = m.nlayers;
     if (!first_done) {
-        dense_lds<RB, false>(in, in_ld, m.dims[0], m.wt[0], m.dims[1], m.b[0], (L == 1) ? out : pre, (L == 1) ? out_ld : HLD,
-                         m.dims[1], tid, nthreads);
+        dense_any<RB, false>(in, in_ld, m.dims[0], m.wt[0], m.dims[1], m.wf[0], m.wsc[0], m.b[0], (L == 1) ? out : pre,
+                             (L == 1) ? out_ld : HLD, m.dims[1], tid, nthreads);
         __syncthreads();
     }
     for (int l = 1; l < L; ++l) {
@@ -225,8 +384,8 @@ __device__ __forceinline__ void mlp_forward_lds(const MLPDev& m, const float* in
         ln_relu_rows<RB>(p, HLD, act, HLD, m.dims[l], m.ln_g[l - 1], m.ln_b[l - 1], tid, nthreads);
         __syncthreads();
         const bool last = (l == L - 1);
-        dense_lds<RB, false>(act, HLD, m.dims[l], m.wt[l], m.dims[l + 1], m.b[l], last ? out : pre + (size_t)l * RB * HLD,
-                         last ? out_ld : HLD, m.dims[l + 1], tid, nthreads);
+        dense_any<RB, false>(act, HLD, m.dims[l], m.wt[l], m.dims[l + 1], m.wf[l], m.wsc[l], m.b[l],
+                             last ? out : pre + (size_t)l * RB * HLD, last ? out_ld : HLD, m.dims[l + 1], tid, nthreads);
         __syncthreads();
     }
 }
@@ -316,7 +475,8 @@ __device__ __forceinline__ void mlp_backward_lds(const MLPDev& m, const float* p
             wgrad_lds(g, g_ld, m.dims[l + 1], act, HLD, m.dims[l], grads->w[l], m.dims[l], grads->b[l], nrows, tid, nthreads);
         }
         // gradient w.r.t. the post-ReLU activation feeding layer l: gb = g * W_l   (W_l torch layout (out,in))
-        dense_lds<RB, false>(g, g_ld, m.dims[l + 1], m.w[l], m.dims[l], nullptr, gb, HLD, m.dims[l], tid, nthreads);
+        dense_any<RB, false>(g, g_ld, m.dims[l + 1], m.w[l], m.dims[l], m.wbf[l], m.wsc[l], nullptr, gb, HLD, m.dims[l], tid,
+                             nthreads);
         __syncthreads();
         ln_relu_bwd_rows<RB>(p, HLD, gb, HLD, ga, HLD, m.dims[l], m.ln_g[l - 1], m.ln_b[l - 1], tid, nthreads,
                              wg ? grads->ln_g[l - 1] : nullptr, wg ? grads->ln_b[l - 1] : nullptr, nrows);
@@ -327,7 +487,8 @@ __device__ __forceinline__ void mlp_backward_lds(const MLPDev& m, const float* p
     if (!skip_first) {
         if (wg) wgrad_lds(g, g_ld, m.dims[1], in, in_ld, m.dims[0], grads->w[0], m.dims[0], grads->b[0], nrows, tid, nthreads);
         if (din) {
-            dense_lds<RB, false>(g, g_ld, m.dims[1], m.w[0], m.dims[0], nullptr, din, din_ld, m.dims[0], tid, nthreads);
+            dense_any<RB, false>(g, g_ld, m.dims[1], m.w[0], m.dims[0], m.wbf[0], m.wsc[0], nullptr, din, din_ld, m.dims[0], tid,
+                                 nthreads);
             __syncthreads();
         }
     }

@@ -30,6 +30,18 @@ class Packed(object):
         return C.byref(self.struct)
 
 
+def dense_fragments(a, scale):
+    """(M, K) fp32 matrix -> int32 tensor of its two-piece fp16 split (scaled by ``scale``) in the operand order of
+    v_mfma_f32_16x16x32_f16 (include/strive_hip.h StriveMLP.wf): [row tile][k-step][piece][lane][8 x fp16]."""
+    M, K = a.shape
+    MT, KS = (M + 15) // 16, (K + 31) // 32
+    pad = torch.zeros((MT * 16, KS * 32), dtype=torch.float32, device=a.device)
+    pad[:M, :K] = a
+    pieces = _f16_split2(pad, scale, 'dense layer')                           # (2, M', K')
+    fr = pieces.view(2, MT, 16, KS, 4, 8).permute(1, 3, 0, 4, 2, 5).contiguous()     # (tile, step, piece, g, row, j)
+    return fr.view(torch.int16).view(-1, 8).contiguous().view(torch.int32)
+
+
 def _fill_mlp(s, holder, sd, prefix):
     """sd keys ``<prefix>.net.{0,3,6,9}`` Linear, ``.net.{1,4,7}`` LayerNorm
     (reference src/models/common.py:26-39)."""
@@ -44,6 +56,11 @@ def _fill_mlp(s, holder, sd, prefix):
         s.w[k] = holder.hold(w)
         s.wt[k] = holder.hold(w.t().contiguous())
         s.b[k] = holder.hold(b)
+        if w.shape[0] >= 32 and w.shape[1] >= 32:          # matrix-core operands (csrc/mlp_dev.h dense_mfma)
+            sc = _pow2_scale(float(w.abs().max()))
+            s.wsc[k] = sc
+            s.wf[k] = holder.hold(dense_fragments(w, sc))
+            s.wbf[k] = holder.hold(dense_fragments(w.t().contiguous(), sc))
         gk = prefix + '.net.%d.weight' % (3 * k + 1)
         if gk in sd:
             s.ln_g[k] = holder.hold(_c(sd[gk]))
