@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define STRIVE_ABI_VERSION 9
+#define STRIVE_ABI_VERSION 10
 #define STRIVE_HID 128        /* hidden width of every MLP in the reference (models/common.py, interaction_net.py:32,41) */
 #define STRIVE_MAX_LAYERS 4
 #define STRIVE_ZDIM 32
@@ -307,6 +307,37 @@ int strive_avoid_coll_fwd(const StriveScenes* sc, const StriveMap* map, const St
 int strive_avoid_coll_bwd(const StriveScenes* sc, const StriveAvoidColl* h, const float* traj, int32_t T, const float* z,
                           const float* mu, const float* var, const float* d_loss, void* ws, size_t ws_bytes,
                           float* d_traj, float* d_z, strive_stream_t stream);
+
+/* AdvGenLoss (reference src/losses/adv_gen_nusc.py:53-262) as one call per direction.  `base` carries what it shares with
+ * AvoidCollLoss: the pair penalties (pair_valid = i != j), the up-sampling taps, the environment term over the NON-EGO agents
+ * (env_agent = their agent indices, NE = NA - B; the latent tensors z / mu / var / init_z have one row per non-ego agent in
+ * the same order, so base.NZ = NE) and the latent size.  base.w_veh / w_env / w_prior / w_init are the weights 'coll_veh',
+ * 'coll_env', 'motion_prior', 'init_z'; base.prior_den = NE, base.init_den is unused (the init term is a plain sum, :216-223). */
+typedef struct StriveAdvGen {
+    StriveAvoidColl base;
+    const int32_t* ne_ptr;       /* (B+1)  offsets of every scene's non-ego agents in the non-ego order */
+    const int32_t* slot_ne;      /* (P)    non-ego row of the non-ego member of a pair slot that involves the scene's ego, else -1 */
+    const uint8_t* atk_mask;     /* (NE)   1 = may be the attacker (attack_agt_idx, :126-130), or NULL = everybody */
+    int32_t t0;                  /* crash_loss_min_time */
+    int32_t use_infront;         /* crash_loss_min_infront given? */
+    float infront;
+    float w_crash, w_plan, w_prior_atk, w_init_atk;   /* 'adv_crash', 'coll_veh_plan', 'motion_prior_atk', 'init_z_atk' */
+} StriveAdvGen;
+
+size_t strive_adv_gen_workspace_bytes(const StriveScenes* sc, const StriveAdvGen* h, int32_t T);
+
+/* traj (NA,T,4) and tgt (B,T,4) unnormalised; z / mu / var (NE,D).  out (16 floats): loss, mean colliding non-ego pair
+ * penalty, mean weighted planner-pair penalty, mean off-road penalty, mean weighted prior NLL, weighted init-z sum, mean crash
+ * term, the four counts (pairs, planner pairs, off-road rows, 1 if every attacker was always behind its target), 0...
+ * soft (NE, T - t0): the per-scene soft-min weights (:133-135), rew (NE): 1 - their sum per agent. */
+int strive_adv_gen_fwd(const StriveScenes* sc, const StriveMap* map, const StriveAdvGen* h, const float* traj, const float* tgt,
+                       int32_t T, const float* z, const float* mu, const float* var, float* out, float* soft, float* rew,
+                       void* ws, size_t ws_bytes, strive_stream_t stream);
+
+/* d_loss: one float on the device.  d_traj (NA,T,4), d_tgt (B,T,4) and d_z (NE,D) are overwritten. */
+int strive_adv_gen_bwd(const StriveScenes* sc, const StriveAdvGen* h, const float* traj, const float* tgt, int32_t T,
+                       const float* z, const float* mu, const float* var, const float* d_loss, void* ws, size_t ws_bytes,
+                       float* d_traj, float* d_tgt, float* d_z, strive_stream_t stream);
 
 /* strive_coll_point over the rows (e, t) of an up-sampled trajectory tensor without expanding the per-agent attributes:
  * car = fine[agent_of[e]*TO + t], size lw[e], map mapix[e]; out_pt (NE*TO,2), out_cnt (NE*TO). */

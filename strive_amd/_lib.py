@@ -70,6 +70,12 @@ class StriveAvoidColl(C.Structure):
                 ('w_veh', C.c_float), ('w_env', C.c_float), ('w_prior', C.c_float), ('w_init', C.c_float)]
 
 
+class StriveAdvGen(C.Structure):
+    _fields_ = [('base', StriveAvoidColl), ('ne_ptr', C.c_void_p), ('slot_ne', C.c_void_p), ('atk_mask', C.c_void_p),
+                ('t0', C.c_int32), ('use_infront', C.c_int32), ('infront', C.c_float), ('w_crash', C.c_float),
+                ('w_plan', C.c_float), ('w_prior_atk', C.c_float), ('w_init_atk', C.c_float)]
+
+
 class StriveDecoder(C.Structure):
     _fields_ = [('gnn', StriveGNN), ('gru', StriveGRU), ('cnn', StriveCNN), ('map', StriveMap),
                 ('state_mean', C.c_float * 6), ('state_std', C.c_float * 6),
@@ -112,6 +118,10 @@ PROTOTYPES = {
     'strive_avoid_coll_fwd': (C.c_int, [C.POINTER(StriveScenes), C.POINTER(StriveMap), C.POINTER(StriveAvoidColl), P, I, P, P, P,
                                         P, P, SZ, P]),
     'strive_avoid_coll_bwd': (C.c_int, [C.POINTER(StriveScenes), C.POINTER(StriveAvoidColl), P, I, P, P, P, P, P, SZ, P, P, P]),
+    'strive_adv_gen_workspace_bytes': (SZ, [C.POINTER(StriveScenes), C.POINTER(StriveAdvGen), I]),
+    'strive_adv_gen_fwd': (C.c_int, [C.POINTER(StriveScenes), C.POINTER(StriveMap), C.POINTER(StriveAdvGen), P, P, I, P, P, P, P, P,
+                                     P, P, SZ, P]),
+    'strive_adv_gen_bwd': (C.c_int, [C.POINTER(StriveScenes), C.POINTER(StriveAdvGen), P, P, I, P, P, P, P, P, SZ, P, P, P, P]),
     'strive_coll_point_rows': (C.c_int, [C.POINTER(StriveMap), P, I, P, P, P, I, I, I, P, P, P, P, P]),
     'strive_mlp_param_count': (SZ, [C.POINTER(StriveMLP)]),
     'strive_gnn_param_count': (SZ, [C.POINTER(StriveGNN)]),
@@ -128,7 +138,7 @@ PROTOTYPES = {
 }
 
 
-ABI_VERSION = 9   # include/strive_hip.h STRIVE_ABI_VERSION
+ABI_VERSION = 10   # include/strive_hip.h STRIVE_ABI_VERSION
 
 
 class StriveLib(object):

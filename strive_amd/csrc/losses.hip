@@ -89,9 +89,14 @@ __global__ __launch_bounds__(256) void veh_coll_fwd_kernel(VehArgs a, float* __r
 struct VehImplicit {
     const uint8_t* hit;       // (T,P)
     const uint8_t* valid;     // (P)
-    const double* sums;       // [1] = number of colliding valid slots
+    const double* sums;       // [1] = number of colliding valid slots ([7] = of planner slots, see slot_ne)
     const float* d_loss;      // device scalar
     float w;
+    // AdvGenLoss: slots that involve the scene's ego form a second masked mean, weighted per slot by rew of the non-ego
+    // member (reference :192-204); slot_ne = that member's non-ego row, -1 for the other slots; null = one mean over all
+    const int32_t* slot_ne;
+    const float* rew;
+    float w2;
 };
 
 // d_traj[i][t] += sum_j [ d_pen(i,j) * dpen(i,j)/dpose_i  +  d_pen(j,i) * dpen(j,i)/dpose_i ]
@@ -111,11 +116,23 @@ __global__ __launch_bounds__(256) void veh_coll_bwd_kernel(VehArgs a, const floa
     const float ri = a.rad[i];
     const int il = i - lo;
     float g[4] = {0.f, 0.f, 0.f, 0.f};
-    float gs = 0.f;
+    float gs = 0.f, gs2 = 0.f;
     if (IMPL) {
         const double c = im.sums[1];
         gs = (float)((double)im.d_loss[0] * (double)im.w / (c < 1.0 ? 1.0 : c));
+        if (im.slot_ne) {
+            const double c2 = im.sums[7];
+            gs2 = (float)((double)im.d_loss[0] * (double)im.w2 / (c2 < 1.0 ? 1.0 : c2));
+        }
     }
+    auto slot_grad = [&](size_t s, int slot) -> float {
+        if (!(im.hit[s] && im.valid[slot])) return 0.f;
+        if (im.slot_ne) {
+            const int ne = im.slot_ne[slot];
+            if (ne >= 0) return gs2 * im.rew[ne];
+        }
+        return gs;
+    };
     for (int jl = sub; live && jl < n; jl += VG) {
         const int j = lo + jl;
         if (j == i) continue;
@@ -125,7 +142,7 @@ __global__ __launch_bounds__(256) void veh_coll_bwd_kernel(VehArgs a, const floa
         // pair (i, j): i is the first member
         {
             const size_t s = (size_t)t * a.P + a.pair_off[i] + jl;
-            const float gp = IMPL ? ((im.hit[s] && im.valid[a.pair_off[i] + jl]) ? gs : 0.f) : d_pen[s];
+            const float gp = IMPL ? slot_grad(s, a.pair_off[i] + jl) : d_pen[s];
             if (gp != 0.f) {
                 const int am = amin[s];
                 const int p = am / NCIRC, q = am - p * NCIRC;
@@ -142,7 +159,7 @@ __global__ __launch_bounds__(256) void veh_coll_bwd_kernel(VehArgs a, const floa
         // pair (j, i): i is the second member
         {
             const size_t s = (size_t)t * a.P + a.pair_off[j] + il;
-            const float gp = IMPL ? ((im.hit[s] && im.valid[a.pair_off[j] + il]) ? gs : 0.f) : d_pen[s];
+            const float gp = IMPL ? slot_grad(s, a.pair_off[j] + il) : d_pen[s];
             if (gp != 0.f) {
                 const int am = amin[s];
                 const int p = am / NCIRC, q = am - p * NCIRC;   // p indexes j's circles, q indexes i's
@@ -196,7 +213,7 @@ extern "C" int strive_veh_coll_bwd(const StriveScenes* sc, const int32_t* pair_o
     const long long n = (long long)sc->NA * T * VG;
     if (n <= 0) return 0;
     hipLaunchKernelGGL(veh_coll_bwd_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       veh_args(sc, pair_off, P, traj, T, cent_x, rad, buffer), d_pen, amin, d_traj, VehImplicit());
+                       veh_args(sc, pair_off, P, traj, T, cent_x, rad, buffer), d_pen, amin, d_traj, VehImplicit{});
     STRIVE_CHECK_LAUNCH();
     return 0;
 }
@@ -657,6 +674,7 @@ extern "C" int strive_avoid_coll_bwd(const StriveScenes* sc, const StriveAvoidCo
     if (h->w_veh > 0.f && h->P > 0) {
         VehImplicit im;
         im.hit = w.hit; im.valid = h->pair_valid; im.sums = w.sums; im.d_loss = d_loss; im.w = h->w_veh;
+        im.slot_ne = nullptr; im.rew = nullptr; im.w2 = 0.f;
         const long long nv = (long long)NA * TO * VG;
         hipLaunchKernelGGL(veh_coll_bwd_kernel<true>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st,
                            veh_args(sc, h->pair_off, h->P, w.fine, TO, h->cent_x, h->rad, h->buffer), (const float*)nullptr,
@@ -664,4 +682,473 @@ extern "C" int strive_avoid_coll_bwd(const StriveScenes* sc, const StriveAvoidCo
         STRIVE_CHECK_LAUNCH();
     }
     return strive_interp_traj_bwd(traj, w.d_fine, NA, T, TO, h->scale, h->i0, h->i1, h->w0, h->w1, d_traj, stream);
+}
+
+
+// =============================================================================================
+// AdvGenLoss in one call per direction (reference src/losses/adv_gen_nusc.py:53-262).
+//   forward : interp -> veh_coll_fwd -> coll_point (non-ego rows) -> adv_crash (one workgroup per scene: distances to the
+//             target, behind test, per-scene soft-min, crash term, prior re-weights) -> adv_partial -> adv_final   (6 launches)
+//   backward: adv_grad (environment term, d_z) -> veh_coll_bwd<implicit, per-slot weights> -> interp_bwd -> adv_crash_bwd
+// against ~140 + ~110 elementwise / scatter torch operators.  The "every attacker is always behind its target" escape
+// (:120-123) is a property of the whole batch: adv_crash evaluates the soft-min with and without the behind mask and leaves a
+// per-scene flag; the kernels after it form the batch-wide AND themselves and pick the variant.
+// =============================================================================================
+#define ADV_TERMS 8         // veh sum, veh count, env sum, env count, weighted prior sum, weighted init sum, planner sum, planner count
+#define ADV_MAXE 1024       // (non-ego agents of a scene) x (crash time samples) the crash kernel keeps in LDS
+
+struct AdvWs {
+    AvoidWs av;
+    double* partial;        // (AV_BLOCKS, ADV_TERMS)
+    double* sums;           // (ADV_TERMS)
+    float* soft2;           // (2, NE, NT)   variant 0 = with the behind mask, 1 = without
+    float* rew2;            // (2, NE)
+    float* crash2;          // (2, B)
+    int32_t* scene_flag;    // (B) 1 = every non-ego agent of the scene is always behind
+    int32_t* sel;           // (1) chosen variant
+    float* rew_sel;         // (NE) re-weights of the chosen variant (the backward kernels read these)
+};
+
+static size_t adv_ws_bytes(size_t NA, size_t TO, size_t P, size_t NE, size_t NT, size_t B) {
+    return avoid_ws_bytes(NA, TO, P, NE) + strive_align_up((size_t)AV_BLOCKS * ADV_TERMS * 8, 256) + 256 +
+           strive_align_up(2 * NE * NT * 4, 256) + strive_align_up(2 * NE * 4, 256) + strive_align_up(2 * B * 4, 256) +
+           strive_align_up(B * 4, 256) + strive_align_up(NE * 4, 256) + 256 + 256;
+}
+
+static AdvWs adv_carve(void* p, size_t bytes, size_t NA, size_t TO, size_t P, size_t NE, size_t NT, size_t B) {
+    const size_t ab = avoid_ws_bytes(NA, TO, P, NE);
+    AdvWs w;
+    w.av = avoid_carve(p, ab, NA, TO, P, NE);
+    StriveArena ar((char*)p + ab, bytes - ab);
+    w.partial = ar.take<double>((size_t)AV_BLOCKS * ADV_TERMS);
+    w.sums = ar.take<double>(ADV_TERMS);
+    w.soft2 = ar.take<float>(2 * NE * NT);
+    w.rew2 = ar.take<float>(2 * NE);
+    w.crash2 = ar.take<float>(2 * B);
+    w.scene_flag = ar.take<int32_t>(B);
+    w.sel = ar.take<int32_t>(1);
+    w.rew_sel = ar.take<float>(NE);
+    return w;
+}
+
+struct AdvArgs {
+    AvoidArgs a;
+    int B, T, t0, NT, use_infront;
+    float infront;
+    const float* traj;          // (NA,T,4)
+    const float* tgt;           // (B,T,4)
+    const int32_t* ne_ptr;
+    const int32_t* nonego;      // (NE) agent index
+    const int32_t* slot_ne;
+    const uint8_t* atk_mask;
+    float w_crash, w_plan, w_prior_atk, w_init_atk;
+    float* soft2;
+    float* rew2;
+    float* crash2;
+    int32_t* scene_flag;
+    float* rew_sel;
+};
+
+// block-wide reductions of a 256-thread workgroup in a fixed order (wave tree, then waves 0..3)
+__device__ __forceinline__ double block_sum_d(double v, double* s_red, int tid) {
+    v = wave_sum_d(v);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    __syncthreads();
+    return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+__device__ __forceinline__ float block_max_f(float v, float* s_red, int tid) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+}
+
+// one workgroup per scene
+__global__ __launch_bounds__(256) void adv_crash_kernel(AdvArgs A) {
+    __shared__ float s_d[ADV_MAXE];
+    __shared__ float s_s[ADV_MAXE];
+    __shared__ int s_nb[64];             // per non-ego agent: time samples at which it is NOT behind the target
+    __shared__ double s_redd[4];
+    __shared__ float s_redf[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int a0 = A.ne_ptr[b], n = A.ne_ptr[b + 1] - a0, NT = A.NT, E = n * NT;
+    if (tid < 64) s_nb[tid] = 0;
+    __syncthreads();
+    for (int e = tid; e < E; e += 256) {
+        const int al = e / NT, t = e - al * NT;
+        const float* p = A.traj + ((size_t)A.nonego[a0 + al] * A.T + A.t0 + t) * 4;
+        const float* q = A.tgt + ((size_t)b * A.T + A.t0 + t) * 4;
+        const float dx = p[0] - q[0], dy = p[1] - q[1];
+        const float d = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+        s_d[e] = d;
+        if (A.use_infront) {
+            // behind <=> (atk - tgt) / |atk - tgt| . heading(tgt) < threshold   (reference :646-673); NaN compares false
+            const float dot = __fadd_rn(__fmul_rn(dx / d, q[2]), __fmul_rn(dy / d, q[3]));
+            if (!(dot < A.infront)) atomicAdd(&s_nb[al], 1);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int all_always = A.use_infront ? 1 : 0;
+        for (int al = 0; al < n; ++al) all_always &= (s_nb[al] == 0);
+        A.scene_flag[b] = all_always;            // (an empty scene leaves 1: it does not veto the batch-wide test)
+    }
+    for (int v = 0; v < 2; ++v) {
+        float mx = -3.0e38f;
+        bool any = false;
+        for (int e = tid; e < E; e += 256) {
+            const int al = e / NT;
+            const bool masked = (v == 0 && A.use_infront && s_nb[al] == 0) || (A.atk_mask && !A.atk_mask[a0 + al]);
+            const float d = s_d[e];
+            if (!masked && !(d != d)) { mx = fmaxf(mx, -d); any = true; }
+        }
+        mx = block_max_f(mx, s_redf, tid);
+        double den = 0.0;
+        for (int e = tid; e < E; e += 256) {
+            const int al = e / NT;
+            const bool masked = (v == 0 && A.use_infront && s_nb[al] == 0) || (A.atk_mask && !A.atk_mask[a0 + al]);
+            const float ex = masked ? 0.f : expf(-s_d[e] - mx);
+            s_s[e] = ex;
+            den += (double)ex;
+        }
+        (void)any;
+        den = block_sum_d(den, s_redd, tid);
+        const bool dead = !(den > 0.0) || mx <= -3.0e38f;          // nothing unmasked (or NaN distances): all weights 0 (:134-135)
+        double cr = 0.0;
+        for (int e = tid; e < E; e += 256) {
+            const float sft = dead ? 0.f : (float)((double)s_s[e] / den);
+            s_s[e] = sft;
+            const float d = s_d[e];
+            cr += (double)(sft * (d * d));
+            A.soft2[((size_t)v * A.a.NE + a0) * NT + e] = sft;
+        }
+        cr = block_sum_d(cr, s_redd, tid);
+        if (tid == 0) A.crash2[(size_t)v * A.B + b] = (float)cr;
+        for (int al = tid; al < n; al += 256) {
+            float sm = 0.f;
+            for (int t = 0; t < NT; ++t) sm += s_s[al * NT + t];
+            A.rew2[(size_t)v * A.a.NE + a0 + al] = 1.0f - sm;
+        }
+        __syncthreads();
+    }
+}
+
+// batch-wide "everybody is always behind" test -> variant 1 (no behind mask); every workgroup that needs it forms it itself
+__device__ __forceinline__ int adv_select(const int32_t* scene_flag, int B, int use_infront, int tid) {
+    __shared__ int s_all;
+    if (tid == 0) s_all = use_infront ? 1 : 0;
+    __syncthreads();
+    int all = 1;
+    for (int b = tid; b < B; b += blockDim.x) all &= scene_flag[b];
+    if (!all) s_all = 0;                 // (every writer stores the same value)
+    __syncthreads();
+    return s_all;
+}
+
+__global__ __launch_bounds__(256) void adv_partial_kernel(AdvArgs A, double* __restrict__ partial) {
+    __shared__ double s_red[4][ADV_TERMS];
+    const AvoidArgs& a = A.a;
+    const int tid = threadIdx.x;
+    const int sel = adv_select(A.scene_flag, A.B, A.use_infront, tid);
+    const float* rew = A.rew2 + (size_t)sel * a.NE;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long g0 = (long long)blockIdx.x * blockDim.x + tid;
+    double acc[ADV_TERMS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (a.w_veh > 0.f || A.w_plan > 0.f) {
+        const int per_t = (a.P + NT_AV - 1) / NT_AV;
+        const long long nchunk = (long long)a.TO * per_t;
+        for (long long ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+            const int t = (int)(ch / per_t), slot = (int)(ch - (long long)t * per_t) * NT_AV + tid;
+            if (slot < a.P) {
+                const size_t i = (size_t)t * a.P + slot;
+                if (a.hit[i] && a.valid[slot]) {
+                    const int ne = A.slot_ne[slot];
+                    if (ne >= 0) {
+                        if (A.w_plan > 0.f) { acc[6] += (double)(a.pen[i] * rew[ne]); acc[7] += 1.0; }
+                    } else if (a.w_veh > 0.f) {
+                        acc[0] += (double)a.pen[i];
+                        acc[1] += 1.0;
+                    }
+                }
+            }
+        }
+    }
+    if (a.w_env > 0.f) {
+        const long long n = (long long)a.NE * a.TO;
+        for (long long i = g0; i < n; i += stride) {
+            float dx, dy, d, pd;
+            if (env_row(a, (int)i, dx, dy, d, pd)) { acc[2] += (double)(1.0f - d / pd); acc[3] += 1.0; }
+        }
+    }
+    if (a.w_prior > 0.f || a.w_init > 0.f) {
+        const long long n = (long long)a.NZ * a.D;
+        for (long long i = g0; i < n; i += stride) {
+            const int r = (int)(i / a.D);
+            const float rw = rew[r];
+            const float z = a.z[i];
+            if (a.w_prior > 0.f) {
+                const float m = a.mu[i], v = a.var[i];
+                const float dz = z - m;
+                const float lp = -logf(sqrtf(v)) - 0.91893853320467267f - (dz * dz) / (2.0f * v);
+                acc[4] -= (double)(lp * (rw * a.w_prior + (1.0f - rw) * A.w_prior_atk));
+            }
+            if (a.w_init > 0.f) {
+                const float di = a.init_z[i] - z;
+                acc[5] += (double)((di * di) * (rw * a.w_init + (1.0f - rw) * A.w_init_atk));
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < ADV_TERMS; ++k) acc[k] = wave_sum_d(acc[k]);
+    if ((tid & 63) == 0)
+        for (int k = 0; k < ADV_TERMS; ++k) s_red[tid >> 6][k] = acc[k];
+    __syncthreads();
+    if (tid < ADV_TERMS) partial[(size_t)blockIdx.x * ADV_TERMS + tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+}
+
+__global__ __launch_bounds__(64) void adv_final_kernel(AdvArgs A, const double* __restrict__ partial, int nblocks,
+                                                         double* __restrict__ sums, int32_t* __restrict__ sel_out,
+                                                         float* __restrict__ out, float* __restrict__ soft,
+                                                         float* __restrict__ rew) {
+    __shared__ double s[ADV_TERMS + 1];
+    const AvoidArgs& a = A.a;
+    const int tid = threadIdx.x;
+    const int sel = adv_select(A.scene_flag, A.B, A.use_infront, tid);
+    for (int k = 0; k < ADV_TERMS; ++k) {
+        double v = 0.0;
+        for (int b = tid; b < nblocks; b += 64) v += partial[(size_t)b * ADV_TERMS + k];
+        v = wave_sum_d(v);
+        if (tid == 0) { s[k] = v; sums[k] = v; }
+    }
+    {
+        double v = 0.0;
+        for (int b = tid; b < A.B; b += 64) v += (double)A.crash2[(size_t)sel * A.B + b];
+        v = wave_sum_d(v);
+        if (tid == 0) s[ADV_TERMS] = v;
+    }
+    // the selected soft-min weights and re-weights, for the caller (return_mins, logging)
+    for (long long i = tid; i < (long long)a.NE * A.NT; i += 64) soft[i] = A.soft2[(size_t)sel * a.NE * A.NT + i];
+    for (int i = tid; i < a.NE; i += 64) {
+        const float rv = A.rew2[(size_t)sel * a.NE + i];
+        rew[i] = rv;
+        A.rew_sel[i] = rv;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double veh = s[0] / (s[1] < 1.0 ? 1.0 : s[1]);
+        const double env = s[2] / (s[3] < 1.0 ? 1.0 : s[3]);
+        const double plan = s[6] / (s[7] < 1.0 ? 1.0 : s[7]);
+        const double pri = a.NZ > 0 ? s[4] / (double)a.NZ : 0.0;
+        const double ini = s[5];
+        const double crash = A.B > 0 ? s[ADV_TERMS] / (double)A.B : 0.0;
+        double loss = 0.0;
+        if (a.w_init > 0.f) loss += ini;
+        if (a.w_prior > 0.f) loss += pri;
+        if (a.w_veh > 0.f) loss += (double)a.w_veh * veh;
+        if (A.w_plan > 0.f) loss += (double)A.w_plan * plan;
+        if (a.w_env > 0.f) loss += (double)a.w_env * env;
+        if (A.w_crash > 0.f) loss += (double)A.w_crash * crash;
+        sel_out[0] = sel;
+        out[0] = (float)loss;
+        out[1] = (float)veh;
+        out[2] = (float)plan;
+        out[3] = (float)env;
+        out[4] = (float)pri;
+        out[5] = (float)ini;
+        out[6] = (float)crash;
+        out[7] = (float)s[1];
+        out[8] = (float)s[7];
+        out[9] = (float)s[3];
+        out[10] = (float)sel;
+        for (int k = 11; k < 16; ++k) out[k] = 0.f;
+    }
+}
+
+// d_fine of the environment term (all rows written, like avoid_grad_kernel) and d_z
+__global__ __launch_bounds__(256) void adv_grad_kernel(AdvArgs A, const int32_t* __restrict__ env_of_agent,
+                                                         const double* __restrict__ sums, const int32_t* __restrict__ sel_p,
+                                                         const float* __restrict__ d_loss, float* __restrict__ d_fine,
+                                                         float* __restrict__ d_z) {
+    const AvoidArgs& a = A.a;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n_rows = (long long)a.NA * a.TO;
+    const float gl = d_loss[0];
+    if (idx < n_rows) {
+        const int ag = (int)(idx / a.TO), t = (int)(idx - (long long)ag * a.TO);
+        float gx = 0.f, gy = 0.f;
+        const int e = (a.w_env > 0.f && env_of_agent) ? env_of_agent[ag] : -1;
+        if (e >= 0) {
+            float dx, dy, d, pd;
+            if (env_row(a, e * a.TO + t, dx, dy, d, pd) && d > 0.f) {
+                const double c = sums[3];
+                const float gs = (float)((double)gl * (double)a.w_env / (c < 1.0 ? 1.0 : c));
+                const float k = -gs / (d * pd);
+                gx = k * dx;
+                gy = k * dy;
+            }
+        }
+        float* o = d_fine + (size_t)idx * 4;
+        o[0] = gx; o[1] = gy; o[2] = 0.f; o[3] = 0.f;
+        return;
+    }
+    const long long i = idx - n_rows;
+    if (i < (long long)a.NZ * a.D) {
+        const float rw = A.rew_sel[(int)(i / a.D)];
+        const float z = a.z[i];
+        float g = 0.f;
+        if (a.w_prior > 0.f) g += gl * (rw * a.w_prior + (1.0f - rw) * A.w_prior_atk) / (float)a.NZ * ((z - a.mu[i]) / a.var[i]);
+        if (a.w_init > 0.f) g += gl * (rw * a.w_init + (1.0f - rw) * A.w_init_atk) * (2.0f * (z - a.init_z[i]));
+        d_z[i] = g;
+    }
+}
+
+// crash term: L = w/B sum_b sum_e s_e d_e^2 with s = softmin(d) over the scene's unmasked entries
+//   dL/dd_e = w/B * s_e * (2 d_e + C_b - d_e^2),  C_b = sum_e s_e d_e^2;   dd/d(atk xy) = (atk - tgt) / d = -dd/d(tgt xy)
+// one workgroup per scene: adds into d_traj (non-ego rows, time >= t0; interp_bwd has written them) and writes d_tgt
+__global__ __launch_bounds__(256) void adv_crash_bwd_kernel(AdvArgs A, const int32_t* __restrict__ sel_p,
+                                                              const float* __restrict__ d_loss, float* __restrict__ d_traj,
+                                                              float* __restrict__ d_tgt) {
+    __shared__ float s_gx[ADV_MAXE], s_gy[ADV_MAXE];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int sel = sel_p[0];
+    const int a0 = A.ne_ptr[b], n = A.ne_ptr[b + 1] - a0, NT = A.NT, E = n * NT;
+    const float C = A.crash2[(size_t)sel * A.B + b];
+    const float gw = A.w_crash > 0.f ? d_loss[0] * A.w_crash / (float)A.B : 0.f;
+    for (int e = tid; e < E; e += 256) {
+        const int al = e / NT, t = e - al * NT;
+        float* gp = d_traj + ((size_t)A.nonego[a0 + al] * A.T + A.t0 + t) * 4;
+        const float* p = A.traj + ((size_t)A.nonego[a0 + al] * A.T + A.t0 + t) * 4;
+        const float* q = A.tgt + ((size_t)b * A.T + A.t0 + t) * 4;
+        const float dx = p[0] - q[0], dy = p[1] - q[1];
+        const float d = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+        const float sft = A.soft2[((size_t)sel * A.a.NE + a0) * NT + e];
+        float gx = 0.f, gy = 0.f;
+        if (sft != 0.f && d > 0.f) {
+            const float gd = gw * sft * (2.0f * d + C - d * d);
+            gx = gd * dx / d;
+            gy = gd * dy / d;
+        }
+        gp[0] += gx;
+        gp[1] += gy;
+        s_gx[e] = gx;
+        s_gy[e] = gy;
+    }
+    __syncthreads();
+    for (int t = tid; t < A.T; t += 256) {
+        float sx = 0.f, sy = 0.f;
+        if (t >= A.t0)
+            for (int al = 0; al < n; ++al) { sx += s_gx[al * NT + t - A.t0]; sy += s_gy[al * NT + t - A.t0]; }
+        float* o = d_tgt + ((size_t)b * A.T + t) * 4;
+        o[0] = -sx; o[1] = -sy; o[2] = 0.f; o[3] = 0.f;
+    }
+}
+
+static int adv_check(const StriveScenes* sc, const StriveAdvGen* h, int T) {
+    STRIVE_CHECK_ARG(sc && h, "null argument");
+    if (int rc = avoid_check(sc, &h->base, T)) return rc;
+    STRIVE_CHECK_ARG(h->ne_ptr && h->slot_ne && h->base.env_agent && h->base.env_of_agent, "null scene tables");
+    if (h->w_plan > 0.f) STRIVE_CHECK_ARG(h->base.pair_off && h->base.cent_x && h->base.rad && h->base.pair_valid, "null vehicle-term constants");
+    STRIVE_CHECK_ARG(h->base.NE == sc->NA - sc->B && h->base.NZ == h->base.NE, "one latent row per non-ego agent");
+    STRIVE_CHECK_ARG(h->t0 >= 0 && h->t0 < T, "bad crash_loss_min_time");
+    STRIVE_CHECK_ARG(h->w_crash > 0.f, "the fused AdvGenLoss needs the crash term (its soft-min defines the re-weights)");
+    STRIVE_CHECK_ARG(sc->max_n >= 1 && (sc->max_n - 1) * (T - h->t0) <= ADV_MAXE && sc->max_n - 1 <= 64,
+                     "scene too large for the crash kernel's LDS tables");
+    return 0;
+}
+
+static AdvArgs adv_args(const StriveScenes* sc, const StriveAdvGen* h, const AdvWs& w, int T, const float* traj, const float* tgt,
+                        const float* z, const float* mu, const float* var) {
+    AdvArgs A;
+    A.a = avoid_args(sc, &h->base, w.av, T * h->base.scale, z, mu, var);
+    A.B = sc->B; A.T = T; A.t0 = h->t0; A.NT = T - h->t0; A.use_infront = h->use_infront; A.infront = h->infront;
+    A.traj = traj; A.tgt = tgt; A.ne_ptr = h->ne_ptr; A.nonego = h->base.env_agent; A.slot_ne = h->slot_ne; A.atk_mask = h->atk_mask;
+    A.w_crash = h->w_crash; A.w_plan = h->w_plan; A.w_prior_atk = h->w_prior_atk; A.w_init_atk = h->w_init_atk;
+    A.soft2 = w.soft2; A.rew2 = w.rew2; A.crash2 = w.crash2; A.scene_flag = w.scene_flag; A.rew_sel = w.rew_sel;
+    return A;
+}
+
+extern "C" size_t strive_adv_gen_workspace_bytes(const StriveScenes* sc, const StriveAdvGen* h, int32_t T) {
+    if (!sc || !h || T <= 0 || h->base.scale < 1 || h->t0 < 0 || h->t0 >= T) return 0;
+    return adv_ws_bytes((size_t)sc->NA, (size_t)T * h->base.scale, (size_t)h->base.P, (size_t)h->base.NE, (size_t)(T - h->t0),
+                        (size_t)sc->B);
+}
+
+extern "C" int strive_adv_gen_fwd(const StriveScenes* sc, const StriveMap* map, const StriveAdvGen* h, const float* traj,
+                                  const float* tgt, int32_t T, const float* z, const float* mu, const float* var, float* out,
+                                  float* soft, float* rew, void* ws, size_t ws_bytes, strive_stream_t stream) {
+    if (int rc = adv_check(sc, h, T)) return rc;
+    STRIVE_CHECK_ARG(traj && tgt && out && soft && rew && ws && z && mu && var, "null argument");
+    const StriveAvoidColl* hb = &h->base;
+    if (hb->w_env > 0.f && hb->NE > 0) STRIVE_CHECK_ARG(map, "null map");
+    const int NA = sc->NA, TO = T * hb->scale, NT = T - h->t0;
+    STRIVE_CHECK_ARG(ws_bytes >= adv_ws_bytes(NA, TO, hb->P, hb->NE, NT, sc->B), "workspace too small");
+    AdvWs w = adv_carve(ws, ws_bytes, NA, TO, hb->P, hb->NE, NT, sc->B);
+    hipStream_t st = (hipStream_t)stream;
+    const bool veh = (hb->w_veh > 0.f || h->w_plan > 0.f) && hb->P > 0;
+    if (NA > 0) {
+        if (int rc = strive_interp_traj_fwd(traj, NA, T, TO, hb->i0, hb->i1, hb->w0, hb->w1, w.av.fine, stream)) return rc;
+        if (veh)
+            if (int rc = strive_veh_coll_fwd(sc, hb->pair_off, hb->P, w.av.fine, TO, hb->cent_x, hb->rad, hb->buffer, w.av.pen,
+                                             w.av.hit, w.av.amin, stream))
+                return rc;
+        if (hb->w_env > 0.f && hb->NE > 0)
+            if (int rc = strive_coll_point_rows(map, w.av.fine, TO, hb->env_agent, hb->env_lw, hb->env_mapix, hb->NE, hb->gl, hb->gw,
+                                                hb->lin_l, hb->lin_w, w.av.pt, w.av.cnt, stream))
+                return rc;
+    }
+    AdvArgs A = adv_args(sc, h, w, T, traj, tgt, z, mu, var);
+    if (!veh) { A.a.w_veh = 0.f; A.w_plan = 0.f; }
+    if (hb->NE == 0) A.a.w_env = 0.f;
+    if (sc->B > 0) {
+        hipLaunchKernelGGL(adv_crash_kernel, dim3(sc->B), dim3(256), 0, st, A);
+        STRIVE_CHECK_LAUNCH();
+    }
+    long long work = (long long)TO * hb->P;
+    if ((long long)hb->NE * TO > work) work = (long long)hb->NE * TO;
+    if ((long long)hb->NZ * hb->D > work) work = (long long)hb->NZ * hb->D;
+    int nb = (int)((work + 2047) / 2048);
+    nb = nb < 1 ? 1 : (nb > AV_BLOCKS ? AV_BLOCKS : nb);
+    hipLaunchKernelGGL(adv_partial_kernel, dim3(nb), dim3(256), 0, st, A, w.partial);
+    STRIVE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(adv_final_kernel, dim3(1), dim3(64), 0, st, A, (const double*)w.partial, nb, w.sums, w.sel, out, soft, rew);
+    STRIVE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int strive_adv_gen_bwd(const StriveScenes* sc, const StriveAdvGen* h, const float* traj, const float* tgt, int32_t T,
+                                  const float* z, const float* mu, const float* var, const float* d_loss, void* ws,
+                                  size_t ws_bytes, float* d_traj, float* d_tgt, float* d_z, strive_stream_t stream) {
+    if (int rc = adv_check(sc, h, T)) return rc;
+    STRIVE_CHECK_ARG(traj && tgt && d_loss && ws && d_traj && d_tgt && d_z && z && mu && var, "null argument");
+    const StriveAvoidColl* hb = &h->base;
+    const int NA = sc->NA, TO = T * hb->scale, NT = T - h->t0;
+    STRIVE_CHECK_ARG(ws_bytes >= adv_ws_bytes(NA, TO, hb->P, hb->NE, NT, sc->B), "workspace too small");
+    if (NA == 0) return 0;
+    AdvWs w = adv_carve(ws, ws_bytes, NA, TO, hb->P, hb->NE, NT, sc->B);
+    hipStream_t st = (hipStream_t)stream;
+    AdvArgs A = adv_args(sc, h, w, T, traj, tgt, z, mu, var);
+    const bool veh = (hb->w_veh > 0.f || h->w_plan > 0.f) && hb->P > 0;
+    if (hb->NE == 0) A.a.w_env = 0.f;
+    const long long n = (long long)NA * TO + (long long)A.a.NZ * A.a.D;
+    hipLaunchKernelGGL(adv_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, hb->env_of_agent,
+                       (const double*)w.sums, (const int32_t*)w.sel, d_loss, w.av.d_fine, d_z);
+    STRIVE_CHECK_LAUNCH();
+    if (veh) {
+        VehImplicit im;
+        im.hit = w.av.hit; im.valid = hb->pair_valid; im.sums = w.sums; im.d_loss = d_loss; im.w = hb->w_veh;
+        im.slot_ne = h->slot_ne; im.rew = w.rew_sel; im.w2 = h->w_plan;
+        const long long nv = (long long)NA * TO * VG;
+        hipLaunchKernelGGL(veh_coll_bwd_kernel<true>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st,
+                           veh_args(sc, hb->pair_off, hb->P, w.av.fine, TO, hb->cent_x, hb->rad, hb->buffer), (const float*)nullptr,
+                           (const uint8_t*)w.av.amin, w.av.d_fine, im);
+        STRIVE_CHECK_LAUNCH();
+    }
+    if (int rc = strive_interp_traj_bwd(traj, w.av.d_fine, NA, T, TO, hb->scale, hb->i0, hb->i1, hb->w0, hb->w1, d_traj, stream)) return rc;
+    if (sc->B > 0) {
+        hipLaunchKernelGGL(adv_crash_bwd_kernel, dim3(sc->B), dim3(256), 0, st, A, (const int32_t*)w.sel, d_loss, d_traj, d_tgt);
+        STRIVE_CHECK_LAUNCH();
+    }
+    return 0;
 }

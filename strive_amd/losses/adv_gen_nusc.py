@@ -372,6 +372,7 @@ class AdvGenLoss(nn.Module):
         nonego_index = torch.cumsum((~self.ego_mask).to(torch.long), 0) - 1
         self.slot_i_ne, self.slot_j_ne = nonego_index[vl.slot_i], nonego_index[vl.slot_j]
         self.slot_i_ego, self.slot_j_ego = self.ego_mask[vl.slot_i], self.ego_mask[vl.slot_j]
+        self._fused = None
 
     def _segment_softmin(self, din):
         """softmin over all (agent, t) entries of each scene; all-inf scenes give zeros (reference :133-135)."""
@@ -385,7 +386,69 @@ class AdvGenLoss(nn.Module):
         soft = e / den[self.seg].view(-1, 1)
         return torch.where(torch.isnan(soft), torch.zeros_like(soft), soft)
 
+    def _setup(self):
+        if self._fused is None:
+            w = self.loss_weights
+            env, vl = self.env_coll_loss, self.veh_coll_loss
+            NE = self.nonego_idx.numel()
+            base = ops.AvoidCollSetup(
+                vl.info, vl.setup, vl.valid, self.nonego_idx, env.veh_att, env.mapixes, env.penalty_dists, env.map_env,
+                lambda TO: env._grid_size(NE, TO), self.init_z,
+                (w.get('coll_veh', 0.0), w.get('coll_env', 0.0), w.get('motion_prior', 0.0), w.get('init_z', 0.0)))
+            slot_ne = torch.where(self.slot_ego, torch.where(self.slot_j_ego, self.slot_i_ne, self.slot_j_ne).clamp(min=0),
+                                  torch.full_like(self.slot_i_ne, -1))
+            self._fused = ops.AdvGenSetup(base, self.nonego_ptr, slot_ne, self.crash_min_t, self.crash_min_infront,
+                                          (w.get('adv_crash', 0.0), w.get('coll_veh_plan', 0.0), w.get('motion_prior_atk', 0.0),
+                                           w.get('init_z_atk', 0.0)))
+        return self._fused
+
+    def _fusable(self, future_pred, tgt_traj, z, prior_out):
+        w = self.loss_weights
+        nmax = int(self.graph_sizes.max()) - 1 if self.B > 0 else 0
+        NT = future_pred.size(1) - self.crash_min_t if future_pred.dim() == 3 else 0
+        return (w.get('adv_crash', 0.0) > 0.0 and future_pred.dim() == 3 and tgt_traj.dim() == 3 and z.dim() == 2 and NT > 0 and
+                nmax <= 64 and nmax * NT <= 1024 and not prior_out[0].requires_grad and not prior_out[1].requires_grad)
+
     def forward(self, future_pred, tgt_traj, z, prior_out, return_mins=False, attack_agt_idx=None):
+        """One HIP call forward, one backward (strive_adv_gen_fwd/bwd) for the objective; the per-term entries of the
+        reference's dict are evaluated by ``forward_terms`` only when somebody reads them (logging)."""
+        if not self._fusable(future_pred, tgt_traj, z, prior_out):
+            return self.forward_terms(future_pred, tgt_traj, z, prior_out, return_mins=return_mins, attack_agt_idx=attack_agt_idx)
+        w = self.loss_weights
+        loss, _, soft, _ = ops.adv_gen_loss(future_pred, tgt_traj, z, prior_out[0], prior_out[1], self._setup(),
+                                            attack_agt_idx=attack_agt_idx)
+        out = LossDict()
+        terms = {}
+
+        def term(key):
+            def thunk():
+                if not terms:
+                    ft = self.forward_terms(future_pred, tgt_traj, z, prior_out, attack_agt_idx=attack_agt_idx)
+                    for k in list(ft.keys()):
+                        terms[k] = ft[k]
+                return terms[key]
+            return thunk
+        for key, present in (('init_loss', w.get('init_z', 0.0) > 0.0), ('motion_prior_loss', w.get('motion_prior', 0.0) > 0.0),
+                             ('coll_veh_loss', w.get('coll_veh', 0.0) > 0.0), ('coll_veh_plan_loss', w.get('coll_veh_plan', 0.0) > 0.0),
+                             ('coll_env_loss', w.get('coll_env', 0.0) > 0.0), ('adv_crash_loss', True)):
+            if present:
+                out.set_lazy(key, term(key))
+        out['loss'] = loss
+        if return_mins:
+            NT = future_pred.size(1) - self.crash_min_t
+            flat = soft.detach().cpu()
+            cur_min_agt, cur_min_t = [], []
+            for b in range(self.B):
+                a0, a1 = int(self.nonego_ptr[b]), int(self.nonego_ptr[b + 1])
+                k = int(torch.max(flat[a0:a1].reshape(-1), dim=0)[1])
+                cur_min_agt.append(k // NT + 1)
+                cur_min_t.append(k % NT + self.crash_min_t)
+            out['min_agt'] = np.array(cur_min_agt, dtype=int)
+            out['min_t'] = np.array(cur_min_t, dtype=int)
+        return out
+
+    def forward_terms(self, future_pred, tgt_traj, z, prior_out, return_mins=False, attack_agt_idx=None):
+        """The same objective term by term with torch glue between the HIP kernels (reference :105-262)."""
         w = self.loss_weights
         NA, B = future_pred.size(0), tgt_traj.size(0)
         dev = future_pred.device

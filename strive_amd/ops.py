@@ -749,30 +749,35 @@ class AvoidCollSetup(object):
         self.weights = tuple(float(w) for w in weights)
         self._structs = {}
 
+    def fill_base(self, h, T, NZ, D, singleton):
+        """fill a StriveAvoidColl; returns the tensors its pointers refer to (keep them alive with the struct)"""
+        dev = self.veh.cent_x.device
+        TO = T * self.scale
+        i0, i1, w0, w1 = _interp_taps(T, self.scale, dev)
+        gl, gw = self.grid(TO) if self.weights[1] > 0.0 and self.env_agent.numel() > 0 else (1, 1)
+        lin_l, lin_w = _linspace_pair(int(gl), int(gw), dev)
+        h.pair_off, h.P = self.veh.pair_off.data_ptr(), self.veh.P
+        h.cent_x, h.rad, h.buffer = self.veh.cent_x.data_ptr(), self.veh.rad.data_ptr(), self.veh.buffer
+        h.pair_valid = self.pair_valid.data_ptr()
+        h.i0, h.i1, h.w0, h.w1, h.scale = i0.data_ptr(), i1.data_ptr(), w0.data_ptr(), w1.data_ptr(), self.scale
+        h.NE = self.env_agent.numel()
+        h.env_agent, h.env_of_agent = self.env_agent.data_ptr(), self.env_of_agent.data_ptr()
+        h.env_lw, h.env_mapix, h.env_pdist = self.env_lw.data_ptr(), self.env_mapix.data_ptr(), self.env_pdist.data_ptr()
+        h.gl, h.gw, h.lin_l, h.lin_w = int(gl), int(gw), lin_l.data_ptr(), lin_w.data_ptr()
+        h.init_z = None if self.init_z is None else self.init_z.data_ptr()
+        h.NZ, h.D = NZ, D
+        h.prior_den, h.init_den = float(NZ), float(NZ * D if singleton else NZ)
+        h.w_veh, h.w_env, h.w_prior, h.w_init = self.weights
+        return (i0, i1, w0, w1, lin_l, lin_w)
+
     def struct_for(self, T, NZ, D, singleton):
         key = (T, NZ, D, singleton)
         st = self._structs.get(key)
         if st is None:
-            dev = self.veh.cent_x.device
-            TO = T * self.scale
-            i0, i1, w0, w1 = _interp_taps(T, self.scale, dev)
-            gl, gw = self.grid(TO) if self.weights[1] > 0.0 and self.env_agent.numel() > 0 else (1, 1)
-            lin_l, lin_w = _linspace_pair(int(gl), int(gw), dev)
             h = L.StriveAvoidColl()
-            h.pair_off, h.P = self.veh.pair_off.data_ptr(), self.veh.P
-            h.cent_x, h.rad, h.buffer = self.veh.cent_x.data_ptr(), self.veh.rad.data_ptr(), self.veh.buffer
-            h.pair_valid = self.pair_valid.data_ptr()
-            h.i0, h.i1, h.w0, h.w1, h.scale = i0.data_ptr(), i1.data_ptr(), w0.data_ptr(), w1.data_ptr(), self.scale
-            h.NE = self.env_agent.numel()
-            h.env_agent, h.env_of_agent = self.env_agent.data_ptr(), self.env_of_agent.data_ptr()
-            h.env_lw, h.env_mapix, h.env_pdist = self.env_lw.data_ptr(), self.env_mapix.data_ptr(), self.env_pdist.data_ptr()
-            h.gl, h.gw, h.lin_l, h.lin_w = int(gl), int(gw), lin_l.data_ptr(), lin_w.data_ptr()
-            h.init_z = None if self.init_z is None else self.init_z.data_ptr()
-            h.NZ, h.D = NZ, D
-            h.prior_den, h.init_den = float(NZ), float(NZ * D if singleton else NZ)
-            h.w_veh, h.w_env, h.w_prior, h.w_init = self.weights
+            keep = self.fill_base(h, T, NZ, D, singleton)
             nbytes = self.lib.query('strive_avoid_coll_workspace_bytes', self.sc.ref(), C.byref(h), T)
-            st = (h, (i0, i1, w0, w1, lin_l, lin_w), int(nbytes))
+            st = (h, keep, int(nbytes))
             self._structs[key] = st
         return st
 
@@ -818,6 +823,103 @@ def avoid_coll_loss(traj, z, mu, var, setup):
     if mu.requires_grad or var.requires_grad:
         raise NotImplementedError('the fused AvoidCollLoss treats the prior as a constant (the optimisation loops detach it)')
     return _AvoidCollFn.apply(traj[:, :, :4], z, mu, var, setup)
+
+
+class AdvGenSetup(object):
+    """Constants of one batch for strive_adv_gen_fwd/bwd (include/strive_hip.h StriveAdvGen).  ``base`` is an AvoidCollSetup
+    whose environment agents are the non-ego agents and whose weights are (coll_veh, coll_env, motion_prior, init_z);
+    ``ne_ptr`` (B+1,) offsets of the scenes in the non-ego order; ``slot_ne`` (P,) non-ego row of the non-ego member of every
+    ego-involving pair slot (-1 elsewhere); ``extra`` = (adv_crash, coll_veh_plan, motion_prior_atk, init_z_atk)."""
+
+    def __init__(self, base, ne_ptr, slot_ne, t0, infront, extra):
+        dev = base.veh.cent_x.device
+        self.base, self.lib, self.sc, self.map_env = base, base.lib, base.sc, base.map_env
+        self.ne_ptr = ne_ptr.to(device=dev, dtype=torch.int32).contiguous()
+        self.slot_ne = slot_ne.to(device=dev, dtype=torch.int32).contiguous()
+        self.t0, self.infront = int(t0), infront
+        self.extra = tuple(float(w) for w in extra)
+        self.NE = base.env_agent.numel()
+        self._structs = {}
+        self._masks = {}
+
+    def atk_mask(self, attack_agt_idx, NA):
+        """(NE,) uint8 selection of the allowed attackers from GLOBAL agent indices (cached per index tensor)"""
+        if attack_agt_idx is None:
+            return None
+        key = (attack_agt_idx.data_ptr(), attack_agt_idx._version, tuple(attack_agt_idx.shape))
+        m = self._masks.get(key)
+        if m is None:
+            dev = self.base.veh.cent_x.device
+            am = torch.zeros((NA,), dtype=torch.uint8, device=dev)
+            am[attack_agt_idx.to(dev).long()] = 1
+            m = am.index_select(0, self.base.env_agent.long()).contiguous()
+            self._masks.clear()
+            self._masks[key] = m
+        return m
+
+    def struct_for(self, T, D, mask):
+        key = (T, D, None if mask is None else mask.data_ptr())
+        st = self._structs.get(key)
+        if st is None:
+            h = L.StriveAdvGen()
+            keep = self.base.fill_base(h.base, T, self.NE, D, False)
+            h.ne_ptr, h.slot_ne = self.ne_ptr.data_ptr(), self.slot_ne.data_ptr()
+            h.atk_mask = None if mask is None else mask.data_ptr()
+            h.t0 = self.t0
+            h.use_infront = 0 if self.infront is None else 1
+            h.infront = 0.0 if self.infront is None else float(self.infront)
+            h.w_crash, h.w_plan, h.w_prior_atk, h.w_init_atk = self.extra
+            nbytes = self.lib.query('strive_adv_gen_workspace_bytes', self.sc.ref(), C.byref(h), T)
+            if nbytes == 0:
+                raise StriveHipError('strive_adv_gen_workspace_bytes rejected the configuration (T=%d, t0=%d)' % (T, self.t0))
+            st = (h, (keep, mask), int(nbytes))
+            if len(self._structs) > 8:
+                self._structs.clear()
+            self._structs[key] = st
+        return st
+
+
+class _AdvGenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, traj, tgt, z, mu, var, h, mask):
+        lib = h.lib
+        tr, tg, zc, muc, varc = _f32c(traj), _f32c(tgt), _f32c(z), _f32c(mu), _f32c(var)
+        NA, T, _ = tr.shape
+        if zc.shape != muc.shape or zc.shape != varc.shape or zc.shape[0] != h.NE or tg.shape != (h.sc.struct.B, T, 4):
+            raise ValueError('adv_gen_loss: shapes traj %s tgt %s z %s prior %s do not match the batch' % (
+                tuple(traj.shape), tuple(tgt.shape), tuple(z.shape), tuple(mu.shape)))
+        st, _keep, nbytes = h.struct_for(T, zc.shape[1], mask)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=tr.device)
+        out = torch.empty((16,), dtype=torch.float32, device=tr.device)
+        NT = T - h.t0
+        soft = torch.empty((h.NE, NT), dtype=torch.float32, device=tr.device)
+        rew = torch.empty((h.NE,), dtype=torch.float32, device=tr.device)
+        pk = _map_pack(h.map_env, tr.device)
+        lib.call('strive_adv_gen_fwd', h.sc.ref(), pk.ref(), C.byref(st), L.ptr(tr), L.ptr(tg), T, L.ptr(zc), L.ptr(muc), L.ptr(varc),
+                 L.ptr(out), L.ptr(soft), L.ptr(rew), L.ptr(ws), nbytes, _stream(tr))
+        ctx.h, ctx.mask, ctx.D = h, mask, zc.shape[1]
+        ctx.save_for_backward(tr, tg, zc, muc, varc, ws)
+        ctx.mark_non_differentiable(out, soft, rew)
+        return out[0].clone(), out, soft, rew
+
+    @staticmethod
+    def backward(ctx, d_loss, _d_out, _d_soft, _d_rew):
+        h = ctx.h
+        tr, tg, zc, muc, varc, ws = ctx.saved_tensors
+        NA, T, _ = tr.shape
+        st, _keep, nbytes = h.struct_for(T, ctx.D, ctx.mask)
+        d_traj, d_tgt, d_z = torch.empty_like(tr), torch.empty_like(tg), torch.zeros_like(zc)
+        h.lib.call('strive_adv_gen_bwd', h.sc.ref(), C.byref(st), L.ptr(tr), L.ptr(tg), T, L.ptr(zc), L.ptr(muc), L.ptr(varc),
+                   L.ptr(_f32c(d_loss).reshape(1)), L.ptr(ws), nbytes, L.ptr(d_traj), L.ptr(d_tgt), L.ptr(d_z), _stream(tr))
+        return d_traj, d_tgt, d_z, None, None, None, None
+
+
+def adv_gen_loss(traj, tgt, z, mu, var, setup, attack_agt_idx=None):
+    """-> (loss 0-dim, differentiable w.r.t. traj, tgt and z; out (16,); soft (NE, T - t0); rew (NE,))"""
+    if mu.requires_grad or var.requires_grad:
+        raise NotImplementedError('the fused AdvGenLoss treats the prior as a constant (the optimisation loops detach it)')
+    mask = setup.atk_mask(attack_agt_idx, traj.shape[0])
+    return _AdvGenFn.apply(traj[:, :, :4], tgt[:, :, :4], z, mu, var, setup, mask)
 
 
 def rect_iou(box_a, lw_a, box_b, lw_b):

@@ -5,6 +5,7 @@ packed tensors are kept alive by the returned holder object.  Layouts are docume
 include/strive_hip.h next to each struct.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -56,7 +57,9 @@ def _fill_mlp(s, holder, sd, prefix):
         s.w[k] = holder.hold(w)
         s.wt[k] = holder.hold(w.t().contiguous())
         s.b[k] = holder.hold(b)
-        if w.shape[0] >= 32 and w.shape[1] >= 32:          # matrix-core operands (csrc/mlp_dev.h dense_mfma)
+        # matrix-core operands (csrc/mlp_dev.h dense_mfma); STRIVE_DENSE_VALU=1 withholds them (A/B measurements: the
+        # layers then run on the vector ALUs in fp32 from w / wt)
+        if w.shape[0] >= 32 and w.shape[1] >= 32 and os.environ.get('STRIVE_DENSE_VALU', '0') != '1':
             sc = _pow2_scale(float(w.abs().max()))
             s.wsc[k] = sc
             s.wf[k] = holder.hold(dense_fragments(w, sc))

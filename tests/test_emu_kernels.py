@@ -477,3 +477,59 @@ def test_avoid_coll_loss_fused(emu, sd, single, monkeypatch):
             assert_close(p1[2], o1[2], 1e-4, 1e-7, 'd z ' + k)
         else:
             assert float(p1[2].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('mt,infront,atk,far', [(2, 0.0, None, False), (0, None, 'idx', False), (2, 0.0, None, True)])
+def test_adv_gen_loss_fused(emu, sd, mt, infront, atk, far, monkeypatch):
+    """strive_adv_gen_fwd/bwd (AdvGenLoss as one call per direction) against the oracle's term-by-term loss: objective, the
+    gradients w.r.t. the trajectories, the planner trajectory and the latents, the soft-min argmax; with the behind mask, with
+    an attacker selection, and with every attacker behind its target (the batch-wide escape that drops the mask)."""
+    from strive_amd import ops
+    from strive_amd.losses.adv_gen_nusc import AdvGenLoss
+    monkeypatch.setattr(ops, '_lib_for', lambda *tensors: emu)
+    g = golden('g5_losses.npz')
+    batch, map_idx, raster, dx = mg.g5_inputs(None, None)
+    orc = oracle_model(sd)
+    env = synth.SyntheticMapEnv(raster, dx)
+    unn = orc.get_normalizer().unnormalize
+    veh_att = orc.get_att_normalizer().unnormalize(batch.lw)
+    mapixes = map_idx[batch.batch]
+    NA, B = batch.past.shape[0], batch.ptr.shape[0] - 1
+    ego = torch.zeros((NA,), dtype=torch.bool)
+    ego[batch.ptr[:-1]] = True
+    traj = unn(torch.from_numpy(g['adv_pred'])).contiguous()
+    tgt = unn(batch.future_gt[ego][:, :, :4]).contiguous()
+    if far:
+        tgt = tgt.clone()
+        tgt[:, :, 0] += 500.0
+        tgt[:, :, 2] = 1.0
+        tgt[:, :, 3] = 0.0
+    D = 32
+    z0 = synth.f32(synth.counter_uniform((NA - B, D), 'emu/agz', -1.0, 1.0))
+    mu = synth.f32(synth.counter_uniform((NA - B, D), 'emu/agm', -0.5, 0.5))
+    var = synth.f32(synth.counter_uniform((NA - B, D), 'emu/agv', 0.3, 2.0))
+    init = synth.f32(synth.counter_uniform((NA - B, D), 'emu/agi', -1.0, 1.0))
+    aidx = None if atk is None else torch.tensor([1, 2, 1]) + batch.ptr[:-1]
+    kw = dict(veh_coll_buffer=0.1, crash_loss_min_time=mt, crash_loss_min_infront=infront)
+
+    def run(loss_fn):
+        tr = traj.clone().requires_grad_(True)
+        tg = tgt.clone().requires_grad_(True)
+        z = z0.clone().requires_grad_(True)
+        out = loss_fn(tr, tg, z, (mu, var), return_mins=True, attack_agt_idx=aidx)
+        out['loss'].backward()
+        return out, tr.grad, tg.grad, z.grad
+
+    oo, otr, otg, oz = run(olosses.AdvGen(mg.ADV_WEIGHTS, veh_att, mapixes, env, init, batch.ptr, **kw))
+    fused = AdvGenLoss(mg.ADV_WEIGHTS, veh_att, mapixes, env, init, batch.ptr, **kw)
+    po, ptr_, ptg, pz = run(fused)
+    assert fused._fused is not None, 'the fused call was not taken'
+    assert_close(po['loss'].detach(), oo['loss'].detach(), 2e-5, 1e-5, 'loss')
+    assert np.array_equal(np.asarray(po['min_agt']), np.asarray(oo['min_agt'])) and np.array_equal(np.asarray(po['min_t']), np.asarray(oo['min_t']))
+    assert_close(ptr_, otr, 5e-3, 1e-5, 'd traj')
+    assert_close(ptg, otg if otg is not None else torch.zeros_like(ptg), 5e-3, 1e-5, 'd tgt')
+    assert_close(pz, oz, 1e-4, 1e-7, 'd z')
+    for k in oo:
+        if k in ('min_agt', 'min_t', 'loss'):
+            continue
+        assert_close(po[k].detach(), oo[k].detach(), 2e-3, 2e-3 if 'env' in k else 2e-4, k)

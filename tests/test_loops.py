@@ -125,8 +125,11 @@ def test_product_loops_textured_raster(fixture, model, name):
     trace, _ = lu.run_product_loop(name, 't', fixture, m, n, DEV)
     tag = 't/' + name
     w0 = lu.compare_trace(trace, fixture, tag, 1e-2, 2e-3, 0.1, 1e-5, z_frac=1.0, n_iters=1, report=REPORT)
-    # (absolute slack 0.05: small terms such as the others' matching loss ~0.1 move by that much once trajectories diverge)
-    w = lu.compare_trace(trace, fixture, tag, 0.15, 5e-2, 10.0, 0.11, z_frac=0.9, report=REPORT)
+    # (absolute slack 0.1: small terms such as the others' matching loss ~0.1 move by that much once trajectories diverge.
+    # Measured A/B on the MI355X: the same loops with the dense layers on the vector ALUs (STRIVE_DENSE_VALU=1) and on the
+    # matrix cores (fp16 x 3) -- two fp32-accurate evaluations 1e-7 apart per layer -- differ from EACH OTHER by 0.07 in
+    # t/sol's other_loss at iteration 4; the uniform-raster tests above pin the same code to 6e-5.)
+    w = lu.compare_trace(trace, fixture, tag, 0.15, 0.1, 10.0, 0.11, z_frac=0.9, report=REPORT)
     print('loop %s: first %s all %s' % (tag, w0, w))
     _dump_report()
 
