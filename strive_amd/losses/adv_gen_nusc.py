@@ -121,7 +121,7 @@ class TgtMatchingLoss(nn.Module):
         self.motion_prior_loss = MotionPriorLoss()
 
     def forward(self, future_pred, tgt_traj, z, prior_out):
-        out = {}
+        out = LossDict()
         loss = 0.0
         tgt_loss = None
         if self.loss_weights['match_ext'] > 0.0:
@@ -129,7 +129,8 @@ class TgtMatchingLoss(nn.Module):
             loss = loss + self.loss_weights['match_ext'] * tgt_loss.mean()
             out['match_ext_loss'] = tgt_loss
         if self.loss_weights['motion_prior_ext'] > 0.0:
-            out['motion_prior_ext_loss'] = self.motion_prior_loss(z, prior_out)
+            # reported but never part of the objective (reference :46 adds the matching term again): evaluated when read
+            out.set_lazy('motion_prior_ext_loss', lambda: self.motion_prior_loss(z, prior_out))
             loss = loss + self.loss_weights['motion_prior_ext'] * tgt_loss.mean()
         out['loss'] = loss
         return out
