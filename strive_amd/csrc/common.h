@@ -45,20 +45,61 @@ struct StriveArena {
 };
 
 // ---- wave-level reductions (64 lanes) ----
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
+// __shfl_xor compiles to ds_bpermute_b32: an LDS-crossbar round trip (~100 cycles) per step, six dependent steps per
+// reduction -- and the small dense kernels are chains of such reductions (two per LayerNorm row, four in its backward;
+// tools/mlp_phase_probe.hip: a LayerNorm of 4 rows costs as much as a 128 x 128 layer).  The first four steps stay inside a
+// row of 16 lanes, where the data-parallel-primitive modifiers move data in the VALU itself (quad_perm, row_half_mirror,
+// row_mirror); the four row totals are then read through scalar registers.  Every lane gets the same value, added in one
+// fixed order.
+#define STRIVE_DPP_QUAD_XOR1 0xB1        // quad_perm [1,0,3,2]
+#define STRIVE_DPP_QUAD_XOR2 0x4E        // quad_perm [2,3,0,1]
+#define STRIVE_DPP_ROW_HALF_MIRROR 0x141 // lane i <- lane 7 - i within each 8
+#define STRIVE_DPP_ROW_MIRROR 0x140      // lane i <- lane 15 - i within each 16
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_move<STRIVE_DPP_QUAD_XOR1>(v);
+    v += dpp_move<STRIVE_DPP_QUAD_XOR2>(v);
+    v += dpp_move<STRIVE_DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_move<STRIVE_DPP_ROW_MIRROR>(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));
-    return v;
+    v = fmaxf(v, dpp_move<STRIVE_DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, dpp_move<STRIVE_DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, dpp_move<STRIVE_DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_move<STRIVE_DPP_ROW_MIRROR>(v));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+    v += dpp_move_d<STRIVE_DPP_QUAD_XOR1>(v);
+    v += dpp_move_d<STRIVE_DPP_QUAD_XOR2>(v);
+    v += dpp_move_d<STRIVE_DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_move_d<STRIVE_DPP_ROW_MIRROR>(v);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 
 // pos*std + mean exactly as MeanStdNormalizer.unnormalize evaluates it in fp32

@@ -166,6 +166,19 @@ template <typename T> inline T __shfl_up(T v, unsigned delta, int width = 64) {
     if (src < 0 || (src / width) != (lane / width)) src = lane;
     return hipemu_exchange(v, src);
 }
+// data-parallel-primitive moves used by common.h's wave reductions (row = 16 lanes): quad_perm xor 1 / xor 2, row_half_mirror,
+// row_mirror; readlane = broadcast of one lane
+inline int __builtin_amdgcn_update_dpp(int /*old*/, int src, int ctrl, int, int, bool) {
+    const int l = hipemu_lane();
+    int from = l;
+    if (ctrl == 0xB1) from = l ^ 1;
+    else if (ctrl == 0x4E) from = l ^ 2;
+    else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));
+    else if (ctrl == 0x140) from = (l & ~15) | (15 - (l & 15));
+    else { fprintf(stderr, "hipemu: unsupported dpp control 0x%x\n", ctrl); abort(); }
+    return hipemu_exchange(src, from);
+}
+inline int __builtin_amdgcn_readlane(int v, int lane) { return hipemu_exchange(v, lane); }
 template <typename T> inline T __shfl(T v, int src, int width = 64) {
     int lane = hipemu_lane();
     return hipemu_exchange(v, (lane / width) * width + (src % width));
