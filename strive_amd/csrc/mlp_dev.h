@@ -265,25 +265,29 @@ __device__ __forceinline__ void dense_any(const float* in, int in_ld, int IN, co
 }
 
 // y = relu(layer_norm(x)) row-wise over N channels (one wave per row, two-pass mean/variance).
+// N <= 128 (the hidden width of every MLP on the path): a lane keeps its (up to) two channels, the LayerNorm parameters and,
+// in the backward, the incoming gradient in registers, so a row costs ONE pass over LDS instead of three (five in the
+// backward); the arithmetic and its order are those of the plain loops over c = lane, lane + 64.
 template <int RB>
 __device__ __forceinline__ void ln_relu_rows(const float* x, int x_ld, float* y, int y_ld, int N,
                                              const float* __restrict__ g, const float* __restrict__ b, int tid,
                                              int nthreads) {
     const int wave = tid >> 6, lane = tid & 63, nw = nthreads >> 6;
+    const int c0 = lane, c1 = lane + 64;
+    const bool h0 = c0 < N, h1 = c1 < N;
+    const float g0 = h0 ? g[c0] : 0.f, g1 = h1 ? g[c1] : 0.f, b0 = h0 ? b[c0] : 0.f, b1 = h1 ? b[c1] : 0.f;
     for (int r = wave; r < RB; r += nw) {
+        const float x0 = h0 ? x[r * x_ld + c0] : 0.f, x1 = h1 ? x[r * x_ld + c1] : 0.f;
         float s = 0.f;
-        for (int c = lane; c < N; c += 64) s += x[r * x_ld + c];
+        if (h0) s += x0;
+        if (h1) s += x1;
         const float mean = wave_sum(s) / (float)N;
         float v = 0.f;
-        for (int c = lane; c < N; c += 64) {
-            const float d = x[r * x_ld + c] - mean;
-            v = fmaf(d, d, v);
-        }
+        if (h0) { const float d = x0 - mean; v = fmaf(d, d, v); }
+        if (h1) { const float d = x1 - mean; v = fmaf(d, d, v); }
         const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)N + LN_EPS);
-        for (int c = lane; c < N; c += 64) {
-            const float t = (x[r * x_ld + c] - mean) * rstd * g[c] + b[c];
-            y[r * y_ld + c] = fmaxf(t, 0.f);
-        }
+        if (h0) y[r * y_ld + c0] = fmaxf((x0 - mean) * rstd * g0 + b0, 0.f);
+        if (h1) y[r * y_ld + c1] = fmaxf((x1 - mean) * rstd * g1 + b1, 0.f);
     }
 }
 
@@ -297,37 +301,49 @@ __device__ __forceinline__ void ln_relu_bwd_rows(const float* x, int x_ld, const
                                                  const float* __restrict__ b, int tid, int nthreads,
                                                  float* dgam = nullptr, float* dbet = nullptr, int nrows = RB) {
     const int wave = tid >> 6, lane = tid & 63, nw = nthreads >> 6;
+    const int cc[2] = {lane, lane + 64};
+    const bool hh[2] = {cc[0] < N, cc[1] < N};
+    float gq[2], bq[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { gq[q] = hh[q] ? g[cc[q]] : 0.f; bq[q] = hh[q] ? b[cc[q]] : 0.f; }
     for (int r = wave; r < RB; r += nw) {
+        float xq[2], dq[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            xq[q] = hh[q] ? x[r * x_ld + cc[q]] : 0.f;
+            dq[q] = hh[q] ? dy[r * dy_ld + cc[q]] : 0.f;
+        }
         float s = 0.f;
-        for (int c = lane; c < N; c += 64) s += x[r * x_ld + c];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (hh[q]) s += xq[q];
         const float mean = wave_sum(s) / (float)N;
         float v = 0.f;
-        for (int c = lane; c < N; c += 64) {
-            const float d = x[r * x_ld + c] - mean;
-            v = fmaf(d, d, v);
-        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (hh[q]) { const float d = xq[q] - mean; v = fmaf(d, d, v); }
         const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)N + LN_EPS);
-        float m1 = 0.f, m2 = 0.f;
-        for (int c = lane; c < N; c += 64) {
-            const float xh = (x[r * x_ld + c] - mean) * rstd;
-            const float pre = xh * g[c] + b[c];
-            const float dn = pre > 0.f ? dy[r * dy_ld + c] : 0.f;
-            const float gg = dn * g[c];
-            m1 += gg;
-            m2 = fmaf(gg, xh, m2);
-            if (dgam && r < nrows && dn != 0.f) {
-                unsafeAtomicAdd(&dgam[c], dn * xh);
-                unsafeAtomicAdd(&dbet[c], dn);
+        float m1 = 0.f, m2 = 0.f, xh[2] = {0.f, 0.f}, gg[2] = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (hh[q]) {
+                xh[q] = (xq[q] - mean) * rstd;
+                const float pre = xh[q] * gq[q] + bq[q];
+                const float dn = pre > 0.f ? dq[q] : 0.f;
+                gg[q] = dn * gq[q];
+                m1 += gg[q];
+                m2 = fmaf(gg[q], xh[q], m2);
+                if (dgam && r < nrows && dn != 0.f) {
+                    unsafeAtomicAdd(&dgam[cc[q]], dn * xh[q]);
+                    unsafeAtomicAdd(&dbet[cc[q]], dn);
+                }
             }
         }
         m1 = wave_sum(m1) / (float)N;
         m2 = wave_sum(m2) / (float)N;
-        for (int c = lane; c < N; c += 64) {
-            const float xh = (x[r * x_ld + c] - mean) * rstd;
-            const float pre = xh * g[c] + b[c];
-            const float gg = (pre > 0.f ? dy[r * dy_ld + c] : 0.f) * g[c];
-            dx[r * dx_ld + c] = rstd * (gg - m1 - xh * m2);
-        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (hh[q]) dx[r * dx_ld + cc[q]] = rstd * (gg[q] - m1 - xh[q] * m2);
     }
 }
 
