@@ -275,6 +275,19 @@ def test_map_cnn_eight_agents(emu, sd):
     emu.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(fr), L.f4([0] * 4), L.f4([1] * 4), L.ptr(mi), n, L.ptr(feat),
              L.ptr(ws), wsb, None)
     assert_close(feat, want, 1e-4, 1e-5, 'cnn x8')
+    # the fused tail (conv5 + conv6 + Linear in one kernel, what strive_map_cnn_fwd runs) against the separate kernels of the
+    # training recompute on the SAME conv4 output left in the workspace; 6 of the 8 poses = one full and one half workgroup
+    for m_ in (8, 6):
+        f_fused, f_sep = torch.zeros((m_, 64)), torch.zeros((m_, 64))
+        args = (mp.ref(), cnn.ref())
+        tail = (L.ptr(fr[:m_].contiguous()), L.f4([0] * 4), L.f4([1] * 4), L.ptr(mi[:m_].contiguous()), m_)
+        wsb2 = emu.query('strive_map_cnn_workspace_bytes', m_)
+        ws2 = torch.zeros(wsb2, dtype=torch.uint8)
+        emu.call('strive_map_cnn_fwd', *args, *tail, L.ptr(f_fused), L.ptr(ws2), wsb2, None)
+        for layer in (4, 5, 6):
+            emu.call('strive_map_cnn_bench_layer', *args, layer, *tail, L.ptr(f_sep), L.ptr(ws2), wsb2, None)
+        assert_close(f_fused, f_sep, 2e-6, 2e-6, 'fused tail vs separate kernels (%d poses)' % m_)
+        assert_close(f_fused, want[:m_], 1e-4, 1e-5, 'cnn x%d' % m_)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -533,3 +546,68 @@ def test_adv_gen_loss_fused(emu, sd, mt, infront, atk, far, monkeypatch):
         if k in ('min_agt', 'min_t', 'loss'):
             continue
         assert_close(po[k].detach(), oo[k].detach(), 2e-3, 2e-3 if 'env' in k else 2e-4, k)
+
+
+def _loss_case(sizes, key, window=8.0, M=2):
+    """ragged scenes packed tightly (collisions of both kinds), two maps, trajectories = the recorded futures"""
+    batch, map_idx, raster, dx = mg.build_inputs(sizes, key, window=window, M=M)
+    env = synth.SyntheticMapEnv(raster, dx)
+    state_n = Normalizer(*[t.double() for t in __import__('strive_amd.constants', fromlist=['x']).state_norm_tensors()])
+    att_n = Normalizer(*[t.double() for t in __import__('strive_amd.constants', fromlist=['x']).att_norm_tensors()])
+    traj = state_n.unnormalize(batch.future_gt.double())[:, :, :4].float().contiguous()
+    veh_att = att_n.unnormalize(batch.lw.double()).float()
+    return batch, map_idx, env, traj, veh_att
+
+
+def test_fused_losses_ragged_scenes(emu, monkeypatch):
+    """The fused loss calls on ragged batches: a one-agent scene (no pairs, no attacker rows), two maps, an attacker selection
+    that leaves one scene without candidates (all soft-min weights 0, :134-135) -- against the oracle."""
+    from strive_amd import ops
+    from strive_amd.losses.adv_gen_nusc import AvoidCollLoss, AdvGenLoss
+    monkeypatch.setattr(ops, '_lib_for', lambda *tensors: emu)
+    D = 32
+    # AvoidCollLoss, sizes with a singleton scene
+    batch, map_idx, env, traj, veh_att = _loss_case([1, 4, 2], 'emu/ragged_a')
+    NA = traj.shape[0]
+    z0 = synth.f32(synth.counter_uniform((NA, D), 'emu/rz', -1.0, 1.0))
+    mu = synth.f32(synth.counter_uniform((NA, D), 'emu/rm', -0.5, 0.5))
+    var = synth.f32(synth.counter_uniform((NA, D), 'emu/rv', 0.3, 2.0))
+    w = {'coll_veh': 1.5, 'coll_env': 0.7, 'motion_prior': 0.02, 'init_z': 0.3}
+    res = []
+    for cls, e in ((olosses.AvoidColl, env), (AvoidCollLoss, env)):
+        tr = traj.clone().requires_grad_(True)
+        z = z0.clone().requires_grad_(True)
+        fn = cls(w, veh_att, map_idx[batch.batch], e, z0 * 0.5, veh_coll_buffer=0.3, ptr=batch.ptr)
+        out = fn(tr, z, (mu, var))
+        out['loss'].backward()
+        res.append((out['loss'].detach(), tr.grad, z.grad))
+    assert_close(res[1][0], res[0][0], 2e-5, 1e-6, 'avoid loss')
+    assert_close(res[1][1], res[0][1], 5e-3, 1e-6, 'avoid d traj')
+    assert_close(res[1][2], res[0][2], 1e-4, 1e-7, 'avoid d z')
+    # AdvGenLoss: every scene has an attacker row, but the selection masks all of scene 1's candidates
+    batch, map_idx, env, traj, veh_att = _loss_case([2, 5, 3], 'emu/ragged_b')
+    NA, B = traj.shape[0], 3
+    ego = torch.zeros((NA,), dtype=torch.bool)
+    ego[batch.ptr[:-1]] = True
+    tgt = traj[ego].clone()
+    tgt[:, :, :2] += 1.5
+    zne = synth.f32(synth.counter_uniform((NA - B, D), 'emu/rz2', -1.0, 1.0))
+    mu = synth.f32(synth.counter_uniform((NA - B, D), 'emu/rm2', -0.5, 0.5))
+    var = synth.f32(synth.counter_uniform((NA - B, D), 'emu/rv2', 0.3, 2.0))
+    aidx = torch.tensor([int(batch.ptr[0]) + 1, int(batch.ptr[2]) + 2])          # scene 0 and scene 2 only
+    res = []
+    for cls in (olosses.AdvGen, AdvGenLoss):
+        tr = traj.clone().requires_grad_(True)
+        tg = tgt.clone().requires_grad_(True)
+        z = zne.clone().requires_grad_(True)
+        fn = cls(mg.ADV_WEIGHTS, veh_att, map_idx[batch.batch], env, zne * 0.5, batch.ptr, veh_coll_buffer=0.1,
+                 crash_loss_min_time=1, crash_loss_min_infront=-0.5)
+        out = fn(tr, tg, z, (mu, var), return_mins=True, attack_agt_idx=aidx)
+        out['loss'].backward()
+        res.append((out['loss'].detach(), tr.grad, tg.grad, z.grad, out['adv_crash_loss'].detach()))
+    assert float(res[0][4][1]) == 0.0, 'scene 1 must have no candidate attacker in this case'
+    assert_close(res[1][0], res[0][0], 2e-5, 1e-5, 'adv loss')
+    assert_close(res[1][4], res[0][4], 1e-4, 1e-5, 'crash per scene')
+    assert_close(res[1][1], res[0][1], 5e-3, 1e-5, 'adv d traj')
+    assert_close(res[1][2], res[0][2], 5e-3, 1e-5, 'adv d tgt')
+    assert_close(res[1][3], res[0][3], 1e-4, 1e-7, 'adv d z')
