@@ -17,6 +17,11 @@ timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
 python profiles/summarize_pmc.py $(find $O/sq -name "*counter_collection.csv" | head -1) > $O/pmc_sq_waits.txt 2>&1
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM --kernel-trace --output-format csv -d $O/sq2 -- $B --steps 1 --warmup 1 > $O/sq2.log 2>&1
 python profiles/summarize_pmc.py $(find $O/sq2 -name "*counter_collection.csv" | head -1) > $O/pmc_sq_mfma.txt 2>&1
+python profiles/make_traffic.py $O/pmc_fetch_size.txt $O/pmc_write_size.txt $O/kernel_stats.txt > $O/traffic.json 2>> $O/fetch.log
 find $O -type f -size +1M -delete
+cp $O/traffic.json profiles/r02_traffic.json          # (this run's own counters feed bench.py's `traffic` fields below)
 python bench.py > $O/bench_line.json 2> $O/bench.err
-tail -c 400 $O/bench_line.json
+python bench.py --workload adv --no-cpu-baseline > $O/bench_line_adv.json 2>> $O/bench.err
+python bench.py --scenes 1 --agents 8 --steps 20 --no-cpu-baseline > $O/bench_line_1x8.json 2>> $O/bench.err
+python bench.py --workload train --no-cpu-baseline --no-roofline > $O/bench_line_train.json 2>> $O/bench.err
+tail -c 300 $O/bench_line.json

@@ -314,6 +314,11 @@ struct BfCfg {
     static_assert(LDS_BYTES * WGS_PER_CU <= 160 * 1024, "LDS budget of the residency target");
     static_assert((KS == 5 && NKS == 13) || (KS == 3 && NKS == 5), "tap orders exist for 5x5 and 3x3 windows");
     static_assert(WSTEP_B == 16 * 128 * CBW && WSTEP_B / 16 <= NT, "weight step = one 16-byte piece for each of the first 128 CBW threads");
+    // weight steps of a pass requested before its staging; the rest is requested at matrix step W_LATE_AT, when the registers
+    // of the first steps have been handed to LDS.  Three workgroups per CU leave 168 registers per lane: with all 13 steps
+    // parked (52 registers) conv2 spilled 11 of them to scratch -- 92 MB written and 92 MB read back per 512-agent launch
+    // (rocprofv3 WRITE_SIZE / FETCH_SIZE), a sixth of the kernel's HBM traffic.
+    static constexpr int W_UPFRONT = (WGS_PER_CU >= 3 && NKS > 8) ? 7 : NKS, W_LATE_AT = 2;
 };
 
 // v = p0 + p1 up to 2^-24 |v| (p0 = fp16(v) rounded to nearest, p1 = fp16(v - p0)); v is pre-scaled into fp16's range.
@@ -357,9 +362,22 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31;
-    const int n = blockIdx.z;
-    const int tile_x = blockIdx.x % Cfg::TILES_X, cb = blockIdx.x / Cfg::TILES_X;
-    const int oy0 = blockIdx.y * TH, ox0 = tile_x * TW;
+    // Workgroups are dealt to the 8 XCDs round-robin by their linear id, and each XCD has its own L2.  Output rows are not
+    // multiples of a 128-byte line (conv2: 61 px x 32 B), so the two x tiles of a row block share lines at their common edge and
+    // at the row ends; left on different XCDs those lines are evicted half written and cost a read-modify-write each (measured:
+    // +92 MB written AND +92 MB fetched per 512-agent launch of conv2).  With two workgroups per row block the pair is therefore
+    // placed on the SAME XCD, 8 ids apart: id = 16 c + r + 8 x  ->  pair 8 c + r, x tile x.
+    int bx = blockIdx.x, by = blockIdx.y, n = blockIdx.z;
+    if (Cfg::TILES_X * Cfg::CSPLIT == 2 && ((gridDim.y * gridDim.z) & 7) == 0) {
+        const unsigned lin = blockIdx.x + 2u * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned c16 = lin >> 4, rem = lin & 15u;
+        const unsigned pair = 8u * c16 + (rem & 7u);
+        bx = (int)(rem >> 3);
+        by = (int)(pair % gridDim.y);
+        n = (int)(pair / gridDim.y);
+    }
+    const int tile_x = bx % Cfg::TILES_X, cb = bx / Cfg::TILES_X;
+    const int oy0 = by * TH, ox0 = tile_x * TW;
     const int iy0 = 2 * oy0, ix0 = 2 * ox0;
 
     // ---- raw input loads of pass 0 go out first: they do not depend on the statistics ----
@@ -442,7 +460,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
         for (int t = 0; t < NKS; ++t) wq[t] = make_uint4(0u, 0u, 0u, 0u);
         if (wmover) {
 #pragma unroll
-            for (int t = 0; t < NKS; ++t) wq[t] = wstep_src(pass, t)[tid];
+            for (int t = 0; t < Cfg::W_UPFRONT; ++t) wq[t] = wstep_src(pass, t)[tid];
         }
         __syncthreads();        // s_gn ready (pass 0) / every wave is done with the previous pass's tiles
         // ---- 8 input channels of the (2TH+KS-2) x (2TW+KS-2) window: GroupNorm + ReLU (pre-scaled), two-piece fp16 split ----
@@ -541,6 +559,10 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
             }
             __builtin_amdgcn_sched_barrier(0);
             if (s + 2 < NKS && wmover) reinterpret_cast<uint4*>(s_w + ((s + 2) % 3) * Cfg::WSTEP_B)[tid] = wq[s + 2];
+            if (s == Cfg::W_LATE_AT && Cfg::W_UPFRONT < NKS && wmover) {
+#pragma unroll
+                for (int t = Cfg::W_UPFRONT; t < NKS; ++t) wq[t] = wstep_src(pass, t)[tid];
+            }
             if (s + 1 < NKS) __syncthreads();
         }
         if (pass < 2) stamp();
@@ -585,7 +607,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
     if (tid == 0) {
         double a = 0.0, b = 0.0;
         for (int w = 0; w < Cfg::NW; ++w) { a += s_red[2 * w]; b += s_red[2 * w + 1]; }
-        GNStats& o = st_out[(size_t)n * Cfg::NPART_OUT + (blockIdx.y * Cfg::TILES_X + tile_x) * Cfg::CSPLIT + cb];
+        GNStats& o = st_out[(size_t)n * Cfg::NPART_OUT + (by * Cfg::TILES_X + tile_x) * Cfg::CSPLIT + cb];
         o.sum = a;
         o.sq = b;
     }
