@@ -362,19 +362,22 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31;
-    // Workgroups are dealt to the 8 XCDs round-robin by their linear id, and each XCD has its own L2.  Output rows are not
-    // multiples of a 128-byte line (conv2: 61 px x 32 B), so the two x tiles of a row block share lines at their common edge and
-    // at the row ends; left on different XCDs those lines are evicted half written and cost a read-modify-write each (measured:
-    // +92 MB written AND +92 MB fetched per 512-agent launch of conv2).  With two workgroups per row block the pair is therefore
-    // placed on the SAME XCD, 8 ids apart: id = 16 c + r + 8 x  ->  pair 8 c + r, x tile x.
-    int bx = blockIdx.x, by = blockIdx.y, n = blockIdx.z;
-    if (Cfg::TILES_X * Cfg::CSPLIT == 2 && ((gridDim.y * gridDim.z) & 7) == 0) {
-        const unsigned lin = blockIdx.x + 2u * (blockIdx.y + gridDim.y * blockIdx.z);
-        const unsigned c16 = lin >> 4, rem = lin & 15u;
-        const unsigned pair = 8u * c16 + (rem & 7u);
-        bx = (int)(rem >> 3);
-        by = (int)(pair % gridDim.y);
-        n = (int)(pair / gridDim.y);
+    // Workgroups are dealt to the 8 XCDs round-robin by their linear id, and each XCD has its own L2.  All tiles of a sample
+    // are therefore given ids of the same residue mod 8 (id = 8 (tile + T (n / 8)) + n % 8; the grid's z extent is N rounded up
+    // to a multiple of 8 and the surplus workgroups leave at once): neighbouring tiles then share their halo rows / columns in
+    // ONE L2 instead of fetching them twice from HBM, and the 128-byte lines that straddle tile edges (output rows are not
+    // multiples of a line: conv2 61 px x 32 B) are completed in that L2 instead of being evicted half written
+    // (rocprofv3 FETCH_SIZE of conv2: 644 -> 602 MB per 512-agent launch with x-tile pairs co-located; all tiles: see
+    // profiles/r02_traffic.json).
+    int bx, by, n;
+    {
+        const unsigned T = gridDim.x * gridDim.y;
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned q = lin >> 3, tile = q % T;
+        n = (int)(8u * (q / T) + (lin & 7u));
+        bx = (int)(tile % gridDim.x);
+        by = (int)(tile / gridDim.x);
+        if (n >= N) return;
     }
     const int tile_x = bx % Cfg::TILES_X, cb = bx / Cfg::TILES_X;
     const int oy0 = by * TH, ox0 = tile_x * TW;
@@ -900,7 +903,7 @@ typedef BfsCfg<128, 128, 6, 2, 32, Bfs5::NPART_OUT, false, 1, 2> Bfs6;  // conv6
 template <class Cfg>
 static int launch_bf6(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
                       const float* bias, float* out, GNStats* st_out, int N, float xscale, float wscale, hipStream_t stream) {
-    dim3 grid(Cfg::TILES_X * Cfg::CSPLIT, Cfg::TILES_Y, N);
+    dim3 grid(Cfg::TILES_X * Cfg::CSPLIT, Cfg::TILES_Y, (N + 7) / 8 * 8);      // z rounded up: see the id -> (sample, tile) map in the kernel
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)conv_bf6_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
@@ -1119,12 +1122,12 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
             hipMemsetAsync(feat, 0, 64, stream);
             if (layer == 21) {
                 hipFuncSetAttribute((const void*)conv_bf6_kernel<Bf2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Bf2::LDS_BYTES);
-                hipLaunchKernelGGL((conv_bf6_kernel<Bf2, true>), dim3(Bf2::TILES_X * Bf2::CSPLIT, Bf2::TILES_Y, N), dim3(Bf2::NT), Bf2::LDS_BYTES,
+                hipLaunchKernelGGL((conv_bf6_kernel<Bf2, true>), dim3(Bf2::TILES_X * Bf2::CSPLIT, Bf2::TILES_Y, (N + 7) / 8 * 8), dim3(Bf2::NT), Bf2::LDS_BYTES,
                                    stream, act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N,
                                    cnn->xscale[1], 1.0f / (cnn->xscale[1] * cnn->wscale[1]), reinterpret_cast<unsigned long long*>(feat));
             } else {
                 hipFuncSetAttribute((const void*)conv_bf6_kernel<Bf3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Bf3::LDS_BYTES);
-                hipLaunchKernelGGL((conv_bf6_kernel<Bf3, true>), dim3(Bf3::TILES_X * Bf3::CSPLIT, Bf3::TILES_Y, N), dim3(Bf3::NT), Bf3::LDS_BYTES,
+                hipLaunchKernelGGL((conv_bf6_kernel<Bf3, true>), dim3(Bf3::TILES_X * Bf3::CSPLIT, Bf3::TILES_Y, (N + 7) / 8 * 8), dim3(Bf3::NT), Bf3::LDS_BYTES,
                                    stream, act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N,
                                    cnn->xscale[2], 1.0f / (cnn->xscale[2] * cnn->wscale[2]), reinterpret_cast<unsigned long long*>(feat));
             }
