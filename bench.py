@@ -320,6 +320,27 @@ def time_bandwidth_kernels(m, env, g, mi, device, reps=20):
     by = NA * T * 16 + T * P * 6        # trajectories read once; pen (4 B) + hit + amin (1 B each) written per pair slot
     out['veh_coll_fwd_kernel'] = {'algorithmic_bytes': by, 'us': round(t * 1e6, 2), 'GBps': round(by / t / 1e9, 1),
                                   'frac_of_hbm_peak': round(by / t / 1e9 / PEAK_HBM_GBS, 4), 'pairs': P, 'T': T}
+    # one GNN message pass of the decoder net (node1 -> edge -> node2 kernels, what every rollout step runs) on this batch's
+    # scenes: algorithmic bytes = node features in, embedding out, the edge layer-0 partials and node embeddings written and read
+    # back once (P, Q, X, aggregated messages), the relative poses' inputs, and the weights once
+    net = m.decoder_net
+    F_in = net.mlp_in.net[0].in_features if hasattr(net, 'mlp_in') else None
+    if F_in is not None:
+        keep = (g.x if 'x' in g else None, g.pos if 'pos' in g else None)
+        g.x = torch.randn((NA, F_in), device=device)
+        g.pos = g.past[:, -1, :4].contiguous()
+        t = _event_time(lambda: ops.gnn_forward(net, g), reps)
+        D_out = int(ops.gnn_forward(net, g).shape[-1])
+        Dn = net.mlp_in.net[-1].out_features
+        nparam = sum(p.numel() for p in net.parameters())
+        by = (NA * (F_in + D_out + 4) + 2 * NA * (2 * 128 + 2 * Dn)) * 4 + nparam * 4
+        out['gnn_step_fwd (node1 + edge + node2)'] = {'algorithmic_bytes': by, 'us': round(t * 1e6, 2), 'GBps': round(by / t / 1e9, 1),
+                                                      'frac_of_hbm_peak': round(by / t / 1e9 / PEAK_HBM_GBS, 4), 'agents': NA,
+                                                      'edges': P - NA, 'note': 'three launches; latency-bound chains of small layers'}
+        if keep[0] is not None:
+            g.x = keep[0]
+        if keep[1] is not None:
+            g.pos = keep[1]
     cars = traj.reshape(NA * T, 4)
     lw = veh_att.unsqueeze(1).expand(NA, T, 2).reshape(NA * T, 2).contiguous()
     mp = mi[g.batch].unsqueeze(1).expand(NA, T).reshape(-1)

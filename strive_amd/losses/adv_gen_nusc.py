@@ -63,6 +63,12 @@ def _masked_mean(pen, mask):
     return torch.where(mask, pen, torch.zeros_like(pen)).sum() / torch.clamp(cnt, min=1).to(pen.dtype)
 
 
+def _setup_signature(weights, init_z):
+    """what a fused-loss descriptor was built from, cheap to compare on every call (no device access)"""
+    zsig = None if init_z is None else (init_z.data_ptr(), init_z._version, tuple(init_z.shape))
+    return (tuple(sorted((k, float(v)) for k, v in weights.items())), zsig)
+
+
 def _compact_or_zero(pen, mask):
     v = pen[mask]
     if v.numel() == 0:
@@ -272,9 +278,12 @@ class AvoidCollLoss(nn.Module):
             mapixes = mapixes[self.single_mask]
         self.env_coll_loss = EnvCollLoss(veh_att, mapixes, map_env)
         self._fused = None
+        self._fused_sig = None
 
     def _setup(self):
-        if self._fused is None:
+        sig = _setup_signature(self.loss_weights, self.init_z)
+        if self._fused is None or self._fused_sig != sig:          # (weights or init_z edited after construction: rebuild)
+            self._fused_sig = sig
             w = self.loss_weights
             env = self.env_coll_loss
             NA = self.veh_coll_loss.veh_att.size(0)
@@ -374,6 +383,7 @@ class AdvGenLoss(nn.Module):
         self.slot_i_ne, self.slot_j_ne = nonego_index[vl.slot_i], nonego_index[vl.slot_j]
         self.slot_i_ego, self.slot_j_ego = self.ego_mask[vl.slot_i], self.ego_mask[vl.slot_j]
         self._fused = None
+        self._fused_sig = None
 
     def _segment_softmin(self, din):
         """softmin over all (agent, t) entries of each scene; all-inf scenes give zeros (reference :133-135)."""
@@ -388,7 +398,9 @@ class AdvGenLoss(nn.Module):
         return torch.where(torch.isnan(soft), torch.zeros_like(soft), soft)
 
     def _setup(self):
-        if self._fused is None:
+        sig = _setup_signature(self.loss_weights, self.init_z)
+        if self._fused is None or self._fused_sig != sig:
+            self._fused_sig = sig
             w = self.loss_weights
             env, vl = self.env_coll_loss, self.veh_coll_loss
             NE = self.nonego_idx.numel()
