@@ -286,12 +286,8 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
 // interleaved with the matrix work of step s.
 // =============================================================================================
 template <int CIN_, int COUT_, int KS_, int IH_, int OH_, int NPART_IN_, bool OUT_OCT_, int PT_ = 2, int WGS_PER_CU_ = 2,
-          bool ROWS2_ = false, int CBW_ = 1, bool PERSIST_ = true>
+          bool ROWS2_ = false, int CBW_ = 1>
 struct BfCfg {
-    // PERSIST: a workgroup walks several tiles and requests the next tile's first pass before its epilogue (conv3 -4 %,
-    // conv4 -1.5 %).  conv2 runs one tile per workgroup: at three workgroups per CU the loop-carried state does not fit its
-    // 168 registers (27 spilled = slower than without the loop).
-    static constexpr bool PERSIST = PERSIST_;
     static constexpr int CIN = CIN_, COUT = COUT_, KS = KS_, IH = IH_, OH = OH_, NPART_IN = NPART_IN_;
     static constexpr bool OUT_OCT = OUT_OCT_;
     static constexpr int PT = PT_;                                  // pixel tiles of 32 per wave
@@ -367,40 +363,30 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31;
     // Workgroups are dealt to the 8 XCDs round-robin by their linear id, and each XCD has its own L2.  All tiles of a sample
-    // are therefore worked on by ONE XCD: neighbouring tiles share their halo rows / columns in that L2 instead of fetching
-    // them twice from HBM, and the 128-byte lines that straddle tile edges (output rows are not multiples of a line: conv2
-    // 61 px x 32 B) are completed in that L2 instead of being evicted half written (rocprofv3 FETCH_SIZE of conv2: 1.23 x
-    // -> 1.00 x its input, profiles/r02_traffic.json).
-    // The grid is PERSISTENT: gridDim.x workgroups (a multiple of 8; about as many as are resident), workgroup w belongs to
-    // XCD w % 8 and walks that XCD's list of (sample, tile) pairs, entry q = 8-th of the list index: sample 8 (q / T) + w % 8,
-    // tile q % T, q = w / 8, w / 8 + gridDim.x / 8, ...  The first input pass of the NEXT tile is requested during the last
-    // matrix steps of the current one, so the wait for it and the statistics read overlap the epilogue stores.
-    struct TileId { int n, by, tile_x, cb, oy0, ox0, iy0, ix0; bool ok; };
-    const unsigned T_per = Cfg::TILES_X * Cfg::CSPLIT * Cfg::TILES_Y;
-    const unsigned xcd = blockIdx.x & 7u, g8 = gridDim.x >> 3;
-    auto tile_of = [&](unsigned q) {
-        TileId t;
-        const unsigned tile = q % T_per;
-        t.n = (int)(8u * (q / T_per) + xcd);
-        const int bx = (int)(tile % (Cfg::TILES_X * Cfg::CSPLIT));
-        t.by = (int)(tile / (Cfg::TILES_X * Cfg::CSPLIT));
-        t.tile_x = bx % Cfg::TILES_X;
-        t.cb = bx / Cfg::TILES_X;
-        t.oy0 = t.by * TH;
-        t.ox0 = t.tile_x * TW;
-        t.iy0 = 2 * t.oy0;
-        t.ix0 = 2 * t.ox0;
-        t.ok = t.n < N;            // (samples grow with q: the first entry past the end ends the list)
-        return t;
-    };
-    unsigned q = blockIdx.x >> 3;
-    TileId cur = tile_of(q);
-    if (!cur.ok) return;
+    // are therefore given ids of the same residue mod 8 (id = 8 (tile + T (n / 8)) + n % 8; the grid's z extent is N rounded up
+    // to a multiple of 8 and the surplus workgroups leave at once): neighbouring tiles then share their halo rows / columns in
+    // ONE L2 instead of fetching them twice from HBM, and the 128-byte lines that straddle tile edges (output rows are not
+    // multiples of a line: conv2 61 px x 32 B) are completed in that L2 instead of being evicted half written
+    // (rocprofv3 FETCH_SIZE of conv2: 644 -> 602 MB per 512-agent launch with x-tile pairs co-located; all tiles: see
+    // profiles/r02_traffic.json).
+    int bx, by, n;
+    {
+        const unsigned T = gridDim.x * gridDim.y;
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned q = lin >> 3, tile = q % T;
+        n = (int)(8u * (q / T) + (lin & 7u));
+        bx = (int)(tile % gridDim.x);
+        by = (int)(tile / gridDim.x);
+        if (n >= N) return;
+    }
+    const int tile_x = bx % Cfg::TILES_X, cb = bx / Cfg::TILES_X;
+    const int oy0 = by * TH, ox0 = tile_x * TW;
+    const int iy0 = 2 * oy0, ix0 = 2 * ox0;
 
     // ---- raw input loads of pass 0 go out first: they do not depend on the statistics ----
+    const float* in_n = in + (size_t)n * IH * IH * CIN;          // [c/8][y][x][c%8]
     float4 raw[Cfg::UITERS][2];
-    auto issue_loads = [&](const TileId& tl, int pass) {
-        const float* in_n = in + (size_t)tl.n * IH * IH * CIN;          // [c/8][y][x][c%8]
+    auto issue_loads = [&](int pass) {
 #pragma unroll
         for (int k = 0; k < Cfg::UITERS; ++k) {
             const int idx = tid + k * NT;
@@ -408,7 +394,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
             raw[k][1] = raw[k][0];
             if (idx < Cfg::UNITS) {
                 const int col = idx % ITW, r = idx / ITW;
-                const int iy = tl.iy0 + r, ix = tl.ix0 + col;
+                const int iy = iy0 + r, ix = ix0 + col;
                 if (iy < IH && ix < IH) {
                     const float4* src = reinterpret_cast<const float4*>(in_n + (((size_t)pass * IH + iy) * IH + ix) * 8);
                     raw[k][0] = src[0];
@@ -417,21 +403,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
             }
         }
     };
-    issue_loads(cur, 0);
+    issue_loads(0);
     const float my_g = tid < CIN ? gn_g[tid] : 0.f, my_b = tid < CIN ? gn_b[tid] : 0.f;   // in flight during the reduction
-    // this lane's pixel inside a pixel tile (row, column) and the byte offset of its window origin in the wave's first
-    // tile; tile i is 2 * TILE_ROWS * i input rows further
-    const int prow = Cfg::ROWS2 ? (j >> 4) : 0, pcol = Cfg::ROWS2 ? (j & 15) : j;
-    const int lane_base = (2 * (Cfg::TILE_ROWS * PT * wave + prow)) * Cfg::ROW_B + pcol * 16;
-    constexpr int CBW = Cfg::CBW, NKS = Cfg::NKS;
-    const uint4* wsrc = reinterpret_cast<const uint4*>(wfrag);
-    constexpr int WQ = Cfg::WSTEP_B / 16;                         // 128 CBW x 16 B per matrix step
-    const bool wmover = tid < WQ;                                 // the first 2 CBW waves move the weight fragments
 
-  for (;;) {                                                      // ---- tiles of this workgroup ----
-    TileId nxt = tile_of(q + g8);
-    if (!Cfg::PERSIST) nxt.ok = false;
-    const int n = cur.n, by = cur.by, tile_x = cur.tile_x, cb = cur.cb, oy0 = cur.oy0, ox0 = cur.ox0, iy0 = cur.iy0, ix0 = cur.ix0;
     // ---- GroupNorm moments of the input sample: the producer's per-tile partial sums, one per lane, reduced in a
     // fixed (butterfly) order ----
     if (wave == 0) {
@@ -460,6 +434,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
     }
     stamp();
 
+    constexpr int CBW = Cfg::CBW, NKS = Cfg::NKS;
     f32x16 acc[CBW][PT];
 #pragma unroll
     for (int c = 0; c < CBW; ++c)
@@ -468,8 +443,16 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
 
+    // this lane's pixel inside a pixel tile (row, column) and the byte offset of its window origin in the wave's first
+    // tile; tile i is 2 * TILE_ROWS * i input rows further
+    const int prow = Cfg::ROWS2 ? (j >> 4) : 0, pcol = Cfg::ROWS2 ? (j & 15) : j;
+    const int lane_base = (2 * (Cfg::TILE_ROWS * PT * wave + prow)) * Cfg::ROW_B + pcol * 16;
+
+    const uint4* wsrc = reinterpret_cast<const uint4*>(wfrag);
+    constexpr int WQ = Cfg::WSTEP_B / 16;                         // 128 CBW x 16 B per matrix step
     // fragments are stored [pass][tap pair][co / 32][piece][lane]: the CBW blocks of this workgroup are adjacent
     auto wstep_src = [&](int pass, int t) { return wsrc + ((size_t)(pass * NKS + t) * (COUT / 32) + cb * CBW) * 128; };
+    const bool wmover = tid < WQ;                                 // the first 2 CBW waves move the weight fragments
 
     for (int pass = 0; pass < Cfg::NPASS; ++pass) {
         // ALL weight fragments of the pass (13 x 16 bytes per moving thread) are requested up front and parked in
@@ -522,7 +505,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
         }
         __syncthreads();
         if (pass < 2) stamp();
-        if (pass + 1 < Cfg::NPASS) issue_loads(cur, pass + 1);      // consumed after this pass's matrix work
+        if (pass + 1 < Cfg::NPASS) issue_loads(pass + 1);      // consumed after this pass's matrix work
 
         // Software pipeline over the MFMA steps: while the matrix cores work on step s, the A/B fragments of step
         // s+1 are read from LDS into the other register set; one barrier per step.
@@ -588,10 +571,6 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
         if (pass < 2) stamp();
     }
 
-    // the next tile's first pass is requested now (the fragment and weight-step registers are free): its latency runs under
-    // the stores below and the next statistics read (requesting it a pass earlier costs more registers than three workgroups
-    // per CU leave: 37 spilled)
-    if (!TIMING && Cfg::PERSIST && nxt.ok) issue_loads(nxt, 0);
     // ---- epilogue: D column = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel within the block ----
     float fsum = 0.f, fsq = 0.f;          // this lane's 16 CBW PT outputs in fp32; everything above that in float64
 #pragma unroll
@@ -635,10 +614,6 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
         o.sum = a;
         o.sq = b;
     }
-    if (TIMING || !Cfg::PERSIST || !nxt.ok) break;          // (the phase profile times one tile per workgroup: it is launched with one workgroup per tile)
-    cur = nxt;
-    q += g8;
-  }
     stamp();
     if (TIMING && tid == 0) {
         // [0] = workgroups, [1 + k] = sum of (stamp k+1 - stamp k): statistics+first loads, staging 0, steps 0,
@@ -918,7 +893,7 @@ static int launch_bf6s(const float* in, const GNStats* st_in, const float* g, co
     return 0;
 }
 
-typedef BfCfg<16, 32, 5, 125, 61, l1b::NPART, true, 2, 3, false, 1, false> Bf2;     // conv2: octet-planar in and out
+typedef BfCfg<16, 32, 5, 125, 61, l1b::NPART, true, 2, 3> Bf2;     // conv2: octet-planar in and out
 typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, true, 2, 2, false, 2> Bf3;   // conv3: octet-planar in and out; both 32-channel blocks from one staging
 // conv4 (3x3, 29 -> 14): the whole 14 x 14 image is one workgroup tile of 16 x 16 (pixel tiles of 2 rows x 16 columns);
 typedef BfCfg<64, 64, 3, 29, 14, Bf3::NPART_OUT, true, 2, 2, true, 2> Bf4;
@@ -928,12 +903,7 @@ typedef BfsCfg<128, 128, 6, 2, 32, Bfs5::NPART_OUT, false, 1, 2> Bfs6;  // conv6
 template <class Cfg>
 static int launch_bf6(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
                       const float* bias, float* out, GNStats* st_out, int N, float xscale, float wscale, hipStream_t stream) {
-    // persistent: as many workgroups as are resident on the 256 CUs (a multiple of 8: one list of (sample, tile) pairs per XCD),
-    // but no more than one per list entry
-    const long long entries = (long long)Cfg::TILES_X * Cfg::CSPLIT * Cfg::TILES_Y * ((N + 7) / 8);      // per XCD
-    long long per_xcd = Cfg::PERSIST ? 32LL * Cfg::WGS_PER_CU : entries;
-    if (per_xcd > entries) per_xcd = entries;
-    dim3 grid((unsigned)(8 * per_xcd));
+    dim3 grid(Cfg::TILES_X * Cfg::CSPLIT, Cfg::TILES_Y, (N + 7) / 8 * 8);      // z rounded up: see the id -> (sample, tile) map in the kernel
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)conv_bf6_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
@@ -1152,12 +1122,12 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
             hipMemsetAsync(feat, 0, 64, stream);
             if (layer == 21) {
                 hipFuncSetAttribute((const void*)conv_bf6_kernel<Bf2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Bf2::LDS_BYTES);
-                hipLaunchKernelGGL((conv_bf6_kernel<Bf2, true>), dim3(8 * Bf2::TILES_X * Bf2::CSPLIT * Bf2::TILES_Y * ((N + 7) / 8)), dim3(Bf2::NT), Bf2::LDS_BYTES,
+                hipLaunchKernelGGL((conv_bf6_kernel<Bf2, true>), dim3(Bf2::TILES_X * Bf2::CSPLIT, Bf2::TILES_Y, (N + 7) / 8 * 8), dim3(Bf2::NT), Bf2::LDS_BYTES,
                                    stream, act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N,
                                    cnn->xscale[1], 1.0f / (cnn->xscale[1] * cnn->wscale[1]), reinterpret_cast<unsigned long long*>(feat));
             } else {
                 hipFuncSetAttribute((const void*)conv_bf6_kernel<Bf3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Bf3::LDS_BYTES);
-                hipLaunchKernelGGL((conv_bf6_kernel<Bf3, true>), dim3(8 * Bf3::TILES_X * Bf3::CSPLIT * Bf3::TILES_Y * ((N + 7) / 8)), dim3(Bf3::NT), Bf3::LDS_BYTES,
+                hipLaunchKernelGGL((conv_bf6_kernel<Bf3, true>), dim3(Bf3::TILES_X * Bf3::CSPLIT, Bf3::TILES_Y, (N + 7) / 8 * 8), dim3(Bf3::NT), Bf3::LDS_BYTES,
                                    stream, act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N,
                                    cnn->xscale[2], 1.0f / (cnn->xscale[2] * cnn->wscale[2]), reinterpret_cast<unsigned long long*>(feat));
             }
