@@ -588,3 +588,36 @@ def test_full_size_properties(model):
         ns = m.decode_embedding(torch.stack([z, z], dim=1).contiguous(), emb, bg, mi, env)['future_pred']
     assert_close(ns[:, 0], full, 0, 1e-6, 'NS path sample 0')
     assert_close(ns[:, 1], full, 0, 1e-6, 'NS path sample 1')
+
+
+def test_fused_losses_are_bitwise_reproducible(model, g5):
+    """The fused AvoidCollLoss / AdvGenLoss calls add their partial sums in a fixed order (no atomics): two evaluations of the
+    same inputs give the same bits for the objective and for every gradient."""
+    from strive_amd.losses.adv_gen_nusc import AvoidCollLoss, AdvGenLoss
+    m, sd = model
+    g, batch, map_idx, env_c, env_g, orc, emb, ego = g5
+    veh_att = orc.get_att_normalizer().unnormalize(batch.lw).to(DEV)
+    mapixes = map_idx[batch.batch].to(DEV)
+    z = synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='g5/z')
+    prior = (emb['prior_out'][0].to(DEV), emb['prior_out'][1].to(DEV))
+    unn = m.get_normalizer().unnormalize
+    pred = torch.from_numpy(g['adv_pred']).to(DEV)
+    planner = batch.future_gt[ego][:, :, :4].to(DEV)
+    egod = ego.to(DEV)
+    av = AvoidCollLoss(mg.REFINE_WEIGHTS, veh_att, mapixes, env_g, (z * 0.9).to(DEV), veh_coll_buffer=0.2)
+    ad = AdvGenLoss(mg.ADV_WEIGHTS, veh_att, mapixes, env_g, (z[~ego] * 0.9).to(DEV), batch.ptr, veh_coll_buffer=0.1,
+                    crash_loss_min_time=2, crash_loss_min_infront=0.0)
+    runs = []
+    for _ in range(2):
+        p1 = pred.clone().requires_grad_(True)
+        z1 = z.clone().to(DEV).requires_grad_(True)
+        l1 = av(unn(p1), z1, prior)['loss']
+        l1.backward()
+        p2 = pred.clone().requires_grad_(True)
+        z2 = z[~ego].clone().to(DEV).requires_grad_(True)
+        l2 = ad(unn(p2), unn(planner), z2, (prior[0][~egod], prior[1][~egod]))['loss']
+        l2.backward()
+        runs.append([t.detach().cpu() for t in (l1, p1.grad, z1.grad, l2, p2.grad, z2.grad)])
+    assert av._fused is not None and ad._fused is not None
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
