@@ -69,6 +69,7 @@ class AdvClosure(object):
                                    scene_graph.ptr, veh_coll_buffer=veh_coll_buffer, crash_loss_min_time=feasibility_time,
                                    crash_loss_min_infront=feasibility_infront_min)
         self.planner_name, self.planner = planner_name, planner
+        self.overlap, self._streams = True, None      # two-stream rollouts (see _two_rollouts); set overlap = False to serialise
         if planner_name == 'ego':
             # open loop: the planner's trajectory is the ego's recorded future, injected into both rollouts
             self.planner_fut = scene_graph.future_gt[self.ego_mask][:, :, :4] if planner_fut is None else planner_fut
@@ -100,16 +101,38 @@ class AdvClosure(object):
         fut = self.planner.rollout(agt, self.plan_t, self.agt_ptr, self.plan_t, control_all=False).to(self.scene_graph.future_gt)
         return self.model.get_normalizer().normalize(fut)
 
+    def _two_rollouts(self, z_a, z_b):
+        """The two rollouts of a closure are independent until the losses.  On the MI355X they run on two HIP streams: the map
+        CNN of one (bandwidth-bound, fills the chip) overlaps the GNN / GRU kernels of the other (latency chains on 128
+        workgroups), forward and -- because autograd replays every node on the stream its forward ran on -- backward.  Same
+        kernels, same inputs, same results; scratch buffers are per stream (ops._workspace)."""
+        m, g = self.model, self.scene_graph
+        kw = dict(ext_future=self.planner_fut, nfuture=self.future_len)
+        if not (z_a.is_cuda and self.overlap):
+            return (m.decode_embedding(z_a, self.embed_info, g, self.map_idx, self.map_env, **kw),
+                    m.decode_embedding(z_b, self.embed_info, g, self.map_idx, self.map_env, **kw))
+        cur = torch.cuda.current_stream(z_a.device)
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(z_a.device), torch.cuda.Stream(z_a.device))
+        outs = []
+        for st, z in zip(self._streams, (z_a, z_b)):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(m.decode_embedding(z, self.embed_info, g, self.map_idx, self.map_env, **kw))
+        for st, o in zip(self._streams, outs):
+            cur.wait_stream(st)
+            for v in o.values():
+                if torch.is_tensor(v):
+                    v.record_stream(cur)          # produced on a side stream, consumed (and later freed) on the caller's
+        return outs[0], outs[1]
+
     def step(self, log=None):
         """(reference src/utils/adv_gen_optim.py:107-171)"""
         m, g = self.model, self.scene_graph
         self.optim.zero_grad()
         z_a = self.collated(detach_other=True)      # ego latents get the matching loss only
         z_b = self.collated(detach_tgt=True)        # the others get the adversarial loss only
-        out_a = m.decode_embedding(z_a, self.embed_info, g, self.map_idx, self.map_env, ext_future=self.planner_fut,
-                                   nfuture=self.future_len)
-        out_b = m.decode_embedding(z_b, self.embed_info, g, self.map_idx, self.map_env, ext_future=self.planner_fut,
-                                   nfuture=self.future_len)
+        out_a, out_b = self._two_rollouts(z_a, z_b)
         if self.planner_name == 'hardcode':
             planner_fut = self.plan(out_a['future_pred'])
             adv_tgt = out_b['future_pred'].index_select(0, self.ego_idx)      # the differentiable stand-in for the planner
