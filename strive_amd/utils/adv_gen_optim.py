@@ -35,6 +35,38 @@ def collate_tgt_other_z(scene_graph, tgt_z, other_z):
     return torch.cat([tgt_z, other_z], dim=0).index_select(0, src)
 
 
+_rollout_streams = {}
+
+
+def two_rollouts(model, embed_info, scene_graph, map_idx, map_env, z_a, kw_a, z_b, kw_b, overlap=True):
+    """The two rollouts of an adversarial / solution closure are independent until the losses.  On the MI355X they run on two
+    HIP streams: the map CNN of one (bandwidth-bound, fills the chip) overlaps the GNN / GRU kernels of the other (latency
+    chains on ~128 workgroups), forward and -- because autograd replays every node on the stream its forward ran on -- backward
+    (measured: adversarial closure 20.4 -> 17.8 ms).  Same kernels, same inputs, same results; scratch buffers are per stream
+    (ops._workspace).  Splitting ONE rollout into two scene halves the same way gains nothing (refine closure 13.51 vs 13.48 ms:
+    the half-size CNN launches lose in tail effects what the hidden GNN time wins)."""
+    if not (z_a.is_cuda and overlap):
+        return (model.decode_embedding(z_a, embed_info, scene_graph, map_idx, map_env, **kw_a),
+                model.decode_embedding(z_b, embed_info, scene_graph, map_idx, map_env, **kw_b))
+    dev = z_a.device
+    cur = torch.cuda.current_stream(dev)
+    streams = _rollout_streams.get(str(dev))
+    if streams is None:
+        streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        _rollout_streams[str(dev)] = streams
+    outs = []
+    for st, z, kw in zip(streams, (z_a, z_b), (kw_a, kw_b)):
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            outs.append(model.decode_embedding(z, embed_info, scene_graph, map_idx, map_env, **kw))
+    for st, o in zip(streams, outs):
+        cur.wait_stream(st)
+        for v in o.values():
+            if torch.is_tensor(v):
+                v.record_stream(cur)          # produced on a side stream, consumed (and later freed) on the caller's
+    return outs[0], outs[1]
+
+
 class AdvClosure(object):
     """State + one iteration of the adversarial optimisation (reference src/utils/adv_gen_optim.py:39-171):
     the two leaf latent groups, Adam over both, the two loss modules and ``step()`` = one closure (zero_grad, two
@@ -69,7 +101,7 @@ class AdvClosure(object):
                                    scene_graph.ptr, veh_coll_buffer=veh_coll_buffer, crash_loss_min_time=feasibility_time,
                                    crash_loss_min_infront=feasibility_infront_min)
         self.planner_name, self.planner = planner_name, planner
-        self.overlap, self._streams = True, None      # two-stream rollouts (see _two_rollouts); set overlap = False to serialise
+        self.overlap = True      # two-stream rollouts (see two_rollouts); set False to serialise
         if planner_name == 'ego':
             # open loop: the planner's trajectory is the ego's recorded future, injected into both rollouts
             self.planner_fut = scene_graph.future_gt[self.ego_mask][:, :, :4] if planner_fut is None else planner_fut
@@ -102,29 +134,9 @@ class AdvClosure(object):
         return self.model.get_normalizer().normalize(fut)
 
     def _two_rollouts(self, z_a, z_b):
-        """The two rollouts of a closure are independent until the losses.  On the MI355X they run on two HIP streams: the map
-        CNN of one (bandwidth-bound, fills the chip) overlaps the GNN / GRU kernels of the other (latency chains on 128
-        workgroups), forward and -- because autograd replays every node on the stream its forward ran on -- backward.  Same
-        kernels, same inputs, same results; scratch buffers are per stream (ops._workspace)."""
-        m, g = self.model, self.scene_graph
         kw = dict(ext_future=self.planner_fut, nfuture=self.future_len)
-        if not (z_a.is_cuda and self.overlap):
-            return (m.decode_embedding(z_a, self.embed_info, g, self.map_idx, self.map_env, **kw),
-                    m.decode_embedding(z_b, self.embed_info, g, self.map_idx, self.map_env, **kw))
-        cur = torch.cuda.current_stream(z_a.device)
-        if self._streams is None:
-            self._streams = (torch.cuda.Stream(z_a.device), torch.cuda.Stream(z_a.device))
-        outs = []
-        for st, z in zip(self._streams, (z_a, z_b)):
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                outs.append(m.decode_embedding(z, self.embed_info, g, self.map_idx, self.map_env, **kw))
-        for st, o in zip(self._streams, outs):
-            cur.wait_stream(st)
-            for v in o.values():
-                if torch.is_tensor(v):
-                    v.record_stream(cur)          # produced on a side stream, consumed (and later freed) on the caller's
-        return outs[0], outs[1]
+        return two_rollouts(self.model, self.embed_info, self.scene_graph, self.map_idx, self.map_env, z_a, kw, z_b, kw,
+                            overlap=self.overlap)
 
     def step(self, log=None):
         """(reference src/utils/adv_gen_optim.py:107-171)"""

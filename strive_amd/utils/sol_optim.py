@@ -2,7 +2,7 @@
 import torch
 import torch.optim as optim
 
-from .adv_gen_optim import collate_tgt_other_z, _collate_index
+from .adv_gen_optim import collate_tgt_other_z, _collate_index, two_rollouts
 
 
 def run_find_solution_optim(cur_z, final_result_traj, future_len, lr, loss_weights, model, scene_graph, map_env,
@@ -29,9 +29,8 @@ def run_find_solution_optim(cur_z, final_result_traj, future_len, lr, loss_weigh
     for _ in range(num_iters):
         sol_optim.zero_grad()
         z_a = collate_tgt_other_z(scene_graph, tgt_z, other_z_all.detach())
-        out_a = model.decode_embedding(z_a, embed_info, scene_graph, map_idx, map_env, nfuture=future_len)
         z_b = collate_tgt_other_z(scene_graph, tgt_z.detach(), other_z_all)
-        out_b = model.decode_embedding(z_b, embed_info, scene_graph, map_idx, map_env)
+        out_a, out_b = two_rollouts(model, embed_info, scene_graph, map_idx, map_env, z_a, dict(nfuture=future_len), z_b, dict())
         tgt_pred = unn(out_a['future_pred']).transpose(0, 1).reshape(NA, future_len, 4)
         lt = avoid_loss(tgt_pred, tgt_z, tgt_prior_distrib)
         lo = match_loss(unn(out_b['future_pred']).index_select(0, other_idx), other_match, other_z_all, other_prior_distrib)
