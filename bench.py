@@ -11,6 +11,10 @@ step.  Workloads (``--workload``):
   adv          (configs[2]) the adversarial loop's closure (reference src/utils/adv_gen_optim.py:107-171, planner 'ego'):
                two rollouts with complementary detach + TgtMatchingLoss + AdvGenLoss + backward + Adam on ~512 agents in
                scenes of 2..30 agents; advances 2*NA*FT agent*timesteps.  Weak scaling like `refine`.
+               ``--planner hardcode``: the same closure in CLOSED LOOP against the rule-based planner (adv_gen_rule_based.cfg:
+               planner 'hardcode', planner_cfg 'default'; reference :133-139): agents on a synthetic lane graph, one
+               HardcodeNuscPlanner.rollout (31 planner steps per scene, on the device) per closure, nothing injected into
+               the decoder.
   sharded4096  (configs[4]) ONE batch of ~4096 agents with NC = 5 classes (reduce_cats), split over the ranks by
                strive_amd.distributed.shard_scenes; every rank runs the adversarial closure on its scenes.  The job is
                fixed, so this is strong scaling.
@@ -128,19 +132,30 @@ def build_model(device, NC):
     return m.eval().to(device)
 
 
-def build_batch(own, NC, raster_px, FT_data=12):
+def build_batch(own, NC, raster_px, FT_data=12, lane_graph=None):
+    """Synthetic scenes; with a lane graph the agents sit on its nodes (the rule-based planner needs lanes to follow), the
+    scenes spread over the crossings of the map."""
+    import numpy as np
     from strive_amd import synth
     from strive_amd.graph import Batch
     extent = raster_px * 0.25
-    scenes = [synth.make_scene(n, key, FT=FT_data, NC=NC, map_extent=(extent, extent)) for n, key in own]
+    if lane_graph is None:
+        scenes = [synth.make_scene(n, key, FT=FT_data, NC=NC, map_extent=(extent, extent)) for n, key in own]
+    else:
+        scenes = []
+        per_row = max(1, int((extent - 240.0) // 120.0))
+        for b, (n, key) in enumerate(own):
+            centre = (129.0 + 120.0 * (b % per_row), 129.0 + 120.0 * ((b // per_row) % per_row))
+            poses = synth.lane_scene_poses(lane_graph, n, key + '/lane', radius=30.0 + 1.5 * n, centre=centre)
+            scenes.append(synth.make_scene(n, key, FT=FT_data, NC=NC, poses=poses))
     batch = Batch.from_data_list(scenes)
     return batch, torch.zeros((len(own),), dtype=torch.long)
 
 
-def build_env(raster_px, device):
+def build_env(raster_px, device, lane_graph=None):
     from strive_amd import synth
     raster, dx = synth.make_raster(raster_px, raster_px)
-    return synth.SyntheticMapEnv(raster, dx).to(device)
+    return synth.SyntheticMapEnv(raster, dx, lane_graph=lane_graph).to(device)
 
 
 def refine_closure_factory(m, env, batch, map_idx, FT, device):
@@ -180,6 +195,20 @@ def adv_closure_factory(m, env, batch, map_idx, FT, device):
     ego = torch.zeros((NA,), dtype=torch.bool, device=device)
     ego[g.ptr[:-1].to(device)] = True
     pm, pv = emb['prior_out']
+    if getattr(env, 'lane_graphs', None) is not None:
+        # closed loop (adv_gen_rule_based.cfg: planner 'hardcode', planner_cfg 'default'; adv_scenario_gen.py:277-281)
+        from strive_amd.planners.planner import PlannerConfig
+        from strive_amd.planners.hardcode_goalcond_nusc import HardcodeNuscPlanner, CONFIG_DICT
+        planner = HardcodeNuscPlanner(env, PlannerConfig(**CONFIG_DICT['default']))
+        c = AdvClosure(emb['posterior_out'][0].clone(), 0.05, ADV_WEIGHTS, m, g, env, mi, emb, (pm[ego], pv[ego]),
+                       (pm[~ego], pv[~ego]), 2, 0.0, future_len=FT, veh_coll_buffer=0.1, planner_name='hardcode', planner=planner)
+
+        def step():
+            loss = c.step()
+            return loss
+        step.planner = planner
+        step.closure = c
+        return step, emb, g, mi, 2
     c = AdvClosure(emb['posterior_out'][0].clone(), 0.05, ADV_WEIGHTS, m, g, env, mi, emb, (pm[ego], pv[ego]),
                    (pm[~ego], pv[~ego]), 2, 0.0, planner_fut=g.future_gt[ego][:, :FT, :4].contiguous(), future_len=FT,
                    veh_coll_buffer=0.1)
@@ -352,6 +381,19 @@ def time_bandwidth_kernels(m, env, g, mi, device, reps=20):
     return out
 
 
+def time_planner(step, device, reps=5):
+    """The planner rollout of the closed loop on its own (events on the launching stream), on the futures of the last closure."""
+    c = step.closure
+    with torch.no_grad():
+        out = c.model.decode_embedding(c.collated(), c.embed_info, c.scene_graph, c.map_idx, c.map_env, nfuture=c.future_len)
+    t = _event_time(lambda: c.plan(out['future_pred']), reps, warm=1)
+    c.planner.check()
+    lg = next(iter(c.map_env.lane_graphs.values()))
+    return {'ms_per_rollout': round(t * 1e3, 3), 'scenes': int(c.scene_graph.ptr.shape[0] - 1), 'planner_steps': 31,
+            'lane_graph_nodes': int(lg['xy'].shape[0]), 'lane_graph_edges': int(lg['edges'].shape[0]), 'arithmetic': 'float64',
+            'note': 'reference / oracle: host numpy, about 25 ms per scene and planner step'}
+
+
 def _cpu_model():
     try:
         with open('/proc/cpuinfo') as f:
@@ -458,6 +500,9 @@ def parse_args(argv=None):
     ap.add_argument('--nc', type=int, default=0, help='semantic classes (default 2; 5 for sharded4096 = reduce_cats)')
     ap.add_argument('--ft', type=int, default=0, help='rollout steps per closure (default: 16 for refine = '
                                                       'refine_traffic_optim.cfg samp_future_len, 12 otherwise)')
+    ap.add_argument('--planner', choices=['ego', 'hardcode'], default='ego',
+                    help="adv: 'ego' = open loop against the recorded ego future, 'hardcode' = closed loop against the rule-based "
+                         "planner (adv_gen_rule_based.cfg)")
     ap.add_argument('--raster', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -504,8 +549,14 @@ def main():
 
     own, desc, scaling = workload_scenes(args, rank, world)
     m = build_model(device, args.nc)
-    env = build_env(args.raster, device)
-    batch, map_idx = build_batch(own, args.nc, args.raster)
+    lane_graph = None
+    if args.planner == 'hardcode':
+        if args.workload != 'adv':
+            raise SystemExit("bench.py: --planner hardcode belongs to --workload adv")
+        from strive_amd import synth
+        lane_graph = synth.make_lane_graph(extent=args.raster * 0.25)
+    env = build_env(args.raster, device, lane_graph)
+    batch, map_idx = build_batch(own, args.nc, args.raster, lane_graph=lane_graph)
     factory = {'refine': refine_closure_factory, 'train': train_step_factory}.get(args.workload, adv_closure_factory)
     step, emb, g, mi, rollouts = factory(m, env, batch, map_idx, args.ft, device)
     for _ in range(args.warmup):
@@ -522,6 +573,10 @@ def main():
         loss = step()
     barrier()
     dt_local = time.perf_counter() - t0
+    planner_ms = None
+    if getattr(step, 'planner', None) is not None:
+        step.planner.check()               # capacity / range status of every planner rollout of the run (raises)
+        planner_ms = time_planner(step, device)
     dt = dt_local
     NA = int(g.past.shape[0])
     units_local = rollouts * NA * args.ft * args.steps
@@ -537,9 +592,14 @@ def main():
         gathered = [None] * world
         dist.all_gather_object(gathered, per_rank[0])
         per_rank = gathered
+    if args.planner == 'hardcode':
+        closure_adv = ('closed-loop adversarial closure: 2 x decode_embedding(nfuture=%d) with complementary detach + '
+                       'HardcodeNuscPlanner.rollout (31 planner steps per scene, device) + TgtMatchingLoss + AdvGenLoss + backward + Adam')
+    else:
+        closure_adv = ('adversarial closure: 2 x decode_embedding(nfuture=%d, ext_future) with complementary detach + '
+                       'TgtMatchingLoss + AdvGenLoss + backward + Adam')
     closure = {'refine': 'refine closure: decode_embedding(nfuture=%d) + AvoidCollLoss + backward + Adam',
-               'adv': 'adversarial closure: 2 x decode_embedding(nfuture=%d, ext_future) with complementary detach + '
-                      'TgtMatchingLoss + AdvGenLoss + backward + Adam',
+               'adv': closure_adv,
                'sharded4096': 'adversarial closure: 2 x decode_embedding(nfuture=%d, ext_future) + TgtMatchingLoss + '
                               'AdvGenLoss + backward + Adam',
                'train': 'training step: TrafficModel.forward(future_sample=True) (2 rollouts of %d steps) + TrafficModelLoss + '
@@ -558,6 +618,7 @@ def main():
                    'arithmetic': 'fp32 everywhere; the map CNN on the fp16 matrix cores with two-piece round-to-nearest operand splits '
                                  '(3 products per fp32 product, dropped terms <= 2^-24), fp32 accumulate'},
         'final_loss': float(loss.detach().cpu()),
+        'planner': None if planner_ms is None else planner_ms,
         'per_rank': [{'rank': r, 'agents': a, 'ms_per_step': t} for r, a, t in per_rank],
     }
     failed = False

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define STRIVE_ABI_VERSION 10
+#define STRIVE_ABI_VERSION 11
 #define STRIVE_HID 128        /* hidden width of every MLP in the reference (models/common.py, interaction_net.py:32,41) */
 #define STRIVE_MAX_LAYERS 4
 #define STRIVE_ZDIM 32
@@ -399,6 +399,89 @@ int strive_rollout_bwd_train(const StriveDecoder* dec, const StriveScenes* sc, c
                              const float* z, const float* ext_future, const int32_t* mapix, int32_t FT, const float* d_traj,
                              float* dz, float* d_past_feat, float* d_map_feat, float* d_gnn, float* d_gru, float* d_cnn,
                              const void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, strive_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rule-based lane-following planner (reference src/planners/hardcode_goalcond_nusc.py), the planner that
+ * adv_gen_rule_based.cfg attacks in closed loop: src/utils/adv_gen_optim.py:133-139 calls
+ * HardcodeNuscPlanner.rollout once per optimisation iteration.  All arithmetic is float64 like the reference's numpy.
+ * ---------------------------------------------------------------------------------------------- */
+#define STRIVE_PLANNER_MAXMAPS 4
+#define STRIVE_PLANNER_NSTATUS 8
+
+/* Connections of one lane-graph node in list order (out_edges / in_edges of the reference's lane-graph dict,
+ * src/datasets/nuscenes_utils.py:50-123), the first four inline; len = |xy[node] - xy[this]|. */
+typedef struct StriveLaneNode {
+    int32_t n;
+    int32_t node[4];
+    int32_t pad[3];
+    double len[4];
+} StriveLaneNode;
+
+/* One map's lane graph + a uniform grid over its directed edges (each edge is listed, in ascending order, in every cell
+ * its bounding box grown by `xydistmax` touches, so that get_lane_matches (:298-322) reads one cell instead of all edges). */
+typedef struct StrivePlannerMap {
+    const double* xy;                 /* (N,2) node positions */
+    const StriveLaneNode* succ;       /* (N) */
+    const StriveLaneNode* pred;       /* (N) */
+    const int32_t* succ_ptr;          /* (N+1)  CSR of the same lists (used beyond the fourth connection) */
+    const int32_t* succ_idx;
+    const double* succ_len;
+    const int32_t* pred_ptr;
+    const int32_t* pred_idx;
+    const double* pred_len;
+    const double* edges;              /* (M,5) x0, y0, unit direction, length */
+    const int32_t* edge_ix;           /* (M,2) node pair */
+    const int32_t* cell_ptr;          /* (gnx*gny+1) */
+    const int32_t* cell_edges;
+    int32_t N, M, gnx, gny;
+    double gx0, gy0, gcell;
+} StrivePlannerMap;
+
+/* PlannerConfig of the reference (:25-59) + two derived values evaluated on the host with numpy's arithmetic. */
+typedef struct StrivePlannerCfg {
+    double dt, preddt, xydistmax, smax, accmax, interacdist, col_plim, score_wmin, score_wfac;
+    double cdistmax;                  /* 1 - cos(radians(cdistang)) */
+    double tmax;                      /* nsteps * preddt */
+    double predsfacs[4], predafacs[4], planaccfacs[4];
+    int32_t nsteps, npredsfacs, npredafacs, nplanaccfacs, plannspeeds;
+} StrivePlannerCfg;
+
+/* The planner after reset() (:109-127): initial world of every scene, scene-sorted, the ego at position `ego_idx` of
+ * its scene.  init (NO,6) = x, y, heading angle, signed speed, length, width.  Rows of `agent_obs` (the non-ego objects
+ * in scene order) are described by row_obj (index into init) and row_scene. */
+typedef struct StrivePlanner {
+    StrivePlannerCfg cfg;
+    int32_t nmaps;
+    StrivePlannerMap maps[STRIVE_PLANNER_MAXMAPS];
+    int32_t B, NO, NR, ego_idx;
+    const int32_t* ptr;               /* (B+1) object offsets */
+    const int32_t* scene_map;         /* (B) map of each scene */
+    const double* init;               /* (NO,6) */
+    const int32_t* row_obj;           /* (NR) */
+    const int32_t* row_scene;         /* (NR) */
+} StrivePlanner;
+
+/* nstep = int(planner_t[-1] / dt) planner steps after the initial one; traj_cap = predicted trajectories kept per scene
+ * and planner step (other objects x routes x speed profiles). */
+size_t strive_planner_workspace_bytes(const StrivePlanner* pl, int32_t nstep, int32_t traj_cap);
+
+/* HardcodeNuscPlanner.rollout(agent_obs, agent_t, agent_ptr, planner_t) (:178-276) for all scenes: agent_obs (NR,T,4)
+ * fp32 UNNORMALISED (x, y, cos, sin) futures of the non-ego objects (NaN from the first unobserved frame on), agent_t (T),
+ * t_out (nstep+1) = linspace(dt, dt*nstep, nstep+1) and planner_t (TP) float64 -> plan (B,TP,4) float64.
+ * Per planner step: lane matching / clustering / breadth-first route enumeration / blended arc-length routes for every
+ * object (compute_splines, :559-598), 5-circle gaps between the ego's candidate speed profiles and every predicted
+ * trajectory (compute_action, :829-857), world update (update_wstate, :601-621).
+ * status (STRIVE_PLANNER_NSTATUS int32, device, zeroed by the caller): non-zero entries name a capacity or range
+ * violation (0 matches, 1 clusters, 2 chains, 3 chain nodes, 4 knots, 5 route range, 6 trajectory cap, 7 action check);
+ * the plan of an affected scene is NaN. */
+int strive_planner_rollout(const StrivePlanner* pl, const double* agent_obs, const double* agent_t, int32_t T,
+                           const double* t_out, int32_t nstep, const double* planner_t, int32_t TP, int32_t traj_cap,
+                           double* plan, int32_t* status, void* ws, size_t ws_bytes, strive_stream_t stream);
+
+/* Debug view used by the parity tests: routes of one object pose (x, y, h, s) on map `mapix` as the planner builds them.
+ * Outputs: nroutes (1), nk (maxr) knots per route, knots (maxr, maxk, 5) = s, x, y, cos, sin. */
+int strive_planner_routes(const StrivePlanner* pl, int32_t mapix, const double* pose4, int32_t maxr, int32_t maxk,
+                          int32_t* nroutes, int32_t* nk, double* knots, int32_t* status, strive_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,33 @@ class StriveDecoder(C.Structure):
                 ('dt', C.c_float), ('max_hdot', C.c_float), ('max_s', C.c_float)]
 
 
+class StriveLaneNode(C.Structure):
+    _fields_ = [('n', C.c_int32), ('node', C.c_int32 * 4), ('pad', C.c_int32 * 3), ('len', C.c_double * 4)]
+
+
+class StrivePlannerMap(C.Structure):
+    _fields_ = [('xy', C.c_void_p), ('succ', C.c_void_p), ('pred', C.c_void_p), ('succ_ptr', C.c_void_p), ('succ_idx', C.c_void_p),
+                ('succ_len', C.c_void_p), ('pred_ptr', C.c_void_p), ('pred_idx', C.c_void_p), ('pred_len', C.c_void_p),
+                ('edges', C.c_void_p), ('edge_ix', C.c_void_p), ('cell_ptr', C.c_void_p), ('cell_edges', C.c_void_p),
+                ('N', C.c_int32), ('M', C.c_int32), ('gnx', C.c_int32), ('gny', C.c_int32),
+                ('gx0', C.c_double), ('gy0', C.c_double), ('gcell', C.c_double)]
+
+
+class StrivePlannerCfg(C.Structure):
+    _fields_ = [('dt', C.c_double), ('preddt', C.c_double), ('xydistmax', C.c_double), ('smax', C.c_double), ('accmax', C.c_double),
+                ('interacdist', C.c_double), ('col_plim', C.c_double), ('score_wmin', C.c_double), ('score_wfac', C.c_double),
+                ('cdistmax', C.c_double), ('tmax', C.c_double),
+                ('predsfacs', C.c_double * 4), ('predafacs', C.c_double * 4), ('planaccfacs', C.c_double * 4),
+                ('nsteps', C.c_int32), ('npredsfacs', C.c_int32), ('npredafacs', C.c_int32), ('nplanaccfacs', C.c_int32),
+                ('plannspeeds', C.c_int32)]
+
+
+class StrivePlanner(C.Structure):
+    _fields_ = [('cfg', StrivePlannerCfg), ('nmaps', C.c_int32), ('maps', StrivePlannerMap * 4),
+                ('B', C.c_int32), ('NO', C.c_int32), ('NR', C.c_int32), ('ego_idx', C.c_int32),
+                ('ptr', C.c_void_p), ('scene_map', C.c_void_p), ('init', C.c_void_p), ('row_obj', C.c_void_p), ('row_scene', C.c_void_p)]
+
+
 P = C.c_void_p
 I = C.c_int32
 SZ = C.c_size_t
@@ -135,10 +162,13 @@ PROTOTYPES = {
     'strive_rollout_train_workspace_bytes': (SZ, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), I]),
     'strive_rollout_bwd_train': (C.c_int, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), P, P, P, P, P, I, P, P, P, P, P, P, P,
                                            P, SZ, P, SZ, P]),
+    'strive_planner_workspace_bytes': (SZ, [C.POINTER(StrivePlanner), I, I]),
+    'strive_planner_rollout': (C.c_int, [C.POINTER(StrivePlanner), P, P, I, P, I, P, I, I, P, P, P, SZ, P]),
+    'strive_planner_routes': (C.c_int, [C.POINTER(StrivePlanner), I, P, I, I, P, P, P, P, P]),
 }
 
 
-ABI_VERSION = 10   # include/strive_hip.h STRIVE_ABI_VERSION
+ABI_VERSION = 11   # include/strive_hip.h STRIVE_ABI_VERSION
 
 
 class StriveLib(object):

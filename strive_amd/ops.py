@@ -71,6 +71,16 @@ def _cached_pack(owner, key, module_for_sig, builder, extra_sig=()):
     return ent[1]
 
 
+def _cached_pack_hit(owner, key, module_for_sig, extra_sig=()):
+    """Would ``_cached_pack`` find an up-to-date entry (nothing is built)?"""
+    cache = owner.__dict__.get('_strive_packs')
+    if cache is None:
+        return False
+    mods = module_for_sig if isinstance(module_for_sig, (tuple, list)) else (module_for_sig,)
+    ent = cache.get(key)
+    return ent is not None and ent[0] == (_param_signature(*mods), extra_sig)
+
+
 def _sd_of(module, prefix):
     return {prefix + '.' + k: v for k, v in module.state_dict().items()}
 
@@ -559,6 +569,28 @@ class _RolloutTrainFn(torch.autograd.Function):
         return (dz.reshape(ctx.zshape), dpf, dmf, None) + tuple(_split_like(dp, ctx.ps))
 
 
+def _decoder_pack_key(model, map_env, dev):
+    key = ('dec', str(dev), map_env.nusc_raster.data_ptr())
+    # plain values the pack copies: normaliser statistics and the bicycle parameters (not object identities)
+    nm, an, bp = model.normalizer, model.att_normalizer, model.bicycle_params
+    extra = (tuple(nm.mean_vals.tolist()), tuple(nm.std_vals.tolist()), tuple(an.mean_vals.tolist()), tuple(an.std_vals.tolist()),
+             tuple(sorted((k, tuple(v) if isinstance(v, (tuple, list)) else v) for k, v in bp.items())),
+             tuple(map_env.bounds), map_env.L, map_env.W)
+    return key, extra
+
+
+def decoder_packs_ready(model, g, map_env, NS, dev):
+    """True when a rollout of (model, g, map_env) with NS samples would build nothing: the decoder's weight pack, the scene
+    descriptor and the map pack are cached.  Callers that fork side streams (utils.adv_gen_optim.two_rollouts) run serially
+    on their own stream until this holds, so that packs are always built -- and their memory owned -- by the caller's stream
+    and never written on one stream while another one reads them."""
+    if model.normalizer is None or model.att_normalizer is None or model.bicycle_params is None:
+        return False
+    info = scene_info(g)                      # (host work + two small uploads on the caller's stream the first time)
+    key, extra = _decoder_pack_key(model, map_env, dev)
+    return _cached_pack_hit(model, key, model, extra) and NS in info._packs
+
+
 def decoder_rollout(model, g, map_feat, past_feat, z, map_idx, map_env, ext_future, FT):
     """autoregressive_decoder as one fused call; differentiable w.r.t. ``z`` only."""
     lib = _lib_for(z, map_feat, past_feat, g.past)
@@ -582,12 +614,7 @@ def decoder_rollout(model, g, map_feat, past_feat, z, map_idx, map_env, ext_futu
     def build():
         return params.pack_decoder(model.state_dict(), NC, map_env, dev, model.normalizer, model.att_normalizer,
                                    model.bicycle_params)
-    key = ('dec', str(dev), map_env.nusc_raster.data_ptr())
-    # plain values the pack copies: normaliser statistics and the bicycle parameters (not object identities)
-    nm, an, bp = model.normalizer, model.att_normalizer, model.bicycle_params
-    extra = (tuple(nm.mean_vals.tolist()), tuple(nm.std_vals.tolist()), tuple(an.mean_vals.tolist()), tuple(an.std_vals.tolist()),
-             tuple(sorted((k, tuple(v) if isinstance(v, (tuple, list)) else v) for k, v in bp.items())),
-             tuple(map_env.bounds), map_env.L, map_env.W)
+    key, extra = _decoder_pack_key(model, map_env, dev)
     h = _RolloutCtx()
     h.lib = lib
     h.dec = _cached_pack(model, key, model, build, extra_sig=extra)

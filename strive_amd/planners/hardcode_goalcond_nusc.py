@@ -1,28 +1,25 @@
 """Rule-based lane-following planner (reference src/planners/hardcode_goalcond_nusc.py), the planner
 ``adv_gen_rule_based.cfg`` attacks in closed loop (src/utils/adv_gen_optim.py:133-139: one ``rollout`` per optimisation
-iteration).  Host-side numpy like the reference -- it walks a lane graph and scores a handful of speed profiles; there is
-nothing for a GPU here -- with the same class name, constructor, ``reset`` / ``rollout`` signatures, configuration
-dictionaries and outputs, restated around three small building blocks:
+iteration) -- same class name, constructor, ``reset`` / ``rollout`` signatures, configuration dictionaries and outputs.
 
-  * ``LinearPath``      piecewise-linear map s -> R^d with strict bounds (what the reference gets from scipy's interp1d);
-  * ``LaneGraph``       the per-map graph (node positions, successor / predecessor lists, directed edge table);
-  * ``VehicleState``    one world object; the world is a dict id -> VehicleState.
+The reference walks its scenes one after the other in numpy (31 planner steps per scene, ~25 ms each).  Here ``rollout`` is
+ONE C-ABI call (``strive_planner_rollout``, strive_amd/csrc/planner.hip) for all scenes of the batch: the non-ego objects'
+lane routes and predicted trajectories of every planner step are built in one launch (only the ego's pose chains the
+steps), then two launches per planner step score the ego's speed profiles and move it.  float64, numpy's operation order.
 
-Per planner step (dt = 0.2 s): every object is matched to the lane edges it could be following (heading within
-``cdistang`` degrees, lateral distance below ``xydistmax``), matches that are connected through other matches are
-clustered and the closest one of each cluster kept (:298-347); from each kept edge all routes at least as long as the
-object could travel are enumerated breadth-first, successor lists in order (:379-414), resampled every 0.4 m, blended so
-that they pass through the object's own position (:487-556) and turned into an arc-length path.  The ego then follows ITS
-FIRST route: 25 two-phase speed profiles (:804-826) are scored by the probability of coming close to any predicted
-trajectory of any other object (5-circle box distance, :860-897; tanh score growing with time, :724-728), the
-fastest profile below ``col_plim`` wins (the safest if none) and its first speed is applied for one step (:829-857).
+Host work happens once, in ``reset`` (reference :109-127): the initial world of every scene, and per map the lane graph
+packed for the device (node connection records, CSR lists, the edge table and a uniform grid over the edges that replaces
+get_lane_matches' scan of all edges, :298-322).  ``rollout`` accepts the futures of the non-ego agents as a device tensor
+(no device->host copy in the optimisation loop) or, like the reference, as a numpy array.
 """
-from collections import deque
+import ctypes as C
 
 import numpy as np
 import torch
 
 from .planner import PlannerNusc, PlannerConfig
+from .. import _lib as L
+from .. import ops
 
 DEF_CONFIG = {
     'dt': 0.2, 'preddt': 0.2, 'nsteps': 25, 'cdistang': 20.0, 'xydistmax': 2.0, 'smax': 15.0, 'accmax': 3.0,
@@ -33,423 +30,278 @@ DEF_CONFIG = {
 TUNED_VAL_FINAL_1 = dict(DEF_CONFIG, smax=20.0, accmax=4.0, score_wmin=0.3, score_wfac=0.02)
 CONFIG_DICT = {'default': DEF_CONFIG, 'final_tuned_val_1': TUNED_VAL_FINAL_1}
 
-LANE_DS, LANE_SIG, SBUFFER = 0.4, 3.5, 4.0      # constants of rollout() in the reference (:211-213)
+STATUS_NAMES = ('lane matches of one pose (> 96)', 'match clusters (> 16)', 'lane chains of one match (> 48 forward / 16 backward)',
+                'nodes of one chain (> 316)', 'route knots (> 384: speed above ~28 m/s)', 'arc length outside a route / time outside the plan',
+                'predicted trajectories per scene and step (raise traj_cap)', 'action speed check')
+
+LANE_NODE = np.dtype([('n', '<i4'), ('node', '<i4', (4,)), ('pad', '<i4', (3,)), ('len', '<f8', (4,))])
+assert LANE_NODE.itemsize == 64
 
 
-class LinearPath(object):
-    """y(t) by linear interpolation between knots, error outside [t0, tN] -- scipy.interpolate.interp1d(kind='linear',
-    bounds_error=True, assume_sorted=True) evaluated with the same arithmetic (slope * (t - t_lo) + y_lo)."""
-
-    def __init__(self, t, y):
-        self.t = np.asarray(t, dtype=np.float64)
-        self.y = np.asarray(y, dtype=np.float64)
-
-    def __call__(self, q):
-        q = np.asarray(q, dtype=np.float64)
-        if np.any(q < self.t[0]) or np.any(q > self.t[-1]):
-            raise ValueError('LinearPath: query outside [%g, %g]' % (self.t[0], self.t[-1]))
-        hi = np.clip(np.searchsorted(self.t, q), 1, len(self.t) - 1)
-        lo = hi - 1
-        tail = (1,) * (self.y.ndim - 1)
-        slope = (self.y[hi] - self.y[lo]) / (self.t[hi] - self.t[lo]).reshape(q.shape + tail)
-        return slope * (q - self.t[lo]).reshape(q.shape + tail) + self.y[lo]
-
-
-class VehicleState(object):
-    __slots__ = ('x', 'y', 'h', 's', 'l', 'w', 'match_edges', 'match_points', 'routes', 'control')
-
-    def __init__(self, x, y, h, s, l, w):
-        self.x, self.y, self.h, self.s, self.l, self.w = float(x), float(y), float(h), float(s), float(l), float(w)
-        self.match_edges = self.match_points = self.routes = self.control = None
+def _connection_records(lists, lengths_of):
+    n = len(lists)
+    rec = np.zeros((n,), dtype=LANE_NODE)
+    ptr = np.zeros((n + 1,), dtype=np.int32)
+    idx, lens = [], []
+    for v, conn in enumerate(lists):
+        rec['n'][v] = len(conn)
+        for j, c in enumerate(conn):
+            ln = lengths_of(v, int(c))
+            if j < 4:
+                rec['node'][v, j] = c
+                rec['len'][v, j] = ln
+            idx.append(int(c))
+            lens.append(ln)
+        ptr[v + 1] = len(idx)
+    return rec, ptr, np.asarray(idx, dtype=np.int32).reshape(-1), np.asarray(lens, dtype=np.float64).reshape(-1)
 
 
-class LaneGraph(object):
-    def __init__(self, lg):
-        self.xy = np.asarray(lg['xy'], dtype=np.float64)
-        self.succ, self.pred = lg['out_edges'], lg['in_edges']
-        e = np.asarray(lg['edges'], dtype=np.float64)
-        self.e_xy, self.e_dir, self.e_len = e[:, 0:2], e[:, 2:4], e[:, 4]
-        self.e_ix = np.asarray(lg['edgeixes'], dtype=np.int64)
-
-    # -- which edges could this pose be on?  (reference get_lane_matches / edge_closest_point, :298-359)
-    def match(self, x, y, h, cdistmax, xydistmax):
-        cdist = 1.0 - self.e_dir[:, 0] * np.cos(h) - self.e_dir[:, 1] * np.sin(h)
-        keep = np.nonzero(cdist < cdistmax)[0]
-        if keep.size == 0:
-            return np.empty((0, 2), dtype=np.int64), np.empty((0, 2))
-        pts, dist = closest_on_segments(self.e_xy[keep], self.e_dir[keep], self.e_len[keep], np.array([x, y]))
-        near = dist < xydistmax
-        return self.e_ix[keep][near], pts[near]
-
-    # -- one representative per group of matches connected through matches  (cluster_matches_combine / cluster_bfs, :324-376)
-    def cluster(self, x, y, edges, points):
-        if len(points) == 0:
-            return edges, points
-        order = np.argsort(np.linalg.norm(np.array([[x, y]]) - points, axis=1))
-        done = {(int(a), int(b)): False for a, b in edges}
-        kept_e, kept_p = [], []
-        for k in order:
-            key = (int(edges[k, 0]), int(edges[k, 1]))
-            if done[key]:
-                continue
-            kept_e.append(list(key))
-            kept_p.append(points[k])
-            for forward in (True, False):
-                todo = deque([key])
-                while todo:
-                    a, b = todo.popleft()
-                    done[(a, b)] = True
-                    if forward:
-                        nxt = [(b, c) for c in self.succ[b]]
-                    else:
-                        nxt = [(c, a) for c in self.pred[a]]
-                    for cand in nxt:
-                        if cand in done and not done[cand]:
-                            todo.append(cand)
-        return np.array(kept_e), np.array(kept_p)
-
-    # -- all node chains from v of length > mindist (or ending at a terminal node), breadth first with the successor
-    #    lists in order: the first chain always takes the first connection  (expand_verts, :379-414)
-    def chains(self, v, table, mindist):
-        todo = deque([([v], 0.0)])
-        out = []
-        while todo:
-            verts, length = todo.popleft()
-            verts = list(verts)
-            while length <= mindist:
-                cur = verts[-1]
-                conn = table[cur]
-                if len(conn) == 0:
-                    break
-                for other in conn[1:]:
-                    todo.append((verts + [other], length + float(np.linalg.norm(self.xy[other] - self.xy[cur]))))
-                first = conn[0]
-                length = length + float(np.linalg.norm(self.xy[first] - self.xy[cur]))
-                verts.append(first)
-            out.append((verts, length))
-        return out
+def edge_grid(edges, margin, cell):
+    """Uniform grid over the directed edges (x0, y0, dx, dy, len): every edge is listed, ascending, in all cells its bounding
+    box grown by ``margin`` touches.  A point closer than ``margin`` to an edge therefore finds it in its own cell."""
+    p0 = edges[:, 0:2]
+    p1 = p0 + edges[:, 4:5] * edges[:, 2:4]
+    pad = margin * (1.0 + 1e-9) + 1e-6
+    lo = np.minimum(p0, p1) - pad
+    hi = np.maximum(p0, p1) + pad
+    gx0, gy0 = float(np.floor(lo[:, 0].min())), float(np.floor(lo[:, 1].min()))
+    ix0 = np.floor((lo[:, 0] - gx0) / cell).astype(np.int64)
+    ix1 = np.floor((hi[:, 0] - gx0) / cell).astype(np.int64)
+    iy0 = np.floor((lo[:, 1] - gy0) / cell).astype(np.int64)
+    iy1 = np.floor((hi[:, 1] - gy0) / cell).astype(np.int64)
+    gnx, gny = int(ix1.max()) + 1, int(iy1.max()) + 1
+    cells, eids = [], []
+    e = np.arange(edges.shape[0], dtype=np.int64)
+    for oy in range(int((iy1 - iy0).max()) + 1):
+        for ox in range(int((ix1 - ix0).max()) + 1):
+            sel = (ix0 + ox <= ix1) & (iy0 + oy <= iy1)
+            cells.append((iy0[sel] + oy) * gnx + ix0[sel] + ox)
+            eids.append(e[sel])
+    cells, eids = np.concatenate(cells), np.concatenate(eids)
+    order = np.lexsort((eids, cells))
+    cells, eids = cells[order], eids[order]
+    ptr = np.zeros((gnx * gny + 1,), dtype=np.int32)
+    np.add.at(ptr, cells + 1, 1)
+    return dict(gx0=gx0, gy0=gy0, gcell=float(cell), gnx=gnx, gny=gny, cell_ptr=np.cumsum(ptr, dtype=np.int64).astype(np.int32),
+                cell_edges=eids.astype(np.int32))
 
 
-def closest_on_segments(p0, direction, length, query):
-    along = (query[None, 0] - p0[:, 0]) * direction[:, 0] + (query[None, 1] - p0[:, 1]) * direction[:, 1]
-    along = np.minimum(np.maximum(along, 0.0), length)
-    pts = p0 + along[:, None] * direction
-    return pts, np.linalg.norm(query[None, :] - pts, axis=1)
+class PackedLaneGraph(object):
+    """One map's lane-graph dict (reference src/datasets/nuscenes_utils.py:50-123) as device arrays + StrivePlannerMap."""
+
+    def __init__(self, lg, xydistmax, device, cell=4.0):
+        xy = np.ascontiguousarray(np.asarray(lg['xy'], dtype=np.float64))
+        edges = np.ascontiguousarray(np.asarray(lg['edges'], dtype=np.float64))
+        eix = np.asarray(lg['edgeixes'], dtype=np.int64)
+        # |xy[b] - xy[a]| as the reference's expand_verts evaluates it (np.linalg.norm of the 1-D difference, :395-399)
+        cache = {}
+
+        def length(a, b):
+            key = (a, b) if a < b else (b, a)
+            v = cache.get(key)
+            if v is None:
+                v = float(np.linalg.norm(xy[b] - xy[a]))
+                cache[key] = v
+            return v
+        succ, sp, si, sl = _connection_records(lg['out_edges'], length)
+        pred, pp, pi, pl = _connection_records(lg['in_edges'], length)
+        grid = edge_grid(edges, float(xydistmax), float(cell))
+        host = dict(xy=xy, succ=succ, pred=pred, succ_ptr=sp, succ_idx=si, succ_len=sl, pred_ptr=pp, pred_idx=pi, pred_len=pl,
+                    edges=edges, edge_ix=eix.astype(np.int32), cell_ptr=grid['cell_ptr'], cell_edges=grid['cell_edges'])
+        self.t = {}
+        for k, v in host.items():
+            a = np.ascontiguousarray(v)
+            if a.size == 0:
+                a = np.zeros((1,), dtype=a.dtype)          # never hand a NULL pointer to the library
+            self.t[k] = torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(device)
+        self.N, self.M = xy.shape[0], edges.shape[0]
+        self.grid = grid
+        self.xydistmax = float(xydistmax)
+
+    def fill(self, m):
+        for k, t in self.t.items():
+            setattr(m, k, t.data_ptr())
+        m.N, m.M, m.gnx, m.gny = self.N, self.M, self.grid['gnx'], self.grid['gny']
+        m.gx0, m.gy0, m.gcell = self.grid['gx0'], self.grid['gy0'], self.grid['gcell']
 
 
-def straight_route(xy, h, back, fwd):
-    """no lane nearby: keep the heading  (constant_heading_spline, :477-484)"""
-    c, s = np.cos(h), np.sin(h)
-    return LinearPath(np.array([-back, fwd]), np.array([[xy[0] - back * c, xy[1] - back * s, c, s],
-                                                         [xy[0] + fwd * c, xy[1] + fwd * s, c, s]]))
-
-
-def routes_through(graph, edges, points, back, fwd, xydistmax, xy, h):
-    """Arc-length paths (x, y, cos, sin)(s), s = 0 at the object, one per (kept match, forward chain, backward chain)
-    (get_prediction_splines / local_lane_closest / xy2spline, :433-556)."""
-    if len(edges) == 0:
-        return [straight_route(xy, h, back, fwd)]
-    out = []
-    need_f, need_b = fwd + SBUFFER + xydistmax, back + SBUFFER + xydistmax
-    nb, nf = int((back + SBUFFER) / LANE_DS) + 1, int((fwd + SBUFFER) / LANE_DS) + 1
-    s_eval = np.concatenate((np.linspace(-back - SBUFFER, 0.0, nb + 1)[:-1], np.linspace(0.0, fwd + SBUFFER, nf)), 0)
-    for (v0, v1), _ in zip(edges, points):
-        fchains = graph.chains(int(v1), graph.succ, need_f)
-        bchains = graph.chains(int(v0), graph.pred, need_b)
-        for fverts, flen in fchains:
-            for bverts, blen in bchains:
-                pts = np.concatenate((graph.xy[bverts[::-1]], graph.xy[fverts]), axis=0)
-                i0 = len(bverts) - 1
-                if flen <= need_f:                                   # dead end ahead: extend straight
-                    d = pts[-1] - pts[-2]
-                    d = d / np.linalg.norm(d)
-                    pts = np.concatenate((pts, (pts[-1] + d * (1.0 + need_f - flen))[None]), axis=0)
-                if blen <= need_b:
-                    d = pts[0] - pts[1]
-                    d = d / np.linalg.norm(d)
-                    pts = np.concatenate(((pts[0] + d * (1.0 + need_b - blen))[None], pts), axis=0)
-                    i0 += 1
-                # the locally closest point of the chain to the object, walking downhill from the matched edge
-                seg = pts[1:] - pts[:-1]
-                seglen = np.linalg.norm(seg, axis=1)
-                cp, cd = closest_on_segments(pts[:-1], seg / seglen[:, None], seglen, xy)
-                k = i0
-                while k - 1 >= 0 and cd[k - 1] < cd[k]:
-                    k -= 1
-                while k + 1 < len(cd) and cd[k + 1] < cd[k]:
-                    k += 1
-                anchor = cp[k]
-                s_nodes = np.zeros(len(pts))
-                s_nodes[1:] = np.cumsum(seglen)
-                s_nodes = s_nodes - s_nodes[k] - np.linalg.norm(anchor - pts[k])
-                lane = LinearPath(s_nodes, pts)(s_eval)
-                # blend from the lane to the object's own position around s = 0
-                lane = lane + (xy - anchor)[None, :] * np.exp(-np.square(s_eval) / LANE_SIG ** 2)[:, None]
-                d = lane[1:] - lane[:-1]
-                dl = np.linalg.norm(d, axis=1)
-                head = d / dl[:, None]
-                head = np.concatenate((head, head[[-1]]), 0)
-                knots = np.concatenate((lane, head), 1)
-                knots[nb, 2], knots[nb, 3] = np.cos(h), np.sin(h)      # pass through the object's heading exactly
-                s = np.zeros(len(lane))
-                s[1:] = np.cumsum(dl)
-                s -= s[nb]
-                if not (s[0] < -back and s[-1] > fwd):
-                    raise AssertionError('route does not cover [%g, %g]: [%g, %g]' % (-back, fwd, s[0], s[-1]))
-                out.append(LinearPath(s, knots))
-    return out
-
-
-def signed_speed(x0, y0, x1, y1, h1, dt):
-    mag = np.sqrt((x1 - x0) ** 2 + (y1 - y0) ** 2) / dt
-    return mag if (x1 - x0) * np.cos(h1) + (y1 - y0) * np.sin(h1) >= 0 else -mag
-
-
-def speed_ramp(s, target, acc, n, dt):
-    """n+1 speeds starting at s, moving towards `target` by at most acc*dt per step  (compute_speed_profile, :670-683)"""
-    k = np.arange(n + 1)
-    if target > s:
-        return np.minimum(s + k * acc * dt, target)
-    if target < s:
-        return np.maximum(s - k * acc * dt, target)
-    return s + np.zeros(n + 1)
-
-
-def travelled(speeds, dt):
-    d = np.zeros(len(speeds))
-    d[1:] = np.cumsum(speeds[1:] * dt)
-    return d
-
-
-def candidate_profiles(s0, dt, nsteps, accfacs, accmax, smax, nspeeds):
-    """two-phase speed profiles: reach one of `nspeeds` speeds after half the horizon, then one of `nspeeds` again
-    (gen_sprofiles, :804-826)"""
-    n1 = nsteps // 2
-    n2 = nsteps - n1
-    out = []
-    for fac in accfacs:
-        acc = fac * accmax
-        for s1 in np.linspace(max(0.0, s0 - n1 * dt * acc), min(smax, s0 + n1 * dt * acc), nspeeds):
-            first = speed_ramp(s0, s1, acc, n1, dt)
-            for s2 in np.linspace(max(0.0, first[-1] - n2 * dt * acc), min(smax, first[-1] + n2 * dt * acc), nspeeds):
-                prof = np.concatenate((first, speed_ramp(first[-1], s2, acc, n2, dt)[1:]))
-                out.append({'speeds': prof, 'dist': travelled(prof, dt), 'acc': acc, 's1': s1, 's2': s2})
-    return out
-
-
-def box_circles(b):
-    """(T, N, 5) boxes (x, y, h, l, w) -> (T, N, 5, 3) circles (x, y, r): four of radius w/4 towards the corners and one of
-    radius w/2 in the middle  (boxes2circles, :860-882)"""
-    xy, hh, li, wi = b[:, :, 0:2], b[:, :, 2], b[:, :, 3], b[:, :, 4]
-    L, W = np.maximum(li, wi), np.minimum(li, wi)
-    H = np.where(li < wi, hh + np.pi / 2.0, hh)
-    a0 = ((L - W) / 2 + W / 4)[:, :, None] * np.stack((np.cos(H), np.sin(H)), 2)
-    a1 = (W / 4)[:, :, None] * np.stack((-np.sin(H), np.cos(H)), 2)
-    c = np.empty(b.shape[:2] + (5, 3))
-    c[:, :, 0, :2] = xy + a0 + a1
-    c[:, :, 1, :2] = xy - a0 + a1
-    c[:, :, 2, :2] = xy - a0 - a1
-    c[:, :, 3, :2] = xy + a0 - a1
-    c[:, :, 4, :2] = xy
-    c[:, :, 4, 2] = W / 2
-    c[:, :, :4, 2] = W[:, :, None] / 4
+def planner_cfg_struct(cfg):
+    c = L.StrivePlannerCfg()
+    for k in ('dt', 'preddt', 'xydistmax', 'smax', 'accmax', 'interacdist', 'col_plim', 'score_wmin', 'score_wfac'):
+        setattr(c, k, float(getattr(cfg, k)))
+    c.cdistmax = float(1.0 - np.cos(np.radians(cfg.cdistang)))
+    c.tmax = float(cfg.nsteps * cfg.preddt)
+    for name, cnt in (('predsfacs', 'npredsfacs'), ('predafacs', 'npredafacs'), ('planaccfacs', 'nplanaccfacs')):
+        vals = [float(v) for v in getattr(cfg, name)]
+        if not 1 <= len(vals) <= 4:
+            raise NotImplementedError('planner config %s: 1..4 entries are supported, got %d' % (name, len(vals)))
+        for i, v in enumerate(vals):
+            getattr(c, name)[i] = v
+        setattr(c, cnt, len(vals))
+    c.nsteps, c.plannspeeds = int(cfg.nsteps), int(cfg.plannspeeds)
     return c
 
 
-def box_gap(b0, b1):
-    """(T, N0, 5), (T, N1, 5) -> (T, N0): smallest circle-to-circle gap to any box of b1  (approx_bbox_distance, :885-897)"""
-    T, N0, _ = b0.shape
-    N1 = b1.shape[1]
-    c0 = box_circles(b0).reshape((T, N0, 5, 1, 1, 3))
-    c1 = box_circles(b1).reshape((T, 1, 1, N1, 5, 3))
-    gap = np.linalg.norm(c1[..., 0:2] - c0[..., 0:2], axis=5) - c0[..., 2] - c1[..., 2]
-    return np.amin(gap, axis=(2, 3, 4))
-
-
 class HardcodeNuscPlanner(PlannerNusc):
+    traj_cap = 512          # predicted trajectories kept per scene and planner step (objects x routes x speed profiles)
+
     def __init__(self, map_env, cfg):
         super(HardcodeNuscPlanner, self).__init__(map_env, cfg)
         assert isinstance(self.cfg, PlannerConfig)
         self.lane_graphs = self.map_env.lane_graphs
         self._graphs = {}
-        self.init_world = None
-        self.batch_mask = self.B = self.batch_maps = None
+        self.B = self.batch_mask = self.batch_maps = None
         self.ego_idx = 0
+        self._world = None
+        self._pending = None
+        self._rows = {}
+        self._tables = {}
 
-    # ---- world construction --------------------------------------------------------------------
-    @staticmethod
-    def _name(i):
-        return '%04d' % i
-
-    def _world_of(self, state, att):
-        """(n,6) unnormalised (x,y,hx,hy,s,hdot) + (n,2) (l,w) of ONE scene -> {id: VehicleState}  (state_conv, :80-98)"""
-        state = state.detach().cpu().numpy()
-        att = att.detach().cpu().numpy()
-        world = {}
-        for i in range(state.shape[0]):
-            x, y, hc, hs, s, _ = state[i]
-            world['ego' if i == self.ego_idx else self._name(i)] = VehicleState(x, y, np.arctan2(hs, hc), s, att[i, 0], att[i, 1])
-        return world
-
+    # ---- reset: initial world + lane graphs on the device (reference :80-127) -----------------------------------------
     def reset(self, init_state, vehicle_atts, batch_mask, batch_size, map_idx, ego_idx=0):
-        """(reference :109-127)"""
-        self.ego_idx = ego_idx
-        self.B = batch_size
-        self.batch_mask = batch_mask
-        self.init_world = [self._world_of(init_state[batch_mask == b], vehicle_atts[batch_mask == b]) for b in range(batch_size)]
-        self.batch_maps = [self.map_env.map_list[int(map_idx[b])] for b in range(batch_size)]
+        """init_state (NA,6) UNNORMALISED (x, y, hx, hy, s, hdot), vehicle_atts (NA,2) (l, w), batch_mask (NA) scene of every
+        agent, map_idx (B).  The device the planner runs on is init_state's."""
+        dev = init_state.device
+        ops._lib_for(init_state)
+        self.ego_idx, self.B, self.batch_mask = int(ego_idx), int(batch_size), batch_mask
+        state = init_state.detach().cpu().numpy()
+        att = vehicle_atts.detach().cpu().numpy()
+        mask = batch_mask.detach().cpu().numpy()
+        rows, counts = [], []
+        for b in range(self.B):
+            idx = np.nonzero(mask == b)[0]
+            counts.append(len(idx))
+            for i in idx:                                       # state_conv (:80-98): heading angle in the state's precision
+                x, y, hc, hs, s, _ = state[i]
+                rows.append([float(x), float(y), float(np.arctan2(hs, hc)), float(s), float(att[i, 0]), float(att[i, 1])])
+        if min(counts) < 1 or not 0 <= self.ego_idx < min(counts):
+            raise ValueError('every scene needs an ego at position %d' % self.ego_idx)
+        ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        self.batch_maps = [self.map_env.map_list[int(map_idx[b])] for b in range(self.B)]
+        names = sorted(set(self.batch_maps), key=self.batch_maps.index)
+        if len(names) > 4:
+            raise NotImplementedError('at most 4 maps per batch (nuScenes has 4)')
+        graphs = []
+        for name in names:
+            key = (name, float(self.cfg.xydistmax), str(dev))
+            g = self._graphs.get(key)
+            if g is None:
+                g = PackedLaneGraph(self.lane_graphs[name], self.cfg.xydistmax, dev)
+                self._graphs[key] = g
+            graphs.append(g)
+        self._world = dict(
+            dev=dev, counts=counts, ptr_np=ptr, graphs=graphs,
+            ptr=torch.from_numpy(ptr).to(dev),
+            scene_map=torch.tensor([names.index(n) for n in self.batch_maps], dtype=torch.int32, device=dev),
+            init=torch.tensor(rows, dtype=torch.float64, device=dev).reshape(-1, 6).contiguous())
+        self._rows = {}
 
-    def _graph(self, name):
-        g = self._graphs.get(name)
-        if g is None:
-            g = LaneGraph(self.lane_graphs[name])
-            self._graphs[name] = g
-        return g
+    def _row_maps(self, agent_ptr):
+        key = tuple(int(v) for v in agent_ptr)
+        ent = self._rows.get(key)
+        if ent is None:
+            w = self._world
+            obj, scene = [], []
+            for b in range(self.B):
+                n = w['counts'][b]
+                if key[b + 1] - key[b] != n - 1 or key[b] != len(obj):
+                    raise ValueError('agent_ptr does not describe the non-ego agents of the reset() batch')
+                for i in range(n):
+                    if i != self.ego_idx:
+                        obj.append(int(w['ptr_np'][b]) + i)
+                        scene.append(b)
+            dev = w['dev']
+            ent = (torch.tensor(obj + [0], dtype=torch.int32, device=dev), torch.tensor(scene + [0], dtype=torch.int32, device=dev), len(obj))
+            self._rows = {key: ent}
+        return ent
 
-    def _observations(self, world, obs, obs_t):
-        """per non-ego object: its observed future as a path over time, up to the first NaN frame  (create_other_agents, :140-176)"""
-        paths = {}
-        for k in range(obs.shape[0]):
-            oid = self._name(k + 1 if k >= self.ego_idx else k)
-            o = world[oid]
-            states = np.concatenate([np.array([[o.x, o.y, np.cos(o.h), np.sin(o.h)]]), obs[k]], axis=0)
-            bad = np.nonzero(np.isnan(states.sum(axis=1)))[0]
-            n = states.shape[0] if bad.size == 0 else int(bad[0])
-            if n == 1:
-                paths[oid] = (0.0, 0.0, None)
-                continue
-            t = np.append(np.array([0.0]), obs_t[:n - 1])
-            paths[oid] = (0.0, float(t[-1]), LinearPath(t, states[:n]))
-        return paths
+    def _table(self, arr):
+        a = np.ascontiguousarray(np.asarray(arr, dtype=np.float64))
+        key = a.tobytes()
+        t = self._tables.get(key)
+        if t is None:
+            if len(self._tables) > 16:
+                self._tables.clear()
+            t = torch.from_numpy(a.copy()).to(self._world['dev'])
+            self._tables[key] = t
+        return t
 
-    # ---- one planner step ------------------------------------------------------------------------
-    def _plan_routes(self, world, graph):
-        cfg = self.cfg
-        tmax = cfg.nsteps * cfg.preddt
-        cdistmax = 1.0 - np.cos(np.radians(cfg.cdistang))
-        for o in world.values():
-            e, p = graph.match(o.x, o.y, o.h, cdistmax, cfg.xydistmax)
-            o.match_edges, o.match_points = graph.cluster(o.x, o.y, e, p)
-            back = 1.0 if o.s > 0 else 1.0 + abs(o.s) * tmax
-            fwd = 1.0 + cfg.smax * tmax if o.s < 0 else max(1.0 + cfg.smax * tmax, 1.0 + o.s * tmax)
-            o.routes = routes_through(graph, o.match_edges, o.match_points, back, fwd, cfg.xydistmax, np.array([o.x, o.y]), o.h)
+    def _descriptor(self, row_obj, row_scene, NR):
+        w = self._world
+        p = L.StrivePlanner()
+        p.cfg = planner_cfg_struct(self.cfg)
+        p.nmaps = len(w['graphs'])
+        for i, g in enumerate(w['graphs']):
+            g.fill(p.maps[i])
+        p.B, p.NO, p.NR, p.ego_idx = self.B, int(w['ptr_np'][-1]), NR, self.ego_idx
+        p.ptr, p.scene_map, p.init = w['ptr'].data_ptr(), w['scene_map'].data_ptr(), w['init'].data_ptr()
+        p.row_obj, p.row_scene = row_obj.data_ptr(), row_scene.data_ptr()
+        return p
 
-    def _predict_others(self, world, ego):
-        cfg = self.cfg
-        trajs = []
-        for oid, o in world.items():
-            if o is ego or np.sqrt((ego.x - o.x) ** 2 + (ego.y - o.y) ** 2) > cfg.interacdist:
-                continue
-            dists = [travelled(speed_ramp(o.s, o.s * sf, cfg.accmax * af, cfg.nsteps, cfg.preddt), cfg.preddt)
-                     for sf in cfg.predsfacs for af in cfg.predafacs]
-            for route in o.routes:
-                for d in dists:
-                    q = route(d)
-                    tr = np.empty((cfg.nsteps + 1, 5))
-                    tr[:, :2] = q[:, :2]
-                    tr[:, 2] = np.arctan2(q[:, 3], q[:, 2])
-                    tr[:, 3], tr[:, 4] = o.l, o.w
-                    trajs.append(tr)
-        if not trajs:
-            return np.empty((cfg.nsteps + 1, 0, 5))
-        return np.transpose(np.array(trajs), (1, 0, 2))
+    # ---- deferred status check: no host synchronisation inside an optimisation closure ----------------------------------
+    def check(self, wait=True):
+        """Raise if an earlier rollout hit a capacity / range limit (its plan is NaN for the affected scenes).  ``wait=False``
+        only looks at rollouts whose status has already arrived on the host."""
+        pend = self._pending
+        if pend is None:
+            return
+        host, event = pend
+        if event is not None:
+            if not wait and not event.query():
+                return
+            event.synchronize()
+        self._pending = None
+        bad = [STATUS_NAMES[i] for i in range(len(STATUS_NAMES)) if int(host[i]) != 0]
+        if bad:
+            raise L.StriveHipError('HardcodeNuscPlanner.rollout exceeded a limit of the device planner: ' + '; '.join(bad))
 
-    def _choose_profile(self, ego, profiles, others, prefer_stop):
-        """(plot_plan_info, :768-801 and score_dists, :724-728)"""
-        cfg = self.cfg
-        if others.shape[1] == 0:
-            return profiles[int(np.argmax([p['dist'][-1] for p in profiles]))]
-        route = ego.routes[0]
-        box = np.empty((cfg.nsteps + 1, 1, 5))
-        box[:, :, 3], box[:, :, 4] = ego.l, ego.w
-        w = cfg.score_wmin + np.arange(cfg.nsteps + 1) * cfg.score_wfac
-        risk = []
-        for p in profiles:
-            q = route(p['dist'])
-            box[:, 0, :2] = q[:, :2]
-            box[:, 0, 2] = np.arctan2(q[:, 3], q[:, 2])
-            gap = box_gap(box, others)[:, 0]
-            pr = 1.0 + np.tanh(-gap * w)
-            pr[gap < 0] = 1.0
-            risk.append(1.0 - np.prod(1.0 - pr))
-        ok = [i for i in range(len(profiles)) if risk[i] < cfg.col_plim]
-        if not ok:
-            return profiles[int(np.argmin(risk))]
-        reach = [profiles[i]['dist'][-1] for i in ok]
-        return profiles[ok[int(np.argmin(reach) if prefer_stop else np.argmax(reach))]]
-
-    def _act(self, world):
-        """(compute_action, :829-857 and postprocess_act_for_speed, :642-666)"""
-        cfg = self.cfg
-        ego = world['ego']
-        profiles = candidate_profiles(ego.s, cfg.preddt, cfg.nsteps, cfg.planaccfacs, cfg.accmax, cfg.smax, cfg.plannspeeds)
-        others = self._predict_others(world, ego)
-        best = self._choose_profile(ego, profiles, others, prefer_stop=len(ego.match_points) == 0)
-        s_next = speed_ramp(ego.s, best['s1'], best['acc'], 1, cfg.dt)[1]
-        nx, ny, nc, ns = ego.routes[0](cfg.dt * s_next)
-        nh = np.arctan2(ns, nc)
-        # place the new pose so that the step's signed speed is exactly s_next
-        if np.sign(signed_speed(ego.x, ego.y, nx, ny, nh, cfg.dt)) != np.sign(s_next):
-            px, py, ph = ego.x + np.cos(ego.h) * s_next * cfg.dt, ego.y + np.sin(ego.h) * s_next * cfg.dt, ego.h
-        else:
-            d = np.array([nx - ego.x, ny - ego.y])
-            dn = np.linalg.norm(d)
-            if dn == 0.0:
-                assert s_next == 0.0
-                px, py, ph = ego.x + np.cos(ego.h) * s_next * cfg.dt, ego.y + np.sin(ego.h) * s_next * cfg.dt, ego.h
-            else:
-                d = d / dn
-                px, py, ph = ego.x + d[0] * abs(s_next) * cfg.dt, ego.y + d[1] * abs(s_next) * cfg.dt, nh
-        assert abs(signed_speed(ego.x, ego.y, px, py, ph, cfg.dt) - s_next) < 1e-6
-        ego.control = (px, py, ph)
-
-    def _advance(self, world, t0, paths):
-        """(update_wstate, :601-621): the ego moves to its control, the others to their observed pose; objects without an
-        observation at the new time leave the world"""
-        dt = self.cfg.dt
-        t1 = t0 + dt
-        new = {}
-        for oid, o in world.items():
-            if o.control is not None:
-                x, y, h = o.control
-                new[oid] = VehicleState(x, y, h, signed_speed(o.x, o.y, x, y, h, dt), o.l, o.w)
-            else:
-                ta, tb, path = paths[oid]
-                if ta <= t1 <= tb:
-                    x, y, hc, hs = path(t1)
-                    h = np.arctan2(hs, hc)
-                    new[oid] = VehicleState(x, y, h, signed_speed(o.x, o.y, x, y, h, dt), o.l, o.w)
-        return new, t1
-
-    # ---- rollout -------------------------------------------------------------------------------------
+    # ---- rollout (reference :178-276) -------------------------------------------------------------------------------------
     def rollout(self, agent_obs, agent_t, agent_ptr, planner_t, init_state=None, control_all=False, viz=None, coll_t=None):
-        """(reference :178-276)  agent_obs (NA-B, T, 4) unnormalised futures of the non-ego agents, agent_t (T) their times,
-        agent_ptr (B+1) scene offsets into agent_obs, planner_t (T') times at which the planner pose is returned.
-        -> float64 tensor (B, T', 4) of (x, y, cos h, sin h)."""
-        if self.init_world is None or self.B is None:
+        """agent_obs (NA-B, T, 4) UNNORMALISED futures of the non-ego agents (device tensor or numpy array), agent_t (T)
+        their times, agent_ptr (B+1) scene offsets into agent_obs, planner_t (T') times at which the planner pose is returned
+        -> float64 tensor (B, T', 4) of (x, y, cos h, sin h): on the device for a device ``agent_obs``, on the host for numpy."""
+        if self._world is None or self.B is None:
             raise RuntimeError('HardcodeNuscPlanner.rollout: call reset() first')
         if init_state is not None or control_all or agent_obs is None:
             raise NotImplementedError('only the closed-loop attack mode of adv_gen_optim is implemented (observed other agents)')
+        if viz is not None:
+            raise NotImplementedError('planner visualisation (viz=...) is outside the hot path; render the returned plan instead')
+        self.check(wait=False)
+        w = self._world
+        dev = w['dev']
+        from_numpy = not torch.is_tensor(agent_obs)
+        obs = torch.from_numpy(np.ascontiguousarray(agent_obs)) if from_numpy else agent_obs.detach()
+        obs = obs.to(dev).to(torch.float64).contiguous()     # widened exactly, as numpy does when stacking onto the float64 world state
+        agent_t = np.asarray(agent_t, dtype=np.float64)
+        planner_t = np.asarray(planner_t, dtype=np.float64)
+        assert obs.dim() == 3 and obs.shape[1] == agent_t.shape[0] and obs.shape[2] == 4
+        row_obj, row_scene, NR = self._row_maps(np.asarray(agent_ptr).reshape(-1))
+        assert obs.shape[0] == NR
         cfg = self.cfg
-        assert agent_obs.shape[1] == agent_t.shape[0]
         nstep = int(planner_t[-1] / cfg.dt)
         t_out = np.linspace(cfg.dt, cfg.dt * nstep, nstep + 1)      # (sic: the reference labels its nstep+1 poses like this)
-        result = []
-        for b in range(self.B):
-            world = {k: VehicleState(o.x, o.y, o.h, o.s, o.l, o.w) for k, o in self.init_world[b].items()}
-            obs = agent_obs[agent_ptr[b]:agent_ptr[b + 1]]
-            assert obs.shape[0] == len(world) - 1
-            paths = self._observations(world, obs, agent_t)
-            graph = self._graph(self.batch_maps[b])
-            t = 0.0
-            poses = []
-            for k in range(nstep + 1):
-                if k > 0:
-                    world, t = self._advance(world, t, paths)
-                self._plan_routes(world, graph)
-                self._act(world)
-                x, y, h = world['ego'].control
-                poses.append([x, y, np.cos(h), np.sin(h)])
-            result.append(np.array(poses))
-        plan = LinearPath(t_out, np.stack(result, axis=1))(np.asarray(planner_t, dtype=np.float64))      # (T', B, 4)
-        return torch.from_numpy(np.ascontiguousarray(np.transpose(plan, (1, 0, 2))))
+        lib = ops._lib_for(obs)
+        desc = self._descriptor(row_obj, row_scene, NR)
+        nbytes = lib.query('strive_planner_workspace_bytes', C.byref(desc), nstep, int(self.traj_cap))
+        if nbytes == 0:
+            raise L.StriveHipError('strive_planner_workspace_bytes: ' + lib.query('strive_last_error').decode())
+        ws = ops._workspace(dev, nbytes, tag='planner')
+        TP = planner_t.shape[0]
+        plan = torch.empty((self.B, TP, 4), dtype=torch.float64, device=dev)
+        status = torch.zeros((8,), dtype=torch.int32, device=dev)
+        at, to, pt = self._table(agent_t), self._table(t_out), self._table(planner_t)
+        if NR == 0:
+            obs = torch.zeros((1, max(1, agent_t.shape[0]), 4), dtype=torch.float64, device=dev)
+        lib.call('strive_planner_rollout', C.byref(desc), L.ptr(obs), L.ptr(at), int(agent_t.shape[0]), L.ptr(to), nstep, L.ptr(pt),
+                 TP, int(self.traj_cap), L.ptr(plan), L.ptr(status), L.ptr(ws), ws.numel(), L.stream_ptr(obs))
+        if dev.type == 'cuda':
+            host = torch.empty((8,), dtype=torch.int32).pin_memory()
+            host.copy_(status, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            self._pending = (host, ev)
+        else:
+            self._pending = (status.clone(), None)
+        if from_numpy or dev.type != 'cuda':
+            self.check(wait=True)
+        return plan.cpu() if from_numpy else plan

@@ -1,7 +1,7 @@
 """Adversarial optimisation loop (reference src/utils/adv_gen_optim.py:19-211): open loop against the recorded ego
 future (planner_name == 'ego') and closed loop against the rule-based planner (planner_name == 'hardcode',
-strive_amd.planners.hardcode_goalcond_nusc -- a host-side numpy component, called once per iteration like the reference
-does)."""
+strive_amd.planners.hardcode_goalcond_nusc: one C-ABI call per iteration on the futures as they sit on the device, where the
+reference copies them to the host and walks its scenes in numpy)."""
 import torch
 import torch.optim as optim
 
@@ -45,10 +45,15 @@ def two_rollouts(model, embed_info, scene_graph, map_idx, map_env, z_a, kw_a, z_
     (measured: adversarial closure 20.4 -> 17.8 ms).  Same kernels, same inputs, same results; scratch buffers are per stream
     (ops._workspace).  Splitting ONE rollout into two scene halves the same way gains nothing (refine closure 13.51 vs 13.48 ms:
     the half-size CNN launches lose in tail effects what the hidden GNN time wins)."""
-    if not (z_a.is_cuda and overlap):
+    from .. import ops
+    dev = z_a.device
+    ns = lambda z: z.shape[1] if z.dim() == 3 else 1
+    # weight / scene / map packs are built lazily inside the first rollout: that one runs on the caller's stream (the packs
+    # then belong to it and are complete before any side stream is forked), see ops.decoder_packs_ready
+    if not (z_a.is_cuda and overlap and ops.decoder_packs_ready(model, scene_graph, map_env, ns(z_a), dev)
+            and ops.decoder_packs_ready(model, scene_graph, map_env, ns(z_b), dev)):
         return (model.decode_embedding(z_a, embed_info, scene_graph, map_idx, map_env, **kw_a),
                 model.decode_embedding(z_b, embed_info, scene_graph, map_idx, map_env, **kw_b))
-    dev = z_a.device
     cur = torch.cuda.current_stream(dev)
     streams = _rollout_streams.get(str(dev))
     if streams is None:
@@ -128,8 +133,8 @@ class AdvClosure(object):
 
     def plan(self, future_pred):
         """The rule-based planner's reaction (B, FT, 4), NORMALISED, to the non-ego agents of ``future_pred`` (reference
-        :133-139).  A host-side numpy component: this is a device->host copy and a CPU rollout per call."""
-        agt = self.unn(future_pred.index_select(0, self.other_idx)).detach().cpu().numpy()
+        :133-139): the futures stay on the device, the plan comes back as a device tensor -- no host round trip."""
+        agt = self.unn(future_pred.index_select(0, self.other_idx)).detach()
         fut = self.planner.rollout(agt, self.plan_t, self.agt_ptr, self.plan_t, control_all=False).to(self.scene_graph.future_gt)
         return self.model.get_normalizer().normalize(fut)
 
@@ -169,6 +174,10 @@ def run_adv_gen_optim(cur_z, lr, loss_weights, model, scene_graph, map_env, map_
                       planner_name, tgt_prior_distrib, other_prior_distrib, feasibility_time, feasibility_infront_min,
                       planner=None, planner_viz_out=None, attack_agt_idx=None, future_len=None, veh_coll_buffer=0.1,
                       log=None):
+    if planner_viz_out is not None:
+        # (the reference renders the final closed-loop rollout frame by frame, :186-190: matplotlib + ffmpeg, outside the path)
+        raise NotImplementedError('planner_viz_out: planner visualisation is not part of this package; render the returned '
+                                  'final_result_traj instead')
     c = AdvClosure(cur_z, lr, loss_weights, model, scene_graph, map_env, map_idx, embed_info, tgt_prior_distrib,
                    other_prior_distrib, feasibility_time, feasibility_infront_min, attack_agt_idx=attack_agt_idx,
                    future_len=future_len, veh_coll_buffer=veh_coll_buffer, planner_name=planner_name, planner=planner)
@@ -184,6 +193,8 @@ def run_adv_gen_optim(cur_z, lr, loss_weights, model, scene_graph, map_env, map_
         final_result_traj[ego_inds, torch.zeros_like(ego_inds)] = scene_graph.future_gt[ego_mask][:, :, :4]
     else:       # the planner's actual reaction to the final scenario (reference :184-192)
         final_result_traj[ego_inds, torch.zeros_like(ego_inds)] = c.plan(final_decoder_out['future_pred'])
+        if hasattr(planner, 'check'):
+            planner.check()                   # deferred capacity / range status of every planner rollout of the loop
     tgt_traj = final_result_traj[ego_inds, torch.zeros_like(ego_inds)]
     with torch.no_grad():
         fin = adv_loss(unn(final_decoder_out['future_pred']), unn(tgt_traj), cur_z[~ego_mask].clone().detach(),

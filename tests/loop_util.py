@@ -171,11 +171,9 @@ def hardcode_inputs():
 
 
 def run_oracle_hardcode_loop(g, orc, n):
-    """oracle rollouts / losses + THIS package's rule-based planner in closed loop (the oracle itself never imports product
-    code: the planner object is handed to it)"""
+    """oracle rollouts / losses + the oracle's restatement of the rule-based planner in closed loop"""
     from oracle import loops
-    from strive_amd.planners.planner import PlannerConfig
-    from strive_amd.planners.hardcode_goalcond_nusc import HardcodeNuscPlanner, CONFIG_DICT
+    from oracle.planner import HardcodeNuscPlanner, PlannerConfig, CONFIG_DICT
     lg, batch, map_idx, raster, dx = hardcode_inputs()
     env = synth.SyntheticMapEnv(raster, dx, lane_graph=lg)
     with torch.no_grad():

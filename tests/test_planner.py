@@ -1,16 +1,102 @@
-"""The rule-based planner: strive_amd.planners.hardcode_goalcond_nusc against the reference's own
-HardcodeNuscPlanner.rollout on a synthetic lane graph (fixture g10, tests/golden/make_golden.py::g10_planner)."""
+"""The rule-based planner.
+
+  * oracle/planner.py (numpy restatement) against the reference's own HardcodeNuscPlanner.rollout on a synthetic lane graph
+    (fixture g10, tests/golden/make_golden.py::g10_planner) -- CPU;
+  * the product planner (strive_amd/planners/hardcode_goalcond_nusc.py -> strive_amd/csrc/planner.hip, ONE C-ABI call for all
+    scenes) against the same fixture and against the oracle on larger random worlds (branching routes, objects off every
+    lane, reversing and parked objects, observations that end early, two maps) -- through the host emulation of the kernels
+    on CPU, and on the MI355X (-m gpu), there also at the 512-agent batch of adv_gen_rule_based.cfg.
+"""
+import os
+import sys
 import time
 
 import numpy as np
+import pytest
 import torch
 
 import make_golden as mg
 from util import golden
-from strive_amd.planners.planner import PlannerConfig
-from strive_amd.planners.hardcode_goalcond_nusc import HardcodeNuscPlanner, CONFIG_DICT, LinearPath, LaneGraph
+from oracle import planner as oplan
 from strive_amd import synth
+from strive_amd import _lib as L
+from strive_amd import ops
+from strive_amd.planners.planner import PlannerConfig
+from strive_amd.planners.hardcode_goalcond_nusc import HardcodeNuscPlanner, CONFIG_DICT, edge_grid
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'hipemu'))
+
+
+@pytest.fixture()
+def emu_ops():
+    import build as emu_build
+    emu = L.StriveLib(emu_build.build(), require_all=True)
+    orig = (ops._lib_for, L.get_lib)
+    ops._lib_for = lambda *tensors: emu           # CPU tensors + the emulated library: test infrastructure only
+    L.get_lib = lambda: emu
+    yield emu
+    ops._lib_for, L.get_lib = orig
+
+
+# ------------------------------------------------------------------------------------------------
+# inputs
+# ------------------------------------------------------------------------------------------------
+
+def random_world(sizes, key, nmaps=1, T=12, tail=True):
+    """Scenes on the synthetic lane graph: agents on lane nodes, curved constant-speed futures (fp32 like the model's
+    output), per scene one agent moved off every lane, one parked, one reversing, one whose observations end early."""
+    lg = synth.make_lane_graph()
+    t = np.linspace(0.5, 0.5 * T, T)
+    states, atts, mask, obs = [], [], [], []
+    for b, n in enumerate(sizes):
+        cx = 128.0 + 40.0 * ((b % 3) - 1)
+        cy = 128.0 + 40.0 * (((b // 3) % 3) - 1)
+        px, py, h, s = synth.lane_scene_poses(lg, n, '%s/%d' % (key, b), radius=38.0, centre=(cx, cy))
+        if n > 3:
+            px[3] += 9.0; py[3] += 7.0; h[3] += 0.9
+        if n > 2:
+            s[2] = 0.0
+        lw = np.stack([4.2 + 0.4 * synth.counter_uniform((n,), '%s/l%d' % (key, b)),
+                       1.9 + 0.2 * synth.counter_uniform((n,), '%s/w%d' % (key, b))], -1)
+        if n > 5:
+            lw[5] = lw[5, ::-1] * np.array([0.5, 2.2])          # wider than long: boxes2circles swaps the axes
+        states.append(np.stack([px, py, np.cos(h), np.sin(h), s, np.zeros(n)], -1))
+        atts.append(lw)
+        mask += [b] * n
+        om = synth.counter_uniform((n - 1, 1), '%s/om%d' % (key, b), -0.03, 0.03)          # yaw rates
+        hh = h[1:, None] + om * t[None]
+        sp = s[1:, None] * np.ones((1, T))
+        if n > 4:
+            sp[3] = -2.5                                          # the object of index 4 backs up
+        dx = np.cumsum(sp * np.cos(hh) * 0.5, axis=1)
+        dy = np.cumsum(sp * np.sin(hh) * 0.5, axis=1)
+        fut = np.stack([px[1:, None] + dx, py[1:, None] + dy, np.cos(hh), np.sin(hh)], -1)
+        if tail and n > 2:
+            fut[1, 7:] = np.nan
+            if n > 6:
+                fut[5, 0:] = np.nan                               # never observed: leaves after the first step
+        obs.append(fut)
+    ptr = np.concatenate([[0], np.cumsum([n - 1 for n in sizes])])
+    map_idx = torch.tensor([b % nmaps for b in range(len(sizes))], dtype=torch.long)
+    return (lg, synth.f32(np.concatenate(states)), synth.f32(np.concatenate(atts)), torch.tensor(mask),
+            np.concatenate(obs).astype(np.float32), t, ptr, map_idx)
+
+
+def both_planners(world, cfg_name, device='cpu'):
+    lg, st, att, mask, obs, t, ptr, map_idx = world
+    nmaps = int(map_idx.max()) + 1
+    B = len(ptr) - 1
+    cfg = CONFIG_DICT[cfg_name]
+    orc = oplan.HardcodeNuscPlanner(mg._LaneEnv(lg, nmaps), oplan.PlannerConfig(**cfg))
+    orc.reset(st, att, mask, B, map_idx)
+    dev = HardcodeNuscPlanner(mg._LaneEnv(lg, nmaps), PlannerConfig(**cfg))
+    dev.reset(st.to(device), att.to(device), mask.to(device), B, map_idx)
+    return orc, dev
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU: oracle against the reference, host logic
+# ------------------------------------------------------------------------------------------------
 
 def test_lane_graph_format():
     lg = synth.make_lane_graph()
@@ -30,28 +116,22 @@ def test_linear_path_is_interp1d():
     t = np.array([-3.0, -1.0, 0.0, 0.5, 4.0])
     y = synth.counter_uniform((5, 4), 'lp/y', -2.0, 2.0)
     q = np.array([-3.0, -2.2, -1.0, 0.0, 0.25, 3.999, 4.0])
-    np.testing.assert_array_equal(LinearPath(t, y)(q), interp1d(t, y, axis=0, bounds_error=True, assume_sorted=True)(q))
-    try:
-        LinearPath(t, y)(np.array([4.1]))
-        raise AssertionError('out-of-range query must raise')
-    except ValueError:
-        pass
+    np.testing.assert_array_equal(oplan.LinearPath(t, y)(q), interp1d(t, y, axis=0, bounds_error=True, assume_sorted=True)(q))
+    with pytest.raises(ValueError):
+        oplan.LinearPath(t, y)(np.array([4.1]))
 
 
-def test_planner_rollout_matches_reference():
+def test_oracle_planner_matches_reference():
     g = golden('g10_planner.npz')
     lg, st, att, mask, obs, t, ptr = mg.g10_inputs()
     for name in ('default', 'final_tuned_val_1'):
-        pl = HardcodeNuscPlanner(mg._LaneEnv(lg), PlannerConfig(**CONFIG_DICT[name]))
+        pl = oplan.HardcodeNuscPlanner(mg._LaneEnv(lg), oplan.PlannerConfig(**oplan.CONFIG_DICT[name]))
         pl.reset(st, att, mask, len(mg.G10_SIZES), torch.zeros((len(mg.G10_SIZES),), dtype=torch.long))
-        t0 = time.time()
         plan = pl.rollout(obs.copy(), t, ptr, t, control_all=False)
-        dt = time.time() - t0
         assert plan.dtype == torch.float64 and tuple(plan.shape) == (2, 12, 4)
         np.testing.assert_allclose(plan.numpy(), g['plan_' + name], rtol=0, atol=1e-9)
         again = pl.rollout(obs.copy(), t, ptr, t, control_all=False)
         assert torch.equal(plan, again)
-        print('%s: 2 scenes x 31 planner steps in %.2f s' % (name, dt))
     # the plan moves along the ego's lane and never jumps
     step = np.linalg.norm(np.diff(g['plan_default'][:, :, :2], axis=1), axis=-1)
     assert step.max() < 0.5 * 20.0 + 1e-6
@@ -59,7 +139,7 @@ def test_planner_rollout_matches_reference():
 
 def test_clustered_matches_keep_one_per_connected_group():
     lg = synth.make_lane_graph()
-    G = LaneGraph(lg)
+    G = oplan.LaneGraph(lg)
     # a pose on a straight lane matches several consecutive edges; they are one cluster
     v = 40
     x, y = lg['xy'][v]
@@ -69,3 +149,220 @@ def test_clustered_matches_keep_one_per_connected_group():
     assert len(e) >= 2
     ke, kp = G.cluster(x, y, e, p)
     assert len(ke) == 1 and np.linalg.norm(kp[0] - np.array([x, y])) < 1e-9
+
+
+def test_edge_grid_finds_every_edge_a_full_scan_finds():
+    """the device reads one grid cell instead of scanning all edges (reference :298-322): same matches, same order"""
+    lg = synth.make_lane_graph()
+    G = oplan.LaneGraph(lg)
+    grid = edge_grid(np.asarray(lg['edges'], dtype=np.float64), 2.0, 4.0)
+    ptr, ce = grid['cell_ptr'], grid['cell_edges']
+    assert ptr[-1] == len(ce) and np.all(np.diff(ptr) >= 0)
+    q = synth.counter_uniform((4000, 3), 'grid/q', 0.0, 1.0)
+    ee = {tuple(int(v) for v in e): k for k, e in enumerate(lg['edgeixes'])}
+    nonempty = 0
+    for x, y, h in q * np.array([270.0, 270.0, 2 * np.pi]) - np.array([7.0, 7.0, np.pi]):
+        e, _ = G.match(x, y, h, 2.0, 2.0)            # cdistmax 2: every heading passes, only the distance test remains
+        want = [ee[tuple(int(v) for v in k)] for k in e]
+        fx, fy = np.floor((x - grid['gx0']) / grid['gcell']), np.floor((y - grid['gy0']) / grid['gcell'])
+        if not (0 <= fx < grid['gnx'] and 0 <= fy < grid['gny']):
+            assert want == []
+            continue
+        c = int(fy) * grid['gnx'] + int(fx)
+        cand = ce[ptr[c]:ptr[c + 1]]
+        assert np.all(np.diff(cand) > 0)
+        assert set(want) <= set(cand.tolist())
+        nonempty += len(want) > 0
+    assert nonempty > 500
+
+
+# ------------------------------------------------------------------------------------------------
+# the device planner through the host emulation of its kernels (CPU)
+# ------------------------------------------------------------------------------------------------
+
+def test_device_planner_emulated_matches_reference(emu_ops):
+    g = golden('g10_planner.npz')
+    lg, st, att, mask, obs, t, ptr = mg.g10_inputs()
+    for name in ('default', 'final_tuned_val_1'):
+        pl = HardcodeNuscPlanner(mg._LaneEnv(lg), PlannerConfig(**CONFIG_DICT[name]))
+        pl.reset(st, att, mask, len(mg.G10_SIZES), torch.zeros((len(mg.G10_SIZES),), dtype=torch.long))
+        plan = pl.rollout(obs.copy(), t, ptr, t, control_all=False)
+        assert plan.dtype == torch.float64 and tuple(plan.shape) == (2, 12, 4)
+        np.testing.assert_allclose(plan.numpy(), g['plan_' + name], rtol=0, atol=1e-9)
+        again = pl.rollout(torch.from_numpy(obs.copy()), t, ptr, t, control_all=False)      # tensor input, reset state untouched
+        assert torch.equal(plan, again)
+
+
+@pytest.mark.parametrize('cfg_name', ['default', 'final_tuned_val_1'])
+def test_device_planner_emulated_random_world(emu_ops, cfg_name):
+    world = random_world([7, 4, 1, 9], 'pw/' + cfg_name, nmaps=2)
+    orc, dev = both_planners(world, cfg_name)
+    _, _, _, _, obs, t, ptr, _ = world
+    want = orc.rollout(obs.copy(), t, ptr, t, control_all=False)
+    got = dev.rollout(obs.copy(), t, ptr, t, control_all=False)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=1e-9)
+    # shorter horizon / different output times (refine-style 16 x 0.5 s is covered by the GPU test)
+    t2 = np.array([0.4, 1.0, 2.0])
+    want = orc.rollout(obs.copy(), t, ptr, t2, control_all=False)
+    got = dev.rollout(obs.copy(), t, ptr, t2, control_all=False)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=1e-9)
+
+
+def test_device_planner_routes_match_oracle(emu_ops):
+    """every route of a pose (matches -> clusters -> chains -> blended arc-length path), knot by knot"""
+    lg = synth.make_lane_graph()
+    G = oplan.LaneGraph(lg)
+    cfgd = CONFIG_DICT['final_tuned_val_1']
+    cfg = PlannerConfig(**cfgd)
+    world = random_world([3], 'rt')
+    pl = HardcodeNuscPlanner(mg._LaneEnv(lg), cfg)
+    pl.reset(world[1], world[2], world[3], 1, torch.zeros((1,), dtype=torch.long))
+    row_obj, row_scene, NR = pl._row_maps(world[6])
+    desc = pl._descriptor(row_obj, row_scene, NR)
+    tmax = cfg.nsteps * cfg.preddt
+    cdistmax = 1.0 - np.cos(np.radians(cfg.cdistang))
+    poses = [(lg['xy'][40, 0] + 0.3, lg['xy'][40, 1] - 0.4, None, 6.0), (lg['xy'][200, 0], lg['xy'][200, 1] + 0.8, None, 0.0),
+             (lg['xy'][333, 0] - 0.5, lg['xy'][333, 1], None, -3.0), (50.0, 50.0, 0.7, 4.0), (lg['xy'][75, 0], lg['xy'][75, 1], None, 27.0)]
+    nbranch = 0
+    for x, y, h, s in poses:
+        if h is None:
+            v = int(np.argmin(np.linalg.norm(lg['xy'] - np.array([[x, y]]), axis=1)))
+            d = lg['xy'][lg['out_edges'][v][0]] - lg['xy'][v] if lg['out_edges'][v] else lg['xy'][v] - lg['xy'][lg['in_edges'][v][0]]
+            h = float(np.arctan2(d[1], d[0])) + 0.05
+        e, p = G.match(x, y, h, cdistmax, cfg.xydistmax)
+        e, p = G.cluster(x, y, e, p)
+        back = 1.0 if s > 0 else 1.0 + abs(s) * tmax
+        fwd = 1.0 + cfg.smax * tmax if s < 0 else max(1.0 + cfg.smax * tmax, 1.0 + s * tmax)
+        want = oplan.routes_through(G, e, p, back, fwd, cfg.xydistmax, np.array([x, y]), h)
+        maxr, maxk = 64, 384
+        nr = torch.zeros((1,), dtype=torch.int32)
+        nk = torch.zeros((maxr,), dtype=torch.int32)
+        kn = torch.zeros((maxr, maxk, 5), dtype=torch.float64)
+        status = torch.zeros((8,), dtype=torch.int32)
+        emu_ops.call('strive_planner_routes', desc, 0, L.ptr(torch.tensor([x, y, h, s], dtype=torch.float64)), maxr, maxk, L.ptr(nr),
+                     L.ptr(nk), L.ptr(kn), L.ptr(status), None)
+        assert int(status.abs().sum()) == 0, status
+        assert int(nr) == len(want)
+        nbranch += len(want) > 1
+        for r, route in enumerate(want):
+            n = len(route.t)
+            assert int(nk[r]) == n
+            np.testing.assert_allclose(kn[r, :n, 0].numpy(), route.t, rtol=0, atol=1e-10)
+            np.testing.assert_allclose(kn[r, :n, 1:].numpy(), route.y, rtol=0, atol=1e-10)
+    assert nbranch >= 2
+
+
+def test_device_planner_reports_exceeded_limits(emu_ops):
+    """a world the fixed-size tables cannot hold (an object at 60 m/s needs more route knots than the kernel keeps) is
+    reported, not silently mis-planned"""
+    world = list(random_world([3], 'lim', tail=False))
+    st = world[1].clone()
+    st[1, 4] = 60.0
+    world[1] = st
+    _, dev = both_planners(tuple(world), 'default')
+    with pytest.raises(L.StriveHipError, match='route knots'):
+        dev.rollout(world[4].copy(), world[5], world[6], world[5], control_all=False)
+
+
+# ------------------------------------------------------------------------------------------------
+# MI355X
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_device_planner_gpu_matches_reference_and_oracle():
+    dev = 'cuda:0'
+    g = golden('g10_planner.npz')
+    lg, st, att, mask, obs, t, ptr = mg.g10_inputs()
+    for name in ('default', 'final_tuned_val_1'):
+        pl = HardcodeNuscPlanner(mg._LaneEnv(lg), PlannerConfig(**CONFIG_DICT[name]))
+        pl.reset(st.to(dev), att.to(dev), mask.to(dev), len(mg.G10_SIZES), torch.zeros((len(mg.G10_SIZES),), dtype=torch.long))
+        plan = pl.rollout(torch.from_numpy(obs.copy()).to(dev), t, ptr, t, control_all=False)
+        assert plan.is_cuda and plan.dtype == torch.float64
+        pl.check()
+        np.testing.assert_allclose(plan.cpu().numpy(), g['plan_' + name], rtol=0, atol=1e-9)
+        host = pl.rollout(obs.copy(), t, ptr, t, control_all=False)                          # the reference's calling convention
+        assert not host.is_cuda and torch.equal(host, plan.cpu())
+    for cfg_name, sizes in (('default', [7, 4, 1, 9]), ('final_tuned_val_1', [12, 3, 16, 6, 2, 8])):
+        world = random_world(sizes, 'pw/' + cfg_name, nmaps=2)
+        orc, prod = both_planners(world, cfg_name, device=dev)
+        _, _, _, _, obs, t, ptr, _ = world
+        for tq in (t, np.linspace(0.5, 8.0, 16)[:12]):
+            want = orc.rollout(obs.copy(), t, ptr, tq, control_all=False)
+            got = prod.rollout(torch.from_numpy(obs.copy()).to(dev), t, ptr, tq, control_all=False)
+            prod.check()
+            np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=1e-9)
+
+
+# scenes of the 512-agent world in which the reference's route construction raises (interp1d bounds error, :433-556: an
+# object whose closest lane point lies more than the 2 m slack behind its matched edge) -- computed by the oracle
+# (test_oracle_rejects_these_scenes_of_the_512_agent_world, slow); the device reports exactly these and plans the others
+P512_REJECTED = [0, 2, 3, 15, 18, 26, 29, 30, 34]
+
+
+def p512_world():
+    import bench
+    sizes = bench.variable_scene_sizes(512, 'bench/adv/r0')
+    return sizes, random_world(sizes, 'p512')
+
+
+def sub_world(world, sizes, pick):
+    lg, st, att, mask, obs, t, ptr, _ = world
+    sub_mask = torch.cat([torch.full((sizes[b],), i, dtype=torch.long) for i, b in enumerate(pick)])
+    rows = torch.cat([mask.eq(b).nonzero().flatten() for b in pick])
+    orow = np.concatenate([np.arange(ptr[b], ptr[b + 1]) for b in pick])
+    sub_ptr = np.concatenate([[0], np.cumsum([sizes[b] - 1 for b in pick])])
+    return (lg, st[rows], att[rows], sub_mask, obs[orow], t, sub_ptr, torch.zeros((len(pick),), dtype=torch.long))
+
+
+@pytest.mark.slow
+def test_oracle_rejects_these_scenes_of_the_512_agent_world():
+    sizes, world = p512_world()
+    bad = []
+    for b in range(len(sizes)):
+        sub = sub_world(world, sizes, [b])
+        orc = oplan.HardcodeNuscPlanner(mg._LaneEnv(sub[0]), oplan.PlannerConfig(**oplan.CONFIG_DICT['default']))
+        orc.reset(sub[1], sub[2], sub[3], 1, sub[7])
+        try:
+            orc.rollout(sub[4].copy(), sub[5], sub[6], sub[5], control_all=False)
+        except ValueError:
+            bad.append(b)
+    assert bad == P512_REJECTED
+
+
+@pytest.mark.gpu
+def test_device_planner_gpu_512_agents():
+    """the batch of adv_gen_rule_based.cfg: ~512 agents in scenes of 2..30.  The scenes the reference's route construction
+    rejects are reported (NaN plan + error on check), every other scene is planned: reproducibly, independently of the batch it
+    is planned in, and -- a sample -- equal to the oracle."""
+    dev = 'cuda:0'
+    sizes, world = p512_world()
+    lg, st, att, mask, obs, t, ptr, map_idx = world
+    _, prod = both_planners(world, 'default', device=dev)
+    obs_d = torch.from_numpy(obs.copy()).to(dev)
+    got = prod.rollout(obs_d, t, ptr, t, control_all=False)
+    with pytest.raises(L.StriveHipError, match='outside a route'):
+        prod.check()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    again = prod.rollout(obs_d, t, ptr, t, control_all=False)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    prod._pending = None
+    nan_scene = torch.isnan(got).flatten(1).any(1).cpu().numpy()
+    assert np.nonzero(nan_scene)[0].tolist() == P512_REJECTED
+    ok = torch.from_numpy(~nan_scene).to(dev)
+    assert torch.equal(got[ok], again[ok])
+    print('device planner: %d scenes / %d agents, 31 planner steps in %.2f ms' % (len(sizes), sum(sizes), 1e3 * dt))
+    pick = [1, 5, 11]
+    sub = sub_world(world, sizes, pick)
+    o3, p3 = both_planners(sub, 'default', device=dev)
+    want = o3.rollout(sub[4].copy(), t, sub[6], t, control_all=False)
+    np.testing.assert_allclose(got[pick].cpu().numpy(), want.numpy(), rtol=0, atol=1e-9)
+    alone = p3.rollout(torch.from_numpy(sub[4].copy()).to(dev), t, sub[6], t, control_all=False)
+    p3.check()
+    assert torch.equal(alone, got[pick])
+    # an oracle-rejected scene raises there too
+    bad = sub_world(world, sizes, [15])
+    o1, _ = both_planners(bad, 'default', device=dev)
+    with pytest.raises(ValueError):
+        o1.rollout(bad[4].copy(), t, bad[6], t, control_all=False)
