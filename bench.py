@@ -240,18 +240,22 @@ def train_step_factory(m, env, batch, map_idx, FT, device):
 # side measurements
 # ------------------------------------------------------------------------------------------------
 
-def _measured_traffic(kernel_name):
-    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/r0N_traffic.json, written from
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command); None if not collected for this kernel."""
-    for name in ('r02_traffic.json', 'r01_traffic.json'):
+TRAFFIC_FILES = ('r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json')
+
+
+def _measured_traffic(kernel_name, with_source=False):
+    """HBM bytes per launch of a kernel from the COMMITTED PMC passes (profiles/r0N_traffic.json, written by
+    profiles/make_traffic.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command) -- not measured in this
+    run: counters need their own rocprofv3 passes.  None if not collected for this kernel."""
+    for name in TRAFFIC_FILES:
         try:
             with open(os.path.join(REPO, 'profiles', name)) as f:
                 ent = json.load(f).get(kernel_name)
             if ent is not None:
-                return ent.get('bytes_per_launch')
+                return (ent.get('bytes_per_launch'), 'profiles/' + name) if with_source else ent.get('bytes_per_launch')
         except (OSError, ValueError):
             continue
-    return None
+    return (None, None) if with_source else None
 
 
 def _event_time(fn, reps, warm=3):
@@ -293,7 +297,7 @@ def time_dominant_kernel(m, env, g, mi, emb, device, reps=20):
     mult, peak, mdt = CONV_ISSUE[dom]
     alg = CONV_FLOPS[dom] * N / times[dom] / 1e12          # algorithmic (fp32-equivalent) TFLOP/s
     ach = alg * mult                                       # matrix-core FLOP/s actually issued
-    traffic = _measured_traffic(CONV_NAMES[dom])
+    traffic, traffic_source = _measured_traffic(CONV_NAMES[dom], with_source=True)
     # Which roof binds?  Since the fp16 x 3 scheme halved the matrix work these kernels sit closer to the HBM roof than to the
     # matrix roof: report the one with the larger fraction as `bound` and keep the other beside it.  HBM bytes per launch =
     # the algorithmic minimum (input once + output once); `traffic` = the PMC-measured bytes.
@@ -301,17 +305,16 @@ def time_dominant_kernel(m, env, g, mi, emb, device, reps=20):
     f_mfma, f_hbm = ach / peak, hbm_gbs / PEAK_HBM_GBS
     if f_hbm >= f_mfma:
         rec = {'bound': 'hbm', 'kernel': CONV_NAMES[dom], 'achieved': round(hbm_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-               'frac': round(f_hbm, 4), 'traffic': traffic,
+               'frac': round(f_hbm, 4), 'traffic': traffic, 'traffic_source': traffic_source,
                'achieved_measured_traffic_GBps': None if traffic is None else round(traffic / times[dom] / 1e9, 1),
                'frac_measured_traffic': None if traffic is None else round(traffic / times[dom] / 1e9 / PEAK_HBM_GBS, 4)}
     else:
         rec = {'bound': 'mfma', 'kernel': CONV_NAMES[dom], 'achieved': round(ach, 3), 'peak': peak, 'unit': 'TFLOP/s',
-               'frac': round(f_mfma, 4), 'traffic': traffic}
+               'frac': round(f_mfma, 4), 'traffic': traffic, 'traffic_source': traffic_source}
     rec.update({'mfma': {'issued_tflops': round(ach, 3), 'peak': peak, 'frac': round(f_mfma, 4), 'dtype': mdt,
                          'products_per_fp32_product': mult},
                 'hbm': {'algorithmic_GBps': round(hbm_gbs, 1), 'peak': PEAK_HBM_GBS, 'frac': round(f_hbm, 4)},
                 'algorithmic_tflops': round(alg, 3),
-                'frac_of_f32_matrix_peak': round(alg / PEAK_FP32_MFMA_TFLOPS, 4),
                 'launch_us': round(times[dom] * 1e6, 2), 'agents_per_launch': N,
                 'all_layers_us': [round(t * 1e6, 2) for t in times],
                 'all_layers_algorithmic_tflops': [round(CONV_FLOPS[l] * N / times[l] / 1e12, 2) for l in range(NK)]})
@@ -422,7 +425,7 @@ def _one_socket_threads():
     return torch.get_num_threads()
 
 
-def cpu_baseline(FT, scenes=4, agents=16, raster_px=4096, timed=3):
+def cpu_baseline(FT, scenes=4, agents=16, raster_px=4096, timed=3, warm=1):
     """The oracle's refine closure (decode + AvoidCollLoss + backward) on `scenes` scenes of the same workload, in the
     reference's structure: materialised fp32/fp64/int64 coordinate tensors per crop, per-edge MLP, and -- because the
     reference's parameters require grad and encode_map runs with grad enabled -- autograd through the map CNN including its
@@ -462,7 +465,8 @@ def cpu_baseline(FT, scenes=4, agents=16, raster_px=4096, timed=3):
             ld = lf(orc.get_normalizer().unnormalize(pred), z, emb['prior_out'])
             ld['loss'].backward()
             opt.step()
-        closure()
+        for _ in range(warm):
+            closure()
         t0 = time.perf_counter()
         for _ in range(timed):
             closure()
@@ -471,9 +475,31 @@ def cpu_baseline(FT, scenes=4, agents=16, raster_px=4096, timed=3):
         torch.set_num_threads(old_threads)
     n = scenes * agents * FT
     return {'value': round(n / dt, 2), 'unit': 'agent*timesteps/s', 'cores': threads, 'kind': 'port', 'cpu': _cpu_model(),
-            'sample': '%d scenes x %d agents, FT=%d: 1 warm-up + %d timed refine closures (decode + AvoidCollLoss + backward '
+            'sample': '%d scenes x %d agents, FT=%d: %d warm-up + %d timed refine closures (decode + AvoidCollLoss + backward '
                       'incl. the CNN weight gradients the reference computes + Adam) of the CPU oracle, %.1f s per closure; '
-                      'threads = one socket' % (scenes, agents, FT, timed, dt)}
+                      'threads = one socket' % (scenes, agents, FT, warm, timed, dt)}
+
+
+def cpu_baseline_record(FT, full=False):
+    """The bench line's `cpu_baseline`.  SURVEY 8(d) quotes the CPU at C2 (32 scenes x 16 agents), where one closure of the
+    oracle takes minutes; the default run therefore times two bounded samples of the same workload -- 4 x 16 agents (1 warm-up +
+    2 timed closures) and 16 x 16 agents (1 timed closure) -- reports the LARGER one as `value` (per-agent CPU throughput falls
+    with the batch: the crop pipeline's GiB-scale intermediates leave the caches) and states both, so the trend towards C2
+    is visible.  ``--cpu-baseline-full`` times C2 itself (1 warm-up + 3 timed closures, ~10 minutes);
+    profiles/r03_cpu_baseline_c2.json holds that run."""
+    if full:
+        rec = cpu_baseline(FT, scenes=32, agents=16, timed=3)
+        rec['sample'] = 'C2 itself: ' + rec['sample']
+        return rec
+    small = cpu_baseline(FT, scenes=4, agents=16, timed=2)
+    large = cpu_baseline(FT, scenes=16, agents=16, timed=1, warm=0)
+    rec = dict(large)
+    rec['sample'] = ('bounded samples of C2 (32 x 16 agents): %s || %s.  `value` is the 16 x 16 sample; per-agent CPU throughput '
+                     'falls with the batch size (4 x 16: %.1f, 16 x 16: %.1f agent*timesteps/s), C2 itself is slower still '
+                     '(profiles/r03_cpu_baseline_c2.json, --cpu-baseline-full)' % (small['sample'], large['sample'], small['value'],
+                                                                                   large['value']))
+    rec['samples'] = [{'scenes': 4, 'agents': 16, 'value': small['value']}, {'scenes': 16, 'agents': 16, 'value': large['value']}]
+    return rec
 
 
 # ------------------------------------------------------------------------------------------------
@@ -505,6 +531,7 @@ def parse_args(argv=None):
                          "planner (adv_gen_rule_based.cfg)")
     ap.add_argument('--raster', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-full', action='store_true', help='time the CPU oracle on C2 itself (32 x 16 agents; ~10 minutes)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--dry-run', action='store_true', help='CPU/gloo: join the ranks, build the scene partition, no kernels')
     args = ap.parse_args(argv)
@@ -581,7 +608,9 @@ def main():
     NA = int(g.past.shape[0])
     units_local = rollouts * NA * args.ft * args.steps
     units = units_local
-    per_rank = [[rank, NA, round(dt_local / args.steps * 1e3, 3)]]
+    props = torch.cuda.get_device_properties(device)
+    dev_id = str(getattr(props, 'uuid', '')) or '%s/pci%s' % (props.name, getattr(props, 'pci_bus_id', local))
+    per_rank = [[rank, NA, round(dt_local / args.steps * 1e3, 3), dev_id, local]]
     if use_dist:
         tt = torch.tensor([dt_local], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -619,7 +648,11 @@ def main():
                                  '(3 products per fp32 product, dropped terms <= 2^-24), fp32 accumulate'},
         'final_loss': float(loss.detach().cpu()),
         'planner': None if planner_ms is None else planner_ms,
-        'per_rank': [{'rank': r, 'agents': a, 'ms_per_step': t} for r, a, t in per_rank],
+        'per_rank': [{'rank': r, 'agents': a, 'ms_per_step': t, 'device': d, 'local_rank': lr} for r, a, t, d, lr in per_rank],
+        # what the collective backend saw (N > 1: RCCL = torch.distributed 'nccl'): world size it reports and the distinct devices
+        'rccl_world_size': dist.get_world_size() if use_dist else None,
+        'rccl_backend': dist.get_backend() if use_dist else None,
+        'distinct_devices': len(set(d for _, _, _, d, _ in per_rank)),
     }
     failed = False
     if rank == 0:
@@ -629,16 +662,29 @@ def main():
                 out['roofline']['bandwidth_kernels'].update(time_bandwidth_kernels(m, env, g, mi, device))
                 # the closure as a whole = 305 MFLOP algorithmic per agent*timestep (map CNN
                 # forward 300.4 + GNN/GRU/dynamics forward+backward), against the fp32 matrix peak
+                # matrix work is issued as fp16 x 3 (conv1: x 2), so the roof it runs against is the f16 dense peak:
+                # `useful` counts the algorithmic FLOPs, `issued` the products actually sent to the matrix cores.
+                # traffic_over_survey_bytes = HBM bytes the five CNN kernels move per agent*step (committed PMC passes) over
+                # SURVEY 8(d)'s algorithmic 268 KB: the layer-by-layer design writes and re-reads its fp32 intermediates.
                 per_gpu = out['value'] / world
+                alg_tf = per_gpu * 305.0e6 / 1e12
+                issued = per_gpu * (sum(f * mlt for f, (mlt, _, _) in zip(CONV_FLOPS, CONV_ISSUE)) + 4.7e6) / 1e12
+                tr = [_measured_traffic(nm) for nm in CONV_NAMES]
+                napl = out['roofline']['agents_per_launch']
                 out['roofline']['whole_path'] = {
-                    'algorithmic_tflops': round(per_gpu * 305.0e6 / 1e12, 2),
-                    'frac_of_f32_matrix_peak': round(per_gpu * 305.0e6 / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+                    'algorithmic_tflops': round(alg_tf, 2),
+                    'frac_of_f16_matrix_peak_useful': round(alg_tf / PEAK_F16_MFMA_TFLOPS, 4),
+                    'frac_of_f16_matrix_peak_issued': round(issued / PEAK_F16_MFMA_TFLOPS, 4),
+                    'survey_bytes_per_agent_step': 268 * 1024,
+                    'cnn_traffic_bytes_per_agent_step': None if any(t is None for t in tr) else int(sum(tr) / napl),
+                    'traffic_over_survey_bytes': None if any(t is None for t in tr) else round(sum(tr) / napl / (268 * 1024), 2),
+                    'traffic_source': _measured_traffic(CONV_NAMES[0], with_source=True)[1]}
             except Exception as e:      # keep the headline number, but the run fails
                 out['roofline'] = {'error': repr(e)}
                 failed = True
         if world == 1 and not args.no_cpu_baseline and args.workload != 'train':
             try:
-                out['cpu_baseline'] = cpu_baseline(args.ft)
+                out['cpu_baseline'] = cpu_baseline_record(args.ft, full=args.cpu_baseline_full)
             except Exception as e:
                 out['cpu_baseline'] = {'error': repr(e)}
                 failed = True
