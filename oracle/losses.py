@@ -435,3 +435,56 @@ def determine_feasibility(samples, normalizer, thresh, time=0, vel=0.0, infront_
     v = torch.norm(oth[:, :, 1:, :2] - oth[:, :, :-1, :2], dim=-1)
     feasible = feasible & (v.amax(dim=(1, 2)) > vel)
     return feasible, step, dist
+
+
+def compute_disp_err(future_gt, ptr, future_pred, normalizer):
+    """Ego-only sample displacement errors (reference src/losses/traffic_model.py:297-364): future_gt (NA,FT,6) and
+    future_pred (NA,NS,FT',4) normalised; per scene min-over-samples ADE / FDE of position (m) and heading (deg), and the
+    average pairwise distance between samples."""
+    FT = min(future_pred.size(2), future_gt.size(1))
+    ego = ptr[:-1]
+    gt = normalizer.unnormalize(future_gt[:, :FT])[ego]
+    pr = normalizer.unnormalize(future_pred[:, :, :FT])[ego]
+    B, NS = pr.shape[0], pr.shape[1]
+    out = {k: torch.zeros((B,)) for k in ('pos_minADE', 'pos_minFDE', 'ang_minADE', 'ang_minFDE', 'APD')}
+    for b in range(B):
+        ade, fde, aade, afde = [], [], [], []
+        for s in range(NS):
+            d = torch.norm(gt[b, :, :2] - pr[b, s, :, :2], dim=-1)
+            gh = gt[b, :, 2:4] / torch.norm(gt[b, :, 2:4], dim=-1, keepdim=True)
+            ph = pr[b, s, :, 2:4] / torch.norm(pr[b, s, :, 2:4], dim=-1, keepdim=True)
+            a = torch.rad2deg(torch.acos(torch.sum(gh * ph, dim=-1).clamp(-1, 1)))
+            ade.append(d.mean()); fde.append(d[-1]); aade.append(a.mean()); afde.append(a[-1])
+        out['pos_minADE'][b], out['pos_minFDE'][b] = torch.stack(ade).min(), torch.stack(fde).min()
+        out['ang_minADE'][b], out['ang_minFDE'][b] = torch.stack(aade).min(), torch.stack(afde).min()
+        tot = 0.0
+        for s in range(NS):
+            for q in range(NS):
+                tot = tot + torch.norm(pr[b, s, :, :2] - pr[b, q, :, :2], dim=-1).sum()
+        out['APD'][b] = tot / (NS * (NS - 1) * FT)
+    return out
+
+
+def compute_coll_rate_veh(edge_index, lw, future_pred, state_normalizer, att_normalizer):
+    """(did_collide (NA,NS) bool, count): per sample, every connected pair (j, i) with j > i is walked in edge order; agent i
+    is marked at the first step where the two boxes overlap with IoU > 0.02; pairs of an already marked agent and NaN frames
+    are skipped (reference src/losses/traffic_model.py:465-545)."""
+    import numpy as np
+    from .geometry import rect_iou
+    tr = state_normalizer.unnormalize(future_pred).cpu().numpy()
+    att = att_normalizer.unnormalize(lw).cpu().numpy()
+    NA, NS, FT, _ = tr.shape
+    did = np.zeros((NA, NS), dtype=bool)
+    count = 0
+    for s in range(NS):
+        for aj, ai in edge_index.cpu().numpy().T:
+            if aj <= ai or did[ai, s]:
+                continue
+            for t in range(FT):
+                if np.isnan(tr[ai, s, t]).any() or np.isnan(tr[aj, s, t]).any():
+                    continue
+                if rect_iou(tr[ai, s, t], att[ai], tr[aj, s, t], att[aj]) > VEH_COLL_THRESH:
+                    did[ai, s] = True
+                    count += 1
+                    break
+    return did, count

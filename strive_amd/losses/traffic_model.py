@@ -126,3 +126,56 @@ def compute_coll_rate_env(scene_graph, map_idx, pred, map_env, state_normalizer,
         frac[valid] = nutils.check_on_layer(map_env.nusc_raster[:, 0], map_env.nusc_dx, flat[valid], att[valid], mix[valid])
     coll = (frac.view(NA, NS, FT) < (1.0 - ENV_COLL_THRESH)).sum(dim=2) >= 1
     return {'num_coll_map': float(coll.sum().item()), 'num_traj_map': float(NS * NA), 'did_collide': coll}
+
+
+def compute_disp_err(scene_graph, pred, normalizer):
+    """Sample-based displacement errors of the EGO of every scene (reference :297-364): ``pred['future_pred']`` (NA,NS,FT',4)
+    NORMALISED against ``scene_graph.future_gt`` over the common horizon.  Returns per scene the best-of-NS average / final
+    position error (m), the same for the heading (degrees) and the average pairwise distance between the samples."""
+    fut = pred['future_pred']
+    gt = scene_graph.future_gt
+    T = min(int(fut.size(2)), int(gt.size(1)))
+    ego = scene_graph.ptr[:-1].to(fut.device)
+    g = normalizer.unnormalize(gt[:, :T]).index_select(0, ego).unsqueeze(1)            # (B,1,T,6)
+    p = normalizer.unnormalize(fut[:, :, :T]).index_select(0, ego)                      # (B,NS,T,4)
+    B, NS = p.size(0), p.size(1)
+    dist = torch.norm(g[..., :2] - p[..., :2], dim=-1)                                  # (B,NS,T)
+    spread = torch.norm(p[:, :, None, :, :2] - p[:, None, :, :, :2], dim=-1)            # (B,NS,NS,T); zero on the diagonal
+    apd = spread.sum(dim=(1, 2)).sum(dim=-1) / (NS * (NS - 1) * T)
+    unit = lambda v: v / torch.norm(v, dim=-1, keepdim=True)
+    ang = torch.rad2deg(torch.acos(torch.sum(unit(g[..., 2:4]) * unit(p[..., 2:4]), dim=-1).clamp(-1, 1)))
+    return {'pos_minADE': dist.mean(dim=-1).min(dim=1)[0], 'pos_minFDE': dist[:, :, -1].min(dim=1)[0],
+            'ang_minADE': ang.mean(dim=-1).min(dim=1)[0], 'ang_minFDE': ang[:, :, -1].min(dim=1)[0], 'APD': apd}
+
+
+VEH_COLL_THRESH = 0.02   # IoU above which two boxes count as collided (reference :18)
+
+
+def compute_coll_rate_veh(scene_graph, pred, state_normalizer, att_normalizer):
+    """Which sampled rollouts collide with another agent?  ``pred`` (NA,NS,FT,4) NORMALISED (or a dict holding
+    ``future_pred``).  Like the reference (:465-545) every connected pair is checked once and charged to its LOWER-indexed
+    agent: ``did_collide[i, s]`` iff the box of agent i overlaps (IoU > 0.02) the box of some connected agent j > i at some
+    step of sample s; NaN frames never count.  The reference walks samples x pairs x steps through shapely polygons on the
+    host; here all (pair, sample, step) boxes go through ONE launch of the exact clipping kernel (ops.rect_iou)."""
+    from .. import ops
+    fut = pred if isinstance(pred, torch.Tensor) else pred['future_pred']
+    NA, NS, FT, _ = fut.size()
+    dev = fut.device
+    traj = state_normalizer.unnormalize(fut)
+    lw = att_normalizer.unnormalize(scene_graph.lw)
+    ei = scene_graph.edge_index.to(dev)
+    keep = ei[0] > ei[1]
+    aj, ai = ei[0][keep], ei[1][keep]
+    did = torch.zeros((NA, NS), dtype=torch.bool, device=dev)
+    Pn = int(aj.numel())
+    if Pn > 0:
+        n = Pn * NS * FT
+        a = traj.index_select(0, ai)[..., :4].reshape(n, 4)
+        b = traj.index_select(0, aj)[..., :4].reshape(n, 4)
+        la = lw.index_select(0, ai).view(Pn, 1, 1, 2).expand(Pn, NS, FT, 2).reshape(n, 2)
+        lb = lw.index_select(0, aj).view(Pn, 1, 1, 2).expand(Pn, NS, FT, 2).reshape(n, 2)
+        hit = (ops.rect_iou(a, la, b, lb).view(Pn, NS, FT) > VEH_COLL_THRESH).any(dim=2)      # NaN compares False
+        did.index_put_((ai.view(Pn, 1).expand(Pn, NS)[hit], torch.arange(NS, device=dev).view(1, NS).expand(Pn, NS)[hit]),
+                       torch.ones((int(hit.sum()),), dtype=torch.bool, device=dev))
+    host = did.cpu().numpy().astype(bool)
+    return {'num_coll_veh': float(host.sum()), 'num_traj_veh': float(NS * NA), 'did_collide': host}

@@ -864,14 +864,122 @@ def g9_wire(R):
     print('wrote g9_scenario_{full,min}.json')
 
 
+def _install_exact_shapely():
+    """shapely is absent from the image: the reference's collision checks get a ``shapely.geometry.Polygon`` stand-in whose
+    ``intersection(...).area`` / ``union(...).area`` are EXACT (rational arithmetic on the corners the reference hands over,
+    tests/golden/make_iou_exact.py) -- everything around that call (pair ordering, skipping, thresholds, NaN frames, counts)
+    is the reference's own code."""
+    from fractions import Fraction
+    import make_iou_exact as mx
+
+    class _Area(object):
+        def __init__(self, area):
+            self.area = area
+
+    class Polygon(object):
+        def __init__(self, corners):
+            self.p = mx._ccw(mx._frac_poly(np.asarray(corners, dtype=np.float64)))
+            self.a = mx._area2(self.p) / 2
+
+        def _inter(self, other):
+            pts = [v for v in self.p if mx._inside(v, other.p)] + [v for v in other.p if mx._inside(v, self.p)]
+            for i in range(4):
+                p, p2 = self.p[i], self.p[(i + 1) % 4]
+                r = (p2[0] - p[0], p2[1] - p[1])
+                for j in range(4):
+                    q, q2 = other.p[j], other.p[(j + 1) % 4]
+                    sv = (q2[0] - q[0], q2[1] - q[1])
+                    den = r[0] * sv[1] - r[1] * sv[0]
+                    if den == 0:
+                        continue
+                    qp = (q[0] - p[0], q[1] - p[1])
+                    t = (qp[0] * sv[1] - qp[1] * sv[0]) / den
+                    u = (qp[0] * r[1] - qp[1] * r[0]) / den
+                    if 0 <= t <= 1 and 0 <= u <= 1:
+                        pts.append((p[0] + t * r[0], p[1] + t * r[1]))
+            pts = list(dict.fromkeys(pts))
+            if len(pts) < 3:
+                return Fraction(0)
+            import functools
+            cx = sum(v[0] for v in pts) / len(pts)
+            cy = sum(v[1] for v in pts) / len(pts)
+            rel = [(v[0] - cx, v[1] - cy) for v in pts]
+
+            def cmp(a, b):
+                ha, hb = mx._half(a), mx._half(b)
+                if ha != hb:
+                    return -1 if ha < hb else 1
+                c = a[0] * b[1] - a[1] * b[0]
+                return -1 if c > 0 else (1 if c < 0 else 0)
+            rel.sort(key=functools.cmp_to_key(cmp))
+            return abs(mx._area2(rel)) / 2
+
+        def intersection(self, other):
+            return _Area(float(self._inter(other)))
+
+        def union(self, other):
+            return _Area(float(self.a + other.a - self._inter(other)))
+
+    m = types.ModuleType('shapely')
+    gm = types.ModuleType('shapely.geometry')
+    gm.Polygon = Polygon
+    m.geometry = gm
+    sys.modules['shapely'] = m
+    sys.modules['shapely.geometry'] = gm
+
+
+G11_SIZES = [5, 3, 4]
+
+
+def g11_inputs():
+    """Three scenes, 4 samples x 8 steps of NORMALISED futures around the scenes' own ground truth: small per-sample offsets so
+    that some pairs overlap at some step, one sample with NaN frames, one prediction horizon shorter than the data's."""
+    batch, _, _, _ = build_inputs(G11_SIZES, 'g11')
+    NA, NS, FT = batch.past.shape[0], 4, 8
+    base = batch.future_gt[:, :FT, :4].unsqueeze(1).expand(NA, NS, FT, 4)
+    off = synth.f32(synth.counter_uniform((NA, NS, 1, 2), 'g11/off', -0.06, 0.06))          # normalised units (15 m per unit)
+    drift = synth.f32(synth.counter_uniform((NA, NS, 1, 2), 'g11/drift', -0.01, 0.01)) * torch.arange(FT).view(1, 1, FT, 1)
+    pred = base.clone()
+    pred[..., :2] = pred[..., :2] + off + drift
+    ang = synth.f32(synth.counter_uniform((NA, NS, 1), 'g11/ang', -0.3, 0.3))
+    c, s_ = torch.cos(ang), torch.sin(ang)
+    hx, hy = pred[..., 2].clone(), pred[..., 3].clone()
+    pred[..., 2], pred[..., 3] = c * hx - s_ * hy, s_ * hx + c * hy
+    # agents 1 and 2 of scene 0 are pulled onto agent 0 in sample 2 (certain overlap); agent 6 loses frames in sample 1
+    pred[1, 2, :, :2] = pred[0, 2, :, :2] + 0.02
+    pred[2, 2, 3:, :2] = pred[0, 2, 3:, :2] - 0.03
+    pred[6, 1, 2:5] = float('nan')
+    return batch, pred.contiguous()
+
+
+def g11_eval(R):
+    """compute_disp_err and compute_coll_rate_veh of the reference (src/losses/traffic_model.py:297-364, 465-545); the latter
+    with the exact shapely stand-in above."""
+    _install_exact_shapely()
+    tm, _ = ref_model(R)
+    nrm, att = tm.get_normalizer(), tm.get_att_normalizer()
+    batch, pred = g11_inputs()
+    out = {}
+    de = R.tm_losses.compute_disp_err(batch, {'future_pred': torch.nan_to_num(pred, nan=0.0)}, nrm)
+    for k, v in de.items():
+        out['disp/' + k] = npy(v)
+    de6 = R.tm_losses.compute_disp_err(batch, {'future_pred': torch.nan_to_num(pred[:, :, :6], nan=0.0)}, nrm)
+    for k, v in de6.items():
+        out['disp6/' + k] = npy(v)
+    cv = R.tm_losses.compute_coll_rate_veh(batch, {'future_pred': pred.clone()}, nrm, att)
+    out['veh/did_collide'] = np.asarray(cv['did_collide'])
+    out['veh/num'] = np.array([cv['num_coll_veh'], cv['num_traj_veh']])
+    save('g11_eval.npz', **out)
+
+
 G8_CASES = [(15.0, 0, 0.0, None, False), (15.0, 2, 0.5, None, True), (25.0, 1, 0.0, 0.0, True), (8.0, 0, 1.0, -0.5, False)]
 
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
     R = import_reference()
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g4b', 'g5', 'g6', 'g6l', 'g6h', 'g7', 'g8', 'g9', 'g10']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g4b', 'g5', 'g6', 'g6l', 'g6h', 'g7', 'g8', 'g9', 'g10', 'g11']
     fns = {'g1': g1_ops, 'g2': g2_crop, 'g3': g3_gnn, 'g4': g4_rollout, 'g5': g5_losses, 'g6': g6_loop, 'g7': g7_sample,
-           'g8': g8_checks, 'g9': g9_wire, 'g6l': g6_loops, 'g4b': g4b_nc5, 'g10': g10_planner, 'g6h': g6h_hardcode}
+           'g8': g8_checks, 'g9': g9_wire, 'g6l': g6_loops, 'g4b': g4b_nc5, 'g10': g10_planner, 'g6h': g6h_hardcode, 'g11': g11_eval}
     for w in which:
         fns[w](R)
