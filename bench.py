@@ -18,6 +18,9 @@ step.  Workloads (``--workload``):
   sharded4096  (configs[4]) ONE batch of ~4096 agents with NC = 5 classes (reduce_cats), split over the ranks by
                strive_amd.distributed.shard_scenes; every rank runs the adversarial closure on its scenes.  The job is
                fixed, so this is strong scaling.
+  sample       the feasibility pre-pass of adv_scenario_gen.py:160-174: TrafficModel.sample_batched(NS = 20, include_mean = True)
+               under no_grad on 32 scenes x 16 agents: embed (map crop + CNN, past encoder, prior network) + ONE joint rollout
+               of NA x 20 sample rows (forward only); advances NA*20*FT agent*timesteps.  Weak scaling.
   train        (configs[3]) one training step of train_traffic.cfg (reference src/train_traffic.py:103-131): batch of 4
                scenes x 16 agents per GPU, TrafficModel.forward(future_sample=True) = posterior-sample + prior-sample rollout,
                TrafficModelLoss, backward to all 174 parameter tensors, flat-bucket gradient all-reduce (RCCL) with the skip
@@ -108,6 +111,9 @@ def workload_scenes(args, rank, world):
         sizes = variable_scene_sizes(args.total_agents or 512, 'bench/adv/r%d' % rank)
         own = [(n, 'bench/adv/r%d/%d' % (rank, b)) for b, n in enumerate(sizes)]
         return own, '%d agents per GPU in %d scenes of 2..30' % (sum(sizes), len(sizes)), 'weak'
+    if args.workload == 'sample':
+        own = [(args.agents, 'bench/sample/r%d/%d' % (rank, b)) for b in range(args.scenes)]
+        return own, '%d scenes x %d agents per GPU x 20 samples' % (args.scenes, args.agents), 'weak'
     if args.workload == 'train':
         nsc = 4 if args.scenes == 32 else args.scenes          # train_traffic.cfg: batch_size 4 (scenes per GPU)
         own = [(args.agents, 'bench/train/r%d/%d' % (rank, b)) for b in range(nsc)]
@@ -213,6 +219,18 @@ def adv_closure_factory(m, env, batch, map_idx, FT, device):
                    (pm[~ego], pv[~ego]), 2, 0.0, planner_fut=g.future_gt[ego][:, :FT, :4].contiguous(), future_len=FT,
                    veh_coll_buffer=0.1)
     return (lambda: c.step()), emb, g, mi, 2
+
+
+def sample_step_factory(m, env, batch, map_idx, FT, device, NS=20):
+    """reference src/adv_scenario_gen.py:160-174 (sample_batched before the feasibility test)"""
+    g = batch.to(device)
+    mi = map_idx.to(device)
+
+    def step():
+        with torch.no_grad():
+            out = m.sample_batched(g, mi, env, NS, include_mean=True, nfuture=FT)
+        return out['future_pred'].abs().mean()
+    return step, None, g, mi, NS
 
 
 TRAIN_WEIGHTS = {'recon': 1.0, 'kl': 0.004, 'coll_veh_prior': 0.05, 'coll_env_prior': 0.1}      # train_traffic.cfg:17-21
@@ -519,7 +537,7 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', choices=['refine', 'adv', 'sharded4096', 'train'], default='refine')
+    ap.add_argument('--workload', choices=['refine', 'adv', 'sharded4096', 'train', 'sample'], default='refine')
     ap.add_argument('--scenes', type=int, default=32)
     ap.add_argument('--agents', type=int, default=16)
     ap.add_argument('--total-agents', type=int, default=0, help='adv / sharded4096: agents in the batch (default 512 / 4096)')
@@ -584,7 +602,7 @@ def main():
         lane_graph = synth.make_lane_graph(extent=args.raster * 0.25)
     env = build_env(args.raster, device, lane_graph)
     batch, map_idx = build_batch(own, args.nc, args.raster, lane_graph=lane_graph)
-    factory = {'refine': refine_closure_factory, 'train': train_step_factory}.get(args.workload, adv_closure_factory)
+    factory = {'refine': refine_closure_factory, 'train': train_step_factory, 'sample': sample_step_factory}.get(args.workload, adv_closure_factory)
     step, emb, g, mi, rollouts = factory(m, env, batch, map_idx, args.ft, device)
     for _ in range(args.warmup):
         step()
@@ -631,10 +649,12 @@ def main():
                'adv': closure_adv,
                'sharded4096': 'adversarial closure: 2 x decode_embedding(nfuture=%d, ext_future) + TgtMatchingLoss + '
                               'AdvGenLoss + backward + Adam',
+               'sample': 'TrafficModel.sample_batched(NS=20, include_mean=True, nfuture=%d) under no_grad: embed + one joint '
+                         'rollout of NA x 20 rows, forward only',
                'train': 'training step: TrafficModel.forward(future_sample=True) (2 rollouts of %d steps) + TrafficModelLoss + '
                         'backward to 174 parameter tensors + gradient all-reduce + Adam'}[args.workload] % args.ft
     cfg_ref = {'refine': 'BASELINE.json configs[1]', 'adv': 'BASELINE.json configs[2]', 'sharded4096': 'BASELINE.json configs[4]',
-               'train': 'BASELINE.json configs[3]'}
+               'train': 'BASELINE.json configs[3]', 'sample': 'SURVEY 8 a18: adv_scenario_gen.py:160-174'}
     out = {
         'metric': 'adv-optim agent*timesteps/sec (decoder fwd+bwd)',
         'value': round(units / dt, 1), 'unit': 'agent*timesteps/s', 'n_gpus': world, 'steps': args.steps,
@@ -656,7 +676,7 @@ def main():
     }
     failed = False
     if rank == 0:
-        if not args.no_roofline and args.workload != 'train':
+        if not args.no_roofline and args.workload not in ('train', 'sample'):
             try:
                 out['roofline'] = time_dominant_kernel(m, env, g, mi, emb, device)
                 out['roofline']['bandwidth_kernels'].update(time_bandwidth_kernels(m, env, g, mi, device))
@@ -682,7 +702,7 @@ def main():
             except Exception as e:      # keep the headline number, but the run fails
                 out['roofline'] = {'error': repr(e)}
                 failed = True
-        if world == 1 and not args.no_cpu_baseline and args.workload != 'train':
+        if world == 1 and not args.no_cpu_baseline and args.workload not in ('train', 'sample'):
             try:
                 out['cpu_baseline'] = cpu_baseline_record(args.ft, full=args.cpu_baseline_full)
             except Exception as e:

@@ -483,6 +483,21 @@ int strive_planner_rollout(const StrivePlanner* pl, const double* agent_obs, con
 int strive_planner_routes(const StrivePlanner* pl, int32_t mapix, const double* pose4, int32_t maxr, int32_t maxk,
                           int32_t* nroutes, int32_t* nk, double* knots, int32_t* status, strive_stream_t stream);
 
+/* Operator-level views of two building blocks the rollout kernels evaluate in registers (the kernels call the same device
+ * functions); used by the parity tests against the reference's own outputs.
+ *
+ * strive_bicycle_step: TrafficModel.sim_traj -> car_dynamics for one step (reference src/models/traffic_model.py:645-650,
+ * 714-733, src/models/common.py:47-68, src/utils/transforms.py:8-29) with dec's normaliser statistics and bicycle
+ * parameters: state (N,6) normalised, dec_out (N,2) the decoder's (acceleration, yaw acceleration) output, lw0 (N) the
+ * normalised vehicle length -> out (N,6) normalised next state; with g_out (N,6) also the adjoints g_state (N,6) and
+ * g_dec (N,2) (zero through an active clamp).
+ * strive_rel_pose: transform2frame(frame, poses) (reference src/utils/transforms.py:78-139, forward branch): frame (N,4),
+ * poses (N,M,4) -> out (N,M,4); with g_out also g_frame (N,4) (summed over M) and g_poses (N,M,4). */
+int strive_bicycle_step(const StriveDecoder* dec, const float* state, const float* dec_out, const float* lw0, const float* g_out,
+                        float* out, float* g_state, float* g_dec, int32_t N, strive_stream_t stream);
+int strive_rel_pose(const float* frame, const float* poses, const float* g_out, float* out, float* g_frame, float* g_poses,
+                    int32_t N, int32_t M, strive_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

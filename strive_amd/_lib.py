@@ -162,6 +162,8 @@ PROTOTYPES = {
     'strive_rollout_train_workspace_bytes': (SZ, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), I]),
     'strive_rollout_bwd_train': (C.c_int, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), P, P, P, P, P, I, P, P, P, P, P, P, P,
                                            P, SZ, P, SZ, P]),
+    'strive_bicycle_step': (C.c_int, [C.POINTER(StriveDecoder), P, P, P, P, P, P, P, I, P]),
+    'strive_rel_pose': (C.c_int, [P, P, P, P, P, P, I, I, P]),
     'strive_planner_workspace_bytes': (SZ, [C.POINTER(StrivePlanner), I, I]),
     'strive_planner_rollout': (C.c_int, [C.POINTER(StrivePlanner), P, P, I, P, I, P, I, I, P, P, P, SZ, P]),
     'strive_planner_routes': (C.c_int, [C.POINTER(StrivePlanner), I, P, I, I, P, P, P, P, P]),

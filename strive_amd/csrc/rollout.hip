@@ -845,3 +845,66 @@ extern "C" int strive_rollout_bwd_train(const StriveDecoder* dec, const StriveSc
     STRIVE_CHECK_LAUNCH();
     return 0;
 }
+
+// =============================================================================================
+// operator-level views of the in-register building blocks (parity tests call these; the rollout kernels call the same
+// device functions): one kinematic bicycle step and the rigid frame change
+// =============================================================================================
+static __global__ void bicycle_step_kernel(DynParams dp, const float* __restrict__ state, const float* __restrict__ dec,
+                                           const float* __restrict__ lw0, const float* __restrict__ g_out, float* __restrict__ out,
+                                           float* __restrict__ g_state, float* __restrict__ g_dec, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    BikeFwd b;
+    bike_forward(dp, state + (size_t)i * 6, dec[2 * i], dec[2 * i + 1], lw0[i], b);
+    for (int c = 0; c < 6; ++c) out[(size_t)i * 6 + c] = b.out[c];
+    if (g_out) {
+        float gs[6], gd[2];
+        bike_backward(dp, b, g_out + (size_t)i * 6, gs, gd);
+        for (int c = 0; c < 6; ++c) g_state[(size_t)i * 6 + c] = gs[c];
+        g_dec[2 * i] = gd[0];
+        g_dec[2 * i + 1] = gd[1];
+    }
+}
+
+extern "C" int strive_bicycle_step(const StriveDecoder* dec, const float* state, const float* dec_out, const float* lw0,
+                                   const float* g_out, float* out, float* g_state, float* g_dec, int32_t N, strive_stream_t stream_) {
+    STRIVE_CHECK_ARG(dec && state && dec_out && lw0 && out && N >= 0, "null argument");
+    STRIVE_CHECK_ARG(!g_out || (g_state && g_dec), "g_state / g_dec missing");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(bicycle_step_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream_, dyn_params(*dec), state, dec_out, lw0,
+                       g_out, out, g_state, g_dec, (int)N);
+    STRIVE_CHECK_LAUNCH();
+    return 0;
+}
+
+static __global__ void rel_pose_kernel(const float* __restrict__ frame, const float* __restrict__ poses, const float* __restrict__ g_out,
+                                       float* __restrict__ out, float* __restrict__ g_frame, float* __restrict__ g_poses, int N, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float gf[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < M; ++j) {
+        const size_t o = ((size_t)i * M + j) * 4;
+        float r[4];
+        rel_pose(frame + (size_t)i * 4, poses + o, r);
+        for (int c = 0; c < 4; ++c) out[o + c] = r[c];
+        if (g_out) {
+            float gp[4] = {0.f, 0.f, 0.f, 0.f};
+            rel_pose_bwd(frame + (size_t)i * 4, poses + o, g_out + o, gf, gp);
+            for (int c = 0; c < 4; ++c) g_poses[o + c] = gp[c];
+        }
+    }
+    if (g_out)
+        for (int c = 0; c < 4; ++c) g_frame[(size_t)i * 4 + c] = gf[c];
+}
+
+extern "C" int strive_rel_pose(const float* frame, const float* poses, const float* g_out, float* out, float* g_frame, float* g_poses,
+                               int32_t N, int32_t M, strive_stream_t stream_) {
+    STRIVE_CHECK_ARG(frame && poses && out && N >= 0 && M >= 1, "null argument");
+    STRIVE_CHECK_ARG(!g_out || (g_frame && g_poses), "g_frame / g_poses missing");
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(rel_pose_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream_, frame, poses, g_out, out, g_frame, g_poses,
+                       (int)N, (int)M);
+    STRIVE_CHECK_LAUNCH();
+    return 0;
+}

@@ -250,3 +250,60 @@ def test_sample_batched_golden_and_feasibility(model):
                                                 infront_min=front, check_sep=True, raster=uraster, dx=udx, map_idx=map_idx[0:1])
         assert np.array_equal(f.cpu().numpy(), fo.numpy()) and np.array_equal(st.cpu().numpy(), sto.numpy())
         np.testing.assert_allclose(ds.cpu().numpy(), dso.numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_sample_batched_at_the_reference_operating_point(model):
+    """adv_scenario_gen.py:160-174 calls sample_batched(NS = 20, include_mean = True) on every scene before it is accepted.  At
+    32 scenes x 16 agents x 20 samples (10,240 rollout rows, uniform raster so that comparisons are tight) the size-independent
+    properties of the joint rollout: sample s of the batch equals a plain 2-D rollout of z[:, s] (the reference's NS code path
+    against its 2-D path), the last sample is the prior mean's rollout, every scene equals itself rolled out alone, z statistics
+    equal their closed forms, and a sample of rows equals the oracle."""
+    m, sd = model
+    sizes = [16] * 32
+    batch, map_idx = synth.make_batch(sizes, key='ns20', FT=12)
+    uraster, udx = mg.loop_rasters('u')
+    env = dev_env(uraster, udx)
+    bg, mi = batch.clone().to(DEV), map_idx.to(DEV)
+    NA, NS, FT = batch.past.shape[0], 20, 12
+    eps = synth.f32(synth.counter_normal((NS, NA, 32), 'ns20/eps')).to(DEV)
+    saved = m.rsample
+    try:
+        m.rsample = lambda mean, var: mean + eps[:, :mean.shape[1]] * torch.sqrt(var)
+        with torch.no_grad():
+            so = m.sample_batched(bg, mi, env, NS, include_mean=True, nfuture=FT)
+    finally:
+        m.rsample = saved
+    fp, z = so['future_pred'], so['z_samp']
+    assert fp.shape == (NA, NS, FT, 4) and z.shape == (NA, NS, 32) and bool(torch.isfinite(fp).all())
+    mu, var = so['prior_out']
+    assert torch.equal(z[:, -1], mu)
+    with torch.no_grad():
+        emb = m.embed(bg, mi, env)
+        for s in (0, 7, NS - 1):
+            one = m.decode_embedding(z[:, s].contiguous(), emb, bg, mi, env, nfuture=FT)['future_pred']
+            assert_close(fp[:, s], one, 1e-4, 2e-5, 'sample %d of the joint rollout vs its own 2-D rollout' % s)
+    # closed forms of the latent statistics
+    lp = (-0.5 * ((z - mu[:, None]) ** 2 / var[:, None]) - 0.5 * torch.log(2 * np.pi * var[:, None])).sum(-1)
+    assert_close(so['z_logprob'], lp, 1e-4, 1e-3, 'z_logprob')
+    assert_close(so['z_mdist'], torch.norm((z - mu[:, None]) / torch.sqrt(var[:, None]), dim=-1), 1e-4, 1e-4, 'z_mdist')
+    # scenes 3 and 17 alone
+    from strive_amd.graph import Batch
+    for b in (3, 17):
+        sub = Batch.from_data_list([batch.to_data_list()[b]])
+        smi = map_idx[b:b + 1]
+        rows = slice(16 * b, 16 * b + 16)
+        try:
+            m.rsample = lambda mean, var, rows=rows: mean + eps[:, rows] * torch.sqrt(var)
+            with torch.no_grad():
+                alone = m.sample_batched(sub.clone().to(DEV), smi.to(DEV), env, NS, include_mean=True, nfuture=FT)
+        finally:
+            m.rsample = saved
+        assert_close(alone['future_pred'], fp[rows], 1e-4, 2e-5, 'scene %d alone vs inside the batch' % b)
+    # the oracle on scene 3, samples 0..2 (CPU: 3 x 16 rollout rows)
+    orc = oracle_model(sd)
+    sub = Batch.from_data_list([batch.to_data_list()[3]])
+    with torch.no_grad():
+        wo = orc.sample_batched(sub, map_idx[3:4], synth.SyntheticMapEnv(uraster, udx), eps[:3, 48:64].cpu(), include_mean=False,
+                                nfuture=FT)
+    assert_close(fp[48:64, :3], wo['future_pred'], RT, AT, 'joint rollout rows vs the oracle')

@@ -210,8 +210,10 @@ def test_embed_golden(model):
 # rollout
 # ------------------------------------------------------------------------------------------------
 
-def _rollout_pair(m, sd, sizes, key, raster, dx, FT, NS=1, ext=False, NC=2):
+def _rollout_pair(m, sd, sizes, key, raster, dx, FT, NS=1, ext=False, NC=2, mutate=None):
     batch, map_idx = synth.make_batch(sizes, key=key, FT=12, NC=NC)
+    if mutate is not None:
+        mutate(batch)
     env_c = synth.SyntheticMapEnv(raster, dx)
     orc = oracle_model(sd, NC=NC)
     with torch.no_grad():
@@ -248,6 +250,31 @@ def test_rollout_smooth_map_tight(model, sizes, FT, NS, ext):
     # float64 evaluation); 12-16 recurrent steps with LayerNorm / max-aggregation kinks amplify that to ~1e-4 of the
     # gradient scale on isolated entries
     assert_close(gg, gc, 2e-3, 1e-6 + 2e-4 * float(gc.abs().max()), 'dL/dz')
+
+
+def test_rollout_with_active_bicycle_clamps(model):
+    """The kinematic bicycle's clamps (reference src/models/common.py:47-68: speed into [0, 50] m/s, yaw rate into
+    [-2 pi, 2 pi]) forced ACTIVE inside the rollout kernels: agents start with a negative speed, 60 m/s, and yaw rates of +-7
+    rad/s.  Forward values and dL/dz (zero through a saturated component, the reverse sweep's m_s / m_h masks) against the oracle
+    over the uniform raster, 3 steps."""
+    from strive_amd.constants import state_norm_tensors
+    m, sd = model
+    raster, dx = uniform_env()
+    mean, std = state_norm_tensors()
+
+    def mutate(batch):
+        last = batch.past[:, -1, :]
+        for row, (col, val) in enumerate([(4, -1.0), (4, 60.0), (5, 7.0), (5, -7.0)]):
+            last[row, col] = (val - float(mean[col])) / float(std[col])
+        batch.past_gt[:, -1, :] = batch.past[:, -1, :]
+    pc, gc, pg, gg = _rollout_pair(m, sd, [5, 3], 'gr/clamp', raster, dx, 3, mutate=mutate)
+    assert_close(pg, pc, RT, AT, 'future_pred with saturated dynamics')
+    assert_close(gg, gc, 2e-3, 1e-6 + 2e-4 * float(gc.abs().max()), 'dL/dz with saturated dynamics')
+    # the saturation is real: agent 0 stands still after the first step, agent 1 moves 25 m per step
+    from oracle.geometry import Normalizer
+    un = Normalizer(mean, std).unnormalize(pc)
+    step = torch.norm(un[:, 1, :2] - un[:, 0, :2], dim=-1)
+    assert float(step[1]) == pytest.approx(25.0, abs=0.6) and float(step[0]) < 2.0
 
 
 def test_rollout_two_steps_textured(model):
