@@ -2,12 +2,17 @@
 // (reference src/models/traffic_model.py:69-87, 437-440), with the raster crop fused into the
 // first convolution so the (N,4,256,256) crop never exists in HBM.
 //
-// Every convolution is an implicit GEMM on the matrix cores,
+// Every convolution is an implicit GEMM on the fp16 matrix cores at fp32 accuracy,
 //     D[co][pixel] += W[co][k] * patch[k][pixel]
-// with A = weights (M = output channels) and B = input patches (N = output pixels):
-//   layer 1 (u8 crop, Cout 16):  v_mfma_f32_16x16x32_bf16, weights split exactly into 3 bf16 pieces (exact fp32 result)
-//   layers 2-6 (fp32 in):        v_mfma_f32_32x32x16_bf16, both operands split exactly into 3 bf16 pieces, 6 products
-//                                (layers 5-6: several whole samples per workgroup)
+// with A = weights (M = output channels) and B = input patches (N = output pixels).  An fp32 operand x is carried as TWO fp16
+// pieces, x0 = fp16(x) rounded to nearest and x1 = fp16(x - x0): because x0 is rounded to nearest the remainder needs 12 bits,
+// so x0 + x1 = x up to 2^-24 |x|, and x w = x0 w0 + x0 w1 + x1 w0 (the dropped x1 w1 is <= 2^-24 |x w|) -- three products, each
+// exact in fp32 (11 x 11 significand bits), fp32 accumulation inside the MFMA.  fp16's narrow exponent range is met with exact
+// power-of-two scales (weights: wscale[l] on the host; activations: xscale[l] folded into the GroupNorm affine map), undone in
+// the epilogue.
+//   layer 1 (u8 crop, exact in fp16; Cout 16):  v_mfma_f32_16x16x32_f16, weights in 2 pieces = 2 products
+//   layers 2-4 (fp32 in):                       v_mfma_f32_32x32x16_f16, both operands in 2 pieces = 3 products
+//   layers 5-6 + Linear:                        one fused kernel (map_cnn_tail.h), same scheme
 // Input tiles are staged once per workgroup into LDS with the previous layer's GroupNorm + ReLU applied
 // on the way in (so normalised activations never exist in HBM either); columns are stored
 // de-interleaved by parity so the stride-2 window reads of consecutive output pixels hit consecutive
@@ -42,12 +47,11 @@ __device__ __forceinline__ void gn_moments(const GNStats* __restrict__ st, int n
 }
 
 // =============================================================================================
-// Layer 1 on the bf16 matrix cores with EXACT fp32 semantics.
-// The crop is uint8 (exactly representable in bf16) and every fp32 weight is the exact sum of three bf16
-// pieces (w = hi + mid + lo, 3 x 8 significand bits), so  sum_k in_k * w_k  ==  sum_k in_k*hi_k + in_k*mid_k +
-// in_k*lo_k  with every product exact in fp32 and fp32 accumulation inside v_mfma_f32_16x16x32_bf16: the result
-// is an fp32 dot product in a different summation order (like any other fp32 implementation), but the matrix
-// pipe runs it at the bf16 rate: 21 MFMAs of 16 cycles per 16-pixel tile instead of 49 of 32 cycles.
+// Layer 1 on the fp16 matrix cores at fp32 accuracy.
+// The crop is uint8 (exactly representable in fp16) and every fp32 weight, scaled by the power of two wscale[0], is carried as
+// two fp16 pieces (w = w0 + w1 up to 2^-24 |w|, w0 rounded to nearest), so  sum_k in_k * w_k  =  sum_k in_k*w0_k + in_k*w1_k
+// with every product exact in fp32 and fp32 accumulation inside v_mfma_f32_16x16x32_f16: an fp32 dot product in a different
+// summation order, at the fp16 matrix rate: 14 MFMAs per 16-pixel tile (7 window rows x 2 weight pieces).
 // k is ordered (ky, column pair g = 0..3, column parity, channel): lane group g of an MFMA holds the 8 values
 // of window columns 2g, 2g+1 (x 4 layers) which are 16 contiguous bytes of the [row][col][layer] bf16 LDS
 // tile; the 8th window column is padding with zero weights.

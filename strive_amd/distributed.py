@@ -70,8 +70,9 @@ class DataParallelTrainer(object):
       2. forward -> TrafficModelLoss -> backward of the rank's share of the global loss (a RuntimeError is caught like the
          reference's per-batch try/except);
       3. ONE all_reduce(SUM) of the flat gradient bucket (1.09 M fp32 = 4.37 MB for NC = 2) whose last element is the
-         rank's "I failed" flag: if any rank failed, every rank skips the optimiser step (the skip vote), otherwise the
-         bucket is scattered back into ``p.grad`` and ``optimizer.step()`` runs -- identical parameters on every rank.
+         rank's "I failed" flag: if any rank failed, every rank skips the optimiser step (the skip vote), otherwise
+         ``optimizer.step()`` runs -- identical parameters on every rank.  The bucket is persistent and every ``p.grad`` is a
+         view into it, so nothing is copied in or out; a single rank never reads the flag back from the device.
     """
 
     def __init__(self, model, loss_fn, optimizer, group=None):
@@ -79,6 +80,22 @@ class DataParallelTrainer(object):
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.last_error = None
+        # ONE persistent flat gradient buffer; every p.grad is a view into it (autograd accumulates in place), so the bucket
+        # that goes through the all-reduce IS the gradients: no per-parameter copy in, no copy out.  The last element carries
+        # the skip vote.
+        dev = self.params[0].device
+        self.bucket = torch.zeros((self.numel + 1,), dtype=torch.float32, device=dev)
+        self._views = []
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self._views.append(self.bucket[off:off + n].view_as(p))
+            off += n
+
+    def _bind_grads(self):
+        for p, v in zip(self.params, self._views):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
 
     def _all_reduce(self, t):
         if dist.is_available() and dist.is_initialized():
@@ -105,40 +122,40 @@ class DataParallelTrainer(object):
     def step(self, scene_graph, map_idx, map_env, future_sample=None):
         dev = self.params[0].device
         local = self.batch_counts(scene_graph, self.model.FT)
-        glob = self._all_reduce(local.clone().to(dev)).cpu()
+        glob = torch.clamp(self._all_reduce(local.clone().to(dev)).cpu(), min=1.0)      # an empty global count never divides
         w = self.loss_fn.loss_weights
         if future_sample is None:
             future_sample = w['coll_veh_prior'] > 0.0 or w['coll_env_prior'] > 0.0
-        self.optimizer.zero_grad()
-        failed, loss_dict, share = 0.0, None, None
+        self.bucket.zero_()
+        self._bind_grads()
+        failed, loss_dict, share, error = 0.0, None, None, None
         try:
             pred = self.model(scene_graph, map_idx, map_env, future_sample=future_sample)
             loss_dict = self.loss_fn(scene_graph, pred, map_idx=map_idx, map_env=map_env)
             share = self.global_loss_share(loss_dict, [float(v) for v in local], [float(v) for v in glob])
             share.backward()
-        except RuntimeError as e:          # like the reference's per-batch try/except: skip, everywhere
+        except Exception as e:             # ANY failure on one rank must still reach the collective below, or the others hang
+            error = e
             self.last_error = e
             failed = 1.0
-        bucket = torch.zeros((self.numel + 1,), dtype=torch.float32, device=dev)
-        if not failed:
-            off = 0
-            for p in self.params:
-                n = p.numel()
-                if p.grad is not None:
-                    bucket[off:off + n] = p.grad.reshape(-1)
-                off += n
-        bucket[-1] = failed
-        self._all_reduce(bucket)
-        if float(bucket[-1]) > 0.0:
-            for p in self.params:
-                p.grad = None
-            return None
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad = bucket[off:off + n].view_as(p).clone()
-            off += n
+        self._bind_grads()                 # (a failed backward may have left some p.grad detached from the bucket)
+        if failed:
+            self.bucket.zero_()
+        self.bucket[-1] = failed
+        self._all_reduce(self.bucket)
+        if error is not None and not isinstance(error, RuntimeError):
+            raise error                    # the reference's loop only swallows RuntimeError (train_traffic.py:120-131)
+        if failed:
+            return None                    # this rank knows its own outcome without looking at the device
+        if self._needs_host_vote() and bool(self.bucket[-1] > 0.0):
+            return None                    # another rank failed: nobody steps
         self.optimizer.step()
         out = dict(loss_dict)
         out['global_loss'] = self._all_reduce(share.detach().clone().reshape(1))
         return out
+
+    def _needs_host_vote(self):
+        """With more than one rank another rank may have failed while this one did not: the optimiser step must then be
+        skipped here too, which needs the vote on the host (one 4-byte read after the all-reduce -- the collective has
+        synchronised the ranks anyway).  A single rank knows its own outcome already and never reads the device."""
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1

@@ -56,6 +56,32 @@ class LossDict(dict):
             self._resolve(k)
         return dict.values(self)
 
+    # bulk access through CPython's dict fast paths (dict(ld), {**ld}, ld.copy(), other.update(ld), pop, pickling) bypasses
+    # __getitem__: resolve everything first so that no None placeholder can leak out
+    def _resolve_all(self):
+        for k in list(self._thunks):
+            self._resolve(k)
+
+    def __iter__(self):
+        self._resolve_all()
+        return dict.__iter__(self)
+
+    def keys(self):
+        self._resolve_all()
+        return dict.keys(self)
+
+    def copy(self):
+        self._resolve_all()
+        return dict(dict.items(self))
+
+    def pop(self, key, *default):
+        self._resolve(key)
+        return dict.pop(self, key, *default)
+
+    def __reduce__(self):
+        self._resolve_all()
+        return (dict, (dict(dict.items(self)),))
+
 
 def _masked_mean(pen, mask):
     """mean of pen[mask], 0 when nothing is selected (= the reference's ``[0.]`` sentinel), without compaction."""

@@ -370,7 +370,8 @@ class _OverrideEnv(object):
 
 
 def cnn_pack(model):
-    """Packed map-CNN weights (bf16 fragment tables + fc), re-packed when any map_conv / map_feature parameter changes."""
+    """Packed map-CNN weights (two-piece fp16 fragment tables in MFMA operand order + their power-of-two scales + fc), re-packed
+    when any map_conv / map_feature parameter changes."""
     return _cached_pack(model, 'cnn', (model.map_conv, model.map_feature), lambda: params.pack_cnn(model.state_dict()))
 
 
