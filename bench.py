@@ -501,21 +501,20 @@ def cpu_baseline(FT, scenes=4, agents=16, raster_px=4096, timed=3, warm=1):
 def cpu_baseline_record(FT, full=False):
     """The bench line's `cpu_baseline`.  SURVEY 8(d) quotes the CPU at C2 (32 scenes x 16 agents), where one closure of the
     oracle takes minutes; the default run therefore times two bounded samples of the same workload -- 4 x 16 agents (1 warm-up +
-    2 timed closures) and 16 x 16 agents (1 timed closure) -- reports the LARGER one as `value` (per-agent CPU throughput falls
-    with the batch: the crop pipeline's GiB-scale intermediates leave the caches) and states both, so the trend towards C2
-    is visible.  ``--cpu-baseline-full`` times C2 itself (1 warm-up + 3 timed closures, ~10 minutes);
-    profiles/r03_cpu_baseline_c2.json holds that run."""
+    2 timed closures) and 16 x 16 agents (1 timed closure) -- reports the LARGER sample as `value` and states both, so the trend
+    towards C2 is visible (it differs by host: 77 -> 31 agent*timesteps/s from 4 to 32 scenes on the 8-vCPU survey container,
+    79 -> 90 from 4 to 16 scenes on the 128-thread EPYC of the GPU boxes).  ``--cpu-baseline-full`` times C2 itself (1 warm-up +
+    2 timed closures, several minutes); profiles/r03_cpu_baseline_c2.json holds that run."""
     if full:
-        rec = cpu_baseline(FT, scenes=32, agents=16, timed=3)
+        rec = cpu_baseline(FT, scenes=32, agents=16, timed=2)
         rec['sample'] = 'C2 itself: ' + rec['sample']
         return rec
     small = cpu_baseline(FT, scenes=4, agents=16, timed=2)
     large = cpu_baseline(FT, scenes=16, agents=16, timed=1, warm=0)
     rec = dict(large)
-    rec['sample'] = ('bounded samples of C2 (32 x 16 agents): %s || %s.  `value` is the 16 x 16 sample; per-agent CPU throughput '
-                     'falls with the batch size (4 x 16: %.1f, 16 x 16: %.1f agent*timesteps/s), C2 itself is slower still '
-                     '(profiles/r03_cpu_baseline_c2.json, --cpu-baseline-full)' % (small['sample'], large['sample'], small['value'],
-                                                                                   large['value']))
+    rec['sample'] = ('bounded samples of C2 (32 x 16 agents): %s || %s.  `value` is the 16 x 16 sample (4 x 16: %.1f, 16 x 16: %.1f '
+                     'agent*timesteps/s); C2 itself, timed with --cpu-baseline-full, is in profiles/r03_cpu_baseline_c2.json' %
+                     (small['sample'], large['sample'], small['value'], large['value']))
     rec['samples'] = [{'scenes': 4, 'agents': 16, 'value': small['value']}, {'scenes': 16, 'agents': 16, 'value': large['value']}]
     return rec
 

@@ -27,7 +27,7 @@
 
 #pragma clang fp contract(off)
 
-namespace {
+namespace strive_planner {
 
 constexpr int MAXM = 96;        // lane matches of one pose
 constexpr int MAXKEEP = 16;     // clusters of matches
@@ -443,6 +443,7 @@ struct Work {
     double* poses;          // (B, K, 4)
     int32_t* scene_bad;     // (B)
     int K, cap, ENT, P, NT;
+    size_t nzero;
 };
 
 __global__ void planner_world_kernel(StrivePlanner pl, Work w, const double* __restrict__ obs, const double* __restrict__ agent_t, int T) {
@@ -872,17 +873,20 @@ Layout carve(const StrivePlanner* pl, int nstep, int traj_cap, void* ws, size_t 
     w.wstate = a.take<double>((size_t)pl->NR * w.K * 4);
     w.present = a.take<int8_t>((size_t)pl->NR * w.K);
     w.traj = a.take<double>((size_t)pl->B * w.K * w.cap * w.ENT);
-    w.traj_cnt = a.take<int32_t>((size_t)pl->B * w.K);
+    // small integer state, zeroed by ONE memset at the start of a rollout: trajectory counts, scene flags, route lengths
+    // (a scene that is given up keeps route length 0 instead of whatever the workspace held), stop preferences, chunk counts
+    w.nzero = (size_t)pl->B * w.K + 3 * (size_t)pl->B + (size_t)pl->B * NCHUNK;
+    w.traj_cnt = a.take<int32_t>(w.nzero);
     w.ego = a.take<double>((size_t)pl->B * 8);
     w.route = a.take<double>((size_t)pl->B * 5 * MAXK);
-    w.route_nk = a.take<int32_t>(pl->B);
-    w.prefer_stop = a.take<int32_t>(pl->B);
+    w.scene_bad = w.traj_cnt ? w.traj_cnt + (size_t)pl->B * w.K : nullptr;
+    w.route_nk = w.traj_cnt ? w.scene_bad + pl->B : nullptr;
+    w.prefer_stop = w.traj_cnt ? w.route_nk + pl->B : nullptr;
+    w.part_cnt = w.traj_cnt ? w.prefer_stop + pl->B : nullptr;
     w.prof = a.take<double>((size_t)pl->B * MAXPROF * 3);
     w.circ = a.take<double>((size_t)pl->B * w.P * w.NT * 10);
     w.part = a.take<double>((size_t)pl->B * NCHUNK * w.P * w.NT);
-    w.part_cnt = a.take<int32_t>((size_t)pl->B * NCHUNK);
     w.poses = a.take<double>((size_t)pl->B * w.K * 4);
-    w.scene_bad = a.take<int32_t>(pl->B);
     L.total = a.ok() ? a.off : 0;
     return L;
 }
@@ -902,7 +906,8 @@ int check_cfg(const StrivePlanner* pl, int nstep, int traj_cap) {
     return 0;
 }
 
-}  // namespace
+}  // namespace strive_planner
+using namespace strive_planner;
 
 extern "C" size_t strive_planner_workspace_bytes(const StrivePlanner* pl, int32_t nstep, int32_t traj_cap) {
     if (check_cfg(pl, nstep, traj_cap)) return 0;
@@ -919,8 +924,7 @@ extern "C" int strive_planner_rollout(const StrivePlanner* pl, const double* age
     Layout L = carve(pl, nstep, traj_cap, ws, ws_bytes);
     STRIVE_CHECK_ARG(L.total != 0, "workspace too small");
     Work& w = L.w;
-    hipMemsetAsync(w.traj_cnt, 0, sizeof(int32_t) * pl->B * w.K, stream);
-    hipMemsetAsync(w.scene_bad, 0, sizeof(int32_t) * pl->B, stream);
+    hipMemsetAsync(w.traj_cnt, 0, sizeof(int32_t) * w.nzero, stream);
     if (pl->NR > 0) {
         hipLaunchKernelGGL(planner_world_kernel, dim3((pl->NR + 63) / 64), dim3(64), 0, stream, *pl, w, agent_obs, agent_t, (int)T);
         hipLaunchKernelGGL(planner_routes_kernel, dim3(pl->NR * w.K), dim3(64), 0, stream, *pl, w, status);

@@ -13,6 +13,7 @@ get_lane_matches' scan of all edges, :298-322).  ``rollout`` accepts the futures
 (no device->host copy in the optimisation loop) or, like the reference, as a numpy array.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -286,6 +287,8 @@ class HardcodeNuscPlanner(PlannerNusc):
         if nbytes == 0:
             raise L.StriveHipError('strive_planner_workspace_bytes: ' + lib.query('strive_last_error').decode())
         ws = ops._workspace(dev, nbytes, tag='planner')
+        if os.environ.get('STRIVE_POISON_WS') == '1':
+            ws.fill_(0x25)                # debug aid (the tests set it): a kernel that reads workspace it did not write sees garbage
         TP = planner_t.shape[0]
         plan = torch.empty((self.B, TP, 4), dtype=torch.float64, device=dev)
         status = torch.zeros((8,), dtype=torch.int32, device=dev)

@@ -25,6 +25,7 @@ from strive_amd.planners.planner import PlannerConfig
 from strive_amd.planners.hardcode_goalcond_nusc import HardcodeNuscPlanner, CONFIG_DICT, edge_grid
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'hipemu'))
+os.environ['STRIVE_POISON_WS'] = '1'          # the planner's workspace starts as garbage in every test of this file
 
 
 @pytest.fixture()
