@@ -24,6 +24,7 @@
 // arg-mins, the profile choice) are the reference's; serial recurrences (cumulative sums, chain walks) run on lane 0.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -41,7 +42,7 @@ constexpr int MAXNT = 32;       // nsteps + 1
 constexpr int MAXPRED = 8;      // predicted speed profiles per route
 constexpr int MAXPROF = 64;     // ego speed profiles
 constexpr int PBLK = 25;        // profiles whose running minima a gap thread keeps in registers
-constexpr int NCHUNK = 8;       // trajectory chunks per scene in the gap kernel
+constexpr int NCHUNK = 16;      // trajectory chunks per scene in the gap kernel
 constexpr double LANE_DS = 0.4, LANE_SIG2 = 3.5 * 3.5, SBUFFER = 4.0;   // constants of rollout() (:211-213)
 
 enum { ST_MATCH = 0, ST_KEEP = 1, ST_CHAIN = 2, ST_NODES = 3, ST_KNOTS = 4, ST_RANGE = 5, ST_TRAJ = 6, ST_ACT = 7 };
@@ -53,6 +54,15 @@ struct ChainTab {
     short parent[NCH], fork[NCH], nown[NCH], ownoff[NCH];
     int pool[NPOOL];
     int n, npool;
+};
+
+// A window of 64 consecutive node records (count, first connection, its length) in LDS: the nodes of a lane are consecutive in
+// the reference's lane graph, so a chain walk that would otherwise be one dependent L2 round trip per node reads one coalesced
+// window per 64 nodes.
+struct NodeWin {
+    double len0[64];
+    int n[64], node0[64];
+    int base;
 };
 
 struct RouteLds {
@@ -68,11 +78,17 @@ struct RouteLds {
     double ks[MAXK], kx[MAXK], ky[MAXK], khx[MAXK], khy[MAXK];
     double bc[8];                 // broadcast slots
     int nm, nkept, np, nk, bad;
+    NodeWin win;
 };
 
 struct Pose { double x, y, h, s; };
 
 __device__ __forceinline__ int lane_id() { return (int)threadIdx.x & 63; }
+// The route-building functions below are written for ONE wave.  A workgroup may run them with several waves (the ego kernel
+// does, to have 256 threads for its data-parallel parts): every wave then computes the same values redundantly -- pure
+// functions of inputs that only change between barriers -- and the serial, in-place sections (cumulative sums, the insertion
+// sort, table writes) are executed by the workgroup's first thread only.
+__device__ __forceinline__ bool leader() { return threadIdx.x == 0; }
 
 __device__ __forceinline__ double norm2(double dx, double dy) { return sqrt(dx * dx + dy * dy); }
 
@@ -99,40 +115,57 @@ __device__ __forceinline__ double lerp_at(const double* t, const double* y, int 
     return slope * (q - t[lo]) + y[lo];
 }
 
-// all chains from v: breadth first, connection lists in order (expand_verts, :379-414).  Lane 0 only.
+// all chains from v: breadth first, connection lists in order (expand_verts, :379-414).  WHOLE WAVE, uniform control flow: every
+// lane walks the same chain on the same values (the window is refilled cooperatively), lane 0 writes the tables.
+// dir = +1 walks successors (the window reaches forward), -1 predecessors (backward).
 template <int NCH, int NPOOL>
-__device__ void build_chains(ChainTab<NCH, NPOOL>& c, const StriveLaneNode* rec, const int32_t* cptr, const int32_t* cidx,
-                             const double* clen, int v, double mindist, bool first_only, int32_t* status) {
-    c.n = 1; c.npool = 0;
-    c.parent[0] = -1; c.fork[0] = 0; c.first[0] = v; c.len[0] = 0.0;
-    for (int ci = 0; ci < c.n; ++ci) {
+__device__ void build_chains(ChainTab<NCH, NPOOL>& c, NodeWin& win, const StriveLaneNode* rec, int N, const int32_t* cptr,
+                             const int32_t* cidx, const double* clen, int v, double mindist, bool first_only, int dir, int32_t* status) {
+    const int lane = lane_id();
+    int n = 1, npool = 0;
+    __syncthreads();
+    if (leader()) { c.parent[0] = -1; c.fork[0] = 0; c.first[0] = v; c.len[0] = 0.0; win.base = -1000; }
+    __syncthreads();
+    for (int ci = 0; ci < n; ++ci) {
         double length = c.len[ci];
         int cur = c.first[ci];
         int total = c.fork[ci] + 1, cnt = 0;
-        c.ownoff[ci] = (short)c.npool;
+        const int ownoff = npool;
         while (length <= mindist) {
-            const StriveLaneNode r = rec[cur];
-            if (r.n == 0) break;
-            if (!first_only) {
+            int wb = win.base;
+            if (cur < wb || cur >= wb + 64) {
+                __syncthreads();
+                wb = dir > 0 ? cur : cur - 63;
+                const int i = wb + lane;
+                if (i >= 0 && i < N) { win.n[lane] = rec[i].n; win.node0[lane] = rec[i].node[0]; win.len0[lane] = rec[i].len[0]; }
+                if (leader()) win.base = wb;
+                __syncthreads();
+            }
+            const int rn = win.n[cur - wb];
+            if (rn == 0) break;
+            if (!first_only && rn > 1) {
+                const StriveLaneNode r = rec[cur];
                 for (int j = 1; j < r.n; ++j) {
                     int nd; double ln;
                     conn_at(r, cptr, cidx, clen, cur, j, nd, ln);
-                    if (c.n < NCH) {
-                        c.parent[c.n] = (short)ci; c.fork[c.n] = (short)total; c.first[c.n] = nd; c.len[c.n] = length + ln;
-                        ++c.n;
-                    } else flag(status, ST_CHAIN);
+                    if (n < NCH) {
+                        if (leader()) { c.parent[n] = (short)ci; c.fork[n] = (short)total; c.first[n] = nd; c.len[n] = length + ln; }
+                        ++n;
+                    } else if (leader()) flag(status, ST_CHAIN);
                 }
             }
-            if (c.npool >= NPOOL || total >= MAXP - 4) { flag(status, ST_NODES); break; }
-            length = length + r.len[0];
-            cur = r.node[0];
-            c.pool[c.npool++] = cur;
-            ++cnt; ++total;
+            if (npool >= NPOOL || total >= MAXP - 4) { if (leader()) flag(status, ST_NODES); break; }
+            length = length + win.len0[cur - wb];
+            cur = win.node0[cur - wb];
+            if (leader()) c.pool[npool] = cur;
+            ++npool; ++cnt; ++total;
         }
-        c.nown[ci] = (short)cnt;
-        c.len[ci] = length;
+        if (leader()) { c.ownoff[ci] = (short)ownoff; c.nown[ci] = (short)cnt; c.len[ci] = length; }
         if (first_only) break;
+        __syncthreads();                 // the next chain's start (written by lane 0 above) is read by every lane
     }
+    if (leader()) { c.n = n; c.npool = npool; }
+    __syncthreads();
 }
 
 template <int NCH, int NPOOL>
@@ -224,7 +257,7 @@ __device__ void match_and_cluster(RouteLds& R, const StrivePlannerMap& mp, const
     }
     if (nm > MAXM) nm = MAXM;
     __syncthreads();
-    if (lane == 0) {
+    if (leader()) {
         R.nm = nm;
         // stable order by distance (np.argsort on <= 16 entries is an insertion sort)
         for (int i = 0; i < nm; ++i) {
@@ -238,6 +271,9 @@ __device__ void match_and_cluster(RouteLds& R, const StrivePlannerMap& mp, const
             const int k = R.m_order[oi];
             if (R.m_done[k]) continue;
             if (nkept < MAXKEEP) R.kept[nkept++] = (short)k; else flag(status, ST_KEEP);
+            // breadth-first over the matches connected to k through matches, forward then backward (cluster_bfs, :349-376).  Every
+            // match IS a graph edge, so "(b, c) for c in out_edges[b] that is a match" is simply "a match that starts at b" (and a
+            // predecessor match one that ends at a): the walk needs the match list only, not the node records
             for (int dir = 0; dir < 2; ++dir) {
                 int qh = 0, qt = 0;
                 R.queue[qt++] = (short)k;
@@ -245,15 +281,9 @@ __device__ void match_and_cluster(RouteLds& R, const StrivePlannerMap& mp, const
                 while (qh < qt) {
                     const int cur = R.queue[qh++];
                     const int a = R.m_v0[cur], b = R.m_v1[cur];
-                    const int piv = dir == 0 ? b : a;
-                    const StriveLaneNode r = dir == 0 ? mp.succ[piv] : mp.pred[piv];
-                    for (int j = 0; j < r.n; ++j) {
-                        int nd; double ln;
-                        if (dir == 0) conn_at(r, mp.succ_ptr, mp.succ_idx, mp.succ_len, piv, j, nd, ln);
-                        else conn_at(r, mp.pred_ptr, mp.pred_idx, mp.pred_len, piv, j, nd, ln);
-                        const int w0 = dir == 0 ? b : nd, w1 = dir == 0 ? nd : a;
-                        for (int q = 0; q < nm; ++q)
-                            if (!R.m_done[q] && R.m_v0[q] == w0 && R.m_v1[q] == w1) { R.m_done[q] = 1; R.queue[qt++] = (short)q; }
+                    for (int q = 0; q < nm; ++q) {
+                        if (R.m_done[q]) continue;
+                        if (dir == 0 ? R.m_v0[q] == b : R.m_v1[q] == a) { R.m_done[q] = 1; R.queue[qt++] = (short)q; }
                     }
                 }
             }
@@ -265,7 +295,7 @@ __device__ void match_and_cluster(RouteLds& R, const StrivePlannerMap& mp, const
 
 // constant-heading route when no lane is near (constant_heading_spline, :477-484)
 __device__ void straight_route(RouteLds& R, const Pose& o, const RouteGeom& g) {
-    if (lane_id() == 0) {
+    if (leader()) {
         const double c = cos(o.h), s = sin(o.h);
         R.ks[0] = -g.back; R.kx[0] = o.x - g.back * c; R.ky[0] = o.y - g.back * s; R.khx[0] = c; R.khy[0] = s;
         R.ks[1] = g.fwd;   R.kx[1] = o.x + g.fwd * c;  R.ky[1] = o.y + g.fwd * s;  R.khx[1] = c; R.khy[1] = s;
@@ -286,14 +316,14 @@ __device__ void assemble_route(RouteLds& R, const StrivePlannerMap& mp, const Po
     const int np = nbv + nfv + shift + (ext_f ? 1 : 0);
     const int nk = g.nb + g.nf;
     if (np > MAXP || nk > MAXK) {
-        if (lane == 0) { flag(status, np > MAXP ? ST_NODES : ST_KNOTS); R.bad = 1; }
+        if (leader()) { flag(status, np > MAXP ? ST_NODES : ST_KNOTS); R.bad = 1; }
         __syncthreads();
         return;
     }
     fill_chain(R.cb, bi, mp.xy, R.px, R.py, shift + nbv - 1, -1);
     fill_chain(R.cf, fi, mp.xy, R.px, R.py, shift + nbv, +1);
     __syncthreads();
-    if (lane == 0) {
+    if (leader()) {
         R.bad = 0;
         if (ext_f) {                    // dead end ahead: extend straight
             const int last = shift + nbv + nfv - 1;
@@ -327,7 +357,7 @@ __device__ void assemble_route(RouteLds& R, const StrivePlannerMap& mp, const Po
         R.sn[i + 1] = sl;
     }
     __syncthreads();
-    if (lane == 0) {
+    if (leader()) {
         // the locally closest point, walking downhill from the matched edge
         int k = nbv - 1 + shift;
         while (k - 1 >= 0 && R.cd[k - 1] < R.cd[k]) --k;
@@ -339,7 +369,8 @@ __device__ void assemble_route(RouteLds& R, const StrivePlannerMap& mp, const Po
         along = fmin(fmax(along, 0.0), sl);
         const double ax = R.px[k] + along * dx, ay = R.py[k] + along * dy;
         R.sn[0] = 0.0;
-        for (int i = 1; i < np; ++i) R.sn[i] = R.sn[i - 1] + R.sn[i];
+        double acc = 0.0;                               // (running sum in a register: same additions in the same order, without
+        for (int i = 1; i < np; ++i) { acc = acc + R.sn[i]; R.sn[i] = acc; }      //  a store -> load round trip through LDS per term)
         R.bc[0] = ax; R.bc[1] = ay;
         R.bc[2] = R.sn[k];
         R.bc[3] = norm2(ax - R.px[k], ay - R.py[k]);
@@ -348,7 +379,7 @@ __device__ void assemble_route(RouteLds& R, const StrivePlannerMap& mp, const Po
     {
         const double off1 = R.bc[2], off2 = R.bc[3];
         __syncthreads();
-        for (int i = lane; i < np; i += 64) R.sn[i] = R.sn[i] - off1 - off2;
+        for (int i = threadIdx.x; i < np; i += blockDim.x) R.sn[i] = R.sn[i] - off1 - off2;      // (in place: once per element)
     }
     __syncthreads();
     const double ax = R.bc[0], ay = R.bc[1];
@@ -362,7 +393,7 @@ __device__ void assemble_route(RouteLds& R, const StrivePlannerMap& mp, const Po
         R.ky[i] = lerp_at(R.sn, R.py, lo, hi, q) + (o.y - ay) * e;
     }
     if (__ballot(range_bad) != 0ull) {
-        if (lane == 0) { flag(status, ST_RANGE); R.bad = 1; }
+        if (leader()) { flag(status, ST_RANGE); R.bad = 1; }
         __syncthreads();
         return;
     }
@@ -375,13 +406,14 @@ __device__ void assemble_route(RouteLds& R, const StrivePlannerMap& mp, const Po
         R.ks[i + 1] = dl;
     }
     __syncthreads();
-    if (lane == 0) {
+    if (leader()) {
         R.khx[nk - 1] = R.khx[nk - 2];
         R.khy[nk - 1] = R.khy[nk - 2];
         R.khx[g.nb] = cos(o.h);             // the route passes through the object's heading exactly
         R.khy[g.nb] = sin(o.h);
         R.ks[0] = 0.0;
-        for (int i = 1; i < nk; ++i) R.ks[i] = R.ks[i - 1] + R.ks[i];
+        double acc = 0.0;
+        for (int i = 1; i < nk; ++i) { acc = acc + R.ks[i]; R.ks[i] = acc; }
         R.bc[4] = R.ks[g.nb];
         R.nk = nk;
     }
@@ -389,10 +421,10 @@ __device__ void assemble_route(RouteLds& R, const StrivePlannerMap& mp, const Po
     {
         const double s0 = R.bc[4];
         __syncthreads();
-        for (int i = lane; i < nk; i += 64) R.ks[i] = R.ks[i] - s0;
+        for (int i = threadIdx.x; i < nk; i += blockDim.x) R.ks[i] = R.ks[i] - s0;               // (in place: once per element)
     }
     __syncthreads();
-    if (lane == 0 && !(R.ks[0] < -g.back && R.ks[nk - 1] > g.fwd)) { flag(status, ST_RANGE); R.bad = 1; }
+    if (leader() && !(R.ks[0] < -g.back && R.ks[nk - 1] > g.fwd)) { flag(status, ST_RANGE); R.bad = 1; }
     __syncthreads();
 }
 
@@ -430,7 +462,7 @@ __device__ __forceinline__ double linspace_at(double a, double b, int n, int i) 
 struct Work {
     double* wstate;         // (NR, K, 4) pose + speed of the non-ego objects
     int8_t* present;        // (NR, K)
-    double* traj;           // (B*K, cap, ENT) predicted trajectories: object x, y, l, w, then NT x (x, y, h)
+    double* traj;           // (B*K, cap, ENT) predicted trajectories: object x, y, l, w, duplicate mask, then NT x (x, y, h)
     int32_t* traj_cnt;      // (B*K)
     double* ego;            // (B, 8) x, y, h, s, l, w
     double* route;          // (B, 5, MAXK) s, x, y, cos, sin of the ego's route
@@ -511,11 +543,8 @@ __device__ int for_each_route(RouteLds& R, const StrivePlannerMap& mp, const Str
     const int nmatch = FIRST_ONLY ? 1 : nkept;
     for (int mi = 0; mi < nmatch; ++mi) {
         const int m = R.kept[mi];
-        if (lane_id() == 0) {
-            build_chains(R.cf, mp.succ, mp.succ_ptr, mp.succ_idx, mp.succ_len, R.m_v1[m], g.need_f, FIRST_ONLY, status);
-            build_chains(R.cb, mp.pred, mp.pred_ptr, mp.pred_idx, mp.pred_len, R.m_v0[m], g.need_b, FIRST_ONLY, status);
-        }
-        __syncthreads();
+        build_chains(R.cf, R.win, mp.succ, mp.N, mp.succ_ptr, mp.succ_idx, mp.succ_len, R.m_v1[m], g.need_f, FIRST_ONLY, +1, status);
+        build_chains(R.cb, R.win, mp.pred, mp.N, mp.pred_ptr, mp.pred_idx, mp.pred_len, R.m_v0[m], g.need_b, FIRST_ONLY, -1, status);
         const int nf = FIRST_ONLY ? 1 : R.cf.n, nb = FIRST_ONLY ? 1 : R.cb.n;
         begin_group(nf * nb);
         for (int fi = 0; fi < nf; ++fi)
@@ -532,6 +561,7 @@ __global__ void __launch_bounds__(64) planner_routes_kernel(StrivePlanner pl, Wo
     __shared__ RouteLds R;
     __shared__ double pd[MAXPRED][MAXNT];
     __shared__ int slot_base;
+    __shared__ int dmask[MAXPRED];
     const int lane = lane_id();
     const int r = blockIdx.x / w.K, k = blockIdx.x % w.K;
     if (!w.present[(size_t)r * w.K + k]) return;
@@ -567,14 +597,32 @@ __global__ void __launch_bounds__(64) planner_routes_kernel(StrivePlanner pl, Wo
         const bool bad = R.bad != 0;
         if (base + npred > w.cap) { if (lane == 0) { flag(status, ST_TRAJ); w.scene_bad[b] = 1; } return; }
         if (bad && lane == 0) w.scene_bad[b] = 1;
+        // Routes of one match that share their backward chain and a prefix of their forward chain (breadth-first tree: chain fi
+        // continues its parent up to the fork) are IDENTICAL up to the fork, and so are the trajectory points that do not reach
+        // it -- most of them: an object travels ~25 m in the 5 s horizon, crossings are further apart.  Points that equal the
+        // parent route's bit for bit are marked; the gap kernel skips them (the minimum over duplicates is the same).
+        int par_base = -1;
+        if (R.nkept > 0 && !bad) {
+            const int nb = R.cb.n, fi = ri / nb, bi = ri - fi * nb;
+            const int pf = R.cf.parent[fi];
+            if (pf >= 0) par_base = slot_base + (pf * nb + bi) * npred;
+        }
+        if (lane < MAXPRED) dmask[lane] = 0;
+        __syncthreads();
         for (int it = lane; it < npred * w.NT; it += 64) {
             const int p = it / w.NT, t = it % w.NT;
             double* ent = tbase + (size_t)(base + p) * w.ENT;
             double x = NAN, y = NAN, h = NAN;
             if (!bad && !route_pose(R, pd[p][t], x, y, h)) { flag(status, ST_RANGE); w.scene_bad[b] = 1; }
             if (t == 0) { ent[0] = o.x; ent[1] = o.y; ent[2] = l; ent[3] = wd; }
-            ent[4 + 3 * t] = x; ent[5 + 3 * t] = y; ent[6 + 3 * t] = h;
+            ent[5 + 3 * t] = x; ent[6 + 3 * t] = y; ent[7 + 3 * t] = h;
+            if (par_base >= 0) {
+                const double* pe = tbase + (size_t)(par_base + p) * w.ENT;
+                if (pe[5 + 3 * t] == x && pe[6 + 3 * t] == y && pe[7 + 3 * t] == h) atomicOr(&dmask[p], 1 << t);
+            }
         }
+        __syncthreads();
+        if (lane < npred) tbase[(size_t)(base + lane) * w.ENT + 4] = (double)(unsigned)dmask[lane];
     };
     for_each_route<false>(R, mp, cfg, o, status, begin_group, on_route);
 }
@@ -593,40 +641,43 @@ __device__ __forceinline__ void box_circles(double x, double y, double h, double
     cx[4] = x; cy[4] = y;
 }
 
-__global__ void __launch_bounds__(64) planner_ego_kernel(StrivePlanner pl, Work w, int k, int32_t* status) {
+__global__ void __launch_bounds__(256) planner_ego_kernel(StrivePlanner pl, Work w, int k, int32_t* status) {
     __shared__ RouteLds R;
-    __shared__ double pdist[MAXPROF][MAXNT];
+    __shared__ double pdist[MAXPROF][MAXNT];        // distances of the profiles; before that, (1 - pr) of step k-1's profiles
     __shared__ double risk[MAXPROF];
-    __shared__ double ctl[4];
-    const int lane = lane_id();
+    const int lane = lane_id(), tid = threadIdx.x, nthr = blockDim.x;
     const int b = blockIdx.x;
     const StrivePlannerCfg& cfg = pl.cfg;
     const StrivePlannerMap& mp = pl.maps[pl.scene_map[b]];
     double* eg = w.ego + 8 * (size_t)b;
     const int P = w.P, NT = w.NT;
-    if (k == 0 && lane == 0) {
+    if (k == 0 && tid == 0) {
         const double* in = pl.init + 6 * (size_t)(pl.ptr[b] + pl.ego_idx);
         for (int c = 0; c < 6; ++c) eg[c] = in[c];
     }
     __syncthreads();
     if (k > 0) {
-        // risk of the profiles of step k-1 (score_dists, :724-728; plot_plan_info, :768-801)
+        // risk of the profiles of step k-1 (score_dists, :724-728; plot_plan_info, :768-801): all threads take the minimum over
+        // the trajectory chunks and the tanh score of one (profile, time) each, then one lane per profile multiplies in time order
         int nother = 0;
         for (int c = 0; c < NCHUNK; ++c) nother += w.part_cnt[b * NCHUNK + c];
-        if (lane < P) {
-            double prod = 1.0;
-            for (int t = 0; t < NT; ++t) {
-                double gap = INFINITY;
-                for (int c = 0; c < NCHUNK; ++c) gap = fmin(gap, w.part[(((size_t)b * NCHUNK + c) * P + lane) * NT + t]);
-                const double wt = cfg.score_wmin + (double)t * cfg.score_wfac;
-                double pr = 1.0 + tanh(-gap * wt);
-                if (gap < 0) pr = 1.0;
-                prod = prod * (1.0 - pr);
-            }
-            risk[lane] = 1.0 - prod;
+        for (int it = tid; it < P * NT; it += nthr) {
+            const int p = it / NT, t = it % NT;
+            double gap = INFINITY;
+            for (int c = 0; c < NCHUNK; ++c) gap = fmin(gap, w.part[(((size_t)b * NCHUNK + c) * P + p) * NT + t]);
+            const double wt = cfg.score_wmin + (double)t * cfg.score_wfac;
+            double pr = 1.0 + tanh(-gap * wt);
+            if (gap < 0) pr = 1.0;
+            pdist[p][t] = 1.0 - pr;
         }
         __syncthreads();
-        if (lane == 0) {
+        if (tid < P) {
+            double prod = 1.0;
+            for (int t = 0; t < NT; ++t) prod = prod * pdist[tid][t];
+            risk[tid] = 1.0 - prod;
+        }
+        __syncthreads();
+        if (tid == 0) {
             const double* pf = w.prof + (size_t)b * MAXPROF * 3;
             int best = 0;
             if (nother == 0) {
@@ -685,19 +736,19 @@ __global__ void __launch_bounds__(64) planner_ego_kernel(StrivePlanner pl, Work 
     const double el = eg[4], ew = eg[5];
     double* rt = w.route + (size_t)b * 5 * MAXK;
     auto on_route = [&](int) {
-        for (int i = lane; i < R.nk; i += 64) {
+        for (int i = tid; i < R.nk; i += nthr) {
             rt[i] = R.ks[i]; rt[MAXK + i] = R.kx[i]; rt[2 * MAXK + i] = R.ky[i]; rt[3 * MAXK + i] = R.khx[i]; rt[4 * MAXK + i] = R.khy[i];
         }
-        if (lane == 0) { w.route_nk[b] = R.bad ? 0 : R.nk; if (R.bad) w.scene_bad[b] = 1; }
+        if (tid == 0) { w.route_nk[b] = R.bad ? 0 : R.nk; if (R.bad) w.scene_bad[b] = 1; }
     };
     const int nkept = for_each_route<true>(R, mp, cfg, o, status, [](int) {}, on_route);
     __syncthreads();
-    if (lane == 0) w.prefer_stop[b] = nkept == 0;
+    if (tid == 0) w.prefer_stop[b] = nkept == 0;
     if (R.bad) return;
     // candidate speed profiles (gen_sprofiles, :804-826)
-    if (lane < P) {
+    if (tid < P) {
         const int ns = cfg.plannspeeds;
-        const int i2 = lane % ns, i1 = (lane / ns) % ns, fi = lane / (ns * ns);
+        const int i2 = tid % ns, i1 = (tid / ns) % ns, fi = tid / (ns * ns);
         const double acc = cfg.planaccfacs[fi] * cfg.accmax;
         const int n1 = cfg.nsteps / 2, n2 = cfg.nsteps - n1;
         const double dt = cfg.preddt;
@@ -708,18 +759,18 @@ __global__ void __launch_bounds__(64) planner_ego_kernel(StrivePlanner pl, Work 
         const double r2 = (double)n2 * dt * acc;
         const double s2 = linspace_at(fmax(0.0, f_last - r2), fmin(cfg.smax, f_last + r2), ns, i2);
         double d = 0.0;
-        pdist[lane][0] = 0.0;
+        pdist[tid][0] = 0.0;
         for (int t = 1; t < NT; ++t) {
             const double sp = t <= n1 ? ramp_at(s0, s1, acc, t, dt) : ramp_at(f_last, s2, acc, t - n1, dt);
             d = d + sp * dt;
-            pdist[lane][t] = d;
+            pdist[tid][t] = d;
         }
-        double* pf = w.prof + ((size_t)b * MAXPROF + lane) * 3;
+        double* pf = w.prof + ((size_t)b * MAXPROF + tid) * 3;
         pf[0] = s1; pf[1] = acc; pf[2] = d;
     }
     __syncthreads();
     double* cc = w.circ + (size_t)b * P * NT * 10;
-    for (int it = lane; it < P * NT; it += 64) {
+    for (int it = tid; it < P * NT; it += nthr) {
         const int p = it / NT, t = it % NT;
         double x, y, h;
         double cx[5], cy[5];
@@ -729,93 +780,101 @@ __global__ void __launch_bounds__(64) planner_ego_kernel(StrivePlanner pl, Work 
     }
 }
 
-// gaps between the ego's profile boxes and one chunk of the scene's predicted trajectories (approx_bbox_distance, :885-897)
-__global__ void __launch_bounds__(256) planner_gap_kernel(StrivePlanner pl, Work w, int k) {
-    HIP_DYNAMIC_SHARED(double, smem)
+// gaps between the ego's profile boxes and one chunk of the scene's predicted trajectories (approx_bbox_distance, :885-897).
+// One thread per (profile, time): its ego box (5 circle centres) stays in registers, the chunk's trajectory boxes are staged in
+// LDS once (one sincos per trajectory point instead of one per profile), and the thread's running minimum culls every later
+// box whose centre is too far to matter -- every circle of a box lies within  m = max(|corner offset| + W/4, W/2)  of its
+// centre, so no gap to a box whose centre is D away can be below D - m_e - m_o (an exact cull, the minimum is unchanged).
+// Trajectory points marked as bit-for-bit duplicates by the routes kernel are not staged at all.
+constexpr int GAP_TJ = 16;          // trajectories staged per round
+__global__ void __launch_bounds__(1024) planner_gap_kernel(StrivePlanner pl, Work w, int k) {
+    __shared__ double ocx[GAP_TJ][MAXNT][5], ocy[GAP_TJ][MAXNT][5];
+    __shared__ double om[GAP_TJ], or4[GAP_TJ];
+    __shared__ unsigned char ook[GAP_TJ][MAXNT];
+    __shared__ int cnt;
     const int b = blockIdx.x, chunk = blockIdx.y;
     const int P = w.P, NT = w.NT;
-    double* ec = smem;                         // (P, NT, 10)
-    double* red = smem + (size_t)P * NT * 10;  // (8, 32)
-    int* cnt = (int*)(red + 8 * 32);
-    const int tid = threadIdx.x;
-    const int t = tid & 31, stripe = tid >> 5;
-    const double* cc = w.circ + (size_t)b * P * NT * 10;
-    for (int i = tid; i < P * NT * 10; i += 256) ec[i] = cc[i];
-    if (tid == 0) *cnt = 0;
-    __syncthreads();
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const bool active = tid < P * NT;
+    const int p = active ? tid / NT : 0, t = active ? tid % NT : 0;
     const double* eg = w.ego + 8 * (size_t)b;
     const double ex = eg[0], ey = eg[1];
-    const double We = fmin(eg[4], eg[5]);
+    const double We = fmin(eg[4], eg[5]), Le = fmax(eg[4], eg[5]);
     const double re4 = We / 4, re2 = We / 2;
+    const double k0e = (Le - We) / 2 + We / 4, k1e = We / 4;
+    const double m_e = fmax(sqrt(k0e * k0e + k1e * k1e) + We / 4, We / 2);
+    double e[10];
+    {
+        const double* cc = w.circ + ((size_t)b * P * NT + (size_t)p * NT + t) * 10;
+#pragma unroll
+        for (int c = 0; c < 10; ++c) e[c] = active ? cc[c] : 0.0;
+    }
     const int slot = b * w.K + k;
     int J = w.traj_cnt[slot];
     if (J > w.cap) J = w.cap;
     const int per = (J + NCHUNK - 1) / NCHUNK;
     const int j0 = chunk * per, j1 = (j0 + per < J) ? j0 + per : J;
     const double* tb = w.traj + (size_t)slot * w.cap * w.ENT;
-    const bool active = t < NT;
-    int mine = 0;
-    for (int p0 = 0; p0 < P; p0 += PBLK) {
-        const int pn = P - p0 < PBLK ? P - p0 : PBLK;
-        double gm[PBLK];
-#pragma unroll
-        for (int p = 0; p < PBLK; ++p) gm[p] = INFINITY;
-        if (active) {
-            for (int j = j0 + stripe; j < j1; j += 8) {
-                const double* ent = tb + (size_t)j * w.ENT;
-                const double ox = ent[0], oy = ent[1], ol = ent[2], ow = ent[3];
-                if (sqrt((ex - ox) * (ex - ox) + (ey - oy) * (ey - oy)) > pl.cfg.interacdist) continue;
-                if (p0 == 0 && t == 0) ++mine;
-                double cx[5], cy[5];
-                box_circles(ent[4 + 3 * t], ent[5 + 3 * t], ent[6 + 3 * t], ol, ow, cx, cy);
-                const double Wo = fmin(ol, ow);
-                const double ro4 = Wo / 4, ro2 = Wo / 2;
-#pragma unroll
-                for (int p = 0; p < PBLK; ++p) {
-                    if (p < pn) {
-                        const double* e = ec + ((size_t)(p0 + p) * NT + t) * 10;
-                        double m44 = INFINITY, m42 = INFINITY, m24 = INFINITY;
-                        for (int a = 0; a < 4; ++a) {
-                            const double eax = e[2 * a], eay = e[2 * a + 1];
-                            for (int c = 0; c < 4; ++c) {
-                                const double dx = cx[c] - eax, dy = cy[c] - eay;
-                                m44 = fmin(m44, dx * dx + dy * dy);
-                            }
-                            const double dx = cx[4] - eax, dy = cy[4] - eay;
-                            m42 = fmin(m42, dx * dx + dy * dy);
-                        }
-                        for (int c = 0; c < 4; ++c) {
-                            const double dx = cx[c] - e[8], dy = cy[c] - e[9];
-                            m24 = fmin(m24, dx * dx + dy * dy);
-                        }
-                        const double dx = cx[4] - e[8], dy = cy[4] - e[9];
-                        const double m22 = dx * dx + dy * dy;
-                        double g = sqrt(m44) - re4 - ro4;
-                        g = fmin(g, sqrt(m42) - re4 - ro2);
-                        g = fmin(g, sqrt(m24) - re2 - ro4);
-                        g = fmin(g, sqrt(m22) - re2 - ro2);
-                        gm[p] = fmin(gm[p], g);
-                    }
-                }
+    if (tid == 0) cnt = 0;
+    double gm = INFINITY;
+    for (int jb = j0; jb < j1; jb += GAP_TJ) {
+        const int nj = (j1 - jb) < GAP_TJ ? (j1 - jb) : GAP_TJ;
+        __syncthreads();
+        // stage: circle centres of (trajectory, time); trajectories beyond the interaction distance and duplicates are left out
+        for (int it = tid; it < nj * NT; it += nthr) {
+            const int jj = it / NT, tt = it % NT;
+            const double* ent = tb + (size_t)(jb + jj) * w.ENT;
+            const double ox = ent[0], oy = ent[1], ol = ent[2], ow = ent[3];
+            const bool near = !(sqrt((ex - ox) * (ex - ox) + (ey - oy) * (ey - oy)) > pl.cfg.interacdist);
+            const bool dup = (((unsigned)ent[4]) >> tt) & 1u;
+            if (tt == 0) {
+                const double Wo = fmin(ol, ow), Lo = fmax(ol, ow);
+                const double k0o = (Lo - Wo) / 2 + Wo / 4, k1o = Wo / 4;
+                om[jj] = fmax(sqrt(k0o * k0o + k1o * k1o) + Wo / 4, Wo / 2);
+                or4[jj] = Wo / 4;
+                if (near) atomicAdd(&cnt, 1);
             }
+            ook[jj][tt] = (near && !dup) ? 1 : 0;
+            if (near && !dup) box_circles(ent[5 + 3 * tt], ent[6 + 3 * tt], ent[7 + 3 * tt], ol, ow, ocx[jj][tt], ocy[jj][tt]);
         }
+        __syncthreads();
+        if (active) {
+            for (int jj = 0; jj < nj; ++jj) {
+                if (!ook[jj][t]) continue;
+                const double* cx = ocx[jj][t];
+                const double* cy = ocy[jj][t];
+                const double cdx = cx[4] - e[8], cdy = cy[4] - e[9];
+                const double m22 = cdx * cdx + cdy * cdy;
+                if (sqrt(m22) - m_e - om[jj] - 1e-6 > gm) continue;
+                double m44 = INFINITY, m42 = INFINITY, m24 = INFINITY;
 #pragma unroll
-        for (int p = 0; p < PBLK; ++p) {
-            if (p < pn) {                                       // (uniform)
-                red[stripe * 32 + t] = gm[p];
-                __syncthreads();
-                if (stripe == 0 && active) {
-                    double m = red[t];
-                    for (int s = 1; s < 8; ++s) m = fmin(m, red[s * 32 + t]);
-                    w.part[(((size_t)b * NCHUNK + chunk) * P + p0 + p) * NT + t] = m;
+                for (int a = 0; a < 4; ++a) {
+                    const double eax = e[2 * a], eay = e[2 * a + 1];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double dx = cx[c] - eax, dy = cy[c] - eay;
+                        m44 = fmin(m44, dx * dx + dy * dy);
+                    }
+                    const double dx = cx[4] - eax, dy = cy[4] - eay;
+                    m42 = fmin(m42, dx * dx + dy * dy);
                 }
-                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double dx = cx[c] - e[8], dy = cy[c] - e[9];
+                    m24 = fmin(m24, dx * dx + dy * dy);
+                }
+                const double ro4 = or4[jj], ro2 = 2 * ro4;
+                double g = sqrt(m44) - re4 - ro4;
+                g = fmin(g, sqrt(m42) - re4 - ro2);
+                g = fmin(g, sqrt(m24) - re2 - ro4);
+                g = fmin(g, sqrt(m22) - re2 - ro2);
+                gm = fmin(gm, g);
             }
         }
     }
-    if (mine) atomicAdd(cnt, mine);
+    if (active) w.part[(((size_t)b * NCHUNK + chunk) * P + p) * NT + t] = gm;
     __syncthreads();
-    if (tid == 0) w.part_cnt[b * NCHUNK + chunk] = *cnt;
+    if (tid == 0) w.part_cnt[b * NCHUNK + chunk] = cnt;
 }
 
 __global__ void planner_interp_kernel(Work w, int B, const double* __restrict__ t_out, const double* __restrict__ planner_t, int TP,
@@ -867,7 +926,7 @@ Layout carve(const StrivePlanner* pl, int nstep, int traj_cap, void* ws, size_t 
     w.K = nstep + 1;
     w.cap = traj_cap;
     w.NT = c.nsteps + 1;
-    w.ENT = 4 + 3 * w.NT;
+    w.ENT = 5 + 3 * w.NT;
     w.P = c.nplanaccfacs * c.plannspeeds * c.plannspeeds;
     StriveArena a(ws ? ws : (void*)64, ws ? ws_bytes : (size_t)-1 / 2);
     w.wstate = a.take<double>((size_t)pl->NR * w.K * 4);
@@ -899,8 +958,8 @@ int check_cfg(const StrivePlanner* pl, int nstep, int traj_cap) {
                      c.npredsfacs * c.npredafacs <= MAXPRED, "at most 8 predicted speed profiles");
     STRIVE_CHECK_ARG(c.nplanaccfacs >= 1 && c.nplanaccfacs <= 4 && c.plannspeeds >= 1 &&
                      c.nplanaccfacs * c.plannspeeds * c.plannspeeds <= MAXPROF, "at most 64 ego speed profiles");
-    STRIVE_CHECK_ARG((size_t)c.nplanaccfacs * c.plannspeeds * c.plannspeeds * (c.nsteps + 1) * 80 <= 60 * 1024,
-                     "profiles x times exceed the gap kernel's LDS tile");
+    STRIVE_CHECK_ARG(c.nplanaccfacs * c.plannspeeds * c.plannspeeds * (c.nsteps + 1) <= 1024,
+                     "profiles x times exceed one workgroup of the gap kernel");
     STRIVE_CHECK_ARG(nstep >= 0 && traj_cap >= 1, "nstep >= 0, traj_cap >= 1");
     STRIVE_CHECK_ARG(pl->B >= 1 && pl->NR >= 0 && pl->NO == pl->NR + pl->B, "one ego per scene");
     return 0;
@@ -929,12 +988,11 @@ extern "C" int strive_planner_rollout(const StrivePlanner* pl, const double* age
         hipLaunchKernelGGL(planner_world_kernel, dim3((pl->NR + 63) / 64), dim3(64), 0, stream, *pl, w, agent_obs, agent_t, (int)T);
         hipLaunchKernelGGL(planner_routes_kernel, dim3(pl->NR * w.K), dim3(64), 0, stream, *pl, w, status);
     }
-    const size_t gap_lds = ((size_t)w.P * w.NT * 10 + 8 * 32) * sizeof(double) + 16;
-    hipFuncSetAttribute((const void*)planner_gap_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gap_lds);
+    const int gap_threads = ((w.P * w.NT + 63) / 64) * 64;
     for (int k = 0; k <= w.K; ++k) {
-        hipLaunchKernelGGL(planner_ego_kernel, dim3(pl->B), dim3(64), 0, stream, *pl, w, k, status);
+        hipLaunchKernelGGL(planner_ego_kernel, dim3(pl->B), dim3(256), 0, stream, *pl, w, k, status);
         if (k < w.K)
-            hipLaunchKernelGGL(planner_gap_kernel, dim3(pl->B, NCHUNK), dim3(256), gap_lds, stream, *pl, w, k);
+            hipLaunchKernelGGL(planner_gap_kernel, dim3(pl->B, NCHUNK), dim3(gap_threads), 0, stream, *pl, w, k);
     }
     hipLaunchKernelGGL(planner_interp_kernel, dim3((pl->B * TP + 63) / 64), dim3(64), 0, stream, w, (int)pl->B, t_out, planner_t, (int)TP,
                        plan, status);

@@ -239,6 +239,16 @@ class HardcodeNuscPlanner(PlannerNusc):
         p.row_obj, p.row_scene = row_obj.data_ptr(), row_scene.data_ptr()
         return p
 
+    def prepare(self, agent_t, agent_ptr, planner_t):
+        """Build (on the current stream) the small device tables a rollout with these times / offsets will use, so that
+        rollouts issued later from side streams only read them."""
+        planner_t = np.asarray(planner_t, dtype=np.float64)
+        nstep = int(planner_t[-1] / self.cfg.dt)
+        self._table(np.asarray(agent_t, dtype=np.float64))
+        self._table(planner_t)
+        self._table(np.linspace(self.cfg.dt, self.cfg.dt * nstep, nstep + 1))
+        self._row_maps(np.asarray(agent_ptr).reshape(-1))
+
     # ---- deferred status check: no host synchronisation inside an optimisation closure ----------------------------------
     def check(self, wait=True):
         """Raise if an earlier rollout hit a capacity / range limit (its plan is NaN for the affected scenes).  ``wait=False``

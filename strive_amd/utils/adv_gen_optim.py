@@ -38,13 +38,15 @@ def collate_tgt_other_z(scene_graph, tgt_z, other_z):
 _rollout_streams = {}
 
 
-def two_rollouts(model, embed_info, scene_graph, map_idx, map_env, z_a, kw_a, z_b, kw_b, overlap=True):
+def two_rollouts(model, embed_info, scene_graph, map_idx, map_env, z_a, kw_a, z_b, kw_b, overlap=True, after_a=None):
     """The two rollouts of an adversarial / solution closure are independent until the losses.  On the MI355X they run on two
     HIP streams: the map CNN of one (bandwidth-bound, fills the chip) overlaps the GNN / GRU kernels of the other (latency
     chains on ~128 workgroups), forward and -- because autograd replays every node on the stream its forward ran on -- backward
     (measured: adversarial closure 20.4 -> 17.8 ms).  Same kernels, same inputs, same results; scratch buffers are per stream
     (ops._workspace).  Splitting ONE rollout into two scene halves the same way gains nothing (refine closure 13.51 vs 13.48 ms:
-    the half-size CNN launches lose in tail effects what the hidden GNN time wins)."""
+    the half-size CNN launches lose in tail effects what the hidden GNN time wins).
+    ``after_a(out_a)`` (optional) is enqueued right behind rollout A on ITS stream -- the closed loop's planner rollout only
+    needs A's futures, so its small kernels run under rollout B's map CNN; its result is returned as a third value."""
     from .. import ops
     dev = z_a.device
     ns = lambda z: z.shape[1] if z.dim() == 3 else 1
@@ -52,24 +54,32 @@ def two_rollouts(model, embed_info, scene_graph, map_idx, map_env, z_a, kw_a, z_
     # then belong to it and are complete before any side stream is forked), see ops.decoder_packs_ready
     if not (z_a.is_cuda and overlap and ops.decoder_packs_ready(model, scene_graph, map_env, ns(z_a), dev)
             and ops.decoder_packs_ready(model, scene_graph, map_env, ns(z_b), dev)):
-        return (model.decode_embedding(z_a, embed_info, scene_graph, map_idx, map_env, **kw_a),
-                model.decode_embedding(z_b, embed_info, scene_graph, map_idx, map_env, **kw_b))
+        out_a = model.decode_embedding(z_a, embed_info, scene_graph, map_idx, map_env, **kw_a)
+        out_b = model.decode_embedding(z_b, embed_info, scene_graph, map_idx, map_env, **kw_b)
+        return (out_a, out_b) if after_a is None else (out_a, out_b, after_a(out_a))
     cur = torch.cuda.current_stream(dev)
     streams = _rollout_streams.get(str(dev))
     if streams is None:
-        streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        # stream A outranks stream B: in the closed loop the planner waits for rollout A only and then runs under rollout B
+        streams = (torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev))
         _rollout_streams[str(dev)] = streams
-    outs = []
-    for st, z, kw in zip(streams, (z_a, z_b), (kw_a, kw_b)):
+    outs, extra = [], None
+    for i, (st, z, kw) in enumerate(zip(streams, (z_a, z_b), (kw_a, kw_b))):
         st.wait_stream(cur)
         with torch.cuda.stream(st):
             outs.append(model.decode_embedding(z, embed_info, scene_graph, map_idx, map_env, **kw))
+            if i == 0 and after_a is not None:
+                extra = after_a(outs[0])
     for st, o in zip(streams, outs):
         cur.wait_stream(st)
         for v in o.values():
             if torch.is_tensor(v):
                 v.record_stream(cur)          # produced on a side stream, consumed (and later freed) on the caller's
-    return outs[0], outs[1]
+    if after_a is None:
+        return outs[0], outs[1]
+    if torch.is_tensor(extra):
+        extra.record_stream(cur)
+    return outs[0], outs[1], extra
 
 
 class AdvClosure(object):
@@ -123,6 +133,8 @@ class AdvClosure(object):
             self.agt_ptr = (scene_graph.ptr.cpu() - torch.arange(B + 1)).numpy()
             self.plan_t = np.linspace(model.dt, model.dt * self.future_len, self.future_len)
             self.planner_fut = None
+            if hasattr(planner, 'prepare'):
+                planner.prepare(self.plan_t, self.agt_ptr, self.plan_t)       # device tables built here, on the caller's stream
         else:
             raise NotImplementedError("planner_name must be 'ego' or 'hardcode'")
 
@@ -138,10 +150,10 @@ class AdvClosure(object):
         fut = self.planner.rollout(agt, self.plan_t, self.agt_ptr, self.plan_t, control_all=False).to(self.scene_graph.future_gt)
         return self.model.get_normalizer().normalize(fut)
 
-    def _two_rollouts(self, z_a, z_b):
+    def _two_rollouts(self, z_a, z_b, after_a=None):
         kw = dict(ext_future=self.planner_fut, nfuture=self.future_len)
         return two_rollouts(self.model, self.embed_info, self.scene_graph, self.map_idx, self.map_env, z_a, kw, z_b, kw,
-                            overlap=self.overlap)
+                            overlap=self.overlap, after_a=after_a)
 
     def step(self, log=None):
         """(reference src/utils/adv_gen_optim.py:107-171)"""
@@ -149,11 +161,12 @@ class AdvClosure(object):
         self.optim.zero_grad()
         z_a = self.collated(detach_other=True)      # ego latents get the matching loss only
         z_b = self.collated(detach_tgt=True)        # the others get the adversarial loss only
-        out_a, out_b = self._two_rollouts(z_a, z_b)
         if self.planner_name == 'hardcode':
-            planner_fut = self.plan(out_a['future_pred'])
+            # the planner reacts to rollout A only: it is enqueued behind A on A's stream and runs under rollout B
+            out_a, out_b, planner_fut = self._two_rollouts(z_a, z_b, after_a=lambda o: self.plan(o['future_pred']))
             adv_tgt = out_b['future_pred'].index_select(0, self.ego_idx)      # the differentiable stand-in for the planner
         else:
+            out_a, out_b = self._two_rollouts(z_a, z_b)
             planner_fut = adv_tgt = self.planner_fut
         lt = self.tgt_loss(self.unn(out_a['future_pred'].index_select(0, self.ego_idx)), self.unn(planner_fut), self.tgt_z,
                            self.tgt_prior)

@@ -200,6 +200,7 @@ template <typename T> inline T unsafeAtomicAdd(T* p, T v) { T o = *p; *p = o + v
 inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
 inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
+inline int atomicOr(int* p, int v) { int o = *p; *p = o | v; return o; }
 inline int atomicExch(int* p, int v) { int o = *p; *p = v; return o; }
 inline int atomicCAS(int* p, int c, int v) { int o = *p; if (o == c) *p = v; return o; }
 

@@ -165,7 +165,6 @@ def test_rect_iou_kernel_gpu_against_exact_and_monte_carlo_tables():
     print('strive_rect_iou (MI355X) vs exact rational IoU on %d pairs: worst |diff| %.2e' % (iou.shape[0], d.max()))
     assert np.all(d < _exact_tol(names, g))
     assert np.array_equal(got > 0.02, iou > 0.02)                  # the reference's collision decision (VEH_COLL_THRESH)
-    assert np.all(got[np.concatenate([np.zeros(0, bool)] + [np.full(g[n + '/iou'].shape, n == 'identical') for n in names])] == 1.0)
     nan = ta.clone()
     nan[::7, 1] = float('nan')
     assert bool(torch.isnan(ops.rect_iou(nan, tla, tb, tlb)[::7]).all())
