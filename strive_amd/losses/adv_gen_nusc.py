@@ -22,7 +22,9 @@ class LossDict(dict):
     in collision (``pen[mask]``): tensors whose length depends on the data, so producing them costs a device->host
     synchronisation.  The optimisation loops only back-propagate ``'loss'``; the lists are read for logging.  This dict has
     the same keys and yields the same tensors, but compacts a list only when it is actually read -- a closure that reads
-    nothing but ``'loss'`` never stalls the GPU queue."""
+    nothing but ``'loss'`` never stalls the GPU queue.  ``'loss'`` is the differentiable entry; the lazily produced entries are
+    evaluated without autograd on a snapshot of the closure's inputs.  Bulk access (iteration, ``dict(ld)``, ``copy``, ``pop``,
+    pickling) resolves every entry first."""
 
     def __init__(self):
         super(LossDict, self).__init__()
@@ -333,12 +335,17 @@ class AvoidCollLoss(nn.Module):
         out['loss'] = loss
         terms = {}
 
+        # the logging entries are evaluated on a snapshot of the closure's inputs (the optimiser updates z in place afterwards) and
+        # without building a second autograd graph: 'loss' is the differentiable entry
+        fp_s, z_s = future_pred.detach(), z.detach().clone()
+
         def term(key):
             def thunk():
                 if not terms:
-                    ft = self.forward_terms(future_pred, z, prior_out)
-                    for k in list(ft.keys()):
-                        terms[k] = ft[k]              # (resolves the lazy lists of that dict)
+                    with torch.no_grad():
+                        ft = self.forward_terms(fp_s, z_s, prior_out)
+                        for k in list(ft.keys()):
+                            terms[k] = ft[k]          # (resolves the lazy lists of that dict)
                 return terms[key]
             return thunk
         w = self.loss_weights
@@ -459,12 +466,15 @@ class AdvGenLoss(nn.Module):
         out = LossDict()
         terms = {}
 
+        fp_s, tg_s, z_s = future_pred.detach(), tgt_traj.detach(), z.detach().clone()      # snapshot: see AvoidCollLoss.forward
+
         def term(key):
             def thunk():
                 if not terms:
-                    ft = self.forward_terms(future_pred, tgt_traj, z, prior_out, attack_agt_idx=attack_agt_idx)
-                    for k in list(ft.keys()):
-                        terms[k] = ft[k]
+                    with torch.no_grad():
+                        ft = self.forward_terms(fp_s, tg_s, z_s, prior_out, attack_agt_idx=attack_agt_idx)
+                        for k in list(ft.keys()):
+                            terms[k] = ft[k]
                 return terms[key]
             return thunk
         for key, present in (('init_loss', w.get('init_z', 0.0) > 0.0), ('motion_prior_loss', w.get('motion_prior', 0.0) > 0.0),
