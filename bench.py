@@ -18,6 +18,12 @@ step.  Workloads (``--workload``):
   sharded4096  (configs[4]) ONE batch of ~4096 agents with NC = 5 classes (reduce_cats), split over the ranks by
                strive_amd.distributed.shard_scenes; every rank runs the adversarial closure on its scenes.  The job is
                fixed, so this is strong scaling.
+  full         (configs[2] end to end) the whole per-batch sequence of adv_scenario_gen.py:262-462 with the iteration counts of
+               adv_gen_rule_based.cfg on ~512 agents on a synthetic lane graph: embed -> init optimisation (75 iterations, lr 0.1)
+               -> planner rollout + init optimisation towards it (100) -> scenes whose planner already collides are dropped ->
+               closed-loop adversarial optimisation (200, planner 'hardcode') -> success tests (rotated-box IoU kernel) ->
+               solution optimisation of the succeeded scenes (200) -> success tests.  One "step" = one batch through all of it;
+               agent*timesteps = rollouts x agents x steps actually decoded.  --iters scales the four iteration counts.
   sample       the feasibility pre-pass of adv_scenario_gen.py:160-174: TrafficModel.sample_batched(NS = 20, include_mean = True)
                under no_grad on 32 scenes x 16 agents: embed (map crop + CNN, past encoder, prior network) + ONE joint rollout
                of NA x 20 sample rows (forward only); advances NA*20*FT agent*timesteps.  Weak scaling.
@@ -108,6 +114,10 @@ def workload_scenes(args, rank, world):
         own = [(args.agents, 'bench/r%d/%d' % (rank, b)) for b in range(args.scenes)]
         return own, '%d scenes x %d agents per GPU' % (args.scenes, args.agents), 'weak'
     if args.workload == 'adv':
+        sizes = variable_scene_sizes(args.total_agents or 512, 'bench/adv/r%d' % rank)
+        own = [(n, 'bench/adv/r%d/%d' % (rank, b)) for b, n in enumerate(sizes)]
+        return own, '%d agents per GPU in %d scenes of 2..30' % (sum(sizes), len(sizes)), 'weak'
+    if args.workload == 'full':
         sizes = variable_scene_sizes(args.total_agents or 512, 'bench/adv/r%d' % rank)
         own = [(n, 'bench/adv/r%d/%d' % (rank, b)) for b, n in enumerate(sizes)]
         return own, '%d agents per GPU in %d scenes of 2..30' % (sum(sizes), len(sizes)), 'weak'
@@ -219,6 +229,125 @@ def adv_closure_factory(m, env, batch, map_idx, FT, device):
                    (pm[~ego], pv[~ego]), 2, 0.0, planner_fut=g.future_gt[ego][:, :FT, :4].contiguous(), future_len=FT,
                    veh_coll_buffer=0.1)
     return (lambda: c.step()), emb, g, mi, 2
+
+
+def full_pipeline_factory(m, env, batch, map_idx, FT, device, scale=1.0):
+    """One scene batch through the reference's whole optimisation sequence (src/adv_scenario_gen.py:262-462, planner 'hardcode',
+    configs/adv_gen_rule_based.cfg: num_iters 200, lr 0.05, sol_future_len 16, feasibility_time 2 (default), infront_min 0)."""
+    import numpy as np
+    from strive_amd.graph import Batch
+    from strive_amd.utils.init_optim import run_init_optim
+    from strive_amd.utils.adv_gen_optim import run_adv_gen_optim, compute_adv_gen_success
+    from strive_amd.utils.sol_optim import run_find_solution_optim, compute_sol_success
+    from strive_amd.utils.scenario_gen import detach_embed_info
+    from strive_amd.losses.adv_gen_nusc import check_single_veh_coll
+    from strive_amd.losses.traffic_model import compute_coll_rate_env
+    from strive_amd.planners.planner import PlannerConfig
+    from strive_amd.planners.hardcode_goalcond_nusc import HardcodeNuscPlanner, CONFIG_DICT
+    n_init, n_fit, n_adv, n_sol = [max(1, int(round(v * scale))) for v in (75, 100, 200, 200)]
+    weights = dict(ADV_WEIGHTS)
+    weights.update({'init_motion_prior_ext': 0.01, 'init_match_ext': 10.0, 'sol_motion_prior': 0.005, 'sol_coll_veh': 10.0,
+                    'sol_coll_env': 10.0, 'sol_motion_prior_ext': 0.001, 'sol_match_ext': 10.0, 'sol_init_z': 0.0})
+    lr, sol_future_len = 0.05, 16
+    stats = {}
+
+    def step():
+        g = batch.clone().to(device)
+        mi = map_idx.to(device)
+        nrm, att = m.get_normalizer(), m.get_att_normalizer()
+        B, NA = int(mi.shape[0]), int(g.past.shape[0])
+        ego = torch.zeros((NA,), dtype=torch.bool, device=device)
+        ego[g.ptr[:-1].to(device)] = True
+        units = 0
+        with torch.no_grad():
+            emb_att = m.embed(g, mi, env)
+        emb = detach_embed_info(emb_att)
+        z = emb_att['posterior_out'][0].detach()
+        init_traj = g.future_gt[:, :, :4].clone().detach()
+        z, fit, _ = run_init_optim(z, init_traj, g.future_vis, 0.1, weights, m, g, env, mi, n_init, emb, emb['prior_out'])
+        units += (n_init + 1) * NA * m.FT
+        planner = HardcodeNuscPlanner(env, PlannerConfig(**CONFIG_DICT['default']))
+        planner.reset(nrm.unnormalize(g.past_gt[:, -1, :]), att.unnormalize(g.lw), g.batch, B, mi)
+        plan_t = np.linspace(m.dt, m.dt * m.FT, m.FT)
+        agt_ptr = (g.ptr.cpu() - torch.arange(B + 1)).numpy()
+        plan0 = planner.rollout(nrm.unnormalize(fit[~ego]).contiguous(), plan_t, agt_ptr, plan_t).to(g.future_gt)
+        planner.check()
+        init_traj[ego] = nrm.normalize(plan0)
+        z, fit, _ = run_init_optim(z, init_traj, g.future_vis, lr, weights, m, g, env, mi, n_fit, emb, emb['prior_out'])
+        units += (n_fit + 1) * NA * m.FT
+        ptr = g.ptr.cpu().tolist()
+        bvalid = []
+        for b in range(B):
+            coll, _ = check_single_veh_coll(nrm.unnormalize(fit[ptr[b]]), att.unnormalize(g.lw[ptr[b]]),
+                                            nrm.unnormalize(fit[ptr[b] + 1:ptr[b + 1]]), att.unnormalize(g.lw[ptr[b] + 1:ptr[b + 1]]))
+            bvalid.append(int(np.sum(coll)) == 0)
+        stats['scenes'], stats['planner_collides_after_init'] = B, B - sum(bvalid)
+        if sum(bvalid) == 0:
+            raise RuntimeError('the planner collides in every scene of the synthetic batch after the init optimisation')
+        if sum(bvalid) < B:                     # rebuild the batch without those scenes (reference :330-360)
+            keep = torch.tensor(bvalid)
+            avalid = torch.zeros((NA,), dtype=torch.bool)
+            for b in range(B):
+                if bvalid[b]:
+                    avalid[ptr[b]:ptr[b + 1]] = True
+            dl = g.to_data_list()
+            g = Batch.from_data_list([d for b, d in enumerate(dl) if bvalid[b]]).to(device)
+            mi = mi[keep.to(device)]
+            z, init_traj = z[avalid.to(device)], init_traj[avalid.to(device)]
+            B, NA = int(mi.shape[0]), int(g.past.shape[0])
+            ego = torch.zeros((NA,), dtype=torch.bool, device=device)
+            ego[g.ptr[:-1].to(device)] = True
+            with torch.no_grad():
+                emb_att = m.embed(g, mi, env)
+            emb = detach_embed_info(emb_att)
+            ptr = g.ptr.cpu().tolist()
+        with torch.no_grad():
+            init_pred = m.decode_embedding(z, emb_att, g, mi, env)['future_pred'].detach()
+            compute_coll_rate_env(g, mi, init_pred.unsqueeze(1).contiguous(), env, nrm, att, ego_only=False)
+        pm, pv = emb['prior_out']
+        tp, op = (pm[ego], pv[ego]), (pm[~ego], pv[~ego])
+        planner = HardcodeNuscPlanner(env, PlannerConfig(**CONFIG_DICT['default']))
+        cur_z, fin, _, agt, tt = run_adv_gen_optim(z.clone().detach(), lr, weights, m, g, env, mi, n_adv, emb, 'hardcode', tp, op, 2, 0.0,
+                                                   planner=planner)
+        units += (2 * n_adv + 1) * NA * m.FT
+        dl = g.to_data_list()
+        ok = [compute_adv_gen_success(fin[ptr[b]:ptr[b + 1]], m, Batch.from_data_list([dl[b]]), int(agt[b]) - ptr[b]) for b in range(B)]
+        stats['adv_succeeded'] = int(sum(ok))
+        stats['sol_forced'] = False
+        if sum(ok) == 0:
+            # random-initialised weights rarely yield a successful attack; so that the run still goes through the solution stage
+            # (the reference only enters it for succeeded scenes) the first quarter of the scenes is sent there, and reported
+            ok = [b < max(1, B // 4) for b in range(B)]
+            stats['sol_forced'] = True
+        stats['sol_scenes'] = int(sum(ok))
+        sol_ok = 0
+        if sum(ok) > 0:
+            sg = Batch.from_data_list([dl[b] for b in range(B) if ok[b]])
+            am = torch.zeros((NA,), dtype=torch.bool, device=device)
+            bm = torch.tensor(ok, device=device)
+            for b in range(B):
+                if ok[b]:
+                    am[ptr[b]:ptr[b + 1]] = True
+            sNA = int(am.sum())
+            sego = torch.zeros((sNA,), dtype=torch.bool, device=device)
+            sego[sg.ptr[:-1].to(device)] = True
+            semb = {k: (v[am] if torch.is_tensor(v) else (v[0][am], v[1][am])) for k, v in emb.items()}
+            stp = (tp[0][bm], tp[1][bm])
+            sop = (semb['prior_out'][0][~sego], semb['prior_out'][1][~sego])
+            _, sol_traj, _ = run_find_solution_optim(cur_z.clone().detach()[am], fin[am], sol_future_len, lr, weights, m, sg, env, mi[bm],
+                                                     n_sol, semb, stp, sop)
+            units += n_sol * sNA * (sol_future_len + m.FT) + sNA * m.FT
+            sdl = sg.to_data_list()
+            sptr = sg.ptr.cpu().tolist()
+            smi = mi[bm]
+            for b in range(len(sdl)):
+                sol_ok += bool(compute_sol_success(sol_traj[sptr[b]:sptr[b + 1]][:, 0:1], m, Batch.from_data_list([sdl[b]]),
+                                                   env, smi[b:b + 1]))
+        stats['sol_succeeded'] = int(sol_ok)
+        stats['units'] = units
+        return torch.tensor(float(stats['adv_succeeded']))
+    step.stats = stats
+    return step, None, batch.to(device), map_idx.to(device), 2
 
 
 def sample_step_factory(m, env, batch, map_idx, FT, device, NS=20):
@@ -536,7 +665,7 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', choices=['refine', 'adv', 'sharded4096', 'train', 'sample'], default='refine')
+    ap.add_argument('--workload', choices=['refine', 'adv', 'sharded4096', 'train', 'sample', 'full'], default='refine')
     ap.add_argument('--scenes', type=int, default=32)
     ap.add_argument('--agents', type=int, default=16)
     ap.add_argument('--total-agents', type=int, default=0, help='adv / sharded4096: agents in the batch (default 512 / 4096)')
@@ -546,6 +675,7 @@ def parse_args(argv=None):
     ap.add_argument('--planner', choices=['ego', 'hardcode'], default='ego',
                     help="adv: 'ego' = open loop against the recorded ego future, 'hardcode' = closed loop against the rule-based "
                          "planner (adv_gen_rule_based.cfg)")
+    ap.add_argument('--iters', type=float, default=1.0, help='full: scale of the iteration counts 75 / 100 / 200 / 200')
     ap.add_argument('--raster', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-full', action='store_true', help='time the CPU oracle on C2 itself (32 x 16 agents; ~10 minutes)')
@@ -594,15 +724,20 @@ def main():
     own, desc, scaling = workload_scenes(args, rank, world)
     m = build_model(device, args.nc)
     lane_graph = None
+    if args.workload == 'full':
+        args.planner = 'hardcode'
     if args.planner == 'hardcode':
-        if args.workload != 'adv':
-            raise SystemExit("bench.py: --planner hardcode belongs to --workload adv")
+        if args.workload not in ('adv', 'full'):
+            raise SystemExit("bench.py: --planner hardcode belongs to --workload adv / full")
         from strive_amd import synth
         lane_graph = synth.make_lane_graph(extent=args.raster * 0.25)
     env = build_env(args.raster, device, lane_graph)
     batch, map_idx = build_batch(own, args.nc, args.raster, lane_graph=lane_graph)
     factory = {'refine': refine_closure_factory, 'train': train_step_factory, 'sample': sample_step_factory}.get(args.workload, adv_closure_factory)
-    step, emb, g, mi, rollouts = factory(m, env, batch, map_idx, args.ft, device)
+    if args.workload == 'full':
+        step, emb, g, mi, rollouts = full_pipeline_factory(m, env, batch, map_idx, args.ft, device, scale=args.iters)
+    else:
+        step, emb, g, mi, rollouts = factory(m, env, batch, map_idx, args.ft, device)
     for _ in range(args.warmup):
         step()
 
@@ -618,12 +753,14 @@ def main():
     barrier()
     dt_local = time.perf_counter() - t0
     planner_ms = None
-    if getattr(step, 'planner', None) is not None:
+    if getattr(step, 'planner', None) is not None and args.workload != 'full':
         step.planner.check()               # capacity / range status of every planner rollout of the run (raises)
         planner_ms = time_planner(step, device)
     dt = dt_local
     NA = int(g.past.shape[0])
     units_local = rollouts * NA * args.ft * args.steps
+    if args.workload == 'full':
+        units_local = step.stats['units'] * args.steps
     units = units_local
     props = torch.cuda.get_device_properties(device)
     dev_id = str(getattr(props, 'uuid', '')) or '%s/pci%s' % (props.name, getattr(props, 'pci_bus_id', local))
@@ -648,12 +785,16 @@ def main():
                'adv': closure_adv,
                'sharded4096': 'adversarial closure: 2 x decode_embedding(nfuture=%d, ext_future) + TgtMatchingLoss + '
                               'AdvGenLoss + backward + Adam',
+               'full': 'adv_scenario_gen.py:262-462 for one batch: embed, init optimisation 75 + 100 iterations around a planner rollout, '
+                       'closed-loop adversarial optimisation 200 iterations (planner hardcode, FT %d), IoU success tests, solution '
+                       'optimisation 200 iterations of the succeeded scenes',
                'sample': 'TrafficModel.sample_batched(NS=20, include_mean=True, nfuture=%d) under no_grad: embed + one joint '
                          'rollout of NA x 20 rows, forward only',
                'train': 'training step: TrafficModel.forward(future_sample=True) (2 rollouts of %d steps) + TrafficModelLoss + '
                         'backward to 174 parameter tensors + gradient all-reduce + Adam'}[args.workload] % args.ft
     cfg_ref = {'refine': 'BASELINE.json configs[1]', 'adv': 'BASELINE.json configs[2]', 'sharded4096': 'BASELINE.json configs[4]',
-               'train': 'BASELINE.json configs[3]', 'sample': 'SURVEY 8 a18: adv_scenario_gen.py:160-174'}
+               'train': 'BASELINE.json configs[3]', 'sample': 'SURVEY 8 a18: adv_scenario_gen.py:160-174',
+               'full': 'BASELINE.json configs[2], end to end'}
     out = {
         'metric': 'adv-optim agent*timesteps/sec (decoder fwd+bwd)',
         'value': round(units / dt, 1), 'unit': 'agent*timesteps/s', 'n_gpus': world, 'steps': args.steps,
@@ -667,6 +808,7 @@ def main():
                                  '(3 products per fp32 product, dropped terms <= 2^-24), fp32 accumulate'},
         'final_loss': float(loss.detach().cpu()),
         'planner': None if planner_ms is None else planner_ms,
+        'pipeline': dict(step.stats) if args.workload == 'full' else None,
         'per_rank': [{'rank': r, 'agents': a, 'ms_per_step': t, 'device': d, 'local_rank': lr} for r, a, t, d, lr in per_rank],
         # what the collective backend saw (N > 1: RCCL = torch.distributed 'nccl'): world size it reports and the distinct devices
         'rccl_world_size': dist.get_world_size() if use_dist else None,
@@ -675,7 +817,7 @@ def main():
     }
     failed = False
     if rank == 0:
-        if not args.no_roofline and args.workload not in ('train', 'sample'):
+        if not args.no_roofline and args.workload not in ('train', 'sample', 'full'):
             try:
                 out['roofline'] = time_dominant_kernel(m, env, g, mi, emb, device)
                 out['roofline']['bandwidth_kernels'].update(time_bandwidth_kernels(m, env, g, mi, device))
@@ -701,7 +843,7 @@ def main():
             except Exception as e:      # keep the headline number, but the run fails
                 out['roofline'] = {'error': repr(e)}
                 failed = True
-        if world == 1 and not args.no_cpu_baseline and args.workload not in ('train', 'sample'):
+        if world == 1 and not args.no_cpu_baseline and args.workload not in ('train', 'sample', 'full'):
             try:
                 out['cpu_baseline'] = cpu_baseline_record(args.ft, full=args.cpu_baseline_full)
             except Exception as e:
