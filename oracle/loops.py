@@ -54,6 +54,41 @@ def refine_loop(model, g, map_idx, map_env, embed_info, z_init, weights, num_ite
     return z.detach()
 
 
+def refine_fn(model, g, map_idx, map_env, weights, num_iters, samp_future_len, save_future_len, use_adam, lr, eps):
+    """The whole refine_traffic_optim() of the reference (src/refine_traffic_optim.py:146-226): one prior sample (``eps (1,NA,D)``
+    injected: the reference draws it unseeded), embed, then Adam -- one closure + one step per iteration -- or LBFGS(max_iter 20,
+    strong-Wolfe line search) -- ``step(closure)`` per iteration -- on the AvoidColl objective, and the final rollout.
+    Returns (init_future_pred, z, result_traj (NA,1,save_future_len,4))."""
+    with torch.no_grad():
+        samp = model.sample_batched(g, map_idx, map_env, eps, include_mean=False)
+        embed_info = model.embed(g, map_idx, map_env)
+    init_future_pred = samp['future_pred'][:, 0]
+    z = samp['z_samp'][:, 0].clone().detach()
+    z.requires_grad = True
+    if use_adam:
+        opt = torch.optim.Adam([z], lr=lr)
+    else:
+        opt = torch.optim.LBFGS([z], max_iter=20, lr=lr, line_search_fn='strong_wolfe')
+    loss_fn = AvoidColl(weights, model.get_att_normalizer().unnormalize(g.lw), map_idx[g.batch], map_env, z.clone().detach(),
+                        veh_coll_buffer=0.2)
+
+    def closure():
+        opt.zero_grad()
+        pred = model.decode_embedding(z, embed_info, g, map_idx, map_env, nfuture=samp_future_len)['future_pred']
+        ld = loss_fn(model.get_normalizer().unnormalize(pred), z, embed_info['prior_out'])
+        ld['loss'].backward()
+        return ld['loss']
+    for _ in range(num_iters):
+        if use_adam:
+            closure()
+            opt.step()
+        else:
+            opt.step(closure)
+    with torch.no_grad():
+        out = model.decode_embedding(z, embed_info, g, map_idx, map_env, nfuture=save_future_len)['future_pred']
+    return init_future_pred, z.detach(), out.unsqueeze(1).clone().detach()
+
+
 def init_loop(model, g, map_idx, map_env, embed_info, z_init, init_traj, traj_vis, weights, num_iters, lr,
               prior_out, trace=None):
     """Fit latents to observed futures.  (reference src/utils/init_optim.py:11-68)"""

@@ -1,4 +1,4 @@
-"""Collision-refinement optimisation (reference src/refine_traffic_optim.py:146-226, Adam branch).
+"""Collision-refinement optimisation (reference src/refine_traffic_optim.py:146-226, Adam and LBFGS branches).
 Same signature; ``z_init`` may be injected (the reference samples it unseeded from the prior)."""
 import torch
 import torch.optim as optim
@@ -9,8 +9,6 @@ from .utils.scenario_gen import detach_embed_info
 
 def refine_traffic_optim(scene_graph, map_idx, map_env, model, loss_weights, num_iters, samp_future_len,
                          save_future_len, optim_use_adam, lr, z_init=None, log=None):
-    if not optim_use_adam:
-        raise NotImplementedError('the LBFGS branch is not used by any shipped config')
     with torch.no_grad():
         if z_init is None:
             sample_pred = model.sample_batched(scene_graph, map_idx, map_env, 1, include_mean=False)
@@ -23,17 +21,26 @@ def refine_traffic_optim(scene_graph, map_idx, map_env, model, loss_weights, num
             init_future_pred = model.decode_embedding(z_init, embed_info, scene_graph, map_idx, map_env)['future_pred']
     cur_z = z_init.clone().detach()
     cur_z.requires_grad = True
-    scene_optim = optim.Adam([cur_z], lr=lr)
+    if optim_use_adam:
+        scene_optim = optim.Adam([cur_z], lr=lr)
+    else:       # --optim_use_lbfgs (reference :53-55, 170-173): 20 inner iterations with a strong-Wolfe line search per step
+        scene_optim = optim.LBFGS([cur_z], max_iter=20, lr=lr, line_search_fn='strong_wolfe')
     avoid_loss = AvoidCollLoss(loss_weights, model.get_att_normalizer().unnormalize(scene_graph.lw),
                                map_idx[scene_graph.batch], map_env, cur_z.clone().detach(), veh_coll_buffer=0.2)
-    for _ in range(num_iters):
+    def closure():
         scene_optim.zero_grad()
         pred = model.decode_embedding(cur_z, embed_info, scene_graph, map_idx, map_env, nfuture=samp_future_len)
         loss_dict = avoid_loss(model.get_normalizer().unnormalize(pred['future_pred']), cur_z, embed_info['prior_out'])
         loss_dict['loss'].backward()
         if log is not None:
             log(loss_dict, cur_z)
-        scene_optim.step()
+        return loss_dict['loss']
+    for _ in range(num_iters):
+        if optim_use_adam:
+            closure()
+            scene_optim.step()
+        else:
+            scene_optim.step(closure)       # (torch's LBFGS reads the loss on the host for its line search, like the reference's run)
     with torch.no_grad():
         final = model.decode_embedding(cur_z, embed_info, scene_graph, map_idx, map_env, nfuture=save_future_len)
     return init_future_pred, cur_z, final['future_pred'].unsqueeze(1).clone().detach(), embed_info

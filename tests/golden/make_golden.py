@@ -972,14 +972,51 @@ def g11_eval(R):
     save('g11_eval.npz', **out)
 
 
+G12_SIZES = [4]
+
+
+def g12_inputs():
+    batch, map_idx, _, _ = build_inputs(G12_SIZES, 'g12', window=14.0)
+    raster, dx = loop_rasters('u')
+    eps = synth.f32(synth.counter_normal((1, batch.past.shape[0], 32), 'g12/eps'))
+    return batch, map_idx, raster, dx, eps
+
+
+def g12_refine_fn(R):
+    """The reference's OWN refine_traffic_optim() (src/refine_traffic_optim.py:146-226) -- its function body executed from its
+    file -- with the unseeded prior sample replaced by a counter-generated one: Adam (3 iterations) and the LBFGS branch
+    (max_iter 20, strong-Wolfe line search; 2 iterations), samp_future_len = save_future_len = 6, uniform raster."""
+    import contextlib
+    import io
+    import tqdm
+    src = open(os.path.join(REF_SRC, 'refine_traffic_optim.py')).read()
+    body = src[src.index('def refine_traffic_optim('):src.index('def run_one_epoch(')]
+    ns = {'torch': torch, 'optim': torch.optim, 'tqdm': tqdm, 'detach_embed_info': R.scenario_gen.detach_embed_info,
+          'AvoidCollLoss': R.adv_losses.AvoidCollLoss}
+    exec(compile(body, 'reference:refine_traffic_optim.py', 'exec'), ns)
+    out = {}
+    for name, use_adam, iters in (('adam', True, 3), ('lbfgs', False, 2)):
+        tm, _ = ref_model(R)
+        batch, map_idx, raster, dx, eps = g12_inputs()
+        env = ref_map_env(R, raster, dx)
+        tm.rsample = lambda mean, var: mean + eps * torch.sqrt(var)
+        sink = io.StringIO()
+        with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+            init_pred, z, res, emb = ns['refine_traffic_optim'](batch, map_idx, env, tm, REFINE_WEIGHTS, iters, 6, 6, use_adam, 0.05)
+        out[name + '/init_future_pred'] = npy(init_pred)
+        out[name + '/z'] = npy(z)
+        out[name + '/result_traj'] = npy(res)
+    save('g12_refine_fn.npz', **out)
+
+
 G8_CASES = [(15.0, 0, 0.0, None, False), (15.0, 2, 0.5, None, True), (25.0, 1, 0.0, 0.0, True), (8.0, 0, 1.0, -0.5, False)]
 
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
     R = import_reference()
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g4b', 'g5', 'g6', 'g6l', 'g6h', 'g7', 'g8', 'g9', 'g10', 'g11']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g4b', 'g5', 'g6', 'g6l', 'g6h', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12']
     fns = {'g1': g1_ops, 'g2': g2_crop, 'g3': g3_gnn, 'g4': g4_rollout, 'g5': g5_losses, 'g6': g6_loop, 'g7': g7_sample,
-           'g8': g8_checks, 'g9': g9_wire, 'g6l': g6_loops, 'g4b': g4b_nc5, 'g10': g10_planner, 'g6h': g6h_hardcode, 'g11': g11_eval}
+           'g8': g8_checks, 'g9': g9_wire, 'g6l': g6_loops, 'g4b': g4b_nc5, 'g10': g10_planner, 'g6h': g6h_hardcode, 'g11': g11_eval, 'g12': g12_refine_fn}
     for w in which:
         fns[w](R)

@@ -231,3 +231,29 @@ def test_refine_closure_at_the_oracle_latents_every_iteration(model):
         assert_close(z.grad, gw, 2e-2, 2e-3 * scale, 'iteration %d: dL/dz at the oracle latents' % it)
     print('refine closure at the oracle latents: worst loss deviation %.2e (relative), worst gradient entry %.2e of the largest' %
           (worst_l, worst_g))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,use_adam,iters', [('adam', True, 3), ('lbfgs', False, 2)])
+def test_refine_function_matches_the_reference_function(model, name, use_adam, iters):
+    """strive_amd.refine_traffic_optim.refine_traffic_optim -- the whole function incl. its prior sample (injected) and, for
+    --optim_use_lbfgs, torch's LBFGS with the strong-Wolfe line search around the HIP closure -- against fixture g12 = the
+    reference's own function (uniform raster)."""
+    from strive_amd.refine_traffic_optim import refine_traffic_optim
+    m, sd = model
+    g = golden('g12_refine_fn.npz')
+    batch, map_idx, raster, dx, eps = mg.g12_inputs()
+    env = synth.SyntheticMapEnv(raster.clone(), dx.clone()).to(DEV)
+    saved = m.rsample
+    try:
+        m.rsample = lambda mean, var: mean + eps.to(mean.device) * torch.sqrt(var)
+        init_pred, z, res, _ = refine_traffic_optim(batch.clone().to(DEV), map_idx.to(DEV), env, m, mg.REFINE_WEIGHTS, iters, 6, 6,
+                                                    use_adam, 0.05)
+    finally:
+        m.rsample = saved
+    assert_close(init_pred, g[name + '/init_future_pred'], 1e-4, 2e-5, name + ' init_future_pred')
+    # LBFGS: 20 inner iterations x 2 with a line search amplify the 1e-6 closure differences; Adam: 3 steps
+    tol = 2e-3 if use_adam else 2e-2
+    frac = float(np.mean(np.abs(z.detach().cpu().numpy() - g[name + '/z']) <= tol))
+    assert frac >= 0.97, '%s: only %.3f of the latent entries within %.0e' % (name, frac, tol)
+    assert_close(res, g[name + '/result_traj'], 0, 5e-3 if use_adam else 5e-2, name + ' result_traj')

@@ -445,3 +445,19 @@ def test_rect_iou_oracle_closed_forms():
         ia, ib = inside(a, la), inside(b, lb)
         est = (ia & ib).sum() / max((ia | ib).sum(), 1)
         assert abs(rect_iou(a, la, b, lb) - est) < 6e-3
+
+
+def test_refine_function_adam_and_lbfgs_match_reference(sd):
+    """fixture g12: the reference's OWN refine_traffic_optim() (function body executed from its file, prior sample injected), Adam
+    branch and --optim_use_lbfgs branch, against the oracle's restatement of the whole function"""
+    from oracle import loops
+    g = golden('g12_refine_fn.npz')
+    for name, use_adam, iters in (('adam', True, 3), ('lbfgs', False, 2)):
+        batch, map_idx, raster, dx, eps = mg.g12_inputs()
+        env = synth.SyntheticMapEnv(raster, dx)
+        orc = oracle_model(sd)
+        init_pred, z, res = loops.refine_fn(orc, batch, map_idx, env, mg.REFINE_WEIGHTS, iters, 6, 6, use_adam, 0.05, eps)
+        assert_close(init_pred, g[name + '/init_future_pred'], 1e-5, 1e-5, name + ' init_future_pred')
+        assert_close(z, g[name + '/z'], 1e-4, 1e-4, name + ' z')
+        assert_close(res, g[name + '/result_traj'], 1e-4, 1e-4, name + ' result_traj')
+    assert np.abs(g['adam/z'] - g['lbfgs/z']).max() > 0.5          # the two branches really differ
