@@ -44,7 +44,7 @@ def lookup(path, prefix, field):
 
 def main():
     fetch, write, stats = sys.argv[1:4]
-    res = {'_how': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace (separate passes, profiles/r02_commands.sh) on `python '
+    res = {'_how': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace (separate passes, profiles/rNN_commands.sh of the round) on `python '
                    'bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline`, summarised by profiles/summarize_pmc.py and '
                    'turned into this file by profiles/make_traffic.py; KB per launch of 512 agents; FETCH_SIZE x2 on gfx950 '
                    '(/opt/skills/guides/MI355X_MICROARCH.md, HBM section), WRITE_SIZE x1; avg_us = rocprofv3 kernel-trace average '
