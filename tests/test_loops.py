@@ -221,7 +221,7 @@ def test_refine_closure_at_the_oracle_latents_every_iteration(model):
         ld['loss'].backward()
         assert ld['coll_veh_loss'].numel() == e['coll_veh_loss'].numel(), 'iteration %d: different colliding-pair sets' % it
         for k in keys:
-            a, b = float(torch.mean(ld[k])), float(torch.mean(e[k]))
+            a, b = float(torch.mean(ld[k].detach())), float(torch.mean(e[k]))
             worst_l = max(worst_l, abs(a - b) / (1e-4 + abs(b)))
             assert abs(a - b) <= 1e-4 + 2e-3 * abs(b), 'iteration %d: %s %.6g vs %.6g' % (it, k, a, b)
         gw = e['grad']
