@@ -209,6 +209,36 @@ def test_device_planner_emulated_random_world(emu_ops, cfg_name):
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=1e-9)
 
 
+def test_device_planner_with_the_ego_in_the_middle_of_its_scene(emu_ops):
+    """reset(..., ego_idx=2): the observed agents are rows 0, 1, 3, 4 of every scene (reference :109-127, create_other_agents)"""
+    lg = synth.make_lane_graph()
+    t = np.linspace(0.5, 6.0, 12)
+    states, atts, mask, obs = [], [], [], []
+    for b, n in enumerate((5, 4)):
+        px, py, h, s = synth.lane_scene_poses(lg, n, 'pe/%d' % b, radius=30.0, centre=(128.0 + 40.0 * b, 128.0))
+        lw = np.stack([4.2 + 0.4 * synth.counter_uniform((n,), 'pe/l%d' % b), 1.9 + 0.2 * synth.counter_uniform((n,), 'pe/w%d' % b)], -1)
+        states.append(np.stack([px, py, np.cos(h), np.sin(h), s, np.zeros(n)], -1))
+        atts.append(lw)
+        mask += [b] * n
+        fut = np.stack([px[:, None] + s[:, None] * np.cos(h[:, None]) * t[None], py[:, None] + s[:, None] * np.sin(h[:, None]) * t[None],
+                        np.broadcast_to(np.cos(h[:, None]), (n, 12)), np.broadcast_to(np.sin(h[:, None]), (n, 12))], -1)
+        obs.append(np.delete(fut, 2, axis=0))
+    st, att = synth.f32(np.concatenate(states)), synth.f32(np.concatenate(atts))
+    obs = np.concatenate(obs).astype(np.float32)
+    ptr = np.array([0, 4, 7])
+    mi = torch.zeros((2,), dtype=torch.long)
+    cfg = CONFIG_DICT['default']
+    orc = oplan.HardcodeNuscPlanner(mg._LaneEnv(lg), oplan.PlannerConfig(**cfg))
+    orc.reset(st, att, torch.tensor(mask), 2, mi, ego_idx=2)
+    dev = HardcodeNuscPlanner(mg._LaneEnv(lg), PlannerConfig(**cfg))
+    dev.reset(st, att, torch.tensor(mask), 2, mi, ego_idx=2)
+    want = orc.rollout(obs.copy(), t, ptr, t, control_all=False)
+    got = dev.rollout(obs.copy(), t, ptr, t, control_all=False)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=1e-9)
+    # and it is the ego's lane the plan follows: the first pose lies within one step of agent 2's start
+    assert np.linalg.norm(got[0, 0, :2].numpy() - states[0][2, :2]) < 0.5 * 10.0
+
+
 def test_device_planner_routes_match_oracle(emu_ops):
     """every route of a pose (matches -> clusters -> chains -> blended arc-length path), knot by knot"""
     lg = synth.make_lane_graph()
