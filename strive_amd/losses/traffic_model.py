@@ -128,6 +128,22 @@ def compute_coll_rate_env(scene_graph, map_idx, pred, map_env, state_normalizer,
     return {'num_coll_map': float(coll.sum().item()), 'num_traj_map': float(NS * NA), 'did_collide': coll}
 
 
+def compute_coll_rate_env_from_traj(pred_future, veh_att, mapixes, map_env):
+    """The same test on UNNORMALISED trajectories: ``pred_future`` (NA,NS,FT,4), ``veh_att`` (NA,2) in metres, ``mapixes`` (NA)
+    (reference :421-463, what the scenario-evaluation tools call on stored scenarios)."""
+    from ..datasets import nuscenes_utils as nutils
+    NA, NS, FT, _ = pred_future.size()
+    flat = pred_future.reshape(NA * NS * FT, 4)
+    att = veh_att.view(NA, 1, 1, 2).expand(NA, NS, FT, 2).reshape(NA * NS * FT, 2)
+    mix = mapixes.view(NA, 1, 1).expand(NA, NS, FT).reshape(NA * NS * FT)
+    valid = ~torch.isnan(flat.sum(-1))
+    frac = torch.ones((NA * NS * FT,), dtype=torch.float32, device=pred_future.device)
+    if bool(valid.any()):
+        frac[valid] = nutils.check_on_layer(map_env.nusc_raster[:, 0], map_env.nusc_dx, flat[valid], att[valid], mix[valid])
+    coll = (frac.view(NA, NS, FT) < (1.0 - ENV_COLL_THRESH)).sum(dim=2) >= 1
+    return {'num_coll_map': float(coll.sum().item()), 'num_traj_map': float(NS * NA), 'did_collide': coll}
+
+
 def compute_disp_err(scene_graph, pred, normalizer):
     """Sample-based displacement errors of the EGO of every scene (reference :297-364): ``pred['future_pred']`` (NA,NS,FT',4)
     NORMALISED against ``scene_graph.future_gt`` over the common horizon.  Returns per scene the best-of-NS average / final

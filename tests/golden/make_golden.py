@@ -833,6 +833,9 @@ def g8_checks(R):
         cd = R.tm_losses.compute_coll_rate_env(batch, map_idx, samples.clone(), env, nrm, att, ego_only=ego_only)
         out['env_did_%s' % name] = npy(cd['did_collide'])
         out['env_num_%s' % name] = np.array([cd['num_coll_map'], cd['num_traj_map']])
+    cd = R.tm_losses.compute_coll_rate_env_from_traj(world.clone(), lw, map_idx.expand(world.shape[0]), env)
+    out['env_did_traj'] = npy(cd['did_collide'])
+    out['env_num_traj'] = np.array([cd['num_coll_map'], cd['num_traj_map']])
     save('g8_checks.npz', **out)
 
 

@@ -410,6 +410,12 @@ def test_g8_env_coll_rate_mirror(sd):
         cd = compute_coll_rate_env(batch, torch.tensor([1]), samples.clone(), env, nrm, att, ego_only=ego_only)
         assert np.array_equal(cd['did_collide'].numpy(), g['env_did_%s' % name].astype(bool)), name
         assert [cd['num_coll_map'], cd['num_traj_map']] == g['env_num_%s' % name].tolist()
+    # the variant on unnormalised trajectories (reference :421-463)
+    from strive_amd.losses.traffic_model import compute_coll_rate_env_from_traj
+    cd = compute_coll_rate_env_from_traj(world.clone(), lw, torch.tensor([1]).expand(world.shape[0]), env)
+    assert np.array_equal(cd['did_collide'].numpy(), g['env_did_traj'].astype(bool))
+    assert [cd['num_coll_map'], cd['num_traj_map']] == g['env_num_traj'].tolist()
+    assert np.array_equal(g['env_did_traj'], g['env_did_all'])
 
 
 def test_rect_iou_oracle_closed_forms():
