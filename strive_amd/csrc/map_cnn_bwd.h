@@ -319,6 +319,166 @@ struct DgradProb {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient with the operands staged ONCE per tile (round 3).  The implicit-GEMM form above fetches every operand
+// element through a functor: run-time index divisions, a GroupNorm + ReLU evaluation per USE of an input value (25 uses for a
+// 5 x 5 window) and 4-byte gathers 32-64 bytes apart -- profiles/r03_train_kernel_stats.txt: 48 % of the training step.
+// Here a workgroup owns one block of 8 input channels (the octet of the forward's activation layout: 32 contiguous bytes per
+// pixel; layer 0: the 4 raster layers) and walks (sample, band of output rows) units: the band of dy (all output channels)
+// and the matching band of the input -- normalised and rectified once per element on the way in -- go to LDS with coalesced
+// row loads, then thread (ci, ky, group of output channels) slides along the band with its KS window values in registers (two new
+// ones per output pixel): COG x KS multiply-adds per 2 + COG LDS reads.  All layer dimensions are template constants.
+// The partial sums of all units of the workgroup stay in registers and are added to dW once, with atomics.
+// ---------------------------------------------------------------------------------------------
+template <int L>
+struct WgTile {
+    static constexpr int CIN = LC_IN[L], COUT = LC_OUT[L], KS = LKS[L], IH = LIH[L], OH = LOH[L];
+    static constexpr int CB = CIN < 8 ? CIN : 8, NCB = CIN / CB;
+    static constexpr int RH = L == 0 ? 2 : L == 1 ? 2 : L == 2 ? 4 : L == 3 ? 7 : L == 4 ? 6 : 2;      // output rows per band
+    static constexpr int NBAND = (OH + RH - 1) / RH, IR = 2 * RH + KS - 2;
+    static constexpr int IWP = IH | 1;                                   // odd row pitch: (ci, ky) rows land in different banks
+    static constexpr int OWP = OH;
+    static constexpr int PAIRS = CB * KS, NG = 256 / PAIRS, COG = (COUT + NG - 1) / NG;
+    static constexpr int A_FLOATS = CB * IR * IWP, DY_FLOATS = COUT * RH * OWP;
+    static constexpr size_t LDS_BYTES = (size_t)(A_FLOATS + DY_FLOATS) * 4;
+    static_assert(LDS_BYTES <= 64 * 1024 && NG >= 1 && COG * KS <= 64, "tile budget");
+};
+
+template <int L>
+static __global__ __launch_bounds__(256) void wgrad_tile_kernel(const float* __restrict__ dy, const float* __restrict__ act_in,
+                                                                 const uint8_t* __restrict__ crop, const float2* __restrict__ mr_in,
+                                                                 const float* __restrict__ gam_in, const float* __restrict__ bet_in,
+                                                                 float* __restrict__ dW, int NS) {
+    using T = WgTile<L>;
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* s_a = smem;                       // [CB][IR][IWP]   input band, GroupNorm + ReLU applied
+    float* s_dy = smem + T::A_FLOATS;        // [COUT][RH][OWP] output-gradient band
+    const int tid = threadIdx.x, cb = blockIdx.y;
+    const int grp = tid / T::PAIRS, pair = tid - grp * T::PAIRS;
+    const int ci = pair / T::KS, ky = pair - ci * T::KS;
+    const bool worker = grp < T::NG;
+    const int co0 = grp * T::COG;
+    float acc[T::COG][T::KS];
+#pragma unroll
+    for (int c = 0; c < T::COG; ++c)
+#pragma unroll
+        for (int k = 0; k < T::KS; ++k) acc[c][k] = 0.f;
+    const int units = NS * T::NBAND;
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        const int n = u / T::NBAND, band = u - n * T::NBAND;
+        const int oy0 = band * T::RH;
+        const int rh = (T::OH - oy0) < T::RH ? (T::OH - oy0) : T::RH;
+        const int ir = 2 * rh + T::KS - 2;
+        __syncthreads();                     // the previous unit's readers are done
+        // ---- dy band: rows oy0 .. oy0+rh of every output channel are contiguous in NCHW ----
+        // (the staging loops are unrolled so that several loads are in flight: with one load per trip these kernels spent most
+        //  of their time waiting for 30-50 dependent-latency loads per unit)
+        {
+            const int cnt = T::COUT * rh * T::OH;
+#pragma unroll 4
+            for (int e = tid; e < cnt; e += 256) {
+                const int co = e / (rh * T::OH), rem = e - co * (rh * T::OH);
+                s_dy[co * (T::RH * T::OWP) + rem] = dy[(((size_t)n * T::COUT + co) * T::OH + oy0) * T::OH + rem];
+            }
+        }
+        // ---- input band of this channel block ----
+        if (L == 0) {
+            // four raster pixels per load (rows of the crop are 256-byte aligned)
+            const int cnt = T::CB * ir * (T::IH / 4);
+#pragma unroll 4
+            for (int e = tid; e < cnt; e += 256) {
+                const int c = e / (ir * (T::IH / 4)), rem = e - c * (ir * (T::IH / 4));
+                const int row = rem / (T::IH / 4), x4 = rem - row * (T::IH / 4);
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(crop + (((size_t)n * 4 + c) * 256 + 2 * oy0 + row) * 256 + 4 * x4);
+                float* dst = s_a + (c * T::IR + row) * T::IWP + 4 * x4;
+                dst[0] = (float)(v & 255u); dst[1] = (float)((v >> 8) & 255u); dst[2] = (float)((v >> 16) & 255u); dst[3] = (float)(v >> 24);
+            }
+        } else {
+            // four channels of a pixel per load (octet-planar rows are 32-byte aligned)
+            const float2 m = mr_in[n];
+            const float4* src = reinterpret_cast<const float4*>(act_in + (((size_t)n * T::NCB + cb) * T::IH + 2 * oy0) * T::IH * 8);
+            const int cnt = ir * T::IH * 2;
+#pragma unroll 4
+            for (int e = tid; e < cnt; e += 256) {
+                const int c4 = (e & 1) * 4, px = e >> 1;
+                const int row = px / T::IH, x = px - row * T::IH;
+                const float4 v = src[e];
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cg = cb * 8 + c4 + q;
+                    s_a[((c4 + q) * T::IR + row) * T::IWP + x] = fmaxf((vv[q] - m.x) * m.y * gam_in[cg] + bet_in[cg], 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        if (worker) {
+            for (int r = 0; r < rh; ++r) {
+                const float* arow = s_a + (ci * T::IR + 2 * r + ky) * T::IWP;
+                const float* drow = s_dy + (size_t)co0 * (T::RH * T::OWP) + r * T::OWP;
+                // the KS window values slide by two per output pixel: two LDS reads per step instead of KS
+                float a[T::KS];
+#pragma unroll
+                for (int k = 2; k < T::KS; ++k) a[k] = arow[k - 2];
+                for (int ox = 0; ox < T::OH; ++ox) {
+#pragma unroll
+                    for (int k = 0; k + 2 < T::KS; ++k) a[k] = a[k + 2];
+                    a[T::KS - 2] = arow[2 * ox + T::KS - 2];
+                    a[T::KS - 1] = arow[2 * ox + T::KS - 1];
+#pragma unroll
+                    for (int c = 0; c < T::COG; ++c) {
+                        if (co0 + c < T::COUT) {
+                            const float d = drow[c * (T::RH * T::OWP) + ox];
+#pragma unroll
+                            for (int k = 0; k < T::KS; ++k) acc[c][k] = fmaf(d, a[k], acc[c][k]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (worker) {
+#pragma unroll
+        for (int c = 0; c < T::COG; ++c) {
+            if (co0 + c < T::COUT) {
+                float* w = dW + (((size_t)(co0 + c) * T::CIN + cb * T::CB + ci) * T::KS + ky) * T::KS;
+#pragma unroll
+                for (int k = 0; k < T::KS; ++k)
+                    if (acc[c][k] != 0.f) unsafeAtomicAdd(&w[k], acc[c][k]);
+            }
+        }
+    }
+}
+
+template <int L>
+static inline void launch_wgrad_tile(const float* dy, const float* act_in, const uint8_t* crop, const float2* mr_in, const float* gam_in,
+                                     const float* bet_in, float* dW, int NS, hipStream_t stream) {
+    using T = WgTile<L>;
+    const int units = NS * T::NBAND;
+    int per_cb = 768 / T::NCB;                 // ~3 workgroups per CU in total
+    if (per_cb > units) per_cb = units;
+    if (per_cb < 1) per_cb = 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)wgrad_tile_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_tile_kernel<L>, dim3(per_cb, T::NCB), dim3(256), T::LDS_BYTES, stream, dy, act_in, crop, mr_in, gam_in,
+                       bet_in, dW, NS);
+}
+
+static inline void launch_wgrad_tile_layer(int l, const float* dy, const float* act_in, const uint8_t* crop, const float2* mr_in,
+                                           const float* gam_in, const float* bet_in, float* dW, int NS, hipStream_t stream) {
+    switch (l) {
+        case 0: launch_wgrad_tile<0>(dy, act_in, crop, mr_in, gam_in, bet_in, dW, NS, stream); break;
+        case 1: launch_wgrad_tile<1>(dy, act_in, crop, mr_in, gam_in, bet_in, dW, NS, stream); break;
+        case 2: launch_wgrad_tile<2>(dy, act_in, crop, mr_in, gam_in, bet_in, dW, NS, stream); break;
+        case 3: launch_wgrad_tile<3>(dy, act_in, crop, mr_in, gam_in, bet_in, dW, NS, stream); break;
+        case 4: launch_wgrad_tile<4>(dy, act_in, crop, mr_in, gam_in, bet_in, dW, NS, stream); break;
+        default: launch_wgrad_tile<5>(dy, act_in, crop, mr_in, gam_in, bet_in, dW, NS, stream); break;
+    }
+}
+
 constexpr int BWD_CHUNK = 64;     // samples pushed through forward-recompute + backward together
 
 static inline size_t grad_floats_per_sample() {
@@ -431,11 +591,18 @@ extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, co
             wp.gam_in = l > 0 ? cnn->gn_g[l - 1] : nullptr;
             wp.bet_in = l > 0 ? cnn->gn_b[l - 1] : nullptr;
             wp.dW = gp.w[l];
-            const int K = n * d.oh * d.oh, NN = d.cin * d.ks * d.ks;
-            wp.kchunk = 2048;
-            hipLaunchKernelGGL(igemm64_kernel<WgradProb>, dim3((NN + 63) / 64, (d.cout + 63) / 64, (K + wp.kchunk - 1) / wp.kchunk),
-                               dim3(256), 0, stream, wp);
+            static const bool use_igemm = getenv("STRIVE_WGRAD_IGEMM") != nullptr;      // A/B switch: the round-2 implicit-GEMM form
+            if (use_igemm || (l > 0 && !d.in_oct)) {
+                const int K = n * d.oh * d.oh, NN = d.cin * d.ks * d.ks;
+                wp.kchunk = 2048;
+                hipLaunchKernelGGL(igemm64_kernel<WgradProb>, dim3((NN + 63) / 64, (d.cout + 63) / 64, (K + wp.kchunk - 1) / wp.kchunk),
+                                   dim3(256), 0, stream, wp);
+            } else {
+                launch_wgrad_tile_layer(l, G[l], wp.act_in, wp.crop, wp.mr_in, wp.gam_in, wp.bet_in, gp.w[l], n, stream);
+            }
             if (l > 0) {
+                // (a staged data-gradient kernel in the style of wgrad_tile_kernel -- thread = input pixel, weights through the
+                // scalar cache -- was measured slower than this form: 2.19 vs 1.36 ms per 64-sample call)
                 DgradProb dp;
                 dp.d = d; dp.M = d.cin; dp.dy = G[l]; dp.w = cnn->w_torch[l]; dp.gin = G[l - 1];
                 const int nmax = ((d.ih + 1) / 2) * ((d.ih + 1) / 2);
