@@ -2,13 +2,13 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r03i
+O=gpurun_out/r03k
 rm -rf $O; mkdir -p $O
 (timeout 600 python -m pytest tests/test_training.py -m gpu -q -s 2>&1 | tail -4) > $O/train_tests.log
 B="python bench.py --no-cpu-baseline --no-roofline --workload train"
-STRIVE_WGRAD_IGEMM=1 $B --steps 5 --warmup 2 > $O/bench_line_train_igemm.json 2>> $O/bench.err
+STRIVE_DGRAD_IGEMM=1 $B --steps 5 --warmup 2 > $O/bench_line_train_igemm.json 2>> $O/bench.err
 $B --steps 5 --warmup 2 > $O/bench_line_train_tile.json 2>> $O/bench.err
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt -- $B --steps 3 --warmup 1 > $O/kt.log 2>&1
 DB=$(find $O/kt -name "*.db" | head -1)
-python profiles/summarize_rocpd.py $DB | head -30 > $O/train_kernel_stats.txt 2>&1
+python profiles/summarize_rocpd.py $DB | head -48 > $O/train_kernel_stats.txt 2>&1
 find $O -type f -size +1M -delete

@@ -479,6 +479,10 @@ static inline void launch_wgrad_tile_layer(int l, const float* dy, const float* 
     }
 }
 
+}  // namespace cnnbwd
+#include "map_cnn_bwd_mfma.h"
+namespace cnnbwd {
+
 constexpr int BWD_CHUNK = 64;     // samples pushed through forward-recompute + backward together
 
 static inline size_t grad_floats_per_sample() {
@@ -522,6 +526,7 @@ extern "C" size_t strive_map_cnn_bwd_workspace_bytes(int32_t N) {
     b += strive_align_up(ch * 6 * sizeof(float2), 256);                         // moments
     b += strive_align_up(ch * 2 * sizeof(double), 256);                         // GroupNorm backward sums
     b += strive_align_up(ch * 64 * 4, 256);                                     // feature scratch of the recomputed forward
+    b += strive_align_up(cnnbwd::dgrad_frag_total() * 16, 256);                 // bf16 weight fragments of the data gradient
     return b + 1024;
 }
 
@@ -546,7 +551,15 @@ extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, co
     float2* mr = ar.take<float2>((size_t)ch * 6);
     double* S = ar.take<double>((size_t)ch * 2);
     float* feat = ar.take<float>((size_t)ch * 64);
+    uint4* dfrag = ar.take<uint4>(dgrad_frag_total());
     STRIVE_CHECK_ARG(ar.ok(), "workspace arena overflow");
+    static const bool dgrad_igemm = getenv("STRIVE_DGRAD_IGEMM") != nullptr;     // A/B switch: the fp32 implicit-GEMM form
+    if (!dgrad_igemm) {
+        DgradPackArgs pa;
+        for (int l = 0; l < 6; ++l) pa.w[l] = cnn->w_torch[l];
+        const int total = (int)dgrad_frag_total();
+        hipLaunchKernelGGL(dgrad_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, pa, dfrag, total);
+    }
     const CnnGradPtrs gp = cnn_grad_ptrs(d_params);
 
     for (int n0 = 0; n0 < N; n0 += ch) {
@@ -600,9 +613,11 @@ extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, co
             } else {
                 launch_wgrad_tile_layer(l, G[l], wp.act_in, wp.crop, wp.mr_in, wp.gam_in, wp.bet_in, gp.w[l], n, stream);
             }
-            if (l > 0) {
-                // (a staged data-gradient kernel in the style of wgrad_tile_kernel -- thread = input pixel, weights through the
-                // scalar cache -- was measured slower than this form: 2.19 vs 1.36 ms per 64-sample call)
+            if (l > 0 && !dgrad_igemm) {
+                launch_dgrad_mfma_layer(l, G[l], dfrag, G[l - 1], n, stream);
+            } else if (l > 0) {
+                // (a staged fp32 data-gradient kernel in the style of wgrad_tile_kernel -- thread = input pixel, weights through
+                // the scalar cache -- was measured slower than this form: 2.19 vs 1.36 ms per 64-sample call)
                 DgradProb dp;
                 dp.d = d; dp.M = d.cin; dp.dy = G[l]; dp.w = cnn->w_torch[l]; dp.gin = G[l - 1];
                 const int nmax = ((d.ih + 1) / 2) * ((d.ih + 1) / 2);
