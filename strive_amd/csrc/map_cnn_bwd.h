@@ -175,6 +175,114 @@ static __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(LayerDesc d, c
     if (tid < d.cout && s_db[tid] != 0.f) unsafeAtomicAdd(&dbias[tid], s_db[tid]);
 }
 
+// ---- the same two passes for the octet-planar layers (l = 0..4), walked in the activation's own order: a thread takes the 8
+// channels of one pixel (32 contiguous bytes of y -- the NCHW walk above uses 4 bytes of every 32-byte sector it fetches) and
+// the 8 matching G values (one coalesced row per channel).  Its channels are fixed, so the per-channel sums stay in registers
+// and meet in LDS once per wave.  grid = (octets x pixel blocks, N), GN_PPB pixels per block.
+constexpr int GN_PPB = 2048;
+
+static __global__ __launch_bounds__(256) void gn_bwd_reduce_oct_kernel(int C, int HW, const float* __restrict__ y,
+                                                                        const float2* __restrict__ mr, const float* __restrict__ gam,
+                                                                        const float* __restrict__ bet, float* __restrict__ G,
+                                                                        double* __restrict__ S, float* __restrict__ dgam,
+                                                                        float* __restrict__ dbet) {
+    __shared__ float s_c[16];
+    __shared__ double s_s[2];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int npb = (HW + GN_PPB - 1) / GN_PPB;
+    const int oct = blockIdx.x / npb, pb = blockIdx.x - oct * npb;
+    const int p1 = (pb + 1) * GN_PPB < HW ? (pb + 1) * GN_PPB : HW;
+    if (tid < 16) s_c[tid] = 0.f;
+    if (tid < 2) s_s[tid] = 0.0;
+    __syncthreads();
+    const float2 m = mr[n];
+    float ga[8], be[8], dg[8], db[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { ga[c] = gam[oct * 8 + c]; be[c] = bet[oct * 8 + c]; dg[c] = 0.f; db[c] = 0.f; }
+    double s1 = 0.0, s2 = 0.0;
+    const float* yb = y + ((size_t)n * (C >> 3) + oct) * HW * 8;
+    float* gb = G + ((size_t)n * C + oct * 8) * HW;
+    for (int p = pb * GN_PPB + tid; p < p1; p += 256) {
+        const float4 y0 = *reinterpret_cast<const float4*>(yb + (size_t)p * 8), y1 = *reinterpret_cast<const float4*>(yb + (size_t)p * 8 + 4);
+        const float yy[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+        float f1 = 0.f, f2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float xh = (yy[c] - m.x) * m.y;
+            const float pre = xh * ga[c] + be[c];
+            float* gp = gb + (size_t)c * HW + p;
+            const float g = *gp;
+            const float dn = pre > 0.f ? g : 0.f;
+            if (dn != g) *gp = dn;
+            const float w = dn * ga[c];
+            f1 += w;
+            f2 = fmaf(w, xh, f2);
+            dg[c] = fmaf(dn, xh, dg[c]);
+            db[c] += dn;
+        }
+        s1 += (double)f1;
+        s2 += (double)f2;
+    }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { dg[c] = wave_sum(dg[c]); db[c] = wave_sum(db[c]); }
+    if ((tid & 63) == 0) {
+        unsafeAtomicAdd(&s_s[0], s1);
+        unsafeAtomicAdd(&s_s[1], s2);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { atomicAdd(&s_c[c], dg[c]); atomicAdd(&s_c[8 + c], db[c]); }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsafeAtomicAdd(&S[2 * n + 0], s_s[0]);
+        unsafeAtomicAdd(&S[2 * n + 1], s_s[1]);
+    }
+    if (tid < 8) { if (s_c[tid] != 0.f) unsafeAtomicAdd(&dgam[oct * 8 + tid], s_c[tid]); }
+    else if (tid < 16) { if (s_c[tid] != 0.f) unsafeAtomicAdd(&dbet[oct * 8 + tid - 8], s_c[tid]); }
+}
+
+static __global__ __launch_bounds__(256) void gn_bwd_apply_oct_kernel(int C, int HW, const float* __restrict__ y,
+                                                                       const float2* __restrict__ mr, const float* __restrict__ gam,
+                                                                       float* __restrict__ G, const double* __restrict__ S,
+                                                                       float* __restrict__ dbias) {
+    __shared__ float s_c[8];
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const int npb = (HW + GN_PPB - 1) / GN_PPB;
+    const int oct = blockIdx.x / npb, pb = blockIdx.x - oct * npb;
+    const int p1 = (pb + 1) * GN_PPB < HW ? (pb + 1) * GN_PPB : HW;
+    if (tid < 8) s_c[tid] = 0.f;
+    __syncthreads();
+    const float2 m = mr[n];
+    const double M = (double)C * HW;
+    const float a1 = (float)(S[2 * n + 0] / M), a2 = (float)(S[2 * n + 1] / M);
+    float ga[8], db[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { ga[c] = gam[oct * 8 + c]; db[c] = 0.f; }
+    const float* yb = y + ((size_t)n * (C >> 3) + oct) * HW * 8;
+    float* gb = G + ((size_t)n * C + oct * 8) * HW;
+    for (int p = pb * GN_PPB + tid; p < p1; p += 256) {
+        const float4 y0 = *reinterpret_cast<const float4*>(yb + (size_t)p * 8), y1 = *reinterpret_cast<const float4*>(yb + (size_t)p * 8 + 4);
+        const float yy[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float xh = (yy[c] - m.x) * m.y;
+            float* gp = gb + (size_t)c * HW + p;
+            const float dyv = m.y * (*gp * ga[c] - a1 - xh * a2);
+            *gp = dyv;
+            db[c] += dyv;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) db[c] = wave_sum(db[c]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) atomicAdd(&s_c[c], db[c]);
+    }
+    __syncthreads();
+    if (tid < 8 && s_c[tid] != 0.f) unsafeAtomicAdd(&dbias[oct * 8 + tid], s_c[tid]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // fp32 implicit GEMM:  C[m][j] (+)= sum_k A(m, k) * B(k, j),  64 x 64 tile per workgroup, K in steps of 16, 256 threads,
 // 4 x 4 outputs per thread (rows ty + 16 i, columns tx + 16 j).  P supplies M, N, the K range of this workgroup and the
@@ -483,7 +591,7 @@ static inline void launch_wgrad_tile_layer(int l, const float* dy, const float* 
 #include "map_cnn_bwd_mfma.h"
 namespace cnnbwd {
 
-constexpr int BWD_CHUNK = 64;     // samples pushed through forward-recompute + backward together
+constexpr int BWD_CHUNK = 256;    // samples pushed through forward-recompute + backward together (3.8 MB of workspace each)
 
 static inline size_t grad_floats_per_sample() {
     size_t t = 0;
@@ -527,6 +635,7 @@ extern "C" size_t strive_map_cnn_bwd_workspace_bytes(int32_t N) {
     b += strive_align_up(ch * 2 * sizeof(double), 256);                         // GroupNorm backward sums
     b += strive_align_up(ch * 64 * 4, 256);                                     // feature scratch of the recomputed forward
     b += strive_align_up(cnnbwd::dgrad_frag_total() * 16, 256);                 // bf16 weight fragments of the data gradient
+    b += strive_align_up(cnnbwd::wgrad_partial_floats() * 4, 256);              // per-workgroup partial weight gradients
     return b + 1024;
 }
 
@@ -552,6 +661,7 @@ extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, co
     double* S = ar.take<double>((size_t)ch * 2);
     float* feat = ar.take<float>((size_t)ch * 64);
     uint4* dfrag = ar.take<uint4>(dgrad_frag_total());
+    float* wpart = ar.take<float>(wgrad_partial_floats());
     STRIVE_CHECK_ARG(ar.ok(), "workspace arena overflow");
     static const bool dgrad_igemm = getenv("STRIVE_DGRAD_IGEMM") != nullptr;     // A/B switch: the fp32 implicit-GEMM form
     if (!dgrad_igemm) {
@@ -591,10 +701,19 @@ extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, co
             int nblk = (M + 8191) / 8192;
             if (nblk < 1) nblk = 1;
             hipMemsetAsync(S, 0, (size_t)n * 2 * sizeof(double), stream);
-            hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nblk, n), dim3(256), 0, stream, d, act[l], mr + (size_t)l * ch, cnn->gn_g[l],
-                               cnn->gn_b[l], G[l], S, gp.g[l], gp.be[l]);
-            hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nblk, n), dim3(256), 0, stream, d, act[l], mr + (size_t)l * ch, cnn->gn_g[l],
-                               G[l], S, gp.b[l]);
+            if (d.out_oct) {
+                const int HW = d.oh * d.oh;
+                const dim3 grid((d.cout / 8) * ((HW + GN_PPB - 1) / GN_PPB), n);
+                hipLaunchKernelGGL(gn_bwd_reduce_oct_kernel, grid, dim3(256), 0, stream, d.cout, HW, act[l], mr + (size_t)l * ch,
+                                   cnn->gn_g[l], cnn->gn_b[l], G[l], S, gp.g[l], gp.be[l]);
+                hipLaunchKernelGGL(gn_bwd_apply_oct_kernel, grid, dim3(256), 0, stream, d.cout, HW, act[l], mr + (size_t)l * ch,
+                                   cnn->gn_g[l], G[l], S, gp.b[l]);
+            } else {
+                hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nblk, n), dim3(256), 0, stream, d, act[l], mr + (size_t)l * ch, cnn->gn_g[l],
+                                   cnn->gn_b[l], G[l], S, gp.g[l], gp.be[l]);
+                hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nblk, n), dim3(256), 0, stream, d, act[l], mr + (size_t)l * ch, cnn->gn_g[l],
+                                   G[l], S, gp.b[l]);
+            }
             // weight gradient
             WgradProb wp;
             wp.d = d; wp.M = d.cout; wp.NS = n; wp.dy = G[l];
@@ -604,14 +723,17 @@ extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, co
             wp.gam_in = l > 0 ? cnn->gn_g[l - 1] : nullptr;
             wp.bet_in = l > 0 ? cnn->gn_b[l - 1] : nullptr;
             wp.dW = gp.w[l];
-            static const bool use_igemm = getenv("STRIVE_WGRAD_IGEMM") != nullptr;      // A/B switch: the round-2 implicit-GEMM form
-            if (use_igemm || (l > 0 && !d.in_oct)) {
+            static const bool use_igemm = getenv("STRIVE_WGRAD_IGEMM") != nullptr;      // A/B switches: the round-2 implicit-GEMM form,
+            static const bool use_tile = getenv("STRIVE_WGRAD_TILE") != nullptr;        // the fp32 LDS-tile form
+            if (use_igemm) {
                 const int K = n * d.oh * d.oh, NN = d.cin * d.ks * d.ks;
                 wp.kchunk = 2048;
                 hipLaunchKernelGGL(igemm64_kernel<WgradProb>, dim3((NN + 63) / 64, (d.cout + 63) / 64, (K + wp.kchunk - 1) / wp.kchunk),
                                    dim3(256), 0, stream, wp);
-            } else {
+            } else if (use_tile) {
                 launch_wgrad_tile_layer(l, G[l], wp.act_in, wp.crop, wp.mr_in, wp.gam_in, wp.bet_in, gp.w[l], n, stream);
+            } else {
+                launch_wgrad_mfma_layer(l, G[l], wp.act_in, wp.crop, wp.mr_in, wp.gam_in, wp.bet_in, gp.w[l], wpart, n, stream);
             }
             if (l > 0 && !dgrad_igemm) {
                 launch_dgrad_mfma_layer(l, G[l], dfrag, G[l - 1], n, stream);

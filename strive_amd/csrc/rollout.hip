@@ -698,9 +698,19 @@ struct TrainOut {
     float* d_gru;          // flat decoder_memory gradients, accumulated
     float* d_cnn;          // flat map_conv + map_feature gradients, accumulated
     const int32_t* mapix;  // (NA)
+    // The adjoints of map_feat_t of ALL steps are kept ((FT, R, 64): step 0 is the encoder's map feature) and the CNN
+    // backward runs ONCE over the (FT - 1) R crops after the reverse sweep: the crop is data (pos_t.detach()), so nothing in the
+    // sweep waits for it, and one call over 11 x more samples fills the chip where 11 calls of R = 64 samples were latency-bound.
+    float* g_mf_all;       // (FT, R, 64)
+    int32_t* mapix_all;    // (FT - 1, R)
     void* cnn_ws;
     size_t cnn_ws_bytes;
 };
+
+static __global__ void tile_mapix_kernel(const int32_t* __restrict__ mapix, int32_t* __restrict__ out, int R, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) out[i] = mapix[i % R];
+}
 
 static __global__ void rollout_init_bwd_kernel(const float* __restrict__ g_pf, const float* __restrict__ g_mem,
                                                const float* __restrict__ g_mf, float* __restrict__ d_past_feat,
@@ -728,6 +738,7 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
     float* d_loc = ar.take<float>(R * 4);
     float* g_pf = ar.take<float>(R * 64);
     float* g_mf = ar.take<float>(R * 64);
+    (void)g_mf;             // (the training path keeps the map-feature adjoints of every step in TrainOut::g_mf_all)
     float* g_mem = ar.take<float>(R * 192);
     GnnBwdBuffers bw = gnn_bwd_buffers_take(ar, R, 64, sc->max_n);
     if (!ar.ok()) { strive_set_error("rollout_bwd: workspace arena overflow"); return -1; }
@@ -773,17 +784,20 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
                            g2, ae);
         Node1BwdArgs a1;
         a1.t = t; a1.R = (int)R; a1.dX = bw.dX; a1.dP = bw.dP; a1.DE1 = bw.DE1; a1.DPJ = bw.DPJ; a1.gpos_tgt = bw.gpos_tgt;
-        a1.sem = sem; a1.PRE_IN = tp.PRE_IN_t(t); a1.X = g2.X; a1.g_pos = g_pos; a1.g_full = nullptr; a1.g_pf = g_pf; a1.g_mf = tr ? g_mf : nullptr; a1.dz = dz;
+        a1.sem = sem; a1.PRE_IN = tp.PRE_IN_t(t); a1.X = g2.X; a1.g_pos = g_pos; a1.g_full = nullptr; a1.g_pf = g_pf; a1.g_mf = tr ? tr->g_mf_all + (size_t)t * R * 64 : nullptr; a1.dz = dz;
         hipLaunchKernelGGL(node1_bwd_kernel<WG>, dim3(nb), dim3(256), node1_bwd_lds_bytes(in_ld1, xs_ld), stream, gd, ggn, sd, f, a1);
-        if (tr && t > 0) {
-            // map_feat_t = CNN(crop(pos_t.detach())) (reference traffic_model.py:694-695): its adjoint reaches the CNN weights
-            int rc = strive_map_cnn_bwd(&dec->map, &dec->cnn, tp.pos_t(t), dec->state_mean, dec->state_std, tr->mapix, (int32_t)R,
-                                        g_mf, tr->d_cnn, tr->cnn_ws, tr->cnn_ws_bytes, stream_);
-            if (rc) return rc;
-        }
+    }
+    if (tr && FT > 1) {
+        // map_feat_t = CNN(crop(pos_t.detach())), t = 1 .. FT-1 (reference traffic_model.py:694-695): the adjoints reach the CNN
+        // weights; positions (FT, R, 4) and adjoints (FT, R, 64) are contiguous over the steps
+        const int total = (int)((FT - 1) * R);
+        hipLaunchKernelGGL(tile_mapix_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, tr->mapix, tr->mapix_all, (int)R, total);
+        int rc = strive_map_cnn_bwd(&dec->map, &dec->cnn, tp.pos_t(1), dec->state_mean, dec->state_std, tr->mapix_all, (int32_t)total,
+                                    tr->g_mf_all + R * 64, tr->d_cnn, tr->cnn_ws, tr->cnn_ws_bytes, stream_);
+        if (rc) return rc;
     }
     if (tr)
-        hipLaunchKernelGGL(rollout_init_bwd_kernel, dim3((unsigned)((R * 64 + 255) / 256)), dim3(256), 0, stream, g_pf, g_mem, g_mf,
+        hipLaunchKernelGGL(rollout_init_bwd_kernel, dim3((unsigned)((R * 64 + 255) / 256)), dim3(256), 0, stream, g_pf, g_mem, tr->g_mf_all,
                            tr->d_past_feat, tr->d_map_feat, (int)R);
     return 0;
 }
@@ -814,7 +828,9 @@ extern "C" int strive_rollout_bwd(const StriveDecoder* dec, const StriveScenes* 
 
 extern "C" size_t strive_rollout_train_workspace_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT) {
     if (!sc) return 0;
-    return strive_rollout_workspace_bytes(dec, sc, FT) + strive_align_up(strive_map_cnn_bwd_workspace_bytes(sc->NA * sc->NS), 256);
+    const size_t R = (size_t)sc->NA * sc->NS, steps = FT > 1 ? (size_t)(FT - 1) : 1;
+    return strive_rollout_workspace_bytes(dec, sc, FT) + strive_align_up(strive_map_cnn_bwd_workspace_bytes((int32_t)(steps * R)), 256) +
+           strive_align_up((size_t)FT * R * 64 * 4, 256) + strive_align_up(steps * R * 4, 256);
 }
 
 extern "C" size_t strive_gnn_param_count(const StriveGNN* gnn) { return gnn ? gnn_param_count(*gnn) : 0; }
@@ -838,8 +854,16 @@ extern "C" int strive_rollout_bwd_train(const StriveDecoder* dec, const StriveSc
     TrainOut tr;
     tr.d_past_feat = d_past_feat; tr.d_map_feat = d_map_feat; tr.d_gnn = d_gnn; tr.d_gru = d_gru; tr.d_cnn = d_cnn;
     tr.mapix = mapix;
-    tr.cnn_ws = (char*)ws + base;
-    tr.cnn_ws_bytes = ws_bytes - base;
+    {
+        const size_t steps = FT > 1 ? (size_t)(FT - 1) : 1;
+        char* p = (char*)ws + base;
+        tr.g_mf_all = (float*)p;
+        p += strive_align_up((size_t)FT * R * 64 * 4, 256);
+        tr.mapix_all = (int32_t*)p;
+        p += strive_align_up(steps * R * 4, 256);
+        tr.cnn_ws = p;
+        tr.cnn_ws_bytes = ws_bytes - (size_t)(p - (char*)ws);
+    }
     int rc = rollout_backward<true>(dec, sc, lw, sem, z, ext_future, FT, d_traj, dz, tape, tape_bytes, ws, base, stream_, &tr);
     if (rc) return rc;
     STRIVE_CHECK_LAUNCH();

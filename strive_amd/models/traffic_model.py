@@ -216,6 +216,11 @@ class TrafficModel(nn.Module):
         encoders, prior / posterior networks, decoder rollout -- is an autograd Function whose backward is the matching
         ``strive_*_bwd`` call, so ``loss.backward()`` fills ``p.grad`` of all 174 tensors like the reference."""
         train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if train:
+            # every weight pack is rebuilt after an optimiser step and each needs max |w| of its tensors on the host (operand
+            # scales are kernel arguments): fetch them all with one read-back instead of one per pack
+            from .. import params as _params
+            _params.prefetch_absmax(list(self.parameters()))
         with ops.weight_grad_mode(train):
             emb = self.embed(scene_graph, map_idx, map_env)
             pmu, pvar = emb['prior_out']

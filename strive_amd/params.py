@@ -31,15 +31,73 @@ class Packed(object):
         return C.byref(self.struct)
 
 
+# ---- max |w| of parameter tensors: ONE device read-back for as many tensors as the caller can name up front ----
+# (the power-of-two operand scales are host scalars -- they are kernel arguments -- so each needs max |w| on the host; fetching
+#  them one by one was ~150 stream synchronisations per training step, where every pack is rebuilt after the optimiser step)
+_ABSMAX = {}
+
+
+def _absmax_key(t):
+    return (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+
+
+def prefetch_absmax(tensors):
+    """Compute and cache max |t| for every tensor of ``tensors`` not yet cached at its current version; one synchronisation."""
+    todo, keys = [], []
+    for t in tensors:
+        t = t.detach()
+        k = _absmax_key(t)
+        if k not in _ABSMAX and t.numel() > 0 and k not in keys:
+            todo.append(t.to(torch.float32))
+            keys.append(k)
+    if not todo:
+        return
+    if len(_ABSMAX) > 4096:
+        _ABSMAX.clear()
+    vals = torch.stack(torch._foreach_norm(todo, float('inf'))).tolist()
+    for k, v in zip(keys, vals):
+        _ABSMAX[k] = float(v)
+
+
+def absmax(t):
+    t = t.detach()
+    k = _absmax_key(t)
+    if k not in _ABSMAX:
+        prefetch_absmax([t])
+    return _ABSMAX.get(k, 0.0)
+
+
+# ---- operand layouts as ONE gather: the layout code below runs once per shape on an index tensor (slot -> element of the
+# flattened two-piece split, or the appended zero), and every later pack is cat + index_select ----
+_LAYOUT = {}
+
+
+def _layout_gather(pieces, key, build_index):
+    """pieces: (2, ...) fp16.  build_index(pidx, zero) lays out an int64 tensor ``pidx`` of the same shape (zero = index of
+    the appended 0) exactly like the fragment order; cached per (key, device)."""
+    ck = (key, tuple(pieces.shape), str(pieces.device))
+    idx = _LAYOUT.get(ck)
+    if idx is None:
+        n = pieces.numel()
+        pidx = torch.arange(n, dtype=torch.int64).view(pieces.shape)
+        idx = build_index(pidx, n).reshape(-1).to(pieces.device)
+        _LAYOUT[ck] = idx
+    flat = torch.cat([pieces.reshape(-1), torch.zeros((1,), dtype=pieces.dtype, device=pieces.device)])
+    return flat.index_select(0, idx)
+
+
 def dense_fragments(a, scale):
     """(M, K) fp32 matrix -> int32 tensor of its two-piece fp16 split (scaled by ``scale``) in the operand order of
     v_mfma_f32_16x16x32_f16 (include/strive_hip.h StriveMLP.wf): [row tile][k-step][piece][lane][8 x fp16]."""
     M, K = a.shape
     MT, KS = (M + 15) // 16, (K + 31) // 32
-    pad = torch.zeros((MT * 16, KS * 32), dtype=torch.float32, device=a.device)
-    pad[:M, :K] = a
-    pieces = _f16_split2(pad, scale, 'dense layer')                           # (2, M', K')
-    fr = pieces.view(2, MT, 16, KS, 4, 8).permute(1, 3, 0, 4, 2, 5).contiguous()     # (tile, step, piece, g, row, j)
+    pieces = _f16_split2(a, scale, 'dense layer')                             # (2, M, K)
+
+    def index(pidx, zero):
+        pad = torch.full((2, MT * 16, KS * 32), zero, dtype=torch.int64)
+        pad[:, :M, :K] = pidx
+        return pad.view(2, MT, 16, KS, 4, 8).permute(1, 3, 0, 4, 2, 5).contiguous()      # (tile, step, piece, g, row, j)
+    fr = _layout_gather(pieces, 'dense', index)
     return fr.view(torch.int16).view(-1, 8).contiguous().view(torch.int32)
 
 
@@ -48,8 +106,12 @@ def _fill_mlp(s, holder, sd, prefix):
     (reference src/models/common.py:26-39)."""
     k = 0
     dims = []
+    ws_ = []
+    while (prefix + '.net.%d.weight' % (3 * len(ws_))) in sd:
+        ws_.append(_c(sd[prefix + '.net.%d.weight' % (3 * len(ws_))]))
+    prefetch_absmax(ws_)
     while (prefix + '.net.%d.weight' % (3 * k)) in sd:
-        w = _c(sd[prefix + '.net.%d.weight' % (3 * k)])
+        w = ws_[k]
         b = _c(sd[prefix + '.net.%d.bias' % (3 * k)])
         if k == 0:
             dims.append(w.shape[1])
@@ -60,7 +122,7 @@ def _fill_mlp(s, holder, sd, prefix):
         # matrix-core operands (csrc/mlp_dev.h dense_mfma); STRIVE_DENSE_VALU=1 withholds them (A/B measurements: the
         # layers then run on the vector ALUs in fp32 from w / wt)
         if w.shape[0] >= 32 and w.shape[1] >= 32 and os.environ.get('STRIVE_DENSE_VALU', '0') != '1':
-            sc = _pow2_scale(float(w.abs().max()))
+            sc = _pow2_scale(_checked_absmax(w, 'dense layer'))
             s.wsc[k] = sc
             s.wf[k] = holder.hold(dense_fragments(w, sc))
             s.wbf[k] = holder.hold(dense_fragments(w.t().contiguous(), sc))
@@ -126,13 +188,20 @@ def _pow2_scale(bound, target=32768.0):
     return float(2.0 ** math.floor(math.log2(target / bound)))
 
 
+def _checked_absmax(w, what):
+    v = absmax(w)
+    import math
+    if not math.isfinite(v):
+        raise ValueError('%s weights are not finite' % what)
+    return v
+
+
 def _f16_split2(w, scale, what):
-    """w * scale = w0 + w1 up to 2^-24 |w|: w0 = fp16 (round to nearest even), w1 = fp16 of the exact remainder."""
+    """w * scale = w0 + w1 up to 2^-24 |w|: w0 = fp16 (round to nearest even), w1 = fp16 of the exact remainder.  ``scale``
+    comes from _pow2_scale(_checked_absmax(w)): max |w| scale <= 32768, so both pieces are finite."""
     ws = w.to(torch.float32) * scale
     w0 = ws.to(torch.float16)
     w1 = (ws - w0.to(torch.float32)).to(torch.float16)
-    if not bool(torch.isfinite(w0.float()).all()) or not bool(torch.isfinite(w1.float()).all()):
-        raise ValueError('%s weights do not fit fp16 after scaling by %g (non-finite values?)' % (what, scale))
     return torch.stack([w0, w1], dim=0)
 
 
@@ -141,10 +210,12 @@ def _conv1_fragments(w, scale):
     weight in the k order of conv1b_kernel (lane group g: window columns 2g, 2g+1; element = parity*4 + layer;
     column 7 is zero padding)."""
     pieces = _f16_split2(w, scale, 'conv1')                          # (2, co, ci, ky, kx)
-    pad = torch.zeros((2, 16, 4, 7, 1), dtype=torch.float16, device=w.device)
-    pk = torch.cat([pieces, pad], dim=4).view(2, 16, 4, 7, 4, 2)     # kx -> (g, parity)
-    # -> [ky][piece][g][co][parity][ci]
-    frag = pk.permute(3, 0, 4, 1, 5, 2).contiguous()                 # (7, 2, 4, 16, 2, 4)
+
+    def index(pidx, zero):
+        pad = torch.full((2, 16, 4, 7, 1), zero, dtype=torch.int64)
+        pk = torch.cat([pidx, pad], dim=4).view(2, 16, 4, 7, 4, 2)   # kx -> (g, parity)
+        return pk.permute(3, 0, 4, 1, 5, 2).contiguous()             # [ky][piece][g][co][parity][ci] = (7, 2, 4, 16, 2, 4)
+    frag = _layout_gather(pieces, 'conv1', index)
     return frag.view(torch.int16).view(7, 2, 64, 8).contiguous().view(torch.int32)
 
 
@@ -173,19 +244,24 @@ def _conv_bf6_fragments(w, scale, pass_ch=BF6_PASS_CH):
     co, ci, k, _ = w.shape
     if pass_ch != 8:
         raise NotImplementedError('conv_bf6_kernel stages 8 channels at a time')
-    pieces = _f16_split2(w, scale, 'conv').permute(0, 1, 3, 4, 2).contiguous()      # (2, co, ky, kx, ci)
+    pieces = _f16_split2(w, scale, 'conv')                                           # (2, co, ci, ky, kx)
     npass, csplit = ci // pass_ch, co // 32
     order = conv_tap_order(k)
-    out = torch.zeros((npass, len(order), csplit, 2, 2, 32, 8), dtype=torch.float16, device=w.device)
-    for p_ in range(npass):
-        for s_, taps in enumerate(order):
-            for h, tap in enumerate(taps):
-                if tap is None:
-                    continue
-                ky, kx = tap
-                blk = pieces[:, :, ky, kx, pass_ch * p_:pass_ch * p_ + 8]       # (2, co, 8)
-                out[p_, s_, :, :, h] = blk.view(2, csplit, 32, 8).permute(1, 0, 2, 3)
-    return out.contiguous().view(torch.int16).view(-1, 8).contiguous().view(torch.int32)
+
+    def index(pidx, zero):
+        pi = pidx.permute(0, 1, 3, 4, 2).contiguous()                                # (2, co, ky, kx, ci)
+        out = torch.full((npass, len(order), csplit, 2, 2, 32, 8), zero, dtype=torch.int64)
+        for p_ in range(npass):
+            for s_, taps in enumerate(order):
+                for h, tap in enumerate(taps):
+                    if tap is None:
+                        continue
+                    ky, kx = tap
+                    blk = pi[:, :, ky, kx, pass_ch * p_:pass_ch * p_ + 8]            # (2, co, 8)
+                    out[p_, s_, :, :, h] = blk.reshape(2, csplit, 32, 8).permute(1, 0, 2, 3)
+        return out
+    out = _layout_gather(pieces, 'bf6', index)
+    return out.view(torch.int16).view(-1, 8).contiguous().view(torch.int32)
 
 
 def _fill_cnn(s, holder, sd):
@@ -208,14 +284,16 @@ def _fill_cnn(s, holder, sd):
     # power-of-two scales: weights so that max |w| * wscale <= 32768; layer inputs (l >= 1) from the bound
     # relu(gamma * xhat + beta) <= max|gamma| * sqrt(C H W) + max|beta|  (|xhat| <= sqrt(#elements) for any sample)
     in_elems = [0, 16 * 125 * 125, 32 * 61 * 61, 64 * 29 * 29, 64 * 14 * 14, 128 * 6 * 6]
+    prefetch_absmax([_c(sd['map_conv.%d.weight' % (3 * l)]) for l in range(6)] +
+                    [_c(sd['map_conv.%d.%s' % (3 * l - 2, n)]) for l in range(1, 6) for n in ('weight', 'bias')])
     for l in range(6):
         w = _c(sd['map_conv.%d.weight' % (3 * l)])
-        s.wscale[l] = _pow2_scale(float(w.abs().max()))
+        s.wscale[l] = _pow2_scale(_checked_absmax(w, 'conv'))
         if l == 0:
             s.xscale[l] = 1.0
         else:
-            g = float(_c(sd['map_conv.%d.weight' % (3 * l - 2)]).abs().max())
-            b = float(_c(sd['map_conv.%d.bias' % (3 * l - 2)]).abs().max())
+            g = absmax(_c(sd['map_conv.%d.weight' % (3 * l - 2)]))
+            b = absmax(_c(sd['map_conv.%d.bias' % (3 * l - 2)]))
             s.xscale[l] = min(_pow2_scale(g * in_elems[l] ** 0.5 + b, 60000.0), 1024.0)
     s.w1_frag = holder.hold(_conv1_fragments(_c(sd['map_conv.0.weight']), s.wscale[0]))
     s.w2_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.3.weight']), s.wscale[1]))

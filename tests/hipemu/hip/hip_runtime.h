@@ -129,6 +129,7 @@ extern dim3 blockDim, gridDim;
 inline void __syncthreads() { hipemu::block_barrier(); }
 inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }      // callers pass wave-uniform values
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 inline void __threadfence() {}
 inline void __threadfence_block() {}

@@ -41,6 +41,13 @@ int main() {
         {"groups 320 B apart", {0, 320, 640, 960}, 16},
         {"groups 576 B apart (rows)", {0, 576, 1152, 1728}, 16},
         {"lanes 32 B apart, groups 16 B apart", {0, 16, 512, 528}, 32},
+        // r03: one 16-byte slot per lane at a padded row pitch (fragment rows = lanes, the transposed wgrad layout)
+        {"lanes 144 B apart, halves +16 B", {0, 2304, 16, 2320}, 144},
+        {"lanes 272 B apart, halves +16 B", {0, 4352, 16, 4368}, 272},
+        {"lanes 528 B apart, halves +16 B", {0, 8448, 16, 8464}, 528},
+        {"lanes 80 B apart, halves +16 B", {0, 1280, 16, 1296}, 80},
+        {"lanes 48 B apart, halves +16 B", {0, 768, 16, 784}, 48},
+        {"lanes 32 B apart, halves +16 B", {0, 512, 16, 528}, 32},
     };
     const int iters = 2000;
     for (auto& c : cases) {
