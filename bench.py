@@ -750,6 +750,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    dt_host = time.perf_counter() - t0          # all work enqueued (diagnostic: host-bound when ~ dt_local)
     barrier()
     dt_local = time.perf_counter() - t0
     planner_ms = None
@@ -807,6 +808,7 @@ def main():
                    'arithmetic': 'fp32 everywhere; the map CNN on the fp16 matrix cores with two-piece round-to-nearest operand splits '
                                  '(3 products per fp32 product, dropped terms <= 2^-24), fp32 accumulate'},
         'final_loss': float(loss.detach().cpu()),
+        'host_enqueue_ms_per_step': round(dt_host / args.steps * 1e3, 3),     # diagnostic: the host has queued everything by then
         'planner': None if planner_ms is None else planner_ms,
         'pipeline': dict(step.stats) if args.workload == 'full' else None,
         'per_rank': [{'rank': r, 'agents': a, 'ms_per_step': t, 'device': d, 'local_rank': lr} for r, a, t, d, lr in per_rank],

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define STRIVE_ABI_VERSION 11
+#define STRIVE_ABI_VERSION 12
 #define STRIVE_HID 128        /* hidden width of every MLP in the reference (models/common.py, interaction_net.py:32,41) */
 #define STRIVE_MAX_LAYERS 4
 #define STRIVE_ZDIM 32
@@ -373,6 +373,12 @@ size_t strive_map_cnn_param_count(void);
  * dx (rows, in).  The forward is recomputed from x. */
 int strive_mlp_bwd(const StriveMLP* mlp, const float* x, const float* dy, int32_t rows, float* dx, float* d_params,
                    strive_stream_t stream);
+
+/* Weight pack of one Linear layer (reference src/models/common.py:26-39 stores W (out, in)): w (M, K) fp32 on the device ->
+ * wt (K, M) fp32, wf / wbf = the two-piece fp16 fragments of w * scale / w^T * scale (StriveMLP.wf / .wbf layout;
+ * (M+15)/16 * (K+31)/32 * 2 KiB and (K+15)/16 * (M+31)/32 * 2 KiB).  Any output may be NULL.  One launch: the training step
+ * re-packs every layer after each optimiser step. */
+int strive_pack_dense(const float* w, int32_t M, int32_t K, float scale, float* wt, void* wf, void* wbf, strive_stream_t stream);
 
 size_t strive_gnn_bwd_workspace_bytes(const StriveGNN* gnn, const StriveScenes* sc);
 

@@ -117,7 +117,7 @@ static __global__ __launch_bounds__(256) void edge_bwd_kernel(GNNDev g, GNNGradD
         if (WG) {
             // layer 0 is factorised: the relative-pose columns of its weight get d e1^T . rel here (NaN components were
             // replaced by 0 in L.rel, like the forward); the node columns and the bias follow in node1_bwd from dP / dQ
-            wgrad_lds(s_ga, HLD, H, L.rel, 4, 4, gr.edge.w[0] + (2 * D + 2 * g.NC), EIN, nullptr, nv, tid, 256);
+            wgrad_lds(s_ga, HLD, H, L.rel, 4, 4, gr.edge.w[0] + (2 * D + 2 * g.NC), EIN, nullptr, nv, tid, 256, gr.edge.jobs);
         }
         // per-edge outputs
         for (int i = tid; i < RB_EDGE * H; i += 256) {
@@ -264,10 +264,10 @@ static __global__ __launch_bounds__(256) void node1_bwd_kernel(GNNDev g, GNNGrad
         }
         __syncthreads();
         float* w0 = gr.edge.w[0];
-        wgrad_lds(s_dp, HLD, H, L.xs, xs_ld, D, w0, EIN, gr.edge.b[0], nrows, tid, 256);
-        wgrad_lds(s_dq, HLD, H, L.xs, xs_ld, D, w0 + D, EIN, nullptr, nrows, tid, 256);
-        wgrad_lds(s_dp, HLD, H, L.xs + D, xs_ld, g.NC, w0 + 2 * D, EIN, nullptr, nrows, tid, 256);
-        wgrad_lds(s_dq, HLD, H, L.xs + D, xs_ld, g.NC, w0 + 2 * D + g.NC, EIN, nullptr, nrows, tid, 256);
+        wgrad_lds(s_dp, HLD, H, L.xs, xs_ld, D, w0, EIN, gr.edge.b[0], nrows, tid, 256, gr.edge.jobs);
+        wgrad_lds(s_dq, HLD, H, L.xs, xs_ld, D, w0 + D, EIN, nullptr, nrows, tid, 256, gr.edge.jobs);
+        wgrad_lds(s_dp, HLD, H, L.xs + D, xs_ld, g.NC, w0 + 2 * D, EIN, nullptr, nrows, tid, 256, gr.edge.jobs);
+        wgrad_lds(s_dq, HLD, H, L.xs + D, xs_ld, g.NC, w0 + 2 * D + g.NC, EIN, nullptr, nrows, tid, 256, gr.edge.jobs);
     }
     __syncthreads();
     // adjoint of x: dP . W_e0[:, 0:D] + dQ . W_e0[:, D:2D] + update-MLP part

@@ -36,6 +36,35 @@ __global__ __launch_bounds__(256) void map_crop_u8_kernel(StriveMap map, const f
     }
 }
 
+// The same crop from the pixel-interleaved raster (one 32-bit word = the 4 layers of a pixel): a thread takes 4 consecutive
+// columns of a row -- 4 word loads instead of 16 byte loads -- and writes one 32-bit word per layer instead of 16 bytes one by
+// one (the byte-wise kernel above moves 67 MB for 256 crops at 0.24 TB/s).  grid = (L / 4, N), 256 threads = 4 rows x 64.
+__global__ __launch_bounds__(256) void map_crop_u8_px4_kernel(StriveMap map, const float* __restrict__ pos, Float4Host pmean,
+                                                                Float4Host pstd, const int32_t* __restrict__ mapix,
+                                                                uint8_t* __restrict__ out) {
+    const int n = blockIdx.y;
+    const int l = blockIdx.x * 4 + (threadIdx.x >> 6), w0 = (threadIdx.x & 63) * 4;
+    if (l >= map.L) return;
+    CropFrame fr = load_crop_frame(map, pos, pmean.v, pstd.v, mapix, n);
+    const uint32_t* px4 = reinterpret_cast<const uint32_t*>(map.raster_px4) + (size_t)mapix[n] * map.H * map.W;
+    const float ll = map.lwise[l];
+    for (int w = w0; w < map.Wc; w += 256) {
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int px, py;
+            crop_pixel(fr, ll, map.wwise[w + k], true, px, py);
+            v[k] = px4[(size_t)py * map.W + px];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t word = ((v[0] >> (8 * c)) & 255u) | (((v[1] >> (8 * c)) & 255u) << 8) | (((v[2] >> (8 * c)) & 255u) << 16) |
+                                  (((v[3] >> (8 * c)) & 255u) << 24);
+            *reinterpret_cast<uint32_t*>(out + (((size_t)n * 4 + c) * map.L + l) * map.Wc + w) = word;
+        }
+    }
+}
+
 extern "C" int strive_map_crop_u8(const StriveMap* map, const float* pos, const float* pos_mean4_host,
                                   const float* pos_std4_host, const int32_t* mapix, int32_t N, uint8_t* out,
                                   strive_stream_t stream) {
@@ -45,8 +74,13 @@ extern "C" int strive_map_crop_u8(const StriveMap* map, const float* pos, const 
     Float4Host m, s;
     memcpy(m.v, pos_mean4_host, 16);
     memcpy(s.v, pos_std4_host, 16);
-    dim3 grid((map->L + CROP_ROWS - 1) / CROP_ROWS, N);
-    hipLaunchKernelGGL(map_crop_u8_kernel, grid, dim3(256), 0, (hipStream_t)stream, *map, pos, m, s, mapix, out);
+    if (map->C == 4 && map->raster_px4 && map->Wc % 4 == 0) {
+        hipLaunchKernelGGL(map_crop_u8_px4_kernel, dim3((map->L + 3) / 4, N), dim3(256), 0, (hipStream_t)stream, *map, pos, m, s, mapix,
+                           out);
+    } else {
+        dim3 grid((map->L + CROP_ROWS - 1) / CROP_ROWS, N);
+        hipLaunchKernelGGL(map_crop_u8_kernel, grid, dim3(256), 0, (hipStream_t)stream, *map, pos, m, s, mapix, out);
+    }
     STRIVE_CHECK_LAUNCH();
     return 0;
 }

@@ -414,6 +414,7 @@ struct MLPGradDev {
     float* b[STRIVE_MAX_LAYERS];
     float* ln_g[STRIVE_MAX_LAYERS];
     float* ln_b[STRIVE_MAX_LAYERS];
+    struct WJobTable* jobs;       // deferred weight gradients (training rollout), or null: atomics
 };
 
 static inline size_t mlp_param_count(const StriveMLP& m) {
@@ -429,6 +430,7 @@ static inline size_t mlp_param_count(const StriveMLP& m) {
 static inline MLPGradDev mlp_grad_dev(const StriveMLP& m, float** flat) {
     MLPGradDev g;
     for (int l = 0; l < STRIVE_MAX_LAYERS; ++l) g.w[l] = g.b[l] = g.ln_g[l] = g.ln_b[l] = nullptr;
+    g.jobs = nullptr;
     if (!flat || !*flat) return g;
     float* p = *flat;
     for (int l = 0; l < m.nlayers; ++l) {
@@ -443,11 +445,56 @@ static inline MLPGradDev mlp_grad_dev(const StriveMLP& m, float** flat) {
     return g;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Deferred weight gradients (training rollout).  A 128 x 128 weight block costs a workgroup 64 atomic wave instructions per
+// layer whatever its row count, and at ~100 cycles each those were 2/3 of the reverse-sweep kernels' time (4 rows per
+// workgroup).  With a job table the kernels instead APPEND their (dL/d pre-activation, layer input) rows to a per-weight-block
+// tape -- two coalesced row copies -- and one product per block  dW += G^T A  over the rows of ALL steps follows the sweep
+// (wjobs_gemm_kernel).  Jobs are keyed by the dW pointer the call site passes; a site without a job keeps the atomic path.
+// ---------------------------------------------------------------------------------------------------------------------
+#define STRIVE_WJOBS_MAX 40
+struct WJobTable {
+    int n, overflow;
+    int count[STRIVE_WJOBS_MAX];          // rows appended so far
+    int OUT[STRIVE_WJOBS_MAX], IN[STRIVE_WJOBS_MAX], ldw[STRIVE_WJOBS_MAX], cap[STRIVE_WJOBS_MAX];
+    float* dW[STRIVE_WJOBS_MAX];
+    float* db[STRIVE_WJOBS_MAX];
+    float* G[STRIVE_WJOBS_MAX];           // (cap, OUT)
+    float* A[STRIVE_WJOBS_MAX];           // (cap, IN)
+};
+
 // dW[o * ldw + i] += sum_{r < nrows} g[r][o] * a[r][i]   (o < OUT, i < IN; dW in torch (out, in) layout, possibly a column
 // block of a wider matrix: ldw = its full row length);  db[o] += sum_r g[r][o]  (db may be null).
 // Lanes run over consecutive i of one output row, so the atomics of a wave hit consecutive addresses.
+// Called by all threads of the workgroup (with `jobs` it synchronises).
 __device__ __forceinline__ void wgrad_lds(const float* g, int g_ld, int OUT, const float* a, int a_ld, int IN, float* dW,
-                                          int ldw, float* db, int nrows, int tid, int nthreads) {
+                                          int ldw, float* db, int nrows, int tid, int nthreads, WJobTable* jobs = nullptr) {
+    if (jobs) {
+        __shared__ int s_job[2];
+        if (tid == 0) {
+            int j = -1, row0 = 0;
+            for (int k = 0; k < jobs->n; ++k)
+                if (jobs->dW[k] == dW) { j = k; break; }
+            if (j >= 0 && nrows > 0) {
+                row0 = atomicAdd(&jobs->count[j], nrows);
+                if (row0 + nrows > jobs->cap[j]) { jobs->overflow = 1; row0 = -1; }      // cannot happen by construction; loud if it does
+            }
+            s_job[0] = j;
+            s_job[1] = row0;
+        }
+        __syncthreads();
+        const int j = s_job[0], row0 = s_job[1];
+        __syncthreads();
+        if (j >= 0) {
+            if (row0 >= 0) {
+                float* G = jobs->G[j] + (size_t)row0 * OUT;
+                float* A = jobs->A[j] + (size_t)row0 * IN;
+                for (int i = tid; i < nrows * OUT; i += nthreads) { const int r = i / OUT, o = i - r * OUT; G[i] = g[r * g_ld + o]; }
+                for (int i = tid; i < nrows * IN; i += nthreads) { const int r = i / IN, c = i - r * IN; A[i] = a[r * a_ld + c]; }
+            }
+            return;
+        }
+    }
     for (int item = tid; item < OUT * IN; item += nthreads) {
         const int o = item / IN, i = item - o * IN;
         float s = 0.f;
@@ -460,6 +507,72 @@ __device__ __forceinline__ void wgrad_lds(const float* g, int g_ld, int OUT, con
             for (int r = 0; r < nrows; ++r) s += g[r * g_ld + o];
             if (s != 0.f) unsafeAtomicAdd(&db[o], s);
         }
+    }
+}
+
+// dW += G^T A, db += column sums of G for every job: 64 x 64 tile of dW per workgroup, the rows split WJOBS_KSPLIT ways.
+// grid = (ceil(maxIN / 64), ceil(maxOUT / 64), n_jobs * WJOBS_KSPLIT)
+#define WJOBS_KSPLIT 16
+static __global__ __launch_bounds__(256) void wjobs_gemm_kernel(const WJobTable* __restrict__ T) {
+    __shared__ float Gs[16][68];
+    __shared__ float As[16][68];
+    const int job = blockIdx.z / WJOBS_KSPLIT, ks = blockIdx.z - job * WJOBS_KSPLIT;
+    if (job >= T->n) return;
+    const int OUT = T->OUT[job], IN = T->IN[job], ldw = T->ldw[job];
+    const int o0 = blockIdx.y * 64, i0 = blockIdx.x * 64;
+    if (o0 >= OUT || i0 >= IN) return;
+    int rows = T->count[job];
+    rows = rows < T->cap[job] ? rows : T->cap[job];
+    const int per = ((rows + WJOBS_KSPLIT - 1) / WJOBS_KSPLIT + 15) / 16 * 16;
+    const int k_begin = ks * per, k_end = (k_begin + per) < rows ? (k_begin + per) : rows;
+    if (k_begin >= k_end) return;
+    const float* G = T->G[job];
+    const float* A = T->A[job];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    float acc[4][4], bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = k_begin; k0 < k_end; k0 += 16) {
+        for (int e = tid; e < 16 * 64; e += 256) {
+            const int mm = e & 63, kk = e >> 6;
+            const int k = k0 + kk;
+            Gs[kk][mm] = (k < k_end && o0 + mm < OUT) ? G[(size_t)k * OUT + o0 + mm] : 0.f;
+            As[kk][mm] = (k < k_end && i0 + mm < IN) ? A[(size_t)k * IN + i0 + mm] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float gv[4], av[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gv[i] = Gs[kk][ty + 16 * i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av[j] = As[kk][tx + 16 * j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bsum[i] += gv[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(gv[i], av[j], acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+    float* dW = T->dW[job];
+    const bool bad = T->overflow != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int o = o0 + ty + 16 * i;
+        if (o >= OUT) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = i0 + tx + 16 * j;
+            if (c < IN) {
+                const float v = bad ? __int_as_float(0x7fc00000) : acc[i][j];
+                if (v != 0.f) unsafeAtomicAdd(&dW[(size_t)o * ldw + c], v);
+            }
+        }
+        if (T->db[job] && blockIdx.x == 0 && tx == 0 && bsum[i] != 0.f) unsafeAtomicAdd(&T->db[job][o], bsum[i]);
     }
 }
 
@@ -488,7 +601,7 @@ __device__ __forceinline__ void mlp_backward_lds(const MLPDev& m, const float* p
             // this layer's input = relu(layer_norm(pre[l-1])), re-derived into `act`
             ln_relu_rows<RB>(p, HLD, act, HLD, m.dims[l], m.ln_g[l - 1], m.ln_b[l - 1], tid, nthreads);
             __syncthreads();
-            wgrad_lds(g, g_ld, m.dims[l + 1], act, HLD, m.dims[l], grads->w[l], m.dims[l], grads->b[l], nrows, tid, nthreads);
+            wgrad_lds(g, g_ld, m.dims[l + 1], act, HLD, m.dims[l], grads->w[l], m.dims[l], grads->b[l], nrows, tid, nthreads, grads->jobs);
         }
         // gradient w.r.t. the post-ReLU activation feeding layer l: gb = g * W_l   (W_l torch layout (out,in))
         dense_any<RB, false>(g, g_ld, m.dims[l + 1], m.w[l], m.dims[l], m.wbf[l], m.wsc[l], nullptr, gb, HLD, m.dims[l], tid,
@@ -501,7 +614,7 @@ __device__ __forceinline__ void mlp_backward_lds(const MLPDev& m, const float* p
         g_ld = HLD;
     }
     if (!skip_first) {
-        if (wg) wgrad_lds(g, g_ld, m.dims[1], in, in_ld, m.dims[0], grads->w[0], m.dims[0], grads->b[0], nrows, tid, nthreads);
+        if (wg) wgrad_lds(g, g_ld, m.dims[1], in, in_ld, m.dims[0], grads->w[0], m.dims[0], grads->b[0], nrows, tid, nthreads, grads->jobs);
         if (din) {
             dense_any<RB, false>(g, g_ld, m.dims[1], m.w[0], m.dims[0], m.wbf[0], m.wsc[0], nullptr, din, din_ld, m.dims[0], tid,
                                  nthreads);

@@ -201,3 +201,69 @@ extern "C" int strive_gnn_bwd(const StriveGNN* gnn, const StriveScenes* sc, cons
     STRIVE_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Weight pack of one Linear layer in one launch (the training step re-packs every layer after the optimiser step; as torch
+// tensor ops that was ~22 launches per layer): w (M, K) fp32 ->
+//   wt  (K, M) fp32                                   the transpose the vector-ALU path streams
+//   wf  fragments of  w  * scale                      [row tile][k-step][piece][lane][8 x fp16]   (StriveMLP.wf)
+//   wbf fragments of  w^T * scale                     the same layout for the transposed matrix   (StriveMLP.wbf)
+// with the two-piece split of strive_hip.h: p0 = fp16(v) to nearest even, p1 = fp16(v - p0).  Any output may be null.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pack_split8(const float v[8], uint4& p0, uint4& p1) {
+    uint32_t h[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const _Float16 a = (_Float16)v[i];
+        const _Float16 c = (_Float16)(v[i] - (float)a);
+        uint16_t ab, cb;
+        __builtin_memcpy(&ab, &a, 2);
+        __builtin_memcpy(&cb, &c, 2);
+        h[i] = ab;
+        l[i] = cb;
+    }
+    p0 = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    p1 = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+// fragments of the (R, C) matrix a[r][c] = src[r * rs + c * cs]; thread = (tile, step, lane): both pieces
+__device__ __forceinline__ void pack_fragments(const float* __restrict__ src, int R, int C, int rs, int cs, float scale,
+                                               uint4* __restrict__ out, int idx) {
+    const int KS = (C + 31) / 32;
+    const int lane = idx & 63, t1 = idx >> 6;
+    const int step = t1 % KS, tile = t1 / KS;
+    const int r = tile * 16 + (lane & 15), c0 = step * 32 + 8 * (lane >> 4);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (r < R && c0 + j < C) ? src[(size_t)r * rs + (size_t)(c0 + j) * cs] * scale : 0.f;
+    uint4 p0, p1;
+    pack_split8(v, p0, p1);
+    uint4* o = out + ((size_t)(tile * KS + step) * 2) * 64 + lane;
+    o[0] = p0;
+    o[64] = p1;
+}
+
+static __global__ __launch_bounds__(256) void pack_dense_kernel(const float* __restrict__ w, int M, int K, float scale,
+                                                                  float* __restrict__ wt, uint4* __restrict__ wf, uint4* __restrict__ wbf) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int nf = ((M + 15) / 16) * ((K + 31) / 32) * 64, nb = ((K + 15) / 16) * ((M + 31) / 32) * 64;
+    if (wf && idx < nf) pack_fragments(w, M, K, K, 1, scale, wf, idx);
+    if (wbf && idx < nb) pack_fragments(w, K, M, 1, K, scale, wbf, idx);
+    if (wt && idx < M * K) {
+        const int k = idx / M, m = idx - k * M;
+        wt[idx] = w[(size_t)m * K + k];
+    }
+}
+
+extern "C" int strive_pack_dense(const float* w, int32_t M, int32_t K, float scale, float* wt, void* wf, void* wbf,
+                                 strive_stream_t stream) {
+    STRIVE_CHECK_ARG(w && M > 0 && K > 0, "bad argument");
+    const int nf = ((M + 15) / 16) * ((K + 31) / 32) * 64, nb = ((K + 15) / 16) * ((M + 31) / 32) * 64;
+    int n = M * K;
+    n = nf > n ? nf : n;
+    n = nb > n ? nb : n;
+    hipLaunchKernelGGL(pack_dense_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, M, K, scale, wt, (uint4*)wf,
+                       (uint4*)wbf);
+    STRIVE_CHECK_LAUNCH();
+    return 0;
+}

@@ -35,6 +35,7 @@ struct GRUGradDev {
     float* bih[3];
     float* bhh[3];
     bool on;
+    WJobTable* jobs;        // deferred weight gradients (see mlp_dev.h), or null
 };
 
 static inline size_t gru_param_count() {
@@ -46,6 +47,7 @@ static inline size_t gru_param_count() {
 static inline GRUGradDev gru_grad_dev(float* flat) {
     GRUGradDev d;
     d.on = flat != nullptr;
+    d.jobs = nullptr;
     float* p = flat;
     for (int l = 0; l < 3; ++l) {
         const int in = l == 0 ? 4 : 64;
@@ -545,8 +547,8 @@ static __global__ __launch_bounds__(256) void gru_bwd_kernel(GRUDev gru, GRUGrad
             // dW_ih = d gi^T . x_l,  dW_hh = d gh^T . h_l  (x_l = the layer below's forward output, still intact in s_hn[l-1])
             const int nrows = (R - r0) < RB_NODE ? (R - r0) : RB_NODE;
             const float* xl = (l == 0) ? s_x : s_hn + (size_t)(l - 1) * RB_NODE * 64;
-            wgrad_lds(s_gi, GLD, GLD, xl, l == 0 ? 4 : 64, xin, gg.wih[l], xin, gg.bih[l], nrows, tid, 256);
-            wgrad_lds(s_gh, GLD, GLD, h, 64, 64, gg.whh[l], 64, gg.bhh[l], nrows, tid, 256);
+            wgrad_lds(s_gi, GLD, GLD, xl, l == 0 ? 4 : 64, xin, gg.wih[l], xin, gg.bih[l], nrows, tid, 256, gg.jobs);
+            wgrad_lds(s_gh, GLD, GLD, h, 64, 64, gg.whh[l], 64, gg.bhh[l], nrows, tid, 256, gg.jobs);
         }
         // adjoint of the hidden input: dh*z + dgh * W_hh ; adjoint of the layer input: dgi * W_ih
         dense_lds<RB_NODE, true>(s_gh, GLD, GLD, gru.whh[l], 64, nullptr, s_hn + (size_t)l * RB_NODE * 64, 64, 64, tid, 256);
@@ -703,6 +705,8 @@ struct TrainOut {
     // sweep waits for it, and one call over 11 x more samples fills the chip where 11 calls of R = 64 samples were latency-bound.
     float* g_mf_all;       // (FT, R, 64)
     int32_t* mapix_all;    // (FT - 1, R)
+    WJobTable* jobs;       // deferred weight gradients of decoder_net / decoder_memory (mlp_dev.h), device copy ...
+    float* wtape;          // ... and its row tapes
     void* cnn_ws;
     size_t cnn_ws_bytes;
 };
@@ -725,6 +729,68 @@ static __global__ void rollout_init_bwd_kernel(const float* __restrict__ g_pf, c
     d_map_feat[i] = g_mf[i];
 }
 
+// ---- job table of the deferred weight gradients: one job per weight block the reverse sweep touches ----
+struct WJobsPlan {
+    WJobTable t;
+    size_t tape_floats;
+    int max_in, max_out;
+};
+
+static void wjobs_add(WJobsPlan& p, float* tape, float* dW, float* db, int OUT, int IN, int ldw, int cap) {
+    if (!dW || OUT <= 0 || IN <= 0 || p.t.n >= STRIVE_WJOBS_MAX) return;
+    const int j = p.t.n++;
+    p.t.count[j] = 0;
+    p.t.OUT[j] = OUT; p.t.IN[j] = IN; p.t.ldw[j] = ldw; p.t.cap[j] = cap;
+    p.t.dW[j] = dW; p.t.db[j] = db;
+    p.t.G[j] = tape + p.tape_floats; p.tape_floats += (size_t)cap * OUT;
+    p.t.A[j] = tape + p.tape_floats; p.tape_floats += (size_t)cap * IN;
+    p.max_in = IN > p.max_in ? IN : p.max_in;
+    p.max_out = OUT > p.max_out ? OUT : p.max_out;
+}
+
+static void wjobs_add_mlp(WJobsPlan& p, float* tape, const StriveMLP& m, const MLPGradDev& g, int cap, bool skip_first) {
+    for (int l = skip_first ? 1 : 0; l < m.nlayers; ++l) wjobs_add(p, tape, g.w[l], g.b[l], m.dims[l + 1], m.dims[l], m.dims[l], cap);
+}
+
+// rows: every node job gets R rows per step, every edge job at most R (max_n - 1)
+static WJobsPlan wjobs_plan(const StriveGNN& g, const GNNGradDev& gr, const GRUGradDev& gg, float* tape, size_t R, int max_n, int FT) {
+    WJobsPlan p;
+    memset(&p.t, 0, sizeof(p.t));
+    p.tape_floats = 0; p.max_in = 1; p.max_out = 1;
+    const int node_cap = (int)(R * FT), edge_cap = (int)(R * (size_t)(max_n > 1 ? max_n : 1) * FT);
+    wjobs_add_mlp(p, tape, g.mlp_in, gr.mlp_in, node_cap, false);
+    wjobs_add_mlp(p, tape, g.update, gr.update, node_cap, false);
+    wjobs_add_mlp(p, tape, g.mlp_out, gr.mlp_out, node_cap, false);
+    wjobs_add_mlp(p, tape, g.edge, gr.edge, edge_cap, true);
+    // the factorised layer 0 of the edge network: [x_i | x_j | sem_i | sem_j | rel] column blocks (gnn_bwd_kernels.h)
+    const int D = g.D, NC = g.NC, H = STRIVE_HID, EIN = g.edge.dims[0];
+    float* w0 = gr.edge.w[0];
+    if (w0) {
+        wjobs_add(p, tape, w0, gr.edge.b[0], H, D, EIN, node_cap);
+        wjobs_add(p, tape, w0 + D, nullptr, H, D, EIN, node_cap);
+        wjobs_add(p, tape, w0 + 2 * D, nullptr, H, NC, EIN, node_cap);
+        wjobs_add(p, tape, w0 + 2 * D + NC, nullptr, H, NC, EIN, node_cap);
+        wjobs_add(p, tape, w0 + 2 * D + 2 * NC, nullptr, H, 4, EIN, edge_cap);
+    }
+    for (int l = 0; l < 3; ++l) {
+        const int xin = l == 0 ? 4 : 64;
+        wjobs_add(p, tape, gg.wih[l], gg.bih[l], GLD, xin, xin, node_cap);
+        wjobs_add(p, tape, gg.whh[l], gg.bhh[l], GLD, 64, 64, node_cap);
+    }
+    return p;
+}
+
+static size_t wjobs_tape_floats(const StriveGNN& g, size_t R, int max_n, int FT) {
+    float* fake = reinterpret_cast<float*>(uintptr_t(1) << 20);      // (planning only: nothing is dereferenced)
+    const GNNGradDev gr = gnn_grad_dev(g, fake);
+    const GRUGradDev gg = gru_grad_dev(fake);
+    return wjobs_plan(g, gr, gg, fake, R, max_n, FT).tape_floats;
+}
+
+static __global__ void wjobs_upload_kernel(WJobTable* dst, WJobTable src) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = src;
+}
+
 template <bool WG>
 int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const float* lw, const float* sem, const float* z,
                      const float* ext_future, int32_t FT, const float* d_traj, float* dz, const void* tape, size_t tape_bytes,
@@ -745,8 +811,16 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
 
     const GNNDev gd = gnn_dev(dec->gnn);
     const GRUDev gr = gru_dev(dec->gru);
-    const GNNGradDev ggn = gnn_grad_dev(dec->gnn, tr ? tr->d_gnn : nullptr);
-    const GRUGradDev ggr = gru_grad_dev(tr ? tr->d_gru : nullptr);
+    GNNGradDev ggn = gnn_grad_dev(dec->gnn, tr ? tr->d_gnn : nullptr);
+    GRUGradDev ggr = gru_grad_dev(tr ? tr->d_gru : nullptr);
+    WJobsPlan plan;
+    plan.t.n = 0;
+    if (tr && tr->jobs) {
+        plan = wjobs_plan(dec->gnn, ggn, ggr, tr->wtape, R, sc->max_n, FT);
+        hipLaunchKernelGGL(wjobs_upload_kernel, dim3(1), dim3(64), 0, stream, tr->jobs, plan.t);
+        ggn.mlp_in.jobs = ggn.edge.jobs = ggn.update.jobs = ggn.mlp_out.jobs = tr->jobs;
+        ggr.jobs = tr->jobs;
+    }
     const DynParams dp = dyn_params(*dec);
     const ScenesDev sd = scenes_dev(*sc);
     const int NC = dec->gnn.NC;
@@ -787,6 +861,9 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
         a1.sem = sem; a1.PRE_IN = tp.PRE_IN_t(t); a1.X = g2.X; a1.g_pos = g_pos; a1.g_full = nullptr; a1.g_pf = g_pf; a1.g_mf = tr ? tr->g_mf_all + (size_t)t * R * 64 : nullptr; a1.dz = dz;
         hipLaunchKernelGGL(node1_bwd_kernel<WG>, dim3(nb), dim3(256), node1_bwd_lds_bytes(in_ld1, xs_ld), stream, gd, ggn, sd, f, a1);
     }
+    if (tr && tr->jobs && plan.t.n > 0)
+        hipLaunchKernelGGL(wjobs_gemm_kernel, dim3((plan.max_in + 63) / 64, (plan.max_out + 63) / 64, plan.t.n * WJOBS_KSPLIT), dim3(256), 0,
+                           stream, tr->jobs);
     if (tr && FT > 1) {
         // map_feat_t = CNN(crop(pos_t.detach())), t = 1 .. FT-1 (reference traffic_model.py:694-695): the adjoints reach the CNN
         // weights; positions (FT, R, 4) and adjoints (FT, R, 64) are contiguous over the steps
@@ -830,7 +907,8 @@ extern "C" size_t strive_rollout_train_workspace_bytes(const StriveDecoder* dec,
     if (!sc) return 0;
     const size_t R = (size_t)sc->NA * sc->NS, steps = FT > 1 ? (size_t)(FT - 1) : 1;
     return strive_rollout_workspace_bytes(dec, sc, FT) + strive_align_up(strive_map_cnn_bwd_workspace_bytes((int32_t)(steps * R)), 256) +
-           strive_align_up((size_t)FT * R * 64 * 4, 256) + strive_align_up(steps * R * 4, 256);
+           strive_align_up((size_t)FT * R * 64 * 4, 256) + strive_align_up(steps * R * 4, 256) +
+           strive_align_up(sizeof(WJobTable), 256) + strive_align_up(wjobs_tape_floats(dec->gnn, R, sc->max_n, FT) * 4, 256);
 }
 
 extern "C" size_t strive_gnn_param_count(const StriveGNN* gnn) { return gnn ? gnn_param_count(*gnn) : 0; }
@@ -861,6 +939,11 @@ extern "C" int strive_rollout_bwd_train(const StriveDecoder* dec, const StriveSc
         p += strive_align_up((size_t)FT * R * 64 * 4, 256);
         tr.mapix_all = (int32_t*)p;
         p += strive_align_up(steps * R * 4, 256);
+        static const bool atomics_only = getenv("STRIVE_WGRAD_ATOMICS") != nullptr;      // A/B switch: no deferred weight gradients
+        tr.jobs = atomics_only ? nullptr : (WJobTable*)p;
+        p += strive_align_up(sizeof(WJobTable), 256);
+        tr.wtape = (float*)p;
+        p += strive_align_up(wjobs_tape_floats(dec->gnn, R, sc->max_n, FT) * 4, 256);
         tr.cnn_ws = p;
         tr.cnn_ws_bytes = ws_bytes - (size_t)(p - (char*)ws);
     }

@@ -86,6 +86,16 @@ def _layout_gather(pieces, key, build_index):
     return flat.index_select(0, idx)
 
 
+def _pack_lib(t):
+    """The library for the one-launch pack kernels: device tensors (or the test emulation); host tensors without it keep the
+    torch layout code below (same bytes)."""
+    from . import ops
+    try:
+        return ops._lib_for(t)
+    except L.StriveHipError:
+        return None
+
+
 def dense_fragments(a, scale):
     """(M, K) fp32 matrix -> int32 tensor of its two-piece fp16 split (scaled by ``scale``) in the operand order of
     v_mfma_f32_16x16x32_f16 (include/strive_hip.h StriveMLP.wf): [row tile][k-step][piece][lane][8 x fp16]."""
@@ -117,15 +127,32 @@ def _fill_mlp(s, holder, sd, prefix):
             dims.append(w.shape[1])
         dims.append(w.shape[0])
         s.w[k] = holder.hold(w)
-        s.wt[k] = holder.hold(w.t().contiguous())
         s.b[k] = holder.hold(b)
         # matrix-core operands (csrc/mlp_dev.h dense_mfma); STRIVE_DENSE_VALU=1 withholds them (A/B measurements: the
         # layers then run on the vector ALUs in fp32 from w / wt)
-        if w.shape[0] >= 32 and w.shape[1] >= 32 and os.environ.get('STRIVE_DENSE_VALU', '0') != '1':
-            sc = _pow2_scale(_checked_absmax(w, 'dense layer'))
-            s.wsc[k] = sc
-            s.wf[k] = holder.hold(dense_fragments(w, sc))
-            s.wbf[k] = holder.hold(dense_fragments(w.t().contiguous(), sc))
+        frag = w.shape[0] >= 32 and w.shape[1] >= 32 and os.environ.get('STRIVE_DENSE_VALU', '0') != '1'
+        sc = _pow2_scale(_checked_absmax(w, 'dense layer')) if frag else 1.0
+        lib = _pack_lib(w)
+        if lib is not None:
+            # transpose + both fragment tables in ONE launch (strive_pack_dense)
+            M, K = w.shape
+            wt = torch.empty((K, M), dtype=torch.float32, device=w.device)
+            s.wt[k] = holder.hold(wt)
+            wf = wbf = None
+            if frag:
+                wf = torch.empty((((M + 15) // 16) * ((K + 31) // 32) * 512,), dtype=torch.int32, device=w.device)
+                wbf = torch.empty((((K + 15) // 16) * ((M + 31) // 32) * 512,), dtype=torch.int32, device=w.device)
+                s.wsc[k] = sc
+                s.wf[k] = holder.hold(wf)
+                s.wbf[k] = holder.hold(wbf)
+            lib.call('strive_pack_dense', L.ptr(w), M, K, sc, L.ptr(wt), L.ptr(wf) if frag else None, L.ptr(wbf) if frag else None,
+                     L.stream_ptr(w))
+        else:
+            s.wt[k] = holder.hold(w.t().contiguous())
+            if frag:
+                s.wsc[k] = sc
+                s.wf[k] = holder.hold(dense_fragments(w, sc))
+                s.wbf[k] = holder.hold(dense_fragments(w.t().contiguous(), sc))
         gk = prefix + '.net.%d.weight' % (3 * k + 1)
         if gk in sd:
             s.ln_g[k] = holder.hold(_c(sd[gk]))
@@ -341,13 +368,19 @@ def pack_map(map_env, device):
     return p
 
 
-def pack_decoder(sd, NC, map_env, device, state_norm, att_norm, bike):
-    """state_norm / att_norm: objects with mean_vals/std_vals (MeanStdNormalizer API); bike: dict."""
+def pack_decoder(sd, NC, map_env, device, state_norm, att_norm, bike, cnn=None):
+    """state_norm / att_norm: objects with mean_vals/std_vals (MeanStdNormalizer API); bike: dict; ``cnn``: an up-to-date
+    pack_cnn() of the same parameters to share (its tensors are kept alive by the returned pack) instead of packing the map
+    CNN a second time."""
     p = Packed(L.StriveDecoder())
     s = p.struct
     _fill_gnn(s.gnn, p, sd, 'decoder_net', NC)
     _fill_gru(s.gru, p, sd, 'decoder_memory')
-    _fill_cnn(s.cnn, p, sd)
+    if cnn is not None:
+        C.memmove(C.byref(s.cnn), C.byref(cnn.struct), C.sizeof(L.StriveCNN))
+        p.keep.append(cnn)
+    else:
+        _fill_cnn(s.cnn, p, sd)
     _fill_map(s.map, p, map_env, device)
     for i in range(6):
         s.state_mean[i] = float(state_norm.mean_vals[i])
