@@ -59,12 +59,24 @@ struct DgM {
     static constexpr int ROWS = RB + PAD, PW = OH + 2 * PAD;
     static constexpr int ENTRIES = S * NOCT * ROWS * PW, PIECE_B = ENTRIES * 16;
     static constexpr size_t LDS_BYTES = 2 * (size_t)PIECE_B;
-    static constexpr int NTILE = (S * RB * NYC + 31) / 32, PT = (NTILE + 3) / 4;
+    // pixel tiles: both column-parity classes of a row parity share ONE linearisation (sample, row, ix2 < NYC), so that a lane
+    // holds horizontally adjacent input pixels (2 ix2, 2 ix2 + 1) and stores them back to back: the stride-2 stores of one
+    // class alone left half-written 128-byte lines for the other class to complete much later (layer 1 writes 256 MB per 256
+    // samples; that, not the matrix work, bounded it)
+    static constexpr int NTILE = (S * RB * NYC + 31) / 32;
+    // which tiles a wave takes: every 4th tile of all four classes (all four waves then stream ALL weight fragments: 400 KB of
+    // L2 reads per workgroup for layer 2, that kernel's bound), or -- WAVE_CLASS -- all tiles of ONE class (each fragment is read
+    // by one wave; the classes have 9 / 6 / 6 / 4 taps, so the matrix work is less balanced, and the two column parities are
+    // stored by different waves).  Measured per 256 samples: layer 2 185 us -> 105 us (137 us with one row parity per wave pair);
+    // layer 1, bound by its 256 MB of output, 236 -> 271 us with WAVE_CLASS and 214 us with the paired stores.
+    static constexpr bool WAVE_CLASS = L == 2;
+    static constexpr int PT = WAVE_CLASS ? NTILE : (NTILE + 3) / 4;
     static constexpr int STEP_Q = CB * 2 * 64;                           // uint4 per (tap, 16 output channels): [cb][piece][lane]
     // the small layers have few (sample group, band) units: their workgroups also split over the parity classes and the blocks
     // of 32 input channels (grid.y), so that 64 samples still make > 100 workgroups
     static constexpr bool CLS_SPLIT = L >= 4;
     static constexpr int CBW = L == 5 ? 1 : CB, NSPLIT = (CLS_SPLIT ? 4 : 1) * (CB / CBW);
+    static constexpr int Q00 = ((KS + 1) / 2) * ((KS + 1) / 2), Q01 = ((KS + 1) / 2) * (KS / 2), Q10 = Q01;   // taps per class
     static constexpr size_t WFRAG_Q = (size_t)KS * KS * NG * STEP_Q;
     static_assert(LDS_BYTES <= 66 * 1024 && COUT % 16 == 0, "tile budget");
 };
@@ -118,35 +130,19 @@ static __global__ __launch_bounds__(256) void dgrad_pack_kernel(DgradPackArgs ar
     out[q] = piece ? lo : hi;
 }
 
+// matrix steps of one parity class for the wave's tiles
 template <int L, int PY, int PX>
-__device__ __forceinline__ void dgrad_class(const unsigned char* __restrict__ s_dy, const uint4* __restrict__ wf, float* __restrict__ gin,
-                                            int n0, int ns, int r0, int lane, int wave, int cb0) {
+__device__ __forceinline__ void dgrad_accum(f32x16 (&acc)[DgM<L>::PT][DgM<L>::CBW], const int (&ent0)[DgM<L>::PT],
+                                            const unsigned char* __restrict__ s_dy, const uint4* __restrict__ wl, int tfirst,
+                                            int tstride) {
     using T = DgM<L>;
-    constexpr int NY = (T::IH - PY + 1) / 2, NX = (T::IH - PX + 1) / 2, NA = (T::KS - PY + 1) / 2, NB = (T::KS - PX + 1) / 2;
-    constexpr int NPIX = T::S * T::RB * NX, NTILE = (NPIX + 31) / 32;
-    const int h = lane >> 5, j = lane & 31;
-    // this lane's pixel in each of the wave's tiles
-    int ent0[T::PT], gofs[T::PT];
-    bool valid[T::PT];
-#pragma unroll
-    for (int i = 0; i < T::PT; ++i) {
-        const int p = (wave + 4 * i) * 32 + j;
-        const int ss = p / (T::RB * NX), rem = p - ss * (T::RB * NX);
-        const int ry = rem / NX, ix2 = rem - ry * NX;
-        valid[i] = p < NPIX && ss < ns && r0 + ry < NY;
-        const int ss_c = valid[i] ? ss : 0, ry_c = valid[i] ? ry : 0, ix_c = valid[i] ? ix2 : 0;
-        ent0[i] = ((ss_c * T::NOCT + h) * T::ROWS + (ry_c + T::PAD)) * T::PW + (ix_c + T::PAD);
-        gofs[i] = (((n0 + ss_c) * T::CIN) * T::IH + 2 * (r0 + ry_c) + PY) * T::IH + 2 * ix_c + PX;
-    }
-    if (wave >= NTILE) return;                                   // (wave-uniform: nothing to do for this class)
-    f32x16 acc[T::PT][T::CBW];
+    constexpr int NA = (T::KS - PY + 1) / 2, NB = (T::KS - PX + 1) / 2;
 #pragma unroll
     for (int i = 0; i < T::PT; ++i)
 #pragma unroll
         for (int c = 0; c < T::CBW; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.f;
-    const uint4* wl = wf + cb0 * 128 + lane;
     // one loop over (tap, 16 output channels), unrolled by four: the weight-fragment loads of four steps go out together (an L2
     // round trip per step, ~1 us under load, is what a rolled loop costs)
 #pragma unroll 4
@@ -162,7 +158,7 @@ __device__ __forceinline__ void dgrad_class(const unsigned char* __restrict__ s_
         }
 #pragma unroll
         for (int i = 0; i < T::PT; ++i) {
-            if (wave + 4 * i < NTILE) {
+            if (tfirst + i * tstride < T::NTILE) {               // (scalar)
                 const int ent = ent0[i] + 2 * g * T::ROWS * T::PW - (a * T::PW + b);
                 const uint4 b0 = *reinterpret_cast<const uint4*>(s_dy + (size_t)ent * 16);
                 const uint4 b1 = *reinterpret_cast<const uint4*>(s_dy + T::PIECE_B + (size_t)ent * 16);
@@ -171,15 +167,48 @@ __device__ __forceinline__ void dgrad_class(const unsigned char* __restrict__ s_
             }
         }
     }
+}
+
+// both column parities (pxmask: bit 0 = even columns, bit 1 = odd) of input rows of parity PY, for tiles tfirst + i tstride
+template <int L, int PY, int pxmask>
+__device__ __forceinline__ void dgrad_rows(const unsigned char* __restrict__ s_dy, const uint4* __restrict__ wfrag, float* __restrict__ gin,
+                                           int n0, int ns, int r0, int lane, int cb0, int tfirst, int tstride) {
+    using T = DgM<L>;
+    constexpr int NY = (T::IH - PY + 1) / 2, NX0 = (T::IH + 1) / 2, NX1 = T::IH / 2;
+    constexpr int NPIX = T::S * T::RB * T::NYC;
+    if (tfirst >= T::NTILE) return;                               // (scalar)
+    const int h = lane >> 5, j = lane & 31;
+    int ent0[T::PT], gofs[T::PT];
+    bool valid0[T::PT], valid1[T::PT];
 #pragma unroll
     for (int i = 0; i < T::PT; ++i) {
-        if (!valid[i]) continue;
+        const int p = (tfirst + i * tstride) * 32 + j;
+        const int ss = p / (T::RB * T::NYC), rem = p - ss * (T::RB * T::NYC);
+        const int ry = rem / T::NYC, ix2 = rem - ry * T::NYC;
+        const bool v = p < NPIX && ss < ns && r0 + ry < NY;
+        valid0[i] = v && ix2 < NX0 && (pxmask & 1);
+        valid1[i] = v && ix2 < NX1 && (pxmask & 2);
+        const int ss_c = v ? ss : 0, ry_c = v ? ry : 0, ix_c = v ? ix2 : 0;
+        ent0[i] = ((ss_c * T::NOCT + h) * T::ROWS + (ry_c + T::PAD)) * T::PW + (ix_c + T::PAD);
+        gofs[i] = (((n0 + ss_c) * T::CIN) * T::IH + 2 * (r0 + ry_c) + PY) * T::IH + 2 * ix_c;
+    }
+    const uint4* w0 = wfrag + (size_t)(PY ? T::Q00 + T::Q01 : 0) * T::NG * T::STEP_Q + cb0 * 128 + lane;
+    const uint4* w1 = w0 + (size_t)(PY ? T::Q10 : T::Q00) * T::NG * T::STEP_Q;
+    f32x16 acc0[(pxmask & 1) ? T::PT : 1][T::CBW], acc1[(pxmask & 2) ? T::PT : 1][T::CBW];
+    if constexpr ((pxmask & 1) != 0) dgrad_accum<L, PY, 0>(acc0, ent0, s_dy, w0, tfirst, tstride);
+    if constexpr ((pxmask & 2) != 0) dgrad_accum<L, PY, 1>(acc1, ent0, s_dy, w1, tfirst, tstride);
+#pragma unroll
+    for (int i = 0; i < T::PT; ++i) {
 #pragma unroll
         for (int c = 0; c < T::CBW; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ci = (cb0 + c) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (ci < T::CIN) gin[(size_t)gofs[i] + (size_t)ci * T::IH * T::IH] = acc[i][c][r];
+                if (ci < T::CIN) {
+                    float* o = gin + (size_t)gofs[i] + (size_t)ci * T::IH * T::IH;
+                    if constexpr ((pxmask & 1) != 0) { if (valid0[i]) o[0] = acc0[i][c][r]; }
+                    if constexpr ((pxmask & 2) != 0) { if (valid1[i]) o[1] = acc1[i][c][r]; }
+                }
             }
     }
 }
@@ -217,17 +246,21 @@ static __global__ __launch_bounds__(256) void dgrad_mfma_kernel(const float* __r
             *reinterpret_cast<uint4*>(s_dy + T::PIECE_B + (size_t)e * 16) = lo;
         }
         __syncthreads();
-        constexpr int Q00 = ((T::KS + 1) / 2) * ((T::KS + 1) / 2), Q01 = ((T::KS + 1) / 2) * (T::KS / 2), Q10 = Q01;
-        const int cls_sel = T::CLS_SPLIT ? (int)(blockIdx.y & 3) : -1;
         const int cb0 = (int)(T::CLS_SPLIT ? blockIdx.y >> 2 : blockIdx.y) * T::CBW;
-        const uint4* wf = wfrag;
-        if (cls_sel < 0 || cls_sel == 0) dgrad_class<L, 0, 0>(s_dy, wf, gin, n0, ns, r0, lane, wave, cb0);
-        wf += (size_t)Q00 * T::NG * T::STEP_Q;
-        if (cls_sel < 0 || cls_sel == 1) dgrad_class<L, 0, 1>(s_dy, wf, gin, n0, ns, r0, lane, wave, cb0);
-        wf += (size_t)Q01 * T::NG * T::STEP_Q;
-        if (cls_sel < 0 || cls_sel == 2) dgrad_class<L, 1, 0>(s_dy, wf, gin, n0, ns, r0, lane, wave, cb0);
-        wf += (size_t)Q10 * T::NG * T::STEP_Q;
-        if (cls_sel < 0 || cls_sel == 3) dgrad_class<L, 1, 1>(s_dy, wf, gin, n0, ns, r0, lane, wave, cb0);
+        if (T::CLS_SPLIT || T::WAVE_CLASS) {
+            // one class per workgroup (small images: the workgroups of a unit split over the four classes) or per wave
+            const int cls = T::CLS_SPLIT ? (int)(blockIdx.y & 3) : wave;
+            const int tf = T::CLS_SPLIT ? wave : 0, ts = T::CLS_SPLIT ? 4 : 1;
+            switch (cls) {                                       // (scalar)
+                case 0: dgrad_rows<L, 0, 1>(s_dy, wfrag, gin, n0, ns, r0, lane, cb0, tf, ts); break;
+                case 1: dgrad_rows<L, 0, 2>(s_dy, wfrag, gin, n0, ns, r0, lane, cb0, tf, ts); break;
+                case 2: dgrad_rows<L, 1, 1>(s_dy, wfrag, gin, n0, ns, r0, lane, cb0, tf, ts); break;
+                default: dgrad_rows<L, 1, 2>(s_dy, wfrag, gin, n0, ns, r0, lane, cb0, tf, ts); break;
+            }
+        } else {
+            dgrad_rows<L, 0, 3>(s_dy, wfrag, gin, n0, ns, r0, lane, cb0, wave, 4);
+            dgrad_rows<L, 1, 3>(s_dy, wfrag, gin, n0, ns, r0, lane, cb0, wave, 4);
+        }
     }
 }
 

@@ -184,6 +184,7 @@ template <typename T> inline T __shfl(T v, int src, int width = 64) {
     int lane = hipemu_lane();
     return hipemu_exchange(v, (lane / width) * width + (src % width));
 }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline unsigned long long __ballot(int pred) {
     hipemu::Wave& w = hipemu_wave();
     int lane = hipemu_lane();
