@@ -34,7 +34,8 @@ class Packed(object):
 # ---- max |w| of parameter tensors: ONE device read-back for as many tensors as the caller can name up front ----
 # (the power-of-two operand scales are host scalars -- they are kernel arguments -- so each needs max |w| on the host; fetching
 #  them one by one was ~150 stream synchronisations per training step, where every pack is rebuilt after the optimiser step)
-_ABSMAX = {}
+_ABSMAX = {}          # key -> (value, tensor): the tensor reference keeps its storage alive, so an address is never reused by
+                      # another tensor while its entry exists (temporaries of non-fp32 parameters would otherwise alias)
 
 
 def _absmax_key(t):
@@ -48,15 +49,15 @@ def prefetch_absmax(tensors):
         t = t.detach()
         k = _absmax_key(t)
         if k not in _ABSMAX and t.numel() > 0 and k not in keys:
-            todo.append(t.to(torch.float32))
+            todo.append(t)
             keys.append(k)
     if not todo:
         return
-    if len(_ABSMAX) > 4096:
+    if len(_ABSMAX) + len(todo) > 2048:
         _ABSMAX.clear()
-    vals = torch.stack(torch._foreach_norm(todo, float('inf'))).tolist()
-    for k, v in zip(keys, vals):
-        _ABSMAX[k] = float(v)
+    vals = torch.stack(torch._foreach_norm([t.to(torch.float32) for t in todo], float('inf'))).tolist()
+    for k, v, t in zip(keys, vals, todo):
+        _ABSMAX[k] = (float(v), t)
 
 
 def absmax(t):
@@ -64,7 +65,8 @@ def absmax(t):
     k = _absmax_key(t)
     if k not in _ABSMAX:
         prefetch_absmax([t])
-    return _ABSMAX.get(k, 0.0)
+    ent = _ABSMAX.get(k)
+    return ent[0] if ent is not None else 0.0
 
 
 # ---- operand layouts as ONE gather: the layout code below runs once per shape on an index tensor (slot -> element of the

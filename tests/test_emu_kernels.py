@@ -611,3 +611,25 @@ def test_fused_losses_ragged_scenes(emu, monkeypatch):
     assert_close(res[1][1], res[0][1], 5e-3, 1e-5, 'adv d traj')
     assert_close(res[1][2], res[0][2], 5e-3, 1e-5, 'adv d tgt')
     assert_close(res[1][3], res[0][3], 1e-4, 1e-7, 'adv d z')
+
+
+def _pack_dense_case(lib, dev, M, K, key):
+    """strive_pack_dense against the torch layout code it replaces (params.dense_fragments): transpose and both fragment
+    tables, byte for byte."""
+    from strive_amd import params, _lib as L
+    w = synth.f32(synth.counter_uniform((M, K), key, -0.7, 0.7)).to(dev).contiguous()
+    sc = params._pow2_scale(float(w.abs().max()))
+    wt = torch.empty((K, M), dtype=torch.float32, device=dev)
+    wf = torch.empty((((M + 15) // 16) * ((K + 31) // 32) * 512,), dtype=torch.int32, device=dev)
+    wbf = torch.empty((((K + 15) // 16) * ((M + 31) // 32) * 512,), dtype=torch.int32, device=dev)
+    lib.call('strive_pack_dense', L.ptr(w), M, K, sc, L.ptr(wt), L.ptr(wf), L.ptr(wbf), L.stream_ptr(w))
+    if dev != 'cpu':
+        torch.cuda.synchronize()
+    assert torch.equal(wt, w.t().contiguous())
+    assert torch.equal(wf, params.dense_fragments(w, sc).reshape(-1))
+    assert torch.equal(wbf, params.dense_fragments(w.t().contiguous(), sc).reshape(-1))
+
+
+@pytest.mark.parametrize('M,K', [(128, 128), (64, 128), (128, 164), (192, 64), (32, 40), (2, 128), (128, 4)])
+def test_pack_dense_equals_torch_layout(emu, M, K):
+    _pack_dense_case(emu, 'cpu', M, K, 'pack/%d/%d' % (M, K))

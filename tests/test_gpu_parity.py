@@ -648,3 +648,12 @@ def test_fused_losses_are_bitwise_reproducible(model, g5):
     assert av._fused is not None and ad._fused is not None
     for a, b in zip(*runs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,K', [(128, 128), (64, 128), (128, 164), (192, 64), (2, 128)])
+def test_pack_dense_equals_torch_layout(M, K):
+    """the one-launch Linear pack (strive_pack_dense) writes the same bytes as the torch layout code"""
+    from test_emu_kernels import _pack_dense_case
+    from strive_amd import _lib as L
+    _pack_dense_case(L.get_lib(), DEV, M, K, 'pack/gpu/%d/%d' % (M, K))
