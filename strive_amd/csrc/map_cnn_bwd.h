@@ -3,17 +3,17 @@
 // pos.detach(), traffic_model.py:694, so dL/dz needs no CNN backward).
 //
 // Included at the end of map_cnn.hip (it re-uses the forward's workspace carve-up, GroupNorm statistics and layer table).
-// The forward of a chunk of samples is re-run to regenerate the raw convolution outputs y_l and their GroupNorm moments
-// (nothing is kept from the rollout's forward sweep: 1.76 MB per agent and step), then per layer, top down:
-//     GroupNorm(1)+ReLU backward in place on G_l   (moments from the forward's float64 partial sums)
+// One call takes ALL crops of a rollout's reverse sweep (the crop is data: nothing in the sweep waits for these gradients) in
+// chunks of BWD_CHUNK samples.  Per chunk the forward is re-run to regenerate the raw convolution outputs y_l and their
+// GroupNorm moments (nothing is kept from the rollout's forward sweep: 1.76 MB per agent and step), then per layer, top down:
+//     GroupNorm(1)+ReLU backward in place on G_l   (moments from the forward's float64 partial sums; gn_bwd_*_oct_kernel walk
+//                                                   the octet-planar activations in their own order)
 //     weight gradient   dW_l[co][ci][ky][kx] += sum_{n,oy,ox} dy_l[n][co][oy][ox] * a_{l-1}[n][ci][2 oy + ky][2 ox + kx]
 //     data gradient     G_{l-1}[n][ci][iy][ix] = sum_{co,ky,kx} dy_l[n][co][(iy-ky)/2][(ix-kx)/2] * W_l[co][ci][ky][kx]
-// Both convolution gradients are implicit GEMMs on one fp32 64 x 64 x 16 LDS-tiled kernel whose operand tiles are fetched
-// through small functors (im2col indexing, GroupNorm + ReLU of the layer input applied on the way in, like the forward does);
-// the stride-2 data gradient is split into the 4 input-pixel parity classes so that no multiply is spent on structurally
-// zero taps.  Weight gradients are split over K (samples x output pixels) and accumulated with fp32 atomics into the flat
-// gradient buffer (parameter order of the reference module).  This path is correct-first: fp32 FMA, not yet on the matrix
-// cores (DESIGN.md lists it under "next").
+// Both convolution gradients run on the matrix cores with two-piece bf16 operand splits (map_cnn_bwd_mfma.h).
+// The round-2 forms stay in this file as A/B switches: one fp32 64 x 64 x 16 LDS-tiled implicit GEMM whose operand tiles are
+// fetched through small functors (STRIVE_DGRAD_IGEMM / STRIVE_WGRAD_IGEMM), and the fp32 weight gradient with operands staged
+// once per tile (STRIVE_WGRAD_TILE).
 #pragma once
 
 namespace cnnbwd {
@@ -739,7 +739,7 @@ extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, co
                 launch_dgrad_mfma_layer(l, G[l], dfrag, G[l - 1], n, stream);
             } else if (l > 0) {
                 // (a staged fp32 data-gradient kernel in the style of wgrad_tile_kernel -- thread = input pixel, weights through
-                // the scalar cache -- was measured slower than this form: 2.19 vs 1.36 ms per 64-sample call, DESIGN.md 4.6 (p))
+                // the scalar cache -- was measured slower than this form: 2.19 vs 1.36 ms per 64-sample call, DESIGN.md 4.7)
                 DgradProb dp;
                 dp.d = d; dp.M = d.cin; dp.dy = G[l]; dp.w = cnn->w_torch[l]; dp.gin = G[l - 1];
                 const int nmax = ((d.ih + 1) / 2) * ((d.ih + 1) / 2);
