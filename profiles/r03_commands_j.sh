@@ -5,8 +5,6 @@ export TMPDIR=/tmp
 O=gpurun_out/r03v
 rm -rf $O; mkdir -p $O
 B="python bench.py --no-cpu-baseline --no-roofline --workload train"
-$B --steps 5 --warmup 2 > $O/bench_a.json 2>> $O/bench.err
-$B --steps 10 --warmup 3 > $O/bench_b.json 2>> $O/bench.err
 python -c "
 import cProfile, pstats, sys, io
 sys.argv = ['bench.py', '--no-cpu-baseline', '--no-roofline', '--workload', 'train', '--steps', '10', '--warmup', '3']
@@ -24,4 +22,7 @@ open('$O/cprofile_cum.txt', 'w').write(s.getvalue())
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(45)
 open('$O/cprofile_tot.txt', 'w').write(s.getvalue())
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats('tottime').print_callers('method .to. of|_lib.py.*call|run_backward')
+open('$O/cprofile_callers.txt', 'w').write(s.getvalue())
 " > $O/bench_c.json 2>> $O/bench.err

@@ -233,3 +233,41 @@ def test_data_parallel_step_equals_single_process(tmp_path):
         assert torch.equal(r0['params'][n], r1['params'][n]), 'ranks diverged on ' + n
         assert_close(r0['params'][n], p, 1e-4, 1e-6, 'parameter after the step: ' + n)
     assert r0['skipped'] and r1['skipped'] and r0['unchanged'] and r1['unchanged']
+
+
+@pytest.mark.gpu
+def test_map_cnn_backward_chunks_add_up():
+    """strive_map_cnn_bwd over 300 crops (two internal chunks, 256 + 44: the rollout's batched call spans several) equals the
+    sum of the gradients of the two parts computed by separate single-chunk calls (additivity of the weight gradient)."""
+    from strive_amd import ops
+    DEV = 'cuda:0'
+    m, sd = product_model(device=DEV)
+    raster, dx = synth.make_raster(1024, 1024, M=2)
+    env = synth.SyntheticMapEnv(raster, dx).to(DEV)
+    n = 300
+    fr = np.zeros((n, 4))
+    fr[:, 0] = synth.counter_uniform((n,), 'chunks/x', 20.0, 236.0)
+    fr[:, 1] = synth.counter_uniform((n,), 'chunks/y', 20.0, 236.0)
+    ang = synth.counter_uniform((n,), 'chunks/h', -np.pi, np.pi)
+    fr[:, 2], fr[:, 3] = np.cos(ang), np.sin(ang)
+    pos = (synth.f32(fr) / torch.tensor([15., 15., 1., 1.])).to(DEV).contiguous()
+    mi = torch.tensor([i % 2 for i in range(n)]).to(DEV)
+    d_feat = synth.f32(synth.counter_uniform((n, 64), 'chunks/df', -1.0, 1.0)).to(DEV)
+    names = [k for k, _ in m.named_parameters() if k.startswith('map_')]
+
+    def grads(lo, hi):
+        for p in m.parameters():
+            p.requires_grad_(True)
+            p.grad = None
+        with torch.enable_grad(), ops.weight_grad_mode(True):
+            feat = ops.encode_map(m, pos[lo:hi].contiguous(), torch.arange(hi - lo).to(DEV), mi[lo:hi].contiguous(), env)
+            feat.backward(d_feat[lo:hi].contiguous())
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters() if k in names}
+    whole, a, b = grads(0, n), grads(0, 256), grads(256, n)
+    worst = 0.0
+    for k in names:
+        want = a[k] + b[k]
+        rel = float((whole[k] - want).norm() / max(float(want.norm()), 1e-30))
+        worst = max(worst, rel)
+        assert rel < 2e-5, 'map CNN gradient %s: chunked call differs from the sum of its parts by %.3g' % (k, rel)
+    print('worst relative difference: %.3g' % worst)
