@@ -344,7 +344,8 @@ __device__ __forceinline__ void split_f16x2(const float v[8], uint4& p0, uint4& 
 }
 
 // TIMING: phase timestamps (s_memtime) of every workgroup summed into `tprof` (measurement hook only)
-template <class Cfg, bool TIMING = false>
+// DBG (measurement hook only, results invalid): 1 = no matrix steps, 2 = no output stores, 3 = no input loads, 4 = 1 + 2
+template <class Cfg, bool TIMING = false, int DBG = 0>
 __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
                                                                 const float* __restrict__ gn_g, const float* __restrict__ gn_b,
                                                                 const uint32_t* __restrict__ wfrag, const float* __restrict__ bias,
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
             const int idx = tid + k * NT;
             raw[k][0] = make_float4(0.f, 0.f, 0.f, 0.f);
             raw[k][1] = raw[k][0];
-            if (idx < Cfg::UNITS) {
+            if (idx < Cfg::UNITS && DBG != 3) {
                 const int col = idx % ITW, r = idx / ITW;
                 const int iy = iy0 + r, ix = ix0 + col;
                 if (iy < IH && ix < IH) {
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
         };
         load_frags(0, 0);
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) {
+        for (int s = 0; s < ((DBG == 1 || DBG == 4) ? 0 : NKS); ++s) {
             const int cur = s & 1;
             if (s + 1 < NKS) load_frags(s + 1, cur ^ 1);
             // three products per (channel block, pixel tile) (w1 x0, w0 x1, w0 x0: the small ones first; w1 x1 is below 2^-24
@@ -593,7 +594,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
                 v.z = fmaf(acc[c][i][4 * rg + 2], unscale, bv.z);
                 v.w = fmaf(acc[c][i][4 * rg + 3], unscale, bv.w);
                 if (valid) {
-                    if (Cfg::OUT_OCT) {     // octet-planar, [n][c/8][y][x][c%8]
+                    if (DBG == 2 || DBG == 4) {
+                        // (no stores)
+                    } else if (Cfg::OUT_OCT) {     // octet-planar, [n][c/8][y][x][c%8]
                         *reinterpret_cast<float4*>(out + ((((size_t)n * (COUT / 8) + (co >> 3)) * OH + oy) * OH + ox) * 8 + (co & 7)) = v;
                     } else {                // NCHW
                         float* o = out + (((size_t)n * COUT + co) * OH + oy) * OH + ox;
@@ -1102,7 +1105,7 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
                                           const float* pos_mean4_host, const float* pos_std4_host, const int32_t* mapix,
                                           int32_t N, float* feat, void* ws, size_t ws_bytes, strive_stream_t stream_) {
     STRIVE_CHECK_ARG(map && cnn && pos && mapix && feat && ws, "null argument");
-    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK_MAX && layer >= 0 && layer <= 27, "bad layer / N");
+    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK_MAX && layer >= 0 && layer <= 44, "bad layer / N");
     STRIVE_CHECK_ARG(ws_bytes >= strive_map_cnn_workspace_bytes(N), "workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
     StriveArena ar(ws, ws_bytes);
@@ -1143,6 +1146,27 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
             if (layer == 12) hipLaunchKernelGGL((conv1b_kernel<true, 2>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, 1.0f / cnn->wscale[0], (const float*)cnn->b[0], act[0], st[0]);
             if (layer == 14) hipLaunchKernelGGL((conv1b_kernel<true, 4>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, 1.0f / cnn->wscale[0], (const float*)cnn->b[0], act[0], st[0]);
             if (layer == 13) hipLaunchKernelGGL((conv1b_kernel<true, 3>), gg, dim3(C1_NT), 0, stream, *map, pos, m, s, mapix, (const uint8_t*)nullptr, cnn->w1_frag, 1.0f / cnn->wscale[0], (const float*)cnn->b[0], act[0], st[0]);
+            break;
+        }
+        case 31: case 32: case 33: case 34: case 41: case 42: case 43: case 44: {   // timing probes of conv2 (3x) / conv3 (4x): DBG 1..4, results invalid
+            const int dbg = layer % 10;
+#define STRIVE_DBG_LAUNCH(CFG, D, IN, STI, G, B, W, BIAS, OUT, STO, L)                                                                   \
+    hipFuncSetAttribute((const void*)conv_bf6_kernel<CFG, false, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CFG::LDS_BYTES);   \
+    hipLaunchKernelGGL((conv_bf6_kernel<CFG, false, D>), dim3(CFG::TILES_X * CFG::CSPLIT, CFG::TILES_Y, (N + 7) / 8 * 8), dim3(CFG::NT),  \
+                       CFG::LDS_BYTES, stream, IN, STI, G, B, W, BIAS, OUT, STO, N, cnn->xscale[L], 1.0f / (cnn->xscale[L] * cnn->wscale[L]), \
+                       (unsigned long long*)nullptr)
+            if (layer < 40) {
+                if (dbg == 1) { STRIVE_DBG_LAUNCH(Bf2, 1, act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], 1); }
+                if (dbg == 2) { STRIVE_DBG_LAUNCH(Bf2, 2, act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], 1); }
+                if (dbg == 3) { STRIVE_DBG_LAUNCH(Bf2, 3, act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], 1); }
+                if (dbg == 4) { STRIVE_DBG_LAUNCH(Bf2, 4, act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], 1); }
+            } else {
+                if (dbg == 1) { STRIVE_DBG_LAUNCH(Bf3, 1, act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], 2); }
+                if (dbg == 2) { STRIVE_DBG_LAUNCH(Bf3, 2, act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], 2); }
+                if (dbg == 3) { STRIVE_DBG_LAUNCH(Bf3, 3, act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], 2); }
+                if (dbg == 4) { STRIVE_DBG_LAUNCH(Bf3, 4, act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], 2); }
+            }
+#undef STRIVE_DBG_LAUNCH
             break;
         }
         case 1: launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
