@@ -2,17 +2,23 @@
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import bench
-from strive_amd import ops, _lib as L
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+from util import product_model
+from strive_amd import ops, _lib as L, synth
 dev = torch.device('cuda', 0)
-m, env, batch, map_idx = bench.build_workload(dev, 32, 16, 16, 'bench/r0', 4096)
-g = batch.to(dev); mi = map_idx.to(dev)
-with torch.no_grad():
-    m.embed(g, mi, env)
+m, sd = product_model(device=dev)
+raster, dx = synth.make_raster(1024, 1024, M=2)
+env = synth.SyntheticMapEnv(raster, dx).to(dev)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+fr = np.zeros((N, 4))
+fr[:, 0] = synth.counter_uniform((N,), 'st/x', 20.0, 236.0); fr[:, 1] = synth.counter_uniform((N,), 'st/y', 20.0, 236.0)
+ang = synth.counter_uniform((N,), 'st/h', -np.pi, np.pi); fr[:, 2], fr[:, 3] = np.cos(ang), np.sin(ang)
+pos = (synth.f32(fr) / torch.tensor([15., 15., 1., 1.])).to(dev).contiguous()
+mi = torch.tensor([i % 2 for i in range(N)]).to(dev)
+ops.encode_map(m, pos, torch.arange(N).to(dev), mi, env)
 lib = L.get_lib()
-N = 256
-pos = g.past[:N, -1, :4].contiguous()
-mapix = mi[g.batch][:N].to(torch.int32).contiguous()
+mapix = mi.to(torch.int32).contiguous()
 mp = ops._map_pack(env, dev); cnn = ops.cnn_pack(m)
 wsb = lib.query('strive_map_cnn_workspace_bytes', N); ws = torch.empty(wsb, dtype=torch.uint8, device=dev); feat = torch.empty((N, 64), device=dev)
 nm = m.normalizer; mean4, std4 = L.f4(nm.mean_vals[:4].tolist()), L.f4(nm.std_vals[:4].tolist()); st = L.stream_ptr(pos)
