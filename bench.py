@@ -63,9 +63,12 @@ PEAK_HBM_GBS = 8000.0              # same guide: HBM3E ~8 TB/s
 # (the fifth kernel is the fused tail: conv5 + conv6 + Linear(512, 64) in one launch)
 CONV_FLOPS = [2 * 16 * 125 * 125 * 4 * 49, 2 * 32 * 61 * 61 * 16 * 25, 2 * 64 * 29 * 29 * 32 * 25,
               2 * 64 * 14 * 14 * 64 * 9, 2 * 128 * 6 * 6 * 64 * 9 + 2 * 128 * 2 * 2 * 128 * 9 + 2 * 512 * 64]
-CONV_NAMES = ['conv1b_kernel<true> (fused crop -> conv1)', 'conv_bf6_kernel<conv2>', 'conv_bf6_kernel<conv3>',
-              'conv_bf6_kernel<conv4>', 'cnn_tail_kernel (conv5 + conv6 + Linear)']
-CONV_LAYER_IDS = [0, 1, 2, 3, 7]      # strive_map_cnn_bench_layer ids of the kernels strive_map_cnn_fwd launches
+# conv2 runs on specialised producer / consumer waves (conv_ws_kernel) unless STRIVE_CONV_WS=0 keeps conv_bf6_kernel: time the one
+# the closure launches
+CONV_WS = os.environ.get('STRIVE_CONV_WS', '1') != '0'
+CONV_NAMES = ['conv1b_kernel<true> (fused crop -> conv1)', 'conv_ws_kernel<conv2>' if CONV_WS else 'conv_bf6_kernel<conv2>',
+              'conv_bf6_kernel<conv3>', 'conv_bf6_kernel<conv4>', 'cnn_tail_kernel (conv5 + conv6 + Linear)']
+CONV_LAYER_IDS = [0, 51 if CONV_WS else 1, 2, 3, 7]      # strive_map_cnn_bench_layer ids of the kernels strive_map_cnn_fwd launches
 # algorithmic HBM bytes per agent of the CNN kernels: input read once + output written once (fp32 activations, uint8 raster)
 CONV_BYTES = [4 * 256 * 256 + 16 * 125 * 125 * 4, (16 * 125 * 125 + 32 * 61 * 61) * 4, (32 * 61 * 61 + 64 * 29 * 29) * 4,
               (64 * 29 * 29 + 64 * 14 * 14) * 4, (64 * 14 * 14 + 64) * 4]

@@ -631,6 +631,278 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
 }
 
 // =============================================================================================
+// conv_bf6_kernel with SPECIALISED waves (round 3).  tools/conv_floor_probe.py: the matrix loop of conv2 is 42 % of the kernel,
+// its memory phases the rest, and the two overlap only across the 3 workgroups of a CU.  Here a persistent workgroup of 8 waves
+// (one per CU) splits the roles: waves 4-7 PRODUCE -- they fetch the 8-channel slice of the next (tile, pass) unit, apply
+// GroupNorm + ReLU, split and write it to one of two LDS input buffers -- while waves 0-3 CONSUME the other buffer: the 13 matrix
+// steps of the previous unit (same instruction order as conv_bf6_kernel: the results are bit-identical) and, after a tile's last
+// pass, its epilogue.  One barrier per unit.  The whole layer's weight fragments stay in LDS (52 KB for conv2), so the matrix
+// loop has no ring and no barrier of its own.  A workgroup walks a contiguous range of tiles (all tiles of a sample in a row:
+// halo rows come from its own XCD's L2).
+// =============================================================================================
+template <class Cfg>
+struct WsCfg {
+    static constexpr int NCONS_W = 8, NT = 1024, NPROD = 512;        // 8 consumer waves (one output row each), 8 producer waves
+    static constexpr int UITERS = (Cfg::UNITS + NPROD - 1) / NPROD;
+    static constexpr int W_B = Cfg::NPASS * Cfg::NKS * Cfg::WSTEP_B;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)Cfg::IN_B + W_B + 2 * (size_t)Cfg::CIN * 8 + 2 * 8 * 16 + 64;
+    static_assert(Cfg::CBW == 1 && Cfg::CSPLIT == 1 && Cfg::OUT_OCT && !Cfg::ROWS2 && Cfg::TH == NCONS_W, "built for conv2's shape");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// the (tile, pass) units of a workgroup and where unit u lives
+template <class Cfg>
+struct WsUnits {
+    int t_begin, nunit;
+    __device__ __forceinline__ void tile(int u, int& n, int& ty, int& tx, int& pass) const {
+        constexpr int TPS = Cfg::TILES_X * Cfg::TILES_Y;
+        const int t = t_begin + u / Cfg::NPASS;
+        pass = u - (u / Cfg::NPASS) * Cfg::NPASS;
+        n = t / TPS;
+        const int r = t - n * TPS;
+        ty = r / Cfg::TILES_X;
+        tx = r - ty * Cfg::TILES_X;
+    }
+};
+
+// ---- producer waves (8-15): own function = own register allocation (raw prefetch sets; the consumers keep accumulators) ----
+template <class Cfg>
+__device__ __forceinline__ void ws_producer(const float* __restrict__ in, const GNStats* __restrict__ st_in, const float* __restrict__ gn_g,
+                                         const float* __restrict__ gn_b, float xscale, unsigned char* s_in, float* s_gn,
+                                         WsUnits<Cfg> un, int dbg) {
+    using W = WsCfg<Cfg>;
+    constexpr int CIN = Cfg::CIN, IH = Cfg::IH, TH = Cfg::TH, TW = Cfg::TW, ITW = Cfg::ITW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ptid = tid - 64 * W::NCONS_W;
+    const int nunit = un.nunit;
+    // (two register sets: the loads of unit u + 1 are requested BEFORE unit u is staged, a whole unit ahead of their use)
+    float4 raw0[W::UITERS][2], raw1[W::UITERS][2];
+    auto issue_loads = [&](int u, float4 (&raw)[W::UITERS][2]) {
+        int n, ty, tx, pass;
+        un.tile(u, n, ty, tx, pass);
+        const float* in_n = in + (size_t)n * IH * IH * CIN;
+        const int iy0 = 2 * ty * TH, ix0 = 2 * tx * TW;
+#pragma unroll
+        for (int k = 0; k < W::UITERS; ++k) {
+            const int idx = ptid + k * W::NPROD;
+            raw[k][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+            raw[k][1] = raw[k][0];
+            if (idx < Cfg::UNITS && !(dbg & 4)) {
+                const int col = idx % ITW, r = idx / ITW;
+                const int iy = iy0 + r, ix = ix0 + col;
+                if (iy < IH && ix < IH) {
+                    const float4* src = reinterpret_cast<const float4*>(in_n + (((size_t)pass * IH + iy) * IH + ix) * 8);
+                    raw[k][0] = src[0];
+                    raw[k][1] = src[1];
+                }
+            }
+        }
+    };
+    // GroupNorm scale / shift of sample n into s_gn[n & 1] (first producer wave; fixed butterfly order like conv_bf6_kernel)
+    auto sample_moments = [&](int n) {
+        double ps = 0.0, pq = 0.0;
+        for (int i = lane; i < Cfg::NPART_IN; i += 64) {
+            ps += st_in[(size_t)n * Cfg::NPART_IN + i].sum;
+            pq += st_in[(size_t)n * Cfg::NPART_IN + i].sq;
+        }
+        ps = wave_sum_d(ps);
+        pq = wave_sum_d(pq);
+        const double cnt = (double)CIN * IH * IH;
+        const double mu = ps / cnt;
+        double var = pq / cnt - mu * mu;
+        var = var < 0.0 ? 0.0 : var;
+        const float mean = (float)mu, rstd = (float)(1.0 / sqrt(var + GN_EPS));
+        if (lane < CIN) {
+            const float sc = rstd * gn_g[lane];
+            float* g = s_gn + (n & 1) * CIN * 2;
+            g[2 * lane] = sc * xscale;
+            g[2 * lane + 1] = (gn_b[lane] - mean * sc) * xscale;
+        }
+    };
+    auto stage = [&](int u, const float4 (&raw)[W::UITERS][2]) {   // raw -> GroupNorm + ReLU -> two fp16 pieces -> s_in[u & 1]
+        int n, ty, tx, pass;
+        un.tile(u, n, ty, tx, pass);
+        const int iy0 = 2 * ty * TH, ix0 = 2 * tx * TW;
+        unsigned char* buf = s_in + (u & 1) * Cfg::IN_B;
+        const float4* gn = reinterpret_cast<const float4*>(s_gn + (n & 1) * CIN * 2 + 2 * pass * Cfg::PASS_CH);
+        const float4 g0 = gn[0], g1 = gn[1], g2 = gn[2], g3 = gn[3];
+#pragma unroll
+        for (int k = 0; k < W::UITERS; ++k) {
+            const int idx = ptid + k * W::NPROD;
+            if (idx < Cfg::UNITS) {
+                const int col = idx % ITW, r = idx / ITW;
+                const int iy = iy0 + r, ix = ix0 + col;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;             // exact zero outside the image
+                if (iy < IH && ix < IH) {
+                    const float4 a = raw[k][0], b = raw[k][1];
+                    v[0] = fmaxf(fmaf(a.x, g0.x, g0.y), 0.f);
+                    v[1] = fmaxf(fmaf(a.y, g0.z, g0.w), 0.f);
+                    v[2] = fmaxf(fmaf(a.z, g1.x, g1.y), 0.f);
+                    v[3] = fmaxf(fmaf(a.w, g1.z, g1.w), 0.f);
+                    v[4] = fmaxf(fmaf(b.x, g2.x, g2.y), 0.f);
+                    v[5] = fmaxf(fmaf(b.y, g2.z, g2.w), 0.f);
+                    v[6] = fmaxf(fmaf(b.z, g3.x, g3.y), 0.f);
+                    v[7] = fmaxf(fmaf(b.w, g3.z, g3.w), 0.f);
+                }
+                uint4 p0, p1;
+                split_f16x2(v, p0, p1);
+                unsigned char* dst = buf + r * Cfg::ROW_B + (col & 1) * Cfg::HALF_B + (col >> 1) * 16;
+                *reinterpret_cast<uint4*>(dst) = p0;
+                *reinterpret_cast<uint4*>(dst + Cfg::PIECE_B) = p1;
+            }
+        }
+    };
+    int cur_sample;
+    {
+        issue_loads(0, raw0);
+        int n, ty, tx, pass;
+        un.tile(0, n, ty, tx, pass);
+        if (wave == W::NCONS_W) sample_moments(n);
+        cur_sample = n;
+    }
+    __syncthreads();                                              // (1) weights and the first sample's scale / shift are in LDS
+    auto iteration = [&](int u, float4 (&raw_cur)[W::UITERS][2], float4 (&raw_next)[W::UITERS][2]) {
+        if (u + 1 < nunit) {
+            issue_loads(u + 1, raw_next);
+            int n, ty, tx, pass;
+            un.tile(u + 1, n, ty, tx, pass);
+            if (n != cur_sample) {                                // (its slot s_gn[n & 1] was last read while staging sample n - 2)
+                if (wave == W::NCONS_W) sample_moments(n);
+                cur_sample = n;
+            }
+        }
+        if (u < nunit && !(dbg & 2)) stage(u, raw_cur);
+        __syncthreads();
+    };
+    for (int u = 0; u <= nunit; u += 2) {
+        iteration(u, raw0, raw1);
+        if (u + 1 <= nunit) iteration(u + 1, raw1, raw0);
+    }
+}
+
+// ---- consumer waves (0-7): wave w owns output row w of the 8-row tile ----
+template <class Cfg>
+__device__ __forceinline__ void ws_consumer(const unsigned char* s_in, const unsigned char* s_w, double* s_red, const float* __restrict__ bias,
+                                         float* __restrict__ out, GNStats* __restrict__ st_out, float unscale, WsUnits<Cfg> un, int dbg) {
+    constexpr int COUT = Cfg::COUT, OH = Cfg::OH, TH = Cfg::TH, TW = Cfg::TW, NKS = Cfg::NKS, NPASS = Cfg::NPASS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int nunit = un.nunit;
+    f32x16 acc0;
+    const int lane_base = (2 * wave) * Cfg::ROW_B + j * 16;
+    auto matrix_steps = [&](int u) {
+        int n, ty, tx, pass;
+        un.tile(u, n, ty, tx, pass);
+        const unsigned char* buf = s_in + (u & 1) * Cfg::IN_B;
+        if (pass == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
+        }
+        f16x8 fa[2][2], fb[2][2];
+        auto load_frags = [&](int t, int set) {
+            int ky, kx;
+            if (Cfg::KS == 5) {
+                if (t < 10) { ky = t >> 1; kx = (t & 1) + 2 * h; }
+                else { ky = 2 * (t - 10) + h; kx = 4; ky = ky > 4 ? 4 : ky; }
+            } else {
+                if (t < 3) { ky = t; kx = 2 * h; }
+                else if (t == 3) { ky = h; kx = 1; }
+                else { ky = 2; kx = 1; }
+            }
+            const int off = ky * Cfg::ROW_B + (kx & 1) * Cfg::HALF_B + (kx >> 1) * 16;
+            const unsigned char* wb = s_w + (size_t)(pass * NKS + t) * Cfg::WSTEP_B + lane * 16;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                fa[set][pl] = *reinterpret_cast<const f16x8*>(wb + pl * 1024);
+                fb[set][pl] = *reinterpret_cast<const f16x8*>(buf + pl * Cfg::PIECE_B + lane_base + off);
+            }
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int s2 = 0; s2 < NKS; ++s2) {
+            const int cur = s2 & 1;
+            if (s2 + 1 < NKS) load_frags(s2 + 1, cur ^ 1);
+            constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][TA[term]], fb[cur][TB[term]], acc0, 0, 0, 0);
+        }
+        if (pass + 1 < NPASS) return;
+        // ---- epilogue of the tile ----
+        const int oy = ty * TH + wave, ox = tx * TW + j;
+        const bool valid = oy < OH && ox < OH;
+        float fsum = 0.f, fsq = 0.f;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int co = 8 * rg + 4 * h;
+            const float4 bv = *reinterpret_cast<const float4*>(bias + co);
+            float4 v;
+            v.x = fmaf(acc0[4 * rg + 0], unscale, bv.x);
+            v.y = fmaf(acc0[4 * rg + 1], unscale, bv.y);
+            v.z = fmaf(acc0[4 * rg + 2], unscale, bv.z);
+            v.w = fmaf(acc0[4 * rg + 3], unscale, bv.w);
+            if (valid) {
+                *reinterpret_cast<float4*>(out + ((((size_t)n * (COUT / 8) + (co >> 3)) * OH + oy) * OH + ox) * 8 + (co & 7)) = v;
+                fsum += (v.x + v.y) + (v.z + v.w);
+                fsq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fsq))));
+            }
+        }
+        const double lsum = wave_sum_d((double)fsum), lsq = wave_sum_d((double)fsq);
+        const int tl = (u / NPASS) & 1;
+        if (lane == 0) { s_red[(tl * 8 + wave) * 2] = lsum; s_red[(tl * 8 + wave) * 2 + 1] = lsq; }
+    };
+    auto publish_stats = [&](int u) {                              // thread 0, one barrier after the tile's epilogue
+        int n, ty, tx, pass;
+        un.tile(u, n, ty, tx, pass);
+        const int tl = (u / NPASS) & 1;
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < 8; ++w) { a += s_red[(tl * 8 + w) * 2]; b += s_red[(tl * 8 + w) * 2 + 1]; }
+        GNStats& o = st_out[(size_t)n * Cfg::NPART_OUT + (ty * Cfg::TILES_X + tx)];
+        o.sum = a;
+        o.sq = b;
+    };
+    __syncthreads();                                              // (1)
+    for (int u = 0; u <= nunit; ++u) {
+        if (u >= 1 && !(dbg & 1)) matrix_steps(u - 1);
+        if (tid == 0 && u >= 2 && ((u - 2) % NPASS) == NPASS - 1) publish_stats(u - 2);
+        __syncthreads();
+    }
+    if (tid == 0 && ((nunit - 1) % NPASS) == NPASS - 1) publish_stats(nunit - 1);
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(1024, 1) void conv_ws_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
+                                                           const float* __restrict__ gn_g, const float* __restrict__ gn_b,
+                                                           const uint32_t* __restrict__ wfrag, const float* __restrict__ bias,
+                                                           float* __restrict__ out, GNStats* __restrict__ st_out, int N, float xscale,
+                                                           float unscale, int dbg) {
+    using W = WsCfg<Cfg>;
+    HIP_DYNAMIC_SHARED(float, smem)
+    unsigned char* s_in = reinterpret_cast<unsigned char*>(smem);          // [2][IN_B]
+    unsigned char* s_w = s_in + 2 * Cfg::IN_B;                              // [pass][step][piece][lane][16 B]
+    float* s_gn = (float*)(s_w + W::W_B);                                   // [2][CIN][2] scale, shift of the sample (parity)
+    double* s_red = (double*)(s_gn + 2 * Cfg::CIN * 2);                     // [2][8][2]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // this workgroup's tiles: a contiguous range of the (sample, tile) list
+    const int total = N * Cfg::TILES_X * Cfg::TILES_Y;
+    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    WsUnits<Cfg> un;
+    un.t_begin = (int)blockIdx.x * per;
+    const int t_end = (un.t_begin + per) < total ? (un.t_begin + per) : total;
+    un.nunit = (t_end > un.t_begin ? t_end - un.t_begin : 0) * Cfg::NPASS;
+    for (int i = tid; i < W::W_B / 16; i += W::NT) reinterpret_cast<uint4*>(s_w)[i] = reinterpret_cast<const uint4*>(wfrag)[i];
+    if (un.nunit == 0) return;
+    // both roles execute the same sequence of barriers: (1), then one per unit
+    if (wave >= W::NCONS_W) ws_producer<Cfg>(in, st_in, gn_g, gn_b, xscale, s_in, s_gn, un, dbg);
+    else ws_consumer<Cfg>(s_in, s_w, s_red, bias, out, st_out, unscale, un, dbg);
+}
+
+// =============================================================================================
 // The same bf16 x 6 scheme for SMALL images (conv5: 64 -> 128 channels, 14 x 14 -> 6 x 6; conv6: 128 -> 128, 6 x 6 -> 2 x 2;
 // both 3x3): a workgroup takes S whole samples, the 32-pixel MFMA tiles are filled with the linearised pixels (sample, y, x) of those samples (S = 7: 252 of
 // 256 lanes carry a pixel), and every lane keeps the LDS offset of its own window origin.  Input octet-planar, the 8
@@ -907,6 +1179,28 @@ typedef BfCfg<64, 64, 3, 29, 14, Bf3::NPART_OUT, true, 2, 2, true, 2> Bf4;
 typedef BfsCfg<64, 128, 14, 6, 7, Bf4::NPART_OUT, true, 2, 2> Bfs5;       // conv5: 7 samples (252 pixels) x 32 channels per workgroup
 typedef BfsCfg<128, 128, 6, 2, 32, Bfs5::NPART_OUT, false, 1, 2> Bfs6;  // conv6: 32 samples (128 pixels) x 32 channels per workgroup; NCHW out (fc)
 
+// the specialised-wave form (conv_ws_kernel): one persistent workgroup per CU; STRIVE_CONV_WS=0 keeps conv_bf6_kernel (A/B)
+template <class Cfg>
+static int launch_ws(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
+                     const float* bias, float* out, GNStats* st_out, int N, float xscale, float wscale, hipStream_t stream) {
+    using W = WsCfg<Cfg>;
+    static bool attr_set = false;
+    static int ncu = 256;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_ws_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES);
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            ncu = v;
+        attr_set = true;
+    }
+    const int total = N * Cfg::TILES_X * Cfg::TILES_Y;
+    const int grid = total < ncu ? total : ncu;
+    static const int dbg = getenv("STRIVE_CONV_WS_DBG") ? atoi(getenv("STRIVE_CONV_WS_DBG")) : 0;     // measurement only (results invalid)
+    hipLaunchKernelGGL(conv_ws_kernel<Cfg>, dim3(grid), dim3(W::NT), W::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out, st_out, N,
+                       xscale, 1.0f / (xscale * wscale), dbg);
+    return 0;
+}
+
 template <class Cfg>
 static int launch_bf6(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
                       const float* bias, float* out, GNStats* st_out, int N, float xscale, float wscale, hipStream_t stream) {
@@ -1064,7 +1358,12 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
                                (const int32_t*)nullptr, crop + (size_t)n0 * 4 * 256 * 256, cnn->w1_frag, 1.0f / cnn->wscale[0],
                                (const float*)cnn->b[0], act[0], st[0]);
         }
-        launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], n, cnn->xscale[1], cnn->wscale[1], stream);
+        // conv2: specialised producer / consumer waves (bit-identical to conv_bf6_kernel; STRIVE_CONV_WS=0 switches back)
+        static const bool conv_ws = !(getenv("STRIVE_CONV_WS") && atoi(getenv("STRIVE_CONV_WS")) == 0);
+        if (conv_ws)
+            launch_ws<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], n, cnn->xscale[1], cnn->wscale[1], stream);
+        else
+            launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], n, cnn->xscale[1], cnn->wscale[1], stream);
         launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
         launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, cnn->xscale[3], cnn->wscale[3], stream);
         if (!keep_tail_activations) {
@@ -1105,7 +1404,7 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
                                           const float* pos_mean4_host, const float* pos_std4_host, const int32_t* mapix,
                                           int32_t N, float* feat, void* ws, size_t ws_bytes, strive_stream_t stream_) {
     STRIVE_CHECK_ARG(map && cnn && pos && mapix && feat && ws, "null argument");
-    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK_MAX && layer >= 0 && layer <= 44, "bad layer / N");
+    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK_MAX && layer >= 0 && layer <= 51, "bad layer / N");
     STRIVE_CHECK_ARG(ws_bytes >= strive_map_cnn_workspace_bytes(N), "workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
     StriveArena ar(ws, ws_bytes);
@@ -1170,6 +1469,7 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
             break;
         }
         case 1: launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
+        case 51: launch_ws<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;   // conv2, specialised waves
         case 2: launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, cnn->xscale[2], cnn->wscale[2], stream); break;
         case 3: launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], N, cnn->xscale[3], cnn->wscale[3], stream); break;
         case 4: launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], N, cnn->xscale[4], cnn->wscale[4], stream); break;

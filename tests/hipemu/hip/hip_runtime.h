@@ -22,6 +22,7 @@
 #define __global__
 #define __device__
 #define __host__
+#define __noinline__ __attribute__((noinline))
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
 #define __launch_bounds__(...)
@@ -59,6 +60,9 @@ inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 struct hipEvent_emu;
 typedef hipEvent_emu* hipEvent_t;
 static const unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2;
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 16 };
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 3; return hipSuccess; }   // 3 "CUs": persistent kernels loop
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
