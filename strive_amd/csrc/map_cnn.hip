@@ -660,8 +660,11 @@ struct WsUnits {
         pass = u - (u / Cfg::NPASS) * Cfg::NPASS;
         n = t / TPS;
         const int r = t - n * TPS;
-        ty = r / Cfg::TILES_X;
-        tx = r - ty * Cfg::TILES_X;
+        // down a column of tiles first: vertical neighbours share 3 rows x 67 columns of halo (12.9 KB per pass, horizontal ones
+        // 3.6 KB), and with the next tile one unit away those rows are still in the XCD's L2 (row-major order: 1.13 x the
+        // algorithmic bytes fetched)
+        tx = r / Cfg::TILES_Y;
+        ty = r - tx * Cfg::TILES_Y;
     }
 };
 
