@@ -44,13 +44,18 @@ __device__ __forceinline__ size_t act_index(bool oct, int C, int H, int n, int c
     return (((size_t)n * C + c) * H + y) * H + x;
 }
 
-// ---- per-sample GroupNorm moments of one layer: MR[n] = (mean, rstd) ----
-static __global__ void moments_kernel(const GNStats* __restrict__ st, int nparts, double count, float2* __restrict__ mr, int N) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+// ---- per-sample GroupNorm moments of all six layers in one launch: MR[l][n] = (mean, rstd); grid = (ceil(N / 64), 6) ----
+struct MomentsArgs {
+    const GNStats* st[6];
+    int nparts[6];
+    double count[6];
+};
+static __global__ void moments_kernel(MomentsArgs a, float2* __restrict__ mr, int ch, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
     if (n >= N) return;
     float mean, rstd;
-    gn_moments(st, n, nparts, count, mean, rstd);
-    mr[n] = make_float2(mean, rstd);
+    gn_moments(a.st[l], n, a.nparts[l], a.count[l], mean, rstd);
+    mr[(size_t)l * ch + n] = make_float2(mean, rstd);
 }
 
 // ---- Linear(512, 64) + GroupNorm6/ReLU input: G5 <- d a6 = W^T d feat;  dW += d feat^T a6;  db += sum d feat ----
@@ -632,7 +637,7 @@ extern "C" size_t strive_map_cnn_bwd_workspace_bytes(int32_t N) {
     b += strive_align_up(ch * cnnbwd::grad_floats_per_sample() * 4, 256);       // G_0 .. G_5
     b += strive_align_up(ch * 4 * 256 * 256, 256);                              // uint8 crop (conv1's input)
     b += strive_align_up(ch * 6 * sizeof(float2), 256);                         // moments
-    b += strive_align_up(ch * 2 * sizeof(double), 256);                         // GroupNorm backward sums
+    b += strive_align_up(ch * 6 * 2 * sizeof(double), 256);                     // GroupNorm backward sums, per layer
     b += strive_align_up(ch * 64 * 4, 256);                                     // feature scratch of the recomputed forward
     b += strive_align_up(cnnbwd::dgrad_frag_total() * 16, 256);                 // bf16 weight fragments of the data gradient
     b += strive_align_up(cnnbwd::wgrad_partial_floats() * 4, 256);              // per-workgroup partial weight gradients
@@ -658,7 +663,7 @@ extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, co
     for (int l = 0; l < 6; ++l) G[l] = ar.take<float>((size_t)ch * L_OUT[l]);
     uint8_t* crop = ar.take<uint8_t>((size_t)ch * 4 * 256 * 256);
     float2* mr = ar.take<float2>((size_t)ch * 6);
-    double* S = ar.take<double>((size_t)ch * 2);
+    double* S = ar.take<double>((size_t)ch * 6 * 2);
     float* feat = ar.take<float>((size_t)ch * 64);
     uint4* dfrag = ar.take<uint4>(dgrad_frag_total());
     float* wpart = ar.take<float>(wgrad_partial_floats());
@@ -690,9 +695,12 @@ extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, co
             size_t off = 0;
             for (int l = 0; l < 6; ++l) { st[l] = stats + off; off += (size_t)n * NPARTS[l]; }
         }
-        for (int l = 0; l < 6; ++l)
-            hipLaunchKernelGGL(moments_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, st[l], NPARTS[l], (double)L_OUT[l],
-                               mr + (size_t)l * ch, n);
+        {
+            MomentsArgs ma;
+            for (int l = 0; l < 6; ++l) { ma.st[l] = st[l]; ma.nparts[l] = NPARTS[l]; ma.count[l] = (double)L_OUT[l]; }
+            hipLaunchKernelGGL(moments_kernel, dim3((n + 63) / 64, 6), dim3(64), 0, stream, ma, mr, ch, n);
+        }
+        hipMemsetAsync(S, 0, (size_t)6 * ch * 2 * sizeof(double), stream);      // GroupNorm-backward sums of all six layers
         hipLaunchKernelGGL(fc_bwd_kernel, dim3((n + 7) / 8), dim3(256), 0, stream, act[5], mr + (size_t)5 * ch, cnn->gn_g[5],
                            cnn->gn_b[5], cnn->fc_wt, d_feat + (size_t)n0 * 64, G[5], gp.fcw, gp.fcb, n);
         for (int l = 5; l >= 0; --l) {
@@ -700,19 +708,19 @@ extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, co
             const int M = d.cout * d.oh * d.oh;
             int nblk = (M + 8191) / 8192;
             if (nblk < 1) nblk = 1;
-            hipMemsetAsync(S, 0, (size_t)n * 2 * sizeof(double), stream);
+            double* Sl = S + (size_t)l * ch * 2;
             if (d.out_oct) {
                 const int HW = d.oh * d.oh;
                 const dim3 grid((d.cout / 8) * ((HW + GN_PPB - 1) / GN_PPB), n);
                 hipLaunchKernelGGL(gn_bwd_reduce_oct_kernel, grid, dim3(256), 0, stream, d.cout, HW, act[l], mr + (size_t)l * ch,
-                                   cnn->gn_g[l], cnn->gn_b[l], G[l], S, gp.g[l], gp.be[l]);
+                                   cnn->gn_g[l], cnn->gn_b[l], G[l], Sl, gp.g[l], gp.be[l]);
                 hipLaunchKernelGGL(gn_bwd_apply_oct_kernel, grid, dim3(256), 0, stream, d.cout, HW, act[l], mr + (size_t)l * ch,
-                                   cnn->gn_g[l], G[l], S, gp.b[l]);
+                                   cnn->gn_g[l], G[l], Sl, gp.b[l]);
             } else {
                 hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nblk, n), dim3(256), 0, stream, d, act[l], mr + (size_t)l * ch, cnn->gn_g[l],
-                                   cnn->gn_b[l], G[l], S, gp.g[l], gp.be[l]);
+                                   cnn->gn_b[l], G[l], Sl, gp.g[l], gp.be[l]);
                 hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nblk, n), dim3(256), 0, stream, d, act[l], mr + (size_t)l * ch, cnn->gn_g[l],
-                                   G[l], S, gp.b[l]);
+                                   G[l], Sl, gp.b[l]);
             }
             // weight gradient
             WgradProb wp;
