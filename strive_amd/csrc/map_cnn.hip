@@ -679,7 +679,10 @@ __device__ __forceinline__ void ws_producer(const float* __restrict__ in, const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ptid = tid - 64 * W::NCONS_W;
     const int nunit = un.nunit;
-    // (two register sets: the loads of unit u + 1 are requested BEFORE unit u is staged, a whole unit ahead of their use)
+    // Two register sets: the loads of unit u + 1 are requested before unit u is staged, a whole unit ahead of their use.  The loads
+    // are UNCONDITIONAL (addresses clamped into the tensor; stage() zeroes what lies outside): with predicated loads the compiler
+    // cannot count what is outstanding and waits for ALL of it (s_waitcnt vmcnt(0)) before staging, i.e. also for the loads it
+    // has just issued -- the period was then load latency + staging, whatever the prefetch distance.
     float4 raw0[W::UITERS][2], raw1[W::UITERS][2];
     auto issue_loads = [&](int u, float4 (&raw)[W::UITERS][2]) {
         int n, ty, tx, pass;
@@ -688,18 +691,15 @@ __device__ __forceinline__ void ws_producer(const float* __restrict__ in, const 
         const int iy0 = 2 * ty * TH, ix0 = 2 * tx * TW;
 #pragma unroll
         for (int k = 0; k < W::UITERS; ++k) {
-            const int idx = ptid + k * W::NPROD;
-            raw[k][0] = make_float4(0.f, 0.f, 0.f, 0.f);
-            raw[k][1] = raw[k][0];
-            if (idx < Cfg::UNITS && !(dbg & 4)) {
-                const int col = idx % ITW, r = idx / ITW;
-                const int iy = iy0 + r, ix = ix0 + col;
-                if (iy < IH && ix < IH) {
-                    const float4* src = reinterpret_cast<const float4*>(in_n + (((size_t)pass * IH + iy) * IH + ix) * 8);
-                    raw[k][0] = src[0];
-                    raw[k][1] = src[1];
-                }
-            }
+            int idx = ptid + k * W::NPROD;
+            idx = idx < Cfg::UNITS ? idx : Cfg::UNITS - 1;
+            const int col = idx % ITW, r = idx / ITW;
+            int iy = iy0 + r, ix = ix0 + col;
+            iy = iy < IH ? iy : IH - 1;
+            ix = ix < IH ? ix : IH - 1;
+            const float4* src = reinterpret_cast<const float4*>(in_n + (((size_t)pass * IH + iy) * IH + ix) * 8);
+            raw[k][0] = src[0];
+            raw[k][1] = src[1];
         }
     };
     // GroupNorm scale / shift of sample n into s_gn[n & 1] (first producer wave; fixed butterfly order like conv_bf6_kernel)
@@ -759,24 +759,21 @@ __device__ __forceinline__ void ws_producer(const float* __restrict__ in, const 
         }
     };
     int cur_sample;
-    {
-        issue_loads(0, raw0);
+    auto request = [&](int u, float4 (&raw)[W::UITERS][2]) {       // loads of unit u (+ its sample's scale / shift when it is a new one)
+        if (u >= nunit) return;
+        issue_loads(u, raw);
         int n, ty, tx, pass;
-        un.tile(0, n, ty, tx, pass);
-        if (wave == W::NCONS_W) sample_moments(n);
-        cur_sample = n;
-    }
+        un.tile(u, n, ty, tx, pass);
+        if (n != cur_sample) {                                    // (its slot s_gn[n & 1] was last read while staging sample n - 2)
+            if (wave == W::NCONS_W) sample_moments(n);
+            cur_sample = n;
+        }
+    };
+    cur_sample = -1;
+    request(0, raw0);
     __syncthreads();                                              // (1) weights and the first sample's scale / shift are in LDS
     auto iteration = [&](int u, float4 (&raw_cur)[W::UITERS][2], float4 (&raw_next)[W::UITERS][2]) {
-        if (u + 1 < nunit) {
-            issue_loads(u + 1, raw_next);
-            int n, ty, tx, pass;
-            un.tile(u + 1, n, ty, tx, pass);
-            if (n != cur_sample) {                                // (its slot s_gn[n & 1] was last read while staging sample n - 2)
-                if (wave == W::NCONS_W) sample_moments(n);
-                cur_sample = n;
-            }
-        }
+        request(u + 1, raw_next);
         if (u < nunit && !(dbg & 2)) stage(u, raw_cur);
         __syncthreads();
     };
