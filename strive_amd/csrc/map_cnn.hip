@@ -1195,7 +1195,8 @@ static int launch_ws(const float* in, const GNStats* st_in, const float* g, cons
     }
     const int total = N * Cfg::TILES_X * Cfg::TILES_Y;
     const int grid = total < ncu ? total : ncu;
-    static const int dbg = getenv("STRIVE_CONV_WS_DBG") ? atoi(getenv("STRIVE_CONV_WS_DBG")) : 0;     // measurement only (results invalid)
+    // STRIVE_CONV_WS_DBG (measurement only, results invalid): 1 = consumers skip the matrix steps, 2 = producers skip the staging
+    static const int dbg = getenv("STRIVE_CONV_WS_DBG") ? atoi(getenv("STRIVE_CONV_WS_DBG")) : 0;
     hipLaunchKernelGGL(conv_ws_kernel<Cfg>, dim3(grid), dim3(W::NT), W::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out, st_out, N,
                        xscale, 1.0f / (xscale * wscale), dbg);
     return 0;
