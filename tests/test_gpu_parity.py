@@ -657,3 +657,46 @@ def test_pack_dense_equals_torch_layout(M, K):
     from test_emu_kernels import _pack_dense_case
     from strive_amd import _lib as L
     _pack_dense_case(L.get_lib(), DEV, M, K, 'pack/gpu/%d/%d' % (M, K))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [3, 40, 300])
+def test_conv2_specialised_waves_bit_identical(model, n):
+    """conv2 as conv_ws_kernel (producer / consumer waves, what strive_map_cnn_fwd launches) against conv_bf6_kernel on the same
+    conv1 output: the activations must agree bit for bit (same products in the same order per output)."""
+    from strive_amd import _lib as L
+    m, _sd = model
+    lib = L.get_lib()
+    raster, dx = synth.make_raster(1024, 1024, M=2)
+    env = synth.SyntheticMapEnv(raster, dx).to(DEV)
+    fr = np.zeros((n, 4))
+    fr[:, 0] = synth.counter_uniform((n,), 'ws/x', 20.0, 236.0)
+    fr[:, 1] = synth.counter_uniform((n,), 'ws/y', 20.0, 236.0)
+    ang = synth.counter_uniform((n,), 'ws/h', -np.pi, np.pi)
+    fr[:, 2], fr[:, 3] = np.cos(ang), np.sin(ang)
+    pos = (synth.f32(fr) / torch.tensor([15., 15., 1., 1.])).to(DEV).contiguous()
+    mi = torch.tensor([i % 2 for i in range(n)]).to(DEV)
+    ops.encode_map(m, pos, torch.arange(n).to(DEV), mi, env)
+    mp, cnn = ops._map_pack(env, torch.device(DEV)), ops.cnn_pack(m)
+    mapix = mi.to(torch.int32).contiguous()
+    wsb = lib.query('strive_map_cnn_workspace_bytes', n)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+    feat = torch.zeros((n, 64), device=DEV)
+    nm = m.normalizer
+    mean4, std4 = L.f4(nm.mean_vals[:4].tolist()), L.f4(nm.std_vals[:4].tolist())
+    st = L.stream_ptr(pos)
+    lib.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(pos), mean4, std4, L.ptr(mapix), n, L.ptr(feat), L.ptr(ws), wsb, st)
+
+    def align(v):
+        return (v + 255) // 256 * 256
+    o1 = align(16 * 125 * 125 * 4 * n)                      # act[0] | act[1] | ... in the workspace (256-byte aligned blocks)
+    nb = 32 * 61 * 61 * 4 * n
+    out = []
+    for layer in (1, 51):
+        ws[o1:o1 + nb].zero_()
+        lib.call('strive_map_cnn_bench_layer', mp.ref(), cnn.ref(), layer, L.ptr(pos), mean4, std4, L.ptr(mapix), n, L.ptr(feat), L.ptr(ws),
+                 wsb, st)
+        torch.cuda.synchronize()
+        out.append(ws[o1:o1 + nb].clone())
+    assert bool(out[0].any()), 'conv2 wrote nothing'
+    assert torch.equal(out[0], out[1])
