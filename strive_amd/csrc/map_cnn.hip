@@ -687,8 +687,8 @@ __device__ __forceinline__ void ws_producer(const float* __restrict__ in, const 
     auto issue_loads = [&](int u, float4 (&raw)[W::UITERS][2]) {
         int n, ty, tx, pass;
         un.tile(u, n, ty, tx, pass);
-        const float* in_n = in + (size_t)n * IH * IH * CIN;
-        const int iy0 = 2 * ty * TH, ix0 = 2 * tx * TW;
+        const float* in_n = in + (size_t)((dbg & 8) ? 0 : n) * IH * IH * CIN;            // (dbg 8: every unit re-reads sample 0's first tile: L2 hits)
+        const int iy0 = (dbg & 8) ? 0 : 2 * ty * TH, ix0 = (dbg & 8) ? 0 : 2 * tx * TW;
 #pragma unroll
         for (int k = 0; k < W::UITERS; ++k) {
             int idx = ptid + k * W::NPROD;
@@ -1195,7 +1195,8 @@ static int launch_ws(const float* in, const GNStats* st_in, const float* g, cons
     }
     const int total = N * Cfg::TILES_X * Cfg::TILES_Y;
     const int grid = total < ncu ? total : ncu;
-    // STRIVE_CONV_WS_DBG (measurement only, results invalid): 1 = consumers skip the matrix steps, 2 = producers skip the staging
+    // STRIVE_CONV_WS_DBG (measurement only, results invalid): 1 = consumers skip the matrix steps, 2 = producers skip the staging,
+    // 8 = every unit loads the same (L2-resident) tile
     static const int dbg = getenv("STRIVE_CONV_WS_DBG") ? atoi(getenv("STRIVE_CONV_WS_DBG")) : 0;
     hipLaunchKernelGGL(conv_ws_kernel<Cfg>, dim3(grid), dim3(W::NT), W::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out, st_out, N,
                        xscale, 1.0f / (xscale * wscale), dbg);
