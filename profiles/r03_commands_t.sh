@@ -2,7 +2,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/r03x2
+O=gpurun_out/r03x3
 rm -rf $O; mkdir -p $O
 (timeout 600 python -m pytest tests/test_training.py -m gpu -q -s 2>&1 | tail -5) > $O/train_tests.log
 B="python bench.py --no-cpu-baseline --no-roofline --workload train"

@@ -130,10 +130,14 @@ class DataParallelTrainer(object):
         self._bind_grads()
         failed, loss_dict, share, error = 0.0, None, None, None
         try:
+            from . import ops
             pred = self.model(scene_graph, map_idx, map_env, future_sample=future_sample)
             loss_dict = self.loss_fn(scene_graph, pred, map_idx=map_idx, map_env=map_env)
             share = self.global_loss_share(loss_dict, [float(v) for v in local], [float(v) for v in glob])
-            share.backward()
+            # the HIP backward calls accumulate straight into the bucket (every p.grad is a view of it): no scratch, no
+            # per-parameter adds by autograd
+            with ops.GradSink(self.params, self.bucket):
+                share.backward()
         except Exception as e:             # ANY failure on one rank must still reach the collective below, or the others hang
             error = e
             self.last_error = e

@@ -8,6 +8,8 @@ memory, streams and as the autograd host: the decoder rollout and the vehicle-co
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -114,6 +116,61 @@ def weight_grad_mode(enable=True):
 
 def _wgrad():
     return _WeightGradMode.on and torch.is_grad_enabled()
+
+
+class GradSink(object):
+    """Where the training Functions put parameter gradients when the caller keeps ALL gradients in one flat buffer whose
+    ``p.grad`` are views (strive_amd.distributed.DataParallelTrainer): every ``strive_*_bwd`` call ACCUMULATES into the flat
+    layout of its module, so when a module's parameters are consecutive in the buffer the call can add straight into it -- no
+    zero-filled scratch, no per-parameter ``add`` by autograd's AccumulateGrad (350 launches per training step).  The Functions
+    then return ``None`` for those parameters (= no further contribution)."""
+    current = None
+
+    def __init__(self, params, bucket):
+        self.bucket = bucket
+        self.offset = {}
+        off = 0
+        for p in params:
+            self.offset[id(p)] = (off, p.numel())
+            off += p.numel()
+
+    def segment(self, ps):
+        """flat view of the bucket that IS the concatenated gradients of ``ps`` (consecutive in the bucket, and every p.grad still
+        the bucket view), else None"""
+        if not ps:
+            return None
+        ent = self.offset.get(id(ps[0]))
+        if ent is None:
+            return None
+        off0, off = ent[0], ent[0]
+        for p in ps:
+            e = self.offset.get(id(p))
+            if e is None or e[0] != off or p.grad is None or p.grad.data_ptr() != self.bucket.data_ptr() + 4 * off:
+                return None
+            off += e[1]
+        return self.bucket[off0:off]
+
+    def __enter__(self):
+        self.prev = GradSink.current
+        GradSink.current = self
+        return self
+
+    def __exit__(self, *exc):
+        GradSink.current = self.prev
+
+
+def _grad_target(ps, count, dev):
+    """(flat fp32 tensor of ``count`` gradients to ACCUMULATE into, whether the caller must hand the pieces back to autograd)"""
+    sink = GradSink.current
+    if sink is not None and os.environ.get('STRIVE_NO_GRADSINK', '0') != '1':      # (A/B switch)
+        seg = sink.segment(list(ps))
+        if seg is not None and seg.numel() == count and seg.device == dev:
+            return seg, False
+    return torch.zeros((count,), dtype=torch.float32, device=dev), True
+
+
+def _grad_return(flat, ps, give_back):
+    return tuple(_split_like(flat, ps)) if give_back else (None,) * len(ps)
 
 
 def _split_like(flat, params):
@@ -247,10 +304,10 @@ class _MLPFn(torch.autograd.Function):
     def backward(ctx, dy):
         h, x2 = ctx.h, ctx.x2
         n = h.lib.query('strive_mlp_param_count', h.pk.ref())
-        dp = torch.zeros((n,), dtype=torch.float32, device=x2.device)
+        dp, give_back = _grad_target(ctx.ps, n, x2.device)
         dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
         h.lib.call('strive_mlp_bwd', h.pk.ref(), L.ptr(x2), L.ptr(_f32c(dy)), x2.shape[0], L.ptr(dx), L.ptr(dp), _stream(x2))
-        return (dx, None) + tuple(_split_like(dp, ctx.ps))
+        return (dx, None) + _grad_return(dp, ctx.ps, give_back)
 
 
 def mlp_forward(mlp_module, x):
@@ -289,13 +346,13 @@ class _GNNFn(torch.autograd.Function):
     def backward(ctx, d_out):
         h, x2 = ctx.h, ctx.x2
         n = h.lib.query('strive_gnn_param_count', h.pk.ref())
-        dp = torch.zeros((n,), dtype=torch.float32, device=x2.device)
+        dp, give_back = _grad_target(ctx.ps, n, x2.device)
         dx = torch.empty_like(x2)
         wsb = h.lib.query('strive_gnn_bwd_workspace_bytes', h.pk.ref(), h.sc.ref())
         ws = _workspace(x2.device, wsb, 'gnn_bwd')
         h.lib.call('strive_gnn_bwd', h.pk.ref(), h.sc.ref(), L.ptr(x2), L.ptr(h.pos), L.ptr(h.sem), L.ptr(_f32c(d_out)), L.ptr(dx),
                    L.ptr(dp), L.ptr(ws), ws.numel(), _stream(x2))
-        return (dx, None) + tuple(_split_like(dp, ctx.ps))
+        return (dx, None) + _grad_return(dp, ctx.ps, give_back)
 
 
 def gnn_forward(net, scene_graph):
@@ -396,12 +453,12 @@ class _CNNFn(torch.autograd.Function):
     def backward(ctx, d_feat):
         h = ctx.h
         dev = h.p2.device
-        dp = torch.zeros((h.lib.query('strive_map_cnn_param_count'),), dtype=torch.float32, device=dev)
+        dp, give_back = _grad_target(ctx.ps, h.lib.query('strive_map_cnn_param_count'), dev)
         wsb = h.lib.query('strive_map_cnn_bwd_workspace_bytes', h.N)
         ws = _workspace(dev, wsb, 'cnn_bwd')
         h.lib.call('strive_map_cnn_bwd', h.mp.ref(), h.cnn.ref(), L.ptr(h.p2), h.mean4, h.std4, L.ptr(h.mapix), h.N,
                    L.ptr(_f32c(d_feat)), L.ptr(dp), L.ptr(ws), ws.numel(), _stream(h.p2))
-        return (None,) + tuple(_split_like(dp, ctx.ps))
+        return (None,) + _grad_return(dp, ctx.ps, give_back)
 
 
 def encode_map(model, pos, batch_of_agent, map_idx, map_env):
@@ -561,13 +618,25 @@ class _RolloutTrainFn(torch.autograd.Function):
         ng = lib.query('strive_gnn_param_count', C.byref(h.dec.struct.gnn))
         nr = lib.query('strive_gru_param_count')
         nc = lib.query('strive_map_cnn_param_count')
-        dp = torch.zeros((ng + nr + nc,), dtype=torch.float32, device=dev)
+        # the three flat blocks of the call: decoder_net | decoder_memory | map_conv + map_feature (ctx.ps in that order)
+        ps = list(ctx.ps)
+        counts, blocks, k = (ng, nr, nc), [], 0
+        for c in counts:
+            sub, tot = [], 0
+            while tot < c:
+                sub.append(ps[k]); tot += ps[k].numel(); k += 1
+            assert tot == c, 'parameter list does not match the flat gradient layout'
+            blocks.append(sub)
+        targets = [_grad_target(sub, c, dev) for sub, c in zip(blocks, counts)]
         wsb = lib.query('strive_rollout_train_workspace_bytes', h.dec.ref(), h.sc.ref(), h.FT)
         ws = _workspace(dev, wsb, 'rollout_train')
         lib.call('strive_rollout_bwd_train', h.dec.ref(), h.sc.ref(), L.ptr(h.lw), L.ptr(h.sem), L.ptr(ctx.zz), L.ptr(h.ext),
-                 L.ptr(h.mapix), h.FT, L.ptr(_f32c(d_traj)), L.ptr(dz), L.ptr(dpf), L.ptr(dmf), L.ptr(dp[:ng]), L.ptr(dp[ng:ng + nr]),
-                 L.ptr(dp[ng + nr:]), L.ptr(ctx.tape), ctx.tape.numel(), L.ptr(ws), ws.numel(), _stream(d_traj))
-        return (dz.reshape(ctx.zshape), dpf, dmf, None) + tuple(_split_like(dp, ctx.ps))
+                 L.ptr(h.mapix), h.FT, L.ptr(_f32c(d_traj)), L.ptr(dz), L.ptr(dpf), L.ptr(dmf), L.ptr(targets[0][0]), L.ptr(targets[1][0]),
+                 L.ptr(targets[2][0]), L.ptr(ctx.tape), ctx.tape.numel(), L.ptr(ws), ws.numel(), _stream(d_traj))
+        grads = ()
+        for (flat, give_back), sub in zip(targets, blocks):
+            grads += _grad_return(flat, sub, give_back)
+        return (dz.reshape(ctx.zshape), dpf, dmf, None) + grads
 
 
 def _decoder_pack_key(model, map_env, dev):
