@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define STRIVE_ABI_VERSION 12
+#define STRIVE_ABI_VERSION 13
 #define STRIVE_HID 128        /* hidden width of every MLP in the reference (models/common.py, interaction_net.py:32,41) */
 #define STRIVE_MAX_LAYERS 4
 #define STRIVE_ZDIM 32
@@ -185,6 +185,14 @@ int strive_map_cnn_fwd(const StriveMap* map, const StriveCNN* cnn, const float* 
 /* The same CNN on an explicit crop (N,4,256,256) uint8 -- for parity tests of the convolution stack. */
 int strive_map_cnn_fwd_from_crop(const StriveCNN* cnn, const uint8_t* crop, int32_t N, float* feat,
                                  void* ws, size_t ws_bytes, strive_stream_t stream);
+
+/* conv2 normally runs as ONE persistent workgroup per CU (specialised producer / consumer waves).  A caller that runs small
+ * latency-bound kernels on a second stream under the CNN (strive_planner_rollout behind one rollout while the other rollout's CNN
+ * runs on another stream: reference src/utils/adv_gen_optim.py:133-139 inside the closure) switches that off for the calls it
+ * enqueues meanwhile: on != 0 -> the ordinary conv2 kernel.  Process-wide, read when a CNN call is enqueued.  The two
+ * kernels write bit-identical activations; their GroupNorm partial sums are added in a different order (8 rows against 4 row
+ * pairs per tile), so later layers agree to fp32 rounding, not bit for bit. */
+void strive_map_cnn_set_concurrent(int32_t on);
 
 /* Measurement hook for bench.py: launch ONE kernel of the stack (layer 0 = fused crop+conv1, 1..3 = conv2..4,
  * 7 = the fused conv5 + conv6 + Linear kernel strive_map_cnn_fwd runs; 4, 5, 6 = the separate conv5 / conv6 /

@@ -156,6 +156,7 @@ PROTOTYPES = {
     'strive_map_cnn_param_count': (SZ, []),
     'strive_mlp_bwd': (C.c_int, [C.POINTER(StriveMLP), P, P, I, P, P, P]),
     'strive_gnn_bwd_workspace_bytes': (SZ, [C.POINTER(StriveGNN), C.POINTER(StriveScenes)]),
+    'strive_map_cnn_set_concurrent': (None, [C.c_int32]),
     'strive_pack_dense': (C.c_int, [P, C.c_int32, C.c_int32, C.c_float, P, P, P, P]),
     'strive_gnn_bwd': (C.c_int, [C.POINTER(StriveGNN), C.POINTER(StriveScenes), P, P, P, P, P, P, P, SZ, P]),
     'strive_map_cnn_bwd_workspace_bytes': (SZ, [I]),
@@ -171,7 +172,7 @@ PROTOTYPES = {
 }
 
 
-ABI_VERSION = 12   # include/strive_hip.h STRIVE_ABI_VERSION
+ABI_VERSION = 13   # include/strive_hip.h STRIVE_ABI_VERSION
 
 
 class StriveLib(object):
