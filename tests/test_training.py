@@ -98,6 +98,33 @@ def test_training_step_all_gradients_emulated(emu_ops):
     worst = _compare_grads(g, g_o, 5e-3, 2e-3, 'emulated training step')
     print('worst relative L2 gradient error: %s %.3g' % worst)
     assert set(err) == {'pos_err', 'ang_err', 'z_logprob', 'z_mdist'} and err['pos_err'].shape == (NA * 2,)
+    # DataParallelTrainer hands the HIP backward calls its flat gradient bucket (ops.GradSink: no scratch, no per-parameter adds):
+    # the bucket after its forward -> loss -> backward equals the gradients autograd collected above, and the direct path was
+    # actually taken for every block of HIP-side parameters (SGD with lr 0: the step itself changes nothing)
+    from strive_amd import ops
+    from strive_amd.distributed import DataParallelTrainer
+    from strive_amd.losses.traffic_model import TrafficModelLoss
+    want = torch.cat([g[n].reshape(-1) for n, _ in m.named_parameters()]).clone()
+    hits, seg0 = [], ops.GradSink.segment
+
+    def counting(self, ps):
+        r = seg0(self, ps)
+        hits.append((len(ps), r is not None))
+        return r
+    seq = [eps_post, eps_prior]
+    saved = m.rsample
+    m.rsample = lambda mean, var: mean + seq.pop(0).to(mean.device) * torch.sqrt(var)
+    ops.GradSink.segment = counting
+    try:
+        tr = DataParallelTrainer(m, TrafficModelLoss(TW, m.get_normalizer(), m.get_att_normalizer()), torch.optim.SGD(m.parameters(), lr=0.0))
+        res = tr.step(batch.clone(), map_idx, env)
+    finally:
+        ops.GradSink.segment = seg0
+        m.rsample = saved
+    assert res is not None, tr.last_error
+    rel = float((tr.bucket[:-1] - want).norm() / want.norm())
+    assert rel < 1e-5, rel
+    assert len(hits) >= 6 and all(h[1] for h in hits), hits
     # the optimisation entry points still give d/dz only and never touch parameter gradients
     for p in m.parameters():
         p.grad = None
@@ -272,54 +299,3 @@ def test_map_cnn_backward_chunks_add_up():
         assert rel < 2e-5, 'map CNN gradient %s: chunked call differs from the sum of its parts by %.3g' % (k, rel)
     print('worst relative difference: %.3g' % worst)
 
-
-def test_trainer_accumulates_into_its_bucket(emu_ops):
-    """DataParallelTrainer hands the HIP backward calls its flat gradient bucket (ops.GradSink): the bucket after
-    forward -> loss -> backward equals the gradients autograd collects without it, and the direct path was actually taken for
-    every block of HIP-side parameters."""
-    from strive_amd import ops
-    from strive_amd.distributed import DataParallelTrainer
-    from strive_amd.losses.traffic_model import TrafficModelLoss
-    m, sd = product_model(FT=2)
-    batch, map_idx = synth.make_batch([2, 1], key='train/sink', FT=2)
-    raster, dx = synth.make_raster(1024, 1024)
-    env = synth.SyntheticMapEnv(raster, dx)
-    NA = batch.past.shape[0]
-    eps = [synth.f32(synth.counter_normal((NA, 32), 'sink/eps_post')), synth.f32(synth.counter_normal((NA, 32), 'sink/eps_prior'))]
-    m.train()
-    lf = TrafficModelLoss(TW, m.get_normalizer(), m.get_att_normalizer())
-    saved = m.rsample
-
-    def fixed_rsample():
-        seq = list(eps)
-        return lambda mean, var: mean + seq.pop(0).to(mean.device) * torch.sqrt(var)
-    # plain autograd
-    for p in m.parameters():
-        p.grad = None
-    m.rsample = fixed_rsample()
-    out = m(batch.clone(), map_idx, env, future_sample=True)
-    lf(batch.clone(), out, map_idx=map_idx, map_env=env)['loss'][0].backward()
-    want = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in m.parameters()]).clone()
-    # the trainer's path (SGD with lr 0: the step itself changes nothing)
-    hits = []
-    seg0 = ops.GradSink.segment
-
-    def counting(self, ps):
-        r = seg0(self, ps)
-        hits.append((len(ps), r is not None))
-        return r
-    ops.GradSink.segment = counting
-    try:
-        tr = DataParallelTrainer(m, lf, torch.optim.SGD(m.parameters(), lr=0.0))
-        m.rsample = fixed_rsample()
-        res = tr.step(batch.clone(), map_idx, env)
-    finally:
-        ops.GradSink.segment = seg0
-        m.rsample = saved
-    assert res is not None, tr.last_error
-    got = tr.bucket[:-1]
-    # the loss the trainer differentiates is the same sum of means on one rank
-    rel = float((got - want).norm() / want.norm())
-    assert rel < 1e-5, rel
-    assert len(hits) >= 6 and all(h[1] for h in hits), hits
-    m.eval()
