@@ -326,21 +326,25 @@ struct BfCfg {
 };
 
 // v = p0 + p1 up to 2^-24 |v| (p0 = fp16(v) rounded to nearest, p1 = fp16(v - p0)); v is pre-scaled into fp16's range.
+// Two values per conversion (v_cvt_pk_f16_f32 on gfx950, round to nearest even like the scalar form: same bits, 6 instead of 8
+// instructions per pair); the subtraction stays scalar (no packed fp32 arithmetic: DESIGN.md 8.1).
+typedef float split_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 split_f16x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_f16x2(const float v[8], uint4& p0, uint4& p1) {
-    uint32_t h[8], l[8];
+    uint32_t h[4], l[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const _Float16 a = (_Float16)v[i];
-        const float r = v[i] - (float)a;                 // exact
-        const _Float16 c = (_Float16)r;
-        uint16_t ab, cb;
-        __builtin_memcpy(&ab, &a, 2);
-        __builtin_memcpy(&cb, &c, 2);
-        h[i] = ab;
-        l[i] = cb;
+    for (int i = 0; i < 4; ++i) {
+        const split_f32x2 v2 = {v[2 * i], v[2 * i + 1]};
+        const split_f16x2v a = __builtin_convertvector(v2, split_f16x2v);
+        const float r0 = v[2 * i] - (float)a[0];            // exact
+        const float r1 = v[2 * i + 1] - (float)a[1];
+        const split_f32x2 r2 = {r0, r1};
+        const split_f16x2v c = __builtin_convertvector(r2, split_f16x2v);
+        __builtin_memcpy(&h[i], &a, 4);
+        __builtin_memcpy(&l[i], &c, 4);
     }
-    p0 = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-    p1 = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    p0 = make_uint4(h[0], h[1], h[2], h[3]);
+    p1 = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
 // TIMING: phase timestamps (s_memtime) of every workgroup summed into `tprof` (measurement hook only)
