@@ -73,14 +73,16 @@ def two_rollouts(model, embed_info, scene_graph, map_idx, map_env, z_a, kw_a, z_
         from .. import _lib as L
         lib = L.get_lib()
         lib.query('strive_map_cnn_set_concurrent', 1)
-    for i, (st, z, kw) in enumerate(zip(streams, (z_a, z_b), (kw_a, kw_b))):
-        st.wait_stream(cur)
-        with torch.cuda.stream(st):
-            outs.append(model.decode_embedding(z, embed_info, scene_graph, map_idx, map_env, **kw))
-            if i == 0 and after_a is not None:
-                extra = after_a(outs[0])
-    if lib is not None:
-        lib.query('strive_map_cnn_set_concurrent', 0)          # (the launches above are enqueued)
+    try:
+        for i, (st, z, kw) in enumerate(zip(streams, (z_a, z_b), (kw_a, kw_b))):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(model.decode_embedding(z, embed_info, scene_graph, map_idx, map_env, **kw))
+                if i == 0 and after_a is not None:
+                    extra = after_a(outs[0])
+    finally:
+        if lib is not None:
+            lib.query('strive_map_cnn_set_concurrent', 0)      # (the launches above are enqueued; also when one of them raised)
     for st, o in zip(streams, outs):
         cur.wait_stream(st)
         for v in o.values():
