@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define STRIVE_ABI_VERSION 13
+#define STRIVE_ABI_VERSION 14
 #define STRIVE_HID 128        /* hidden width of every MLP in the reference (models/common.py, interaction_net.py:32,41) */
 #define STRIVE_MAX_LAYERS 4
 #define STRIVE_ZDIM 32
@@ -73,7 +73,11 @@ typedef struct StriveGNN {
 
 /* 3-layer GRU memory, hidden 64, input 4; reference src/models/traffic_model.py:151-156.
  * wih_t[l]: (in_l, 192) with in_0 = 4, in_1 = in_2 = 64;  whh_t[l]: (64, 192); gate order r,z,n.
- * wih[l], whh[l]: torch layouts (192, in_l), (192, 64) for the backward kernels. */
+ * wih[l], whh[l]: torch layouts (192, in_l), (192, 64) for the backward kernels.
+ * Optional matrix-core operands (ABI 14; NULL = the scene-resident rollout kernels are not used): whh_f[l] / wih_f[l] = the
+ * two-piece fp16 fragments (StriveMLP.wf layout) of whh[l] * hh_sc[l] / wih[l] * ih_sc[l] (rows = the 192 gate outputs),
+ * whh_bf[l] / wih_bf[l] those of the transposes (rows = the 64 inputs: the input-gradient products of the reverse sweep).
+ * Layer 0's input is 4 wide: wih_f[0] / wih_bf[0] stay NULL (that product runs on the vector ALUs). */
 typedef struct StriveGRU {
     const float* wih[3];
     const float* whh[3];
@@ -81,6 +85,12 @@ typedef struct StriveGRU {
     const float* whh_t[3];
     const float* bih[3];
     const float* bhh[3];
+    const void* whh_f[3];
+    const void* wih_f[3];
+    const void* whh_bf[3];
+    const void* wih_bf[3];
+    float hh_sc[3];
+    float ih_sc[3];
 } StriveGRU;
 
 /* Rasterised maps + crop geometry; reference src/datasets/map_env.py:50-61,165-166 and
@@ -224,6 +234,13 @@ int strive_gnn_fwd(const StriveGNN* gnn, const StriveScenes* sc, const float* x,
 
 size_t strive_rollout_tape_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT);
 size_t strive_rollout_workspace_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT);
+
+/* 1 when strive_rollout_fwd / strive_rollout_bwd will run this batch on the scene-resident kernels (one workgroup per scene:
+ * a decoder step is ONE launch, the reverse sweep over all FT steps is ONE launch; csrc/scene_rollout.h) -- single-sample
+ * rollouts, scenes of <= 16 agents, weight packs with matrix-core fragments (StriveMLP.wf / StriveGRU.whh_f) -- else 0: the
+ * launch-per-phase kernels.  Same arithmetic scheme, same tape layout; results agree to fp32 rounding.  The environment
+ * variable STRIVE_SCENE_KERNELS=0 (read per call) forces 0. */
+int strive_rollout_scene_resident(const StriveDecoder* dec, const StriveScenes* sc);
 
 /* TrafficModel.autoregressive_decoder (reference src/models/traffic_model.py:589-704).
  * past_last (NA,6) normalised last past state; lw (NA,2) normalised; sem (NA,NC); past_feat, map_feat

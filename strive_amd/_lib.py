@@ -39,7 +39,9 @@ class StriveGNN(C.Structure):
 
 class StriveGRU(C.Structure):
     _fields_ = [('wih', C.c_void_p * 3), ('whh', C.c_void_p * 3), ('wih_t', C.c_void_p * 3),
-                ('whh_t', C.c_void_p * 3), ('bih', C.c_void_p * 3), ('bhh', C.c_void_p * 3)]
+                ('whh_t', C.c_void_p * 3), ('bih', C.c_void_p * 3), ('bhh', C.c_void_p * 3),
+                ('whh_f', C.c_void_p * 3), ('wih_f', C.c_void_p * 3), ('whh_bf', C.c_void_p * 3), ('wih_bf', C.c_void_p * 3),
+                ('hh_sc', C.c_float * 3), ('ih_sc', C.c_float * 3)]
 
 
 class StriveMap(C.Structure):
@@ -130,6 +132,7 @@ PROTOTYPES = {
     'strive_mlp_fwd': (C.c_int, [C.POINTER(StriveMLP), P, I, P, P]),
     'strive_gnn_workspace_bytes': (SZ, [C.POINTER(StriveGNN), C.POINTER(StriveScenes)]),
     'strive_gnn_fwd': (C.c_int, [C.POINTER(StriveGNN), C.POINTER(StriveScenes), P, P, P, P, P, SZ, P]),
+    'strive_rollout_scene_resident': (C.c_int, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes)]),
     'strive_rollout_tape_bytes': (SZ, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), I]),
     'strive_rollout_workspace_bytes': (SZ, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), I]),
     'strive_rollout_fwd': (C.c_int, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), P, P, P, P, P, P, P, P, I,
@@ -172,7 +175,7 @@ PROTOTYPES = {
 }
 
 
-ABI_VERSION = 13   # include/strive_hip.h STRIVE_ABI_VERSION
+ABI_VERSION = 14   # include/strive_hip.h STRIVE_ABI_VERSION
 
 
 class StriveLib(object):

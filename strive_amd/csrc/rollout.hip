@@ -10,6 +10,7 @@
 // (cheap: the GNN/GRU are ~1.6 MFLOP per agent-step against 300 MFLOP for the CNN, which needs no backward
 // at all because the reference crops at pos.detach()).  The backward is four launches per step:
 // node1 (recompute), gru_bwd, node2_bwd, edge_bwd, node1_bwd.
+#include <atomic>
 #include "gnn_bwd_kernels.h"
 
 struct DynParams {
@@ -337,10 +338,36 @@ static __global__ void rollout_init_kernel(Tape tp, const float* __restrict__ pa
     if (c == 0) mapix_rows[r] = mapix[ag];
 }
 
+#include "scene_rollout.h"
+
 // =============================================================================================
 // host orchestration: forward
 // =============================================================================================
 namespace {
+
+// The scene-resident kernels (scene_rollout.h) serve single-sample rollouts of scenes with <= 16 agents whose weight packs
+// carry matrix-core fragments; STRIVE_SCENE_KERNELS=0 keeps the launch-per-phase kernels (A/B measurements).
+bool scene_kernels_on(const StriveDecoder* dec, const StriveScenes* sc) {
+    const char* e = getenv("STRIVE_SCENE_KERNELS");          // read per call: tests and A/B runs switch it inside one process
+    return !(e && atoi(e) == 0) && scn::supported(*dec, *sc);
+}
+
+// more than 64 KB of LDS per workgroup needs the attribute, once per device
+int scene_kernels_prepare() {
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    if (done.load(std::memory_order_acquire) & (1ull << dev)) return 0;
+    if (hipFuncSetAttribute((const void*)scn::scene_fwd_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scn::FwdLds::BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)scn::scene_fwd_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scn::FwdLds::BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)scn::scene_bwd_sweep_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scn::BwdLds::BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)scn::scene_bwd_sweep_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scn::BwdLds::BYTES) != hipSuccess) {
+        strive_set_error("rollout: the scene kernels' LDS request was refused");
+        return -1;
+    }
+    done.fetch_or(1ull << dev, std::memory_order_release);
+    return 0;
+}
 
 struct FwdWs {
     GnnBuffers gb;       // X, P, Q (A/ARG live in the tape)
@@ -400,6 +427,10 @@ int check_decoder(const StriveDecoder* dec, const StriveScenes* sc, int FT) {
 
 }  // namespace
 
+extern "C" int strive_rollout_scene_resident(const StriveDecoder* dec, const StriveScenes* sc) {
+    return dec && sc && scene_kernels_on(dec, sc) ? 1 : 0;
+}
+
 extern "C" size_t strive_rollout_tape_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT) {
     if (!sc) return 0;
     return tape_bytes_for((size_t)sc->NA * sc->NS, FT, sc->max_n > 0 ? sc->max_n : 1);
@@ -437,9 +468,31 @@ extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* 
     const int in_ld1 = ld4(dec->gnn.mlp_in.dims[0]), xs_ld = ld4(64 + NC), in_ld2 = ld4(128 + NC);
     const int nb = (int)((R + RB_NODE - 1) / RB_NODE);
 
+    const bool scene = scene_kernels_on(dec, sc);
+    if (scene && scene_kernels_prepare()) return -1;
+    const scn::GRUFrag gf = scn::gru_frag(dec->gru);
+    const char* pe = getenv("STRIVE_SCENE_PROF");
+    const bool scene_prof = scene && pe && atoi(pe) != 0;
     hipLaunchKernelGGL(rollout_init_kernel, dim3((unsigned)((R * 64 + 255) / 256)), dim3(256), 0, stream, tp, past_last,
                        past_feat, map_feat, mapix, w.mapix_rows, (int)R, sc->NS);
     for (int t = 0; t < FT; ++t) {
+        if (scene) {
+            scn::StepArgsS a;
+            a.t = t; a.FT = FT; a.NC = NC; a.max_n = sc->max_n; a.sem = sem; a.lw = lw; a.z = z; a.ext = ext_future; a.ptr = sc->ptr;
+            a.traj = traj;
+            if (scene_prof)       // (tools/scene_phase_probe.py: phase ticks of workgroup 0 at the start of the workspace)
+                hipLaunchKernelGGL(scn::scene_fwd_step_kernel<true>, dim3((unsigned)sc->B), dim3(scn::NTHR), scn::FwdLds::BYTES, stream, gd, gr,
+                                   gf, dp, a, tp, (unsigned long long*)ws);
+            else
+                hipLaunchKernelGGL(scn::scene_fwd_step_kernel<false>, dim3((unsigned)sc->B), dim3(scn::NTHR), scn::FwdLds::BYTES, stream, gd, gr,
+                                   gf, dp, a, tp, (unsigned long long*)nullptr);
+            if (t < FT - 1) {
+                int rc = strive_map_cnn_fwd(&dec->map, &dec->cnn, tp.pos_t(t + 1), dec->state_mean, dec->state_std,
+                                            w.mapix_rows, (int32_t)R, tp.mf_t(t + 1), w.cnn_ws, w.cnn_bytes, stream_);
+                if (rc) return rc;
+            }
+            continue;
+        }
         GnnBuffers gb = w.gb;
         gb.A = tp.A_t(t);
         gb.ARG = tp.ARG_t(t);
@@ -897,6 +950,25 @@ extern "C" int strive_rollout_bwd(const StriveDecoder* dec, const StriveScenes* 
     STRIVE_CHECK_ARG(tape_bytes >= tape_bytes_for(R, FT, sc->max_n > 0 ? sc->max_n : 1), "tape too small");
     STRIVE_CHECK_ARG(ws_bytes >= strive_rollout_workspace_bytes(dec, sc, FT), "workspace too small");
     STRIVE_CHECK_ARG(sc->max_n >= 1, "max_n not set");
+    if (scene_kernels_on(dec, sc)) {
+        // the whole reverse sweep of a scene in one launch (scene_rollout.h)
+        if (scene_kernels_prepare()) return -1;
+        Tape tp = carve_tape(const_cast<void*>(tape), tape_bytes, R, FT, sc->max_n);
+        scn::SweepArgs a;
+        a.FT = FT; a.NC = dec->gnn.NC; a.max_n = sc->max_n; a.sem = sem; a.lw = lw; a.ext = ext_future; a.ptr = sc->ptr;
+        a.g_traj = d_traj; a.dz = dz;
+        // STRIVE_SCENE_PROF=1 (tools/scene_phase_probe.py): workgroup 0 adds the core-clock ticks of every phase to 16 counters at the
+        // start of the workspace, which this path does not use otherwise
+        const char* pe = getenv("STRIVE_SCENE_PROF");
+        if (pe && atoi(pe) != 0)
+            hipLaunchKernelGGL(scn::scene_bwd_sweep_kernel<true>, dim3((unsigned)sc->B), dim3(scn::NTHR), scn::BwdLds::BYTES, (hipStream_t)stream_,
+                               gnn_dev(dec->gnn), gru_dev(dec->gru), scn::gru_frag(dec->gru), dyn_params(*dec), a, tp, (unsigned long long*)ws + 32);
+        else
+            hipLaunchKernelGGL(scn::scene_bwd_sweep_kernel<false>, dim3((unsigned)sc->B), dim3(scn::NTHR), scn::BwdLds::BYTES, (hipStream_t)stream_,
+                               gnn_dev(dec->gnn), gru_dev(dec->gru), scn::gru_frag(dec->gru), dyn_params(*dec), a, tp, (unsigned long long*)nullptr);
+        STRIVE_CHECK_LAUNCH();
+        return 0;
+    }
     int rc = rollout_backward<false>(dec, sc, lw, sem, z, ext_future, FT, d_traj, dz, tape, tape_bytes, ws, ws_bytes, stream_, nullptr);
     if (rc) return rc;
     STRIVE_CHECK_LAUNCH();

@@ -198,6 +198,7 @@ def pack_gnn(sd, prefix, NC):
 
 
 def _fill_gru(s, holder, sd, prefix):
+    prefetch_absmax([_c(sd['%s.weight_%s_l%d' % (prefix, k, l)]) for l in range(3) for k in ('ih', 'hh')])
     for l in range(3):
         wih = _c(sd['%s.weight_ih_l%d' % (prefix, l)])
         whh = _c(sd['%s.weight_hh_l%d' % (prefix, l)])
@@ -207,6 +208,25 @@ def _fill_gru(s, holder, sd, prefix):
         s.whh_t[l] = holder.hold(whh.t().contiguous())
         s.bih[l] = holder.hold(_c(sd['%s.bias_ih_l%d' % (prefix, l)]))
         s.bhh[l] = holder.hold(_c(sd['%s.bias_hh_l%d' % (prefix, l)]))
+        # matrix-core operands of the scene-resident rollout kernels (csrc/scene_rollout.h): both fragment tables of every
+        # 192 x 64 matrix (layer 0's 192 x 4 input matrix stays on the vector ALUs)
+        if os.environ.get('STRIVE_DENSE_VALU', '0') == '1':
+            continue
+        for name, w in (('hh', whh), ('ih', wih)):
+            if w.shape[1] < 32:
+                continue
+            sc = _pow2_scale(_checked_absmax(w, 'GRU'))
+            M, K = w.shape
+            lib = _pack_lib(w)
+            if lib is not None:
+                wf = torch.empty((((M + 15) // 16) * ((K + 31) // 32) * 512,), dtype=torch.int32, device=w.device)
+                wbf = torch.empty((((K + 15) // 16) * ((M + 31) // 32) * 512,), dtype=torch.int32, device=w.device)
+                lib.call('strive_pack_dense', L.ptr(w), M, K, sc, None, L.ptr(wf), L.ptr(wbf), L.stream_ptr(w))
+            else:
+                wf, wbf = dense_fragments(w, sc), dense_fragments(w.t().contiguous(), sc)
+            getattr(s, 'w%s_f' % name)[l] = holder.hold(wf)
+            getattr(s, 'w%s_bf' % name)[l] = holder.hold(wbf)
+            getattr(s, '%s_sc' % name)[l] = sc
 
 
 def _pow2_scale(bound, target=32768.0):

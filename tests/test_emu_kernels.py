@@ -633,3 +633,56 @@ def _pack_dense_case(lib, dev, M, K, key):
 @pytest.mark.parametrize('M,K', [(128, 128), (64, 128), (128, 164), (192, 64), (32, 40), (2, 128), (128, 4)])
 def test_pack_dense_equals_torch_layout(emu, M, K):
     _pack_dense_case(emu, 'cpu', M, K, 'pack/%d/%d' % (M, K))
+
+
+# ---- scene-resident rollout kernels (csrc/scene_rollout.h) against the launch-per-phase kernels on the same inputs ----
+def _rollout_both_paths(emu, sd, sizes, FT, ext=False, NC=2, monkeypatch=None):
+    batch, map_idx, raster, dx = mg.build_inputs(sizes, 'emu', NC=NC)
+    env = synth.SyntheticMapEnv(raster, dx)
+    orc = oracle_model(sd, NC=NC)
+    NA = batch.past.shape[0]
+    emb = {'map_feat': synth.f32(synth.counter_uniform((NA, 64), 'emu/mf', -1, 1)),
+           'past_feat': synth.f32(synth.counter_uniform((NA, 64), 'emu/pf', -1, 1))}
+    z = synth.f32(synth.counter_uniform((NA, 32), 'emu/zz', -1.5, 1.5)).contiguous()
+    extf = batch.future_gt[batch.ptr[:-1]][:, :FT, :4].contiguous() if ext else None
+    sn, an = orc.get_normalizer(), orc.get_att_normalizer()
+    dec = params.pack_decoder(sd, NC, env, 'cpu', sn, an, NUSC_BIKE_PARAMS)
+    sc = params.pack_scenes(batch.ptr, 1, 'cpu')
+    tb = emu.query('strive_rollout_tape_bytes', dec.ref(), sc.ref(), FT)
+    wb = emu.query('strive_rollout_workspace_bytes', dec.ref(), sc.ref(), FT)
+    rw = synth.f32(synth.counter_uniform((NA, FT, 4), 'emu/rw', -1.0, 1.0)).contiguous()
+    mi = map_idx[batch.batch].int().contiguous()
+    lw, sem = batch.lw.contiguous(), batch.sem.contiguous()
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('STRIVE_SCENE_KERNELS', mode)
+        assert emu.query('strive_rollout_scene_resident', dec.ref(), sc.ref()) == int(mode)
+        tape, ws = torch.zeros(tb, dtype=torch.uint8), torch.zeros(wb, dtype=torch.uint8)
+        traj = torch.zeros((NA, FT, 4))
+        emu.call('strive_rollout_fwd', dec.ref(), sc.ref(), L.ptr(batch.past[:, -1, :].contiguous()), L.ptr(lw), L.ptr(sem),
+                 L.ptr(emb['past_feat'].contiguous()), L.ptr(emb['map_feat'].contiguous()), L.ptr(z), L.ptr(mi), L.ptr(extf), FT,
+                 L.ptr(traj), L.ptr(tape), tb, L.ptr(ws), wb, None)
+        dz = torch.zeros((NA, 32))
+        emu.call('strive_rollout_bwd', dec.ref(), sc.ref(), L.ptr(lw), L.ptr(sem), L.ptr(z), L.ptr(extf), FT,
+                 L.ptr(rw), L.ptr(dz), L.ptr(tape), tb, L.ptr(ws), wb, None)
+        out[mode] = (traj, dz, tape)
+    # cross pairing: the tape is the same layout, so the sweep of one path runs on the tape of the other
+    monkeypatch.setenv('STRIVE_SCENE_KERNELS', '1')
+    dz_x = torch.zeros((NA, 32))
+    ws = torch.zeros(wb, dtype=torch.uint8)
+    emu.call('strive_rollout_bwd', dec.ref(), sc.ref(), L.ptr(lw), L.ptr(sem), L.ptr(z), L.ptr(extf), FT,
+             L.ptr(rw), L.ptr(dz_x), L.ptr(out['0'][2]), tb, L.ptr(ws), wb, None)
+    return out, dz_x
+
+
+@pytest.mark.parametrize('sizes,FT,ext', [([3, 1, 5, 2], 1, False), ([16, 9], 1, True), ([4, 2], 3, True)])
+def test_scene_resident_rollout_equals_phase_kernels(emu, sd, sizes, FT, ext, monkeypatch):
+    """One workgroup per scene (a step = one launch, the reverse sweep = one launch) against the launch-per-phase kernels:
+    same trajectories and latent gradients to fp32 rounding; scenes of 1, 2 and 16 agents (no edges / one edge row / four
+    chunks of edge rows), teacher-forced ego rows, several steps (GRU + CNN between the steps)."""
+    out, dz_x = _rollout_both_paths(emu, sd, sizes, FT, ext=ext, monkeypatch=monkeypatch)
+    (t0, d0, _), (t1, d1, _) = out['0'], out['1']
+    assert_close(t1, t0, 2e-5, 2e-6, 'scene-resident forward')
+    scale = float(d0.abs().max())
+    assert_close(d1, d0, 1e-3, 2e-5 * scale, 'scene-resident backward')
+    assert_close(dz_x, d0, 1e-3, 2e-5 * scale, 'scene-resident sweep on the phase kernels\' tape')

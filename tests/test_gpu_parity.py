@@ -613,8 +613,10 @@ def test_full_size_properties(model):
     # multi-sample path with identical samples == 2-D path
     with torch.no_grad():
         ns = m.decode_embedding(torch.stack([z, z], dim=1).contiguous(), emb, bg, mi, env)['future_pred']
-    assert_close(ns[:, 0], full, 0, 1e-6, 'NS path sample 0')
-    assert_close(ns[:, 1], full, 0, 1e-6, 'NS path sample 1')
+    # (the multi-sample rollout runs on the launch-per-phase kernels, the 2-D one on the scene-resident kernels since round 4:
+    #  the same arithmetic scheme in a different summation order, so fp32 rounding apart -- 2 ulp of the largest coordinate seen)
+    assert_close(ns[:, 0], full, 2e-6, 2e-6, 'NS path sample 0')
+    assert_close(ns[:, 1], full, 2e-6, 2e-6, 'NS path sample 1')
 
 
 def test_fused_losses_are_bitwise_reproducible(model, g5):
