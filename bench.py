@@ -187,17 +187,21 @@ def refine_closure_factory(m, env, batch, map_idx, FT, device):
         emb = detach_embed_info(m.embed(g, mi, env))
     z0 = synth.make_latents(emb['prior_out'][0].cpu(), emb['prior_out'][1].cpu(), key='bench/z').to(device)
     z = z0.clone().requires_grad_(True)
-    opt = torch.optim.Adam([z], lr=0.05)
+    # like strive_amd.refine_traffic_optim: small batches replay the iteration as a HIP graph (strive_amd/utils/graphed.py)
+    from strive_amd.utils.graphed import GraphedIteration, adam_kwargs, graph_mode
+    graphed = graph_mode(z.shape[0], device)
+    opt = torch.optim.Adam([z], lr=0.05, **adam_kwargs(graphed))
     loss_fn = AvoidCollLoss(REFINE_WEIGHTS, m.get_att_normalizer().unnormalize(g.lw), mi[g.batch], env, z0.clone(),
                             veh_coll_buffer=0.2)
 
-    def step():
+    def iteration():
         opt.zero_grad()
         pred = m.decode_embedding(z, emb, g, mi, env, nfuture=FT)['future_pred']
         ld = loss_fn(m.get_normalizer().unnormalize(pred), z, emb['prior_out'])
         ld['loss'].backward()
         opt.step()
         return ld['loss']
+    step = GraphedIteration(iteration, graphed)
     return step, emb, g, mi, 1
 
 
@@ -231,7 +235,8 @@ def adv_closure_factory(m, env, batch, map_idx, FT, device):
     c = AdvClosure(emb['posterior_out'][0].clone(), 0.05, ADV_WEIGHTS, m, g, env, mi, emb, (pm[ego], pv[ego]),
                    (pm[~ego], pv[~ego]), 2, 0.0, planner_fut=g.future_gt[ego][:, :FT, :4].contiguous(), future_len=FT,
                    veh_coll_buffer=0.1)
-    return (lambda: c.step()), emb, g, mi, 2
+    from strive_amd.utils.graphed import GraphedIteration
+    return GraphedIteration(c.step, c.graphed), emb, g, mi, 2
 
 
 def full_pipeline_factory(m, env, batch, map_idx, FT, device, scale=1.0):
@@ -743,6 +748,12 @@ def main():
         step, emb, g, mi, rollouts = factory(m, env, batch, map_idx, args.ft, device)
     for _ in range(args.warmup):
         step()
+    hip_graph = bool(getattr(step, 'enabled', False))
+    if hip_graph:
+        # the iteration is captured after GraphedIteration's eager calls: finish that before the timed region starts
+        while step.graph is None and step.enabled:
+            step()
+        hip_graph = step.graph is not None
 
     def barrier():
         if use_dist:
@@ -799,6 +810,16 @@ def main():
     cfg_ref = {'refine': 'BASELINE.json configs[1]', 'adv': 'BASELINE.json configs[2]', 'sharded4096': 'BASELINE.json configs[4]',
                'train': 'BASELINE.json configs[3]', 'sample': 'SURVEY 8 a18: adv_scenario_gen.py:160-174',
                'full': 'BASELINE.json configs[2], end to end'}
+    # which decoder kernels served the rollouts of this batch (include/strive_hip.h strive_rollout_scene_resident)
+    rollout_kernels = None
+    try:
+        from strive_amd import ops as _ops, _lib as _L
+        pk = [v[1] for k, v in m.__dict__.get('_strive_packs', {}).items() if isinstance(k, tuple) and k and k[0] == 'dec']
+        sc = _ops.scene_info(g).pack(1)
+        if pk:
+            rollout_kernels = 'scene-resident' if _L.get_lib().query('strive_rollout_scene_resident', pk[0].ref(), sc.ref()) else 'per-phase'
+    except Exception:
+        rollout_kernels = None
     out = {
         'metric': 'adv-optim agent*timesteps/sec (decoder fwd+bwd)',
         'value': round(units / dt, 1), 'unit': 'agent*timesteps/s', 'n_gpus': world, 'steps': args.steps,
@@ -808,8 +829,12 @@ def main():
                    'agents_per_gpu': NA, 'FT': args.ft, 'NC': args.nc, 'rollouts_per_closure': rollouts,
                    'raster': '%dx%d x4 uint8 @0.25 m' % (args.raster, args.raster),
                    'parallelism': 'scene-sharded replicas x%d' % world,
-                   'arithmetic': 'fp32 everywhere; the map CNN on the fp16 matrix cores with two-piece round-to-nearest operand splits '
-                                 '(3 products per fp32 product, dropped terms <= 2^-24), fp32 accumulate'},
+                   'arithmetic': ('fp32 everywhere; the map CNN on the fp16 matrix cores with two-piece round-to-nearest operand splits '
+                                  '(3 products per fp32 product, dropped terms <= 2^-24), fp32 accumulate' if args.workload != 'train' else
+                                  'fp32 everywhere; forward map CNN and dense layers on the fp16 matrix cores with two-piece round-to-nearest '
+                                  'operand splits (3 products per fp32 product, dropped terms <= 2^-24); the CNN BACKWARD (data and weight '
+                                  'gradients) with two-piece bf16 operand splits: 2^-16 per product (TF32-class), fp32 accumulate'),
+                   'rollout_kernels': rollout_kernels, 'hip_graph': hip_graph},
         'final_loss': float(loss.detach().cpu()),
         'host_enqueue_ms_per_step': round(dt_host / args.steps * 1e3, 3),     # diagnostic: the host has queued everything by then
         'planner': None if planner_ms is None else planner_ms,

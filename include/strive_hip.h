@@ -160,6 +160,14 @@ typedef struct StriveDecoder {
     float state_mean[6], state_std[6];   /* (x,y,hx,hy,s,hdot) normaliser, datasets/utils.py:44-113 */
     float att_mean[2], att_std[2];       /* (l,w) normaliser */
     float a_mean, a_std, ddh_mean, ddh_std, dt, max_hdot, max_s;   /* NUSC_BIKE_PARAMS, datasets/utils.py:121-127 */
+    /* optional (ABI 14; NULL = the scene-resident kernels are not used): the small parameters of decoder_net / decoder_memory in
+     * one block of 6340 floats that those kernels copy to LDS -- offsets in floats (csrc/scene_rollout.h Par):
+     * mlp_in  b0 0, b1 128, b2 256, ln_g0 320, ln_b0 448, ln_g1 576, ln_b1 704;
+     * edge    b0 832, b1 960, b2 1088, ln_g0 1152, ln_b0 1280, ln_g1 1408, ln_b1 1536, W_rel^T (4,128) = rows 128+2NC.. of wt[0] 1664;
+     * update  b0 2176, b1 2304, ln_g0 2368, ln_b0 2496;
+     * mlp_out b0 2624, b1 2752, b2 2880 (2 + 2 pad), ln_g0 2884, ln_b0 3012, ln_g1 3140, ln_b1 3268, w[2] (2,128) 3396;
+     * GRU     b_ih (3,192) 3652, b_hh (3,192) 4228, wih_t[0] (4,192) 4804, wih[0] (192,4) 5572. */
+    const float* scene_par;
 } StriveDecoder;
 
 /* ------------------------------------------------------------------------------------------------

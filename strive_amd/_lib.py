@@ -83,7 +83,7 @@ class StriveDecoder(C.Structure):
                 ('state_mean', C.c_float * 6), ('state_std', C.c_float * 6),
                 ('att_mean', C.c_float * 2), ('att_std', C.c_float * 2),
                 ('a_mean', C.c_float), ('a_std', C.c_float), ('ddh_mean', C.c_float), ('ddh_std', C.c_float),
-                ('dt', C.c_float), ('max_hdot', C.c_float), ('max_s', C.c_float)]
+                ('dt', C.c_float), ('max_hdot', C.c_float), ('max_s', C.c_float), ('scene_par', C.c_void_p)]
 
 
 class StriveLaneNode(C.Structure):

@@ -479,7 +479,7 @@ extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* 
         if (scene) {
             scn::StepArgsS a;
             a.t = t; a.FT = FT; a.NC = NC; a.max_n = sc->max_n; a.sem = sem; a.lw = lw; a.z = z; a.ext = ext_future; a.ptr = sc->ptr;
-            a.traj = traj;
+            a.par = dec->scene_par; a.traj = traj;
             if (scene_prof)       // (tools/scene_phase_probe.py: phase ticks of workgroup 0 at the start of the workspace)
                 hipLaunchKernelGGL(scn::scene_fwd_step_kernel<true>, dim3((unsigned)sc->B), dim3(scn::NTHR), scn::FwdLds::BYTES, stream, gd, gr,
                                    gf, dp, a, tp, (unsigned long long*)ws);
@@ -956,7 +956,7 @@ extern "C" int strive_rollout_bwd(const StriveDecoder* dec, const StriveScenes* 
         Tape tp = carve_tape(const_cast<void*>(tape), tape_bytes, R, FT, sc->max_n);
         scn::SweepArgs a;
         a.FT = FT; a.NC = dec->gnn.NC; a.max_n = sc->max_n; a.sem = sem; a.lw = lw; a.ext = ext_future; a.ptr = sc->ptr;
-        a.g_traj = d_traj; a.dz = dz;
+        a.par = dec->scene_par; a.g_traj = d_traj; a.dz = dz;
         // STRIVE_SCENE_PROF=1 (tools/scene_phase_probe.py): workgroup 0 adds the core-clock ticks of every phase to 16 counters at the
         // start of the workspace, which this path does not use otherwise
         const char* pe = getenv("STRIVE_SCENE_PROF");

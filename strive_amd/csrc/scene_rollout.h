@@ -65,7 +65,7 @@ static inline GRUFrag gru_frag(const StriveGRU& g) {
 
 // Are the matrix-core operands this path needs all there (weights packed with fragments, GRU included)?
 static inline bool supported(const StriveDecoder& d, const StriveScenes& sc) {
-    if (sc.NS != 1 || sc.max_n > NR || sc.max_n < 1) return false;
+    if (sc.NS != 1 || sc.max_n > NR || sc.max_n < 1 || !d.scene_par) return false;
     if (d.gnn.D != 64 || d.gnn.NC > 8) return false;
     // k-step counts the kernels are written for: mlp_in 162 + NC -> 6, edge layer 0 (132 + 2 NC: sem_i, sem_j and the relative
     // pose share the 5th step), update 128 + NC -> 5
@@ -375,7 +375,8 @@ __device__ __forceinline__ void mma_tiles(const uint4* __restrict__ frag, int KS
         const int nt = T % NTL, rt = T / NTL;
         const int row = 16 * rt + row16;
         const unsigned char* bp = sb.base + (size_t)row * sb.BROW + g * 16;
-        mf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // one accumulator per product term: three independent chains of NK matrix instructions instead of one of 3 NK
+        mf_f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
         auto tile = [&](const uint4 (&a)[NK][2]) {
 #pragma unroll
             for (int i = 0; i < NK; ++i) {
@@ -384,8 +385,8 @@ __device__ __forceinline__ void mma_tiles(const uint4* __restrict__ frag, int KS
                 mf_f16x8 w0, w1;
                 __builtin_memcpy(&w0, &a[i][0], 16);
                 __builtin_memcpy(&w1, &a[i][1], 16);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, b1, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, b0, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, b1, acc2, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, b0, acc, 0, 0, 0);
             }
         };
@@ -397,7 +398,7 @@ __device__ __forceinline__ void mma_tiles(const uint4* __restrict__ frag, int KS
         const float rs = sb.rs[row] * inv_w;
         float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[r] * rs;
+        for (int r = 0; r < 4; ++r) v[r] = ((acc1[r] + acc2[r]) + acc[r]) * rs;
         epi(row, 16 * (nt0 + nt) + 4 * g, v);
     }
 }
@@ -434,33 +435,27 @@ struct Par {
         E_B0 = 832, E_B1 = 960, E_B2 = 1088, E_G0 = 1152, E_E0 = 1280, E_G1 = 1408, E_E1 = 1536, E_WREL = 1664,
         U_B0 = 2176, U_B1 = 2304, U_G0 = 2368, U_E0 = 2496,
         O_B0 = 2624, O_B1 = 2752, O_B2 = 2880, O_G0 = 2884, O_E0 = 3012, O_G1 = 3140, O_E1 = 3268, O_W2 = 3396,
-        R_BIH = 3652, R_BHH = 4228, R_WIH0 = 4804, FLOATS = 5572
+        R_BIH = 3652, R_BHH = 4228, R_WIH0T = 4804, R_WIH0 = 5572, FLOATS = 6340
     };
 };
 
-// forward = true: everything; false (the sweep): LayerNorm terms, W_rel, the last layer's rows, W_ih of GRU layer 0 (torch layout)
-__device__ __forceinline__ void par_stage(float* par, const GNNDev& g, const GRUDev& gru, int NC, bool forward, int tid) {
-    auto cp = [&](int off, const float* __restrict__ src, int n) {
-        for (int i = tid; i < n; i += NTHR) par[off + i] = src[i];
-    };
-    const int H = STRIVE_HID;
-    cp(Par::IN_G0, g.mlp_in.ln_g[0], H); cp(Par::IN_E0, g.mlp_in.ln_b[0], H); cp(Par::IN_G1, g.mlp_in.ln_g[1], H); cp(Par::IN_E1, g.mlp_in.ln_b[1], H);
-    cp(Par::E_G0, g.edge.ln_g[0], H); cp(Par::E_E0, g.edge.ln_b[0], H); cp(Par::E_G1, g.edge.ln_g[1], H); cp(Par::E_E1, g.edge.ln_b[1], H);
-    cp(Par::E_WREL, g.edge.wt[0] + (size_t)(2 * 64 + 2 * NC) * H, 4 * H);
-    cp(Par::U_G0, g.update.ln_g[0], H); cp(Par::U_E0, g.update.ln_b[0], H);
-    cp(Par::O_G0, g.mlp_out.ln_g[0], H); cp(Par::O_E0, g.mlp_out.ln_b[0], H); cp(Par::O_G1, g.mlp_out.ln_g[1], H); cp(Par::O_E1, g.mlp_out.ln_b[1], H);
-    cp(Par::O_W2, g.mlp_out.w[2], 2 * H);
-    if (forward) {
-        cp(Par::IN_B0, g.mlp_in.b[0], H); cp(Par::IN_B1, g.mlp_in.b[1], H); cp(Par::IN_B2, g.mlp_in.b[2], 64);
-        cp(Par::E_B0, g.edge.b[0], H); cp(Par::E_B1, g.edge.b[1], H); cp(Par::E_B2, g.edge.b[2], 64);
-        cp(Par::U_B0, g.update.b[0], H); cp(Par::U_B1, g.update.b[1], 64);
-        cp(Par::O_B0, g.mlp_out.b[0], H); cp(Par::O_B1, g.mlp_out.b[1], H); cp(Par::O_B2, g.mlp_out.b[2], 2);
-        for (int l = 0; l < 3; ++l) { cp(Par::R_BIH + l * GLD, gru.bih[l], GLD); cp(Par::R_BHH + l * GLD, gru.bhh[l], GLD); }
-        cp(Par::R_WIH0, gru.wih_t[0], 4 * GLD);
-    } else {
-        cp(Par::R_WIH0, gru.wih[0], 4 * GLD);
+// The block is laid out on the host (StriveDecoder.scene_par, strive_amd/params.py): one coalesced copy, every load in flight.
+__device__ __forceinline__ void par_stage(float* par, const float* __restrict__ src, int tid) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(par);
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = tid + k * NTHR;
+        if (i < Par::FLOATS / 4) v[k] = s4[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = tid + k * NTHR;
+        if (i < Par::FLOATS / 4) d4[i] = v[k];
     }
 }
+static_assert(Par::FLOATS % 4 == 0 && Par::FLOATS / 4 <= 4 * NTHR, "par_stage copies four float4 per thread");
 
 // ---------------------------------------------------------------------------------------------------------------------
 // LDS map (bytes).  Persistent regions first, then one scratch region that the phases carve differently.
@@ -508,6 +503,7 @@ struct StepArgsS {
     const float* z;            // (NA, 32)
     const float* ext;          // (B, FT, 4) or null
     const int32_t* ptr;        // (B + 1)
+    const float* par;          // StriveDecoder.scene_par
     float* traj;               // (NA, FT, 4)
 };
 
@@ -565,7 +561,7 @@ static __global__ __launch_bounds__(NTHR) void scene_fwd_step_kernel(GNNDev g, G
     }
     if (tid < n * 4) L.pos[tid] = tp.pos_t(t)[(size_t)lo * 4 + tid];
     for (int i = tid; i < NR * 64; i += NTHR) { L.A[i] = 0.f; L.ARG[i] = -1; }
-    par_stage(L.par, g, gru, NC, true, tid);
+    par_stage(L.par, a.par, tid);
     __syncthreads();
 
     // ---- mlp_in: F -> 128 -> 128 -> 64 ----
@@ -883,7 +879,7 @@ static __global__ __launch_bounds__(NTHR) void scene_fwd_step_kernel(GNNDev g, G
                 const int rr = i / GLD, c = i - rr * GLD;
                 float v = L.par[Par::R_BIH + c];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v = fmaf(s_loc[rr * 4 + k], L.par[Par::R_WIH0 + k * GLD + c], v);
+                for (int k = 0; k < 4; ++k) v = fmaf(s_loc[rr * 4 + k], L.par[Par::R_WIH0T + k * GLD + c], v);
                 s_gi[rr * GLDS + c] = v;
             }
         }
@@ -975,6 +971,7 @@ struct SweepArgs {
     const float* lw;
     const float* ext;
     const int32_t* ptr;
+    const float* par;          // StriveDecoder.scene_par
     const float* g_traj;       // (NA, FT, 4)
     float* dz;                 // (NA, 32)
 };
@@ -1016,7 +1013,7 @@ static __global__ __launch_bounds__(NTHR) void scene_bwd_sweep_kernel(GNNDev g, 
     for (int i = tid; i < 3 * NR * XLD; i += NTHR) L.g_mem[i] = 0.f;
     for (int i = tid; i < NR * 32; i += NTHR) L.dz[i] = 0.f;
     for (int i = tid; i < NR * HLD; i += NTHR) { L.dP[i] = 0.f; L.dQ[i] = 0.f; }
-    par_stage(L.par, g, gru, NC, false, tid);
+    par_stage(L.par, a.par, tid);
     SCN_SYNC(tid);
 
     for (int t = FT - 1; t >= 0; --t) {
@@ -1099,11 +1096,26 @@ static __global__ __launch_bounds__(NTHR) void scene_bwd_sweep_kernel(GNNDev g, 
                             for (int r = 0; r < 4; ++r) s_dx[row * XLD + c0 + r] = v[r];
                         }
                     });
-                } else if (tid < n * 4) {
-                    const int rr = tid >> 2, k = tid & 3;
-                    float v = 0.f;
-                    for (int c = 0; c < GLD; ++c) v = fmaf(s_dgi[rr * GLDS + c], L.par[Par::R_WIH0 + c * 4 + k], v);
-                    L.d_loc[rr * 4 + k] = v;
+                } else {
+                    // layer 0's input is the 4-wide local pose: d_loc = d gi . W_ih on the vector ALUs, 16 lanes per row
+                    const int lane = tid & 63, wave = tid >> 6, q = lane & 15, sub = lane >> 4;
+                    for (int r0 = 4 * wave; r0 < NR; r0 += 4 * NWAVE) {
+                        const int rr = r0 + sub;
+                        float v[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (rr < n) {
+#pragma unroll
+                            for (int j = 0; j < 12; ++j) {
+                                const int c = q + 16 * j;
+                                const float ge = s_dgi[rr * GLDS + c];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) v[k] = fmaf(ge, L.par[Par::R_WIH0 + c * 4 + k], v[k]);
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = grp_sum(v[k]);
+                        if (rr < n && q == 0)
+                            for (int k = 0; k < 4; ++k) L.d_loc[rr * 4 + k] = v[k];
+                    }
                 }
                 SCN_SYNC(tid);
             }

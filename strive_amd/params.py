@@ -415,7 +415,38 @@ def pack_decoder(sd, NC, map_env, device, state_norm, att_norm, bike, cnn=None):
     s.dt = bike['dt']
     s.max_hdot = bike['maxhdot']
     s.max_s = bike['maxs']
+    s.scene_par = p.hold(_scene_par(sd, NC).to(device))
     return p
+
+
+def _scene_par(sd, NC):
+    """The small decoder parameters in the order of csrc/scene_rollout.h Par (include/strive_hip.h StriveDecoder.scene_par):
+    what the scene-resident rollout kernels keep in LDS."""
+    def t(k):
+        return _c(sd[k]).reshape(-1)
+
+    def mlp(prefix, nlin):
+        bs = [t('%s.net.%d.bias' % (prefix, 3 * k)) for k in range(nlin)]
+        ln = [(t('%s.net.%d.weight' % (prefix, 3 * k + 1)), t('%s.net.%d.bias' % (prefix, 3 * k + 1))) for k in range(nlin - 1)]
+        return bs, ln
+    out = []
+    b, ln = mlp('decoder_net.mlp_in', 3)
+    out += [b[0], b[1], b[2], ln[0][0], ln[0][1], ln[1][0], ln[1][1]]
+    b, ln = mlp('decoder_net.msg.0.edge_mlp', 3)
+    w0 = _c(sd['decoder_net.msg.0.edge_mlp.net.0.weight'])                    # (128, 132 + 2 NC)
+    wrel_t = w0[:, 128 + 2 * NC:128 + 2 * NC + 4].t().contiguous().reshape(-1)  # (4, 128)
+    out += [b[0], b[1], b[2], ln[0][0], ln[0][1], ln[1][0], ln[1][1], wrel_t]
+    b, ln = mlp('decoder_net.msg.0.update_mlp', 2)
+    out += [b[0], b[1], ln[0][0], ln[0][1]]
+    b, ln = mlp('decoder_net.mlp_out', 3)
+    pad2 = torch.zeros((2,), dtype=torch.float32, device=b[2].device)
+    out += [b[0], b[1], b[2], pad2, ln[0][0], ln[0][1], ln[1][0], ln[1][1], t('decoder_net.mlp_out.net.6.weight')]
+    out += [t('decoder_memory.bias_ih_l%d' % l) for l in range(3)] + [t('decoder_memory.bias_hh_l%d' % l) for l in range(3)]
+    wih0 = _c(sd['decoder_memory.weight_ih_l0'])                               # (192, 4)
+    out += [wih0.t().contiguous().reshape(-1), wih0.reshape(-1)]
+    blk = torch.cat(out)
+    assert blk.numel() == 6340, 'scene_par layout: %d floats' % blk.numel()
+    return blk.contiguous()
 
 
 def pack_scenes(ptr, NS, device):

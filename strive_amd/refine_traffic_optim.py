@@ -4,6 +4,7 @@ import torch
 import torch.optim as optim
 
 from .losses.adv_gen_nusc import AvoidCollLoss
+from .utils.graphed import GraphedIteration, adam_kwargs, graph_mode
 from .utils.scenario_gen import detach_embed_info
 
 
@@ -21,8 +22,9 @@ def refine_traffic_optim(scene_graph, map_idx, map_env, model, loss_weights, num
             init_future_pred = model.decode_embedding(z_init, embed_info, scene_graph, map_idx, map_env)['future_pred']
     cur_z = z_init.clone().detach()
     cur_z.requires_grad = True
+    graphed = optim_use_adam and graph_mode(cur_z.shape[0], cur_z.device, log)
     if optim_use_adam:
-        scene_optim = optim.Adam([cur_z], lr=lr)
+        scene_optim = optim.Adam([cur_z], lr=lr, **adam_kwargs(graphed))
     else:       # --optim_use_lbfgs (reference :53-55, 170-173): 20 inner iterations with a strong-Wolfe line search per step
         scene_optim = optim.LBFGS([cur_z], max_iter=20, lr=lr, line_search_fn='strong_wolfe')
     avoid_loss = AvoidCollLoss(loss_weights, model.get_att_normalizer().unnormalize(scene_graph.lw),
@@ -35,10 +37,15 @@ def refine_traffic_optim(scene_graph, map_idx, map_env, model, loss_weights, num
         if log is not None:
             log(loss_dict, cur_z)
         return loss_dict['loss']
+    def iteration():
+        loss = closure()
+        scene_optim.step()
+        return loss
+    # (one scene per batch is the shipped operating point: the iteration is replayed as a HIP graph there, utils/graphed.py)
+    it = GraphedIteration(iteration, graphed)
     for _ in range(num_iters):
         if optim_use_adam:
-            closure()
-            scene_optim.step()
+            it()
         else:
             scene_optim.step(closure)       # (torch's LBFGS reads the loss on the host for its line search, like the reference's run)
     with torch.no_grad():

@@ -7,6 +7,8 @@ import os
 import torch
 import torch.optim as optim
 
+from .graphed import GraphedIteration, adam_kwargs, graph_mode
+
 
 def _collate_index(scene_graph, device):
     """Row of cat([tgt_z, other_z]) that belongs to each agent of the batched graph (ego first in every scene); built once
@@ -120,7 +122,11 @@ class AdvClosure(object):
         self.tgt_z.requires_grad = True
         self.other_z = cur_z[~self.ego_mask].clone().detach()
         self.other_z.requires_grad = True
-        self.optim = optim.Adam([self.tgt_z, self.other_z], lr=lr)
+        # the open-loop iteration can be replayed as a HIP graph (utils/graphed.py); the closed loop reads the planner's status
+        # word back through an event per iteration and stays eager
+        self.graphed = planner_name == 'ego' and graph_mode(NA, dev, rollouts=2)
+        self.optim = optim.Adam([self.tgt_z, self.other_z], lr=lr, **adam_kwargs(self.graphed))
+        self._iter = None
         self.unn = model.get_normalizer().unnormalize
         self.tgt_prior, self.other_prior = tgt_prior_distrib, other_prior_distrib
         self.tgt_loss = TgtMatchingLoss(loss_weights)
@@ -129,7 +135,10 @@ class AdvClosure(object):
                                    scene_graph.ptr, veh_coll_buffer=veh_coll_buffer, crash_loss_min_time=feasibility_time,
                                    crash_loss_min_infront=feasibility_infront_min)
         self.planner_name, self.planner = planner_name, planner
-        self.overlap = True      # two-stream rollouts (see two_rollouts); set False to serialise
+        # two-stream rollouts (see two_rollouts); set False to serialise.  A replayed HIP graph keeps ONE stream: with the fork /
+        # join captured, hipGraphLaunch of the 16-agent adversarial iteration took 5.4 ms on the host and the iteration 8.6 ms
+        # against 4.2 ms eager (profiles/r04_graph_ab.txt)
+        self.overlap = not self.graphed
         if planner_name == 'ego':
             # open loop: the planner's trajectory is the ego's recorded future, injected into both rollouts
             self.planner_fut = scene_graph.future_gt[self.ego_mask][:, :, :4] if planner_fut is None else planner_fut
@@ -207,8 +216,13 @@ def run_adv_gen_optim(cur_z, lr, loss_weights, model, scene_graph, map_env, map_
     c = AdvClosure(cur_z, lr, loss_weights, model, scene_graph, map_env, map_idx, embed_info, tgt_prior_distrib,
                    other_prior_distrib, feasibility_time, feasibility_infront_min, attack_agt_idx=attack_agt_idx,
                    future_len=future_len, veh_coll_buffer=veh_coll_buffer, planner_name=planner_name, planner=planner)
-    for _ in range(num_iters):
-        c.step(log=log)
+    if log is None and c.graphed:
+        it = GraphedIteration(c.step, True)
+        for _ in range(num_iters):
+            it()
+    else:
+        for _ in range(num_iters):
+            c.step(log=log)
     ego_inds, ego_mask, unn, adv_loss, future_len = c.ego_inds, c.ego_mask, c.unn, c.adv_loss, c.future_len
 
     cur_z = c.collated()

@@ -4,6 +4,8 @@ iteration.  Progress bars / per-term ``.item()`` prints are dropped (they are ho
 import torch
 import torch.optim as optim
 
+from .graphed import GraphedIteration, adam_kwargs, graph_mode
+
 
 def run_init_optim(cur_z, init_traj, traj_vis, lr, loss_weights, model, scene_graph, map_env, map_idx, num_iters,
                    embed_info, prior_distrib, log=None):
@@ -12,9 +14,10 @@ def run_init_optim(cur_z, init_traj, traj_vis, lr, loss_weights, model, scene_gr
     init_traj = model.get_normalizer().unnormalize(init_traj).reshape(-1, init_traj.size(-1)).index_select(0, vis_idx)
     cur_z = cur_z.clone().detach()
     cur_z.requires_grad = True
-    init_optim = optim.Adam([cur_z], lr=lr)
+    graphed = graph_mode(cur_z.shape[0], cur_z.device, log)
+    init_optim = optim.Adam([cur_z], lr=lr, **adam_kwargs(graphed))
     match_loss = TgtMatchingLoss({k[5:]: v for k, v in loss_weights.items() if k[:5] == 'init_'})
-    for _ in range(num_iters):
+    def iteration():
         init_optim.zero_grad()
         pred = model.decode_embedding(cur_z, embed_info, scene_graph, map_idx, map_env)['future_pred']
         pred = model.get_normalizer().unnormalize(pred).reshape(-1, pred.size(-1)).index_select(0, vis_idx)
@@ -23,6 +26,10 @@ def run_init_optim(cur_z, init_traj, traj_vis, lr, loss_weights, model, scene_gr
         if log is not None:
             log(loss_dict, cur_z)
         init_optim.step()
+        return loss_dict['loss']
+    it = GraphedIteration(iteration, graphed)
+    for _ in range(num_iters):
+        it()
     with torch.no_grad():
         init_decoder_out = model.decode_embedding(cur_z, embed_info, scene_graph, map_idx, map_env)
     return cur_z, init_decoder_out['future_pred'].clone().detach(), init_decoder_out

@@ -3,6 +3,7 @@ import torch
 import torch.optim as optim
 
 from .adv_gen_optim import collate_tgt_other_z, _collate_index, two_rollouts
+from .graphed import GraphedIteration, adam_kwargs, graph_mode
 
 
 def run_find_solution_optim(cur_z, final_result_traj, future_len, lr, loss_weights, model, scene_graph, map_env,
@@ -20,17 +21,19 @@ def run_find_solution_optim(cur_z, final_result_traj, future_len, lr, loss_weigh
     tgt_z.requires_grad = True
     other_z_all = cur_z[~tgt_mask].view(NA - B, 1, -1).clone().detach()
     other_z_all.requires_grad = True
-    sol_optim = optim.Adam([tgt_z, other_z_all], lr=lr)
+    graphed = graph_mode(NA, dev, log, rollouts=2)
+    sol_optim = optim.Adam([tgt_z, other_z_all], lr=lr, **adam_kwargs(graphed))
     _, _, other_idx = _collate_index(scene_graph, dev)
     w = {k[4:]: v for k, v in loss_weights.items() if k[:4] == 'sol_'}
     avoid_loss = AvoidCollLoss(w, model.get_att_normalizer().unnormalize(scene_graph.lw), map_idx[scene_graph.batch],
                                map_env, tgt_z.clone().detach(), veh_coll_buffer=0.5, single_veh_idx=0, ptr=scene_graph.ptr)
     match_loss = TgtMatchingLoss(w)
-    for _ in range(num_iters):
+    def iteration():
         sol_optim.zero_grad()
         z_a = collate_tgt_other_z(scene_graph, tgt_z, other_z_all.detach())
         z_b = collate_tgt_other_z(scene_graph, tgt_z.detach(), other_z_all)
-        out_a, out_b = two_rollouts(model, embed_info, scene_graph, map_idx, map_env, z_a, dict(nfuture=future_len), z_b, dict())
+        out_a, out_b = two_rollouts(model, embed_info, scene_graph, map_idx, map_env, z_a, dict(nfuture=future_len), z_b, dict(),
+                                    overlap=not graphed)      # (a replayed graph keeps one stream, see AdvClosure)
         tgt_pred = unn(out_a['future_pred']).transpose(0, 1).reshape(NA, future_len, 4)
         lt = avoid_loss(tgt_pred, tgt_z, tgt_prior_distrib)
         lo = match_loss(unn(out_b['future_pred']).index_select(0, other_idx), other_match, other_z_all, other_prior_distrib)
@@ -41,6 +44,10 @@ def run_find_solution_optim(cur_z, final_result_traj, future_len, lr, loss_weigh
             loss_dict.update({'other_' + k: v for k, v in lo.items()})
             log(loss_dict, tgt_z, other_z_all)
         sol_optim.step()
+        return loss
+    it = GraphedIteration(iteration, graphed)
+    for _ in range(num_iters):
+        it()
     cur_z = collate_tgt_other_z(scene_graph, tgt_z, other_z_all)
     with torch.no_grad():
         sol_decoder_out = model.decode_embedding(cur_z, embed_info, scene_graph, map_idx, map_env)

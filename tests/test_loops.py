@@ -97,7 +97,14 @@ def test_product_loops_uniform_raster_tight(fixture, model, name):
     m, _ = model
     n = mg.LOOP_ITERS['u']
     trace, res = lu.run_product_loop(name, 'u', fixture, m, n, DEV)
-    w = lu.compare_trace(trace, fixture, 'u/' + name, 2e-3, 1e-4, 2e-2, 1e-3, z_frac=0.995, report=REPORT)
+    # The solution loop optimises the ego latents through AvoidCollLoss: like the refine loop below it has kinks (arg-min over
+    # the 25 circle pairs, arg-max messages).  The scene-resident rollout kernels (round 4) are as close to the oracle's gradient
+    # as the launch-per-phase kernels (tools/grad_accuracy.py on the MI355X: relative L2 7.8e-7 both, 1.6e-7 of max |g| apart),
+    # but they round differently, and around iteration 5 one scene resolves a kink the other way: from then on the two runs follow
+    # slightly different trajectories (other_loss 0.4 % apart at iteration 6).  Tight up to and including the first such event
+    # (never before iteration 4), direction / losses / latents afterwards -- the refine loop's rule.
+    kink = dict(grad_row_frac=0.66, kink_after=4) if name == 'sol' else {}
+    w = lu.compare_trace(trace, fixture, 'u/' + name, 2e-3, 1e-4, 2e-2, 1e-3, z_frac=0.995, report=REPORT, **kink)
     print('loop u/%s: %s' % (name, w))
     _dump_report()
     if name == 'adv':
@@ -107,8 +114,9 @@ def test_product_loops_uniform_raster_tight(fixture, model, name):
         assert_close(fin, fixture['u/adv/final_result_traj'], 0, 2e-3, 'final_result_traj')
     elif name == 'sol':
         z, sol, _ = res
-        assert lu.frac_within(z.detach().cpu().numpy().reshape(-1), fixture['u/sol/z_out'].reshape(-1), 1e-3) >= 0.995
-        assert_close(sol, fixture['u/sol/traj_out'], 0, 2e-3, 'sol_result_traj')
+        post = 'first_kink' in w
+        assert lu.frac_within(z.detach().cpu().numpy().reshape(-1), fixture['u/sol/z_out'].reshape(-1), 5e-3 if post else 1e-3) >= (0.9 if post else 0.995)
+        assert_close(sol, fixture['u/sol/traj_out'], 0, 2e-2 if post else 2e-3, 'sol_result_traj')
     else:
         z, traj, _ = res
         assert lu.frac_within(z.detach().cpu().numpy(), fixture['u/init/z_out'], 1e-3) >= 0.995
@@ -257,3 +265,41 @@ def test_refine_function_matches_the_reference_function(model, name, use_adam, i
     frac = float(np.mean(np.abs(z.detach().cpu().numpy() - g[name + '/z']) <= tol))
     assert frac >= 0.97, '%s: only %.3f of the latent entries within %.0e' % (name, frac, tol)
     assert_close(res, g[name + '/result_traj'], 0, 5e-3 if use_adam else 5e-2, name + ' result_traj')
+
+
+@pytest.mark.gpu
+def test_graph_replay_equals_eager_iterations(model, monkeypatch):
+    """The shipped one-scene-per-batch operating point replays the optimisation iteration as a HIP graph
+    (strive_amd/utils/graphed.py: 3 eager iterations, capture, replay).  Same function, same inputs, STRIVE_HIP_GRAPH=0/1:
+    the latents after 9 iterations (3 eager + 6 replayed) agree to what Adam's device-side step count changes (its bias
+    corrections are fp32 on the device instead of Python floats: ~1e-7 relative per step); the first (reference) case also
+    checks that the replay really happened."""
+    from strive_amd.refine_traffic_optim import refine_traffic_optim
+    from strive_amd.utils import graphed as gmod
+    m, sd = model
+    batch, map_idx, raster, dx, eps = mg.g12_inputs()
+    env = synth.SyntheticMapEnv(raster.clone(), dx.clone()).to(DEV)
+    saved = m.rsample
+    outs = {}
+    replays = {'n': 0}
+    orig_call = gmod.GraphedIteration.__call__
+
+    def counting(self):
+        r = orig_call(self)
+        if self.graph is not None:
+            replays['n'] += 1
+        return r
+    monkeypatch.setattr(gmod.GraphedIteration, '__call__', counting)
+    try:
+        m.rsample = lambda mean, var: mean + eps.to(mean.device) * torch.sqrt(var)
+        for mode in ('1', '0'):
+            monkeypatch.setenv('STRIVE_HIP_GRAPH', mode)
+            replays['n'] = 0
+            _, z, res, _ = refine_traffic_optim(batch.clone().to(DEV), map_idx.to(DEV), env, m, mg.REFINE_WEIGHTS, 9, 6, 6, True, 0.05)
+            outs[mode] = (z.detach().cpu().clone(), res.detach().cpu().clone(), replays['n'])
+    finally:
+        m.rsample = saved
+    assert outs['1'][2] == 6 and outs['0'][2] == 0, 'iterations replayed from the graph: %d (graph on), %d (off)' % (outs['1'][2], outs['0'][2])
+    frac = float((outs['1'][0] - outs['0'][0]).abs().le(1e-3).float().mean())
+    assert frac >= 0.98, 'graph replay: only %.3f of the latent entries within 1e-3 of the eager run' % frac
+    assert_close(outs['1'][1], outs['0'][1], 0, 5e-3, 'graph replay result_traj')
