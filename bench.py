@@ -353,7 +353,27 @@ def full_pipeline_factory(m, env, batch, map_idx, FT, device, scale=1.0):
                                                    env, smi[b:b + 1]))
         stats['sol_succeeded'] = int(sol_ok)
         stats['units'] = units
+        # what the reference writes per scene at adv_scenario_gen.py:465-538 (kept on the device; step.write_scenarios dumps it)
+        last.clear()
+        last.update(dict(g=g, mi=mi, init=init_pred, fin=fin, z=cur_z, agt=agt, tt=tt, prior=(pm, pv), ptr=ptr))
         return torch.tensor(float(stats['adv_succeeded']))
+    last = {}
+
+    def write_scenarios(out_dir):
+        import json
+        import os
+        from strive_amd.utils.scenario_gen import prepare_output_dict
+        os.makedirs(out_dir, exist_ok=True)
+        dl, ptr = last['g'].to_data_list(), last['ptr']
+        for b in range(len(dl)):
+            lo, hi = ptr[b], ptr[b + 1]
+            d = prepare_output_dict(dl[b], int(last['mi'][b]), env, m.dt, m, last['init'][lo:hi], last['fin'][lo:hi, 0],
+                                    attack_agt=int(last['agt'][b]) - lo, attack_t=int(last['tt'][b]), adv_z=last['z'][lo:hi],
+                                    prior_distrib=(last['prior'][0][lo:hi], last['prior'][1][lo:hi]))
+            with open(os.path.join(out_dir, 'scene_%04d.json' % b), 'w') as f:
+                json.dump(d, f)
+        return len(dl)
+    step.write_scenarios = write_scenarios
     step.stats = stats
     return step, None, batch.to(device), map_idx.to(device), 2
 
@@ -684,6 +704,8 @@ def parse_args(argv=None):
                     help="adv: 'ego' = open loop against the recorded ego future, 'hardcode' = closed loop against the rule-based "
                          "planner (adv_gen_rule_based.cfg)")
     ap.add_argument('--iters', type=float, default=1.0, help='full: scale of the iteration counts 75 / 100 / 200 / 200')
+    ap.add_argument('--scenario-out', default='', help='full: directory for the scenario JSON of every scene (reference '
+                    'src/adv_scenario_gen.py:465-538 -> prepare_output_dict), written from the device tensors after the timed region')
     ap.add_argument('--raster', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-full', action='store_true', help='time the CPU oracle on C2 itself (32 x 16 agents; ~10 minutes)')
@@ -767,6 +789,8 @@ def main():
     dt_host = time.perf_counter() - t0          # all work enqueued (diagnostic: host-bound when ~ dt_local)
     barrier()
     dt_local = time.perf_counter() - t0
+    if args.workload == 'full' and args.scenario_out and rank == 0:
+        step.stats['scenarios_written'] = step.write_scenarios(args.scenario_out)
     planner_ms = None
     if getattr(step, 'planner', None) is not None and args.workload != 'full':
         step.planner.check()               # capacity / range status of every planner rollout of the run (raises)

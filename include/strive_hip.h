@@ -139,6 +139,14 @@ typedef struct StriveCNN {
                                   in fp16's normal range) */
     float xscale[6];           /* power of two the GroupNorm+ReLU input of layer l (l >= 1) is multiplied by before its fp16
                                   split; chosen from the bound |gamma| sqrt(C H W) + |beta| so that it cannot overflow */
+    int32_t conv2_plain;       /* (ABI 14) conv2 normally runs as ONE persistent workgroup per CU (specialised producer / consumer
+                                  waves).  A caller that runs small latency-bound kernels on a second stream under the CNN (the
+                                  planner rollout behind one decoder rollout while the other rollout's CNN runs, reference
+                                  src/utils/adv_gen_optim.py:133-139) passes a descriptor with conv2_plain != 0 for those calls:
+                                  the ordinary conv2 kernel.  The two kernels write bit-identical activations; their GroupNorm
+                                  partial sums are added in a different order (8 rows against 4 row pairs per tile), so later
+                                  layers agree to fp32 rounding, not bit for bit.  A field of the caller's descriptor, not a
+                                  switch inside the library: no global mutable state. */
 } StriveCNN;
 
 /* Scene structure of a batch: agents of scene b are rows ptr[b] .. ptr[b+1]-1, ego first
@@ -147,6 +155,8 @@ typedef struct StriveCNN {
 typedef struct StriveScenes {
     int32_t NA, NS, B;
     int32_t max_n;            /* largest scene size (host-known; sizes per-edge scratch) */
+    int64_t n_edges;          /* (ABI 14) sum over scenes of n (n - 1) NS directed edge rows (host-known; sizes the training sweep's
+                                 per-edge row tapes exactly instead of NA NS max_n) */
     const int32_t* ptr;       /* (B+1) */
     const int32_t* scene_of;  /* (NA)  */
 } StriveScenes;
@@ -203,14 +213,6 @@ int strive_map_cnn_fwd(const StriveMap* map, const StriveCNN* cnn, const float* 
 /* The same CNN on an explicit crop (N,4,256,256) uint8 -- for parity tests of the convolution stack. */
 int strive_map_cnn_fwd_from_crop(const StriveCNN* cnn, const uint8_t* crop, int32_t N, float* feat,
                                  void* ws, size_t ws_bytes, strive_stream_t stream);
-
-/* conv2 normally runs as ONE persistent workgroup per CU (specialised producer / consumer waves).  A caller that runs small
- * latency-bound kernels on a second stream under the CNN (strive_planner_rollout behind one rollout while the other rollout's CNN
- * runs on another stream: reference src/utils/adv_gen_optim.py:133-139 inside the closure) switches that off for the calls it
- * enqueues meanwhile: on != 0 -> the ordinary conv2 kernel.  Process-wide, read when a CNN call is enqueued.  The two
- * kernels write bit-identical activations; their GroupNorm partial sums are added in a different order (8 rows against 4 row
- * pairs per tile), so later layers agree to fp32 rounding, not bit for bit. */
-void strive_map_cnn_set_concurrent(int32_t on);
 
 /* Measurement hook for bench.py: launch ONE kernel of the stack (layer 0 = fused crop+conv1, 1..3 = conv2..4,
  * 7 = the fused conv5 + conv6 + Linear kernel strive_map_cnn_fwd runs; 4, 5, 6 = the separate conv5 / conv6 /

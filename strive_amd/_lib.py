@@ -54,12 +54,12 @@ class StriveCNN(C.Structure):
     _fields_ = [('w', C.c_void_p * 6), ('b', C.c_void_p * 6), ('gn_g', C.c_void_p * 6), ('gn_b', C.c_void_p * 6),
                 ('fc_wt', C.c_void_p), ('fc_b', C.c_void_p), ('w1_frag', C.c_void_p),
                 ('w2_frag', C.c_void_p), ('w3_frag', C.c_void_p), ('w4_frag', C.c_void_p), ('w5_frag', C.c_void_p), ('w6_frag', C.c_void_p),
-                ('w_torch', C.c_void_p * 6), ('wscale', C.c_float * 6), ('xscale', C.c_float * 6)]
+                ('w_torch', C.c_void_p * 6), ('wscale', C.c_float * 6), ('xscale', C.c_float * 6), ('conv2_plain', C.c_int32)]
 
 
 class StriveScenes(C.Structure):
-    _fields_ = [('NA', C.c_int32), ('NS', C.c_int32), ('B', C.c_int32), ('max_n', C.c_int32), ('ptr', C.c_void_p),
-                ('scene_of', C.c_void_p)]
+    _fields_ = [('NA', C.c_int32), ('NS', C.c_int32), ('B', C.c_int32), ('max_n', C.c_int32), ('n_edges', C.c_int64),
+                ('ptr', C.c_void_p), ('scene_of', C.c_void_p)]
 
 
 class StriveAvoidColl(C.Structure):
@@ -159,7 +159,6 @@ PROTOTYPES = {
     'strive_map_cnn_param_count': (SZ, []),
     'strive_mlp_bwd': (C.c_int, [C.POINTER(StriveMLP), P, P, I, P, P, P]),
     'strive_gnn_bwd_workspace_bytes': (SZ, [C.POINTER(StriveGNN), C.POINTER(StriveScenes)]),
-    'strive_map_cnn_set_concurrent': (None, [C.c_int32]),
     'strive_pack_dense': (C.c_int, [P, C.c_int32, C.c_int32, C.c_float, P, P, P, P]),
     'strive_gnn_bwd': (C.c_int, [C.POINTER(StriveGNN), C.POINTER(StriveScenes), P, P, P, P, P, P, P, SZ, P]),
     'strive_map_cnn_bwd_workspace_bytes': (SZ, [I]),

@@ -1,6 +1,7 @@
 // Shared host/device helpers for libstrive_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -26,6 +27,20 @@ void strive_set_error(const char* fmt, ...);
             return -2;                                                                    \
         }                                                                                 \
     } while (0)
+
+// Per-device one-time set-up (a dynamic-LDS attribute, the CU count): a process may drive several GPUs, and the attribute and
+// the count belong to the device that is current when the launch is made.
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> done{0};
+    std::atomic<int> value[64];
+    int device() const {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+        return dev;
+    }
+    bool is_done(int dev) const { return (done.load(std::memory_order_acquire) >> dev) & 1ull; }
+    void set_done(int dev) { done.fetch_or(1ull << dev, std::memory_order_release); }
+};
 
 static inline size_t strive_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

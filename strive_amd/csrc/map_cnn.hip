@@ -1166,10 +1166,11 @@ template <class Cfg>
 static int launch_bf6s(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
                        const float* bias, float* out, GNStats* st_out, int N, float xscale, float wscale, hipStream_t stream) {
     dim3 grid(((N + Cfg::S - 1) / Cfg::S) * Cfg::CSPLIT);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    const int dev = once.device();
+    if (!once.is_done(dev)) {
         hipFuncSetAttribute((const void*)conv_bf6s_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-        attr_set = true;
+        once.set_done(dev);
     }
     hipLaunchKernelGGL(conv_bf6s_kernel<Cfg>, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out,
                        st_out, N, xscale, 1.0f / (xscale * wscale));
@@ -1183,27 +1184,26 @@ typedef BfCfg<64, 64, 3, 29, 14, Bf3::NPART_OUT, true, 2, 2, true, 2> Bf4;
 typedef BfsCfg<64, 128, 14, 6, 7, Bf4::NPART_OUT, true, 2, 2> Bfs5;       // conv5: 7 samples (252 pixels) x 32 channels per workgroup
 typedef BfsCfg<128, 128, 6, 2, 32, Bfs5::NPART_OUT, false, 1, 2> Bfs6;  // conv6: 32 samples (128 pixels) x 32 channels per workgroup; NCHW out (fc)
 
-// strive_map_cnn_set_concurrent(1): the caller runs small latency-bound kernels of ANOTHER stream under the CNN (the rule-based
-// planner behind one rollout while the second rollout's CNN runs).  conv2 then stays on conv_bf6_kernel: the persistent
-// conv_ws_kernel is faster alone and in the two-stream open loop (17.9 against 18.35 ms) but costs the closed loop 1 ms
-// (22.8 against 21.9 ms; leaving 16 or 32 CUs free changes nothing: profiles/r03_ab_conv_ws_closed_loop.json).
-static int g_cnn_concurrent = 0;
-extern "C" void strive_map_cnn_set_concurrent(int32_t on) { g_cnn_concurrent = on ? 1 : 0; }
+// StriveCNN.conv2_plain: the caller runs small latency-bound kernels of ANOTHER stream under the CNN (the rule-based planner
+// behind one rollout while the second rollout's CNN runs).  conv2 then stays on conv_bf6_kernel: the persistent conv_ws_kernel
+// is faster alone and in the two-stream open loop (17.9 against 18.35 ms) but costs the closed loop 1 ms (22.8 against 21.9 ms;
+// leaving 16 or 32 CUs free changes nothing: profiles/r03_ab_conv_ws_closed_loop.json).
 
 // the specialised-wave form (conv_ws_kernel): one persistent workgroup per CU; STRIVE_CONV_WS=0 keeps conv_bf6_kernel (A/B)
 template <class Cfg>
 static int launch_ws(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
                      const float* bias, float* out, GNStats* st_out, int N, float xscale, float wscale, hipStream_t stream) {
     using W = WsCfg<Cfg>;
-    static bool attr_set = false;
-    static int ncu = 256;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    const int dev = once.device();
+    if (!once.is_done(dev)) {
         hipFuncSetAttribute((const void*)conv_ws_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES);
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            ncu = v;
-        attr_set = true;
+        int v = 0;
+        if (!(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)) v = 256;
+        once.value[dev].store(v, std::memory_order_relaxed);
+        once.set_done(dev);
     }
+    const int ncu = once.value[dev].load(std::memory_order_relaxed);
     const int total = N * Cfg::TILES_X * Cfg::TILES_Y;
     const int grid = total < ncu ? total : ncu;
     // STRIVE_CONV_WS_DBG (measurement only, results invalid): 1 = consumers skip the matrix steps, 2 = producers skip the staging,
@@ -1218,10 +1218,11 @@ template <class Cfg>
 static int launch_bf6(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
                       const float* bias, float* out, GNStats* st_out, int N, float xscale, float wscale, hipStream_t stream) {
     dim3 grid(Cfg::TILES_X * Cfg::CSPLIT, Cfg::TILES_Y, (N + 7) / 8 * 8);      // z rounded up: see the id -> (sample, tile) map in the kernel
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    const int dev = once.device();
+    if (!once.is_done(dev)) {
         hipFuncSetAttribute((const void*)conv_bf6_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-        attr_set = true;
+        once.set_done(dev);
     }
     hipLaunchKernelGGL(conv_bf6_kernel<Cfg>, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out,
                        st_out, N, xscale, 1.0f / (xscale * wscale));
@@ -1373,7 +1374,7 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         }
         // conv2: specialised producer / consumer waves (bit-identical to conv_bf6_kernel; STRIVE_CONV_WS=0 switches back)
         static const bool conv_ws = !(getenv("STRIVE_CONV_WS") && atoi(getenv("STRIVE_CONV_WS")) == 0);
-        if (conv_ws && !g_cnn_concurrent)
+        if (conv_ws && !cnn->conv2_plain)
             launch_ws<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], n, cnn->xscale[1], cnn->wscale[1], stream);
         else
             launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], n, cnn->xscale[1], cnn->wscale[1], stream);

@@ -571,10 +571,11 @@ static inline void launch_wgrad_tile(const float* dy, const float* act_in, const
     int per_cb = 768 / T::NCB;                 // ~3 workgroups per CU in total
     if (per_cb > units) per_cb = units;
     if (per_cb < 1) per_cb = 1;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    const int dev_ = once.device();
+    if (!once.is_done(dev_)) {
         hipFuncSetAttribute((const void*)wgrad_tile_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
-        attr_set = true;
+        once.set_done(dev_);
     }
     hipLaunchKernelGGL(wgrad_tile_kernel<L>, dim3(per_cb, T::NCB), dim3(256), T::LDS_BYTES, stream, dy, act_in, crop, mr_in, gam_in,
                        bet_in, dW, NS);

@@ -270,10 +270,11 @@ static inline void launch_dgrad_mfma(const float* dy, const uint4* wfrag_all, fl
     const int units = ((NS + T::S - 1) / T::S) * T::NBAND;
     int grid = units < 1024 ? units : 1024;
     if (grid < 1) grid = 1;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    const int dev_ = once.device();
+    if (!once.is_done(dev_)) {
         hipFuncSetAttribute((const void*)dgrad_mfma_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
-        attr_set = true;
+        once.set_done(dev_);
     }
     hipLaunchKernelGGL(dgrad_mfma_kernel<L>, dim3(grid, T::NSPLIT), dim3(256), T::LDS_BYTES, stream, dy, wfrag_all + dgrad_frag_offset(L), gin, NS);
 }
@@ -604,10 +605,11 @@ static inline void launch_wgrad_mfma(const float* dy, const float* act_in, const
     int gx = 512 / T::NSPLIT;                 // ~2 workgroups per CU in total
     if (gx > units) gx = units;
     if (gx < 1) gx = 1;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    const int dev_ = once.device();
+    if (!once.is_done(dev_)) {
         hipFuncSetAttribute((const void*)wgrad_mfma_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
-        attr_set = true;
+        once.set_done(dev_);
     }
     static const int dbg = getenv("STRIVE_WGRAD_DBG") ? atoi(getenv("STRIVE_WGRAD_DBG")) : 0;
     hipLaunchKernelGGL(wgrad_mfma_kernel<L>, dim3(gx, T::NSPLIT), dim3(256), T::LDS_BYTES, stream, dy, act_in, crop, mr_in, gam_in,

@@ -477,11 +477,12 @@ static int launch_cnn_tail(const StriveCNN* cnn, const float* act4, const GNStat
     a.xs5 = cnn->xscale[4]; a.un5 = 1.0f / (cnn->xscale[4] * cnn->wscale[4]);
     a.xs6 = cnn->xscale[5]; a.un6 = 1.0f / (cnn->xscale[5] * cnn->wscale[5]);
     a.feat = feat; a.N = N;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce once;
+    const int dev_ = once.device();
+    if (!once.is_done(dev_)) {
         (void)hipFuncSetAttribute((const void*)cnn_tail_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)cnn_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail::LDS_BYTES);
-        attr_set = true;
+        once.set_done(dev_);
     }
     const dim3 grid((N + tail::S - 1) / tail::S);
     if (tprof) hipLaunchKernelGGL(cnn_tail_kernel<true>, grid, dim3(tail::NT), tail::LDS_BYTES, stream, a, tprof);

@@ -787,10 +787,12 @@ struct WJobsPlan {
     WJobTable t;
     size_t tape_floats;
     int max_in, max_out;
+    bool dropped, too_large;
 };
 
 static void wjobs_add(WJobsPlan& p, float* tape, float* dW, float* db, int OUT, int IN, int ldw, int cap) {
-    if (!dW || OUT <= 0 || IN <= 0 || p.t.n >= STRIVE_WJOBS_MAX) return;
+    if (!dW || OUT <= 0 || IN <= 0) return;
+    if (p.t.n >= STRIVE_WJOBS_MAX) { p.dropped = true; return; }      // (27 blocks today; a dropped block would silently fall back to atomics)
     const int j = p.t.n++;
     p.t.count[j] = 0;
     p.t.OUT[j] = OUT; p.t.IN[j] = IN; p.t.ldw[j] = ldw; p.t.cap[j] = cap;
@@ -805,12 +807,19 @@ static void wjobs_add_mlp(WJobsPlan& p, float* tape, const StriveMLP& m, const M
     for (int l = skip_first ? 1 : 0; l < m.nlayers; ++l) wjobs_add(p, tape, g.w[l], g.b[l], m.dims[l + 1], m.dims[l], m.dims[l], cap);
 }
 
-// rows: every node job gets R rows per step, every edge job at most R (max_n - 1)
-static WJobsPlan wjobs_plan(const StriveGNN& g, const GNNGradDev& gr, const GRUGradDev& gg, float* tape, size_t R, int max_n, int FT) {
+// rows: every node job gets R rows per step, every edge job one row per directed edge and step: the exact count n_edges when the
+// caller's StriveScenes has it (ABI 14), else the bound R max_n (one 60-agent scene in a batch of small ones used to size the
+// five edge tapes for R x 60 rows: GBs)
+static WJobsPlan wjobs_plan(const StriveGNN& g, const GNNGradDev& gr, const GRUGradDev& gg, float* tape, size_t R, int max_n, int FT,
+                            long long n_edges) {
     WJobsPlan p;
     memset(&p.t, 0, sizeof(p.t));
     p.tape_floats = 0; p.max_in = 1; p.max_out = 1;
-    const int node_cap = (int)(R * FT), edge_cap = (int)(R * (size_t)(max_n > 1 ? max_n : 1) * FT);
+    p.dropped = false;
+    const size_t node_rows = R * (size_t)FT;
+    const size_t edge_rows = (n_edges > 0 ? (size_t)n_edges : R * (size_t)(max_n > 1 ? max_n : 1)) * (size_t)FT;
+    p.too_large = node_rows > 0x7fffffffull || edge_rows > 0x7fffffffull;
+    const int node_cap = p.too_large ? 1 : (int)node_rows, edge_cap = p.too_large ? 1 : (int)(edge_rows > 0 ? edge_rows : 1);
     wjobs_add_mlp(p, tape, g.mlp_in, gr.mlp_in, node_cap, false);
     wjobs_add_mlp(p, tape, g.update, gr.update, node_cap, false);
     wjobs_add_mlp(p, tape, g.mlp_out, gr.mlp_out, node_cap, false);
@@ -833,11 +842,11 @@ static WJobsPlan wjobs_plan(const StriveGNN& g, const GNNGradDev& gr, const GRUG
     return p;
 }
 
-static size_t wjobs_tape_floats(const StriveGNN& g, size_t R, int max_n, int FT) {
+static size_t wjobs_tape_floats(const StriveGNN& g, size_t R, int max_n, int FT, long long n_edges) {
     float* fake = reinterpret_cast<float*>(uintptr_t(1) << 20);      // (planning only: nothing is dereferenced)
     const GNNGradDev gr = gnn_grad_dev(g, fake);
     const GRUGradDev gg = gru_grad_dev(fake);
-    return wjobs_plan(g, gr, gg, fake, R, max_n, FT).tape_floats;
+    return wjobs_plan(g, gr, gg, fake, R, max_n, FT, n_edges).tape_floats;
 }
 
 static __global__ void wjobs_upload_kernel(WJobTable* dst, WJobTable src) {
@@ -869,7 +878,12 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
     WJobsPlan plan;
     plan.t.n = 0;
     if (tr && tr->jobs) {
-        plan = wjobs_plan(dec->gnn, ggn, ggr, tr->wtape, R, sc->max_n, FT);
+        plan = wjobs_plan(dec->gnn, ggn, ggr, tr->wtape, R, sc->max_n, FT, sc->n_edges);
+        if (plan.too_large || plan.dropped) {
+            strive_set_error(plan.too_large ? "rollout_bwd_train: more than 2^31 tape rows (split the batch)" :
+                                              "rollout_bwd_train: more deferred weight blocks than STRIVE_WJOBS_MAX");
+            return -1;
+        }
         hipLaunchKernelGGL(wjobs_upload_kernel, dim3(1), dim3(64), 0, stream, tr->jobs, plan.t);
         ggn.mlp_in.jobs = ggn.edge.jobs = ggn.update.jobs = ggn.mlp_out.jobs = tr->jobs;
         ggr.jobs = tr->jobs;
@@ -980,7 +994,7 @@ extern "C" size_t strive_rollout_train_workspace_bytes(const StriveDecoder* dec,
     const size_t R = (size_t)sc->NA * sc->NS, steps = FT > 1 ? (size_t)(FT - 1) : 1;
     return strive_rollout_workspace_bytes(dec, sc, FT) + strive_align_up(strive_map_cnn_bwd_workspace_bytes((int32_t)(steps * R)), 256) +
            strive_align_up((size_t)FT * R * 64 * 4, 256) + strive_align_up(steps * R * 4, 256) +
-           strive_align_up(sizeof(WJobTable), 256) + strive_align_up(wjobs_tape_floats(dec->gnn, R, sc->max_n, FT) * 4, 256);
+           strive_align_up(sizeof(WJobTable), 256) + strive_align_up(wjobs_tape_floats(dec->gnn, R, sc->max_n, FT, sc->n_edges) * 4, 256);
 }
 
 extern "C" size_t strive_gnn_param_count(const StriveGNN* gnn) { return gnn ? gnn_param_count(*gnn) : 0; }
@@ -1015,7 +1029,7 @@ extern "C" int strive_rollout_bwd_train(const StriveDecoder* dec, const StriveSc
         tr.jobs = atomics_only ? nullptr : (WJobTable*)p;
         p += strive_align_up(sizeof(WJobTable), 256);
         tr.wtape = (float*)p;
-        p += strive_align_up(wjobs_tape_floats(dec->gnn, R, sc->max_n, FT) * 4, 256);
+        p += strive_align_up(wjobs_tape_floats(dec->gnn, R, sc->max_n, FT, sc->n_edges) * 4, 256);
         tr.cnn_ws = p;
         tr.cnn_ws_bytes = ws_bytes - (size_t)(p - (char*)ws);
     }

@@ -639,6 +639,35 @@ class _RolloutTrainFn(torch.autograd.Function):
         return (dz.reshape(ctx.zshape), dpf, dmf, None) + grads
 
 
+class conv2_plain(object):
+    """Context: decoder rollouts enqueued inside it hand the library a descriptor with StriveCNN.conv2_plain = 1 (conv2 on its
+    non-persistent kernel: the caller runs small kernels on another stream meanwhile, utils.adv_gen_optim.two_rollouts)."""
+    on = False
+
+    def __init__(self, enable=True):
+        self.enable = bool(enable)
+
+    def __enter__(self):
+        self.prev = conv2_plain.on
+        conv2_plain.on = self.enable
+        return self
+
+    def __exit__(self, *exc):
+        conv2_plain.on = self.prev
+
+
+def _decoder_variant(pack):
+    """the same decoder descriptor with conv2_plain set (a copy of the struct; the tensors stay owned by ``pack``)"""
+    v = pack.__dict__.get('_conv2_plain_variant')
+    if v is None:
+        v = params.Packed(type(pack.struct)())
+        C.memmove(C.byref(v.struct), C.byref(pack.struct), C.sizeof(pack.struct))
+        v.struct.cnn.conv2_plain = 1
+        v.keep.append(pack)
+        pack.__dict__['_conv2_plain_variant'] = v
+    return v
+
+
 def _decoder_pack_key(model, map_env, dev):
     key = ('dec', str(dev), map_env.nusc_raster.data_ptr())
     # plain values the pack copies: normaliser statistics and the bicycle parameters (not object identities)
@@ -688,6 +717,8 @@ def decoder_rollout(model, g, map_feat, past_feat, z, map_idx, map_env, ext_futu
     h = _RolloutCtx()
     h.lib = lib
     h.dec = _cached_pack(model, key, model, build, extra_sig=extra)
+    if conv2_plain.on:
+        h.dec = _decoder_variant(h.dec)
     h.sc = info.pack(NS)
     h.R = info.NA * NS
     h.FT = int(FT)

@@ -460,6 +460,7 @@ def pack_scenes(ptr, NS, device):
     p.struct.NS = int(NS)
     p.struct.B = int(B)
     p.struct.max_n = int(sizes.max()) if B > 0 else 0
+    p.struct.n_edges = int((sizes.to(torch.int64) * (sizes.to(torch.int64) - 1)).sum()) * int(NS) if B > 0 else 0
     p.struct.ptr = p.hold(ptr32)
     p.struct.scene_of = p.hold(scene_of)
     p.sizes = sizes

@@ -154,7 +154,10 @@ class HardcodeNuscPlanner(PlannerNusc):
         self.B = self.batch_mask = self.batch_maps = None
         self.ego_idx = 0
         self._world = None
-        self._pending = None
+        self._pending = None      # (pinned snapshot of the status flags, event) of a read-back that is under way, or None
+        self._status = None       # device flags: the kernels only SET them, so one tensor accumulates every rollout since reset()
+        self.defer_check = None   # None: rollouts on device tensors defer the status check to check() (no synchronisation inside
+                                  # an optimisation closure), host calls check at once; True / False force either
         self._rows = {}
         self._tables = {}
 
@@ -164,6 +167,8 @@ class HardcodeNuscPlanner(PlannerNusc):
         agent, map_idx (B).  The device the planner runs on is init_state's."""
         dev = init_state.device
         ops._lib_for(init_state)
+        self._status = torch.zeros((8,), dtype=torch.int32, device=dev)
+        self._pending = None
         self.ego_idx, self.B, self.batch_mask = int(ego_idx), int(batch_size), batch_mask
         state = init_state.detach().cpu().numpy()
         att = vehicle_atts.detach().cpu().numpy()
@@ -251,19 +256,36 @@ class HardcodeNuscPlanner(PlannerNusc):
 
     # ---- deferred status check: no host synchronisation inside an optimisation closure ----------------------------------
     def check(self, wait=True):
-        """Raise if an earlier rollout hit a capacity / range limit (its plan is NaN for the affected scenes).  ``wait=False``
-        only looks at rollouts whose status has already arrived on the host."""
-        pend = self._pending
-        if pend is None:
+        """Raise if ANY rollout since reset() (or since the last raising check) hit a capacity / range limit -- its plan is NaN
+        for the affected scenes.  The device kernels only set flags in one persistent status tensor, so nothing is lost between
+        rollouts: ``wait=True`` reads the flags back (one synchronisation; the loops call it once, after their last iteration);
+        ``wait=False`` never blocks -- it looks at a snapshot whose asynchronous copy has already arrived and starts the next
+        one, which is how a failure surfaces early inside a synchronisation-free optimisation loop."""
+        st = self._status
+        if st is None:
             return
-        host, event = pend
-        if event is not None:
-            if not wait and not event.query():
-                return
-            event.synchronize()
-        self._pending = None
+        host = None
+        if st.device.type != 'cuda':
+            host = st
+        elif wait:
+            self._pending = None
+            host = st.cpu()                   # (ordered behind every rollout enqueued on, or joined into, the current stream)
+        else:
+            pend = self._pending
+            if pend is not None and pend[1].query():
+                host, self._pending = pend[0], None
+            if self._pending is None:
+                snap = torch.empty((8,), dtype=torch.int32).pin_memory()
+                snap.copy_(st, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(st.device))
+                self._pending = (snap, ev)
+        if host is None:
+            return
         bad = [STATUS_NAMES[i] for i in range(len(STATUS_NAMES)) if int(host[i]) != 0]
         if bad:
+            st.zero_()
+            self._pending = None
             raise L.StriveHipError('HardcodeNuscPlanner.rollout exceeded a limit of the device planner: ' + '; '.join(bad))
 
     # ---- rollout (reference :178-276) -------------------------------------------------------------------------------------
@@ -301,20 +323,13 @@ class HardcodeNuscPlanner(PlannerNusc):
             ws.fill_(0x25)                # debug aid (the tests set it): a kernel that reads workspace it did not write sees garbage
         TP = planner_t.shape[0]
         plan = torch.empty((self.B, TP, 4), dtype=torch.float64, device=dev)
-        status = torch.zeros((8,), dtype=torch.int32, device=dev)
+        status = self._status
         at, to, pt = self._table(agent_t), self._table(t_out), self._table(planner_t)
         if NR == 0:
             obs = torch.zeros((1, max(1, agent_t.shape[0]), 4), dtype=torch.float64, device=dev)
         lib.call('strive_planner_rollout', C.byref(desc), L.ptr(obs), L.ptr(at), int(agent_t.shape[0]), L.ptr(to), nstep, L.ptr(pt),
                  TP, int(self.traj_cap), L.ptr(plan), L.ptr(status), L.ptr(ws), ws.numel(), L.stream_ptr(obs))
-        if dev.type == 'cuda':
-            host = torch.empty((8,), dtype=torch.int32).pin_memory()
-            host.copy_(status, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-            self._pending = (host, ev)
-        else:
-            self._pending = (status.clone(), None)
-        if from_numpy or dev.type != 'cuda':
+        defer = (dev.type == 'cuda') if self.defer_check is None else bool(self.defer_check)
+        if from_numpy or not defer:
             self.check(wait=True)
         return plan.cpu() if from_numpy else plan

@@ -68,23 +68,16 @@ def two_rollouts(model, embed_info, scene_graph, map_idx, map_env, z_a, kw_a, z_
         streams = (torch.cuda.Stream(dev, priority=-1), torch.cuda.Stream(dev))
         _rollout_streams[str(dev)] = streams
     outs, extra = [], None
-    lib = None
-    if after_a is not None:
-        # the planner's small kernels run under the other rollout's CNN: conv2 stays on its non-persistent kernel meanwhile
-        # (measured: 21.9 against 22.8 ms per closed-loop closure; include/strive_hip.h strive_map_cnn_set_concurrent)
-        from .. import _lib as L
-        lib = L.get_lib()
-        lib.query('strive_map_cnn_set_concurrent', 1)
-    try:
+    # the planner's small kernels run under the other rollout's CNN: conv2 stays on its non-persistent kernel for the calls
+    # enqueued meanwhile (measured: 21.9 against 22.8 ms per closed-loop closure) -- a field of the descriptor those calls are
+    # given (StriveCNN.conv2_plain), not a switch inside the library
+    with ops.conv2_plain(after_a is not None):
         for i, (st, z, kw) in enumerate(zip(streams, (z_a, z_b), (kw_a, kw_b))):
             st.wait_stream(cur)
             with torch.cuda.stream(st):
                 outs.append(model.decode_embedding(z, embed_info, scene_graph, map_idx, map_env, **kw))
                 if i == 0 and after_a is not None:
                     extra = after_a(outs[0])
-    finally:
-        if lib is not None:
-            lib.query('strive_map_cnn_set_concurrent', 0)      # (the launches above are enqueued; also when one of them raised)
     for st, o in zip(streams, outs):
         cur.wait_stream(st)
         for v in o.values():

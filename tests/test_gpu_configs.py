@@ -204,6 +204,257 @@ def test_adv_closure_at_size(model, NC):
 
 
 # ------------------------------------------------------------------------------------------------
+# configs[2], closed loop: the adversarial closure against the rule-based planner at ~512 agents
+# ------------------------------------------------------------------------------------------------
+
+def test_closed_loop_adv_closure_at_size(model):
+    """One closed-loop iteration (adv_gen_rule_based.cfg's planner 'hardcode'; reference src/utils/adv_gen_optim.py:90-103,
+    133-139) on 512 agents in scenes of 2..30: the device planner runs behind rollout A on A's stream, under rollout B's CNN.
+    Three scenes are sampled against the oracle: the planner's reaction to that scene's predicted futures (oracle planner,
+    1e-6), both rollouts' rows (oracle rollout of the scene alone), and -- on the sub-batch of the three scenes -- every
+    AdvGenLoss / TgtMatchingLoss entry and the gradient w.r.t. both latent groups through rollout + planner + losses.
+    While the planner's small kernels run on the other stream conv2 is on its non-persistent kernel (StriveCNN.conv2_plain):
+    the difference that makes to the trajectories is bounded explicitly."""
+    import bench
+    from oracle import planner as oplan
+    from oracle import loops as oloops
+    from strive_amd import ops
+    from strive_amd.utils.adv_gen_optim import AdvClosure, collate_tgt_other_z
+    from strive_amd.utils.scenario_gen import detach_embed_info
+    from strive_amd.planners.planner import PlannerConfig
+    from strive_amd.planners.hardcode_goalcond_nusc import HardcodeNuscPlanner, CONFIG_DICT
+    m, sd = model
+    px = 2048
+    lane_graph = synth.make_lane_graph(extent=px * 0.25)
+    raster, dx = uniform(px)
+    env = synth.SyntheticMapEnv(raster.clone(), dx.clone(), lane_graph=lane_graph).to(DEV)
+    sizes = bench.variable_scene_sizes(512, 'gc/cl')
+    own = [(n, 'gc/cl/%d' % b) for b, n in enumerate(sizes)]
+    batch, map_idx = bench.build_batch(own, 2, px, lane_graph=lane_graph)
+    bg, mi = batch.clone().to(DEV), map_idx.to(DEV)
+    with torch.no_grad():
+        emb = detach_embed_info(m.embed(bg, mi, env))
+    NA, B = 512, len(sizes)
+    ego = torch.zeros((NA,), dtype=torch.bool, device=DEV)
+    ego[bg.ptr[:-1].to(DEV)] = True
+    pm, pv = emb['prior_out']
+    z0 = emb['posterior_out'][0].clone()
+
+    def closure_for(g, g_mi, e, zs, tp, op):
+        planner = HardcodeNuscPlanner(env, PlannerConfig(**CONFIG_DICT['default']))
+        return AdvClosure(zs, 0.05, bench.ADV_WEIGHTS, m, g, env, g_mi, e, tp, op, 2, 0.0, future_len=12, veh_coll_buffer=0.1,
+                          planner_name='hardcode', planner=planner), planner
+
+    def run_step(c):
+        seen = {}
+        two = c._two_rollouts
+
+        def spy(z_a, z_b, after_a=None):
+            out = two(z_a, z_b, after_a=after_a)
+            seen['pa'], seen['pb'], seen['plan'] = out[0]['future_pred'].detach(), out[1]['future_pred'].detach(), out[2].detach()
+            return out
+        c._two_rollouts = spy
+
+        def log(ld, tz, oz):
+            seen.update({k: v.detach().clone() for k, v in ld.items() if torch.is_tensor(v)})
+            seen['g_tgt'], seen['g_other'] = tz.grad.clone(), oz.grad.clone()
+        z_t0, z_o0 = c.tgt_z.detach().clone(), c.other_z.detach().clone()
+        loss = c.step(log=log)
+        assert torch.isfinite(loss)
+        return seen, z_t0, z_o0
+
+    c, planner = closure_for(bg, mi, emb, z0, (pm[ego], pv[ego]), (pm[~ego], pv[~ego]))
+    seen, z_t0, z_o0 = run_step(c)
+    planner.check()                                    # no scene of this world exceeds a limit of the device planner
+    assert seen['plan'].shape == (B, 12, 4) and torch.isfinite(seen['plan']).all()
+    assert all(torch.isfinite(v).all() for v in seen.values())
+
+    # conv2 on the non-persistent kernel while the planner runs: what that changes in a rollout, bounded
+    zc = collate_tgt_other_z(bg, z_t0, z_o0)
+    with torch.no_grad():
+        p_ws = m.decode_embedding(zc, emb, bg, mi, env, nfuture=12)['future_pred']
+        with ops.conv2_plain(True):
+            p_pl = m.decode_embedding(zc, emb, bg, mi, env, nfuture=12)['future_pred']
+    d_conv2 = float((p_ws - p_pl).abs().max())
+    assert d_conv2 <= 2e-5, 'conv2 persistent vs plain kernel: trajectories %.3g apart (normalised units)' % d_conv2
+    assert_close(seen['pa'], p_pl, 0, 2e-5, 'rollout A of the closure = a plain rollout of the same latents')
+
+    # ---- three scenes against the oracle ----
+    orc = oracle_model(sd)
+    env_c = synth.SyntheticMapEnv(raster, dx)
+    scenes = batch.to_data_list()
+    order = sorted(range(B), key=lambda i: sizes[i])
+    pick = [order[0], order[len(order) // 3], order[len(order) // 2]]
+    unn_c = orc.get_normalizer().unnormalize
+    plan_t = np.linspace(0.5, 6.0, 12)
+    for b in pick:
+        lo, hi = int(batch.ptr[b]), int(batch.ptr[b + 1])
+        n = hi - lo
+        sb = Batch.from_data_list([scenes[b]])
+        e1 = {'map_feat': emb['map_feat'][lo:hi].cpu(), 'past_feat': emb['past_feat'][lo:hi].cpu()}
+        with torch.no_grad():
+            pa_c = orc.decode_embedding(zc[lo:hi].cpu(), e1, sb, map_idx[b:b + 1], env_c, nfuture=12)['future_pred']
+        assert_close(seen['pa'][lo:hi], pa_c, RT, AT, 'scene %d (n=%d): rollout A vs oracle' % (b, n))
+        assert_close(seen['pb'][lo:hi], pa_c, RT, AT, 'scene %d (n=%d): rollout B vs oracle' % (b, n))
+        # the planner's reaction to the PRODUCT's futures of this scene, by the oracle's planner
+        op_ = oplan.HardcodeNuscPlanner(mg._LaneEnv(lane_graph), oplan.PlannerConfig(**CONFIG_DICT['default']))
+        op_.reset(unn_c(sb.past_gt[:, -1, :]), orc.get_att_normalizer().unnormalize(sb.lw), sb.batch, 1, map_idx[b:b + 1])
+        agt = unn_c(seen['pa'][lo + 1:hi].cpu()).numpy()
+        want = op_.rollout(agt, plan_t, np.array([0, n - 1]), plan_t, control_all=False)
+        want_n = orc.get_normalizer().normalize(want.to(torch.float32))         # (the closure keeps the plan normalised, in fp32)
+        assert_close(seen['plan'][b], want_n[0], 0, 4e-6, 'scene %d: planner reaction vs the oracle planner' % b)
+
+    # ---- the sub-batch of the three scenes: losses and gradients through rollout + planner + losses ----
+    sub = Batch.from_data_list([scenes[b] for b in pick])
+    rows = torch.cat([torch.arange(int(batch.ptr[b]), int(batch.ptr[b + 1])) for b in pick])
+    sub_mi = map_idx[pick]
+    e_sub = {k: (tuple(t[rows.to(DEV)] for t in v) if isinstance(v, tuple) else v[rows.to(DEV)]) for k, v in emb.items()}
+    z_sub = zc[rows.to(DEV)].clone()
+    sg = sub.clone().to(DEV)
+    ego_s = torch.zeros((rows.shape[0],), dtype=torch.bool, device=DEV)
+    ego_s[sg.ptr[:-1].to(DEV)] = True
+    pms, pvs = e_sub['prior_out']
+    cs, planner_s = closure_for(sg, sub_mi.to(DEV), e_sub, z_sub, (pms[ego_s], pvs[ego_s]), (pms[~ego_s], pvs[~ego_s]))
+    seen_s, _, _ = run_step(cs)
+    planner_s.check()
+    for i, b in enumerate(pick):                        # the sub-batch closure sees the same per-scene quantities as the full one
+        lo, hi = int(batch.ptr[b]), int(batch.ptr[b + 1])
+        slo, shi = int(sub.ptr[i]), int(sub.ptr[i + 1])
+        assert_close(seen_s['pa'][slo:shi], seen['pa'][lo:hi], 0, 2e-6, 'scene %d: rollout A in the sub-batch = in the 512-agent batch' % b)
+        assert_close(seen_s['plan'][i], seen['plan'][b], 0, 1e-6, 'scene %d: plan in the sub-batch = in the 512-agent batch' % b)
+        assert_close(seen_s['adv_adv_crash_loss'][i], seen['adv_adv_crash_loss'][b], 1e-4, 1e-6, 'scene %d: crash term' % b)
+    e_c = {k: (tuple(t.cpu() for t in v) if isinstance(v, tuple) else v.cpu()) for k, v in e_sub.items()}
+    ego_c = ego_s.cpu()
+    trace = []
+    o_pl = oplan.HardcodeNuscPlanner(mg._LaneEnv(lane_graph), oplan.PlannerConfig(**CONFIG_DICT['default']))
+    oloops.adv_loop(orc, sub, sub_mi, env_c, e_c, z_sub.cpu(), bench.ADV_WEIGHTS, 1, 0.05, (pms[ego_s].cpu(), pvs[ego_s].cpu()),
+                    (pms[~ego_s].cpu(), pvs[~ego_s].cpu()), feasibility_time=2, feasibility_infront_min=0.0, future_len=12,
+                    veh_coll_buffer=0.1, trace=trace, planner=o_pl)
+    want = trace[0]
+    for k, v in want.items():
+        if k in ('z', 'grad') or k not in seen_s:
+            continue
+        assert_close(seen_s[k].float().mean(), v.float().mean(), 2e-4, 1e-5, 'closed-loop loss entry %s' % k)
+    for name, got, w in (('ego latents', seen_s['g_tgt'], want['grad'][0]), ('other latents', seen_s['g_other'], want['grad'][1])):
+        gmax = float(w.abs().max())
+        rel = float((got.cpu() - w).norm() / max(float(w.norm()), 1e-30))
+        assert rel < 5e-3, 'closed loop, %s: gradient relative L2 error %.3g' % (name, rel)
+        assert_close_frac(got, w, 2e-3, 1e-6 + 2e-4 * gmax, 0.9, 2e-2 * gmax, 'closed loop, %s: gradient vs oracle' % name)
+
+
+# ------------------------------------------------------------------------------------------------
+# SURVEY 8(f) #3 on the device path: the scenario JSON of a closed-loop run
+# ------------------------------------------------------------------------------------------------
+
+def test_scenario_json_from_the_device_pipeline(model, tmp_path):
+    """prepare_output_dict (reference src/utils/scenario_gen.py:189-254) is fed what the reference feeds it at
+    src/adv_scenario_gen.py:465-538 -- here DEVICE tensors straight out of run_adv_gen_optim(planner_name='hardcode') and
+    run_find_solution_optim -- written as JSON, read back with read_adv_scenes, and compared with the JSON the same code
+    produces from the ORACLE's run of the same three closed-loop iterations (oracle rollouts, losses, Adam and rule-based
+    planner on the CPU)."""
+    import json
+    from oracle import planner as oplan
+    from oracle import loops as oloops
+    from oracle.losses import AdvGen
+    from strive_amd.utils.adv_gen_optim import run_adv_gen_optim
+    from strive_amd.utils.sol_optim import run_find_solution_optim
+    from strive_amd.utils.scenario_gen import detach_embed_info, prepare_output_dict
+    from strive_amd.datasets.utils import read_adv_scenes
+    from strive_amd.planners.planner import PlannerConfig
+    from strive_amd.planners.hardcode_goalcond_nusc import HardcodeNuscPlanner, CONFIG_DICT
+    import bench
+    m, sd = model
+    px, iters = 1024, 3
+    lane_graph = synth.make_lane_graph(extent=px * 0.25)
+    raster, dx = uniform(px)
+    env = synth.SyntheticMapEnv(raster.clone(), dx.clone(), lane_graph=lane_graph).to(DEV)
+    own = [(3, 'gc/json/0'), (4, 'gc/json/1')]
+    batch, map_idx = bench.build_batch(own, 2, px, lane_graph=lane_graph)
+    bg, mi = batch.clone().to(DEV), map_idx.to(DEV)
+    with torch.no_grad():
+        emb = detach_embed_info(m.embed(bg, mi, env))
+    NA, B = int(bg.past.shape[0]), 2
+    ego = torch.zeros((NA,), dtype=torch.bool, device=DEV)
+    ego[bg.ptr[:-1].to(DEV)] = True
+    pm, pv = emb['prior_out']
+    z0 = emb['posterior_out'][0].clone()
+    with torch.no_grad():
+        init_fut = m.decode_embedding(z0, emb, bg, mi, env)['future_pred']
+    planner = HardcodeNuscPlanner(env, PlannerConfig(**CONFIG_DICT['default']))
+    w = dict(bench.ADV_WEIGHTS)
+    w.update({'sol_coll_veh': 10.0, 'sol_coll_env': 10.0, 'sol_motion_prior_ext': 0.001, 'sol_match_ext': 10.0, 'sol_init_z': 0.0,
+              'sol_motion_prior': 0.005})
+    z_adv, fin, _, agt, tt = run_adv_gen_optim(z0.clone(), 0.05, w, m, bg, env, mi, iters, emb, 'hardcode', (pm[ego], pv[ego]),
+                                               (pm[~ego], pv[~ego]), 2, 0.0, planner=planner)
+    z_sol, sol_traj, _ = run_find_solution_optim(z_adv.clone().detach(), fin, 16, 0.05, w, m, bg, env, mi, 2, emb,
+                                                 (pm[ego], pv[ego]), (pm[~ego], pv[~ego]))
+    assert fin.is_cuda and z_adv.is_cuda and sol_traj.is_cuda
+    ptr = batch.ptr.tolist()
+    scenes = bg.to_data_list()
+    out_dir = tmp_path / 'device'
+    out_dir.mkdir()
+    got = []
+    for b in range(B):
+        lo, hi = ptr[b], ptr[b + 1]
+        d = prepare_output_dict(scenes[b], int(map_idx[b]), env, m.dt, m, init_fut[lo:hi], fin[lo:hi, 0], sol_fut_traj=sol_traj[lo:hi, 0],
+                                attack_agt=int(agt[b]) - lo, attack_t=int(tt[b]), adv_z=z_adv[lo:hi], sol_z=z_sol[lo:hi],
+                                prior_distrib=(pm[lo:hi], pv[lo:hi]))
+        with open(out_dir / ('scene_%03d.json' % b), 'w') as f:
+            json.dump(d, f)
+        got.append(json.loads(json.dumps(d)))
+    back = read_adv_scenes(str(out_dir))
+    assert [s_['name'] for s_ in back] == ['scene_000', 'scene_001']
+    for b, s_ in enumerate(back):
+        assert s_['scene_fut'].shape == (ptr[b + 1] - ptr[b], 12, 4) and s_['attack_t'] == got[b]['attack_t']
+
+    # ---- the oracle's run of the same loop, through the same writer ----
+    orc = oracle_model(sd)
+    env_c = synth.SyntheticMapEnv(raster, dx)
+    e_c = {k: (tuple(t.cpu() for t in v) if isinstance(v, tuple) else v.cpu()) for k, v in emb.items()}
+    ego_c = ego.cpu()
+    pm_c, pv_c = e_c['prior_out']
+    o_pl = oplan.HardcodeNuscPlanner(mg._LaneEnv(lane_graph), oplan.PlannerConfig(**CONFIG_DICT['default']))
+    z_adv_c = oloops.adv_loop(orc, batch, map_idx, env_c, e_c, z0.cpu(), w, iters, 0.05, (pm_c[ego_c], pv_c[ego_c]),
+                              (pm_c[~ego_c], pv_c[~ego_c]), feasibility_time=2, feasibility_infront_min=0.0, future_len=12,
+                              veh_coll_buffer=0.1, planner=o_pl)
+    nrm_c, att_c = orc.get_normalizer(), orc.get_att_normalizer()
+    with torch.no_grad():
+        fin_c = orc.decode_embedding(z_adv_c, e_c, batch, map_idx, env_c, nfuture=12)['future_pred'].clone()
+        init_c = orc.decode_embedding(z0.cpu(), e_c, batch, map_idx, env_c)['future_pred']
+    plan_t = np.linspace(0.5, 6.0, 12)
+    agt_ptr = (batch.ptr - torch.arange(B + 1)).numpy()
+    react = o_pl.rollout(nrm_c.unnormalize(fin_c[~ego_c]).numpy(), plan_t, agt_ptr, plan_t, control_all=False).to(fin_c)
+    fin_c[ego_c] = nrm_c.normalize(react)
+    with torch.no_grad():
+        adv_c = AdvGen(w, att_c.unnormalize(batch.lw), map_idx[batch.batch], env_c, z0.cpu()[~ego_c], batch.ptr, veh_coll_buffer=0.1,
+                       crash_loss_min_time=2, crash_loss_min_infront=0.0)
+        mins = adv_c(nrm_c.unnormalize(fin_c), nrm_c.unnormalize(fin_c[ego_c]), z_adv_c[~ego_c], (pm_c[~ego_c], pv_c[~ego_c]),
+                     return_mins=True)
+
+    class Holder(object):          # prepare_output_dict only asks the model for its two normalisers
+        def get_normalizer(self):
+            return nrm_c
+
+        def get_att_normalizer(self):
+            return att_c
+    cscenes = batch.to_data_list()
+    for b in range(B):
+        lo, hi = ptr[b], ptr[b + 1]
+        want = prepare_output_dict(cscenes[b], int(map_idx[b]), env_c, 0.5, Holder(), init_c[lo:hi], fin_c[lo:hi], attack_agt=int(mins['min_agt'][b]),
+                                   attack_t=int(mins['min_t'][b]), adv_z=z_adv_c[lo:hi], prior_distrib=(pm_c[lo:hi], pv_c[lo:hi]))
+        want = json.loads(json.dumps(want))
+        g_ = got[b]
+        assert set(want.keys()) <= set(g_.keys()) and {'fut_sol', 'z_sol'} <= set(g_.keys()), sorted(g_.keys())
+        assert g_['N'] == want['N'] and g_['map'] == want['map'] and g_['dt'] == want['dt']
+        assert g_['attack_agt'] == want['attack_agt'] and g_['attack_t'] == want['attack_t'], 'scene %d: attacker %s/%s vs %s/%s' % (
+            b, g_['attack_agt'], g_['attack_t'], want['attack_agt'], want['attack_t'])
+        for k, tol in (('lw', 1e-5), ('sem', 0.0), ('past', 1e-3), ('fut_init', 2e-3), ('fut_adv', 5e-3), ('z_adv', 2e-3)):
+            assert_close(np.asarray(g_[k]), np.asarray(want[k]), 0, tol, 'scene %d JSON entry %s' % (b, k))
+        assert_close(np.asarray(g_['z_prior']['mean']), np.asarray(want['z_prior']['mean']), 1e-4, 2e-5, 'z_prior mean')
+        assert np.asarray(g_['fut_sol']).shape == (hi - lo, 12, 4) and np.isfinite(np.asarray(g_['fut_sol'])).all()
+
+
+# ------------------------------------------------------------------------------------------------
 # sample_batched + feasibility
 # ------------------------------------------------------------------------------------------------
 

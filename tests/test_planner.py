@@ -295,6 +295,33 @@ def test_device_planner_reports_exceeded_limits(emu_ops):
         dev.rollout(world[4].copy(), world[5], world[6], world[5], control_all=False)
 
 
+def test_device_planner_status_of_earlier_rollouts_is_kept(emu_ops):
+    """The optimisation loops look at the planner's status once, after their last iteration.  The flags live in one status
+    tensor per planner that the kernels only set: a limit exceeded in an EARLIER rollout is still reported after later,
+    clean rollouts (it used to be overwritten by the newest rollout's status), and a raising check() clears it."""
+    world = list(random_world([3, 2], 'lim2', tail=False))
+    _, dev = both_planners(tuple(world), 'default')
+    dev.defer_check = True                      # what rollouts on device tensors do inside the optimisation loops
+    obs = torch.from_numpy(world[4].copy())
+    dev.rollout(obs, world[5], world[6], world[5], control_all=False)
+    dev.check()                                 # clean
+    dev.traj_cap = 1                            # one rollout with a trajectory list that cannot hold a scene's predictions
+    plan_bad = dev.rollout(obs, world[5], world[6], world[5], control_all=False)
+    dev.traj_cap = type(dev).traj_cap
+    assert bool(torch.isnan(plan_bad).any()), 'the overflowing rollout must poison its plan'
+    # it surfaces at a later rollout's non-blocking look at the flags (here, on the host device, the very next one; on the GPU
+    # when the asynchronous snapshot has arrived) or at the loop's final check() -- never lost behind later, clean rollouts
+    real_check = dev.check
+    dev.check = lambda wait=True: real_check(wait) if wait else None          # loop without the opportunistic look
+    for _ in range(2):
+        plan = dev.rollout(obs, world[5], world[6], world[5], control_all=False)       # later rollouts are clean
+        assert not bool(torch.isnan(plan).any())
+    dev.check = real_check
+    with pytest.raises(L.StriveHipError, match='traj'):
+        dev.check()
+    dev.check()                                 # cleared by the raising check
+
+
 # ------------------------------------------------------------------------------------------------
 # MI355X
 # ------------------------------------------------------------------------------------------------
