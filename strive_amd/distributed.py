@@ -104,25 +104,42 @@ class DataParallelTrainer(object):
 
     @staticmethod
     def batch_counts(scene_graph, FT):
-        """(visible frames, agents, ordered in-scene pairs, ego frames) of this rank's scenes."""
-        sizes = (scene_graph.ptr[1:] - scene_graph.ptr[:-1]).to(torch.float64)
-        return torch.stack([(scene_graph.future_vis == 1.0).sum().to(torch.float64).cpu(), sizes.sum().cpu(),
-                            (sizes * sizes - sizes).sum().cpu(), torch.tensor(float(sizes.numel() * FT), dtype=torch.float64)])
+        """(visible frames, agents, ordered in-scene pairs, ego frames) of this rank's scenes: float64 on the graph's device.
+        They depend on the batch only, so they are computed once per batch (kept on the graph object) and never read on the
+        host: a read-back here made the host wait for the previous step's kernels at the start of every step."""
+        key = (scene_graph.ptr.data_ptr(), scene_graph.ptr._version, scene_graph.future_vis.data_ptr(), scene_graph.future_vis._version, FT)
+        ent = scene_graph.__dict__.get('_strive_batch_counts')
+        if ent is not None and ent[0] == key:
+            return ent[1]
+        dev = scene_graph.future_vis.device
+        sizes = (scene_graph.ptr[1:] - scene_graph.ptr[:-1]).to(device=dev, dtype=torch.float64)
+        counts = torch.stack([(scene_graph.future_vis == 1.0).sum().to(torch.float64), sizes.sum(), (sizes * sizes - sizes).sum(),
+                              torch.tensor(float(sizes.numel() * FT), dtype=torch.float64, device=dev)])
+        scene_graph.__dict__['_strive_batch_counts'] = (key, counts)
+        return counts
 
     def global_loss_share(self, loss_dict, local, glob):
-        """This rank's additive share of the global-batch loss from the per-element outputs of TrafficModelLoss."""
+        """This rank's additive share of the global-batch loss from the per-element outputs of TrafficModelLoss.  ``local`` /
+        ``glob``: the four counts as device tensors (or sequences of floats); everything stays on the device."""
         w = self.loss_fn.loss_weights
         loss = w['recon'] * loss_dict['recon_loss'].sum() / glob[0] + w['kl'] * loss_dict['kl_loss'].sum() / glob[1]
-        if 'coll_veh_prior' in loss_dict and local[2] > 0:      # a rank without pairs (one-agent scenes) has 0/0 locally
-            loss = loss + w['coll_veh_prior'] * loss_dict['coll_veh_prior'].sum() * (local[2] / glob[2])
+        if 'coll_veh_prior' in loss_dict:
+            cv = loss_dict['coll_veh_prior'].sum() * (local[2] / glob[2])
+            if torch.is_tensor(local[2]):
+                # a rank without pairs (one-agent scenes) has 0/0 = NaN locally: it contributes nothing
+                cv = torch.where(local[2] > 0, cv, torch.zeros_like(cv))
+            elif not local[2] > 0:
+                cv = None
+            if cv is not None:
+                loss = loss + w['coll_veh_prior'] * cv
         if 'coll_env_prior' in loss_dict:
             loss = loss + w['coll_env_prior'] * loss_dict['coll_env_prior'].sum() / glob[3]
         return loss
 
     def step(self, scene_graph, map_idx, map_env, future_sample=None):
         dev = self.params[0].device
-        local = self.batch_counts(scene_graph, self.model.FT)
-        glob = torch.clamp(self._all_reduce(local.clone().to(dev)).cpu(), min=1.0)      # an empty global count never divides
+        local = self.batch_counts(scene_graph, self.model.FT).to(dev)
+        glob = torch.clamp(self._all_reduce(local.clone()), min=1.0)      # an empty global count never divides; stays on the device
         w = self.loss_fn.loss_weights
         if future_sample is None:
             future_sample = w['coll_veh_prior'] > 0.0 or w['coll_env_prior'] > 0.0
@@ -130,10 +147,15 @@ class DataParallelTrainer(object):
         self._bind_grads()
         failed, loss_dict, share, error = 0.0, None, None, None
         try:
-            from . import ops
-            pred = self.model(scene_graph, map_idx, map_env, future_sample=future_sample)
+            from . import ops, params
+            # weight packs are rebuilt after every optimiser step and need max |w| of every tensor on the host (operand scales are
+            # kernel arguments): taken from the read-back of the PREVIOUS step (plus the most an optimiser step can add), so the
+            # host never waits for the step it has just enqueued
+            lr = max(float(g_['lr']) for g_ in self.optimizer.param_groups)
+            with params.lagged_absmax(slack=8.0 * lr):
+                pred = self.model(scene_graph, map_idx, map_env, future_sample=future_sample)
             loss_dict = self.loss_fn(scene_graph, pred, map_idx=map_idx, map_env=map_env)
-            share = self.global_loss_share(loss_dict, [float(v) for v in local], [float(v) for v in glob])
+            share = self.global_loss_share(loss_dict, local.to(torch.float32), glob.to(torch.float32))
             # the HIP backward calls accumulate straight into the bucket (every p.grad is a view of it): no scratch, no
             # per-parameter adds by autograd
             with ops.GradSink(self.params, self.bucket):
@@ -145,7 +167,7 @@ class DataParallelTrainer(object):
         self._bind_grads()                 # (a failed backward may have left some p.grad detached from the bucket)
         if failed:
             self.bucket.zero_()
-        self.bucket[-1] = failed
+        self.bucket[-1:].fill_(failed)     # (a fill kernel; `bucket[-1] = failed` is a synchronous copy of a host scalar)
         self._all_reduce(self.bucket)
         if error is not None and not isinstance(error, RuntimeError):
             raise error                    # the reference's loop only swallows RuntimeError (train_traffic.py:120-131)

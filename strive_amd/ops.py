@@ -712,7 +712,7 @@ def decoder_rollout(model, g, map_feat, past_feat, z, map_idx, map_env, ext_futu
 
     def build():
         return params.pack_decoder(model.state_dict(), NC, map_env, dev, model.normalizer, model.att_normalizer,
-                                   model.bicycle_params, cnn=cnn_pack(model))
+                                   model.bicycle_params, cnn=cnn_pack(model), map_pack=_map_pack(map_env, dev))
     key, extra = _decoder_pack_key(model, map_env, dev)
     h = _RolloutCtx()
     h.lib = lib

@@ -42,8 +42,70 @@ def _absmax_key(t):
     return (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
 
 
+class lagged_absmax(object):
+    """Context (the training step): prefetch_absmax() does not wait for the device.  It enqueues the read-back of max |t| into
+    pinned memory and serves, for every tensor, the value of the most recent read-back that has ARRIVED (the first call waits)
+    plus ``slack`` -- the most the tensors can have grown since: ``slack`` = a bound on two optimiser steps' change of an entry
+    (Adam: ~4 lr per step).  The power-of-two operand scales are then chosen with a factor 2 of extra head-room
+    (_pow2_scale), so a stale, slightly-too-small bound cannot overflow fp16: |w| scale <= 16384 (1 + slack / max|w|) << 65504."""
+    active = None
+
+    def __init__(self, slack):
+        self.slack = float(slack)
+
+    def __enter__(self):
+        self.prev = lagged_absmax.active
+        lagged_absmax.active = self
+        return self
+
+    def __exit__(self, *exc):
+        lagged_absmax.active = self.prev
+
+
+_LAG = {}             # data_ptr -> {'val': float, 'pending': (pinned tensor, event, index) or None}
+_LAG_BATCH = []       # read-backs under way: (pinned values, event, [data_ptr, ...])
+
+
+def _lagged_prefetch(tensors, slack):
+    todo = [t.detach() for t in tensors if t.numel() > 0 and _absmax_key(t.detach()) not in _ABSMAX]
+    if not todo:
+        return
+    dev = todo[0].device
+    if dev.type != 'cuda':
+        vals = torch.stack(torch._foreach_norm([t.to(torch.float32) for t in todo], float('inf'))).tolist()
+        for t, v in zip(todo, vals):
+            _ABSMAX[_absmax_key(t)] = (float(v), t)
+        return
+    # harvest the read-backs that have arrived
+    while _LAG_BATCH and _LAG_BATCH[0][1].query():
+        host, _, ptrs = _LAG_BATCH.pop(0)
+        for pv, v in zip(ptrs, host.tolist()):
+            _LAG[pv] = float(v)
+    # enqueue this step's read-back
+    norms = torch.stack(torch._foreach_norm([t.to(torch.float32) for t in todo], float('inf')))
+    host = torch.empty((len(todo),), dtype=torch.float32).pin_memory()
+    host.copy_(norms, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    _LAG_BATCH.append((host, ev, [t.data_ptr() for t in todo]))
+    if any(t.data_ptr() not in _LAG for t in todo):          # first sight of a tensor: this one read-back is waited for
+        ev.synchronize()
+        while _LAG_BATCH:
+            h, _, ptrs = _LAG_BATCH.pop(0)
+            for pv, v in zip(ptrs, h.tolist()):
+                _LAG[pv] = float(v)
+        slack = 0.0
+    if len(_ABSMAX) + len(todo) > 2048:
+        _ABSMAX.clear()
+    for t in todo:
+        _ABSMAX[_absmax_key(t)] = (_LAG[t.data_ptr()] + slack, t)
+
+
 def prefetch_absmax(tensors):
-    """Compute and cache max |t| for every tensor of ``tensors`` not yet cached at its current version; one synchronisation."""
+    """Compute and cache max |t| for every tensor of ``tensors`` not yet cached at its current version; one synchronisation
+    (none inside a ``lagged_absmax`` context, see there)."""
+    if lagged_absmax.active is not None:
+        return _lagged_prefetch(list(tensors), lagged_absmax.active.slack)
     todo, keys = [], []
     for t in tensors:
         t = t.detach()
@@ -229,9 +291,12 @@ def _fill_gru(s, holder, sd, prefix):
             getattr(s, '%s_sc' % name)[l] = sc
 
 
-def _pow2_scale(bound, target=32768.0):
-    """largest power of two S with bound * S <= target (fp16's largest finite value is 65504)"""
+def _pow2_scale(bound, target=None):
+    """largest power of two S with bound * S <= target (fp16's largest finite value is 65504); inside a lagged_absmax context
+    the bound is one step old and the target leaves another factor 2"""
     import math
+    if target is None:
+        target = 16384.0 if lagged_absmax.active is not None else 32768.0
     if not (bound > 0.0) or not math.isfinite(bound):
         return 1.0
     return float(2.0 ** math.floor(math.log2(target / bound)))
@@ -343,7 +408,7 @@ def _fill_cnn(s, holder, sd):
         else:
             g = absmax(_c(sd['map_conv.%d.weight' % (3 * l - 2)]))
             b = absmax(_c(sd['map_conv.%d.bias' % (3 * l - 2)]))
-            s.xscale[l] = min(_pow2_scale(g * in_elems[l] ** 0.5 + b, 60000.0), 1024.0)
+            s.xscale[l] = min(_pow2_scale(g * in_elems[l] ** 0.5 + b, 30000.0 if lagged_absmax.active is not None else 60000.0), 1024.0)
     s.w1_frag = holder.hold(_conv1_fragments(_c(sd['map_conv.0.weight']), s.wscale[0]))
     s.w2_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.3.weight']), s.wscale[1]))
     s.w3_frag = holder.hold(_conv_bf6_fragments(_c(sd['map_conv.6.weight']), s.wscale[2]))
@@ -390,10 +455,12 @@ def pack_map(map_env, device):
     return p
 
 
-def pack_decoder(sd, NC, map_env, device, state_norm, att_norm, bike, cnn=None):
+def pack_decoder(sd, NC, map_env, device, state_norm, att_norm, bike, cnn=None, map_pack=None):
     """state_norm / att_norm: objects with mean_vals/std_vals (MeanStdNormalizer API); bike: dict; ``cnn``: an up-to-date
     pack_cnn() of the same parameters to share (its tensors are kept alive by the returned pack) instead of packing the map
-    CNN a second time."""
+    CNN a second time; ``map_pack``: likewise a pack_map() of (map_env, device) -- the training step rebuilds the decoder pack
+    after every optimiser step, and building the map pack again (interleaved raster copy, two host-to-device table uploads)
+    was HALF of that step's host time (16 of 33 ms, profiles/r04_train_host_cprofile.txt)."""
     p = Packed(L.StriveDecoder())
     s = p.struct
     _fill_gnn(s.gnn, p, sd, 'decoder_net', NC)
@@ -403,7 +470,11 @@ def pack_decoder(sd, NC, map_env, device, state_norm, att_norm, bike, cnn=None):
         p.keep.append(cnn)
     else:
         _fill_cnn(s.cnn, p, sd)
-    _fill_map(s.map, p, map_env, device)
+    if map_pack is not None:
+        C.memmove(C.byref(s.map), C.byref(map_pack.struct), C.sizeof(L.StriveMap))
+        p.keep.append(map_pack)
+    else:
+        _fill_map(s.map, p, map_env, device)
     for i in range(6):
         s.state_mean[i] = float(state_norm.mean_vals[i])
         s.state_std[i] = float(state_norm.std_vals[i])

@@ -52,7 +52,7 @@ def _product_step(m, batch, map_idx, env, eps_post, eps_prior):
     return out, ld, {n: p.grad for n, p in m.named_parameters()}, err
 
 
-def _compare_grads(got, want, rtol, frac_atol, what):
+def _compare_grads(got, want, rtol, frac_atol, what, rel_l2=None):
     assert set(got) == set(want) and len(got) == 174
     worst = ('', 0.0)
     for n in want:
@@ -64,6 +64,8 @@ def _compare_grads(got, want, rtol, frac_atol, what):
         if rel > worst[1]:
             worst = (n, rel)
         assert_close(g, w, rtol, 1e-7 + frac_atol * scale, '%s: grad %s' % (what, n))
+        if rel_l2 is not None and float(w.norm()) > 1e-12:
+            assert rel <= rel_l2, '%s: grad %s: relative L2 error %.3g > %.1e' % (what, n, rel, rel_l2)
     return worst
 
 
@@ -172,7 +174,9 @@ def test_training_step_golden_and_all_gradients():
     assert_close(out['future_pred'], out_o['future_pred'], 1e-4, 2e-5, 'future_pred (uniform)')
     for k in ('loss', 'recon_loss', 'kl_loss', 'coll_veh_prior', 'coll_env_prior'):
         assert_close(ld[k], ld_o[k], 2e-3, 2e-3 if 'env' in k else 1e-5, k + ' (uniform)')
-    worst = _compare_grads(grads, g_o, 1e-2, 5e-3, 'training step (uniform raster)')
+    # measured on the MI355X: worst tensor 1.4e-5 relative L2 (map_conv.1.weight; the CNN backward multiplies two-piece bf16
+    # operands, 2^-16 per product) -- the bound is 7 x that, so a precision regression of the backward fails here
+    worst = _compare_grads(grads, g_o, 2e-3, 5e-4, 'training step (uniform raster)', rel_l2=1e-4)
     print('worst relative L2 gradient error: %s %.3g' % worst)
     m.eval()
 

@@ -1,5 +1,5 @@
 """Which torch calls inside one optimisation closure synchronise the host with the GPU?  (torch.cuda.set_sync_debug_mode)
-Run on the GPU box: python tools/sync_audit.py [refine|adv]"""
+Run on the GPU box: python tools/sync_audit.py [refine|adv|train]"""
 import os
 import sys
 import warnings
@@ -15,7 +15,7 @@ own, desc, _ = bench.workload_scenes(args, 0, 1)
 m = bench.build_model(dev, args.nc)
 env = bench.build_env(1024, dev)
 batch, map_idx = bench.build_batch(own, args.nc, 1024)
-fac = bench.refine_closure_factory if wl == 'refine' else bench.adv_closure_factory
+fac = {'refine': bench.refine_closure_factory, 'train': bench.train_step_factory}.get(wl, bench.adv_closure_factory)
 step, emb, g, mi, _ = fac(m, env, batch, map_idx, args.ft, dev)
 step()
 step()
