@@ -583,21 +583,28 @@ def _cpu_model():
     return 'unknown'
 
 
-def _one_socket_threads():
-    """Hardware threads of one socket (what the reference's single-socket CPU run would use)."""
+def _one_socket():
+    """(physical cores, hardware threads) of ONE socket -- what the reference's single-socket CPU run would use."""
     try:
-        sockets, cpus = set(), 0
+        sockets, cpus, cores = set(), 0, 0
         with open('/proc/cpuinfo') as f:
             for line in f:
                 if line.startswith('physical id'):
                     sockets.add(line.split(':', 1)[1].strip())
                 elif line.startswith('processor'):
                     cpus += 1
+                elif line.startswith('cpu cores') and not cores:
+                    cores = int(line.split(':', 1)[1])
         if sockets and cpus:
-            return max(1, cpus // len(sockets))
-    except OSError:
+            threads = max(1, cpus // len(sockets))
+            return (cores or threads), threads
+    except (OSError, ValueError):
         pass
-    return torch.get_num_threads()
+    return torch.get_num_threads(), torch.get_num_threads()
+
+
+def _one_socket_threads():
+    return _one_socket()[1]
 
 
 def cpu_baseline(FT, scenes=4, agents=16, raster_px=4096, timed=3, warm=1):
@@ -649,16 +656,17 @@ def cpu_baseline(FT, scenes=4, agents=16, raster_px=4096, timed=3, warm=1):
     finally:
         torch.set_num_threads(old_threads)
     n = scenes * agents * FT
-    return {'value': round(n / dt, 2), 'unit': 'agent*timesteps/s', 'cores': threads, 'kind': 'port', 'cpu': _cpu_model(),
+    return {'value': round(n / dt, 2), 'unit': 'agent*timesteps/s', 'cores': _one_socket()[0], 'threads': threads, 'kind': 'port',
+            'cpu': _cpu_model(),
             'sample': '%d scenes x %d agents, FT=%d: %d warm-up + %d timed refine closures (decode + AvoidCollLoss + backward '
                       'incl. the CNN weight gradients the reference computes + Adam) of the CPU oracle, %.1f s per closure; '
-                      'threads = one socket' % (scenes, agents, FT, warm, timed, dt)}
+                      'torch threads = the hardware threads of one socket, `cores` = its physical cores' % (scenes, agents, FT, warm, timed, dt)}
 
 
 def cpu_baseline_record(FT, full=False):
     """The bench line's `cpu_baseline`.  SURVEY 8(d) quotes the CPU at C2 (32 scenes x 16 agents), where one closure of the
-    oracle takes minutes; the default run therefore times two bounded samples of the same workload -- 4 x 16 agents (1 warm-up +
-    2 timed closures) and 16 x 16 agents (1 timed closure) -- reports the LARGER sample as `value` and states both, so the trend
+    oracle takes minutes; the default run therefore times two bounded samples of the same workload -- 4 x 16 agents and 16 x 16 agents, each
+    with 1 warm-up + 1 timed closure -- reports the LARGER sample as `value` and states both, so the trend
     towards C2 is visible (it differs by host: 77 -> 31 agent*timesteps/s from 4 to 32 scenes on the 8-vCPU survey container,
     79 -> 90 from 4 to 16 scenes on the 128-thread EPYC of the GPU boxes).  ``--cpu-baseline-full`` times C2 itself (1 warm-up +
     2 timed closures, several minutes); profiles/r03_cpu_baseline_c2.json holds that run."""
@@ -666,8 +674,8 @@ def cpu_baseline_record(FT, full=False):
         rec = cpu_baseline(FT, scenes=32, agents=16, timed=2)
         rec['sample'] = 'C2 itself: ' + rec['sample']
         return rec
-    small = cpu_baseline(FT, scenes=4, agents=16, timed=2)
-    large = cpu_baseline(FT, scenes=16, agents=16, timed=1, warm=0)
+    small = cpu_baseline(FT, scenes=4, agents=16, timed=1)
+    large = cpu_baseline(FT, scenes=16, agents=16, timed=1, warm=1)
     rec = dict(large)
     rec['sample'] = ('bounded samples of C2 (32 x 16 agents): %s || %s.  `value` is the 16 x 16 sample (4 x 16: %.1f, 16 x 16: %.1f '
                      'agent*timesteps/s); C2 itself, timed with --cpu-baseline-full, is in profiles/r03_cpu_baseline_c2.json' %
@@ -679,6 +687,45 @@ def cpu_baseline_record(FT, full=False):
 # ------------------------------------------------------------------------------------------------
 # launch
 # ------------------------------------------------------------------------------------------------
+
+def pin_host_threads(local, nlocal):
+    """N ranks of one node share its host cores: every rank enqueues ~200-700 launches per step from Python (1.6-5.6 ms of host
+    work per closure at one rank), so they must not fight over cores or oversubscribe them with intra-op threads.  Each local
+    rank gets an equal, disjoint slice of the cores the job may use and at most 8 torch threads."""
+    info = {'affinity': None, 'torch_threads': torch.get_num_threads()}
+    if nlocal <= 1:
+        return info
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cpus) // nlocal)
+        mine = cpus[local * per:(local + 1) * per] or cpus
+        os.sched_setaffinity(0, mine)
+        info['affinity'] = '%d cores (%d-%d)' % (len(mine), mine[0], mine[-1])
+        torch.set_num_threads(max(1, min(8, len(mine))))
+    except (AttributeError, OSError):
+        torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // nlocal)))
+    info['torch_threads'] = torch.get_num_threads()
+    return info
+
+
+def gather_ranks(use_dist, world, device, dt_local, units_local, rank_record):
+    """(max over ranks of the timed region, units of all ranks, every rank's record, what the collective backend reports)"""
+    dt, units, per_rank = dt_local, units_local, [rank_record]
+    backend = {'rccl_world_size': None, 'rccl_backend': None}
+    if use_dist:
+        import torch.distributed as dist
+        tt = torch.tensor([dt_local], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        uu = torch.tensor([units_local], device=device, dtype=torch.float64)
+        dist.all_reduce(uu, op=dist.ReduceOp.SUM)
+        units = int(uu.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, rank_record)
+        backend = {'rccl_world_size': dist.get_world_size(), 'rccl_backend': dist.get_backend()}
+    backend['distinct_devices'] = len(set(r[3] for r in per_rank))
+    return dt, units, per_rank, backend
+
 
 def _free_port():
     s = socket.socket()
@@ -711,6 +758,7 @@ def parse_args(argv=None):
     ap.add_argument('--cpu-baseline-full', action='store_true', help='time the CPU oracle on C2 itself (32 x 16 agents; ~10 minutes)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--dry-run', action='store_true', help='CPU/gloo: join the ranks, build the scene partition, no kernels')
+    ap.add_argument('--fail-rank', type=int, default=-1, help='dry run only (test hook): this rank raises before the collectives')
     args = ap.parse_args(argv)
     if not args.nc:
         args.nc = 5 if args.workload == 'sharded4096' else 2
@@ -740,6 +788,7 @@ def main():
         raise SystemExit('bench.py: rank %d has no GPU (%d visible)' % (local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
+    host_pin = pin_host_threads(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -803,17 +852,8 @@ def main():
     units = units_local
     props = torch.cuda.get_device_properties(device)
     dev_id = str(getattr(props, 'uuid', '')) or '%s/pci%s' % (props.name, getattr(props, 'pci_bus_id', local))
-    per_rank = [[rank, NA, round(dt_local / args.steps * 1e3, 3), dev_id, local]]
-    if use_dist:
-        tt = torch.tensor([dt_local], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        uu = torch.tensor([units_local], device=device, dtype=torch.float64)
-        dist.all_reduce(uu, op=dist.ReduceOp.SUM)
-        units = int(uu.item())
-        gathered = [None] * world
-        dist.all_gather_object(gathered, per_rank[0])
-        per_rank = gathered
+    dt, units, per_rank, backend = gather_ranks(use_dist, world, device, dt_local, units_local,
+                                                [rank, NA, round(dt_local / args.steps * 1e3, 3), dev_id, local])
     if args.planner == 'hardcode':
         closure_adv = ('closed-loop adversarial closure: 2 x decode_embedding(nfuture=%d) with complementary detach + '
                        'HardcodeNuscPlanner.rollout (31 planner steps per scene, device) + TgtMatchingLoss + AdvGenLoss + backward + Adam')
@@ -865,9 +905,9 @@ def main():
         'pipeline': dict(step.stats) if args.workload == 'full' else None,
         'per_rank': [{'rank': r, 'agents': a, 'ms_per_step': t, 'device': d, 'local_rank': lr} for r, a, t, d, lr in per_rank],
         # what the collective backend saw (N > 1: RCCL = torch.distributed 'nccl'): world size it reports and the distinct devices
-        'rccl_world_size': dist.get_world_size() if use_dist else None,
-        'rccl_backend': dist.get_backend() if use_dist else None,
-        'distinct_devices': len(set(d for _, _, _, d, _ in per_rank)),
+        'rccl_world_size': backend['rccl_world_size'], 'rccl_backend': backend['rccl_backend'],
+        'distinct_devices': backend['distinct_devices'],
+        'host': host_pin,
     }
     failed = False
     if rank == 0:
@@ -912,31 +952,65 @@ def main():
 
 
 def dry_run(args, rank, world):
-    """No GPU: the ranks join a gloo group, build their part of the workload and rank 0 checks that the union of the
-    per-rank scene lists is exactly the job (disjoint + complete for `sharded4096`)."""
+    """No GPU: the ranks join a gloo group, build their part of the workload, go through the SAME timing / gathering code as
+    the real run (barrier, max over ranks, summed units, per-rank records, what the collective backend reports) around a
+    stand-in step, and rank 0 checks that the union of the per-rank scene lists is exactly the job (disjoint + complete for
+    `sharded4096`).  `--fail-rank R`: rank R raises before the collectives -- the job must end non-zero, not hang."""
     import torch.distributed as dist
-    if world > 1:
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    host_pin = pin_host_threads(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
+    use_dist = world > 1
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo', rank=rank, world_size=world)
+    if args.fail_rank == rank:
+        raise RuntimeError('bench.py --fail-rank %d: this rank fails before the collectives' % rank)
     own, desc, scaling = workload_scenes(args, rank, world)
     mine = {'rank': rank, 'scenes': [k for _, k in own], 'agents': sum(n for n, _ in own)}
     everyone = [mine]
-    if world > 1:
+    if use_dist:
         everyone = [None] * world
         dist.all_gather_object(everyone, mine)
+        dist.barrier()
+    t0 = time.perf_counter()
+    x = torch.zeros((256, 256))
+    for _ in range(args.steps):
+        x = x @ x + 1.0                        # the stand-in "step"
+    if use_dist:
+        dist.barrier()
+    dt_local = time.perf_counter() - t0
+    rollouts = 2 if args.workload in ('adv', 'sharded4096', 'train') else 1
+    units_local = rollouts * mine['agents'] * args.ft * args.steps
+    dt, units, per_rank, backend = gather_ranks(use_dist, world, torch.device('cpu'), dt_local, units_local,
+                                                [rank, mine['agents'], round(dt_local / args.steps * 1e3, 3), 'cpu:rank%d/pid%d' % (rank, os.getpid()), local])
     if rank == 0:
         keys = [k for e in everyone for k in e['scenes']]
         rec = {'dry_run': True, 'n_gpus': world, 'ranks_joined': sorted(e['rank'] for e in everyone), 'scaling': scaling,
                'workload': desc, 'agents_per_rank': [e['agents'] for e in everyone], 'total_agents': sum(e['agents'] for e in everyone),
-               'scenes_per_rank': [len(e['scenes']) for e in everyone], 'disjoint': len(keys) == len(set(keys))}
+               'scenes_per_rank': [len(e['scenes']) for e in everyone], 'disjoint': len(keys) == len(set(keys)),
+               'units': units, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+               'per_rank': [{'rank': r, 'agents': a, 'ms_per_step': t, 'device': d, 'local_rank': lr} for r, a, t, d, lr in per_rank],
+               'rccl_world_size': backend['rccl_world_size'], 'rccl_backend': backend['rccl_backend'],
+               'distinct_devices': backend['distinct_devices'], 'host': host_pin}
         if args.workload == 'sharded4096':
             sizes = variable_scene_sizes(args.total_agents or 4096, 'bench/sharded')
             rec['complete'] = sorted(keys) == sorted('bench/sharded/%d' % i for i in range(len(sizes)))
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
 if __name__ == '__main__':
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        # a rank that fails must END (the launcher then stops the other ranks) instead of waiting in the process group's
+        # destructor for peers that are blocked in a collective it will never join
+        import traceback
+        traceback.print_exc()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1)
