@@ -158,6 +158,17 @@ class TrafficModel(nn.Module):
         return {'future_pred': self.decoder(scene_graph, embed_out['map_feat'], embed_out['past_feat'], z, map_idx,
                                             map_env, ext_future=ext_future, nfuture=nfuture)}
 
+    def decode_embedding_pair(self, z_a, z_b, embed_out, scene_graph, map_idx, map_env, ext_future=None, nfuture_a=None, nfuture_b=None):
+        """``decode_embedding(z_a, ..., nfuture=nfuture_a)`` and ``decode_embedding(z_b, ..., nfuture=nfuture_b)`` for latents of
+        EQUAL VALUES that differ only in which leaves they are differentiated for (the complementary-detach pair of the
+        adversarial and solution loops, reference src/utils/adv_gen_optim.py:120-131, src/utils/sol_optim.py:73-80): one forward
+        rollout serves both, each keeps its own backward (ops._RolloutPairFn).  Not part of the reference's API."""
+        fa = self.FT if nfuture_a is None else nfuture_a
+        fb = self.FT if nfuture_b is None else nfuture_b
+        ta, tb = ops.decoder_rollout_pair(self, scene_graph, embed_out['map_feat'], embed_out['past_feat'], z_a, z_b, map_idx, map_env,
+                                          ext_future, fa, fb)
+        return {'future_pred': ta}, {'future_pred': tb}
+
     def rsample(self, mean, var):
         """(reference src/models/traffic_model.py:706-712)"""
         return mean + torch.randn_like(mean) * torch.sqrt(var)

@@ -587,6 +587,76 @@ class _RolloutFn(torch.autograd.Function):
         return dz.reshape(ctx.zshape), None
 
 
+_pair_streams = {}
+
+
+class _RolloutPairFn(torch.autograd.Function):
+    """Two decodes that differ only in WHICH latents they are differentiated for (reference src/utils/adv_gen_optim.py:120-121,
+    src/utils/sol_optim.py:73-76: ``z_a = collate(tgt_z, other_z.detach())``, ``z_b = collate(tgt_z.detach(), other_z)`` -- the same
+    values, the same scene, the same injected future).  Their forward rollouts are the same computation, so it is done ONCE:
+    one strive_rollout_fwd, one tape; the two results are handed back as two tensors and each gets its own reverse sweep over the
+    shared tape (the sweep is linear in the trajectory adjoint and only reads the tape).  Port B may be shorter (``FT_b`` <= FT:
+    the solution loop decodes 16 steps for the ego term and 12 for the others'; the rollout is causal, so B = the first FT_b
+    steps).  Gradients: d/dz_a from port A's adjoint, d/dz_b from port B's; autograd then drops the detached halves."""
+
+    @staticmethod
+    def forward(ctx, z_a, z_b, h):
+        lib = h.lib
+        dev = z_a.device
+        zz = _f32c(z_a).reshape(h.R, 32)
+        traj = torch.empty((h.R, h.FT, 4), dtype=torch.float32, device=dev)
+        tape = torch.empty(h.tape_bytes, dtype=torch.uint8, device=dev)
+        ws = _workspace(dev, h.ws_bytes, 'rollout')
+        lib.call('strive_rollout_fwd', h.dec.ref(), h.sc.ref(), L.ptr(h.past_last), L.ptr(h.lw), L.ptr(h.sem),
+                 L.ptr(h.past_feat), L.ptr(h.map_feat), L.ptr(zz), L.ptr(h.mapix), L.ptr(h.ext), h.FT, L.ptr(traj),
+                 L.ptr(tape), tape.numel(), L.ptr(ws), ws.numel(), _stream(z_a))
+        ctx.h, ctx.tape, ctx.zz = h, tape, zz
+        ctx.shape_a, ctx.shape_b = z_a.shape, z_b.shape
+        return traj, traj[:, :h.FT_b].clone()
+
+    @staticmethod
+    def backward(ctx, d_a, d_b):
+        h = ctx.h
+        dev = d_a.device
+        ws = _workspace(dev, h.ws_bytes, 'rollout')
+
+        def sweep(d_traj):
+            dz = torch.empty((h.R, 32), dtype=torch.float32, device=dev)
+            h.lib.call('strive_rollout_bwd', h.dec.ref(), h.sc.ref(), L.ptr(h.lw), L.ptr(h.sem), L.ptr(ctx.zz), L.ptr(h.ext),
+                       h.FT, L.ptr(d_traj), L.ptr(dz), L.ptr(ctx.tape), ctx.tape.numel(), L.ptr(ws), ws.numel(), _stream(d_traj))
+            return dz
+        ga = gb = None
+        both = ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and dev.type == 'cuda' and not torch.cuda.is_current_stream_capturing()
+        side = None
+        if ctx.needs_input_grad[1]:
+            db = _f32c(d_b)
+            if h.FT_b < h.FT:           # the steps port B does not have carry no adjoint
+                db = torch.cat([db, torch.zeros((h.R, h.FT - h.FT_b, 4), dtype=torch.float32, device=dev)], dim=1)
+            if both:
+                # the two sweeps are independent latency chains (one workgroup per scene each): B's runs on a side stream under A's
+                cur = torch.cuda.current_stream(dev)
+                side = _pair_streams.get(str(dev))
+                if side is None:
+                    side = torch.cuda.Stream(dev)
+                    _pair_streams[str(dev)] = side
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    ws_b = _workspace(dev, h.ws_bytes, 'rollout')          # (scratch is per stream)
+                    dzb = torch.empty((h.R, 32), dtype=torch.float32, device=dev)
+                    h.lib.call('strive_rollout_bwd', h.dec.ref(), h.sc.ref(), L.ptr(h.lw), L.ptr(h.sem), L.ptr(ctx.zz), L.ptr(h.ext),
+                               h.FT, L.ptr(db), L.ptr(dzb), L.ptr(ctx.tape), ctx.tape.numel(), L.ptr(ws_b), ws_b.numel(), _stream(db))
+                db.record_stream(side)
+                gb = dzb.reshape(ctx.shape_b)
+            else:
+                gb = sweep(db).reshape(ctx.shape_b)
+        if ctx.needs_input_grad[0]:
+            ga = sweep(_f32c(d_a)).reshape(ctx.shape_a)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
+            gb.record_stream(torch.cuda.current_stream(dev))
+        return ga, gb, None
+
+
 class _RolloutTrainFn(torch.autograd.Function):
     """autoregressive_decoder with parameter gradients (training path): strive_rollout_fwd / strive_rollout_bwd_train.
     Differentiable inputs: z, past_feat, map_feat; parameters: decoder_net, decoder_memory, map_conv, map_feature."""
@@ -690,12 +760,39 @@ def decoder_packs_ready(model, g, map_env, NS, dev):
     return _cached_pack_hit(model, key, model, extra) and NS in info._packs
 
 
+def decoder_rollout_pair(model, g, map_feat, past_feat, z_a, z_b, map_idx, map_env, ext_future, FT_a, FT_b):
+    """Two decodes of the SAME latent values (``z_a`` and ``z_b`` differ only in which leaves they reach, see _RolloutPairFn)
+    with one forward rollout: -> (traj_a (NA,[1,]FT_a,4) differentiable w.r.t. z_a, traj_b (NA,[1,]FT_b,4) w.r.t. z_b),
+    FT_b <= FT_a.  The caller guarantees the values are equal (the loops build both from the same two leaves)."""
+    if _wgrad():
+        raise NotImplementedError('decoder_rollout_pair serves the latent-optimisation loops, not the training forward')
+    if z_a.shape != z_b.shape or int(FT_b) > int(FT_a):
+        raise ValueError('decoder_rollout_pair: latents %s vs %s, FT %d vs %d' % (tuple(z_a.shape), tuple(z_b.shape), FT_a, FT_b))
+    h, info, multi, NS = _rollout_context(model, g, map_feat, past_feat, z_a, map_idx, map_env, ext_future, FT_a, False)
+    h.FT_b = int(FT_b)
+    ta, tb = _RolloutPairFn.apply(z_a, z_b, h)
+    if multi:
+        return ta.reshape(info.NA, NS, h.FT, 4), tb.reshape(info.NA, NS, h.FT_b, 4)
+    return ta.reshape(info.NA, h.FT, 4), tb.reshape(info.NA, h.FT_b, 4)
+
+
 def decoder_rollout(model, g, map_feat, past_feat, z, map_idx, map_env, ext_future, FT):
     """autoregressive_decoder as one fused call; differentiable w.r.t. ``z`` only."""
+    train = _wgrad()
+    h, info, multi, NS = _rollout_context(model, g, map_feat, past_feat, z, map_idx, map_env, ext_future, FT, train)
+    if train:
+        ps = list(model.decoder_net.parameters()) + list(model.decoder_memory.parameters()) + _cnn_params(model)
+        traj = _RolloutTrainFn.apply(z, past_feat, map_feat, h, *ps)
+        return traj.reshape(info.NA, h.FT, 4)
+    traj = _RolloutFn.apply(z, h)
+    return traj.reshape(info.NA, NS, h.FT, 4) if multi else traj.reshape(info.NA, h.FT, 4)
+
+
+def _rollout_context(model, g, map_feat, past_feat, z, map_idx, map_env, ext_future, FT, train):
+    """descriptors, per-call tensors and sizes of one rollout (shared by decoder_rollout and decoder_rollout_pair)"""
     lib = _lib_for(z, map_feat, past_feat, g.past)
     if model.normalizer is None or model.att_normalizer is None or model.bicycle_params is None:
         raise RuntimeError('set_normalizer / set_att_normalizer / set_bicycle_params must be called before decoding')
-    train = _wgrad()
     if train:
         _no_grad_inputs('decoder (ext_future)', ext_future)
     else:
@@ -733,12 +830,7 @@ def decoder_rollout(model, g, map_feat, past_feat, z, map_idx, map_env, ext_futu
         raise ValueError('ext_future must be (B, FT, 4), got %s' % (tuple(h.ext.shape),))
     h.tape_bytes = lib.query('strive_rollout_tape_bytes', h.dec.ref(), h.sc.ref(), h.FT)
     h.ws_bytes = lib.query('strive_rollout_workspace_bytes', h.dec.ref(), h.sc.ref(), h.FT)
-    if train:
-        ps = list(model.decoder_net.parameters()) + list(model.decoder_memory.parameters()) + _cnn_params(model)
-        traj = _RolloutTrainFn.apply(z, past_feat, map_feat, h, *ps)
-        return traj.reshape(info.NA, h.FT, 4)
-    traj = _RolloutFn.apply(z, h)
-    return traj.reshape(info.NA, NS, h.FT, 4) if multi else traj.reshape(info.NA, h.FT, 4)
+    return h, info, multi, NS
 
 
 # ------------------------------------------------------------------------------------------------

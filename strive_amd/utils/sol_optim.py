@@ -33,7 +33,7 @@ def run_find_solution_optim(cur_z, final_result_traj, future_len, lr, loss_weigh
         z_a = collate_tgt_other_z(scene_graph, tgt_z, other_z_all.detach())
         z_b = collate_tgt_other_z(scene_graph, tgt_z.detach(), other_z_all)
         out_a, out_b = two_rollouts(model, embed_info, scene_graph, map_idx, map_env, z_a, dict(nfuture=future_len), z_b, dict(),
-                                    overlap=not graphed)      # (a replayed graph keeps one stream, see AdvClosure)
+                                    overlap=not graphed, same_values=True)      # (a replayed graph keeps one stream, see AdvClosure)
         tgt_pred = unn(out_a['future_pred']).transpose(0, 1).reshape(NA, future_len, 4)
         lt = avoid_loss(tgt_pred, tgt_z, tgt_prior_distrib)
         lo = match_loss(unn(out_b['future_pred']).index_select(0, other_idx), other_match, other_z_all, other_prior_distrib)

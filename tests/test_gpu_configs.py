@@ -203,6 +203,54 @@ def test_adv_closure_at_size(model, NC):
         assert float(zf.grad[others.to(DEV)].abs().max()) == 0.0, 'no gradient may leak into other scenes'
 
 
+def test_shared_forward_rollout_equals_two_rollouts(model, monkeypatch):
+    """The complementary-detach pair of an adversarial iteration (reference src/utils/adv_gen_optim.py:120-131) holds the same
+    latent values twice, so the product decodes ONCE and sweeps twice (ops._RolloutPairFn).  Against two separate rollouts
+    (STRIVE_SHARED_ROLLOUT=0) on 8 scenes of 2..30 agents: the same losses and the same gradients of both latent groups, and
+    likewise for the solution loop's 16- and 12-step pair (two iterations of run_find_solution_optim)."""
+    import bench
+    from strive_amd.utils.adv_gen_optim import AdvClosure
+    from strive_amd.utils.sol_optim import run_find_solution_optim
+    from strive_amd.utils.scenario_gen import detach_embed_info
+    m, sd = model
+    sizes = [2, 30, 7, 16, 3, 11, 1, 5]
+    raster, dx = uniform()
+    env = dev_env(raster, dx)
+    batch, map_idx = synth.make_batch(sizes, key='gc/shared', map_extent=(512.0, 512.0))
+    bg, mi = batch.clone().to(DEV), map_idx.to(DEV)
+    with torch.no_grad():
+        emb = detach_embed_info(m.embed(bg, mi, env))
+    NA = sum(sizes)
+    ego = torch.zeros((NA,), dtype=torch.bool, device=DEV)
+    ego[bg.ptr[:-1].to(DEV)] = True
+    pm, pv = emb['prior_out']
+    res = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('STRIVE_SHARED_ROLLOUT', mode)
+        monkeypatch.setenv('STRIVE_HIP_GRAPH', '0')
+        c = AdvClosure(emb['posterior_out'][0].clone(), 0.05, bench.ADV_WEIGHTS, m, bg, env, mi, emb, (pm[ego], pv[ego]),
+                       (pm[~ego], pv[~ego]), 2, 0.0, veh_coll_buffer=0.1)
+        seen = {}
+
+        def log(ld, tz, oz):
+            seen.update({k: v.detach().clone() for k, v in ld.items() if torch.is_tensor(v)})
+            seen['g_tgt'], seen['g_other'] = tz.grad.clone(), oz.grad.clone()
+        c.step(log=log)
+        w = dict(bench.ADV_WEIGHTS)
+        w.update({'sol_coll_veh': 10.0, 'sol_coll_env': 10.0, 'sol_motion_prior_ext': 0.001, 'sol_match_ext': 10.0, 'sol_init_z': 0.0,
+                  'sol_motion_prior': 0.005})
+        fin = m.decode_embedding(emb['posterior_out'][0], emb, bg, mi, env)['future_pred'].detach().unsqueeze(1)
+        z_sol, sol_traj, _ = run_find_solution_optim(emb['posterior_out'][0].clone(), fin, 16, 0.05, w, m, bg, env, mi, 2, emb,
+                                                     (pm[ego], pv[ego]), (pm[~ego], pv[~ego]))
+        res[mode] = (seen, z_sol.detach().clone(), sol_traj.detach().clone())
+    a, b = res['1'], res['0']
+    for k in b[0]:
+        scale = max(1.0, float(b[0][k].abs().max()))
+        assert_close(a[0][k], b[0][k], 1e-5, 1e-6 * scale, 'shared forward: %s' % k)
+    assert_close(a[1], b[1], 0, 1e-5, 'solution loop latents after two iterations')
+    assert_close(a[2], b[2], 0, 1e-5, 'solution loop trajectories')
+
+
 # ------------------------------------------------------------------------------------------------
 # configs[2], closed loop: the adversarial closure against the rule-based planner at ~512 agents
 # ------------------------------------------------------------------------------------------------
