@@ -415,7 +415,7 @@ def train_step_factory(m, env, batch, map_idx, FT, device):
 # side measurements
 # ------------------------------------------------------------------------------------------------
 
-TRAFFIC_FILES = ('r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json')
+TRAFFIC_FILES = ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json')
 
 
 def _measured_traffic(kernel_name, with_source=False):
