@@ -312,10 +312,16 @@ def _checked_absmax(w, what):
 
 def _f16_split2(w, scale, what):
     """w * scale = w0 + w1 up to 2^-24 |w|: w0 = fp16 (round to nearest even), w1 = fp16 of the exact remainder.  ``scale``
-    comes from _pow2_scale(_checked_absmax(w)): max |w| scale <= 32768, so both pieces are finite."""
+    comes from _pow2_scale(_checked_absmax(w)): max |w| scale <= 32768, so both pieces are finite.
+    CONTRACT: max |w| is cached per (address, in-place version) of the parameter (_ABSMAX).  Parameters must therefore only be
+    modified through operations that bump the version counter (optimiser steps, ``p.copy_()``, ``p.mul_()`` ...); an edit through
+    ``p.data`` or an external alias leaves a stale bound, and a weight that grew past 2 x the bound would overflow its fp16 pieces
+    to inf without an error.  STRIVE_CHECK_PACKS=1 verifies every packed piece on the device (one synchronisation per pack)."""
     ws = w.to(torch.float32) * scale
     w0 = ws.to(torch.float16)
     w1 = (ws - w0.to(torch.float32)).to(torch.float16)
+    if os.environ.get('STRIVE_CHECK_PACKS') == '1' and not bool(torch.isfinite(w0).all() and torch.isfinite(w1).all()):
+        raise ValueError('%s: fp16 operand pieces are not finite (stale max |w|? see _f16_split2)' % what)
     return torch.stack([w0, w1], dim=0)
 
 
