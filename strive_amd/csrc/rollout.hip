@@ -473,6 +473,11 @@ extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* 
     const scn::GRUFrag gf = scn::gru_frag(dec->gru);
     const char* pe = getenv("STRIVE_SCENE_PROF");
     const bool scene_prof = scene && pe && atoi(pe) != 0;
+    // scenes of >= STRIVE_SCENE_SPLIT agents (default 15; 0 = never): their 130-240 edge rows are 3-4 chunks on ONE CU inside the
+    // scene kernel and one workgroup per target node in gnn_edge_kernel (profiles/r04_ab_scene_split.txt)
+    const char* se = getenv("STRIVE_SCENE_SPLIT");
+    const int split_min = se ? atoi(se) : 15;
+    const bool scene_split = scene && split_min > 0 && sc->max_n >= split_min;
     hipLaunchKernelGGL(rollout_init_kernel, dim3((unsigned)((R * 64 + 255) / 256)), dim3(256), 0, stream, tp, past_last,
                        past_feat, map_feat, mapix, w.mapix_rows, (int)R, sc->NS);
     for (int t = 0; t < FT; ++t) {
@@ -480,12 +485,26 @@ extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* 
             scn::StepArgsS a;
             a.t = t; a.FT = FT; a.NC = NC; a.max_n = sc->max_n; a.sem = sem; a.lw = lw; a.z = z; a.ext = ext_future; a.ptr = sc->ptr;
             a.par = dec->scene_par; a.traj = traj;
-            if (scene_prof)       // (tools/scene_phase_probe.py: phase ticks of workgroup 0 at the start of the workspace)
-                hipLaunchKernelGGL(scn::scene_fwd_step_kernel<true>, dim3((unsigned)sc->B), dim3(scn::NTHR), scn::FwdLds::BYTES, stream, gd, gr,
-                                   gf, dp, a, tp, (unsigned long long*)ws);
-            else
-                hipLaunchKernelGGL(scn::scene_fwd_step_kernel<false>, dim3((unsigned)sc->B), dim3(scn::NTHR), scn::FwdLds::BYTES, stream, gd, gr,
-                                   gf, dp, a, tp, (unsigned long long*)nullptr);
+            auto launch_scene = [&](int mode) {
+                a.mode = mode;
+                if (scene_prof)       // (tools/scene_phase_probe.py: phase ticks of workgroup 0 at the start of the workspace)
+                    hipLaunchKernelGGL(scn::scene_fwd_step_kernel<true>, dim3((unsigned)sc->B), dim3(scn::NTHR), scn::FwdLds::BYTES, stream, gd,
+                                       gr, gf, dp, a, tp, (unsigned long long*)ws);
+                else
+                    hipLaunchKernelGGL(scn::scene_fwd_step_kernel<false>, dim3((unsigned)sc->B), dim3(scn::NTHR), scn::FwdLds::BYTES, stream, gd,
+                                       gr, gf, dp, a, tp, (unsigned long long*)nullptr);
+            };
+            if (scene_split) {
+                // large scenes: node phases per scene, the edge rows on one workgroup per target node in between (gnn_kernels.h)
+                GnnBuffers gb = w.gb;
+                gb.A = tp.A_t(t); gb.ARG = tp.ARG_t(t); gb.X = tp.X_t(t); gb.P = tp.P_t(t); gb.Q = tp.Q_t(t);
+                gb.PRE_IN = tp.PRE_IN_t(t); gb.PRE_E = tp.PRE_E_t(t);
+                launch_scene(1);
+                hipLaunchKernelGGL(gnn_edge_kernel, dim3((unsigned)R), dim3(256), EdgeLds::bytes(), stream, gd, sd, tp.pos_t(t), gb);
+                launch_scene(4);
+            } else {
+                launch_scene(7);
+            }
             if (t < FT - 1) {
                 int rc = strive_map_cnn_fwd(&dec->map, &dec->cnn, tp.pos_t(t + 1), dec->state_mean, dec->state_std,
                                             w.mapix_rows, (int32_t)R, tp.mf_t(t + 1), w.cnn_ws, w.cnn_bytes, stream_);

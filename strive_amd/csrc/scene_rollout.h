@@ -498,6 +498,10 @@ struct FwdLds {
 
 struct StepArgsS {
     int t, FT, NC, max_n;
+    int mode;                  // bit 0: features .. edge partials (x, P, Q into the tape); bit 1: the edge chunks (running max);
+                               // bit 2: update MLP .. GRU (x and the aggregate come from the tape when bits 0 / 1 are off).  7 = a whole
+                               // step in one launch.  Scenes of >= 15 agents run 1 | edge kernel of gnn_kernels.h | 4: their 130-240 edge
+                               // rows are 3-4 chunks on ONE CU here and one workgroup per target there
     const float* sem;          // (NA, NC)
     const float* lw;           // (NA, 2) normalised
     const float* z;            // (NA, 32)
@@ -548,6 +552,7 @@ static __global__ __launch_bounds__(NTHR) void scene_fwd_step_kernel(GNNDev g, G
             }
     }
 
+    if (a.mode & 1) {
     // ---- features [past_feat_t | map_feat_t | sem | z | lw], poses ----
     for (int i = tid; i < n * F; i += NTHR) {
         const int rr = i / F, k = i - rr * F, r = lo + rr;
@@ -636,9 +641,19 @@ static __global__ __launch_bounds__(NTHR) void scene_fwd_step_kernel(GNNDev g, G
         tp.Q_t(t)[(size_t)(lo + rr) * H + c] = L.Q[rr * HLD + c];
     }
     SCN_TICK(1);
+    } else {
+        // the node embeddings and the aggregated messages of this step are in the tape (written by the launches before this one)
+        for (int i = tid; i < n * 64; i += NTHR) {
+            L.x[(i >> 6) * XLD + (i & 63)] = tp.X_t(t)[(size_t)lo * 64 + i];
+            L.A[i] = tp.A_t(t)[(size_t)lo * 64 + i];
+        }
+        par_stage(L.par, a.par, tid);
+        __syncthreads();
+    }
+    if (!(a.mode & 6)) return;
 
     // ---- edges in chunks of EC rows: e = i (n - 1) + jj, source jl = jj + (jj >= i) ----
-    {
+    if (a.mode & 2) {
         float* s_e = L.U;                  // [EC][HLD]
         float* s_m = L.U + EC * HLD;       // [EC][XLD]
         const int E = n * (n - 1);
@@ -713,7 +728,6 @@ static __global__ __launch_bounds__(NTHR) void scene_fwd_step_kernel(GNNDev g, G
             __syncthreads();
             SCN_TICK(7);
         }
-    }
     for (int i = tid; i < n * 64; i += NTHR) {
         const int arg = L.ARG[i];
         const float v = arg < 0 ? 0.f : L.A[i];          // isolated node: aggregate 0 (interaction_net.py:188)
@@ -722,6 +736,8 @@ static __global__ __launch_bounds__(NTHR) void scene_fwd_step_kernel(GNNDev g, G
         tp.ARG_t(t)[(size_t)lo * 64 + i] = arg;
     }
     __syncthreads();
+    }
+    if (!(a.mode & 4)) return;
 
     SCN_TICK(8);
     // ---- update MLP [x | aggr | sem] -> 128 -> 64, mlp_out 64 -> 128 -> 128 -> 2 ----
