@@ -191,6 +191,32 @@ int strive_map_crop_u8(const StriveMap* map, const float* pos, const float* pos_
                        const float* pos_std4_host, const int32_t* mapix, int32_t N, uint8_t* out,
                        strive_stream_t stream);
 
+/* NuScenesMapEnv.__init__'s rasterisation (reference src/datasets/map_env.py:79-166): one layer of one map from polygon / line
+ * geometry.  THE REFERENCE TAKES THE GEOMETRY AND ITS RASTERISER FROM THE nuscenes DEVKIT (NuScenesMap.get_map_mask ->
+ * cv2.fillPoly / cv2.polylines), which is not installed here and cannot be: no fixture of its output can exist, so this entry
+ * point is pinned to its own stated rule by an exact rational-arithmetic oracle (oracle/raster.py), not to the devkit.
+ * Rule: pixel (r, c) = the layer's value at the world point the crop looks it up for, (c dx_x, r dx_y) (get_map_obs reads
+ * raster[round(y / dx_y), round(x / dx_x)], nuscenes_utils.py:250-263): 1 inside or on the boundary of a polygon (even-odd over the
+ * rings of a shape = holes) or within half_width of a polyline.  Sets bytes to 1, never clears: the caller zero-fills the layer, and
+ * several jobs may target one layer (the reference collapses the road layers into channel 0, :108-113).
+ * Tables (device, built by the host): shapes s = rings ring_ptr[shape_ptr[s] .. shape_ptr[s+1]]; ring r = vertices
+ * verts[ring_ptr[r] .. ring_ptr[r+1]] (x, y in metres, float64; polygon rings close implicitly); shape_kind[s] 0 = polygon, 1 = line;
+ * tile t = 32 x 32 pixels, row-major over ceil(H/32) x ceil(W/32): the shapes whose bounding box (grown by half_width) touches it are
+ * tile_shapes[tile_ptr[t] .. tile_ptr[t+1]].  flip_rows: write row H-1-r (the reference flips the Singapore maps about the x axis,
+ * :125-127).  out_layer (H, out_pitch) uint8. */
+typedef struct StriveRasterJob {
+    const double* verts;
+    const int32_t* ring_ptr;
+    const int32_t* shape_ptr;
+    const uint8_t* shape_kind;
+    const int32_t* tile_ptr;
+    const int32_t* tile_shapes;
+    int32_t H, W, out_pitch, flip_rows;
+    double dx_x, dx_y, half_width;
+} StriveRasterJob;
+
+int strive_map_rasterize(const StriveRasterJob* job, uint8_t* out_layer, strive_stream_t stream);
+
 /* get_coll_point (reference src/datasets/nuscenes_utils.py:334-390) on raster layer 0.
  * cars (N,4) unnormalised, lw (N,2); gl/gw = grid size (host computes it from the batch mean like the
  * reference, lines 351-354); lin_l (gl), lin_w (gw) = fp32 linspace(-1,1,.) tables.

@@ -57,6 +57,12 @@ class StriveCNN(C.Structure):
                 ('w_torch', C.c_void_p * 6), ('wscale', C.c_float * 6), ('xscale', C.c_float * 6), ('conv2_plain', C.c_int32)]
 
 
+class StriveRasterJob(C.Structure):
+    _fields_ = [('verts', C.c_void_p), ('ring_ptr', C.c_void_p), ('shape_ptr', C.c_void_p), ('shape_kind', C.c_void_p),
+                ('tile_ptr', C.c_void_p), ('tile_shapes', C.c_void_p), ('H', C.c_int32), ('W', C.c_int32), ('out_pitch', C.c_int32),
+                ('flip_rows', C.c_int32), ('dx_x', C.c_double), ('dx_y', C.c_double), ('half_width', C.c_double)]
+
+
 class StriveScenes(C.Structure):
     _fields_ = [('NA', C.c_int32), ('NS', C.c_int32), ('B', C.c_int32), ('max_n', C.c_int32), ('n_edges', C.c_int64),
                 ('ptr', C.c_void_p), ('scene_of', C.c_void_p)]
@@ -124,6 +130,7 @@ PROTOTYPES = {
     'strive_abi_version': (C.c_int, []),
     'strive_last_error': (C.c_char_p, []),
     'strive_map_crop_u8': (C.c_int, [C.POINTER(StriveMap), P, F4, F4, P, I, P, P]),
+    'strive_map_rasterize': (C.c_int, [C.POINTER(StriveRasterJob), P, P]),
     'strive_coll_point': (C.c_int, [C.POINTER(StriveMap), P, P, P, I, I, I, P, P, P, P, P]),
     'strive_map_cnn_workspace_bytes': (SZ, [I]),
     'strive_map_cnn_fwd': (C.c_int, [C.POINTER(StriveMap), C.POINTER(StriveCNN), P, F4, F4, P, I, P, P, SZ, P]),

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libstrive_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 
-SOURCES = ['capi.hip', 'map_crop.hip', 'map_cnn.hip', 'mlp_gnn.hip', 'rollout.hip', 'losses.hip', 'planner.hip']
+SOURCES = ['capi.hip', 'map_crop.hip', 'map_raster.hip', 'map_cnn.hip', 'mlp_gnn.hip', 'rollout.hip', 'losses.hip', 'planner.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-fast-math', '-ffp-contract=on',
          '-fhip-fp32-correctly-rounded-divide-sqrt', '-Wno-unused-result', '-Wno-unused-value',
          # no auto-formed v_pk_*_f32: on MI355X a v_pk_add_f32 with crossed op_sel halves returned wrong values in
