@@ -191,18 +191,23 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
         }
     };
 
-    if (FUSED_CROP) tables(0, 0);
+    // gridDim.y workgroups share a row of tiles: each walks TILES_X / gridDim.y of them.  One (the whole row, pipelined) when the
+    // batch fills the chip; four (one tile each) for small batches, where the row's 4-tile chain is what a launch waits for
+    // (8 samples: 17.7 -> ~8 us, profiles/r04_ab_cnn_small_batch.txt).  Same tiles, same arithmetic, same statistics slots.
+    const int tpb = TILES_X / (int)gridDim.y;
+    const int tx_begin = (int)blockIdx.y * tpb, tx_end = tx_begin + tpb;
+    if (FUSED_CROP) tables(tx_begin, tx_begin & 1);
     __syncthreads();
-    gather(0, 0);
-    if (FUSED_CROP && TILES_X > 1) tables(1, 1);
-    deposit(0);
+    gather(tx_begin, tx_begin & 1);
+    if (FUSED_CROP && tx_begin + 1 < tx_end) tables(tx_begin + 1, (tx_begin + 1) & 1);
+    deposit(tx_begin & 1);
     __syncthreads();
     const f16x8* wl = reinterpret_cast<const f16x8*>(s_w) + lane;
-    for (int tx = 0; tx < TILES_X; ++tx) {
+    for (int tx = tx_begin; tx < tx_end; ++tx) {
         const int buf = tx & 1;
-        if (tx + 1 < TILES_X) gather(tx + 1, (tx + 1) & 1);
+        if (tx + 1 < tx_end) gather(tx + 1, (tx + 1) & 1);
         // statistics of the previous tile (its per-wave partials were published before the last barrier)
-        if (tx > 0 && tid == 0) {
+        if (tx > tx_begin && tid == 0) {
             double a = 0.0, b = 0.0;
             for (int w = 0; w < 8; ++w) { a += s_red[(tx - 1) & 1][2 * w]; b += s_red[(tx - 1) & 1][2 * w + 1]; }
             GNStats& o = stats[(size_t)n * NPART + ty * TILES_X + (tx - 1)];
@@ -252,14 +257,14 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
         lsum = wave_sum_d(lsum);
         lsq = wave_sum_d(lsq);
         if (lane == 0) { s_red[buf][2 * wave] = lsum; s_red[buf][2 * wave + 1] = lsq; }
-        if (tx + 1 < TILES_X) deposit(buf ^ 1);
-        if (FUSED_CROP && tx + 2 < TILES_X) tables(tx + 2, tx & 1);   // slot tx&1 was last read by gather(tx)
+        if (tx + 1 < tx_end) deposit(buf ^ 1);
+        if (FUSED_CROP && tx + 2 < tx_end) tables(tx + 2, tx & 1);   // slot tx&1 was last read by gather(tx)
         __syncthreads();
     }
     if (tid == 0) {
         double a = 0.0, b = 0.0;
-        for (int w = 0; w < 8; ++w) { a += s_red[(TILES_X - 1) & 1][2 * w]; b += s_red[(TILES_X - 1) & 1][2 * w + 1]; }
-        GNStats& o = stats[(size_t)n * NPART + ty * TILES_X + (TILES_X - 1)];
+        for (int w = 0; w < 8; ++w) { a += s_red[(tx_end - 1) & 1][2 * w]; b += s_red[(tx_end - 1) & 1][2 * w + 1]; }
+        GNStats& o = stats[(size_t)n * NPART + ty * TILES_X + (tx_end - 1)];
         o.sum = a;
         o.sq = b;
     }
@@ -1181,6 +1186,12 @@ typedef BfCfg<16, 32, 5, 125, 61, l1b::NPART, true, 2, 3> Bf2;     // conv2: oct
 typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, true, 2, 2, false, 2> Bf3;   // conv3: octet-planar in and out; both 32-channel blocks from one staging
 // conv4 (3x3, 29 -> 14): the whole 14 x 14 image is one workgroup tile of 16 x 16 (pixel tiles of 2 rows x 16 columns);
 typedef BfCfg<64, 64, 3, 29, 14, Bf3::NPART_OUT, true, 2, 2, true, 2> Bf4;
+// small batches (<= CNN_SMALL_BATCH samples): one 32-channel block per workgroup for conv3 / conv4 -- twice the workgroups, half
+// the matrix steps per workgroup: a launch is then a few per-workgroup latency chains, not throughput (8 samples: conv3 23.7 ->
+// ~17 us, conv4 26.2 -> ~19 us, profiles/r04_ab_cnn_small_batch.txt).  Same products in the same order per output; the GroupNorm
+// moments are float64 partial sums per (tile, block) added in a fixed order, so the normalisation agrees to 1e-16.
+typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, true, 2, 2, false, 1> Bf3s;
+typedef BfCfg<64, 64, 3, 29, 14, Bf3s::NPART_OUT, true, 2, 2, true, 1> Bf4s;
 typedef BfsCfg<64, 128, 14, 6, 7, Bf4::NPART_OUT, true, 2, 2> Bfs5;       // conv5: 7 samples (252 pixels) x 32 channels per workgroup
 typedef BfsCfg<128, 128, 6, 2, 32, Bfs5::NPART_OUT, false, 1, 2> Bfs6;  // conv6: 32 samples (128 pixels) x 32 channels per workgroup; NCHW out (fc)
 
@@ -1298,6 +1309,12 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ in, c
 namespace {
 constexpr size_t L_OUT[6] = {16u * 125 * 125, 32u * 61 * 61, 64u * 29 * 29, 64u * 14 * 14, 128u * 6 * 6, 128u * 2 * 2};
 constexpr int CNN_CHUNK_MAX = 1024;   // workspace is sized for this many agents per pass
+constexpr int CNN_SMALL_BATCH = 32;   // up to here a launch is a few latency chains: conv1 gives every tile its own workgroup
+// STRIVE_CNN_SMALL_BATCH=<n> moves the threshold (0: never), read per call: the tests and A/B runs exercise both chains in one process
+static int cnn_small_batch() {
+    const char* e = getenv("STRIVE_CNN_SMALL_BATCH");
+    return e ? atoi(e) : CNN_SMALL_BATCH;
+}
 // agents pushed through the layer stack together; STRIVE_CNN_CHUNK overrides (tuning knob, read once)
 static int cnn_chunk() {
     static int v = 0;
@@ -1310,7 +1327,15 @@ static int cnn_chunk() {
     return v;
 }
 constexpr int NPARTS[6] = {l1b::NPART, Bf2::NPART_OUT, Bf3::NPART_OUT, Bf4::NPART_OUT, Bfs5::NPART_OUT, Bfs6::NPART_OUT};
-constexpr int STAT_SLOTS = l1b::NPART + Bf2::NPART_OUT + Bf3::NPART_OUT + Bf4::NPART_OUT + Bfs5::NPART_OUT + Bfs6::NPART_OUT;
+// slots reserved per layer: the small-batch chain (Bf3s / Bf4s) writes twice as many partial moments for conv3 / conv4
+constexpr int NPMAX[6] = {l1b::NPART, Bf2::NPART_OUT, Bf3s::NPART_OUT, Bf4s::NPART_OUT, Bfs5::NPART_OUT, Bfs6::NPART_OUT};
+constexpr int STAT_SLOTS = NPMAX[0] + NPMAX[1] + NPMAX[2] + NPMAX[3] + NPMAX[4] + NPMAX[5];
+static_assert(Bf3s::NPART_OUT >= Bf3::NPART_OUT && Bf4s::NPART_OUT >= Bf4::NPART_OUT, "reserved statistics slots cover both chains");
+// the statistics block of `per` samples carved into the six layers' slot arrays (one carve-up for every user of the workspace)
+static inline void stat_slots(GNStats* stats, size_t per, GNStats* (&st)[6]) {
+    size_t off = 0;
+    for (int l = 0; l < 6; ++l) { st[l] = stats + off; off += per * NPMAX[l]; }
+}
 static_assert(Bfs5::NPART_IN == Bf4::NPART_OUT &&
               Bfs6::NPART_IN == Bfs5::NPART_OUT, "statistics slot chain");
 
@@ -1356,14 +1381,12 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         memset(&m, 0, sizeof(m));
         memset(&s, 0, sizeof(s));
     }
+    const int small_batch = cnn_small_batch();
     for (int n0 = 0; n0 < N; n0 += ch) {
         const int n = (N - n0) < ch ? (N - n0) : ch;
         GNStats* st[6];
-        {
-            size_t off = 0;
-            for (int l = 0; l < 6; ++l) { st[l] = stats + off; off += (size_t)ch * NPARTS[l]; }
-        }
-        dim3 g1(l1b::TILES_Y, 1, n);
+        stat_slots(stats, (size_t)ch, st);
+        dim3 g1(l1b::TILES_Y, n <= small_batch ? l1b::TILES_X : 1, n);
         if (map) {
             hipLaunchKernelGGL(conv1b_kernel<true>, g1, dim3(C1_NT), 0, stream, mp, pos + (size_t)n0 * 4, m, s, mapix + n0,
                                (const uint8_t*)nullptr, cnn->w1_frag, 1.0f / cnn->wscale[0], (const float*)cnn->b[0], act[0], st[0]);
@@ -1378,6 +1401,12 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
             launch_ws<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], n, cnn->xscale[1], cnn->wscale[1], stream);
         else
             launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], n, cnn->xscale[1], cnn->wscale[1], stream);
+        if (!keep_tail_activations && n <= small_batch) {
+            launch_bf6<Bf3s>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
+            launch_bf6<Bf4s>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, cnn->xscale[3], cnn->wscale[3], stream);
+            launch_cnn_tail(cnn, act[3], st[3], Bf4s::NPART_OUT, feat + (size_t)n0 * 64, n, stream);
+            continue;
+        }
         launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
         launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, cnn->xscale[3], cnn->wscale[3], stream);
         if (!keep_tail_activations) {
@@ -1426,10 +1455,7 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
     for (int l = 0; l < 6; ++l) act[l] = ar.take<float>((size_t)N * L_OUT[l]);
     GNStats* stats = ar.take<GNStats>((size_t)N * STAT_SLOTS);
     GNStats* st[6];
-    {
-        size_t off = 0;
-        for (int l = 0; l < 6; ++l) { st[l] = stats + off; off += (size_t)N * NPARTS[l]; }
-    }
+    stat_slots(stats, (size_t)N, st);
     Float4Host m, s;
     memcpy(m.v, pos_mean4_host, 16);
     memcpy(s.v, pos_std4_host, 16);

@@ -692,10 +692,7 @@ extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, co
         for (int l = 0; l < 6; ++l) act[l] = fa.take<float>((size_t)n * L_OUT[l]);
         GNStats* stats = fa.take<GNStats>((size_t)n * STAT_SLOTS);
         GNStats* st[6];
-        {
-            size_t off = 0;
-            for (int l = 0; l < 6; ++l) { st[l] = stats + off; off += (size_t)n * NPARTS[l]; }
-        }
+        stat_slots(stats, (size_t)n, st);
         {
             MomentsArgs ma;
             for (int l = 0; l < 6; ++l) { ma.st[l] = st[l]; ma.nparts[l] = NPARTS[l]; ma.count[l] = (double)L_OUT[l]; }

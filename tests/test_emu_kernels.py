@@ -79,7 +79,9 @@ def test_mlp_and_gnn(emu, sd):
         assert_close(out, g3[name + '_out'], 1e-4, 1e-5, name)
 
 
-def test_map_cnn_one_agent(emu, sd):
+def test_map_cnn_one_agent(emu, sd, monkeypatch):
+    """Both forward chains: batches of up to 32 samples give conv1 one workgroup per tile and conv3 / conv4 one 32-channel block per
+    workgroup (STRIVE_CNN_SMALL_BATCH=0 selects the throughput chain); the two agree to fp32 rounding of the GroupNorm moments."""
     raster, dx, frame, mapixes, lw = mg.g2_inputs()
     env = synth.SyntheticMapEnv(raster, dx)
     fr = frame[7:8].contiguous()
@@ -93,6 +95,12 @@ def test_map_cnn_one_agent(emu, sd):
     emu.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(fr), L.f4([0] * 4), L.f4([1] * 4), L.ptr(mi), 1, L.ptr(feat),
              L.ptr(ws), wsb, None)
     assert_close(feat, want, 1e-4, 1e-5, 'cnn')
+    monkeypatch.setenv('STRIVE_CNN_SMALL_BATCH', '0')
+    big = torch.zeros((1, 64))
+    emu.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(fr), L.f4([0] * 4), L.f4([1] * 4), L.ptr(mi), 1, L.ptr(big),
+             L.ptr(ws), wsb, None)
+    assert_close(big, want, 1e-4, 1e-5, 'cnn, throughput chain')
+    assert_close(big, feat, 2e-6, 2e-7, 'the two chains')
 
 
 def _rollout(emu, sd, sizes, FT, NS=1, ext=False, NC=2):
@@ -254,7 +262,7 @@ def test_rect_iou_kernel(emu):
     assert (want[ok] > 0.02).sum() > 10 and (want[ok] == 0).sum() > 10      # both outcomes are exercised
 
 
-def test_map_cnn_eight_agents(emu, sd):
+def test_map_cnn_eight_agents(emu, sd, monkeypatch):
     """Eight agents: conv5's workgroups take 7 samples each (one full, one with a single sample), conv6 / fc take 8 / 4."""
     raster, dx, frame, mapixes, lw = mg.g2_inputs()
     env = synth.SyntheticMapEnv(raster, dx)
@@ -276,7 +284,9 @@ def test_map_cnn_eight_agents(emu, sd):
              L.ptr(ws), wsb, None)
     assert_close(feat, want, 1e-4, 1e-5, 'cnn x8')
     # the fused tail (conv5 + conv6 + Linear in one kernel, what strive_map_cnn_fwd runs) against the separate kernels of the
-    # training recompute on the SAME conv4 output left in the workspace; 6 of the 8 poses = one full and one half workgroup
+    # training recompute on the SAME conv4 output left in the workspace; 6 of the 8 poses = one full and one half workgroup.  The
+    # separate kernels read the throughput chain's statistics slots, so this half runs that chain (the call above ran the small one).
+    monkeypatch.setenv('STRIVE_CNN_SMALL_BATCH', '0')
     for m_ in (8, 6):
         f_fused, f_sep = torch.zeros((m_, 64)), torch.zeros((m_, 64))
         args = (mp.ref(), cnn.ref())
