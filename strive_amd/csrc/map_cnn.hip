@@ -1382,6 +1382,8 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         memset(&s, 0, sizeof(s));
     }
     const int small_batch = cnn_small_batch();
+    int tail_s = 1;                                            // samples per workgroup of the fused tail in the small-batch chain
+    if (const char* e = getenv("STRIVE_CNN_TAIL_S")) tail_s = atoi(e);      // (A/B switch: 1, 2 or 4)
     for (int n0 = 0; n0 < N; n0 += ch) {
         const int n = (N - n0) < ch ? (N - n0) : ch;
         GNStats* st[6];
@@ -1404,7 +1406,7 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         if (!keep_tail_activations && n <= small_batch) {
             launch_bf6<Bf3s>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
             launch_bf6<Bf4s>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, cnn->xscale[3], cnn->wscale[3], stream);
-            launch_cnn_tail(cnn, act[3], st[3], Bf4s::NPART_OUT, feat + (size_t)n0 * 64, n, stream);
+            launch_cnn_tail(cnn, act[3], st[3], Bf4s::NPART_OUT, feat + (size_t)n0 * 64, n, stream, nullptr, tail_s);
             continue;
         }
         launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);

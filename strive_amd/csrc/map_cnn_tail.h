@@ -17,26 +17,42 @@
 #pragma once
 #include <type_traits>
 
+//
+// S = samples per workgroup is a template parameter: 4 is the throughput form; with S = 1 a batch of <= 32 samples (the one-scene
+// operating point of the shipped .cfg files) spreads over N workgroups instead of N / 4, each walking 2 pixel tiles per conv5 step
+// instead of 5 -- the kernel is a per-workgroup latency chain there (43 us for 8 samples as for 512).  Per sample the arithmetic
+// and the order of every sum are the same for every S: the results are bit-identical.
 namespace tail {
-constexpr int S = 4, NT = 256, NW = 4, NKS = 5;
+constexpr int NT = 256, NW = 4, NKS = 5;
 // conv5: 64 -> 128 channels, 14 x 14 -> 6 x 6
-constexpr int C5I = 64, IH5 = 14, OH5 = 6, PPS5 = OH5 * OH5, NPIX5 = S * PPS5, PT5 = (NPIX5 + 31) / 32;
-constexpr int HW5 = (IH5 + 1) / 2, HALF5 = HW5 * 16, ROW5 = 2 * HALF5, SAMPLE5 = IH5 * ROW5, PIECE5 = S * SAMPLE5, IN5_B = 2 * PIECE5;
-constexpr int NPASS5 = C5I / 8, UNITS5 = S * IH5 * IH5, UIT5 = (UNITS5 + NT - 1) / NT;
+constexpr int C5I = 64, IH5 = 14, OH5 = 6, PPS5 = OH5 * OH5;
+constexpr int HW5 = (IH5 + 1) / 2, HALF5 = HW5 * 16, ROW5 = 2 * HALF5, SAMPLE5 = IH5 * ROW5;
+constexpr int NPASS5 = C5I / 8;
 // conv6: 128 -> 128 channels, 6 x 6 -> 2 x 2; all 16 channel octets of the input resident
-constexpr int C6I = 128, IH6 = 6, OH6 = 2, PPS6 = OH6 * OH6, NPIX6 = S * PPS6;
-constexpr int HW6 = (IH6 + 1) / 2, HALF6 = HW6 * 16, ROW6 = 2 * HALF6, SAMPLE6 = IH6 * ROW6, PIECE6 = S * SAMPLE6, OCT6_B = 2 * PIECE6;
-constexpr int NPASS6 = C6I / 8, IN6_B = NPASS6 * OCT6_B;
+constexpr int C6I = 128, IH6 = 6, OH6 = 2, PPS6 = OH6 * OH6;
+constexpr int HW6 = (IH6 + 1) / 2, HALF6 = HW6 * 16, ROW6 = 2 * HALF6, SAMPLE6 = IH6 * ROW6;
+constexpr int NPASS6 = C6I / 8;
 constexpr int COUT = 128;
-// LDS: [tile: max(two conv5 input buffers, conv6 input)] [partials] [fc input] [fc partial sums] [gamma/beta x3] [moments x3]
-constexpr int TILE_B = (2 * IN5_B > IN6_B ? 2 * IN5_B : IN6_B);
-constexpr int PART_B = PT5 * 32 * NW * 2 * 8;                  // (pixel, wave, half) -> (sum, sum of squares)
-constexpr int Y_B = S * 512 * 4, FCP_B = 4 * S * 64 * 4;
-constexpr int GB_B = (C5I + COUT + COUT) * 8, MR_B = 3 * S * 8;
-constexpr size_t LDS_BYTES = (size_t)TILE_B + PART_B + Y_B + FCP_B + GB_B + MR_B + 64;
-static_assert(NPIX6 <= 32 && S == 4 && S == NW && PPS6 * NW * 2 <= 64, "conv6 fills (part of) one 32-pixel tile; the Linear layer is written for 4 samples");
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-static_assert(IN5_B % 16 == 0 && OCT6_B % 16 == 0 && TILE_B % 16 == 0, "16-byte fragment reads");
+constexpr int GB_B = (C5I + COUT + COUT) * 8;
+
+template <int S_>
+struct Cfg {
+    static constexpr int S = S_;
+    static constexpr int NPIX5 = S * PPS5, PT5 = (NPIX5 + 31) / 32;
+    static constexpr int PIECE5 = S * SAMPLE5, IN5_B = 2 * PIECE5;
+    static constexpr int UNITS5 = S * IH5 * IH5, UIT5 = (UNITS5 + NT - 1) / NT;
+    static constexpr int NPIX6 = S * PPS6;
+    static constexpr int PIECE6 = S * SAMPLE6, OCT6_B = 2 * PIECE6, IN6_B = NPASS6 * OCT6_B;
+    // LDS: [tile: max(two conv5 input buffers, conv6 input)] [partials] [fc input] [fc partial sums] [gamma/beta x3] [moments x3]
+    static constexpr int TILE_B = (2 * IN5_B > IN6_B ? 2 * IN5_B : IN6_B);
+    static constexpr int PART_B = PT5 * 32 * NW * 2 * 8;                  // (pixel, wave, half) -> (sum, sum of squares)
+    static constexpr int Y_B = S * 512 * 4, FCP_B = 4 * S * 64 * 4;
+    static constexpr int MR_B = 3 * S * 8;
+    static constexpr size_t LDS_BYTES = (size_t)TILE_B + PART_B + Y_B + FCP_B + GB_B + MR_B + 64;
+    static_assert(NPIX6 <= 32 && S >= 1 && S <= NW && PPS6 * NW * 2 <= 64, "conv6 fills (part of) one 32-pixel tile; wave s reduces sample s");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(IN5_B % 16 == 0 && OCT6_B % 16 == 0 && TILE_B % 16 == 0, "16-byte fragment reads");
+};
 }  // namespace tail
 
 // window offset of matrix step t for lane half h (3x3 tap order of conv_bf6_kernel / conv_bf6s_kernel)
@@ -86,9 +102,12 @@ struct TailArgs {
 };
 
 // TIMING: clock64 stamps of the phases summed over workgroups into `tprof` (measurement hook only)
-template <bool TIMING = false>
+template <int S_, bool TIMING = false>
 __global__ __launch_bounds__(tail::NT, 1) void cnn_tail_kernel(TailArgs A, unsigned long long* __restrict__ tprof = nullptr) {
     using namespace tail;
+    using C = tail::Cfg<S_>;
+    constexpr int S = C::S, NPIX5 = C::NPIX5, PT5 = C::PT5, PIECE5 = C::PIECE5, IN5_B = C::IN5_B, UNITS5 = C::UNITS5, UIT5 = C::UIT5;
+    constexpr int NPIX6 = C::NPIX6, PIECE6 = C::PIECE6, OCT6_B = C::OCT6_B, TILE_B = C::TILE_B, PART_B = C::PART_B;
     long long tstamp[8];
     int nstamp = 0;
     auto stamp = [&]() { if (TIMING) tstamp[nstamp++] = clock64(); };
@@ -294,7 +313,7 @@ __global__ __launch_bounds__(tail::NT, 1) void cnn_tail_kernel(TailArgs A, unsig
         *o = make_float2(valid ? fsum : 0.f, valid ? fsq : 0.f);
     }
     __syncthreads();              // (also: every wave is done with the conv5 input buffers)
-    {   // wave = sample (S == NW): lanes stride over its partials, then a shuffle tree -- a fixed order, like everything else
+    if (wave < S) {   // wave = sample: lanes stride over its partials, then a shuffle tree -- a fixed order, like everything else
         double a = 0.0, b = 0.0;
         const float2* p = reinterpret_cast<const float2*>(s_part) + (size_t)wave * PPS5 * NW * 2;
         for (int q = lane; q < PPS5 * NW * 2; q += 64) { a += (double)p[q].x; b += (double)p[q].y; }
@@ -396,7 +415,7 @@ __global__ __launch_bounds__(tail::NT, 1) void cnn_tail_kernel(TailArgs A, unsig
         float2* o = reinterpret_cast<float2*>(s_part) + ((size_t)j * NW + wave) * 2 + h;
         *o = make_float2(valid ? fsum : 0.f, valid ? fsq : 0.f);
         __syncthreads();
-        {
+        if (wave < S) {
             double sa = 0.0, sb = 0.0;
             const float2* p = reinterpret_cast<const float2*>(s_part) + (size_t)wave * PPS6 * NW * 2;
             if (lane < PPS6 * NW * 2) { sa = (double)p[lane].x; sb = (double)p[lane].y; }
@@ -431,7 +450,9 @@ __global__ __launch_bounds__(tail::NT, 1) void cnn_tail_kernel(TailArgs A, unsig
     stamp();
     // ================= Linear(512 -> 64): thread = (output o, k quarter), 4 samples (as fc_kernel) =================
     const int o = tid & 63, kq = tid >> 6;
-    float fc[S] = {0.f, 0.f, 0.f, 0.f};
+    float fc[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) fc[s] = 0.f;
 #pragma unroll 1
     for (int kb = 0; kb < 4; ++kb) {
         const int k0 = kq * 128 + kb * 32;
@@ -454,7 +475,7 @@ __global__ __launch_bounds__(tail::NT, 1) void cnn_tail_kernel(TailArgs A, unsig
     for (int s = 0; s < S; ++s) s_p[(kq * S + s) * 64 + o] = fc[s];
     __syncthreads();
     const int s = tid >> 6;
-    if (n0 + s < N)
+    if (s < S && n0 + s < N)
         A.feat[(size_t)(n0 + s) * 64 + o] = ((s_p[(0 * S + s) * 64 + o] + s_p[(1 * S + s) * 64 + o]) +
                                              (s_p[(2 * S + s) * 64 + o] + s_p[(3 * S + s) * 64 + o])) + A.fc_b[o];
     stamp();
@@ -466,8 +487,24 @@ __global__ __launch_bounds__(tail::NT, 1) void cnn_tail_kernel(TailArgs A, unsig
     }
 }
 
+template <int S_>
+static void launch_cnn_tail_s(const TailArgs& a, int N, hipStream_t stream, unsigned long long* tprof) {
+    using C = tail::Cfg<S_>;
+    static PerDeviceOnce once;
+    const int dev_ = once.device();
+    if (!once.is_done(dev_)) {
+        (void)hipFuncSetAttribute((const void*)cnn_tail_kernel<S_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)cnn_tail_kernel<S_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+        once.set_done(dev_);
+    }
+    const dim3 grid((N + S_ - 1) / S_);
+    if (tprof) hipLaunchKernelGGL((cnn_tail_kernel<S_, true>), grid, dim3(tail::NT), C::LDS_BYTES, stream, a, tprof);
+    else hipLaunchKernelGGL((cnn_tail_kernel<S_, false>), grid, dim3(tail::NT), C::LDS_BYTES, stream, a, (unsigned long long*)nullptr);
+}
+
+// samples_per_wg: 4 = throughput form; 1 (or 2) for small batches -- see the note on S above
 static int launch_cnn_tail(const StriveCNN* cnn, const float* act4, const GNStats* st4, int npart_in, float* feat, int N,
-                           hipStream_t stream, unsigned long long* tprof = nullptr) {
+                           hipStream_t stream, unsigned long long* tprof = nullptr, int samples_per_wg = 4) {
     TailArgs a;
     a.in = act4; a.st_in = st4; a.npart_in = npart_in;
     a.g4 = cnn->gn_g[3]; a.b4 = cnn->gn_b[3];
@@ -477,15 +514,10 @@ static int launch_cnn_tail(const StriveCNN* cnn, const float* act4, const GNStat
     a.xs5 = cnn->xscale[4]; a.un5 = 1.0f / (cnn->xscale[4] * cnn->wscale[4]);
     a.xs6 = cnn->xscale[5]; a.un6 = 1.0f / (cnn->xscale[5] * cnn->wscale[5]);
     a.feat = feat; a.N = N;
-    static PerDeviceOnce once;
-    const int dev_ = once.device();
-    if (!once.is_done(dev_)) {
-        (void)hipFuncSetAttribute((const void*)cnn_tail_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)cnn_tail_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail::LDS_BYTES);
-        once.set_done(dev_);
+    switch (samples_per_wg) {
+        case 1: launch_cnn_tail_s<1>(a, N, stream, tprof); break;
+        case 2: launch_cnn_tail_s<2>(a, N, stream, tprof); break;
+        default: launch_cnn_tail_s<4>(a, N, stream, tprof); break;
     }
-    const dim3 grid((N + tail::S - 1) / tail::S);
-    if (tprof) hipLaunchKernelGGL(cnn_tail_kernel<true>, grid, dim3(tail::NT), tail::LDS_BYTES, stream, a, tprof);
-    else hipLaunchKernelGGL(cnn_tail_kernel<false>, grid, dim3(tail::NT), tail::LDS_BYTES, stream, a, (unsigned long long*)nullptr);
     return 0;
 }

@@ -283,6 +283,14 @@ def test_map_cnn_eight_agents(emu, sd, monkeypatch):
     emu.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(fr), L.f4([0] * 4), L.f4([1] * 4), L.ptr(mi), n, L.ptr(feat),
              L.ptr(ws), wsb, None)
     assert_close(feat, want, 1e-4, 1e-5, 'cnn x8')
+    # samples per workgroup of the fused tail in the small-batch chain (1 by default): per sample the same sums in the same order
+    for tail_s, m_ in (('2', 8), ('4', 8), ('2', 5)):
+        monkeypatch.setenv('STRIVE_CNN_TAIL_S', tail_s)
+        other = torch.zeros((m_, 64))
+        emu.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(fr[:m_].contiguous()), L.f4([0] * 4), L.f4([1] * 4),
+                 L.ptr(mi[:m_].contiguous()), m_, L.ptr(other), L.ptr(ws), wsb, None)
+        assert torch.equal(other, feat[:m_]), 'tail with %s samples per workgroup' % tail_s
+    monkeypatch.delenv('STRIVE_CNN_TAIL_S')
     # the fused tail (conv5 + conv6 + Linear in one kernel, what strive_map_cnn_fwd runs) against the separate kernels of the
     # training recompute on the SAME conv4 output left in the workspace; 6 of the 8 poses = one full and one half workgroup.  The
     # separate kernels read the throughput chain's statistics slots, so this half runs that chain (the call above ran the small one).
