@@ -503,6 +503,63 @@ def time_dominant_kernel(m, env, g, mi, emb, device, reps=20):
     return rec
 
 
+# the data-gradient kernels of the CNN backward (csrc/map_cnn_bwd_mfma.h, dgrad_mfma_kernel<L>, L = 1..5 = d conv2 .. d conv6 input):
+# (Cin, Cout, k, IH, OH) per layer; algorithmic FLOPs per sample 2 Cin Cout k^2 OH^2, bytes = dy read once + d input written once
+DGRAD_SHAPES = {1: (16, 32, 5, 125, 61), 2: (32, 64, 5, 61, 29), 3: (64, 64, 3, 29, 14), 4: (64, 128, 3, 14, 6), 5: (128, 128, 3, 6, 2)}
+PEAK_BF16_MFMA_TFLOPS = 2516.0     # same guide: bf16 dense = f16 dense
+
+
+def time_train_dominant_kernel(m, env, g, mi, device, reps=20):
+    """The training step's largest single launch (profiles/r0N_train_kernel_stats.txt): the data gradient of conv2,
+    cnnbwd::dgrad_mfma_kernel<1>, on one backward chunk of 256 samples -- the size the rollout's CNN backward launches (64 agents x
+    11 re-encoded steps in chunks of 256).  strive_map_cnn_bwd fills the workspace once, then strive_map_cnn_bwd_bench_dgrad times
+    every data-gradient kernel alone (events on the launching stream).  Operands are two bf16 pieces, three products per fp32
+    product; bytes = the output gradient read once + the input gradient written once."""
+    from strive_amd import ops, _lib as L
+    lib = L.get_lib()
+    N = 256
+    NA = g.past.shape[0]
+    idx = torch.arange(N, device=device) % NA
+    pos = g.past[idx, -1, :4].contiguous()
+    mapix = mi[g.batch][idx].to(torch.int32).contiguous()
+    mp = ops._map_pack(env, device)
+    cnn = ops.cnn_pack(m)
+    nm = m.normalizer
+    mean4, std4 = L.f4(nm.mean_vals[:4].tolist()), L.f4(nm.std_vals[:4].tolist())
+    st = L.stream_ptr(pos)
+    gen = torch.Generator(device='cpu').manual_seed(7)
+    d_feat = torch.randn((N, 64), generator=gen).to(device)
+    dp = torch.zeros(lib.query('strive_map_cnn_param_count'), device=device)
+    wsb = lib.query('strive_map_cnn_bwd_workspace_bytes', N)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=device)
+    lib.call('strive_map_cnn_bwd', mp.ref(), cnn.ref(), L.ptr(pos), mean4, std4, L.ptr(mapix), N, L.ptr(d_feat), L.ptr(dp),
+             L.ptr(ws), wsb, st)
+    torch.cuda.synchronize()
+    layers = sorted(DGRAD_SHAPES)
+    times = {l: _event_time(lambda: lib.call('strive_map_cnn_bwd_bench_dgrad', l, N, L.ptr(ws), wsb, st), reps) for l in layers}
+    dom = max(layers, key=lambda l: times[l])
+    cin, cout, k, ih, oh = DGRAD_SHAPES[dom]
+    flops = 2.0 * cin * cout * k * k * oh * oh * N
+    by = (cout * oh * oh + cin * ih * ih) * 4 * N
+    issued = 3.0 * flops / times[dom] / 1e12
+    gbs = by / times[dom] / 1e9
+    f_mfma, f_hbm = issued / PEAK_BF16_MFMA_TFLOPS, gbs / PEAK_HBM_GBS
+    rec = {'kernel': 'cnnbwd::dgrad_mfma_kernel<%d>' % dom, 'launch_us': round(times[dom] * 1e6, 2), 'samples_per_launch': N,
+           'traffic': None, 'algorithmic_tflops': round(flops / times[dom] / 1e12, 3),
+           'mfma': {'issued_tflops': round(issued, 3), 'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': round(f_mfma, 4), 'dtype': 'bf16',
+                    'products_per_fp32_product': 3},
+           'hbm': {'algorithmic_GBps': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'frac': round(f_hbm, 4), 'algorithmic_bytes': by},
+           'all_dgrad_layers_us': {str(l): round(times[l] * 1e6, 2) for l in layers},
+           'note': 'largest single launch of the training step; the step itself is a flat profile (no kernel above 7 % of the GPU '
+                   'time, profiles/r0N_train_kernel_stats.txt)'}
+    if f_hbm >= f_mfma:
+        rec.update({'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(f_hbm, 4)})
+    else:
+        rec.update({'bound': 'mfma', 'achieved': round(issued, 3), 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(f_mfma, 4)})
+    return rec
+
+
 def time_bandwidth_kernels(m, env, g, mi, device, reps=20):
     """Achieved GB/s of the byte-bound kernels outside the CNN: the stand-alone raster crop, the
     vehicle-collision penalty and the off-road collision point, each on this batch's own sizes."""
@@ -935,6 +992,12 @@ def main():
                     'traffic_over_survey_bytes': None if any(t is None for t in tr) else round(sum(tr) / napl / (268 * 1024), 2),
                     'traffic_source': _measured_traffic(CONV_NAMES[0], with_source=True)[1]}
             except Exception as e:      # keep the headline number, but the run fails
+                out['roofline'] = {'error': repr(e)}
+                failed = True
+        if not args.no_roofline and args.workload == 'train':
+            try:
+                out['roofline'] = time_train_dominant_kernel(m, env, g, mi, device)
+            except Exception as e:
                 out['roofline'] = {'error': repr(e)}
                 failed = True
         if world == 1 and not args.no_cpu_baseline and args.workload not in ('train', 'sample', 'full'):

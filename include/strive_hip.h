@@ -456,6 +456,12 @@ int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, const float* 
                        const float* pos_std4_host, const int32_t* mapix, int32_t N, const float* d_feat, float* d_params,
                        void* ws, size_t ws_bytes, strive_stream_t stream);
 
+/* Measurement hook for bench.py's training line (the counterpart of strive_map_cnn_bench_layer): launch ONE kernel of the CNN
+ * backward -- the data gradient of conv layer `layer` (1..5: d conv2 .. d conv6 input) -- on the buffers a previous
+ * strive_map_cnn_bwd over the same N (<= 256, one backward chunk) samples left in `ws`, so it can be timed with events on the
+ * launching stream.  It overwrites the gradient buffer of layer - 1 in `ws` (scratch of the finished call). */
+int strive_map_cnn_bwd_bench_dgrad(int32_t layer, int32_t N, void* ws, size_t ws_bytes, strive_stream_t stream);
+
 size_t strive_rollout_train_workspace_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT);
 
 /* autoregressive_decoder under autograd with parameter gradients (reference src/models/traffic_model.py:589-704 as used

@@ -170,6 +170,7 @@ PROTOTYPES = {
     'strive_gnn_bwd': (C.c_int, [C.POINTER(StriveGNN), C.POINTER(StriveScenes), P, P, P, P, P, P, P, SZ, P]),
     'strive_map_cnn_bwd_workspace_bytes': (SZ, [I]),
     'strive_map_cnn_bwd': (C.c_int, [C.POINTER(StriveMap), C.POINTER(StriveCNN), P, F4, F4, P, I, P, P, P, SZ, P]),
+    'strive_map_cnn_bwd_bench_dgrad': (C.c_int, [I, I, P, SZ, P]),
     'strive_rollout_train_workspace_bytes': (SZ, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), I]),
     'strive_rollout_bwd_train': (C.c_int, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), P, P, P, P, P, I, P, P, P, P, P, P, P,
                                            P, SZ, P, SZ, P]),

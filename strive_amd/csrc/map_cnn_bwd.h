@@ -645,6 +645,48 @@ extern "C" size_t strive_map_cnn_bwd_workspace_bytes(int32_t N) {
     return b + 1024;
 }
 
+namespace cnnbwd {
+// the workspace of one backward chunk of `ch` samples (strive_map_cnn_bwd_workspace_bytes lists the same blocks)
+struct BwdArena {
+    char* fwd_ws;
+    size_t fwd_bytes;
+    float* G[6];
+    uint8_t* crop;
+    float2* mr;
+    double* S;
+    float* feat;
+    uint4* dfrag;
+    float* wpart;
+    bool ok;
+};
+static inline BwdArena carve_bwd(void* ws, size_t ws_bytes, int ch) {
+    BwdArena a;
+    StriveArena ar(ws, ws_bytes);
+    a.fwd_bytes = strive_map_cnn_workspace_bytes(ch);
+    a.fwd_ws = ar.take<char>(a.fwd_bytes);
+    for (int l = 0; l < 6; ++l) a.G[l] = ar.take<float>((size_t)ch * L_OUT[l]);
+    a.crop = ar.take<uint8_t>((size_t)ch * 4 * 256 * 256);
+    a.mr = ar.take<float2>((size_t)ch * 6);
+    a.S = ar.take<double>((size_t)ch * 6 * 2);
+    a.feat = ar.take<float>((size_t)ch * 64);
+    a.dfrag = ar.take<uint4>(dgrad_frag_total());
+    a.wpart = ar.take<float>(wgrad_partial_floats());
+    a.ok = ar.ok();
+    return a;
+}
+}  // namespace cnnbwd
+
+extern "C" int strive_map_cnn_bwd_bench_dgrad(int32_t layer, int32_t N, void* ws, size_t ws_bytes, strive_stream_t stream_) {
+    using namespace cnnbwd;
+    STRIVE_CHECK_ARG(ws && layer >= 1 && layer <= 5 && N > 0 && N <= BWD_CHUNK, "bad layer / N");
+    STRIVE_CHECK_ARG(ws_bytes >= strive_map_cnn_bwd_workspace_bytes(N), "workspace too small");
+    const BwdArena a = carve_bwd(ws, ws_bytes, N);
+    STRIVE_CHECK_ARG(a.ok, "workspace arena overflow");
+    launch_dgrad_mfma_layer(layer, a.G[layer], a.dfrag, a.G[layer - 1], N, (hipStream_t)stream_);
+    STRIVE_CHECK_LAUNCH();
+    return 0;
+}
+
 // d_feat (N,64) -> CNN weight gradients at the N poses `pos`, ACCUMULATED into d_params (flat, see strive_hip.h).
 extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, const float* pos, const float* pos_mean4_host,
                                   const float* pos_std4_host, const int32_t* mapix, int32_t N, const float* d_feat,
@@ -657,18 +699,17 @@ extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, co
     STRIVE_CHECK_ARG(ws_bytes >= strive_map_cnn_bwd_workspace_bytes(N), "workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
     const int ch = N < BWD_CHUNK ? N : BWD_CHUNK;
-    StriveArena ar(ws, ws_bytes);
-    const size_t fwd_bytes = strive_map_cnn_workspace_bytes(ch);
-    char* fwd_ws = ar.take<char>(fwd_bytes);
-    float* G[6];
-    for (int l = 0; l < 6; ++l) G[l] = ar.take<float>((size_t)ch * L_OUT[l]);
-    uint8_t* crop = ar.take<uint8_t>((size_t)ch * 4 * 256 * 256);
-    float2* mr = ar.take<float2>((size_t)ch * 6);
-    double* S = ar.take<double>((size_t)ch * 6 * 2);
-    float* feat = ar.take<float>((size_t)ch * 64);
-    uint4* dfrag = ar.take<uint4>(dgrad_frag_total());
-    float* wpart = ar.take<float>(wgrad_partial_floats());
-    STRIVE_CHECK_ARG(ar.ok(), "workspace arena overflow");
+    const BwdArena arena = carve_bwd(ws, ws_bytes, ch);
+    STRIVE_CHECK_ARG(arena.ok, "workspace arena overflow");
+    char* fwd_ws = arena.fwd_ws;
+    const size_t fwd_bytes = arena.fwd_bytes;
+    float* const* G = arena.G;
+    uint8_t* crop = arena.crop;
+    float2* mr = arena.mr;
+    double* S = arena.S;
+    float* feat = arena.feat;
+    uint4* dfrag = arena.dfrag;
+    float* wpart = arena.wpart;
     static const bool dgrad_igemm = getenv("STRIVE_DGRAD_IGEMM") != nullptr;     // A/B switch: the fp32 implicit-GEMM form
     if (!dgrad_igemm) {
         DgradPackArgs pa;

@@ -163,6 +163,43 @@ def test_map_cnn_vs_oracle(model):
     assert torch.equal(got, got2), 'CNN must be bitwise reproducible'
 
 
+def test_map_cnn_small_batch_chain(model, monkeypatch):
+    """Batches of <= 32 samples (the one-scene operating point of the shipped .cfg files) run conv1 with one tile per workgroup,
+    conv3 / conv4 with one 32-channel block per workgroup and the fused tail with one sample per workgroup
+    (csrc/map_cnn.hip: CNN_SMALL_BATCH).  Same products in the same order: against the throughput chain only the float64
+    GroupNorm partial sums are grouped differently (conv3 / conv4); the tail is bit-identical for 1, 2 or 4 samples per workgroup."""
+    m, sd = model
+    raster, dx, frame, mapixes, lw = mg.g2_inputs()
+    env = dev_env(raster, dx)
+    nmax = 33
+    fr = np.zeros((nmax, 4))
+    fr[:, 0] = synth.counter_uniform((nmax,), 'gs/x', 20.0, 236.0)
+    fr[:, 1] = synth.counter_uniform((nmax,), 'gs/y', 20.0, 236.0)
+    ang = synth.counter_uniform((nmax,), 'gs/h', -np.pi, np.pi)
+    fr[:, 2], fr[:, 3] = np.cos(ang), np.sin(ang)
+    scale = torch.tensor([15., 15., 1., 1.])
+    pos_n = (synth.f32(fr) / scale).to(DEV)
+    mi = torch.tensor([i % 2 for i in range(nmax)]).to(DEV)
+    want = om.map_cnn(sd, mapenv.map_crop(raster, dx, pos_n.cpu() * scale, mi.cpu(), env.bounds).float())
+
+    def run(n):
+        return ops.encode_map(m, pos_n[:n].contiguous(), torch.arange(n).to(DEV), mi[:n].contiguous(), env).clone()
+    for n in (1, 8, 31, 32, 33):
+        monkeypatch.delenv('STRIVE_CNN_SMALL_BATCH', raising=False)
+        monkeypatch.delenv('STRIVE_CNN_TAIL_S', raising=False)
+        got = run(n)
+        assert_close(got, want[:n], RT, AT, 'map cnn, %d samples' % n)
+        assert torch.equal(got, run(n)), 'bitwise reproducible (%d samples)' % n
+        for tail_s in ('2', '4'):
+            monkeypatch.setenv('STRIVE_CNN_TAIL_S', tail_s)
+            assert torch.equal(got, run(n)), 'tail with %s samples per workgroup (%d samples)' % (tail_s, n)
+        monkeypatch.setenv('STRIVE_CNN_SMALL_BATCH', '0')
+        big = run(n)
+        assert_close(got, big, 1e-5, 1e-6, 'small-batch chain vs throughput chain, %d samples' % n)
+        if n > 32:
+            assert torch.equal(got, big)
+
+
 def test_map_cnn_full_occupancy_reproducible(model):
     """Regression: with > 32 agents two conv1 workgroups share a CU.  A build with auto-formed v_pk_add_f32 lost
     lanes 48-63 of some gathers there; the fused crop+CNN must equal

@@ -303,3 +303,43 @@ def test_map_cnn_backward_chunks_add_up():
         assert rel < 2e-5, 'map CNN gradient %s: chunked call differs from the sum of its parts by %.3g' % (k, rel)
     print('worst relative difference: %.3g' % worst)
 
+
+
+@pytest.mark.gpu
+def test_cnn_backward_measurement_hook():
+    """strive_map_cnn_bwd_bench_dgrad (bench.py's training-line roofline): launches on the workspace of a finished backward call,
+    refuses layers without a data gradient and more than one chunk, and leaves the next real backward unchanged."""
+    from strive_amd import ops, _lib as L
+    DEV = 'cuda:0'
+    m, sd = product_model(device=DEV)
+    raster, dx = synth.make_raster(1024, 1024, M=2)
+    env = synth.SyntheticMapEnv(raster, dx).to(DEV)
+    n = 40
+    fr = np.zeros((n, 4))
+    fr[:, 0] = synth.counter_uniform((n,), 'hook/x', 20.0, 236.0)
+    fr[:, 1] = synth.counter_uniform((n,), 'hook/y', 20.0, 236.0)
+    fr[:, 2] = 1.0
+    pos = (synth.f32(fr) / torch.tensor([15., 15., 1., 1.])).to(DEV).contiguous()
+    mi = torch.zeros(n, dtype=torch.long, device=DEV)
+    d_feat = synth.f32(synth.counter_uniform((n, 64), 'hook/df', -1.0, 1.0)).to(DEV)
+
+    def grads():
+        for p in m.parameters():
+            p.requires_grad_(True)
+            p.grad = None
+        with torch.enable_grad(), ops.weight_grad_mode(True):
+            ops.encode_map(m, pos, torch.arange(n).to(DEV), mi, env).backward(d_feat)
+        return torch.cat([p.grad.reshape(-1) for k, p in m.named_parameters() if k.startswith('map_')]).clone()
+    first = grads()
+    lib = L.get_lib()
+    wsb = lib.query('strive_map_cnn_bwd_workspace_bytes', n)
+    ws = ops._workspace(torch.device(DEV), wsb, 'cnn_bwd')
+    st = L.stream_ptr(pos)
+    for layer in (5, 4, 3, 2, 1):
+        lib.call('strive_map_cnn_bwd_bench_dgrad', layer, n, L.ptr(ws), ws.numel(), st)
+    torch.cuda.synchronize()
+    for layer, nn in ((0, n), (6, n), (1, 257)):
+        with pytest.raises(L.StriveHipError):
+            lib.call('strive_map_cnn_bwd_bench_dgrad', layer, nn, L.ptr(ws), ws.numel(), st)
+    again = grads()
+    assert float((again - first).norm() / first.norm()) < 1e-6
