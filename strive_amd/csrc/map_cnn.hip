@@ -1186,12 +1186,13 @@ typedef BfCfg<16, 32, 5, 125, 61, l1b::NPART, true, 2, 3> Bf2;     // conv2: oct
 typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, true, 2, 2, false, 2> Bf3;   // conv3: octet-planar in and out; both 32-channel blocks from one staging
 // conv4 (3x3, 29 -> 14): the whole 14 x 14 image is one workgroup tile of 16 x 16 (pixel tiles of 2 rows x 16 columns);
 typedef BfCfg<64, 64, 3, 29, 14, Bf3::NPART_OUT, true, 2, 2, true, 2> Bf4;
-// small batches (<= CNN_SMALL_BATCH samples): one 32-channel block per workgroup for conv3 / conv4 -- twice the workgroups, half
-// the matrix steps per workgroup: a launch is then a few per-workgroup latency chains, not throughput (8 samples: conv3 23.7 ->
-// ~17 us, conv4 26.2 -> ~19 us, profiles/r04_ab_cnn_small_batch.txt).  Same products in the same order per output; the GroupNorm
-// moments are float64 partial sums per (tile, block) added in a fixed order, so the normalisation agrees to 1e-16.
-typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, true, 2, 2, false, 1> Bf3s;
-typedef BfCfg<64, 64, 3, 29, 14, Bf3s::NPART_OUT, true, 2, 2, true, 1> Bf4s;
+// small batches (<= CNN_SMALL_BATCH samples): one 32-channel block per workgroup and one pixel tile per wave for conv3 / conv4 --
+// four times the workgroups, a quarter of the matrix work per step in each: a launch is then a few per-workgroup latency chains,
+// not throughput (8 samples: conv3 23.7 -> 12.4 us, conv4 26.2 -> 15.7 us, profiles/r04_ab_cnn_small_batch.txt).  Same products
+// in the same order per output; the GroupNorm moments are float64 partial sums per (tile, block) added in a fixed order, so the
+// normalisation agrees to 1e-16.
+typedef BfCfg<32, 64, 5, 61, 29, Bf2::NPART_OUT, true, 1, 2, false, 1> Bf3s;
+typedef BfCfg<64, 64, 3, 29, 14, Bf3s::NPART_OUT, true, 1, 2, true, 1> Bf4s;
 typedef BfsCfg<64, 128, 14, 6, 7, Bf4::NPART_OUT, true, 2, 2> Bfs5;       // conv5: 7 samples (252 pixels) x 32 channels per workgroup
 typedef BfsCfg<128, 128, 6, 2, 32, Bfs5::NPART_OUT, false, 1, 2> Bfs6;  // conv6: 32 samples (128 pixels) x 32 channels per workgroup; NCHW out (fc)
 
@@ -1327,7 +1328,7 @@ static int cnn_chunk() {
     return v;
 }
 constexpr int NPARTS[6] = {l1b::NPART, Bf2::NPART_OUT, Bf3::NPART_OUT, Bf4::NPART_OUT, Bfs5::NPART_OUT, Bfs6::NPART_OUT};
-// slots reserved per layer: the small-batch chain (Bf3s / Bf4s) writes twice as many partial moments for conv3 / conv4
+// slots reserved per layer: the small-batch chain (Bf3s / Bf4s) writes four times as many partial moments for conv3 / conv4
 constexpr int NPMAX[6] = {l1b::NPART, Bf2::NPART_OUT, Bf3s::NPART_OUT, Bf4s::NPART_OUT, Bfs5::NPART_OUT, Bfs6::NPART_OUT};
 constexpr int STAT_SLOTS = NPMAX[0] + NPMAX[1] + NPMAX[2] + NPMAX[3] + NPMAX[4] + NPMAX[5];
 static_assert(Bf3s::NPART_OUT >= Bf3::NPART_OUT && Bf4s::NPART_OUT >= Bf4::NPART_OUT, "reserved statistics slots cover both chains");
