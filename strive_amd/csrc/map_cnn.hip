@@ -1310,7 +1310,12 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ in, c
 namespace {
 constexpr size_t L_OUT[6] = {16u * 125 * 125, 32u * 61 * 61, 64u * 29 * 29, 64u * 14 * 14, 128u * 6 * 6, 128u * 2 * 2};
 constexpr int CNN_CHUNK_MAX = 1024;   // workspace is sized for this many agents per pass
-constexpr int CNN_SMALL_BATCH = 32;   // up to here a launch is a few latency chains: conv1 gives every tile its own workgroup
+// up to here a launch is a few latency chains: conv1 gives every tile its own workgroup, conv3 / conv4 run Bf3s / Bf4s.  Measured
+// (profiles/r04_ab_cnn_small_batch.txt, refine closures): 48 samples -9.5 %, 64 -5.7 %, 96 -4.5 %, 128 -0.6 %, 192 +3 %.
+constexpr int CNN_SMALL_BATCH = 96;
+// the fused tail takes ONE sample per workgroup up to here (bit-identical either way): -0.2 ms per closure at 192 samples,
+// -0.12 at 256, nothing at 512 (where the four-sample form keeps the weight streams per CU lower)
+constexpr int CNN_TAIL_ONE_SAMPLE = 256;
 // STRIVE_CNN_SMALL_BATCH=<n> moves the threshold (0: never), read per call: the tests and A/B runs exercise both chains in one process
 static int cnn_small_batch() {
     const char* e = getenv("STRIVE_CNN_SMALL_BATCH");
@@ -1383,13 +1388,14 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         memset(&s, 0, sizeof(s));
     }
     const int small_batch = cnn_small_batch();
-    int tail_s = 1;                                            // samples per workgroup of the fused tail in the small-batch chain
-    if (const char* e = getenv("STRIVE_CNN_TAIL_S")) tail_s = atoi(e);      // (A/B switch: 1, 2 or 4)
+    int tail_force = 0;                                        // samples per workgroup of the fused tail (A/B switch: 1, 2 or 4)
+    if (const char* e = getenv("STRIVE_CNN_TAIL_S")) tail_force = atoi(e);
     for (int n0 = 0; n0 < N; n0 += ch) {
         const int n = (N - n0) < ch ? (N - n0) : ch;
         GNStats* st[6];
         stat_slots(stats, (size_t)ch, st);
         dim3 g1(l1b::TILES_Y, n <= small_batch ? l1b::TILES_X : 1, n);
+        const int tail_s = tail_force ? tail_force : (n <= CNN_TAIL_ONE_SAMPLE ? 1 : 4);
         if (map) {
             hipLaunchKernelGGL(conv1b_kernel<true>, g1, dim3(C1_NT), 0, stream, mp, pos + (size_t)n0 * 4, m, s, mapix + n0,
                                (const uint8_t*)nullptr, cnn->w1_frag, 1.0f / cnn->wscale[0], (const float*)cnn->b[0], act[0], st[0]);
@@ -1413,7 +1419,7 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
         launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, cnn->xscale[3], cnn->wscale[3], stream);
         if (!keep_tail_activations) {
-            launch_cnn_tail(cnn, act[3], st[3], NPARTS[3], feat + (size_t)n0 * 64, n, stream);
+            launch_cnn_tail(cnn, act[3], st[3], NPARTS[3], feat + (size_t)n0 * 64, n, stream, nullptr, tail_s);
             continue;
         }
         launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], n, cnn->xscale[4], cnn->wscale[4], stream);

@@ -164,14 +164,15 @@ def test_map_cnn_vs_oracle(model):
 
 
 def test_map_cnn_small_batch_chain(model, monkeypatch):
-    """Batches of <= 32 samples (the one-scene operating point of the shipped .cfg files) run conv1 with one tile per workgroup,
-    conv3 / conv4 with one 32-channel block per workgroup and the fused tail with one sample per workgroup
-    (csrc/map_cnn.hip: CNN_SMALL_BATCH).  Same products in the same order: against the throughput chain only the float64
-    GroupNorm partial sums are grouped differently (conv3 / conv4); the tail is bit-identical for 1, 2 or 4 samples per workgroup."""
+    """Batches of <= 96 samples (the one-scene operating point of the shipped .cfg files and a few scenes around it) run conv1 with
+    one tile per workgroup and conv3 / conv4 with one 32-channel block per workgroup and one pixel tile per wave (csrc/map_cnn.hip:
+    CNN_SMALL_BATCH); up to 256 samples the fused tail takes one sample per workgroup.  Same products in the same order: against the
+    throughput chain only the float64 GroupNorm partial sums are grouped differently (conv3 / conv4); the tail is bit-identical for
+    1, 2 or 4 samples per workgroup."""
     m, sd = model
     raster, dx, frame, mapixes, lw = mg.g2_inputs()
     env = dev_env(raster, dx)
-    nmax = 33
+    nmax = 97
     fr = np.zeros((nmax, 4))
     fr[:, 0] = synth.counter_uniform((nmax,), 'gs/x', 20.0, 236.0)
     fr[:, 1] = synth.counter_uniform((nmax,), 'gs/y', 20.0, 236.0)
@@ -184,7 +185,7 @@ def test_map_cnn_small_batch_chain(model, monkeypatch):
 
     def run(n):
         return ops.encode_map(m, pos_n[:n].contiguous(), torch.arange(n).to(DEV), mi[:n].contiguous(), env).clone()
-    for n in (1, 8, 31, 32, 33):
+    for n in (1, 8, 33, 96, 97):
         monkeypatch.delenv('STRIVE_CNN_SMALL_BATCH', raising=False)
         monkeypatch.delenv('STRIVE_CNN_TAIL_S', raising=False)
         got = run(n)
@@ -196,7 +197,7 @@ def test_map_cnn_small_batch_chain(model, monkeypatch):
         monkeypatch.setenv('STRIVE_CNN_SMALL_BATCH', '0')
         big = run(n)
         assert_close(got, big, 1e-5, 1e-6, 'small-batch chain vs throughput chain, %d samples' % n)
-        if n > 32:
+        if n > 96:
             assert torch.equal(got, big)
 
 
