@@ -226,9 +226,8 @@ def adv_closure_factory(m, env, batch, map_idx, FT, device):
         c = AdvClosure(emb['posterior_out'][0].clone(), 0.05, ADV_WEIGHTS, m, g, env, mi, emb, (pm[ego], pv[ego]),
                        (pm[~ego], pv[~ego]), 2, 0.0, future_len=FT, veh_coll_buffer=0.1, planner_name='hardcode', planner=planner)
 
-        def step():
-            loss = c.step()
-            return loss
+        from strive_amd.utils.graphed import GraphedIteration
+        step = GraphedIteration(c.step, c.graphed)
         step.planner = planner
         step.closure = c
         return step, emb, g, mi, 2

@@ -476,6 +476,7 @@ struct Work {
     int32_t* scene_bad;     // (B)
     int K, cap, ENT, P, NT;
     size_t nzero;
+    unsigned long long* tprof;   // measurement only (STRIVE_PLANNER_PROF): clock sums of the ego kernel's phases, in the workspace's spare tail
 };
 
 __global__ void planner_world_kernel(StrivePlanner pl, Work w, const double* __restrict__ obs, const double* __restrict__ agent_t, int T) {
@@ -529,9 +530,12 @@ __global__ void planner_world_kernel(StrivePlanner pl, Work w, const double* __r
 // `on_route(i)` is called by the whole wave for i = 0..n-1 with the knots in R (R.bad != 0: the route could not be built)
 template <bool FIRST_ONLY, class G, class F>
 __device__ int for_each_route(RouteLds& R, const StrivePlannerMap& mp, const StrivePlannerCfg& cfg, const Pose& o, int32_t* status,
-                              G&& begin_group, F&& on_route) {
+                              G&& begin_group, F&& on_route, unsigned long long* tp = nullptr) {
     const RouteGeom g = route_geom(cfg, o.s);
+    long long t0 = tp ? (long long)clock64() : 0;
+    auto tk = [&](int id) { if (tp) { const long long n = (long long)clock64(); atomicAdd(tp + id, (unsigned long long)(n - t0)); t0 = n; } };
     match_and_cluster(R, mp, cfg, o, status);
+    tk(0);
     const int nkept = R.nkept;
     if (nkept == 0) {
         begin_group(1);
@@ -545,6 +549,7 @@ __device__ int for_each_route(RouteLds& R, const StrivePlannerMap& mp, const Str
         const int m = R.kept[mi];
         build_chains(R.cf, R.win, mp.succ, mp.N, mp.succ_ptr, mp.succ_idx, mp.succ_len, R.m_v1[m], g.need_f, FIRST_ONLY, +1, status);
         build_chains(R.cb, R.win, mp.pred, mp.N, mp.pred_ptr, mp.pred_idx, mp.pred_len, R.m_v0[m], g.need_b, FIRST_ONLY, -1, status);
+        tk(1);
         const int nf = FIRST_ONLY ? 1 : R.cf.n, nb = FIRST_ONLY ? 1 : R.cb.n;
         begin_group(nf * nb);
         for (int fi = 0; fi < nf; ++fi)
@@ -553,6 +558,7 @@ __device__ int for_each_route(RouteLds& R, const StrivePlannerMap& mp, const Str
                 on_route(fi * nb + bi);
                 __syncthreads();
             }
+        tk(2);
     }
     return nkept;
 }
@@ -651,6 +657,14 @@ __global__ void __launch_bounds__(256) planner_ego_kernel(StrivePlanner pl, Work
     const StrivePlannerMap& mp = pl.maps[pl.scene_map[b]];
     double* eg = w.ego + 8 * (size_t)b;
     const int P = w.P, NT = w.NT;
+    long long tlast = w.tprof ? (long long)clock64() : 0;
+    auto tick = [&](int id) {
+        if (w.tprof && tid == 0 && b == 0) {
+            const long long now = (long long)clock64();
+            atomicAdd(w.tprof + id, (unsigned long long)(now - tlast));
+            tlast = now;
+        }
+    };
     if (k == 0 && tid == 0) {
         const double* in = pl.init + 6 * (size_t)(pl.ptr[b] + pl.ego_idx);
         for (int c = 0; c < 6; ++c) eg[c] = in[c];
@@ -730,6 +744,7 @@ __global__ void __launch_bounds__(256) planner_ego_kernel(StrivePlanner pl, Work
         }
         __syncthreads();
     }
+    tick(0);                                          // risk scores, choice, action
     if (k >= w.K) return;
     if (w.scene_bad[b]) return;                       // (NaN state: nothing more to plan for this scene)
     const Pose o = {eg[0], eg[1], eg[2], eg[3]};
@@ -741,8 +756,9 @@ __global__ void __launch_bounds__(256) planner_ego_kernel(StrivePlanner pl, Work
         }
         if (tid == 0) { w.route_nk[b] = R.bad ? 0 : R.nk; if (R.bad) w.scene_bad[b] = 1; }
     };
-    const int nkept = for_each_route<true>(R, mp, cfg, o, status, [](int) {}, on_route);
+    const int nkept = for_each_route<true>(R, mp, cfg, o, status, [](int) {}, on_route, w.tprof && tid == 0 && b == 0 ? w.tprof + 4 : nullptr);
     __syncthreads();
+    tick(1);                                          // match + chains + route
     if (tid == 0) w.prefer_stop[b] = nkept == 0;
     if (R.bad) return;
     // candidate speed profiles (gen_sprofiles, :804-826)
@@ -769,6 +785,7 @@ __global__ void __launch_bounds__(256) planner_ego_kernel(StrivePlanner pl, Work
         pf[0] = s1; pf[1] = acc; pf[2] = d;
     }
     __syncthreads();
+    tick(2);                                          // speed profiles
     double* cc = w.circ + (size_t)b * P * NT * 10;
     for (int it = tid; it < P * NT; it += nthr) {
         const int p = it / NT, t = it % NT;
@@ -778,6 +795,7 @@ __global__ void __launch_bounds__(256) planner_ego_kernel(StrivePlanner pl, Work
         box_circles(x, y, h, el, ew, cx, cy);
         for (int c = 0; c < 5; ++c) { cc[(size_t)it * 10 + 2 * c] = cx[c]; cc[(size_t)it * 10 + 2 * c + 1] = cy[c]; }
     }
+    tick(3);                                          // circles
 }
 
 // gaps between the ego's profile boxes and one chunk of the scene's predicted trajectories (approx_bbox_distance, :885-897).
@@ -983,6 +1001,10 @@ extern "C" int strive_planner_rollout(const StrivePlanner* pl, const double* age
     Layout L = carve(pl, nstep, traj_cap, ws, ws_bytes);
     STRIVE_CHECK_ARG(L.total != 0, "workspace too small");
     Work& w = L.w;
+    w.tprof = nullptr;
+    if (getenv("STRIVE_PLANNER_PROF")) {      // (measurement only: the last 64 bytes of the workspace's spare tail, accumulated over rollouts)
+        w.tprof = reinterpret_cast<unsigned long long*>((char*)ws + ((L.total + 7) / 8) * 8 + 64);
+    }
     hipMemsetAsync(w.traj_cnt, 0, sizeof(int32_t) * w.nzero, stream);
     if (pl->NR > 0) {
         hipLaunchKernelGGL(planner_world_kernel, dim3((pl->NR + 63) / 64), dim3(64), 0, stream, *pl, w, agent_obs, agent_t, (int)T);

@@ -264,6 +264,8 @@ class HardcodeNuscPlanner(PlannerNusc):
         st = self._status
         if st is None:
             return
+        if st.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            return            # inside a HIP-graph capture (utils/graphed.py): the flags accumulate over the replays, the loop checks at its end
         host = None
         if st.device.type != 'cuda':
             host = st

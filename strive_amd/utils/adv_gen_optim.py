@@ -132,9 +132,10 @@ class AdvClosure(object):
         self.tgt_z.requires_grad = True
         self.other_z = cur_z[~self.ego_mask].clone().detach()
         self.other_z.requires_grad = True
-        # the open-loop iteration can be replayed as a HIP graph (utils/graphed.py); the closed loop reads the planner's status
-        # word back through an event per iteration and stays eager
-        self.graphed = planner_name == 'ego' and graph_mode(NA, dev, rollouts=2)
+        # the iteration can be replayed as a HIP graph (utils/graphed.py).  Closed loop: the planner's status flags accumulate in
+        # one device tensor over the replays (its per-iteration look at them is skipped while capturing) and the loop checks them
+        # after its last iteration, like the eager loop does
+        self.graphed = graph_mode(NA, dev, rollouts=2, closed_loop=planner_name == 'hardcode')
         self.optim = optim.Adam([self.tgt_z, self.other_z], lr=lr, **adam_kwargs(self.graphed))
         self._iter = None
         self.unn = model.get_normalizer().unnormalize

@@ -18,7 +18,7 @@ import torch
 AUTO_MAX_AGENTS = 64
 
 
-def graph_mode(n_agents, device, log=None, rollouts=1):
+def graph_mode(n_agents, device, log=None, rollouts=1, closed_loop=False):
     """``rollouts`` = decoder rollouts per iteration.  Iterations with TWO independent rollouts (adversarial, solution) are not
     replayed unless STRIVE_HIP_GRAPH=1 asks for it: eager, the two rollouts run on two HIP streams and their latency chains
     overlap (16 agents: 4.2 ms per iteration); a captured fork / join replays slowly on this runtime (8.6 ms) and a
