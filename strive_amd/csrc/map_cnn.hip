@@ -586,13 +586,18 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
     }
 
     // ---- epilogue: D column = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = channel within the block ----
-    float fsum = 0.f, fsq = 0.f;          // this lane's 16 CBW PT outputs in fp32; everything above that in float64
+    // GroupNorm moments: the 16 outputs of one accumulator tile (one pixel x 16 channels) are summed in fp32, everything above that
+    // in float64.  The fp32 unit is the same set of values in the same order for every tiling of the layer (CBW, PT are per-form
+    // parameters: DESIGN.md 4.10), so the forms differ only in the grouping of float64 additions: 1e-16, i.e. the same fp32 mean and
+    // rstd -- a scene decoded alone and inside a large batch gets the same map features.
+    double dsum = 0.0, dsq = 0.0;
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
 #pragma unroll
         for (int i = 0; i < PT; ++i) {
             const int oy = oy0 + Cfg::TILE_ROWS * (PT * wave + i) + prow, ox = ox0 + pcol;
             const bool valid = oy < OH && ox < OH;
+            float fsum = 0.f, fsq = 0.f;
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int co = (cb * CBW + c) * 32 + 8 * rg + 4 * h;
@@ -618,9 +623,11 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
                     fsq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fsq))));
                 }
             }
+            dsum += (double)fsum;
+            dsq += (double)fsq;
         }
     }
-    const double lsum = wave_sum_d((double)fsum), lsq = wave_sum_d((double)fsq);
+    const double lsum = wave_sum_d(dsum), lsq = wave_sum_d(dsq);
     if (lane == 0) { s_red[2 * wave] = lsum; s_red[2 * wave + 1] = lsq; }
     __syncthreads();
     if (tid == 0) {

@@ -612,12 +612,15 @@ class _RolloutPairFn(torch.autograd.Function):
                  L.ptr(tape), tape.numel(), L.ptr(ws), ws.numel(), _stream(z_a))
         ctx.h, ctx.tape, ctx.zz = h, tape, zz
         ctx.shape_a, ctx.shape_b = z_a.shape, z_b.shape
+        # a port without an incoming adjoint gets None, not zeros: the closed loop differentiates port B's loss while the planner
+        # is still working on port A's input (two backward calls over the one tape), and a sweep of zeros is a whole sweep
+        ctx.set_materialize_grads(False)
         return traj, traj[:, :h.FT_b].clone()
 
     @staticmethod
     def backward(ctx, d_a, d_b):
         h = ctx.h
-        dev = d_a.device
+        dev = (d_a if d_a is not None else d_b).device
         ws = _workspace(dev, h.ws_bytes, 'rollout')
 
         def sweep(d_traj):
@@ -626,9 +629,11 @@ class _RolloutPairFn(torch.autograd.Function):
                        h.FT, L.ptr(d_traj), L.ptr(dz), L.ptr(ctx.tape), ctx.tape.numel(), L.ptr(ws), ws.numel(), _stream(d_traj))
             return dz
         ga = gb = None
-        both = ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and dev.type == 'cuda' and not torch.cuda.is_current_stream_capturing()
+        want_a = ctx.needs_input_grad[0] and d_a is not None
+        want_b = ctx.needs_input_grad[1] and d_b is not None
+        both = want_a and want_b and dev.type == 'cuda' and not torch.cuda.is_current_stream_capturing()
         side = None
-        if ctx.needs_input_grad[1]:
+        if want_b:
             db = _f32c(d_b)
             if h.FT_b < h.FT:           # the steps port B does not have carry no adjoint
                 db = torch.cat([db, torch.zeros((h.R, h.FT - h.FT_b, 4), dtype=torch.float32, device=dev)], dim=1)
@@ -649,7 +654,7 @@ class _RolloutPairFn(torch.autograd.Function):
                 gb = dzb.reshape(ctx.shape_b)
             else:
                 gb = sweep(db).reshape(ctx.shape_b)
-        if ctx.needs_input_grad[0]:
+        if want_a:
             ga = sweep(_f32c(d_a)).reshape(ctx.shape_a)
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)

@@ -46,6 +46,18 @@ def _shared_forward_on():
     return os.environ.get('STRIVE_SHARED_ROLLOUT', '1') != '0'        # (A/B switch)
 
 
+def shared_forward_applies(model, z_a, kw_a, kw_b):
+    """True when two_rollouts(..., same_values=True) will run ONE forward rollout for both results (ops._RolloutPairFn)."""
+    fa, fb = kw_a.get('nfuture'), kw_b.get('nfuture')
+    fa = model.FT if fa is None else fa
+    fb = model.FT if fb is None else fb
+    return bool(z_a.is_cuda and _shared_forward_on() and hasattr(model, 'decode_embedding_pair') and
+                kw_a.get('ext_future') is kw_b.get('ext_future') and fa >= fb)
+
+
+_planner_streams = {}
+
+
 def two_rollouts(model, embed_info, scene_graph, map_idx, map_env, z_a, kw_a, z_b, kw_b, overlap=True, after_a=None, same_values=False):
     """The two rollouts of an adversarial / solution closure are independent until the losses.  On the MI355X they run on two
     HIP streams: the map CNN of one (bandwidth-bound, fills the chip) overlaps the GNN / GRU kernels of the other (latency
@@ -188,12 +200,49 @@ class AdvClosure(object):
         return two_rollouts(self.model, self.embed_info, self.scene_graph, self.map_idx, self.map_env, z_a, kw, z_b, kw,
                             overlap=self.overlap, after_a=after_a, same_values=True)
 
+    def _step_closed_loop_overlapped(self, z_a, z_b, log):
+        """Closed loop with the shared forward rollout: the planner (65 dependent float64 launches, one workgroup per scene) only
+        needs rollout A's futures and only the matching loss needs its plan, so it runs on a side stream while the adversarial loss
+        and ITS reverse sweep run on the caller's; the matching loss and the second sweep follow the join.  The two losses reach
+        disjoint leaves (complementary detach), so two backward calls leave exactly the gradients of one call on their sum."""
+        dev = z_a.device
+        out_a, out_b = self._two_rollouts(z_a, z_b)
+        cur = torch.cuda.current_stream(dev)
+        side = _planner_streams.get(str(dev))
+        if side is None:
+            side = torch.cuda.Stream(dev)
+            _planner_streams[str(dev)] = side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            planner_fut = self.plan(out_a['future_pred'])
+        out_a['future_pred'].record_stream(side)
+        adv_tgt = out_b['future_pred'].index_select(0, self.ego_idx)
+        la = self.adv_loss(self.unn(out_b['future_pred']), self.unn(adv_tgt), self.other_z, self.other_prior,
+                           attack_agt_idx=self.attack_agt_idx)
+        la['loss'].backward(retain_graph=True)
+        cur.wait_stream(side)
+        planner_fut.record_stream(cur)
+        lt = self.tgt_loss(self.unn(out_a['future_pred'].index_select(0, self.ego_idx)), self.unn(planner_fut), self.tgt_z,
+                           self.tgt_prior)
+        lt['loss'].backward()
+        loss = lt['loss'].detach() + la['loss'].detach()
+        if log is not None:
+            loss_dict = {'tgt_match_' + k: v for k, v in lt.items()}
+            loss_dict.update({'adv_' + k: v for k, v in la.items()})
+            log(loss_dict, self.tgt_z, self.other_z)
+        self.optim.step()
+        return loss
+
     def step(self, log=None):
         """(reference src/utils/adv_gen_optim.py:107-171)"""
         m, g = self.model, self.scene_graph
         self.optim.zero_grad()
         z_a = self.collated(detach_other=True)      # ego latents get the matching loss only
         z_b = self.collated(detach_tgt=True)        # the others get the adversarial loss only
+        kw = dict(ext_future=self.planner_fut, nfuture=self.future_len)
+        if self.planner_name == 'hardcode' and self.overlap and os.environ.get('STRIVE_PLANNER_OVERLAP', '1') != '0' and \
+                shared_forward_applies(m, z_a, kw, kw):
+            return self._step_closed_loop_overlapped(z_a, z_b, log)
         if self.planner_name == 'hardcode':
             # the planner reacts to rollout A only: it is enqueued behind A on A's stream and runs under rollout B
             out_a, out_b, planner_fut = self._two_rollouts(z_a, z_b, after_a=lambda o: self.plan(o['future_pred']))

@@ -86,11 +86,14 @@ def compare_trace(trace, g, tag, loss_rtol, loss_atol, grad_rtol, z_atol, z_frac
                 cos = float((gg * gw).sum() / max(np.linalg.norm(gg) * np.linalg.norm(gw), 1e-30))
                 assert cos >= 0.99, '%s iteration %d: gradient direction cos = %.4f' % (tag, it, cos)
                 ok = float(np.mean(rows <= grad_rtol))
+                if it in grad_skip:
+                    ok = 1.0          # (a different NUMBER of active pairs rescales every row: direction only, see the caller)
                 if ok < 1.0 and kink_after is not None and it >= kink_after:
                     worst['first_kink'] = min(worst.get('first_kink', it), it)
                 if 'first_kink' not in worst or it <= worst['first_kink']:
                     # up to and including the first kink event: all rows but the pair on the kink agree tightly
-                    assert ok >= grad_row_frac, '%s iteration %d: only %.3f of the gradient rows within %.1e' % (tag, it, ok, grad_rtol)
+                    assert ok >= grad_row_frac, '%s iteration %d: only %.3f of the gradient rows within %.1e (rows: %s; cos %.5f)' % (
+                        tag, it, ok, grad_rtol, ' '.join('%.3g' % r for r in rows), cos)
                 gr = float(np.median(rows)) if 'first_kink' not in worst else 0.0
             if it in grad_skip:
                 gr = 0.0

@@ -255,9 +255,12 @@ def test_shared_forward_rollout_equals_two_rollouts(model, monkeypatch):
 # configs[2], closed loop: the adversarial closure against the rule-based planner at ~512 agents
 # ------------------------------------------------------------------------------------------------
 
-def test_closed_loop_adv_closure_at_size(model):
+@pytest.mark.parametrize('planner_overlap', ['1', '0'])
+def test_closed_loop_adv_closure_at_size(model, monkeypatch, planner_overlap):
     """One closed-loop iteration (adv_gen_rule_based.cfg's planner 'hardcode'; reference src/utils/adv_gen_optim.py:90-103,
-    133-139) on 512 agents in scenes of 2..30: the device planner runs behind rollout A on A's stream, under rollout B's CNN.
+    133-139) on 512 agents in scenes of 2..30.  Default ('1'): one shared forward rollout, then the device planner on a side stream
+    under the adversarial loss and its reverse sweep, the matching loss and its sweep after the join (two backward calls onto
+    disjoint leaves); '0': planner, both losses, one backward call.
     Three scenes are sampled against the oracle: the planner's reaction to that scene's predicted futures (oracle planner,
     1e-6), both rollouts' rows (oracle rollout of the scene alone), and -- on the sub-batch of the three scenes -- every
     AdvGenLoss / TgtMatchingLoss entry and the gradient w.r.t. both latent groups through rollout + planner + losses.
@@ -272,6 +275,7 @@ def test_closed_loop_adv_closure_at_size(model):
     from strive_amd.planners.planner import PlannerConfig
     from strive_amd.planners.hardcode_goalcond_nusc import HardcodeNuscPlanner, CONFIG_DICT
     m, sd = model
+    monkeypatch.setenv('STRIVE_PLANNER_OVERLAP', planner_overlap)
     px = 2048
     lane_graph = synth.make_lane_graph(extent=px * 0.25)
     raster, dx = uniform(px)
@@ -299,9 +303,16 @@ def test_closed_loop_adv_closure_at_size(model):
 
         def spy(z_a, z_b, after_a=None):
             out = two(z_a, z_b, after_a=after_a)
-            seen['pa'], seen['pb'], seen['plan'] = out[0]['future_pred'].detach(), out[1]['future_pred'].detach(), out[2].detach()
+            seen['pa'], seen['pb'] = out[0]['future_pred'].detach(), out[1]['future_pred'].detach()
             return out
         c._two_rollouts = spy
+        plan = c.plan
+
+        def plan_spy(future_pred):
+            fut = plan(future_pred)
+            seen['plan'] = fut.detach()
+            return fut
+        c.plan = plan_spy
 
         def log(ld, tz, oz):
             seen.update({k: v.detach().clone() for k, v in ld.items() if torch.is_tensor(v)})
