@@ -90,8 +90,14 @@ def compare_trace(trace, g, tag, loss_rtol, loss_atol, grad_rtol, z_atol, z_frac
                     ok = 1.0          # (a different NUMBER of active pairs rescales every row: direction only, see the caller)
                 if ok < 1.0 and kink_after is not None and it >= kink_after:
                     worst['first_kink'] = min(worst.get('first_kink', it), it)
-                if 'first_kink' not in worst or it <= worst['first_kink']:
-                    # up to and including the first kink event: all rows but the pair on the kink agree tightly
+                if 'first_kink' not in worst:
+                    # before the first kink event (never before iteration `kink_after`): the rows agree tightly.  AT the event the
+                    # free-running comparison keeps the direction (cos, above), the losses and the latents only: with ONE scene in
+                    # the batch a circle pair changing sides of its hinge moves every agent's gradient through the interaction net,
+                    # and whether the two runs are on the same side is decided by the last bit of either run (round 4: the verdict
+                    # of the row check at such an iteration flipped between identical builds with the order of the tests run
+                    # before it).  The gradient AT the oracle's latents of EVERY iteration is pinned separately, without
+                    # accumulation: test_refine_closure_at_the_oracle_latents_every_iteration.
                     assert ok >= grad_row_frac, '%s iteration %d: only %.3f of the gradient rows within %.1e (rows: %s; cos %.5f)' % (
                         tag, it, ok, grad_rtol, ' '.join('%.3g' % r for r in rows), cos)
                 gr = float(np.median(rows)) if 'first_kink' not in worst else 0.0
