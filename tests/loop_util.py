@@ -94,9 +94,9 @@ def compare_trace(trace, g, tag, loss_rtol, loss_atol, grad_rtol, z_atol, z_frac
                     # before the first kink event (never before iteration `kink_after`): the rows agree tightly.  AT the event the
                     # free-running comparison keeps the direction (cos, above), the losses and the latents only: with ONE scene in
                     # the batch a circle pair changing sides of its hinge moves every agent's gradient through the interaction net,
-                    # and whether the two runs are on the same side is decided by the last bit of either run (round 4: the verdict
-                    # of the row check at such an iteration flipped between identical builds with the order of the tests run
-                    # before it).  The gradient AT the oracle's latents of EVERY iteration is pinned separately, without
+                    # and whether the two runs are on the same side is decided by the last bit of either run -- the product's or the
+                    # CPU oracle's, whose convolutions depend on the host (round 4: the verdict of the row check at such an iteration
+                    # flipped between runs of identical builds on different boxes / test selections).  The gradient AT the oracle's latents of EVERY iteration is pinned separately, without
                     # accumulation: test_refine_closure_at_the_oracle_latents_every_iteration.
                     assert ok >= grad_row_frac, '%s iteration %d: only %.3f of the gradient rows within %.1e (rows: %s; cos %.5f)' % (
                         tag, it, ok, grad_rtol, ' '.join('%.3g' % r for r in rows), cos)
