@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import make_golden as mg
-from util import golden, oracle_model, product_model, assert_close
+from util import golden, oracle_model, product_model, assert_close, poisoned_workspace
 from strive_amd import _lib as L, params, synth
 from strive_amd.constants import NUSC_BIKE_PARAMS
 from oracle import mapenv, losses as olosses
@@ -96,10 +96,16 @@ def test_map_cnn_one_agent(emu, sd, monkeypatch):
     emu.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(fr), L.f4([0] * 4), L.f4([1] * 4), L.ptr(mi), 1, L.ptr(feat),
              L.ptr(ws), wsb, None)
     assert_close(feat, want, 1e-4, 1e-5, 'cnn')
+    # the workspace arrives uninitialised: with every byte 0xFF (NaN) the same bits
+    ws_nan = torch.full((wsb,), 0xFF, dtype=torch.uint8)
+    again = torch.zeros((1, 64))
+    emu.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(fr), L.f4([0] * 4), L.f4([1] * 4), L.ptr(mi), 1, L.ptr(again),
+             L.ptr(ws_nan), wsb, None)
+    assert torch.equal(again, feat), 'the CNN read workspace it had not written'
     monkeypatch.setenv('STRIVE_CNN_SMALL_BATCH', '0')
     big = torch.zeros((1, 64))
     emu.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(fr), L.f4([0] * 4), L.f4([1] * 4), L.ptr(mi), 1, L.ptr(big),
-             L.ptr(ws), wsb, None)
+             L.ptr(ws_nan.fill_(0xFF)), wsb, None)
     assert_close(big, want, 1e-4, 1e-5, 'cnn, throughput chain')
     assert torch.equal(big, feat), 'the two chains: %.3g apart' % float((big - feat).abs().max())
 
@@ -453,6 +459,8 @@ def test_avoid_coll_loss_fused(emu, sd, single, monkeypatch):
     from strive_amd import ops
     from strive_amd.losses.adv_gen_nusc import AvoidCollLoss
     monkeypatch.setattr(ops, '_lib_for', lambda *tensors: emu)
+    monkeypatch.setattr(ops, '_ws_cache', {})                           # fresh scratch buffers for this test ...
+    monkeypatch.setattr(ops, '_workspace', poisoned_workspace(ops))    # ... that start as NaN bytes (tests/util.py)
     g = golden('g5_losses.npz')
     batch, map_idx, raster, dx = mg.g5_inputs(None, None)
     orc = oracle_model(sd)
@@ -519,6 +527,8 @@ def test_adv_gen_loss_fused(emu, sd, mt, infront, atk, far, monkeypatch):
     from strive_amd import ops
     from strive_amd.losses.adv_gen_nusc import AdvGenLoss
     monkeypatch.setattr(ops, '_lib_for', lambda *tensors: emu)
+    monkeypatch.setattr(ops, '_ws_cache', {})                           # fresh scratch buffers for this test ...
+    monkeypatch.setattr(ops, '_workspace', poisoned_workspace(ops))    # ... that start as NaN bytes (tests/util.py)
     g = golden('g5_losses.npz')
     batch, map_idx, raster, dx = mg.g5_inputs(None, None)
     orc = oracle_model(sd)
@@ -584,6 +594,8 @@ def test_fused_losses_ragged_scenes(emu, monkeypatch):
     from strive_amd import ops
     from strive_amd.losses.adv_gen_nusc import AvoidCollLoss, AdvGenLoss
     monkeypatch.setattr(ops, '_lib_for', lambda *tensors: emu)
+    monkeypatch.setattr(ops, '_ws_cache', {})                           # fresh scratch buffers for this test ...
+    monkeypatch.setattr(ops, '_workspace', poisoned_workspace(ops))    # ... that start as NaN bytes (tests/util.py)
     D = 32
     # AvoidCollLoss, sizes with a singleton scene
     batch, map_idx, env, traj, veh_att = _loss_case([1, 4, 2], 'emu/ragged_a')
@@ -655,7 +667,7 @@ def test_pack_dense_equals_torch_layout(emu, M, K):
 
 
 # ---- scene-resident rollout kernels (csrc/scene_rollout.h) against the launch-per-phase kernels on the same inputs ----
-def _rollout_both_paths(emu, sd, sizes, FT, ext=False, NC=2, monkeypatch=None):
+def _rollout_both_paths(emu, sd, sizes, FT, ext=False, NC=2, monkeypatch=None, fill=0):
     batch, map_idx, raster, dx = mg.build_inputs(sizes, 'emu', NC=NC)
     env = synth.SyntheticMapEnv(raster, dx)
     orc = oracle_model(sd, NC=NC)
@@ -676,7 +688,8 @@ def _rollout_both_paths(emu, sd, sizes, FT, ext=False, NC=2, monkeypatch=None):
     for mode in ('0', '1'):
         monkeypatch.setenv('STRIVE_SCENE_KERNELS', mode)
         assert emu.query('strive_rollout_scene_resident', dec.ref(), sc.ref()) == int(mode)
-        tape, ws = torch.zeros(tb, dtype=torch.uint8), torch.zeros(wb, dtype=torch.uint8)
+        # (`fill`: what the caller-owned tape and workspace hold before the calls -- 0xFF = NaN in every float the kernels might read)
+        tape, ws = torch.full((tb,), fill, dtype=torch.uint8), torch.full((wb,), fill, dtype=torch.uint8)
         traj = torch.zeros((NA, FT, 4))
         emu.call('strive_rollout_fwd', dec.ref(), sc.ref(), L.ptr(batch.past[:, -1, :].contiguous()), L.ptr(lw), L.ptr(sem),
                  L.ptr(emb['past_feat'].contiguous()), L.ptr(emb['map_feat'].contiguous()), L.ptr(z), L.ptr(mi), L.ptr(extf), FT,
@@ -688,7 +701,7 @@ def _rollout_both_paths(emu, sd, sizes, FT, ext=False, NC=2, monkeypatch=None):
     # cross pairing: the tape is the same layout, so the sweep of one path runs on the tape of the other
     monkeypatch.setenv('STRIVE_SCENE_KERNELS', '1')
     dz_x = torch.zeros((NA, 32))
-    ws = torch.zeros(wb, dtype=torch.uint8)
+    ws = torch.full((wb,), fill, dtype=torch.uint8)
     emu.call('strive_rollout_bwd', dec.ref(), sc.ref(), L.ptr(lw), L.ptr(sem), L.ptr(z), L.ptr(extf), FT,
              L.ptr(rw), L.ptr(dz_x), L.ptr(out['0'][2]), tb, L.ptr(ws), wb, None)
     return out, dz_x
@@ -705,3 +718,18 @@ def test_scene_resident_rollout_equals_phase_kernels(emu, sd, sizes, FT, ext, mo
     scale = float(d0.abs().max())
     assert_close(d1, d0, 1e-3, 2e-5 * scale, 'scene-resident backward')
     assert_close(dz_x, d0, 1e-3, 2e-5 * scale, 'scene-resident sweep on the phase kernels\' tape')
+
+
+@pytest.mark.parametrize('sizes,FT,ext', [([3, 1, 5, 2], 1, False), ([16, 9], 1, True),
+                                          ([4, 2], 2, False)])
+def test_rollout_reads_nothing_it_did_not_write(emu, sd, sizes, FT, ext, monkeypatch):
+    """The tape and the workspace are caller-owned and arrive uninitialised (torch.empty): with every byte 0xFF (NaN in any float
+    a kernel might pick up) both kernel paths must give the bits they give on zeroed buffers -- no row, slot or padding of either
+    buffer is read before the call that needs it has written it."""
+    zero, dz_zero = _rollout_both_paths(emu, sd, sizes, FT, ext=ext, monkeypatch=monkeypatch, fill=0)
+    nan, dz_nan = _rollout_both_paths(emu, sd, sizes, FT, ext=ext, monkeypatch=monkeypatch, fill=0xFF)
+    for mode in ('0', '1'):
+        assert torch.isfinite(nan[mode][0]).all() and torch.isfinite(nan[mode][1]).all()
+        assert torch.equal(zero[mode][0], nan[mode][0]), 'trajectories depend on what the buffers held (STRIVE_SCENE_KERNELS=%s)' % mode
+        assert torch.equal(zero[mode][1], nan[mode][1]), 'latent gradients depend on what the buffers held (STRIVE_SCENE_KERNELS=%s)' % mode
+    assert torch.equal(dz_zero, dz_nan)

@@ -77,7 +77,10 @@ def emu_ops():
     orig = (ops._lib_for, L.get_lib)
     ops._lib_for = lambda *tensors: emu           # CPU tensors + the emulated library: test infrastructure only
     L.get_lib = lambda: emu
+    from util import poison_new_workspaces
+    orig_ws = poison_new_workspaces(ops)          # new scratch buffers start as NaN bytes, not as whatever torch.empty holds
     yield emu
+    ops._workspace = orig_ws
     ops._lib_for, L.get_lib = orig
 
 

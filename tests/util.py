@@ -58,3 +58,25 @@ def assert_close_frac(a, b, rtol, atol, frac, hard_atol, what=''):
     ok = float(np.mean(err <= atol + rtol * np.abs(b)))
     assert ok >= frac, '%s: only %.4f of the entries within rtol %.1e / atol %.1e' % (what, ok, rtol, atol)
     assert float(err.max()) <= hard_atol, '%s: worst entry off by %.3g (> %.3g)' % (what, float(err.max()), hard_atol)
+
+
+def poisoned_workspace(ops):
+    """Test infrastructure for the emulated (CPU) library: a replacement for ops._workspace whose NEW scratch buffers start as 0xFF
+    bytes (NaN in any float a kernel might pick up) instead of whatever torch.empty returns -- a kernel that reads scratch it has not
+    written shows up as NaN / a mismatch against the oracle."""
+    orig = ops._workspace
+
+    def _ws(device, nbytes, tag='ws'):
+        known = {id(v) for v in ops._ws_cache.values()}
+        buf = orig(device, nbytes, tag)
+        if id(buf) not in known and buf.device.type == 'cpu':
+            buf.fill_(0xFF)
+        return buf
+    return _ws
+
+
+def poison_new_workspaces(ops):
+    """Install poisoned_workspace(ops); returns the function to restore."""
+    orig = ops._workspace
+    ops._workspace = poisoned_workspace(ops)
+    return orig
