@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import make_golden as mg
-from util import golden, oracle_model, product_model, assert_close, poisoned_workspace
+from util import golden, oracle_model, product_model, assert_close, poisoned_workspace, nan_empty
 from strive_amd import _lib as L, params, synth
 from strive_amd.constants import NUSC_BIKE_PARAMS
 from oracle import mapenv, losses as olosses
@@ -461,6 +461,7 @@ def test_avoid_coll_loss_fused(emu, sd, single, monkeypatch):
     monkeypatch.setattr(ops, '_lib_for', lambda *tensors: emu)
     monkeypatch.setattr(ops, '_ws_cache', {})                           # fresh scratch buffers for this test ...
     monkeypatch.setattr(ops, '_workspace', poisoned_workspace(ops))    # ... that start as NaN bytes (tests/util.py)
+    monkeypatch.setattr(torch, 'empty', nan_empty())                   # and so does everything else allocated uninitialised
     g = golden('g5_losses.npz')
     batch, map_idx, raster, dx = mg.g5_inputs(None, None)
     orc = oracle_model(sd)
@@ -529,6 +530,7 @@ def test_adv_gen_loss_fused(emu, sd, mt, infront, atk, far, monkeypatch):
     monkeypatch.setattr(ops, '_lib_for', lambda *tensors: emu)
     monkeypatch.setattr(ops, '_ws_cache', {})                           # fresh scratch buffers for this test ...
     monkeypatch.setattr(ops, '_workspace', poisoned_workspace(ops))    # ... that start as NaN bytes (tests/util.py)
+    monkeypatch.setattr(torch, 'empty', nan_empty())                   # and so does everything else allocated uninitialised
     g = golden('g5_losses.npz')
     batch, map_idx, raster, dx = mg.g5_inputs(None, None)
     orc = oracle_model(sd)
@@ -596,6 +598,7 @@ def test_fused_losses_ragged_scenes(emu, monkeypatch):
     monkeypatch.setattr(ops, '_lib_for', lambda *tensors: emu)
     monkeypatch.setattr(ops, '_ws_cache', {})                           # fresh scratch buffers for this test ...
     monkeypatch.setattr(ops, '_workspace', poisoned_workspace(ops))    # ... that start as NaN bytes (tests/util.py)
+    monkeypatch.setattr(torch, 'empty', nan_empty())                   # and so does everything else allocated uninitialised
     D = 32
     # AvoidCollLoss, sizes with a singleton scene
     batch, map_idx, env, traj, veh_att = _loss_case([1, 4, 2], 'emu/ragged_a')

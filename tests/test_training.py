@@ -95,7 +95,9 @@ def test_training_step_all_gradients_emulated(emu_ops):
     eps_post = synth.f32(synth.counter_normal((NA, 32), 'train/eps_post'))
     eps_prior = synth.f32(synth.counter_normal((NA, 32), 'train/eps_prior'))
     out_o, ld_o, g_o = _oracle_step(sd, batch, map_idx, env, eps_post, eps_prior, FT=2)
-    out, ld, g, err = _product_step(m, batch.clone(), map_idx, env, eps_post, eps_prior)
+    from util import poisoned_empty
+    with poisoned_empty():          # every buffer the product allocates uninitialised (outputs, tapes, scratch) starts as NaN
+        out, ld, g, err = _product_step(m, batch.clone(), map_idx, env, eps_post, eps_prior)
     assert_close(out['future_pred'], out_o['future_pred'], 1e-4, 2e-5, 'future_pred')
     assert_close(out['future_samp'], out_o['future_samp'], 1e-4, 2e-5, 'future_samp')
     for k in ('loss', 'recon_loss', 'kl_loss', 'coll_veh_prior', 'coll_env_prior'):

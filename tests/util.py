@@ -80,3 +80,37 @@ def poison_new_workspaces(ops):
     orig = ops._workspace
     ops._workspace = poisoned_workspace(ops)
     return orig
+
+
+def nan_empty():
+    """torch.empty that returns NaN floats / 0xFF bytes / a recognisable negative integer instead of whatever the allocator holds
+    (test infrastructure, CPU emulation runs): outputs, tapes and scratch the product allocates with torch.empty and a kernel then
+    fails to write completely show up as NaN / a mismatch against the oracle."""
+    import torch
+    orig = torch.empty
+
+    def empty(*a, **k):
+        t = orig(*a, **k)
+        if t.device.type == 'cpu' and t.numel():
+            if t.dtype.is_floating_point:
+                t.fill_(float('nan'))
+            elif t.dtype == torch.uint8:
+                t.fill_(0xFF)
+            elif t.dtype in (torch.int32, torch.int64):
+                t.fill_(-0x0F0F0F0F)
+        return t
+    return empty
+
+
+class poisoned_empty(object):
+    """Context manager installing nan_empty() as torch.empty."""
+
+    def __enter__(self):
+        import torch
+        self.torch, self.orig = torch, torch.empty
+        torch.empty = nan_empty()
+        return self
+
+    def __exit__(self, *exc):
+        self.torch.empty = self.orig
+        return False
