@@ -82,9 +82,11 @@ def emu_ops():
     orig = (ops._lib_for, L.get_lib)
     ops._lib_for = lambda *tensors: emu
     L.get_lib = lambda: emu
-    from util import poison_new_workspaces
+    from util import poison_new_workspaces, nan_empty
     orig_ws = poison_new_workspaces(ops)          # new scratch buffers start as NaN bytes, not as whatever torch.empty holds
+    orig_empty, torch.empty = torch.empty, nan_empty()      # ... and so does every output allocated with torch.empty
     yield emu
+    torch.empty = orig_empty
     ops._workspace = orig_ws
     ops._lib_for, L.get_lib = orig
 
