@@ -1,4 +1,5 @@
-"""conv2 as launched by the CNN (conv_bf6_kernel, bench-layer code 1) against the specialised-wave form (code 51)."""
+"""conv2 (bench-layer codes 1 / 51) and conv3 (codes 2 / 52) as conv_bf6_kernel against the specialised-wave forms (conv_ws_kernel,
+conv_ws2_kernel): time per launch and bit identity of the outputs.  usage: python tools/conv_ws_probe.py [N ...]"""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
@@ -36,8 +37,14 @@ for n in (int(a) for a in (sys.argv[1:] or ['512'])):
             lib.call('strive_map_cnn_bench_layer', mp.ref(), cnn.ref(), layer, L.ptr(pos), mean4, std4, L.ptr(mapix), n, L.ptr(feat), L.ptr(ws), wsb, st)
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / reps
-    o1 = 16 * 125 * 125 * 4 * n
-    nb = 32 * 61 * 61 * 4 * n
-    run(1, 1); torch.cuda.synchronize(); a = ws[o1 + 0:o1 + nb].clone()      # (offsets: act[0] then act[1], 256-byte aligned sizes)
-    run(51, 1); torch.cuda.synchronize(); b = ws[o1 + 0:o1 + nb].clone()
-    print('N=%d: conv_bf6_kernel %.1f us, conv_ws_kernel %.1f us, outputs bit-identical: %s' % (n, run(1), run(51), bool(torch.equal(a, b))))
+    def align(v):
+        return (v + 255) // 256 * 256
+    o1 = align(16 * 125 * 125 * 4 * n)          # act[0] | act[1] | act[2] ... (256-byte aligned blocks)
+    nb1 = 32 * 61 * 61 * 4 * n
+    o2 = o1 + align(nb1)
+    nb2 = 64 * 29 * 29 * 4 * n
+    for name, a_id, b_id, off, nb in (('conv2', 1, 51, o1, nb1), ('conv3', 2, 52, o2, nb2)):
+        ws[off:off + nb].zero_(); run(a_id, 1); torch.cuda.synchronize(); a = ws[off:off + nb].clone()
+        ws[off:off + nb].zero_(); run(b_id, 1); torch.cuda.synchronize(); b = ws[off:off + nb].clone()
+        print('N=%d %s: conv_bf6_kernel %.1f us, specialised waves %.1f us, outputs bit-identical: %s (non-zero: %s)' % (
+            n, name, run(a_id), run(b_id), bool(torch.equal(a, b)), bool(a.any())), flush=True)
