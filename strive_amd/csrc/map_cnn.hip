@@ -937,9 +937,11 @@ __global__ __launch_bounds__(1024, 1) void conv_ws_kernel(const float* __restric
 // in float64.  BUILT AND VERIFIED ON THE EMULATOR AT THE END OF ROUND 4 (tests/test_emu_kernels.py); NOT YET MEASURED: it is not
 // used unless STRIVE_CONV3_WS=1 (strive_map_cnn_bench_layer: layer 52).
 // =============================================================================================
-template <class Cfg>
+// NCW = consumer waves: 8 (one output row each, 1024 threads, <= 128 registers) or 4 (TWO rows each: the weight fragments of a step
+// are read from LDS once for two pixel tiles -- 8 KB per 12 matrix instructions instead of 6 KB per 6; 768 threads, <= 168 registers)
+template <class Cfg, int NCW = 8>
 struct Ws2Cfg {
-    static constexpr int NCONS_W = 8, NT = 1024, NPROD = 512;
+    static constexpr int NCONS_W = NCW, RPW = Cfg::TH / NCW, NPROD = 512, NT = 64 * NCW + NPROD;
     static constexpr int UITERS = (Cfg::UNITS + NPROD - 1) / NPROD;
     static constexpr int KSPLIT = (UITERS + 1) / 2;                 // staging iterations done in the first half of a unit
     static constexpr int WLO_STEPS = (Cfg::NKS + 1) / 2, WHI_STEPS = Cfg::NKS - WLO_STEPS;
@@ -947,15 +949,16 @@ struct Ws2Cfg {
     static constexpr int WLO_Q = WLO_STEPS * Cfg::WSTEP_B / 16, WHI_Q = WHI_STEPS * Cfg::WSTEP_B / 16;     // 16-byte words of a half
     static constexpr int WLO_IT = (WLO_Q + NPROD - 1) / NPROD, WHI_IT = (WHI_Q + NPROD - 1) / NPROD;
     static constexpr size_t LDS_BYTES = 2 * (size_t)Cfg::IN_B + WPASS_B + 2 * (size_t)Cfg::CIN * 8 + 2 * 8 * 16 + 64;
-    static_assert(Cfg::CBW == 2 && Cfg::CSPLIT == 1 && Cfg::OUT_OCT && !Cfg::ROWS2 && Cfg::TH == NCONS_W, "built for conv3's shape");
+    static_assert(Cfg::CBW == 2 && Cfg::CSPLIT == 1 && Cfg::OUT_OCT && !Cfg::ROWS2 && Cfg::TH == NCONS_W * RPW && (NCW == 4 || NCW == 8),
+                  "built for conv3's shape");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <class Cfg>
+template <class Cfg, int NCW>
 __device__ __forceinline__ void ws2_producer(const float* __restrict__ in, const GNStats* __restrict__ st_in, const float* __restrict__ gn_g,
                                           const float* __restrict__ gn_b, const uint32_t* __restrict__ wfrag, float xscale,
                                           unsigned char* s_in, unsigned char* s_w, float* s_gn, WsUnits<Cfg> un) {
-    using W = Ws2Cfg<Cfg>;
+    using W = Ws2Cfg<Cfg, NCW>;
     constexpr int CIN = Cfg::CIN, IH = Cfg::IH, TH = Cfg::TH, TW = Cfg::TW, ITW = Cfg::ITW;
     constexpr int K1 = W::KSPLIT, K2 = W::UITERS - W::KSPLIT;          // staging iterations of the first / second half of a unit
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1107,18 +1110,19 @@ __device__ __forceinline__ void ws2_producer(const float* __restrict__ in, const
     }
 }
 
-template <class Cfg>
+template <class Cfg, int NCW>
 __device__ __forceinline__ void ws2_consumer(const unsigned char* s_in, const unsigned char* s_w, double* s_red, const float* __restrict__ bias,
                                           float* __restrict__ out, GNStats* __restrict__ st_out, float unscale, WsUnits<Cfg> un) {
-    using W = Ws2Cfg<Cfg>;
+    using W = Ws2Cfg<Cfg, NCW>;
+    constexpr int RPW = W::RPW;
     constexpr int COUT = Cfg::COUT, OH = Cfg::OH, TH = Cfg::TH, TW = Cfg::TW, NKS = Cfg::NKS, NPASS = Cfg::NPASS, CBW = Cfg::CBW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
     const int nunit = un.nunit;
-    f32x16 acc[CBW];
-    const int lane_base = (2 * wave) * Cfg::ROW_B + j * 16;
-    f16x8 fa[2][CBW][2], fb[2][2];
+    f32x16 acc[CBW][RPW];
+    const int lane_base = (2 * RPW * wave) * Cfg::ROW_B + j * 16;         // output row RPW wave + i reads input rows from 2 (RPW wave + i)
+    f16x8 fa[2][CBW][2], fb[2][RPW][2];
     auto load_frags = [&](const unsigned char* buf, int t, int set) {
         int ky, kx;
         if (Cfg::KS == 5) {
@@ -1135,7 +1139,9 @@ __device__ __forceinline__ void ws2_consumer(const unsigned char* s_in, const un
         for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
             for (int c = 0; c < CBW; ++c) fa[set][c][pl] = *reinterpret_cast<const f16x8*>(wb + (c * 2 + pl) * 1024);
-            fb[set][pl] = *reinterpret_cast<const f16x8*>(buf + pl * Cfg::PIECE_B + lane_base + off);
+#pragma unroll
+            for (int i = 0; i < RPW; ++i)
+                fb[set][i][pl] = *reinterpret_cast<const f16x8*>(buf + pl * Cfg::PIECE_B + lane_base + 2 * i * Cfg::ROW_B + off);
         }
     };
     // matrix steps t0 .. t1-1 of unit u (a half of the unit: the fragments of t0 are read here, after the barrier that released them)
@@ -1148,7 +1154,9 @@ __device__ __forceinline__ void ws2_consumer(const unsigned char* s_in, const un
 #pragma unroll
             for (int c = 0; c < CBW; ++c)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+                for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
         }
         load_frags(buf, t0, t0 & 1);
 #pragma unroll
@@ -1161,27 +1169,32 @@ __device__ __forceinline__ void ws2_consumer(const unsigned char* s_in, const un
             for (int term = 0; term < 3; ++term)
 #pragma unroll
                 for (int c = 0; c < CBW; ++c)
-                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][c][TA[term]], fb[cur][TB[term]], acc[c], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i)
+                        acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][c][TA[term]], fb[cur][i][TB[term]], acc[c][i], 0, 0, 0);
         }
     };
     auto epilogue = [&](int u) {                                   // after the last step of the tile's last pass
         int n, ty, tx, pass;
         un.tile(u, n, ty, tx, pass);
-        const int oy = ty * TH + wave, ox = tx * TW + j;
-        const bool valid = oy < OH && ox < OH;
+        const int ox = tx * TW + j;
         double dsum = 0.0, dsq = 0.0;
 #pragma unroll
-        for (int c = 0; c < CBW; ++c) {
+        for (int c = 0; c < CBW; ++c)
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int oy = ty * TH + RPW * wave + i;
+            const bool valid = oy < OH && ox < OH;
             float fsum = 0.f, fsq = 0.f;
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int co = c * 32 + 8 * rg + 4 * h;
                 const float4 bv = *reinterpret_cast<const float4*>(bias + co);
                 float4 v;
-                v.x = fmaf(acc[c][4 * rg + 0], unscale, bv.x);
-                v.y = fmaf(acc[c][4 * rg + 1], unscale, bv.y);
-                v.z = fmaf(acc[c][4 * rg + 2], unscale, bv.z);
-                v.w = fmaf(acc[c][4 * rg + 3], unscale, bv.w);
+                v.x = fmaf(acc[c][i][4 * rg + 0], unscale, bv.x);
+                v.y = fmaf(acc[c][i][4 * rg + 1], unscale, bv.y);
+                v.z = fmaf(acc[c][i][4 * rg + 2], unscale, bv.z);
+                v.w = fmaf(acc[c][i][4 * rg + 3], unscale, bv.w);
                 if (valid) {
                     *reinterpret_cast<float4*>(out + ((((size_t)n * (COUT / 8) + (co >> 3)) * OH + oy) * OH + ox) * 8 + (co & 7)) = v;
                     fsum += (v.x + v.y) + (v.z + v.w);
@@ -1200,7 +1213,7 @@ __device__ __forceinline__ void ws2_consumer(const unsigned char* s_in, const un
         un.tile(u, n, ty, tx, pass);
         const int tl = (u / NPASS) & 1;
         double a = 0.0, b = 0.0;
-        for (int w = 0; w < 8; ++w) { a += s_red[(tl * 8 + w) * 2]; b += s_red[(tl * 8 + w) * 2 + 1]; }
+        for (int w = 0; w < W::NCONS_W; ++w) { a += s_red[(tl * 8 + w) * 2]; b += s_red[(tl * 8 + w) * 2 + 1]; }
         GNStats& o = st_out[(size_t)n * Cfg::NPART_OUT + (ty * Cfg::TILES_X + tx)];
         o.sum = a;
         o.sq = b;
@@ -1220,13 +1233,13 @@ __device__ __forceinline__ void ws2_consumer(const unsigned char* s_in, const un
     if (tid == 0 && nunit >= 1 && ((nunit - 1) % NPASS) == NPASS - 1) publish_stats(nunit - 1);
 }
 
-template <class Cfg>
-__global__ __launch_bounds__(1024, 1) void conv_ws2_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
+template <class Cfg, int NCW>
+__global__ __launch_bounds__(64 * NCW + 512, 1) void conv_ws2_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
                                                             const float* __restrict__ gn_g, const float* __restrict__ gn_b,
                                                             const uint32_t* __restrict__ wfrag, const float* __restrict__ bias,
                                                             float* __restrict__ out, GNStats* __restrict__ st_out, int N, float xscale,
                                                             float unscale) {
-    using W = Ws2Cfg<Cfg>;
+    using W = Ws2Cfg<Cfg, NCW>;
     HIP_DYNAMIC_SHARED(float, smem)
     unsigned char* s_in = reinterpret_cast<unsigned char*>(smem);          // [2][IN_B]
     unsigned char* s_w = s_in + 2 * Cfg::IN_B;                              // one pass: [step][block][piece][lane][16 B]
@@ -1242,8 +1255,8 @@ __global__ __launch_bounds__(1024, 1) void conv_ws2_kernel(const float* __restri
     un.nunit = (t_end > un.t_begin ? t_end - un.t_begin : 0) * Cfg::NPASS;
     if (un.nunit == 0) return;
     // both roles execute the same sequence of barriers: (P), then (A), (B) per iteration
-    if (wave >= W::NCONS_W) ws2_producer<Cfg>(in, st_in, gn_g, gn_b, wfrag, xscale, s_in, s_w, s_gn, un);
-    else ws2_consumer<Cfg>(s_in, s_w, s_red, bias, out, st_out, unscale, un);
+    if (wave >= W::NCONS_W) ws2_producer<Cfg, NCW>(in, st_in, gn_g, gn_b, wfrag, xscale, s_in, s_w, s_gn, un);
+    else ws2_consumer<Cfg, NCW>(s_in, s_w, s_red, bias, out, st_out, unscale, un);
 }
 
 // =============================================================================================
@@ -1561,14 +1574,14 @@ static int launch_ws(const float* in, const GNStats* st_in, const float* g, cons
     return 0;
 }
 
-template <class Cfg>
+template <class Cfg, int NCW>
 static int launch_ws2(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
                       const float* bias, float* out, GNStats* st_out, int N, float xscale, float wscale, hipStream_t stream) {
-    using W = Ws2Cfg<Cfg>;
+    using W = Ws2Cfg<Cfg, NCW>;
     static PerDeviceOnce once;
     const int dev = once.device();
     if (!once.is_done(dev)) {
-        hipFuncSetAttribute((const void*)conv_ws2_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES);
+        hipFuncSetAttribute((const void*)(conv_ws2_kernel<Cfg, NCW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES);
         int v = 0;
         if (!(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)) v = 256;
         once.value[dev].store(v, std::memory_order_relaxed);
@@ -1581,7 +1594,7 @@ static int launch_ws2(const float* in, const GNStats* st_in, const float* g, con
         const int g = atoi(e);
         if (g >= 1 && g < grid) grid = g;
     }
-    hipLaunchKernelGGL(conv_ws2_kernel<Cfg>, dim3(grid), dim3(W::NT), W::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out, st_out, N,
+    hipLaunchKernelGGL((conv_ws2_kernel<Cfg, NCW>), dim3(grid), dim3(W::NT), W::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out, st_out, N,
                        xscale, 1.0f / (xscale * wscale));
     return 0;
 }
@@ -1778,9 +1791,11 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         }
         // conv3 on specialised waves with a one-pass weight ring: built and emulator-verified, not yet measured -> opt-in
         const char* c3 = getenv("STRIVE_CONV3_WS");               // (read per call: the tests switch it inside one process)
-        const bool conv3_ws = c3 && atoi(c3) != 0;
-        if (conv3_ws && !cnn->conv2_plain)
-            launch_ws2<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
+        const int conv3_ws = c3 ? atoi(c3) : 0;                    // 1: 8 consumer waves x 1 row, 2: 4 consumer waves x 2 rows
+        if (conv3_ws == 2 && !cnn->conv2_plain)
+            launch_ws2<Bf3, 4>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
+        else if (conv3_ws && !cnn->conv2_plain)
+            launch_ws2<Bf3, 8>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
         else
             launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
         launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, cnn->xscale[3], cnn->wscale[3], stream);
@@ -1822,7 +1837,7 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
                                           const float* pos_mean4_host, const float* pos_std4_host, const int32_t* mapix,
                                           int32_t N, float* feat, void* ws, size_t ws_bytes, strive_stream_t stream_) {
     STRIVE_CHECK_ARG(map && cnn && pos && mapix && feat && ws, "null argument");
-    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK_MAX && layer >= 0 && layer <= 52, "bad layer / N");
+    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK_MAX && layer >= 0 && layer <= 53, "bad layer / N");
     STRIVE_CHECK_ARG(ws_bytes >= strive_map_cnn_workspace_bytes(N), "workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
     StriveArena ar(ws, ws_bytes);
@@ -1886,7 +1901,8 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
         case 1: launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
         case 51: launch_ws<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;   // conv2, specialised waves
         case 2: launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, cnn->xscale[2], cnn->wscale[2], stream); break;
-        case 52: launch_ws2<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, cnn->xscale[2], cnn->wscale[2], stream); break;   // conv3, specialised waves + weight ring
+        case 53: launch_ws2<Bf3, 4>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, cnn->xscale[2], cnn->wscale[2], stream); break;   // the same with 4 consumer waves x 2 rows
+        case 52: launch_ws2<Bf3, 8>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, cnn->xscale[2], cnn->wscale[2], stream); break;   // conv3, specialised waves + weight ring
         case 3: launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], N, cnn->xscale[3], cnn->wscale[3], stream); break;
         case 4: launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], N, cnn->xscale[4], cnn->wscale[4], stream); break;
         case 5: launch_bf6s<Bfs6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w6_frag, cnn->b[5], act[5], st[5], N, cnn->xscale[5], cnn->wscale[5], stream); break;

@@ -768,7 +768,8 @@ def test_conv3_specialised_waves_bit_identical(emu, sd, monkeypatch):
     out = {}
     # grids of 12 / 5 / 1 workgroups: one tile each; ranges of 3 tiles that end inside a sample (and a workgroup without work); ONE
     # workgroup walking all 48 (tile, pass) units of the three samples through the ring
-    for layer, grid in ((2, None), (52, None), (52, '5'), (52, '1')):
+    # (layer 53: the same kernel with 4 consumer waves of two output rows each)
+    for layer, grid in ((2, None), (52, None), (52, '5'), (52, '1'), (53, None), (53, '5'), (53, '1')):
         ws[o2:o2 + nb] = 0xFF
         if grid is None:
             monkeypatch.delenv('STRIVE_CONV_WS_GRID', raising=False)
@@ -787,9 +788,10 @@ def test_conv3_specialised_waves_bit_identical(emu, sd, monkeypatch):
     want = _cnn_features(emu, args, fr, mi, n)
     assert torch.equal(feat, want)
     # and as strive_map_cnn_fwd runs it when asked to (STRIVE_CONV3_WS=1: opt-in until it has been measured)
-    monkeypatch.setenv('STRIVE_CONV3_WS', '1')
     monkeypatch.setenv('STRIVE_CONV_WS_GRID', '2')
-    assert torch.equal(_cnn_features(emu, args, fr, mi, n), want)
+    for form in ('1', '2'):
+        monkeypatch.setenv('STRIVE_CONV3_WS', form)
+        assert torch.equal(_cnn_features(emu, args, fr, mi, n), want)
 
 
 def _cnn_features(emu, args, fr, mi, n):

@@ -43,7 +43,7 @@ for n in (int(a) for a in (sys.argv[1:] or ['512'])):
     nb1 = 32 * 61 * 61 * 4 * n
     o2 = o1 + align(nb1)
     nb2 = 64 * 29 * 29 * 4 * n
-    for name, a_id, b_id, off, nb in (('conv2', 1, 51, o1, nb1), ('conv3', 2, 52, o2, nb2)):
+    for name, a_id, b_id, off, nb in (('conv2', 1, 51, o1, nb1), ('conv3 (8 consumer waves)', 2, 52, o2, nb2), ('conv3 (4 consumer waves x 2 rows)', 2, 53, o2, nb2)):
         ws[off:off + nb].zero_(); run(a_id, 1); torch.cuda.synchronize(); a = ws[off:off + nb].clone()
         ws[off:off + nb].zero_(); run(b_id, 1); torch.cuda.synchronize(); b = ws[off:off + nb].clone()
         print('N=%d %s: conv_bf6_kernel %.1f us, specialised waves %.1f us, outputs bit-identical: %s (non-zero: %s)' % (
