@@ -934,8 +934,10 @@ __global__ __launch_bounds__(1024, 1) void conv_ws_kernel(const float* __restric
 // Every global load is requested half a unit before it is used.  A consumer
 // wave owns one output row of the 8 x 32 tile and BOTH channel blocks (2 x 16 accumulator registers), same instruction order per
 // accumulator as conv_bf6_kernel: the activations are bit-identical, the GroupNorm moments are the same 16-value fp32 units added
-// in float64.  BUILT AND VERIFIED ON THE EMULATOR AT THE END OF ROUND 4 (tests/test_emu_kernels.py); NOT YET MEASURED: it is not
-// used unless STRIVE_CONV3_WS=1 (strive_map_cnn_bench_layer: layer 52).
+// in float64 (tests/test_emu_kernels.py::test_conv3_specialised_waves_bit_identical; bit-identical on the GPU as well).
+// MEASURED NOT TO PAY (profiles/r04_conv3_ws_probe.txt: refine closure 12.83 / 12.93 against 12.78 ms): with one output row per
+// consumer wave a step reads 6 KB of fragments from LDS for 6 matrix instructions -- 624 KB per unit = the unit's matrix time; with two
+// rows per wave one wave per SIMD issues everything.  Not used unless STRIVE_CONV3_WS=1 | 2 (strive_map_cnn_bench_layer: 52 / 53).
 // =============================================================================================
 // NCW = consumer waves: 8 (one output row each, 1024 threads, <= 128 registers) or 4 (TWO rows each: the weight fragments of a step
 // are read from LDS once for two pixel tiles -- 8 KB per 12 matrix instructions instead of 6 KB per 6; 768 threads, <= 168 registers)
@@ -1789,7 +1791,7 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
             launch_cnn_tail(cnn, act[3], st[3], Bf4s::NPART_OUT, feat + (size_t)n0 * 64, n, stream, nullptr, tail_s);
             continue;
         }
-        // conv3 on specialised waves with a one-pass weight ring: built and emulator-verified, not yet measured -> opt-in
+        // conv3 on specialised waves with a one-pass weight ring: measured a wash (profiles/r04_conv3_ws_probe.txt) -> opt-in
         const char* c3 = getenv("STRIVE_CONV3_WS");               // (read per call: the tests switch it inside one process)
         const int conv3_ws = c3 ? atoi(c3) : 0;                    // 1: 8 consumer waves x 1 row, 2: 4 consumer waves x 2 rows
         if (conv3_ws == 2 && !cnn->conv2_plain)
