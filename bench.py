@@ -205,7 +205,7 @@ def refine_closure_factory(m, env, batch, map_idx, FT, device):
     return step, emb, g, mi, 1
 
 
-def adv_closure_factory(m, env, batch, map_idx, FT, device):
+def adv_closure_factory(m, env, batch, map_idx, FT, device, on_planner_error='drop'):
     """reference src/utils/adv_gen_optim.py:39-171 in 'ego' planner mode, latents initialised at the posterior mean like
     adv_scenario_gen.py:297-312 does after the init optimisation."""
     from strive_amd.utils.adv_gen_optim import AdvClosure
@@ -224,7 +224,8 @@ def adv_closure_factory(m, env, batch, map_idx, FT, device):
         from strive_amd.planners.hardcode_goalcond_nusc import HardcodeNuscPlanner, CONFIG_DICT
         planner = HardcodeNuscPlanner(env, PlannerConfig(**CONFIG_DICT['default']))
         c = AdvClosure(emb['posterior_out'][0].clone(), 0.05, ADV_WEIGHTS, m, g, env, mi, emb, (pm[ego], pv[ego]),
-                       (pm[~ego], pv[~ego]), 2, 0.0, future_len=FT, veh_coll_buffer=0.1, planner_name='hardcode', planner=planner)
+                       (pm[~ego], pv[~ego]), 2, 0.0, future_len=FT, veh_coll_buffer=0.1, planner_name='hardcode', planner=planner,
+                       on_planner_error=on_planner_error)
 
         from strive_amd.utils.graphed import GraphedIteration
         step = GraphedIteration(c.step, c.graphed)
@@ -278,8 +279,15 @@ def full_pipeline_factory(m, env, batch, map_idx, FT, device, scale=1.0):
         plan_t = np.linspace(m.dt, m.dt * m.FT, m.FT)
         agt_ptr = (g.ptr.cpu() - torch.arange(B + 1)).numpy()
         plan0 = planner.rollout(nrm.unnormalize(fit[~ego]).contiguous(), plan_t, agt_ptr, plan_t).to(g.future_gt)
-        planner.check()
-        init_traj[ego] = nrm.normalize(plan0)
+        # a scene whose planner rollout fails here (NaN plan; the reference's planner raises for it) is given up like the scenes
+        # whose planner collides after the init stage (:323-356): until the batch is rebuilt it is fitted to its own prediction
+        init_failed = planner.check(on_error='report')
+        plan0_n = nrm.normalize(plan0)
+        if init_failed:
+            bad = torch.zeros((B,), dtype=torch.bool, device=device)
+            bad[torch.tensor(sorted(init_failed), device=device)] = True
+            plan0_n = torch.where(bad.view(-1, 1, 1), fit[ego][:, :, :4].detach(), plan0_n)
+        init_traj[ego] = plan0_n
         z, fit, _ = run_init_optim(z, init_traj, g.future_vis, lr, weights, m, g, env, mi, n_fit, emb, emb['prior_out'])
         units += (n_fit + 1) * NA * m.FT
         ptr = g.ptr.cpu().tolist()
@@ -287,10 +295,12 @@ def full_pipeline_factory(m, env, batch, map_idx, FT, device, scale=1.0):
         for b in range(B):
             coll, _ = check_single_veh_coll(nrm.unnormalize(fit[ptr[b]]), att.unnormalize(g.lw[ptr[b]]),
                                             nrm.unnormalize(fit[ptr[b] + 1:ptr[b + 1]]), att.unnormalize(g.lw[ptr[b] + 1:ptr[b + 1]]))
-            bvalid.append(int(np.sum(coll)) == 0)
-        stats['scenes'], stats['planner_collides_after_init'] = B, B - sum(bvalid)
+            bvalid.append(int(np.sum(coll)) == 0 and b not in init_failed)
+        stats['scenes'], stats['planner_collides_after_init'] = B, B - sum(bvalid) - len(init_failed)
+        stats['scenes_dropped'] = {'planner_failed_at_init': len(init_failed), 'planner_failed_in_adv_loop': 0, 'limits': sorted(
+            set(n for v in init_failed.values() for n in v))}
         if sum(bvalid) == 0:
-            raise RuntimeError('the planner collides in every scene of the synthetic batch after the init optimisation')
+            raise RuntimeError('no scene of the synthetic batch is left after the init stage (planner collides or fails in every one)')
         if sum(bvalid) < B:                     # rebuild the batch without those scenes (reference :330-360)
             keep = torch.tensor(bvalid)
             avalid = torch.zeros((NA,), dtype=torch.bool)
@@ -314,17 +324,27 @@ def full_pipeline_factory(m, env, batch, map_idx, FT, device, scale=1.0):
         pm, pv = emb['prior_out']
         tp, op = (pm[ego], pv[ego]), (pm[~ego], pv[~ego])
         planner = HardcodeNuscPlanner(env, PlannerConfig(**CONFIG_DICT['default']))
-        cur_z, fin, _, agt, tt = run_adv_gen_optim(z.clone().detach(), lr, weights, m, g, env, mi, n_adv, emb, 'hardcode', tp, op, 2, 0.0,
-                                                   planner=planner)
+        cur_z, fin, dec_out, agt, tt = run_adv_gen_optim(z.clone().detach(), lr, weights, m, g, env, mi, n_adv, emb, 'hardcode', tp, op, 2,
+                                                         0.0, planner=planner)
         units += (2 * n_adv + 1) * NA * m.FT
+        # scenes the closed loop lost to a failing planner rollout (masked out of the losses on the device from that iteration on):
+        # no success test, no solution stage, no scenario file -- what the reference's run of that scene alone would have produced
+        lost = set(dec_out.get('scenes_dropped', []))
+        stats['scenes_dropped']['planner_failed_in_adv_loop'] = len(lost)
+        stats['scenes_dropped']['limits'] = sorted(set(stats['scenes_dropped']['limits']) | set(
+            n for v in dec_out.get('planner_failures', {}).values() for n in v))
+        stats['scenes_after_adv'] = B - len(lost)
         dl = g.to_data_list()
-        ok = [compute_adv_gen_success(fin[ptr[b]:ptr[b + 1]], m, Batch.from_data_list([dl[b]]), int(agt[b]) - ptr[b]) for b in range(B)]
+        ok = [b not in lost and compute_adv_gen_success(fin[ptr[b]:ptr[b + 1]], m, Batch.from_data_list([dl[b]]), int(agt[b]) - ptr[b])
+              for b in range(B)]
         stats['adv_succeeded'] = int(sum(ok))
         stats['sol_forced'] = False
         if sum(ok) == 0:
             # random-initialised weights rarely yield a successful attack; so that the run still goes through the solution stage
-            # (the reference only enters it for succeeded scenes) the first quarter of the scenes is sent there, and reported
-            ok = [b < max(1, B // 4) for b in range(B)]
+            # (the reference only enters it for succeeded scenes) the first quarter of the surviving scenes is sent there, and reported
+            alive_b = [b for b in range(B) if b not in lost]
+            chosen = set(alive_b[:max(1, len(alive_b) // 4)])
+            ok = [b in chosen for b in range(B)]
             stats['sol_forced'] = True
         stats['sol_scenes'] = int(sum(ok))
         sol_ok = 0
@@ -354,7 +374,7 @@ def full_pipeline_factory(m, env, batch, map_idx, FT, device, scale=1.0):
         stats['units'] = units
         # what the reference writes per scene at adv_scenario_gen.py:465-538 (kept on the device; step.write_scenarios dumps it)
         last.clear()
-        last.update(dict(g=g, mi=mi, init=init_pred, fin=fin, z=cur_z, agt=agt, tt=tt, prior=(pm, pv), ptr=ptr))
+        last.update(dict(g=g, mi=mi, init=init_pred, fin=fin, z=cur_z, agt=agt, tt=tt, prior=(pm, pv), ptr=ptr, lost=lost))
         return torch.tensor(float(stats['adv_succeeded']))
     last = {}
 
@@ -364,14 +384,18 @@ def full_pipeline_factory(m, env, batch, map_idx, FT, device, scale=1.0):
         from strive_amd.utils.scenario_gen import prepare_output_dict
         os.makedirs(out_dir, exist_ok=True)
         dl, ptr = last['g'].to_data_list(), last['ptr']
+        written = 0
         for b in range(len(dl)):
+            if b in last.get('lost', ()):
+                continue
+            written += 1
             lo, hi = ptr[b], ptr[b + 1]
             d = prepare_output_dict(dl[b], int(last['mi'][b]), env, m.dt, m, last['init'][lo:hi], last['fin'][lo:hi, 0],
                                     attack_agt=int(last['agt'][b]) - lo, attack_t=int(last['tt'][b]), adv_z=last['z'][lo:hi],
                                     prior_distrib=(last['prior'][0][lo:hi], last['prior'][1][lo:hi]))
             with open(os.path.join(out_dir, 'scene_%04d.json' % b), 'w') as f:
                 json.dump(d, f)
-        return len(dl)
+        return written
     step.write_scenarios = write_scenarios
     step.stats = stats
     return step, None, batch.to(device), map_idx.to(device), 2
@@ -621,7 +645,7 @@ def time_planner(step, device, reps=5):
     with torch.no_grad():
         out = c.model.decode_embedding(c.collated(), c.embed_info, c.scene_graph, c.map_idx, c.map_env, nfuture=c.future_len)
     t = _event_time(lambda: c.plan(out['future_pred']), reps, warm=1)
-    c.planner.check()
+    c.planner.check(on_error='report')
     lg = next(iter(c.map_env.lane_graphs.values()))
     return {'ms_per_rollout': round(t * 1e3, 3), 'scenes': int(c.scene_graph.ptr.shape[0] - 1), 'planner_steps': 31,
             'lane_graph_nodes': int(lg['xy'].shape[0]), 'lane_graph_edges': int(lg['edges'].shape[0]), 'arithmetic': 'float64',
@@ -806,6 +830,10 @@ def parse_args(argv=None):
     ap.add_argument('--planner', choices=['ego', 'hardcode'], default='ego',
                     help="adv: 'ego' = open loop against the recorded ego future, 'hardcode' = closed loop against the rule-based "
                          "planner (adv_gen_rule_based.cfg)")
+    ap.add_argument('--on-planner-error', choices=['drop', 'raise'], default='drop',
+                    help="closed loop: 'drop' = a scene whose planner rollout fails is masked out of the losses on the device and "
+                         "reported (scenes_dropped); 'raise' = the reference's behaviour, the run ends (planner overlapped under the "
+                         "adversarial half of the iteration)")
     ap.add_argument('--iters', type=float, default=1.0, help='full: scale of the iteration counts 75 / 100 / 200 / 200')
     ap.add_argument('--scenario-out', default='', help='full: directory for the scenario JSON of every scene (reference '
                     'src/adv_scenario_gen.py:465-538 -> prepare_output_dict), written from the device tensors after the timed region')
@@ -871,6 +899,8 @@ def main():
     factory = {'refine': refine_closure_factory, 'train': train_step_factory, 'sample': sample_step_factory}.get(args.workload, adv_closure_factory)
     if args.workload == 'full':
         step, emb, g, mi, rollouts = full_pipeline_factory(m, env, batch, map_idx, args.ft, device, scale=args.iters)
+    elif factory is adv_closure_factory:
+        step, emb, g, mi, rollouts = factory(m, env, batch, map_idx, args.ft, device, on_planner_error=args.on_planner_error)
     else:
         step, emb, g, mi, rollouts = factory(m, env, batch, map_idx, args.ft, device)
     for _ in range(args.warmup):
@@ -897,8 +927,17 @@ def main():
     if args.workload == 'full' and args.scenario_out and rank == 0:
         step.stats['scenarios_written'] = step.write_scenarios(args.scenario_out)
     planner_ms = None
+    scenes_dropped = None
     if getattr(step, 'planner', None) is not None and args.workload != 'full':
-        step.planner.check()               # capacity / range status of every planner rollout of the run (raises)
+        # capacity / range status of every planner rollout of the run, per scene: a scene whose rollout failed (an object pushed off
+        # its lane by these random-weight scenes: the case in which the reference's planner raises) was masked out of the losses on
+        # the device from that iteration on (AdvClosure on_planner_error='drop'); the others ran on as in a batch without it
+        failed_scenes = step.planner.check(on_error='report' if args.on_planner_error == 'drop' else 'raise')
+        scenes_dropped = {'count': len(failed_scenes), 'of': int(g.ptr.shape[0] - 1), 'scenes': sorted(failed_scenes),
+                          'agents': int(sum(int(g.ptr[b + 1] - g.ptr[b]) for b in failed_scenes)),
+                          'limits': sorted(set(n for v in failed_scenes.values() for n in v)),
+                          'note': 'units count every scene of the batch: a dropped scene is still rolled out and planned, only its '
+                                  'loss terms and gradients are masked'}
         planner_ms = time_planner(step, device)
     dt = dt_local
     NA = int(g.past.shape[0])
@@ -958,6 +997,7 @@ def main():
         'final_loss': float(loss.detach().cpu()),
         'host_enqueue_ms_per_step': round(dt_host / args.steps * 1e3, 3),     # diagnostic: the host has queued everything by then
         'planner': None if planner_ms is None else planner_ms,
+        'scenes_dropped': scenes_dropped if args.workload != 'full' else step.stats.get('scenes_dropped'),
         'pipeline': dict(step.stats) if args.workload == 'full' else None,
         'per_rank': [{'rank': r, 'agents': a, 'ms_per_step': t, 'device': d, 'local_rank': lr} for r, a, t, d, lr in per_rank],
         # what the collective backend saw (N > 1: RCCL = torch.distributed 'nccl'): world size it reports and the distinct devices

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define STRIVE_ABI_VERSION 14
+#define STRIVE_ABI_VERSION 15
 #define STRIVE_HID 128        /* hidden width of every MLP in the reference (models/common.py, interaction_net.py:32,41) */
 #define STRIVE_MAX_LAYERS 4
 #define STRIVE_ZDIM 32
@@ -379,6 +379,11 @@ typedef struct StriveAdvGen {
     const int32_t* ne_ptr;       /* (B+1)  offsets of every scene's non-ego agents in the non-ego order */
     const int32_t* slot_ne;      /* (P)    non-ego row of the non-ego member of a pair slot that involves the scene's ego, else -1 */
     const uint8_t* atk_mask;     /* (NE)   1 = may be the attacker (attack_agt_idx, :126-130), or NULL = everybody */
+    const uint8_t* scene_alive;  /* (B) or NULL.  0 = the scene has left the batch (closed loop: its planner rollout failed,
+                                    strive_planner_rollout's `alive`): it contributes to no sum and no count -- colliding pairs,
+                                    off-road rows, prior / init rows, crash term, the 1/NE and 1/B of the two means -- and receives
+                                    zero gradients; the other scenes get exactly the values of the batch rebuilt without it
+                                    (the reference's remedy for scenes it gives up, adv_scenario_gen.py:323-356) */
     int32_t t0;                  /* crash_loss_min_time */
     int32_t use_infront;         /* crash_loss_min_infront given? */
     float infront;
@@ -544,12 +549,17 @@ size_t strive_planner_workspace_bytes(const StrivePlanner* pl, int32_t nstep, in
  * Per planner step: lane matching / clustering / breadth-first route enumeration / blended arc-length routes for every
  * object (compute_splines, :559-598), 5-circle gaps between the ego's candidate speed profiles and every predicted
  * trajectory (compute_action, :829-857), world update (update_wstate, :601-621).
- * status (STRIVE_PLANNER_NSTATUS int32, device, zeroed by the caller): non-zero entries name a capacity or range
- * violation (0 matches, 1 clusters, 2 chains, 3 chain nodes, 4 knots, 5 route range, 6 trajectory cap, 7 action check);
- * the plan of an affected scene is NaN. */
+ * status (B, STRIVE_PLANNER_NSTATUS) int32 on the device, zeroed by the caller once and then only ever SET by the kernels
+ * (sticky over rollouts): a non-zero entry of row b names a capacity or range violation in scene b (0 matches, 1 clusters,
+ * 2 chains, 3 chain nodes, 4 knots, 5 route range, 6 trajectory cap, 7 action check) -- the cases in which the reference's
+ * numpy planner raises (interp1d bounds, :411-428; the speed assertion, :659-666), which there ends the run of that scene
+ * (adv_scenario_gen.py:540-543 with the shipped batch_size 1).  The plan of an affected scene is NaN; every other scene of
+ * the batch is planned as if the failing one were not there (scenes share nothing but this call).
+ * alive (B) uint8 or NULL: written last, alive[b] = (row b of status is all zero) -- the device-side mask the closed loop
+ * hands to strive_adv_gen_fwd (StriveAdvGen.scene_alive) so that a failed scene leaves the losses without a host round trip. */
 int strive_planner_rollout(const StrivePlanner* pl, const double* agent_obs, const double* agent_t, int32_t T,
                            const double* t_out, int32_t nstep, const double* planner_t, int32_t TP, int32_t traj_cap,
-                           double* plan, int32_t* status, void* ws, size_t ws_bytes, strive_stream_t stream);
+                           double* plan, int32_t* status, uint8_t* alive, void* ws, size_t ws_bytes, strive_stream_t stream);
 
 /* Debug view used by the parity tests: routes of one object pose (x, y, h, s) on map `mapix` as the planner builds them.
  * Outputs: nroutes (1), nk (maxr) knots per route, knots (maxr, maxk, 5) = s, x, y, cos, sin. */

@@ -80,7 +80,7 @@ class StriveAvoidColl(C.Structure):
 
 class StriveAdvGen(C.Structure):
     _fields_ = [('base', StriveAvoidColl), ('ne_ptr', C.c_void_p), ('slot_ne', C.c_void_p), ('atk_mask', C.c_void_p),
-                ('t0', C.c_int32), ('use_infront', C.c_int32), ('infront', C.c_float), ('w_crash', C.c_float),
+                ('scene_alive', C.c_void_p), ('t0', C.c_int32), ('use_infront', C.c_int32), ('infront', C.c_float), ('w_crash', C.c_float),
                 ('w_plan', C.c_float), ('w_prior_atk', C.c_float), ('w_init_atk', C.c_float)]
 
 
@@ -177,12 +177,12 @@ PROTOTYPES = {
     'strive_bicycle_step': (C.c_int, [C.POINTER(StriveDecoder), P, P, P, P, P, P, P, I, P]),
     'strive_rel_pose': (C.c_int, [P, P, P, P, P, P, I, I, P]),
     'strive_planner_workspace_bytes': (SZ, [C.POINTER(StrivePlanner), I, I]),
-    'strive_planner_rollout': (C.c_int, [C.POINTER(StrivePlanner), P, P, I, P, I, P, I, I, P, P, P, SZ, P]),
+    'strive_planner_rollout': (C.c_int, [C.POINTER(StrivePlanner), P, P, I, P, I, P, I, I, P, P, P, P, SZ, P]),
     'strive_planner_routes': (C.c_int, [C.POINTER(StrivePlanner), I, P, I, I, P, P, P, P, P]),
 }
 
 
-ABI_VERSION = 14   # include/strive_hip.h STRIVE_ABI_VERSION
+ABI_VERSION = 15   # include/strive_hip.h STRIVE_ABI_VERSION
 
 
 class StriveLib(object):

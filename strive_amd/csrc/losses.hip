@@ -19,6 +19,8 @@ struct VehArgs {
     const float* cent_x;   // (NA, 5)
     const float* rad;      // (NA)
     float buffer;
+    const uint8_t* alive;  // (B) or null: pairs of a scene with alive == 0 are written as "not colliding" (AdvGenLoss with a
+                           // quarantined scene, StriveAdvGen.scene_alive): they then enter neither a sum, a count nor a gradient
 };
 
 // world-frame circle centres of agent a at time t: transform2frame(inverse) of (cx, 0)
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void veh_coll_fwd_kernel(VehArgs a, float* __r
         if (am == NCIRC * NCIRC) am = 0;
         const float pd = (ri + a.rad[j]) + a.buffer;
         pen[base + jl] = 1.0f - dmin / pd;
-        hit[base + jl] = (j != i && dmin <= pd) ? 1 : 0;
+        hit[base + jl] = (j != i && dmin <= pd && !(a.alive && !a.alive[b])) ? 1 : 0;
         amin[base + jl] = (uint8_t)am;
     }
 }
@@ -188,21 +190,28 @@ static VehArgs veh_args(const StriveScenes* sc, const int32_t* pair_off, int P, 
                         const float* cent_x, const float* rad, float buffer) {
     VehArgs a;
     a.NA = sc->NA; a.T = T; a.P = P; a.ptr = sc->ptr; a.scene_of = sc->scene_of; a.pair_off = pair_off;
-    a.traj = traj; a.cent_x = cent_x; a.rad = rad; a.buffer = buffer;
+    a.traj = traj; a.cent_x = cent_x; a.rad = rad; a.buffer = buffer; a.alive = nullptr;
     return a;
+}
+
+static int veh_coll_fwd_masked(const StriveScenes* sc, const int32_t* pair_off, int32_t P, const float* traj, int32_t T,
+                               const float* cent_x, const float* rad, float buffer, const uint8_t* scene_alive, float* pen,
+                               uint8_t* hit, uint8_t* amin, strive_stream_t stream) {
+    STRIVE_CHECK_ARG(sc && pair_off && traj && cent_x && rad && pen && hit && amin, "null argument");
+    STRIVE_CHECK_ARG(sc->NS == 1, "collision losses take one trajectory per agent");
+    const long long n = (long long)sc->NA * T * VG;
+    if (n <= 0) return 0;
+    VehArgs a = veh_args(sc, pair_off, P, traj, T, cent_x, rad, buffer);
+    a.alive = scene_alive;
+    hipLaunchKernelGGL(veh_coll_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, pen, hit, amin);
+    STRIVE_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int strive_veh_coll_fwd(const StriveScenes* sc, const int32_t* pair_off, int32_t P, const float* traj, int32_t T,
                                    const float* cent_x, const float* rad, float buffer, float* pen, uint8_t* hit,
                                    uint8_t* amin, strive_stream_t stream) {
-    STRIVE_CHECK_ARG(sc && pair_off && traj && cent_x && rad && pen && hit && amin, "null argument");
-    STRIVE_CHECK_ARG(sc->NS == 1, "collision losses take one trajectory per agent");
-    const long long n = (long long)sc->NA * T * VG;
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(veh_coll_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       veh_args(sc, pair_off, P, traj, T, cent_x, rad, buffer), pen, hit, amin);
-    STRIVE_CHECK_LAUNCH();
-    return 0;
+    return veh_coll_fwd_masked(sc, pair_off, P, traj, T, cent_x, rad, buffer, nullptr, pen, hit, amin, stream);
 }
 
 extern "C" int strive_veh_coll_bwd(const StriveScenes* sc, const int32_t* pair_off, int32_t P, const float* traj, int32_t T,
@@ -449,6 +458,8 @@ struct AvoidArgs {
     const float* pdist;
     const float *z, *mu, *var, *init_z;
     float w_veh, w_env, w_prior, w_init;
+    const uint8_t* scene_alive;     // (B) or null; AdvGenLoss only (a quarantined scene's rows count as "no collision point")
+    const int32_t* scene_of;        // (NA)
 };
 
 // off-road penalty of row (e, t): 1 - |c - p| / r for rows with a collision point (reference :384-403)
@@ -456,6 +467,7 @@ __device__ __forceinline__ bool env_row(const AvoidArgs& a, int row, float& dx, 
     const float px = a.pt[(size_t)row * 2], py = a.pt[(size_t)row * 2 + 1];
     if (!(px + py == px + py)) return false;      // NaN point = no collision point
     const int e = row / a.TO, t = row - e * a.TO;
+    if (a.scene_alive && !a.scene_alive[a.scene_of[a.env_agent[e]]]) return false;
     const float* c = a.fine + ((size_t)a.env_agent[e] * a.TO + t) * 4;
     dx = c[0] - px;
     dy = c[1] - py;
@@ -592,6 +604,7 @@ static AvoidArgs avoid_args(const StriveScenes* sc, const StriveAvoidColl* h, co
     a.env_agent = h->env_agent; a.pt = w.pt; a.pdist = h->env_pdist;
     a.z = z; a.mu = mu; a.var = var; a.init_z = h->init_z;
     a.w_veh = h->w_veh; a.w_env = h->w_env; a.w_prior = h->w_prior; a.w_init = h->w_init;
+    a.scene_alive = nullptr; a.scene_of = sc->scene_of;
     return a;
 }
 
@@ -695,6 +708,7 @@ extern "C" int strive_avoid_coll_bwd(const StriveScenes* sc, const StriveAvoidCo
 // per-scene flag; the kernels after it form the batch-wide AND themselves and pick the variant.
 // =============================================================================================
 #define ADV_TERMS 8         // veh sum, veh count, env sum, env count, weighted prior sum, weighted init sum, planner sum, planner count
+#define ADV_SUMS 10         // sums[]: the terms above, then [8] latent rows and [9] scenes that are alive (all of them without a mask)
 #define ADV_MAXE 1024       // (non-ego agents of a scene) x (crash time samples) the crash kernel keeps in LDS
 
 struct AdvWs {
@@ -721,7 +735,7 @@ static AdvWs adv_carve(void* p, size_t bytes, size_t NA, size_t TO, size_t P, si
     w.av = avoid_carve(p, ab, NA, TO, P, NE);
     StriveArena ar((char*)p + ab, bytes - ab);
     w.partial = ar.take<double>((size_t)AV_BLOCKS * ADV_TERMS);
-    w.sums = ar.take<double>(ADV_TERMS);
+    w.sums = ar.take<double>(ADV_SUMS);
     w.soft2 = ar.take<float>(2 * NE * NT);
     w.rew2 = ar.take<float>(2 * NE);
     w.crash2 = ar.take<float>(2 * B);
@@ -741,6 +755,7 @@ struct AdvArgs {
     const int32_t* nonego;      // (NE) agent index
     const int32_t* slot_ne;
     const uint8_t* atk_mask;
+    const uint8_t* scene_alive;     // (B) or null
     float w_crash, w_plan, w_prior_atk, w_init_atk;
     float* soft2;
     float* rew2;
@@ -774,6 +789,17 @@ __global__ __launch_bounds__(256) void adv_crash_kernel(AdvArgs A) {
     __shared__ float s_redf[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int a0 = A.ne_ptr[b], n = A.ne_ptr[b + 1] - a0, NT = A.NT, E = n * NT;
+    if (A.scene_alive && !A.scene_alive[b]) {
+        // quarantined scene (its planner failed, StriveAdvGen.scene_alive): no crash term, no soft-min weights, re-weights 1, and
+        // like an empty scene it does not veto the batch-wide "everybody is behind" test
+        for (int v = 0; v < 2; ++v) {
+            for (int e = tid; e < E; e += 256) A.soft2[((size_t)v * A.a.NE + a0) * NT + e] = 0.f;
+            for (int al = tid; al < n; al += 256) A.rew2[(size_t)v * A.a.NE + a0 + al] = 1.0f;
+            if (tid == 0) A.crash2[(size_t)v * A.B + b] = 0.f;
+        }
+        if (tid == 0) A.scene_flag[b] = 1;
+        return;
+    }
     if (tid < 64) s_nb[tid] = 0;
     __syncthreads();
     for (int e = tid; e < E; e += 256) {
@@ -886,6 +912,7 @@ __global__ __launch_bounds__(256) void adv_partial_kernel(AdvArgs A, double* __r
         const long long n = (long long)a.NZ * a.D;
         for (long long i = g0; i < n; i += stride) {
             const int r = (int)(i / a.D);
+            if (A.scene_alive && !A.scene_alive[a.scene_of[A.nonego[r]]]) continue;
             const float rw = rew[r];
             const float z = a.z[i];
             if (a.w_prior > 0.f) {
@@ -912,7 +939,7 @@ __global__ __launch_bounds__(64) void adv_final_kernel(AdvArgs A, const double* 
                                                          double* __restrict__ sums, int32_t* __restrict__ sel_out,
                                                          float* __restrict__ out, float* __restrict__ soft,
                                                          float* __restrict__ rew) {
-    __shared__ double s[ADV_TERMS + 1];
+    __shared__ double s[ADV_TERMS + 3];
     const AvoidArgs& a = A.a;
     const int tid = threadIdx.x;
     const int sel = adv_select(A.scene_flag, A.B, A.use_infront, tid);
@@ -923,10 +950,15 @@ __global__ __launch_bounds__(64) void adv_final_kernel(AdvArgs A, const double* 
         if (tid == 0) { s[k] = v; sums[k] = v; }
     }
     {
-        double v = 0.0;
-        for (int b = tid; b < A.B; b += 64) v += (double)A.crash2[(size_t)sel * A.B + b];
+        double v = 0.0, rows = 0.0, scenes = 0.0;
+        for (int b = tid; b < A.B; b += 64) {
+            v += (double)A.crash2[(size_t)sel * A.B + b];
+            if (!A.scene_alive || A.scene_alive[b]) { scenes += 1.0; rows += (double)(A.ne_ptr[b + 1] - A.ne_ptr[b]); }
+        }
         v = wave_sum_d(v);
-        if (tid == 0) s[ADV_TERMS] = v;
+        rows = wave_sum_d(rows);
+        scenes = wave_sum_d(scenes);
+        if (tid == 0) { s[ADV_TERMS] = v; s[ADV_TERMS + 1] = rows; s[ADV_TERMS + 2] = scenes; sums[8] = rows; sums[9] = scenes; }
     }
     // the selected soft-min weights and re-weights, for the caller (return_mins, logging)
     for (long long i = tid; i < (long long)a.NE * A.NT; i += 64) soft[i] = A.soft2[(size_t)sel * a.NE * A.NT + i];
@@ -940,9 +972,11 @@ __global__ __launch_bounds__(64) void adv_final_kernel(AdvArgs A, const double* 
         const double veh = s[0] / (s[1] < 1.0 ? 1.0 : s[1]);
         const double env = s[2] / (s[3] < 1.0 ? 1.0 : s[3]);
         const double plan = s[6] / (s[7] < 1.0 ? 1.0 : s[7]);
-        const double pri = a.NZ > 0 ? s[4] / (double)a.NZ : 0.0;
+        // means over the latent rows / scenes that are in the batch: all of them, or the alive ones (= the batch rebuilt
+        // without the quarantined scenes, which is what the reference's batch_size-1 runs amount to)
+        const double pri = s[ADV_TERMS + 1] > 0.0 ? s[4] / s[ADV_TERMS + 1] : 0.0;
         const double ini = s[5];
-        const double crash = A.B > 0 ? s[ADV_TERMS] / (double)A.B : 0.0;
+        const double crash = s[ADV_TERMS + 2] > 0.0 ? s[ADV_TERMS] / s[ADV_TERMS + 2] : 0.0;
         double loss = 0.0;
         if (a.w_init > 0.f) loss += ini;
         if (a.w_prior > 0.f) loss += pri;
@@ -995,11 +1029,14 @@ __global__ __launch_bounds__(256) void adv_grad_kernel(AdvArgs A, const int32_t*
     }
     const long long i = idx - n_rows;
     if (i < (long long)a.NZ * a.D) {
-        const float rw = A.rew_sel[(int)(i / a.D)];
+        const int r = (int)(i / a.D);
+        const float rw = A.rew_sel[r];
         const float z = a.z[i];
         float g = 0.f;
-        if (a.w_prior > 0.f) g += gl * (rw * a.w_prior + (1.0f - rw) * A.w_prior_atk) / (float)a.NZ * ((z - a.mu[i]) / a.var[i]);
-        if (a.w_init > 0.f) g += gl * (rw * a.w_init + (1.0f - rw) * A.w_init_atk) * (2.0f * (z - a.init_z[i]));
+        if (!(A.scene_alive && !A.scene_alive[a.scene_of[A.nonego[r]]])) {
+            if (a.w_prior > 0.f) g += gl * (rw * a.w_prior + (1.0f - rw) * A.w_prior_atk) / (float)sums[8] * ((z - a.mu[i]) / a.var[i]);
+            if (a.w_init > 0.f) g += gl * (rw * a.w_init + (1.0f - rw) * A.w_init_atk) * (2.0f * (z - a.init_z[i]));
+        }
         d_z[i] = g;
     }
 }
@@ -1007,7 +1044,7 @@ __global__ __launch_bounds__(256) void adv_grad_kernel(AdvArgs A, const int32_t*
 // crash term: L = w/B sum_b sum_e s_e d_e^2 with s = softmin(d) over the scene's unmasked entries
 //   dL/dd_e = w/B * s_e * (2 d_e + C_b - d_e^2),  C_b = sum_e s_e d_e^2;   dd/d(atk xy) = (atk - tgt) / d = -dd/d(tgt xy)
 // one workgroup per scene: adds into d_traj (non-ego rows, time >= t0; interp_bwd has written them) and writes d_tgt
-__global__ __launch_bounds__(256) void adv_crash_bwd_kernel(AdvArgs A, const int32_t* __restrict__ sel_p,
+__global__ __launch_bounds__(256) void adv_crash_bwd_kernel(AdvArgs A, const int32_t* __restrict__ sel_p, const double* __restrict__ sums,
                                                               const float* __restrict__ d_loss, float* __restrict__ d_traj,
                                                               float* __restrict__ d_tgt) {
     __shared__ float s_gx[ADV_MAXE], s_gy[ADV_MAXE];
@@ -1015,7 +1052,7 @@ __global__ __launch_bounds__(256) void adv_crash_bwd_kernel(AdvArgs A, const int
     const int sel = sel_p[0];
     const int a0 = A.ne_ptr[b], n = A.ne_ptr[b + 1] - a0, NT = A.NT, E = n * NT;
     const float C = A.crash2[(size_t)sel * A.B + b];
-    const float gw = A.w_crash > 0.f ? d_loss[0] * A.w_crash / (float)A.B : 0.f;
+    const float gw = A.w_crash > 0.f ? d_loss[0] * A.w_crash / (float)sums[9] : 0.f;      // (a quarantined scene has soft == 0 throughout)
     for (int e = tid; e < E; e += 256) {
         const int al = e / NT, t = e - al * NT;
         float* gp = d_traj + ((size_t)A.nonego[a0 + al] * A.T + A.t0 + t) * 4;
@@ -1064,6 +1101,7 @@ static AdvArgs adv_args(const StriveScenes* sc, const StriveAdvGen* h, const Adv
     A.a = avoid_args(sc, &h->base, w.av, T * h->base.scale, z, mu, var);
     A.B = sc->B; A.T = T; A.t0 = h->t0; A.NT = T - h->t0; A.use_infront = h->use_infront; A.infront = h->infront;
     A.traj = traj; A.tgt = tgt; A.ne_ptr = h->ne_ptr; A.nonego = h->base.env_agent; A.slot_ne = h->slot_ne; A.atk_mask = h->atk_mask;
+    A.scene_alive = h->scene_alive; A.a.scene_alive = h->scene_alive;
     A.w_crash = h->w_crash; A.w_plan = h->w_plan; A.w_prior_atk = h->w_prior_atk; A.w_init_atk = h->w_init_atk;
     A.soft2 = w.soft2; A.rew2 = w.rew2; A.crash2 = w.crash2; A.scene_flag = w.scene_flag; A.rew_sel = w.rew_sel;
     return A;
@@ -1090,8 +1128,8 @@ extern "C" int strive_adv_gen_fwd(const StriveScenes* sc, const StriveMap* map, 
     if (NA > 0) {
         if (int rc = strive_interp_traj_fwd(traj, NA, T, TO, hb->i0, hb->i1, hb->w0, hb->w1, w.av.fine, stream)) return rc;
         if (veh)
-            if (int rc = strive_veh_coll_fwd(sc, hb->pair_off, hb->P, w.av.fine, TO, hb->cent_x, hb->rad, hb->buffer, w.av.pen,
-                                             w.av.hit, w.av.amin, stream))
+            if (int rc = veh_coll_fwd_masked(sc, hb->pair_off, hb->P, w.av.fine, TO, hb->cent_x, hb->rad, hb->buffer, h->scene_alive,
+                                             w.av.pen, w.av.hit, w.av.amin, stream))
                 return rc;
         if (hb->w_env > 0.f && hb->NE > 0)
             if (int rc = strive_coll_point_rows(map, w.av.fine, TO, hb->env_agent, hb->env_lw, hb->env_mapix, hb->NE, hb->gl, hb->gw,
@@ -1147,7 +1185,8 @@ extern "C" int strive_adv_gen_bwd(const StriveScenes* sc, const StriveAdvGen* h,
     }
     if (int rc = strive_interp_traj_bwd(traj, w.av.d_fine, NA, T, TO, hb->scale, hb->i0, hb->i1, hb->w0, hb->w1, d_traj, stream)) return rc;
     if (sc->B > 0) {
-        hipLaunchKernelGGL(adv_crash_bwd_kernel, dim3(sc->B), dim3(256), 0, st, A, (const int32_t*)w.sel, d_loss, d_traj, d_tgt);
+        hipLaunchKernelGGL(adv_crash_bwd_kernel, dim3(sc->B), dim3(256), 0, st, A, (const int32_t*)w.sel, (const double*)w.sums, d_loss, d_traj,
+                           d_tgt);
         STRIVE_CHECK_LAUNCH();
     }
     return 0;

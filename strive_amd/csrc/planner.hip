@@ -46,6 +46,7 @@ constexpr int NCHUNK = 16;      // trajectory chunks per scene in the gap kernel
 constexpr double LANE_DS = 0.4, LANE_SIG2 = 3.5 * 3.5, SBUFFER = 4.0;   // constants of rollout() (:211-213)
 
 enum { ST_MATCH = 0, ST_KEEP = 1, ST_CHAIN = 2, ST_NODES = 3, ST_KNOTS = 4, ST_RANGE = 5, ST_TRAJ = 6, ST_ACT = 7 };
+constexpr int NSTATUS = STRIVE_PLANNER_NSTATUS;
 
 template <int NCH, int NPOOL>
 struct ChainTab {
@@ -563,7 +564,9 @@ __device__ int for_each_route(RouteLds& R, const StrivePlannerMap& mp, const Str
     return nkept;
 }
 
-__global__ void __launch_bounds__(64) planner_routes_kernel(StrivePlanner pl, Work w, int32_t* status) {
+// `status` of the rollout kernels is (B, 8): a kernel offsets it to its scene's row before anything can set a flag, so a capacity
+// or range violation poisons (and is reported for) the scene it happened in and no other
+__global__ void __launch_bounds__(64) planner_routes_kernel(StrivePlanner pl, Work w, int32_t* status_all) {
     __shared__ RouteLds R;
     __shared__ double pd[MAXPRED][MAXNT];
     __shared__ int slot_base;
@@ -574,6 +577,7 @@ __global__ void __launch_bounds__(64) planner_routes_kernel(StrivePlanner pl, Wo
     const double* ws = w.wstate + ((size_t)r * w.K + k) * 4;
     const Pose o = {ws[0], ws[1], ws[2], ws[3]};
     const int b = pl.row_scene[r];
+    int32_t* status = status_all + NSTATUS * (size_t)b;
     const double* in = pl.init + 6 * (size_t)pl.row_obj[r];
     const double l = in[4], wd = in[5];
     const StrivePlannerCfg& cfg = pl.cfg;
@@ -647,12 +651,13 @@ __device__ __forceinline__ void box_circles(double x, double y, double h, double
     cx[4] = x; cy[4] = y;
 }
 
-__global__ void __launch_bounds__(256) planner_ego_kernel(StrivePlanner pl, Work w, int k, int32_t* status) {
+__global__ void __launch_bounds__(256) planner_ego_kernel(StrivePlanner pl, Work w, int k, int32_t* status_all) {
     __shared__ RouteLds R;
     __shared__ double pdist[MAXPROF][MAXNT];        // distances of the profiles; before that, (1 - pr) of step k-1's profiles
     __shared__ double risk[MAXPROF];
     const int lane = lane_id(), tid = threadIdx.x, nthr = blockDim.x;
     const int b = blockIdx.x;
+    int32_t* status = status_all + NSTATUS * (size_t)b;
     const StrivePlannerCfg& cfg = pl.cfg;
     const StrivePlannerMap& mp = pl.maps[pl.scene_map[b]];
     double* eg = w.ego + 8 * (size_t)b;
@@ -902,13 +907,23 @@ __global__ void planner_interp_kernel(Work w, int B, const double* __restrict__ 
     const int b = i / TP, j = i % TP;
     const double q = planner_t[j];
     double* out = plan + (size_t)i * 4;
-    if (q < t_out[0] || q > t_out[w.K - 1]) { flag(status, ST_RANGE); out[0] = out[1] = out[2] = out[3] = NAN; return; }
+    if (q < t_out[0] || q > t_out[w.K - 1]) { flag(status + NSTATUS * (size_t)b, ST_RANGE); out[0] = out[1] = out[2] = out[3] = NAN; return; }
     const int hi = knot_hi(t_out, w.K, q), lo = hi - 1;
     const double* po = w.poses + (size_t)b * w.K * 4;
     for (int c = 0; c < 4; ++c) {
         const double slope = (po[4 * hi + c] - po[4 * lo + c]) / (t_out[hi] - t_out[lo]);
         out[c] = slope * (q - t_out[lo]) + po[4 * lo + c];
     }
+}
+
+// alive[b] = no flag of scene b is set -- by this rollout or any earlier one since the caller zeroed the status (the flags are
+// sticky).  The optimisation loop masks a scene with alive == 0 out of its losses without a host round trip.
+__global__ void planner_alive_kernel(int B, const int32_t* __restrict__ status, uint8_t* __restrict__ alive) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int any = 0;
+    for (int i = 0; i < NSTATUS; ++i) any |= status[NSTATUS * (size_t)b + i];
+    alive[b] = any == 0;
 }
 
 __global__ void __launch_bounds__(64) planner_routes_debug_kernel(StrivePlanner pl, int mapix, const double* __restrict__ pose4, int maxr, int maxk,
@@ -993,7 +1008,8 @@ extern "C" size_t strive_planner_workspace_bytes(const StrivePlanner* pl, int32_
 
 extern "C" int strive_planner_rollout(const StrivePlanner* pl, const double* agent_obs, const double* agent_t, int32_t T,
                                       const double* t_out, int32_t nstep, const double* planner_t, int32_t TP, int32_t traj_cap,
-                                      double* plan, int32_t* status, void* ws, size_t ws_bytes, strive_stream_t stream_) {
+                                      double* plan, int32_t* status, uint8_t* alive, void* ws, size_t ws_bytes,
+                                      strive_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (check_cfg(pl, nstep, traj_cap)) return -1;
     STRIVE_CHECK_ARG(plan && status && ws && t_out && planner_t && TP >= 1, "null argument");
@@ -1018,6 +1034,7 @@ extern "C" int strive_planner_rollout(const StrivePlanner* pl, const double* age
     }
     hipLaunchKernelGGL(planner_interp_kernel, dim3((pl->B * TP + 63) / 64), dim3(64), 0, stream, w, (int)pl->B, t_out, planner_t, (int)TP,
                        plan, status);
+    if (alive) hipLaunchKernelGGL(planner_alive_kernel, dim3((pl->B + 63) / 64), dim3(64), 0, stream, (int)pl->B, (const int32_t*)status, alive);
     STRIVE_CHECK_LAUNCH();
     return 0;
 }

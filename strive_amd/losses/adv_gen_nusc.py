@@ -154,18 +154,31 @@ class TgtMatchingLoss(nn.Module):
         self.loss_weights = loss_weights
         self.motion_prior_loss = MotionPriorLoss()
 
-    def forward(self, future_pred, tgt_traj, z, prior_out):
+    def forward(self, future_pred, tgt_traj, z, prior_out, scene_alive=None):
+        """``scene_alive`` (B,) uint8 / bool on the device or None (not in the reference): scenes with 0 have left the batch --
+        their target may be NaN (a failed planner rollout), they add nothing to the mean, their rows get zero gradients and the
+        mean's denominator counts the alive scenes only, i.e. the other scenes see the batch rebuilt without them."""
         out = LossDict()
         loss = 0.0
         tgt_loss = None
+        alive = None
+        if scene_alive is not None:
+            alive = scene_alive.to(torch.bool).view(-1, *([1] * (future_pred.dim() - 1)))
+            tgt_traj = torch.where(alive, tgt_traj, future_pred.detach())          # (no NaN may reach the subtraction's backward)
+
+        def mean(v):
+            if alive is None:
+                return v.mean()
+            per_scene = v[0].numel()
+            return v.sum() / torch.clamp(scene_alive.sum() * per_scene, min=1).to(v.dtype)
         if self.loss_weights['match_ext'] > 0.0:
             tgt_loss = torch.sum((future_pred - tgt_traj) ** 2, dim=-1)
-            loss = loss + self.loss_weights['match_ext'] * tgt_loss.mean()
+            loss = loss + self.loss_weights['match_ext'] * mean(tgt_loss)
             out['match_ext_loss'] = tgt_loss
         if self.loss_weights['motion_prior_ext'] > 0.0:
             # reported but never part of the objective (reference :46 adds the matching term again): evaluated when read
             out.set_lazy('motion_prior_ext_loss', lambda: self.motion_prior_loss(z, prior_out))
-            loss = loss + self.loss_weights['motion_prior_ext'] * tgt_loss.mean()
+            loss = loss + self.loss_weights['motion_prior_ext'] * mean(tgt_loss)
         out['loss'] = loss
         return out
 
@@ -415,6 +428,7 @@ class AdvGenLoss(nn.Module):
         nonego_index = torch.cumsum((~self.ego_mask).to(torch.long), 0) - 1
         self.slot_i_ne, self.slot_j_ne = nonego_index[vl.slot_i], nonego_index[vl.slot_j]
         self.slot_i_ego, self.slot_j_ego = self.ego_mask[vl.slot_i], self.ego_mask[vl.slot_j]
+        self.slot_scene = torch.repeat_interleave(torch.arange(self.B), self.graph_sizes).to(dev)[vl.slot_i]      # (P,) scene of a pair slot
         self._fused = None
         self._fused_sig = None
 
@@ -455,24 +469,32 @@ class AdvGenLoss(nn.Module):
         return (w.get('adv_crash', 0.0) > 0.0 and future_pred.dim() == 3 and tgt_traj.dim() == 3 and z.dim() == 2 and NT > 0 and
                 nmax <= 64 and nmax * NT <= 1024 and not prior_out[0].requires_grad and not prior_out[1].requires_grad)
 
-    def forward(self, future_pred, tgt_traj, z, prior_out, return_mins=False, attack_agt_idx=None):
+    def forward(self, future_pred, tgt_traj, z, prior_out, return_mins=False, attack_agt_idx=None, scene_alive=None):
         """One HIP call forward, one backward (strive_adv_gen_fwd/bwd) for the objective; the per-term entries of the
-        reference's dict are evaluated by ``forward_terms`` only when somebody reads them (logging)."""
+        reference's dict are evaluated by ``forward_terms`` only when somebody reads them (logging).
+        ``scene_alive`` (B,) uint8 on the device or None (not in the reference): scenes with 0 have left the batch (closed loop:
+        their planner rollout failed) -- every sum, count and mean is the one of the batch rebuilt without them, their agents get
+        zero gradients, ``tgt_traj`` may be NaN for them."""
+        if scene_alive is not None:
+            scene_alive = scene_alive.to(torch.uint8).contiguous()
+            tgt_traj = torch.where(scene_alive.to(torch.bool).view(-1, 1, 1), tgt_traj, torch.zeros_like(tgt_traj))
         if not self._fusable(future_pred, tgt_traj, z, prior_out):
-            return self.forward_terms(future_pred, tgt_traj, z, prior_out, return_mins=return_mins, attack_agt_idx=attack_agt_idx)
+            return self.forward_terms(future_pred, tgt_traj, z, prior_out, return_mins=return_mins, attack_agt_idx=attack_agt_idx,
+                                      scene_alive=scene_alive)
         w = self.loss_weights
         loss, _, soft, _ = ops.adv_gen_loss(future_pred, tgt_traj, z, prior_out[0], prior_out[1], self._setup(),
-                                            attack_agt_idx=attack_agt_idx)
+                                            attack_agt_idx=attack_agt_idx, scene_alive=scene_alive)
         out = LossDict()
         terms = {}
 
         fp_s, tg_s, z_s = future_pred.detach(), tgt_traj.detach(), z.detach().clone()      # snapshot: see AvoidCollLoss.forward
+        alive_s = None if scene_alive is None else scene_alive.clone()
 
         def term(key):
             def thunk():
                 if not terms:
                     with torch.no_grad():
-                        ft = self.forward_terms(fp_s, tg_s, z_s, prior_out, attack_agt_idx=attack_agt_idx)
+                        ft = self.forward_terms(fp_s, tg_s, z_s, prior_out, attack_agt_idx=attack_agt_idx, scene_alive=alive_s)
                         for k in list(ft.keys()):
                             terms[k] = ft[k]
                 return terms[key]
@@ -496,13 +518,20 @@ class AdvGenLoss(nn.Module):
             out['min_t'] = np.array(cur_min_t, dtype=int)
         return out
 
-    def forward_terms(self, future_pred, tgt_traj, z, prior_out, return_mins=False, attack_agt_idx=None):
-        """The same objective term by term with torch glue between the HIP kernels (reference :105-262)."""
+    def forward_terms(self, future_pred, tgt_traj, z, prior_out, return_mins=False, attack_agt_idx=None, scene_alive=None):
+        """The same objective term by term with torch glue between the HIP kernels (reference :105-262).  With ``scene_alive``
+        (see ``forward``) every term is restricted to the agents / pairs / scenes that are still in the batch."""
         w = self.loss_weights
         NA, B = future_pred.size(0), tgt_traj.size(0)
         dev = future_pred.device
         crash = soft = None
         cur_min_agt = cur_min_t = None
+        sa = ne_alive = slot_alive = None
+        if scene_alive is not None:
+            sa = scene_alive.to(device=dev, dtype=torch.bool)
+            ne_alive = sa[self.seg]                                               # (NA-B,)
+            slot_alive = sa[self.slot_scene]
+            tgt_traj = torch.where(sa.view(-1, 1, 1), tgt_traj, torch.zeros_like(tgt_traj))
         if w.get('adv_crash', 0.0) > 0.0:
             atk = future_pred.index_select(0, self.nonego_idx)[:, self.crash_min_t:, :]
             tgt = tgt_traj[:, self.crash_min_t:, :4]
@@ -521,6 +550,8 @@ class AdvGenLoss(nn.Module):
                 am[attack_agt_idx.to(dev)] = True
                 am = am.index_select(0, self.nonego_idx).unsqueeze(1).expand_as(din)
                 din = torch.where(~am, inf, din)
+            if ne_alive is not None:
+                din = torch.where(ne_alive.view(-1, 1), din, inf)                 # all-inf scene: soft-min weights 0 (:134-135)
             NT = future_pred.size(1) - self.crash_min_t
             soft = self._segment_softmin(din)
             weighted = soft * dist ** 2
@@ -543,6 +574,8 @@ class AdvGenLoss(nn.Module):
         veh_l = plan_l = None
         if ('coll_veh' in w or 'coll_veh_plan' in w) and (w['coll_veh'] > 0.0 or w['coll_veh_plan'] > 0.0):
             pen, cmask = self.veh_coll_loss.block_penalties(fine)
+            if slot_alive is not None:
+                cmask = cmask & slot_alive.view(1, -1)
             if w['coll_veh'] > 0.0:
                 m_veh = cmask & (~self.slot_ego).view(1, -1)
                 veh_l = (pen, m_veh)
@@ -559,9 +592,14 @@ class AdvGenLoss(nn.Module):
         env_l = None
         if w.get('coll_env', 0.0) > 0.0:
             env_l = self.env_coll_loss.valid_penalties(fine.index_select(0, self.nonego_idx))
+            if ne_alive is not None:
+                TO = fine.size(1)
+                env_l = (env_l[0], env_l[1] & ne_alive.view(-1, 1).expand(-1, TO).reshape(-1))
         init_l = None
         if w.get('init_z', 0.0) > 0.0:
             coeff = rew * w['init_z'] + (1.0 - rew) * w['init_z_atk']
+            if ne_alive is not None:
+                coeff = coeff * ne_alive.to(coeff.dtype)
             init_l = torch.sum(torch.sum((self.init_z - z) ** 2, dim=1) * coeff)
 
         loss = 0.0
@@ -570,7 +608,11 @@ class AdvGenLoss(nn.Module):
             loss = loss + init_l.mean()
             out['init_loss'] = init_l
         if prior_l is not None:
-            loss = loss + prior_l.mean()
+            if ne_alive is None:
+                loss = loss + prior_l.mean()
+            else:
+                pz = prior_l * ne_alive.to(prior_l.dtype).view(-1, *([1] * (prior_l.dim() - 1)))
+                loss = loss + pz.sum() / torch.clamp(ne_alive.sum() * (prior_l.numel() // max(1, prior_l.size(0))), min=1).to(prior_l.dtype)
             out['motion_prior_loss'] = prior_l
         # the three collision terms are means over the entries currently in collision ([0.] if none): formed as masked
         # sums / counts on the device; the compacted lists themselves are produced only if somebody reads them
@@ -584,7 +626,10 @@ class AdvGenLoss(nn.Module):
             loss = loss + w['coll_env'] * _masked_mean(*env_l)
             out.set_lazy('coll_env_loss', lambda: _compact_or_zero(*env_l))
         if crash is not None:
-            loss = loss + w['adv_crash'] * crash.mean()
+            if sa is None:
+                loss = loss + w['adv_crash'] * crash.mean()
+            else:
+                loss = loss + w['adv_crash'] * (crash * sa.to(crash.dtype)).sum() / torch.clamp(sa.sum(), min=1).to(crash.dtype)
             out['adv_crash_loss'] = crash
         out['loss'] = loss
         if return_mins and cur_min_agt is not None:

@@ -7,6 +7,7 @@ memory, streams and as the autograd host: the decoder rollout and the vehicle-co
 ``torch.autograd.Function``s whose forward/backward are single C-ABI calls.
 """
 import ctypes as C
+import threading
 
 import os
 
@@ -43,16 +44,40 @@ def _f32c(t):
 
 
 _ws_cache = {}
+_ws_lock = threading.Lock()
+_ws_local = threading.local()
+
+
+class graph_workspaces(object):
+    """Context: scratch buffers requested inside belong to ``store`` -- a dict owned by the HIP graph being captured
+    (utils/graphed.GraphedIteration) -- instead of the process-wide cache: a capture allocates from the graph's private pool, and
+    such a buffer must neither outlive its graph in a global table nor be handed to another loop's capture.  Per thread."""
+
+    def __init__(self, store):
+        self.store = store
+
+    def __enter__(self):
+        self.prev = getattr(_ws_local, 'store', None)
+        _ws_local.store = self.store
+        return self
+
+    def __exit__(self, *exc):
+        _ws_local.store = self.prev
+        return False
 
 
 def _workspace(device, nbytes, tag='ws'):
-    """Scratch buffer per (device, tag, current stream): launches on different streams never share one."""
+    """Scratch buffer per (device, tag, current stream): launches on different streams never share one.  Inside a
+    ``graph_workspaces`` context the buffers live in that context's store."""
     stream = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == 'cuda' else 0
     key = (str(device), tag, stream)
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
+    store = getattr(_ws_local, 'store', None)
+    cache = _ws_cache if store is None else store
+    with _ws_lock:
+        buf = cache.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+            cache[key] = buf
     return buf
 
 
@@ -1082,14 +1107,15 @@ class AdvGenSetup(object):
             self._masks[key] = m
         return m
 
-    def struct_for(self, T, D, mask):
-        key = (T, D, None if mask is None else mask.data_ptr())
+    def struct_for(self, T, D, mask, alive=None):
+        key = (T, D, None if mask is None else mask.data_ptr(), None if alive is None else alive.data_ptr())
         st = self._structs.get(key)
         if st is None:
             h = L.StriveAdvGen()
             keep = self.base.fill_base(h.base, T, self.NE, D, False)
             h.ne_ptr, h.slot_ne = self.ne_ptr.data_ptr(), self.slot_ne.data_ptr()
             h.atk_mask = None if mask is None else mask.data_ptr()
+            h.scene_alive = None if alive is None else alive.data_ptr()
             h.t0 = self.t0
             h.use_infront = 0 if self.infront is None else 1
             h.infront = 0.0 if self.infront is None else float(self.infront)
@@ -1097,7 +1123,7 @@ class AdvGenSetup(object):
             nbytes = self.lib.query('strive_adv_gen_workspace_bytes', self.sc.ref(), C.byref(h), T)
             if nbytes == 0:
                 raise StriveHipError('strive_adv_gen_workspace_bytes rejected the configuration (T=%d, t0=%d)' % (T, self.t0))
-            st = (h, (keep, mask), int(nbytes))
+            st = (h, (keep, mask, alive), int(nbytes))
             if len(self._structs) > 8:
                 self._structs.clear()
             self._structs[key] = st
@@ -1106,14 +1132,17 @@ class AdvGenSetup(object):
 
 class _AdvGenFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, traj, tgt, z, mu, var, h, mask):
+    def forward(ctx, traj, tgt, z, mu, var, h, mask, alive=None):
         lib = h.lib
         tr, tg, zc, muc, varc = _f32c(traj), _f32c(tgt), _f32c(z), _f32c(mu), _f32c(var)
         NA, T, _ = tr.shape
         if zc.shape != muc.shape or zc.shape != varc.shape or zc.shape[0] != h.NE or tg.shape != (h.sc.struct.B, T, 4):
             raise ValueError('adv_gen_loss: shapes traj %s tgt %s z %s prior %s do not match the batch' % (
                 tuple(traj.shape), tuple(tgt.shape), tuple(z.shape), tuple(mu.shape)))
-        st, _keep, nbytes = h.struct_for(T, zc.shape[1], mask)
+        if alive is not None and (alive.dtype != torch.uint8 or tuple(alive.shape) != (h.sc.struct.B,) or alive.device != tr.device or
+                                  not alive.is_contiguous()):
+            raise ValueError('adv_gen_loss: scene_alive must be a contiguous uint8 tensor (B,) on the device of the trajectories')
+        st, _keep, nbytes = h.struct_for(T, zc.shape[1], mask, alive)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=tr.device)
         out = torch.empty((16,), dtype=torch.float32, device=tr.device)
         NT = T - h.t0
@@ -1122,7 +1151,7 @@ class _AdvGenFn(torch.autograd.Function):
         pk = _map_pack(h.map_env, tr.device)
         lib.call('strive_adv_gen_fwd', h.sc.ref(), pk.ref(), C.byref(st), L.ptr(tr), L.ptr(tg), T, L.ptr(zc), L.ptr(muc), L.ptr(varc),
                  L.ptr(out), L.ptr(soft), L.ptr(rew), L.ptr(ws), nbytes, _stream(tr))
-        ctx.h, ctx.mask, ctx.D = h, mask, zc.shape[1]
+        ctx.h, ctx.mask, ctx.D, ctx.alive = h, mask, zc.shape[1], alive
         ctx.save_for_backward(tr, tg, zc, muc, varc, ws)
         ctx.mark_non_differentiable(out, soft, rew)
         return out[0].clone(), out, soft, rew
@@ -1132,19 +1161,22 @@ class _AdvGenFn(torch.autograd.Function):
         h = ctx.h
         tr, tg, zc, muc, varc, ws = ctx.saved_tensors
         NA, T, _ = tr.shape
-        st, _keep, nbytes = h.struct_for(T, ctx.D, ctx.mask)
+        st, _keep, nbytes = h.struct_for(T, ctx.D, ctx.mask, ctx.alive)
         d_traj, d_tgt, d_z = torch.empty_like(tr), torch.empty_like(tg), torch.zeros_like(zc)
         h.lib.call('strive_adv_gen_bwd', h.sc.ref(), C.byref(st), L.ptr(tr), L.ptr(tg), T, L.ptr(zc), L.ptr(muc), L.ptr(varc),
                    L.ptr(_f32c(d_loss).reshape(1)), L.ptr(ws), nbytes, L.ptr(d_traj), L.ptr(d_tgt), L.ptr(d_z), _stream(tr))
-        return d_traj, d_tgt, d_z, None, None, None, None
+        return d_traj, d_tgt, d_z, None, None, None, None, None
 
 
-def adv_gen_loss(traj, tgt, z, mu, var, setup, attack_agt_idx=None):
-    """-> (loss 0-dim, differentiable w.r.t. traj, tgt and z; out (16,); soft (NE, T - t0); rew (NE,))"""
+def adv_gen_loss(traj, tgt, z, mu, var, setup, attack_agt_idx=None, scene_alive=None):
+    """-> (loss 0-dim, differentiable w.r.t. traj, tgt and z; out (16,); soft (NE, T - t0); rew (NE,)).  ``scene_alive`` (B,) uint8
+    on the device (or None): scenes with 0 have left the batch (StriveAdvGen.scene_alive) -- the values and gradients of the others
+    are those of the batch rebuilt without them; the mask is read when the kernels run, so a tensor the planner call of the same
+    iteration wrote is honoured without a host round trip."""
     if mu.requires_grad or var.requires_grad:
         raise NotImplementedError('the fused AdvGenLoss treats the prior as a constant (the optimisation loops detach it)')
     mask = setup.atk_mask(attack_agt_idx, traj.shape[0])
-    return _AdvGenFn.apply(traj[:, :, :4], tgt[:, :, :4], z, mu, var, setup, mask)
+    return _AdvGenFn.apply(traj[:, :, :4], tgt[:, :, :4], z, mu, var, setup, mask, scene_alive)
 
 
 def rect_iou(box_a, lw_a, box_b, lw_b):

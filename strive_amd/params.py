@@ -44,9 +44,9 @@ def _absmax_key(t):
 
 class lagged_absmax(object):
     """Context (the training step): prefetch_absmax() does not wait for the device.  It enqueues the read-back of max |t| into
-    pinned memory and serves, for every tensor, the value of the most recent read-back that has ARRIVED (the first call waits)
-    plus ``slack`` -- the most the tensors can have grown since: ``slack`` = a bound on two optimiser steps' change of an entry
-    (Adam: ~4 lr per step).  The power-of-two operand scales are then chosen with a factor 2 of extra head-room
+    pinned memory and serves, for every tensor, the value read back exactly two calls earlier (the first call of a tensor
+    waits and serves its own) plus ``slack`` -- the most the tensors can have grown since: ``slack`` = a bound on two optimiser
+    steps' change of an entry (Adam: ~4 lr per step).  The power-of-two operand scales are then chosen with a factor 2 of extra head-room
     (_pow2_scale), so a stale, slightly-too-small bound cannot overflow fp16: |w| scale <= 16384 (1 + slack / max|w|) << 65504."""
     active = None
 
@@ -62,8 +62,19 @@ class lagged_absmax(object):
         lagged_absmax.active = self.prev
 
 
-_LAG = {}             # data_ptr -> {'val': float, 'pending': (pinned tensor, event, index) or None}
-_LAG_BATCH = []       # read-backs under way: (pinned values, event, [data_ptr, ...])
+# Lagged read-backs.  An entry is keyed by what identifies the parameter's storage slot (address, shape, device) AND keeps the
+# tensor, so its address cannot be handed to another tensor while the entry exists (a second model in the process, a replaced
+# p.data: each gets its own first-sight read-back instead of a stranger's stale bound).  The lag is FIXED: the value served at a
+# call is the one read back _LAG_DEPTH calls of the same tensor group earlier (its event is waited for if it has not arrived --
+# it practically always has), never older and never a matter of ev.query() timing, so the scales a run chooses are reproducible
+# and the caller's slack (a bound on _LAG_DEPTH optimiser steps) always covers it.
+_LAG_DEPTH = 2
+_LAG = {}             # (data_ptr, shape, device) -> [value, tensor]
+_LAG_BATCH = {}       # tensor group (tuple of keys) -> FIFO of read-backs under way: (pinned values, event)
+
+
+def _lag_key(t):
+    return (t.data_ptr(), tuple(t.shape), str(t.device))
 
 
 def _lagged_prefetch(tensors, slack):
@@ -76,29 +87,38 @@ def _lagged_prefetch(tensors, slack):
         for t, v in zip(todo, vals):
             _ABSMAX[_absmax_key(t)] = (float(v), t)
         return
-    # harvest the read-backs that have arrived
-    while _LAG_BATCH and _LAG_BATCH[0][1].query():
-        host, _, ptrs = _LAG_BATCH.pop(0)
-        for pv, v in zip(ptrs, host.tolist()):
-            _LAG[pv] = float(v)
-    # enqueue this step's read-back
+    keys = [_lag_key(t) for t in todo]
+    group = tuple(keys)
+    fifo = _LAG_BATCH.setdefault(group, [])
+    # enqueue this call's read-back
     norms = torch.stack(torch._foreach_norm([t.to(torch.float32) for t in todo], float('inf')))
     host = torch.empty((len(todo),), dtype=torch.float32).pin_memory()
     host.copy_(norms, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
-    _LAG_BATCH.append((host, ev, [t.data_ptr() for t in todo]))
-    if any(t.data_ptr() not in _LAG for t in todo):          # first sight of a tensor: this one read-back is waited for
+    fifo.append((host, ev))
+    # first sight of a tensor (new address / shape, or an entry whose tensor is not this storage any more): this read-back is
+    # waited for and served exactly
+    first = any(k not in _LAG or _LAG[k][1].data_ptr() != k[0] for k in keys)
+    if first:
         ev.synchronize()
-        while _LAG_BATCH:
-            h, _, ptrs = _LAG_BATCH.pop(0)
-            for pv, v in zip(ptrs, h.tolist()):
-                _LAG[pv] = float(v)
+        vals = host.tolist()
+        del fifo[:]
+        if len(_LAG) + len(todo) > 4096:
+            _LAG.clear()
+        for k, v, t in zip(keys, vals, todo):
+            _LAG[k] = [float(v), t]
         slack = 0.0
+    else:
+        while len(fifo) > _LAG_DEPTH:                       # the read-back of _LAG_DEPTH calls ago becomes the value served
+            h, e = fifo.pop(0)
+            e.synchronize()
+            for k, v in zip(keys, h.tolist()):
+                _LAG[k][0] = float(v)
     if len(_ABSMAX) + len(todo) > 2048:
         _ABSMAX.clear()
-    for t in todo:
-        _ABSMAX[_absmax_key(t)] = (_LAG[t.data_ptr()] + slack, t)
+    for t, k in zip(todo, keys):
+        _ABSMAX[_absmax_key(t)] = (_LAG[k][0] + slack, t)
 
 
 def prefetch_absmax(tensors):

@@ -155,7 +155,12 @@ class HardcodeNuscPlanner(PlannerNusc):
         self.ego_idx = 0
         self._world = None
         self._pending = None      # (pinned snapshot of the status flags, event) of a read-back that is under way, or None
-        self._status = None       # device flags: the kernels only SET them, so one tensor accumulates every rollout since reset()
+        self._status = None       # device flags (B, 8): the kernels only SET them, so one tensor accumulates every rollout since
+                                  # reset(); row b belongs to scene b alone
+        self.alive = None         # device (B,) uint8, written at the end of every rollout: 1 = no flag of the scene is set.  The
+                                  # closed loop hands it to the loss kernels (no host round trip): a failed scene is quarantined
+        self.on_error = 'raise'   # what check() does with failed scenes: 'raise' (the reference's numpy planner raises) or
+                                  # 'report' (return them: the caller drops those scenes, utils/adv_gen_optim.py)
         self.defer_check = None   # None: rollouts on device tensors defer the status check to check() (no synchronisation inside
                                   # an optimisation closure), host calls check at once; True / False force either
         self._rows = {}
@@ -167,7 +172,8 @@ class HardcodeNuscPlanner(PlannerNusc):
         agent, map_idx (B).  The device the planner runs on is init_state's."""
         dev = init_state.device
         ops._lib_for(init_state)
-        self._status = torch.zeros((8,), dtype=torch.int32, device=dev)
+        self._status = torch.zeros((int(batch_size), len(STATUS_NAMES)), dtype=torch.int32, device=dev)
+        self.alive = torch.ones((int(batch_size),), dtype=torch.uint8, device=dev)
         self._pending = None
         self.ego_idx, self.B, self.batch_mask = int(ego_idx), int(batch_size), batch_mask
         state = init_state.detach().cpu().numpy()
@@ -255,40 +261,62 @@ class HardcodeNuscPlanner(PlannerNusc):
         self._row_maps(np.asarray(agent_ptr).reshape(-1))
 
     # ---- deferred status check: no host synchronisation inside an optimisation closure ----------------------------------
-    def check(self, wait=True):
-        """Raise if ANY rollout since reset() (or since the last raising check) hit a capacity / range limit -- its plan is NaN
-        for the affected scenes.  The device kernels only set flags in one persistent status tensor, so nothing is lost between
-        rollouts: ``wait=True`` reads the flags back (one synchronisation; the loops call it once, after their last iteration);
-        ``wait=False`` never blocks -- it looks at a snapshot whose asynchronous copy has already arrived and starts the next
-        one, which is how a failure surfaces early inside a synchronisation-free optimisation loop."""
+    def _read_status(self, wait):
+        """Host copy (B, 8) of the flags or None: ``wait=True`` reads them back (one synchronisation); ``wait=False`` never blocks --
+        it returns a snapshot whose asynchronous copy has already arrived (if any) and starts the next one."""
         st = self._status
         if st is None:
-            return
+            return None
         if st.device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
-            return            # inside a HIP-graph capture (utils/graphed.py): the flags accumulate over the replays, the loop checks at its end
-        host = None
+            return None       # inside a HIP-graph capture (utils/graphed.py): the flags accumulate over the replays, the loop checks at its end
         if st.device.type != 'cuda':
-            host = st
-        elif wait:
+            return st
+        if wait:
             self._pending = None
-            host = st.cpu()                   # (ordered behind every rollout enqueued on, or joined into, the current stream)
-        else:
-            pend = self._pending
-            if pend is not None and pend[1].query():
-                host, self._pending = pend[0], None
-            if self._pending is None:
-                snap = torch.empty((8,), dtype=torch.int32).pin_memory()
-                snap.copy_(st, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(st.device))
-                self._pending = (snap, ev)
+            return st.cpu()                   # (ordered behind every rollout enqueued on, or joined into, the current stream)
+        host = None
+        pend = self._pending
+        if pend is not None and pend[1].query():
+            host, self._pending = pend[0], None
+        if self._pending is None:
+            snap = torch.empty(tuple(st.shape), dtype=torch.int32).pin_memory()
+            snap.copy_(st, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(st.device))
+            self._pending = (snap, ev)
+        return host
+
+    def failed_scenes(self, wait=True):
+        """{scene: [limit names]} of the scenes whose plan is NaN because SOME rollout since reset() hit a capacity / range limit in
+        them (the cases in which the reference's planner raises).  The flags are per scene and sticky; the other scenes' plans are
+        unaffected.  Does not clear anything."""
+        host = self._read_status(wait)
         if host is None:
-            return
-        bad = [STATUS_NAMES[i] for i in range(len(STATUS_NAMES)) if int(host[i]) != 0]
-        if bad:
-            st.zero_()
+            return {}
+        host = host.reshape(-1, len(STATUS_NAMES))
+        return {b: [STATUS_NAMES[i] for i in range(len(STATUS_NAMES)) if int(host[b, i]) != 0]
+                for b in range(host.shape[0]) if bool((host[b] != 0).any())}
+
+    def check(self, wait=True, on_error=None):
+        """What became of the rollouts since reset(): ``on_error='raise'`` (default, ``self.on_error``) raises StriveHipError naming
+        the failed scenes and limits and clears the flags -- a failure costs the caller the whole batch, which is what a raise
+        inside the reference's per-scene numpy loop costs it (:178-276 called from adv_gen_optim.py:133-139); ``'report'`` returns
+        ``failed_scenes()`` and leaves the flags set, for callers that quarantine the scenes (run_adv_gen_optim).
+        The device kernels only set flags in one persistent tensor, so nothing is lost between rollouts: ``wait=True`` reads it back
+        (one synchronisation; the loops call it once, after their last iteration); ``wait=False`` never blocks -- which is how a
+        failure surfaces early inside a synchronisation-free optimisation loop."""
+        bad = self.failed_scenes(wait)
+        mode = self.on_error if on_error is None else on_error
+        if mode not in ('raise', 'report'):
+            raise ValueError("on_error must be 'raise' or 'report'")
+        if bad and mode == 'raise':
+            self._status.zero_()
+            self.alive.fill_(1)
             self._pending = None
-            raise L.StriveHipError('HardcodeNuscPlanner.rollout exceeded a limit of the device planner: ' + '; '.join(bad))
+            names = sorted(set(n for v in bad.values() for n in v))
+            raise L.StriveHipError('HardcodeNuscPlanner.rollout exceeded a limit of the device planner in scene(s) %s: %s' % (
+                ', '.join(str(b) for b in sorted(bad)), '; '.join(names)))
+        return bad
 
     # ---- rollout (reference :178-276) -------------------------------------------------------------------------------------
     def rollout(self, agent_obs, agent_t, agent_ptr, planner_t, init_state=None, control_all=False, viz=None, coll_t=None):
@@ -325,12 +353,12 @@ class HardcodeNuscPlanner(PlannerNusc):
             ws.fill_(0x25)                # debug aid (the tests set it): a kernel that reads workspace it did not write sees garbage
         TP = planner_t.shape[0]
         plan = torch.empty((self.B, TP, 4), dtype=torch.float64, device=dev)
-        status = self._status
+        status, alive = self._status, self.alive
         at, to, pt = self._table(agent_t), self._table(t_out), self._table(planner_t)
         if NR == 0:
             obs = torch.zeros((1, max(1, agent_t.shape[0]), 4), dtype=torch.float64, device=dev)
         lib.call('strive_planner_rollout', C.byref(desc), L.ptr(obs), L.ptr(at), int(agent_t.shape[0]), L.ptr(to), nstep, L.ptr(pt),
-                 TP, int(self.traj_cap), L.ptr(plan), L.ptr(status), L.ptr(ws), ws.numel(), L.stream_ptr(obs))
+                 TP, int(self.traj_cap), L.ptr(plan), L.ptr(status), L.ptr(alive), L.ptr(ws), ws.numel(), L.stream_ptr(obs))
         defer = (dev.type == 'cuda') if self.defer_check is None else bool(self.defer_check)
         if from_numpy or not defer:
             self.check(wait=True)

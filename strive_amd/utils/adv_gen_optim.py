@@ -127,7 +127,14 @@ class AdvClosure(object):
 
     def __init__(self, cur_z, lr, loss_weights, model, scene_graph, map_env, map_idx, embed_info, tgt_prior_distrib,
                  other_prior_distrib, feasibility_time, feasibility_infront_min, planner_fut=None, attack_agt_idx=None,
-                 future_len=None, veh_coll_buffer=0.1, planner_name='ego', planner=None):
+                 future_len=None, veh_coll_buffer=0.1, planner_name='ego', planner=None, on_planner_error='drop'):
+        """``on_planner_error`` (closed loop only; not in the reference): what a planner rollout that fails in some scene -- an
+        object pushed off its lane, a capacity limit: the cases in which the reference's numpy planner raises and its batch_size-1
+        run loses that scene (adv_scenario_gen.py:540-543) -- costs a BATCH here.  'drop' (default): that scene alone; from the
+        iteration of the failure on it is masked out of both losses on the device (the planner's ``alive`` flags go straight to the
+        loss kernels, no host round trip), the other scenes continue exactly as in a batch rebuilt without it (the reference's
+        remedy for scenes it gives up after the init stage, :323-356), and the caller is told (``failed_scenes``).  'raise': the
+        whole batch (StriveHipError from the planner's deferred check), with the planner overlapped under the adversarial half."""
         from ..losses.adv_gen_nusc import TgtMatchingLoss, AdvGenLoss
         dev = cur_z.device
         NA = cur_z.size(0)
@@ -158,6 +165,9 @@ class AdvClosure(object):
                                    scene_graph.ptr, veh_coll_buffer=veh_coll_buffer, crash_loss_min_time=feasibility_time,
                                    crash_loss_min_infront=feasibility_infront_min)
         self.planner_name, self.planner = planner_name, planner
+        if on_planner_error not in ('drop', 'raise'):
+            raise ValueError("on_planner_error must be 'drop' or 'raise'")
+        self.quarantine = planner_name == 'hardcode' and on_planner_error == 'drop' and hasattr(planner, 'failed_scenes')
         # two-stream rollouts (see two_rollouts); set False to serialise.  A replayed HIP graph keeps ONE stream: with the fork /
         # join captured, hipGraphLaunch of the 16-agent adversarial iteration took 5.4 ms on the host and the iteration 8.6 ms
         # against 4.2 ms eager (profiles/r04_graph_ab.txt)
@@ -175,6 +185,8 @@ class AdvClosure(object):
             B = scene_graph.ptr.shape[0] - 1
             planner.reset(self.unn(scene_graph.past_gt[:, -1, :]), model.get_att_normalizer().unnormalize(scene_graph.lw),
                           scene_graph.batch, B, map_idx)
+            if self.quarantine:
+                planner.on_error = 'report'          # its own opportunistic look at the flags (rollout -> check(wait=False)) must not raise
             self.agt_ptr = (scene_graph.ptr.cpu() - torch.arange(B + 1)).numpy()
             self.plan_t = np.linspace(model.dt, model.dt * self.future_len, self.future_len)
             self.planner_fut = None
@@ -241,19 +253,24 @@ class AdvClosure(object):
         z_b = self.collated(detach_tgt=True)        # the others get the adversarial loss only
         kw = dict(ext_future=self.planner_fut, nfuture=self.future_len)
         if self.planner_name == 'hardcode' and self.overlap and os.environ.get('STRIVE_PLANNER_OVERLAP', '1') != '0' and \
-                shared_forward_applies(m, z_a, kw, kw):
+                shared_forward_applies(m, z_a, kw, kw) and not self.quarantine:
+            # (with quarantine BOTH losses wait for this iteration's planner rollout: which scenes are in the batch is its result)
             return self._step_closed_loop_overlapped(z_a, z_b, log)
+        alive = None
         if self.planner_name == 'hardcode':
             # the planner reacts to rollout A only: it is enqueued behind A on A's stream and runs under rollout B
             out_a, out_b, planner_fut = self._two_rollouts(z_a, z_b, after_a=lambda o: self.plan(o['future_pred']))
             adv_tgt = out_b['future_pred'].index_select(0, self.ego_idx)      # the differentiable stand-in for the planner
+            if self.quarantine:
+                alive = self.planner.alive           # (B,) uint8 on the device, written by the rollout just enqueued
         else:
             out_a, out_b = self._two_rollouts(z_a, z_b)
             planner_fut = adv_tgt = self.planner_fut
+        mask_kw = {} if alive is None else {'scene_alive': alive}
         lt = self.tgt_loss(self.unn(out_a['future_pred'].index_select(0, self.ego_idx)), self.unn(planner_fut), self.tgt_z,
-                           self.tgt_prior)
+                           self.tgt_prior, **mask_kw)
         la = self.adv_loss(self.unn(out_b['future_pred']), self.unn(adv_tgt), self.other_z, self.other_prior,
-                           attack_agt_idx=self.attack_agt_idx)
+                           attack_agt_idx=self.attack_agt_idx, **mask_kw)
         loss = lt['loss'] + la['loss']
         loss.backward()
         if log is not None:
@@ -268,14 +285,20 @@ class AdvClosure(object):
 def run_adv_gen_optim(cur_z, lr, loss_weights, model, scene_graph, map_env, map_idx, num_iters, embed_info,
                       planner_name, tgt_prior_distrib, other_prior_distrib, feasibility_time, feasibility_infront_min,
                       planner=None, planner_viz_out=None, attack_agt_idx=None, future_len=None, veh_coll_buffer=0.1,
-                      log=None):
+                      log=None, on_planner_error='drop'):
+    """Same arguments and return value as the reference (src/utils/adv_gen_optim.py:39-211).  ``on_planner_error`` (closed loop,
+    see AdvClosure): with 'drop' a scene whose planner rollout fails leaves the losses from that iteration on instead of ending
+    the whole batch; the scenes lost this way are listed in ``final_decoder_out['scenes_dropped']`` (with the limits they hit in
+    ``final_decoder_out['planner_failures']``) -- their rows of the returned tensors are meaningless (the planner's trajectory
+    is NaN) and the caller drops them like the reference drops scenes after its init stage (adv_scenario_gen.py:323-356)."""
     if planner_viz_out is not None:
         # (the reference renders the final closed-loop rollout frame by frame, :186-190: matplotlib + ffmpeg, outside the path)
         raise NotImplementedError('planner_viz_out: planner visualisation is not part of this package; render the returned '
                                   'final_result_traj instead')
     c = AdvClosure(cur_z, lr, loss_weights, model, scene_graph, map_env, map_idx, embed_info, tgt_prior_distrib,
                    other_prior_distrib, feasibility_time, feasibility_infront_min, attack_agt_idx=attack_agt_idx,
-                   future_len=future_len, veh_coll_buffer=veh_coll_buffer, planner_name=planner_name, planner=planner)
+                   future_len=future_len, veh_coll_buffer=veh_coll_buffer, planner_name=planner_name, planner=planner,
+                   on_planner_error=on_planner_error)
     if log is None and c.graphed:
         it = GraphedIteration(c.step, True)
         for _ in range(num_iters):
@@ -294,11 +317,15 @@ def run_adv_gen_optim(cur_z, lr, loss_weights, model, scene_graph, map_env, map_
     else:       # the planner's actual reaction to the final scenario (reference :184-192)
         final_result_traj[ego_inds, torch.zeros_like(ego_inds)] = c.plan(final_decoder_out['future_pred'])
         if hasattr(planner, 'check'):
-            planner.check()                   # deferred capacity / range status of every planner rollout of the loop
+            # deferred capacity / range status of every planner rollout of the loop: raises, or names the quarantined scenes
+            failures = planner.check(on_error='report') if c.quarantine else planner.check()
+            final_decoder_out['planner_failures'] = dict(failures or {})
+            final_decoder_out['scenes_dropped'] = sorted((failures or {}).keys())
     tgt_traj = final_result_traj[ego_inds, torch.zeros_like(ego_inds)]
+    fin_kw = {'scene_alive': planner.alive} if c.quarantine else {}
     with torch.no_grad():
         fin = adv_loss(unn(final_decoder_out['future_pred']), unn(tgt_traj), cur_z[~ego_mask].clone().detach(),
-                       other_prior_distrib, return_mins=True)
+                       other_prior_distrib, return_mins=True, **fin_kw)
     cur_min_agt = cur_min_t = None
     if 'min_agt' in fin:
         cur_min_agt = fin['min_agt'] + scene_graph.ptr[:-1].cpu().numpy()

@@ -647,6 +647,105 @@ def test_fused_losses_ragged_scenes(emu, monkeypatch):
     assert_close(res[1][3], res[0][3], 1e-4, 1e-7, 'adv d z')
 
 
+def _adv_quarantine_case(dead, key='emu/quarantine', sizes=(3, 5, 2, 4), D=32):
+    """a ragged batch, the same batch without the scenes in ``dead``, and the row maps between them"""
+    batch, map_idx, env, traj, veh_att = _loss_case(list(sizes), key)
+    NA, B = traj.shape[0], len(sizes)
+    ptr = batch.ptr
+    ego = torch.zeros((NA,), dtype=torch.bool)
+    ego[ptr[:-1]] = True
+    scene = torch.repeat_interleave(torch.arange(B), torch.tensor(sizes))
+    keep_scene = torch.tensor([b not in dead for b in range(B)])
+    keep = keep_scene[scene]
+    tgt = traj[ego].clone()
+    tgt[:, :, :2] += 1.5
+    zne = synth.f32(synth.counter_uniform((NA - B, D), key + '/z', -1.0, 1.0))
+    mu = synth.f32(synth.counter_uniform((NA - B, D), key + '/m', -0.5, 0.5))
+    var = synth.f32(synth.counter_uniform((NA - B, D), key + '/v', 0.3, 2.0))
+    keep_ne = keep[~ego]
+    sub_sizes = [n for b, n in enumerate(sizes) if b not in dead]
+    sub_ptr = torch.tensor([0] + list(np.cumsum(sub_sizes)), dtype=ptr.dtype)
+    full = dict(traj=traj, tgt=tgt, z=zne, mu=mu, var=var, veh_att=veh_att, mapixes=map_idx[batch.batch], ptr=ptr, init=zne * 0.5)
+    sub = dict(traj=traj[keep], tgt=tgt[keep_scene], z=zne[keep_ne], mu=mu[keep_ne], var=var[keep_ne], veh_att=veh_att[keep],
+               mapixes=map_idx[batch.batch][keep], ptr=sub_ptr, init=(zne * 0.5)[keep_ne])
+    return env, full, sub, keep, keep_scene, keep_ne
+
+
+@pytest.mark.parametrize('dead,infront', [([1], -0.5), ([0, 3], None), ([2], 0.0)])
+def test_adv_gen_loss_quarantined_scenes_equal_the_batch_without_them(emu, monkeypatch, dead, infront):
+    """StriveAdvGen.scene_alive (the closed loop's answer to a planner rollout that fails in ONE scene; the reference's
+    batch_size-1 run loses that scene, adv_scenario_gen.py:540-543, and rebuilds batches without the scenes it gives up,
+    :323-356): the fused AdvGenLoss with scenes masked out -- their planner trajectory NaN -- gives the other scenes the SAME
+    BITS as the loss evaluated on the batch rebuilt without them (every gradient; the objective up to the grouping of its float64
+    partial sums), zero gradients to the masked scenes, and agrees with the masked term-by-term path."""
+    from strive_amd import ops
+    from strive_amd.losses.adv_gen_nusc import AdvGenLoss, TgtMatchingLoss
+    monkeypatch.setattr(ops, '_lib_for', lambda *tensors: emu)
+    monkeypatch.setattr(ops, '_ws_cache', {})
+    monkeypatch.setattr(ops, '_workspace', poisoned_workspace(ops))
+    monkeypatch.setattr(torch, 'empty', nan_empty())
+    env, full, sub, keep, keep_scene, keep_ne = _adv_quarantine_case(dead)
+    kw = dict(veh_coll_buffer=0.1, crash_loss_min_time=1, crash_loss_min_infront=infront)
+    ego_full = torch.zeros((full['traj'].shape[0],), dtype=torch.bool)
+    ego_full[full['ptr'][:-1]] = True
+
+    grid = {}
+
+    def run(d, alive=None, nan_tgt=False, terms=False):
+        fn = AdvGenLoss(mg.ADV_WEIGHTS, d['veh_att'], d['mapixes'], env, d['init'], d['ptr'], **kw)
+        # the reference's one batch-wide constant: get_coll_point sizes its sampling grid from the batch MEAN of the vehicle sizes
+        # (nuscenes_utils.py:351-354).  A quarantined batch keeps the grid it was built with, so the rebuilt batch is given the same
+        if d is full:
+            grid.update({3 * d['traj'].shape[1]: fn.env_coll_loss._grid_size(int((~ego_full).sum()), 3 * d['traj'].shape[1])})
+        fn.env_coll_loss._grid = dict(grid)
+        tr = d['traj'].clone().requires_grad_(True)
+        tgv = d['tgt'].clone()
+        if nan_tgt:
+            tgv[~keep_scene] = float('nan')
+        tg = tgv.requires_grad_(True)
+        z = d['z'].clone().requires_grad_(True)
+        call = fn.forward_terms if terms else fn
+        out = call(tr, tg, z, (d['mu'], d['var']), return_mins=True, **({} if alive is None else {'scene_alive': alive}))
+        if not terms:
+            assert fn._fused is not None, 'the fused call was not taken'
+        out['loss'].backward()
+        return out, tr.grad, tg.grad, z.grad
+    alive = keep_scene.to(torch.uint8)
+    of, trf, tgf, zf = run(full, alive, nan_tgt=True)
+    os_, trs, tgs, zs = run(sub)
+    assert torch.isfinite(of['loss']) and torch.isfinite(trf).all() and torch.isfinite(tgf).all() and torch.isfinite(zf).all()
+    assert_close(of['loss'].detach(), os_['loss'].detach(), 1e-6, 1e-7, 'loss')
+    assert torch.equal(trf[keep], trs) and torch.equal(tgf[keep_scene], tgs) and torch.equal(zf[keep_ne], zs), \
+        'the alive scenes must receive the gradients of the batch without the masked ones, bit for bit'
+    assert float(trf[~keep].abs().max()) == 0.0 and float(tgf[~keep_scene].abs().max()) == 0.0 and float(zf[~keep_ne].abs().max()) == 0.0
+    alive_b = [b for b in range(len(keep_scene)) if bool(keep_scene[b])]
+    assert np.array_equal(np.asarray(of['min_agt'])[alive_b], np.asarray(os_['min_agt']))
+    assert np.array_equal(np.asarray(of['min_t'])[alive_b], np.asarray(os_['min_t']))
+    # the masked term-by-term path (what the logging entries are computed by)
+    ot, trt, tgt_, zt = run(full, alive, nan_tgt=True, terms=True)
+    assert_close(ot['loss'].detach(), of['loss'].detach(), 2e-5, 1e-5, 'terms loss')
+    assert_close(trt, trf, 5e-3, 1e-5, 'terms d traj')
+    assert_close(zt, zf, 1e-4, 1e-7, 'terms d z')
+    # everybody alive = no mask
+    o1, tr1, tg1, z1 = run(full, torch.ones_like(alive))
+    o0, tr0, tg0, z0 = run(full)
+    assert torch.equal(o1['loss'], o0['loss']) and torch.equal(tr1, tr0) and torch.equal(tg1, tg0) and torch.equal(z1, z0)
+    # the matching loss: same contract
+    w = {'match_ext': 10.0, 'motion_prior_ext': 0.001}
+    B, T = full['tgt'].shape[0], full['tgt'].shape[1]
+    pred = (full['tgt'] + 0.3).clone()
+    res = []
+    for p_, t_, a_ in ((pred, full['tgt'].clone(), alive), (pred[keep_scene], full['tgt'][keep_scene].clone(), None)):
+        if a_ is not None:
+            t_[~keep_scene] = float('nan')
+        p_ = p_.clone().requires_grad_(True)
+        out = TgtMatchingLoss(w)(p_, t_, None, None, **({} if a_ is None else {'scene_alive': a_}))
+        out['loss'].backward()
+        res.append((out['loss'].detach(), p_.grad))
+    assert_close(res[0][0], res[1][0], 1e-6, 1e-7, 'matching loss')
+    assert torch.equal(res[0][1][keep_scene], res[1][1]) and float(res[0][1][~keep_scene].abs().max()) == 0.0
+
+
 def _pack_dense_case(lib, dev, M, K, key):
     """strive_pack_dense against the torch layout code it replaces (params.dense_fragments): transpose and both fragment
     tables, byte for byte."""

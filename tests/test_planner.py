@@ -300,6 +300,42 @@ def test_device_planner_reports_exceeded_limits(emu_ops):
         dev.rollout(world[4].copy(), world[5], world[6], world[5], control_all=False)
 
 
+def test_device_planner_failure_is_per_scene(emu_ops):
+    """One scene of a batch exceeds a limit (an object at 60 m/s needs more route knots than the kernel keeps; the reference's
+    planner raises for that scene's rollout, which with its batch_size-1 runs costs that scene, adv_scenario_gen.py:540-543):
+    the status row, the NaN plan and the ``alive`` flag of THAT scene say so; every other scene gets, bit for bit, the plan of
+    the batch without the failing one; 'report' mode names the scene, 'raise' mode names it in the error."""
+    sizes = [3, 4, 2]
+    world = list(random_world(sizes, 'lim3', tail=False))
+    lg, st, att, mask, obs, t, ptr, mi = world
+    clean = both_planners(tuple(world), 'default')[1]
+    clean.defer_check = True
+    want = clean.rollout(torch.from_numpy(obs.copy()), t, ptr, t, control_all=False)
+    assert clean.check() == {} and bool(clean.alive.all())
+    bad_scene = 1
+    st2 = st.clone()
+    st2[sizes[0] + 1, 4] = 60.0                    # a non-ego object of scene 1
+    world[1] = st2
+    dev = both_planners(tuple(world), 'default')[1]
+    dev.defer_check = True
+    got = dev.rollout(torch.from_numpy(obs.copy()), t, ptr, t, control_all=False)
+    assert dev.alive.tolist() == [1, 0, 1]
+    assert bool(torch.isnan(got[bad_scene]).all()) and not bool(torch.isnan(got[[0, 2]]).any())
+    assert torch.equal(got[[0, 2]], want[[0, 2]])
+    failed = dev.check(on_error='report')
+    assert list(failed) == [bad_scene] and any('route knots' in n for n in failed[bad_scene])
+    assert dev.failed_scenes() == failed, "'report' leaves the flags set"
+    # the flags are sticky per scene: a later clean rollout of the same world keeps scene 1 out, and only scene 1
+    world[1] = st
+    dev._world['init'] = clean._world['init']
+    dev.on_error = 'report'                        # (what the quarantining loop sets: rollout's own look at the flags must not raise)
+    again = dev.rollout(torch.from_numpy(obs.copy()), t, ptr, t, control_all=False)
+    assert dev.alive.tolist() == [1, 0, 1] and torch.equal(again, want)
+    with pytest.raises(L.StriveHipError, match=r'scene\(s\) 1: .*route knots'):
+        dev.check(on_error='raise')
+    assert dev.check() == {} and dev.alive.tolist() == [1, 1, 1]          # cleared by the raising check
+
+
 def test_device_planner_status_of_earlier_rollouts_is_kept(emu_ops):
     """The optimisation loops look at the planner's status once, after their last iteration.  The flags live in one status
     tensor per planner that the kernels only set: a limit exceeded in an EARLIER rollout is still reported after later,
@@ -403,6 +439,9 @@ def test_device_planner_gpu_512_agents():
     _, prod = both_planners(world, 'default', device=dev)
     obs_d = torch.from_numpy(obs.copy()).to(dev)
     got = prod.rollout(obs_d, t, ptr, t, control_all=False)
+    failed = prod.check(on_error='report')
+    assert sorted(failed) == P512_REJECTED and all(any('outside a route' in n for n in v) for v in failed.values())
+    assert np.nonzero(prod.alive.cpu().numpy() == 0)[0].tolist() == P512_REJECTED
     with pytest.raises(L.StriveHipError, match='outside a route'):
         prod.check()
     torch.cuda.synchronize()

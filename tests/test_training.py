@@ -348,3 +348,36 @@ def test_cnn_backward_measurement_hook():
             lib.call('strive_map_cnn_bwd_bench_dgrad', layer, nn, L.ptr(ws), ws.numel(), st)
     again = grads()
     assert float((again - first).norm() / first.norm()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_lagged_absmax_serves_the_right_tensor_a_bounded_lag_behind():
+    """params.lagged_absmax (the training step's operand scales without a host wait): an entry belongs to ONE tensor -- a tensor
+    freed and another one allocated (possibly at the same address, same shape) gets its own exact first-sight value, never the
+    dead tensor's bound -- and the value served is the read-back of exactly two calls earlier plus the slack, so with a slack that
+    bounds two steps' growth it never undercuts the true max |w| and does not depend on when the copies happen to arrive."""
+    from strive_amd import params
+    dev = 'cuda:0'
+    params._ABSMAX.clear(); params._LAG.clear(); params._LAG_BATCH.clear()
+    with params.lagged_absmax(slack=0.25):
+        a = torch.full((4096,), 3.0, device=dev)
+        assert params.absmax(a) == 3.0                         # first sight: exact
+        addr = a.data_ptr()
+        del a
+        torch.cuda.synchronize()
+        b = torch.full((4096,), 7.0, device=dev)               # the caching allocator hands the block out again
+        same_address = b.data_ptr() == addr
+        assert params.absmax(b) == 7.0, 'a new tensor must not inherit a dead tensor\'s bound (same address: %s)' % same_address
+        # the entry kept `a`'s storage alive, so `b` cannot alias it while the entry exists
+        assert not same_address
+        served = []
+        for step in range(8):                                  # an "optimiser" that grows max |w| by 0.1 per step
+            b.add_(0.1)
+            params.prefetch_absmax([b])
+            v = params.absmax(b)
+            true = float(b.abs().max())
+            assert v >= true - 1e-6, 'step %d: served bound %.4f below the true max %.4f' % (step, v, true)
+            served.append(round(v - true, 4))
+        # fixed two-call lag: from the third call on the bound is (value two calls ago) + slack = true - 0.2 + 0.25
+        assert all(abs(s - 0.05) < 1e-3 for s in served[2:]), served
+    params._ABSMAX.clear(); params._LAG.clear(); params._LAG_BATCH.clear()
