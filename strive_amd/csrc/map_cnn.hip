@@ -920,348 +920,6 @@ __global__ __launch_bounds__(1024, 1) void conv_ws_kernel(const float* __restric
 }
 
 // =============================================================================================
-// Specialised waves for a layer whose weight fragments do NOT fit LDS beside two input buffers (conv3: 4 passes x 13 steps x 4 KB =
-// 208 KB for both 32-channel blocks): conv_ws_kernel's split of roles, with ONE pass of weights resident (52 KB) and refilled per
-// (tile, pass) unit in two halves -- a weight ring of depth one pass:
-//     iteration u          consumers (waves 0-7, unit c = u - 1)            producers (waves 8-15)
-//     first half           matrix steps 0..6 of c  [input(c), Wlo(c)]       Whi(c) -> LDS (its steps 7..12 were last read before the
-//                                                                           previous barrier B; loads requested at the start of the
-//                                                                           half, written at its end), first part of input(u)'s staging
-//     barrier A
-//     second half          matrix steps 7..12 of c [Whi(c)], epilogue       Wlo(u) -> LDS (steps 0..6, last read before A), rest of the
-//                          after the tile's last pass                       staging of input(u)
-//     barrier B
-// Every global load is requested half a unit before it is used.  A consumer
-// wave owns one output row of the 8 x 32 tile and BOTH channel blocks (2 x 16 accumulator registers), same instruction order per
-// accumulator as conv_bf6_kernel: the activations are bit-identical, the GroupNorm moments are the same 16-value fp32 units added
-// in float64 (tests/test_emu_kernels.py::test_conv3_specialised_waves_bit_identical; bit-identical on the GPU as well).
-// MEASURED NOT TO PAY (profiles/r04_conv3_ws_probe.txt: refine closure 12.83 / 12.93 against 12.78 ms): with one output row per
-// consumer wave a step reads 6 KB of fragments from LDS for 6 matrix instructions -- 624 KB per unit = the unit's matrix time; with two
-// rows per wave one wave per SIMD issues everything.  Not used unless STRIVE_CONV3_WS=1 | 2 (strive_map_cnn_bench_layer: 52 / 53).
-// =============================================================================================
-// NCW = consumer waves: 8 (one output row each, 1024 threads, <= 128 registers) or 4 (TWO rows each: the weight fragments of a step
-// are read from LDS once for two pixel tiles -- 8 KB per 12 matrix instructions instead of 6 KB per 6; 768 threads, <= 168 registers)
-template <class Cfg, int NCW = 8>
-struct Ws2Cfg {
-    static constexpr int NCONS_W = NCW, RPW = Cfg::TH / NCW, NPROD = 512, NT = 64 * NCW + NPROD;
-    static constexpr int UITERS = (Cfg::UNITS + NPROD - 1) / NPROD;
-    static constexpr int KSPLIT = (UITERS + 1) / 2;                 // staging iterations done in the first half of a unit
-    static constexpr int WLO_STEPS = (Cfg::NKS + 1) / 2, WHI_STEPS = Cfg::NKS - WLO_STEPS;
-    static constexpr int WPASS_B = Cfg::NKS * Cfg::WSTEP_B;
-    static constexpr int WLO_Q = WLO_STEPS * Cfg::WSTEP_B / 16, WHI_Q = WHI_STEPS * Cfg::WSTEP_B / 16;     // 16-byte words of a half
-    static constexpr int WLO_IT = (WLO_Q + NPROD - 1) / NPROD, WHI_IT = (WHI_Q + NPROD - 1) / NPROD;
-    static constexpr size_t LDS_BYTES = 2 * (size_t)Cfg::IN_B + WPASS_B + 2 * (size_t)Cfg::CIN * 8 + 2 * 8 * 16 + 64;
-    static_assert(Cfg::CBW == 2 && Cfg::CSPLIT == 1 && Cfg::OUT_OCT && !Cfg::ROWS2 && Cfg::TH == NCONS_W * RPW && (NCW == 4 || NCW == 8),
-                  "built for conv3's shape");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-};
-
-template <class Cfg, int NCW>
-__device__ __forceinline__ void ws2_producer(const float* __restrict__ in, const GNStats* __restrict__ st_in, const float* __restrict__ gn_g,
-                                          const float* __restrict__ gn_b, const uint32_t* __restrict__ wfrag, float xscale,
-                                          unsigned char* s_in, unsigned char* s_w, float* s_gn, WsUnits<Cfg> un) {
-    using W = Ws2Cfg<Cfg, NCW>;
-    constexpr int CIN = Cfg::CIN, IH = Cfg::IH, TH = Cfg::TH, TW = Cfg::TW, ITW = Cfg::ITW;
-    constexpr int K1 = W::KSPLIT, K2 = W::UITERS - W::KSPLIT;          // staging iterations of the first / second half of a unit
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ptid = tid - 64 * W::NCONS_W;
-    const int nunit = un.nunit;
-    // raw input of the two parts of a unit: each part is requested half a unit before it is staged, so one register set per part
-    // is enough (16 workgroup waves per CU leave 128 registers per lane)
-    float4 rawa[K1][2], rawb[K2 > 0 ? K2 : 1][2];
-    // loads of staging iterations KB .. KB+NK-1 of unit u: unconditional, clamped (see conv_ws_kernel's producer)
-    auto issue_loads = [&](int u, auto kbc, auto& raw) __attribute__((always_inline)) {
-        constexpr int KB = decltype(kbc)::value;
-        constexpr int NK = KB == 0 ? K1 : K2;
-        int n, ty, tx, pass;
-        un.tile(u, n, ty, tx, pass);
-        const float* in_n = in + (size_t)n * IH * IH * CIN;
-        const int iy0 = 2 * ty * TH, ix0 = 2 * tx * TW;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            int idx = ptid + (KB + k) * W::NPROD;
-            idx = idx < Cfg::UNITS ? idx : Cfg::UNITS - 1;
-            const int col = idx % ITW, r = idx / ITW;
-            int iy = iy0 + r, ix = ix0 + col;
-            iy = iy < IH ? iy : IH - 1;
-            ix = ix < IH ? ix : IH - 1;
-            const float4* src = reinterpret_cast<const float4*>(in_n + (((size_t)pass * IH + iy) * IH + ix) * 8);
-            raw[k][0] = src[0];
-            raw[k][1] = src[1];
-        }
-    };
-    auto sample_moments = [&](int n) __attribute__((always_inline)) {   // (first producer wave; fixed butterfly order)
-        double ps = 0.0, pq = 0.0;
-        for (int i = lane; i < Cfg::NPART_IN; i += 64) {
-            ps += st_in[(size_t)n * Cfg::NPART_IN + i].sum;
-            pq += st_in[(size_t)n * Cfg::NPART_IN + i].sq;
-        }
-        ps = wave_sum_d(ps);
-        pq = wave_sum_d(pq);
-        const double cnt = (double)CIN * IH * IH;
-        const double mu = ps / cnt;
-        double var = pq / cnt - mu * mu;
-        var = var < 0.0 ? 0.0 : var;
-        const float mean = (float)mu, rstd = (float)(1.0 / sqrt(var + GN_EPS));
-        if (lane < CIN) {
-            const float sc = rstd * gn_g[lane];
-            float* g = s_gn + (n & 1) * CIN * 2;
-            g[2 * lane] = sc * xscale;
-            g[2 * lane + 1] = (gn_b[lane] - mean * sc) * xscale;
-        }
-    };
-    // staging iterations KB .. KB+NK-1 of unit u: raw -> GroupNorm + ReLU -> two fp16 pieces -> s_in[u & 1]
-    auto stage = [&](int u, auto kbc, const auto& raw) __attribute__((always_inline)) {
-        constexpr int KB = decltype(kbc)::value;
-        constexpr int NK = KB == 0 ? K1 : K2;
-        int n, ty, tx, pass;
-        un.tile(u, n, ty, tx, pass);
-        const int iy0 = 2 * ty * TH, ix0 = 2 * tx * TW;
-        unsigned char* buf = s_in + (u & 1) * Cfg::IN_B;
-        const float4* gn = reinterpret_cast<const float4*>(s_gn + (n & 1) * CIN * 2 + 2 * pass * Cfg::PASS_CH);
-        const float4 g0 = gn[0], g1 = gn[1], g2 = gn[2], g3 = gn[3];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int idx = ptid + (KB + k) * W::NPROD;
-            if (idx < Cfg::UNITS) {
-                const int col = idx % ITW, r = idx / ITW;
-                const int iy = iy0 + r, ix = ix0 + col;
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 0.f;             // exact zero outside the image
-                if (iy < IH && ix < IH) {
-                    const float4 a = raw[k][0], b = raw[k][1];
-                    v[0] = fmaxf(fmaf(a.x, g0.x, g0.y), 0.f);
-                    v[1] = fmaxf(fmaf(a.y, g0.z, g0.w), 0.f);
-                    v[2] = fmaxf(fmaf(a.z, g1.x, g1.y), 0.f);
-                    v[3] = fmaxf(fmaf(a.w, g1.z, g1.w), 0.f);
-                    v[4] = fmaxf(fmaf(b.x, g2.x, g2.y), 0.f);
-                    v[5] = fmaxf(fmaf(b.y, g2.z, g2.w), 0.f);
-                    v[6] = fmaxf(fmaf(b.z, g3.x, g3.y), 0.f);
-                    v[7] = fmaxf(fmaf(b.w, g3.z, g3.w), 0.f);
-                }
-                uint4 p0, p1;
-                split_f16x2(v, p0, p1);
-                unsigned char* dst = buf + r * Cfg::ROW_B + (col & 1) * Cfg::HALF_B + (col >> 1) * 16;
-                *reinterpret_cast<uint4*>(dst) = p0;
-                *reinterpret_cast<uint4*>(dst + Cfg::PIECE_B) = p1;
-            }
-        }
-    };
-    // weight halves: global [pass][step][block][piece][lane] is exactly the LDS order, a half is a plain copy.  The loads of a half
-    // are requested at the START of the half they are written in and parked in registers across its staging work (that is what
-    // hides their latency); nothing is parked across a barrier.
-    const uint4* wsrc = reinterpret_cast<const uint4*>(wfrag);
-    uint4* wdst = reinterpret_cast<uint4*>(s_w);
-    constexpr int WIT = W::WLO_IT > W::WHI_IT ? W::WLO_IT : W::WHI_IT;
-    static_assert(WIT <= 4, "four named registers per thread below");
-    // (named registers, not an array: an array written in one conditional block and read in another stayed in scratch memory here)
-    uint4 wr0, wr1, wr2, wr3;
-    wr0 = wr1 = wr2 = wr3 = make_uint4(0u, 0u, 0u, 0u);
-    auto load_half = [&](int u, auto hic) __attribute__((always_inline)) {
-        constexpr bool HI = decltype(hic)::value;
-        constexpr int Q = HI ? W::WHI_Q : W::WLO_Q, IT = HI ? W::WHI_IT : W::WLO_IT;
-        const uint4* src = wsrc + (size_t)(u % Cfg::NPASS) * (W::WPASS_B / 16) + (HI ? W::WLO_Q : 0);
-        auto at = [&](int k) __attribute__((always_inline)) { const int q = ptid + k * W::NPROD; return src[q < Q ? q : Q - 1]; };
-        if (IT > 0) wr0 = at(0);
-        if (IT > 1) wr1 = at(1);
-        if (IT > 2) wr2 = at(2);
-        if (IT > 3) wr3 = at(3);
-    };
-    auto write_half = [&](auto hic) __attribute__((always_inline)) {
-        constexpr bool HI = decltype(hic)::value;
-        constexpr int Q = HI ? W::WHI_Q : W::WLO_Q, IT = HI ? W::WHI_IT : W::WLO_IT;
-        uint4* dst = wdst + (HI ? W::WLO_Q : 0);
-        if (IT > 0 && ptid + 0 * W::NPROD < Q) dst[ptid + 0 * W::NPROD] = wr0;
-        if (IT > 1 && ptid + 1 * W::NPROD < Q) dst[ptid + 1 * W::NPROD] = wr1;
-        if (IT > 2 && ptid + 2 * W::NPROD < Q) dst[ptid + 2 * W::NPROD] = wr2;
-        if (IT > 3 && ptid + 3 * W::NPROD < Q) dst[ptid + 3 * W::NPROD] = wr3;
-    };
-    int cur_sample = -1;
-    // first-part loads of unit u (+ its sample's scale / shift when it is a new one: slot s_gn[n & 1] was last read while staging
-    // sample n - 2)
-    auto request = [&](int u) __attribute__((always_inline)) {
-        if (u >= nunit) return;
-        issue_loads(u, std::integral_constant<int, 0>(), rawa);
-        int n, ty, tx, pass;
-        un.tile(u, n, ty, tx, pass);
-        if (n != cur_sample) {
-            if (wave == W::NCONS_W) sample_moments(n);
-            cur_sample = n;
-        }
-    };
-    // prologue: the first unit's low weight half and the first part of its input (its high half goes in during iteration 1)
-    load_half(0, std::false_type());
-    request(0);
-    write_half(std::false_type());
-    __syncthreads();                                              // (P) Wlo(0) and the first sample's scale / shift are in LDS
-    for (int u = 0; u <= nunit; ++u) {
-        // ---- first half: consumers run steps 0 .. WLO_STEPS-1 of unit u - 1 ----
-        if (u >= 1) load_half(u - 1, std::true_type());           // Whi(u - 1): its region was last read before the previous barrier B
-        if (K2 > 0 && u < nunit) issue_loads(u, std::integral_constant<int, K1>(), rawb);
-        if (u < nunit) stage(u, std::integral_constant<int, 0>(), rawa);
-        if (u >= 1) write_half(std::true_type());
-        __syncthreads();                                          // (A)
-        // ---- second half: consumers run the remaining steps of unit u - 1 (+ the tile's epilogue) ----
-        if (u >= 1 && u < nunit) load_half(u, std::false_type());   // Wlo(u): steps 0 .. WLO_STEPS-1 were last read before A
-        request(u + 1);
-        if (K2 > 0 && u < nunit) stage(u, std::integral_constant<int, K1>(), rawb);
-        if (u >= 1 && u < nunit) write_half(std::false_type());
-        __syncthreads();                                          // (B)
-    }
-}
-
-template <class Cfg, int NCW>
-__device__ __forceinline__ void ws2_consumer(const unsigned char* s_in, const unsigned char* s_w, double* s_red, const float* __restrict__ bias,
-                                          float* __restrict__ out, GNStats* __restrict__ st_out, float unscale, WsUnits<Cfg> un) {
-    using W = Ws2Cfg<Cfg, NCW>;
-    constexpr int RPW = W::RPW;
-    constexpr int COUT = Cfg::COUT, OH = Cfg::OH, TH = Cfg::TH, TW = Cfg::TW, NKS = Cfg::NKS, NPASS = Cfg::NPASS, CBW = Cfg::CBW;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, j = lane & 31;
-    const int nunit = un.nunit;
-    f32x16 acc[CBW][RPW];
-    const int lane_base = (2 * RPW * wave) * Cfg::ROW_B + j * 16;         // output row RPW wave + i reads input rows from 2 (RPW wave + i)
-    f16x8 fa[2][CBW][2], fb[2][RPW][2];
-    auto load_frags = [&](const unsigned char* buf, int t, int set) {
-        int ky, kx;
-        if (Cfg::KS == 5) {
-            if (t < 10) { ky = t >> 1; kx = (t & 1) + 2 * h; }
-            else { ky = 2 * (t - 10) + h; kx = 4; ky = ky > 4 ? 4 : ky; }
-        } else {
-            if (t < 3) { ky = t; kx = 2 * h; }
-            else if (t == 3) { ky = h; kx = 1; }
-            else { ky = 2; kx = 1; }
-        }
-        const int off = ky * Cfg::ROW_B + (kx & 1) * Cfg::HALF_B + (kx >> 1) * 16;
-        const unsigned char* wb = s_w + (size_t)t * Cfg::WSTEP_B + lane * 16;        // one pass resident: [step][block][piece][lane]
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-            for (int c = 0; c < CBW; ++c) fa[set][c][pl] = *reinterpret_cast<const f16x8*>(wb + (c * 2 + pl) * 1024);
-#pragma unroll
-            for (int i = 0; i < RPW; ++i)
-                fb[set][i][pl] = *reinterpret_cast<const f16x8*>(buf + pl * Cfg::PIECE_B + lane_base + 2 * i * Cfg::ROW_B + off);
-        }
-    };
-    // matrix steps t0 .. t1-1 of unit u (a half of the unit: the fragments of t0 are read here, after the barrier that released them)
-    auto matrix_steps = [&](int u, auto t0c, auto t1c) {
-        constexpr int t0 = decltype(t0c)::value, t1 = decltype(t1c)::value;
-        int n, ty, tx, pass;
-        un.tile(u, n, ty, tx, pass);
-        const unsigned char* buf = s_in + (u & 1) * Cfg::IN_B;
-        if (pass == 0 && t0 == 0) {
-#pragma unroll
-            for (int c = 0; c < CBW; ++c)
-#pragma unroll
-                for (int i = 0; i < RPW; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
-        }
-        load_frags(buf, t0, t0 & 1);
-#pragma unroll
-        for (int s2 = 0; s2 < NKS; ++s2) {
-            if (s2 < t0 || s2 >= t1) continue;
-            const int cur = s2 & 1;
-            if (s2 + 1 < t1) load_frags(buf, s2 + 1, cur ^ 1);
-            constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
-#pragma unroll
-            for (int term = 0; term < 3; ++term)
-#pragma unroll
-                for (int c = 0; c < CBW; ++c)
-#pragma unroll
-                    for (int i = 0; i < RPW; ++i)
-                        acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][c][TA[term]], fb[cur][i][TB[term]], acc[c][i], 0, 0, 0);
-        }
-    };
-    auto epilogue = [&](int u) {                                   // after the last step of the tile's last pass
-        int n, ty, tx, pass;
-        un.tile(u, n, ty, tx, pass);
-        const int ox = tx * TW + j;
-        double dsum = 0.0, dsq = 0.0;
-#pragma unroll
-        for (int c = 0; c < CBW; ++c)
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int oy = ty * TH + RPW * wave + i;
-            const bool valid = oy < OH && ox < OH;
-            float fsum = 0.f, fsq = 0.f;
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int co = c * 32 + 8 * rg + 4 * h;
-                const float4 bv = *reinterpret_cast<const float4*>(bias + co);
-                float4 v;
-                v.x = fmaf(acc[c][i][4 * rg + 0], unscale, bv.x);
-                v.y = fmaf(acc[c][i][4 * rg + 1], unscale, bv.y);
-                v.z = fmaf(acc[c][i][4 * rg + 2], unscale, bv.z);
-                v.w = fmaf(acc[c][i][4 * rg + 3], unscale, bv.w);
-                if (valid) {
-                    *reinterpret_cast<float4*>(out + ((((size_t)n * (COUT / 8) + (co >> 3)) * OH + oy) * OH + ox) * 8 + (co & 7)) = v;
-                    fsum += (v.x + v.y) + (v.z + v.w);
-                    fsq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fsq))));
-                }
-            }
-            dsum += (double)fsum;                                   // fp32 over one accumulator tile, float64 above (see conv_bf6_kernel)
-            dsq += (double)fsq;
-        }
-        const double lsum = wave_sum_d(dsum), lsq = wave_sum_d(dsq);
-        const int tl = (u / NPASS) & 1;
-        if (lane == 0) { s_red[(tl * 8 + wave) * 2] = lsum; s_red[(tl * 8 + wave) * 2 + 1] = lsq; }
-    };
-    auto publish_stats = [&](int u) {                              // thread 0, one barrier after the tile's epilogue
-        int n, ty, tx, pass;
-        un.tile(u, n, ty, tx, pass);
-        const int tl = (u / NPASS) & 1;
-        double a = 0.0, b = 0.0;
-        for (int w = 0; w < W::NCONS_W; ++w) { a += s_red[(tl * 8 + w) * 2]; b += s_red[(tl * 8 + w) * 2 + 1]; }
-        GNStats& o = st_out[(size_t)n * Cfg::NPART_OUT + (ty * Cfg::TILES_X + tx)];
-        o.sum = a;
-        o.sq = b;
-    };
-    __syncthreads();                                              // (P)
-    for (int u = 0; u <= nunit; ++u) {
-        if (u >= 1) matrix_steps(u - 1, std::integral_constant<int, 0>(), std::integral_constant<int, W::WLO_STEPS>());
-        // the statistics of the tile that ended with unit u - 2: its epilogue ran before barrier B of iteration u - 1
-        if (tid == 0 && u >= 2 && ((u - 2) % NPASS) == NPASS - 1) publish_stats(u - 2);
-        __syncthreads();                                          // (A)
-        if (u >= 1) {
-            matrix_steps(u - 1, std::integral_constant<int, W::WLO_STEPS>(), std::integral_constant<int, NKS>());
-            if (((u - 1) % NPASS) == NPASS - 1) epilogue(u - 1);
-        }
-        __syncthreads();                                          // (B)
-    }
-    if (tid == 0 && nunit >= 1 && ((nunit - 1) % NPASS) == NPASS - 1) publish_stats(nunit - 1);
-}
-
-template <class Cfg, int NCW>
-__global__ __launch_bounds__(64 * NCW + 512, 1) void conv_ws2_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
-                                                            const float* __restrict__ gn_g, const float* __restrict__ gn_b,
-                                                            const uint32_t* __restrict__ wfrag, const float* __restrict__ bias,
-                                                            float* __restrict__ out, GNStats* __restrict__ st_out, int N, float xscale,
-                                                            float unscale) {
-    using W = Ws2Cfg<Cfg, NCW>;
-    HIP_DYNAMIC_SHARED(float, smem)
-    unsigned char* s_in = reinterpret_cast<unsigned char*>(smem);          // [2][IN_B]
-    unsigned char* s_w = s_in + 2 * Cfg::IN_B;                              // one pass: [step][block][piece][lane][16 B]
-    float* s_gn = (float*)(s_w + W::WPASS_B);                               // [2][CIN][2] scale, shift of the sample (parity)
-    double* s_red = (double*)(s_gn + 2 * Cfg::CIN * 2);                     // [2][8][2]
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int total = N * Cfg::TILES_X * Cfg::TILES_Y;
-    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
-    WsUnits<Cfg> un;
-    un.t_begin = (int)blockIdx.x * per;
-    const int t_end = (un.t_begin + per) < total ? (un.t_begin + per) : total;
-    un.nunit = (t_end > un.t_begin ? t_end - un.t_begin : 0) * Cfg::NPASS;
-    if (un.nunit == 0) return;
-    // both roles execute the same sequence of barriers: (P), then (A), (B) per iteration
-    if (wave >= W::NCONS_W) ws2_producer<Cfg, NCW>(in, st_in, gn_g, gn_b, wfrag, xscale, s_in, s_w, s_gn, un);
-    else ws2_consumer<Cfg, NCW>(s_in, s_w, s_red, bias, out, st_out, unscale, un);
-}
-
-// =============================================================================================
 // The same bf16 x 6 scheme for SMALL images (conv5: 64 -> 128 channels, 14 x 14 -> 6 x 6; conv6: 128 -> 128, 6 x 6 -> 2 x 2;
 // both 3x3): a workgroup takes S whole samples, the 32-pixel MFMA tiles are filled with the linearised pixels (sample, y, x) of those samples (S = 7: 252 of
 // 256 lanes carry a pixel), and every lane keeps the LDS offset of its own window origin.  Input octet-planar, the 8
@@ -1576,31 +1234,6 @@ static int launch_ws(const float* in, const GNStats* st_in, const float* g, cons
     return 0;
 }
 
-template <class Cfg, int NCW>
-static int launch_ws2(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
-                      const float* bias, float* out, GNStats* st_out, int N, float xscale, float wscale, hipStream_t stream) {
-    using W = Ws2Cfg<Cfg, NCW>;
-    static PerDeviceOnce once;
-    const int dev = once.device();
-    if (!once.is_done(dev)) {
-        hipFuncSetAttribute((const void*)(conv_ws2_kernel<Cfg, NCW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES);
-        int v = 0;
-        if (!(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)) v = 256;
-        once.value[dev].store(v, std::memory_order_relaxed);
-        once.set_done(dev);
-    }
-    const int ncu = once.value[dev].load(std::memory_order_relaxed);
-    const int total = N * Cfg::TILES_X * Cfg::TILES_Y;
-    int grid = total < ncu ? total : ncu;
-    if (const char* e = getenv("STRIVE_CONV_WS_GRID")) {          // test hook: fewer workgroups = longer tile ranges per workgroup
-        const int g = atoi(e);
-        if (g >= 1 && g < grid) grid = g;
-    }
-    hipLaunchKernelGGL((conv_ws2_kernel<Cfg, NCW>), dim3(grid), dim3(W::NT), W::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out, st_out, N,
-                       xscale, 1.0f / (xscale * wscale));
-    return 0;
-}
-
 template <class Cfg>
 static int launch_bf6(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
                       const float* bias, float* out, GNStats* st_out, int N, float xscale, float wscale, hipStream_t stream) {
@@ -1611,6 +1244,9 @@ static int launch_bf6(const float* in, const GNStats* st_in, const float* g, con
         hipFuncSetAttribute((const void*)conv_bf6_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
         once.set_done(dev);
     }
+    // (round 5, tools/conv_dephase_probe.py at commit "dephase probe": holding back one of every two co-resident workgroups by a
+    // fraction of a staging + matrix period -- by wave slot parity or by id -- changes conv2 / conv3 / conv4 by less than the
+    // run-to-run noise, profiles/r05_conv_dephase_probe.txt: the workgroups of a CU do not run in lock step)
     hipLaunchKernelGGL(conv_bf6_kernel<Cfg>, grid, dim3(Cfg::NT), Cfg::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out,
                        st_out, N, xscale, 1.0f / (xscale * wscale));
     return 0;
@@ -1791,15 +1427,7 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
             launch_cnn_tail(cnn, act[3], st[3], Bf4s::NPART_OUT, feat + (size_t)n0 * 64, n, stream, nullptr, tail_s);
             continue;
         }
-        // conv3 on specialised waves with a one-pass weight ring: measured a wash (profiles/r04_conv3_ws_probe.txt) -> opt-in
-        const char* c3 = getenv("STRIVE_CONV3_WS");               // (read per call: the tests switch it inside one process)
-        const int conv3_ws = c3 ? atoi(c3) : 0;                    // 1: 8 consumer waves x 1 row, 2: 4 consumer waves x 2 rows
-        if (conv3_ws == 2 && !cnn->conv2_plain)
-            launch_ws2<Bf3, 4>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
-        else if (conv3_ws && !cnn->conv2_plain)
-            launch_ws2<Bf3, 8>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
-        else
-            launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
+        launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
         launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, cnn->xscale[3], cnn->wscale[3], stream);
         if (!keep_tail_activations) {
             launch_cnn_tail(cnn, act[3], st[3], NPARTS[3], feat + (size_t)n0 * 64, n, stream, nullptr, tail_s);
@@ -1839,7 +1467,7 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
                                           const float* pos_mean4_host, const float* pos_std4_host, const int32_t* mapix,
                                           int32_t N, float* feat, void* ws, size_t ws_bytes, strive_stream_t stream_) {
     STRIVE_CHECK_ARG(map && cnn && pos && mapix && feat && ws, "null argument");
-    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK_MAX && layer >= 0 && layer <= 53, "bad layer / N");
+    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK_MAX && layer >= 0 && layer <= 51, "bad layer / N");
     STRIVE_CHECK_ARG(ws_bytes >= strive_map_cnn_workspace_bytes(N), "workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
     StriveArena ar(ws, ws_bytes);
@@ -1903,8 +1531,6 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
         case 1: launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
         case 51: launch_ws<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;   // conv2, specialised waves
         case 2: launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, cnn->xscale[2], cnn->wscale[2], stream); break;
-        case 53: launch_ws2<Bf3, 4>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, cnn->xscale[2], cnn->wscale[2], stream); break;   // the same with 4 consumer waves x 2 rows
-        case 52: launch_ws2<Bf3, 8>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, cnn->xscale[2], cnn->wscale[2], stream); break;   // conv3, specialised waves + weight ring
         case 3: launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], N, cnn->xscale[3], cnn->wscale[3], stream); break;
         case 4: launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], N, cnn->xscale[4], cnn->wscale[4], stream); break;
         case 5: launch_bf6s<Bfs6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w6_frag, cnn->b[5], act[5], st[5], N, cnn->xscale[5], cnn->wscale[5], stream); break;

@@ -837,62 +837,6 @@ def test_rollout_reads_nothing_it_did_not_write(emu, sd, sizes, FT, ext, monkeyp
     assert torch.equal(dz_zero, dz_nan)
 
 
-def test_conv3_specialised_waves_bit_identical(emu, sd, monkeypatch):
-    """conv3 on producer / consumer waves with a one-pass weight ring (conv_ws2_kernel, hook layer 52) against conv_bf6_kernel
-    (layer 2) on the same conv2 output: the activations bit for bit, the GroupNorm moments to float64 rounding (the layers behind
-    it give the same features)."""
-    monkeypatch.setenv('STRIVE_CNN_SMALL_BATCH', '0')
-    raster, dx, frame, mapixes, lw = mg.g2_inputs()
-    env = synth.SyntheticMapEnv(raster, dx)
-    n = 3
-    fr = np.zeros((n, 4))
-    fr[:, 0] = synth.counter_uniform((n,), 'w3/x', 40.0, 200.0)
-    fr[:, 1] = synth.counter_uniform((n,), 'w3/y', 40.0, 200.0)
-    ang = synth.counter_uniform((n,), 'w3/h', -np.pi, np.pi)
-    fr[:, 2], fr[:, 3] = np.cos(ang), np.sin(ang)
-    fr = synth.f32(fr).contiguous()
-    mi = torch.tensor([i % 2 for i in range(n)], dtype=torch.int32)
-    cnn, mp = params.pack_cnn(sd), params.pack_map(env, 'cpu')
-    wsb = emu.query('strive_map_cnn_workspace_bytes', n)
-    ws = torch.full((wsb,), 0xFF, dtype=torch.uint8)
-    feat = torch.zeros((n, 64))
-    args = (mp.ref(), cnn.ref())
-    tail = (L.ptr(fr), L.f4([0] * 4), L.f4([1] * 4), L.ptr(mi), n)
-    emu.call('strive_map_cnn_fwd', *args, *tail, L.ptr(feat), L.ptr(ws), wsb, None)
-
-    def align(v):
-        return (v + 255) // 256 * 256
-    o2 = align(16 * 125 * 125 * 4 * n) + align(32 * 61 * 61 * 4 * n)      # act[0] | act[1] | act[2] ... (256-byte aligned blocks)
-    nb = 64 * 29 * 29 * 4 * n
-    out = {}
-    # grids of 12 / 5 / 1 workgroups: one tile each; ranges of 3 tiles that end inside a sample (and a workgroup without work); ONE
-    # workgroup walking all 48 (tile, pass) units of the three samples through the ring
-    # (layer 53: the same kernel with 4 consumer waves of two output rows each)
-    for layer, grid in ((2, None), (52, None), (52, '5'), (52, '1'), (53, None), (53, '5'), (53, '1')):
-        ws[o2:o2 + nb] = 0xFF
-        if grid is None:
-            monkeypatch.delenv('STRIVE_CONV_WS_GRID', raising=False)
-        else:
-            monkeypatch.setenv('STRIVE_CONV_WS_GRID', grid)
-        emu.call('strive_map_cnn_bench_layer', *args, layer, *tail, L.ptr(feat), L.ptr(ws), wsb, None)
-        got = ws[o2:o2 + nb].clone().view(torch.float32)
-        assert torch.isfinite(got).all(), 'layer %d (grid %s) left part of conv3\'s output unwritten' % (layer, grid)
-        if layer == 2:
-            out[2] = got
-        else:
-            assert torch.equal(out[2], got), 'conv3, grid %s: %.3g apart' % (grid, float((out[2] - got).abs().max()))
-    # the layers behind it read its statistics: the whole CNN with conv3 on the new kernel gives the same features
-    for layer in (3, 7):
-        emu.call('strive_map_cnn_bench_layer', *args, layer, *tail, L.ptr(feat), L.ptr(ws), wsb, None)
-    want = _cnn_features(emu, args, fr, mi, n)
-    assert torch.equal(feat, want)
-    # and as strive_map_cnn_fwd runs it when asked to (STRIVE_CONV3_WS=1: opt-in until it has been measured)
-    monkeypatch.setenv('STRIVE_CONV_WS_GRID', '2')
-    for form in ('1', '2'):
-        monkeypatch.setenv('STRIVE_CONV3_WS', form)
-        assert torch.equal(_cnn_features(emu, args, fr, mi, n), want)
-
-
 def _cnn_features(emu, args, fr, mi, n):
     wsb = emu.query('strive_map_cnn_workspace_bytes', n)
     ws = torch.zeros(wsb, dtype=torch.uint8)

@@ -1,5 +1,6 @@
-"""conv2 (bench-layer codes 1 / 51) and conv3 (codes 2 / 52) as conv_bf6_kernel against the specialised-wave forms (conv_ws_kernel,
-conv_ws2_kernel): time per launch and bit identity of the outputs.  usage: python tools/conv_ws_probe.py [N ...]"""
+"""conv2 (bench-layer codes 1 / 51) as conv_bf6_kernel against the specialised-wave form (conv_ws_kernel): time per launch and bit
+identity of the outputs.  (conv3's specialised-wave forms, codes 52 / 53, were measured in round 4 -- profiles/r04_conv3_ws_probe.txt --
+and removed from the library in round 5: git show 5eda569:strive_amd/csrc/map_cnn.hip.)  usage: python tools/conv_ws_probe.py [N ...]"""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
@@ -43,7 +44,7 @@ for n in (int(a) for a in (sys.argv[1:] or ['512'])):
     nb1 = 32 * 61 * 61 * 4 * n
     o2 = o1 + align(nb1)
     nb2 = 64 * 29 * 29 * 4 * n
-    for name, a_id, b_id, off, nb in (('conv2', 1, 51, o1, nb1), ('conv3 (8 consumer waves)', 2, 52, o2, nb2), ('conv3 (4 consumer waves x 2 rows)', 2, 53, o2, nb2)):
+    for name, a_id, b_id, off, nb in (('conv2', 1, 51, o1, nb1),):
         ws[off:off + nb].zero_(); run(a_id, 1); torch.cuda.synchronize(); a = ws[off:off + nb].clone()
         ws[off:off + nb].zero_(); run(b_id, 1); torch.cuda.synchronize(); b = ws[off:off + nb].clone()
         print('N=%d %s: conv_bf6_kernel %.1f us, specialised waves %.1f us, outputs bit-identical: %s (non-zero: %s)' % (
