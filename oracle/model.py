@@ -147,7 +147,7 @@ class OracleTrafficModel(object):
         return self.att_normalizer
 
     # -- encoders ---------------------------------------------------------------------------
-    def encode_map(self, pos_norm, batch_of_agent, map_idx, map_env):
+    def encode_map(self, pos_norm, batch_of_agent, map_idx, map_env, return_crop=False, crop_only=False):
         """pos_norm (NA,4) or (NA,NS,4) NORMALISED -> map feature (NA,[NS,]64).
         Restates encode_map (reference src/models/traffic_model.py:416-451) without the in-place
         graph (un)normalisation round trip (it has no observable effect)."""
@@ -159,10 +159,12 @@ class OracleTrafficModel(object):
             NS = pos.shape[1]
             pos = pos.reshape(NA * NS, 4)
             mapixes = mapixes.unsqueeze(1).expand(NA, NS).reshape(-1)
-        crop = map_crop(map_env.nusc_raster, map_env.nusc_dx, pos, mapixes, map_env.bounds,
-                        L=map_env.L, W=map_env.W).to(torch.float)
-        feat = map_cnn(self.sd, crop, self.nconv)
-        return feat.reshape(NA, NS, -1) if multi else feat
+        crop_u8 = map_crop(map_env.nusc_raster, map_env.nusc_dx, pos, mapixes, map_env.bounds, L=map_env.L, W=map_env.W)
+        if crop_only:
+            return None, crop_u8
+        feat = map_cnn(self.sd, crop_u8.to(torch.float), self.nconv)
+        feat = feat.reshape(NA, NS, -1) if multi else feat
+        return (feat, crop_u8) if return_crop else feat
 
     def _encode_traj(self, prefix, g, traj, vis):
         NA, T, _ = traj.shape
@@ -206,10 +208,18 @@ class OracleTrafficModel(object):
 
     # -- decoder ----------------------------------------------------------------------------
     def decode(self, g, map_feat, past_feat, z, map_idx, map_env, ext_future=None, nfuture=None,
-               return_trace=False):
+               return_trace=False, crop_poses=None):
         """Autoregressive rollout; ``z (NA,D)`` or ``(NA,NS,D)`` -> normalised global
         (x,y,hx,hy) of shape ``(NA,FT,4)`` / ``(NA,NS,FT,4)``.
-        Restates autoregressive_decoder (reference src/models/traffic_model.py:589-704)."""
+        Restates autoregressive_decoder (reference src/models/traffic_model.py:589-704).
+
+        ``crop_poses`` (test hook, not in the reference): ``(NA,[NS,]>=FT-1,4)`` normalised poses at which the raster is cropped
+        for steps 1 .. FT-1 INSTEAD of this rollout's own (detached) poses.  The reference crops at ``pos.detach()`` (:694-695), so
+        the crop is data, not part of the autograd graph: feeding the poses of ANOTHER evaluation of the same rollout (the HIP
+        path's, 1e-7 away) removes the one discontinuous step of the chain -- a pose difference in the last bit can flip crop
+        pixels and move a map feature by 4e-3 -- and leaves a smooth function that two fp32 implementations must agree on
+        tightly, forward and backward.  ``self.last_crop_flips`` then holds, per (row, step), whether the crop at the forced pose
+        differs from the crop at this rollout's own pose."""
         NA = map_feat.shape[0]
         FT = self.FT if nfuture is None else nfuture
         multi = z.dim() == 3
@@ -236,6 +246,10 @@ class OracleTrafficModel(object):
             ext = ext.reshape(-1, ext_future.shape[1], 4)
         traj = []
         trace = []
+        flips = torch.zeros((R, FT), dtype=torch.bool)
+        if crop_poses is not None:
+            crop_poses = crop_poses.detach().reshape(NA, NS, crop_poses.shape[-2], 4)
+            assert crop_poses.shape[2] >= FT - 1
         for t in range(FT):
             feat = torch.cat([cur_past, cur_map, sem_r, zz, lw_r], dim=-1)
             dec = interaction_net(self.sd, 'decoder_net', feat, pos, g.sem, g.edge_index).reshape(R, 2)
@@ -260,16 +274,27 @@ class OracleTrafficModel(object):
             if t < FT - 1:
                 top, mem = gru_step(self.sd, 'decoder_memory', local, mem)
                 cur_past = top.reshape(NA, NS, -1)
-                cur_map = self.encode_map(glob.detach().reshape(NA, NS, 4), g.batch, map_idx, map_env)
+                own = glob.detach().reshape(NA, NS, 4)
+                if crop_poses is None:
+                    cur_map = self.encode_map(own, g.batch, map_idx, map_env)
+                else:
+                    forced = crop_poses[:, :, t].clone()
+                    if ext_future is not None:
+                        forced.reshape(R, 4)[ego_rows] = ext[:, t]          # (the injected ego pose is the same data in both runs)
+                    cur_map, crop_f = self.encode_map(forced, g.batch, map_idx, map_env, return_crop=True)
+                    with torch.no_grad():
+                        _, crop_o = self.encode_map(own, g.batch, map_idx, map_env, return_crop=True, crop_only=True)
+                    flips[:, t + 1] = (crop_f != crop_o).flatten(1).any(1)
                 pos = glob.reshape(NA, NS, 4)
         out = torch.stack(traj, dim=1)
         out = out.reshape(NA, NS, FT, 4) if multi else out
+        self.last_crop_flips = flips
         return (out, trace) if return_trace else out
 
-    def decode_embedding(self, z, embed_out, g, map_idx, map_env, ext_future=None, nfuture=None):
-        """(reference src/models/traffic_model.py:405-414)"""
+    def decode_embedding(self, z, embed_out, g, map_idx, map_env, ext_future=None, nfuture=None, crop_poses=None):
+        """(reference src/models/traffic_model.py:405-414); ``crop_poses``: see decode (test hook)"""
         return {'future_pred': self.decode(g, embed_out['map_feat'], embed_out['past_feat'], z, map_idx,
-                                           map_env, ext_future=ext_future, nfuture=nfuture)}
+                                           map_env, ext_future=ext_future, nfuture=nfuture, crop_poses=crop_poses)}
 
     def sample_batched(self, g, map_idx, map_env, eps, include_mean=False, nfuture=None):
         """NS prior samples rolled out jointly; ``eps (NS,NA,D)`` is injected because the reference
@@ -293,9 +318,11 @@ class OracleTrafficModel(object):
             'z_mdist': torch.norm((z - smu) / torch.sqrt(svar), dim=-1).transpose(0, 1),
         }
 
-    def forward(self, g, map_idx, map_env, eps_post=None, eps_prior=None, use_post_mean=False):
+    def forward(self, g, map_idx, map_env, eps_post=None, eps_prior=None, use_post_mean=False, crop_poses=None):
         """Training forward: posterior-sample rollout (+ prior-sample rollout when ``eps_prior``
-        is given).  (reference src/models/traffic_model.py:178-225)"""
+        is given).  (reference src/models/traffic_model.py:178-225).  ``crop_poses`` = (poses of the posterior rollout, poses of
+        the prior rollout): the test hook of ``decode``."""
+        cp_pred, cp_samp = crop_poses if crop_poses is not None else (None, None)
         map_feat = self.encode_map(g.past[:, -1, :4], g.batch, map_idx, map_env)
         past_feat = self.encode_past(g)
         future_feat = self.encode_future(g)
@@ -303,8 +330,10 @@ class OracleTrafficModel(object):
         qmu, qvar = self.posterior(g, map_feat, past_feat, future_feat)
         z = qmu if use_post_mean else qmu + eps_post * torch.sqrt(qvar)
         out = {'prior_out': (pmu, pvar), 'posterior_out': (qmu, qvar),
-               'future_pred': self.decode(g, map_feat, past_feat, z, map_idx, map_env)}
+               'future_pred': self.decode(g, map_feat, past_feat, z, map_idx, map_env, crop_poses=cp_pred)}
+        out['crop_flips_pred'] = self.last_crop_flips
         if eps_prior is not None:
             zp = pmu + eps_prior * torch.sqrt(pvar)
-            out['future_samp'] = self.decode(g, map_feat, past_feat, zp, map_idx, map_env)
+            out['future_samp'] = self.decode(g, map_feat, past_feat, zp, map_idx, map_env, crop_poses=cp_samp)
+            out['crop_flips_samp'] = self.last_crop_flips
         return out

@@ -221,3 +221,66 @@ def run_product_hardcode_loop(g, m, n, device):
     res = run_adv_gen_optim(z0, mg.LOOP_LR, mg.LOOP_WEIGHTS, m, bg, env, mi, n, emb, 'hardcode', (pm[ego], pv[ego]), (pm[~ego], pv[~ego]),
                             2, 0.0, planner=planner, log=trace_logger(trace))
     return trace, res
+
+
+def check_trace_at_product_latents(name, kind, g, m, orc, trace, device, loss_rtol=2e-3, loss_atol=1e-4, grad_rel=2e-2, report=None):
+    """Iteration by iteration, WITHOUT accumulation: the oracle's closure of loop ``name`` evaluated at the latents the PRODUCT's
+    loop visited (``trace`` of run_product_loop), cropping the raster at the product's rollout poses (oracle/loops.py test hooks:
+    num_iters = 1, init_z, crop_poses) -- i.e. the same smooth function on both sides, also over the textured raster, also after
+    the two free-running runs have passed a kink or a crop flip at slightly different latents.  Every loss entry (mean) within
+    loss_rtol / loss_atol and every leaf's gradient within ``grad_rel`` (relative L2) at EVERY iteration.  Returns the worst figures."""
+    from oracle import loops
+    from strive_amd.utils.scenario_gen import detach_embed_info
+    batch, map_idx, raster, dx = loop_inputs(kind)
+    env_c = synth.SyntheticMapEnv(raster, dx)
+    env_g = synth.SyntheticMapEnv(raster.clone(), dx.clone()).to(device)
+    bg, mi = batch.clone().to(device), map_idx.to(device)
+    with torch.no_grad():
+        emb_g = detach_embed_info(m.embed(bg, mi, env_g))
+    emb_c = {k: (tuple(t.cpu() for t in v) if isinstance(v, tuple) else v.cpu()) for k, v in emb_g.items()}      # the product's embed on both sides
+    NA = batch.past.shape[0]
+    ego = torch.zeros((NA,), dtype=torch.bool)
+    ego[batch.ptr[:-1]] = True
+    pm, pv = emb_c['prior_out']
+    tp, op = (pm[ego], pv[ego]), (pm[~ego], pv[~ego])
+    worst = {'loss_rel': 0.0, 'grad_rel': 0.0, 'crop_flips': 0}
+    z_first = [z.clone() for z in trace[0]['z']]
+    fin = torch.from_numpy(g[kind + '/adv/final_result_traj']) if name == 'sol' else None
+    ext = batch.future_gt[ego][:, :, :4].contiguous() if name == 'adv' else None
+    for it, ent in enumerate(trace):
+        zs = [z.clone() for z in ent['z']]
+        if name == 'init':
+            zc = zs[0]
+        else:
+            zc = loops.collate_tgt_other_z(batch.ptr, zs[0].reshape(zs[0].shape[0], -1), zs[1].reshape(zs[1].shape[0], -1))
+        with torch.no_grad():       # the product's rollout at these latents (bit-reproducible): the poses its crops were taken at
+            kw = {'nfuture': 16} if name == 'sol' else ({'ext_future': ext.to(device)} if name == 'adv' else {})
+            poses = m.decode_embedding(zc.to(device), emb_g, bg, mi, env_g, **kw)['future_pred'].cpu()
+        t = []
+        if name == 'init':
+            loops.init_loop(orc, batch, map_idx, env_c, emb_c, zc, batch.future_gt[:, :, :4], batch.future_vis, mg.LOOP_WEIGHTS, 1,
+                            mg.LOOP_LR, emb_c['prior_out'], trace=t, crop_poses=poses)
+        elif name == 'adv':
+            z0c = loops.collate_tgt_other_z(batch.ptr, z_first[0], z_first[1])
+            loops.adv_loop(orc, batch, map_idx, env_c, emb_c, zc, mg.LOOP_WEIGHTS, 1, mg.LOOP_LR, tp, op, feasibility_time=2,
+                           feasibility_infront_min=0.0, trace=t, init_z=z0c[~ego], crop_poses=poses)
+        else:
+            loops.sol_loop(orc, batch, map_idx, env_c, emb_c, zc, fin, 16, mg.LOOP_WEIGHTS, 1, mg.LOOP_LR, tp, op, trace=t,
+                           init_z=z_first[0].reshape(z_first[0].shape[0], -1),
+                           start_z=(zs[0].reshape(zs[0].shape[0], -1), zs[1].reshape(zs[1].shape[0], -1)), crop_poses=poses)
+        want = t[0]
+        worst['crop_flips'] += int(want['crop_flips'].sum())
+        for k, v in want.items():
+            if k in ('z', 'grad', 'crop_flips') or k not in ent or not torch.is_tensor(v):
+                continue
+            a, b = float(torch.mean(ent[k].float())), float(torch.mean(v.float()))
+            worst['loss_rel'] = max(worst['loss_rel'], abs(a - b) / (loss_atol / loss_rtol + abs(b)))
+            assert abs(a - b) <= loss_atol + loss_rtol * abs(b), '%s/%s iteration %d at the product latents: %s %.6g vs %.6g' % (kind, name, it, k, a, b)
+        for i, (gg, gw) in enumerate(zip(ent['grad'], want['grad'])):
+            gg, gw = gg.double().reshape(-1), gw.double().reshape(-1)
+            rel = float((gg - gw).norm() / max(float(gw.norm()), 1e-30))
+            worst['grad_rel'] = max(worst['grad_rel'], rel)
+            assert rel <= grad_rel, '%s/%s iteration %d at the product latents: gradient of leaf %d off by %.3g (relative L2)' % (kind, name, it, i, rel)
+    if report is not None:
+        report.append(('%s/%s@product' % (kind, name), len(trace), worst))
+    return worst

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import make_golden as mg
-from util import golden, oracle_model, product_model, assert_close, assert_close_frac
+from util import golden, oracle_model, product_model, assert_close, assert_close_frac, crop_flips, clean_mask, assert_close_flip_gated
 from strive_amd import synth
 from strive_amd.graph import Batch
 
@@ -71,8 +71,31 @@ def test_nc5_embed_and_rollout_golden():
             assert_close(pred, g[pre + 'pred'], RT, AT, 'NC=5 future_pred (uniform raster)')
             assert_close(zg.grad, gz, 2e-3, 1e-6 + 2e-4 * float(np.abs(gz).max()), 'NC=5 dL/dz (uniform raster)')
         else:
-            assert_close(pred, g['pred'], 0, 1e-2, 'NC=5 future_pred (textured)')
-            assert_close(zg.grad, gz, 0, 5e-2 * float(np.abs(gz).max()), 'NC=5 dL/dz (textured)')
+            # textured raster against the REFERENCE's free-running rollout: tight up to a scene's first OBSERVED crop difference
+            # (both runs' crops compared exactly, tests/util.py), the loose bound only downstream of one ...
+            from strive_amd.constants import state_norm_tensors
+            mean, std = state_norm_tensors()
+            want = torch.from_numpy(g['pred'])
+            FT = pred.shape[1]
+            flips = crop_flips(env, synth.SyntheticMapEnv(ra, dxx), pred.detach().cpu(), want, map_idx[batch.batch], mean[:4], std[:4])
+            clean = clean_mask(flips, batch.batch)
+            n_clean, n_all = assert_close_flip_gated(pred, want, clean, RT, AT, 1e-2, 'NC=5 future_pred (textured)', min_clean=pred.shape[0])
+            print('NC=5 textured: %d crop differences in %d crops, %d of %d cells tight' % (int(flips.sum()), pred.shape[0] * (FT - 1), n_clean, n_all))
+            dirty = {int(b) for b in torch.unique(batch.batch[flips.any(1)]).tolist()}
+            ok_rows = torch.tensor([int(b) not in dirty for b in batch.batch.tolist()])
+            gg, gw = zg.grad.detach().cpu(), torch.from_numpy(gz)
+            if bool(ok_rows.any()):
+                assert_close(gg[ok_rows], gw[ok_rows], 2e-3, 1e-6 + 2e-4 * float(np.abs(gz).max()), 'NC=5 dL/dz (scenes without a crop difference)')
+            if bool((~ok_rows).any()):
+                assert_close(gg[~ok_rows], gw[~ok_rows], 0, 5e-2 * float(np.abs(gz).max()), 'NC=5 dL/dz (scenes with an observed crop difference)')
+            # ... and tight everywhere against the oracle evaluating the same smooth function (cropping at the product's poses)
+            orc5 = oracle_model(sd5, NC=5)
+            zc = z.clone().requires_grad_(True)
+            femb_c = {'map_feat': torch.from_numpy(g['map_feat']), 'past_feat': torch.from_numpy(g['past_feat'])}
+            pc = orc5.decode_embedding(zc, femb_c, batch, map_idx, synth.SyntheticMapEnv(ra, dxx), crop_poses=pred.detach().cpu())['future_pred']
+            gc, = torch.autograd.grad((pc * rw.cpu()).sum(), [zc])
+            assert_close(pred, pc, RT, AT, 'NC=5 future_pred (textured, same crops)')
+            assert_close(zg.grad, gc, 2e-3, 1e-6 + 2e-4 * float(gc.abs().max()), 'NC=5 dL/dz (textured, same crops)')
 
 
 # ------------------------------------------------------------------------------------------------
@@ -122,8 +145,11 @@ def test_headline_closure_backward_is_per_scene(model):
 # configs[2]: the adversarial closure at ~512 agents in scenes of 2..30
 # ------------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize('NC', [2, 5])
-def test_adv_closure_at_size(model, NC):
+@pytest.mark.parametrize('NC,NA', [(2, 512), (5, 512), (5, 4096)])
+def test_adv_closure_at_size(model, NC, NA):
+    """One adversarial closure on ~512 agents (configs[2]) and on the 4096-agent NC = 5 batch of configs[4] (adv_gen_replay_cyclist
+    .cfg's all-category batch; bench.py --workload sharded4096 runs it, this test pins it): complementary detach, and three
+    sampled scenes -- largest, smallest, one in between -- forward + d/dz against the oracle's rollout of the scene ALONE."""
     import bench
     from strive_amd.utils.adv_gen_optim import AdvClosure
     from strive_amd.utils.scenario_gen import detach_embed_info
@@ -131,16 +157,15 @@ def test_adv_closure_at_size(model, NC):
         m, sd = model
     else:
         m, sd = product_model(NC=5, device=DEV, key='weights5')
-    sizes = bench.variable_scene_sizes(512, 'gc/adv')
-    assert sum(sizes) == 512 and min(sizes) >= 2 and max(sizes) <= 30
+    sizes = bench.variable_scene_sizes(NA, 'gc/adv' if NA == 512 else 'gc/adv%d' % NA)
+    assert sum(sizes) == NA and min(sizes) >= 2 and max(sizes) <= 30
     raster, dx = uniform()
     env = dev_env(raster, dx)
-    batch, map_idx = synth.make_batch(sizes, key='gc/adv%d' % NC, NC=NC, map_extent=(512.0, 512.0))
+    batch, map_idx = synth.make_batch(sizes, key='gc/adv%d' % NC if NA == 512 else 'gc/adv%d/%d' % (NC, NA), NC=NC, map_extent=(512.0, 512.0))
     bg = batch.clone().to(DEV)
     mi = map_idx.to(DEV)
     with torch.no_grad():
         emb = detach_embed_info(m.embed(bg, mi, env))
-    NA = 512
     ego = torch.zeros((NA,), dtype=torch.bool, device=DEV)
     ego[bg.ptr[:-1].to(DEV)] = True
     pm, pv = emb['prior_out']
@@ -201,6 +226,67 @@ def test_adv_closure_at_size(model, NC):
         others = torch.ones((NA,), dtype=torch.bool)
         others[lo:hi] = False
         assert float(zf.grad[others.to(DEV)].abs().max()) == 0.0, 'no gradient may leak into other scenes'
+
+
+def test_adv_loop_with_an_attacker_of_one_category_nc5():
+    """configs[4] (adv_gen_replay_cyclist.cfg: all categories, ``adv_attack_with: cyclist``): what the attacker restriction turns
+    into inside the loop is ``attack_agt_idx`` -- per scene the LOCAL index of the one agent allowed to attack (reference
+    src/utils/adv_gen_optim.py:43-58, :154; the category filter itself is adv_scenario_gen.py:209-220) -- which masks every other
+    agent out of the crash soft-min.  run_adv_gen_optim(NC = 5, attack_agt_idx = the first agent of the chosen category in every
+    scene) for 3 iterations against oracle.loops.adv_loop: every loss entry, both gradients and the latents per iteration, and
+    the attacker the loop reports is the one it was given."""
+    from oracle import loops as oloops
+    import loop_util as lu
+    from strive_amd.utils.adv_gen_optim import run_adv_gen_optim
+    from strive_amd.utils.scenario_gen import detach_embed_info
+    m5, sd5 = product_model(NC=5, device=DEV, key='weights5')
+    sizes = [4, 7, 3, 5]
+    batch, map_idx = synth.make_batch(sizes, key='gc/atk5', NC=5, FT=12)
+    raster, dx = uniform(1024)
+    env_c = synth.SyntheticMapEnv(raster, dx)
+    env = dev_env(raster, dx)
+    cat = 3                                                   # the semantic class the attack is restricted to
+    ptr = batch.ptr.tolist()
+    aidx = []
+    for b in range(len(sizes)):
+        cls = batch.sem[ptr[b] + 1:ptr[b + 1]].argmax(dim=1).tolist()
+        aidx.append(1 + (cls.index(cat) if cat in cls else 0))
+    assert any(batch.sem[ptr[b] + aidx[b]].argmax().item() == cat for b in range(len(sizes))), 'no scene has an agent of the category'
+    orc = oracle_model(sd5, NC=5)
+    bg, mi = batch.clone().to(DEV), map_idx.to(DEV)
+    with torch.no_grad():
+        emb = detach_embed_info(m5.embed(bg, mi, env))
+    emb_c = {k: (tuple(t.cpu() for t in v) if isinstance(v, tuple) else v.cpu()) for k, v in emb.items()}
+    NA = sum(sizes)
+    ego = torch.zeros((NA,), dtype=torch.bool)
+    ego[batch.ptr[:-1]] = True
+    pm, pv = emb_c['prior_out']
+    z0 = synth.make_latents(pm, pv, key='gc/atk5/z')
+    iters = 3
+    want = []
+    oloops.adv_loop(orc, batch, map_idx, env_c, emb_c, z0, mg.LOOP_WEIGHTS, iters, mg.LOOP_LR, (pm[ego], pv[ego]), (pm[~ego], pv[~ego]),
+                    feasibility_time=2, feasibility_infront_min=0.0, attack_agt_idx=aidx, trace=want)
+    trace = []
+    eg = ego.to(DEV)
+    pmg, pvg = emb['prior_out']
+    z, fin, _, agt, tt = run_adv_gen_optim(z0.to(DEV), mg.LOOP_LR, mg.LOOP_WEIGHTS, m5, bg, env, mi, iters, emb, 'ego', (pmg[eg], pvg[eg]),
+                                           (pmg[~eg], pvg[~eg]), 2, 0.0, attack_agt_idx=aidx, log=lu.trace_logger(trace))
+    assert [int(a) - ptr[b] for b, a in enumerate(agt)] == aidx, 'the reported attacker is the one the loop was restricted to'
+    for it in range(iters):
+        for k, v in want[it].items():
+            if k in ('z', 'grad', 'crop_flips') or not torch.is_tensor(v):
+                continue
+            a, b = float(torch.mean(trace[it][k].float())), float(torch.mean(v.float()))
+            assert abs(a - b) <= 1e-4 + 2e-3 * abs(b), 'iteration %d: %s %.6g vs %.6g' % (it, k, a, b)
+        for i in range(2):
+            gg, gw = trace[it]['grad'][i].double().reshape(-1), want[it]['grad'][i].double().reshape(-1)
+            rel = float((gg - gw).norm() / max(float(gw.norm()), 1e-30))
+            assert rel <= 2e-2, 'iteration %d: gradient of leaf %d off by %.3g (relative L2)' % (it, i, rel)
+            assert lu.frac_within(trace[it]['z'][i].numpy(), want[it]['z'][i].numpy(), 1e-3) >= 0.995
+    # (for the log: what the unrestricted loop would have picked)
+    _, _, _, agt_free, _ = run_adv_gen_optim(z0.to(DEV), mg.LOOP_LR, mg.LOOP_WEIGHTS, m5, bg, env, mi, 1, emb, 'ego', (pmg[eg], pvg[eg]),
+                                             (pmg[~eg], pvg[~eg]), 2, 0.0)
+    print('attacker per scene: restricted %s, unrestricted %s' % (aidx, [int(a) - ptr[b] for b, a in enumerate(agt_free)]))
 
 
 def test_shared_forward_rollout_equals_two_rollouts(model, monkeypatch):
@@ -666,7 +752,18 @@ def test_sample_batched_golden_and_feasibility(model):
     assert_close(so['z_samp'], g['z_samp'], RT, AT, 'z_samp')
     assert_close(so['z_logprob'], g['z_logprob'], 1e-4, 1e-3, 'z_logprob')
     assert_close(so['z_mdist'], g['z_mdist'], 1e-4, 1e-4, 'z_mdist')
-    assert_close(so['future_pred'], g['future_pred'], 0, 1e-2, 'sample future_pred (textured)')
+    # 7 re-sampled steps against the REFERENCE's samples: tight up to a (scene, sample)'s first observed crop difference
+    from strive_amd.constants import state_norm_tensors
+    mean, std = state_norm_tensors()
+    NSg, FTg = 3, 8
+    want = torch.from_numpy(g['future_pred'])
+    rows_map = map_idx[batch.batch].repeat_interleave(NSg)
+    flips = crop_flips(dev_env(raster, dx), synth.SyntheticMapEnv(raster, dx), so['future_pred'].cpu().reshape(NA * NSg, FTg, 4),
+                       want.reshape(NA * NSg, FTg, 4), rows_map, mean[:4], std[:4])
+    group = (batch.batch.view(-1, 1) * NSg + torch.arange(NSg).view(1, NSg)).reshape(-1)
+    n_clean, n_all = assert_close_flip_gated(so['future_pred'].reshape(NA * NSg, FTg, 4), want.reshape(NA * NSg, FTg, 4), clean_mask(flips, group),
+                                             RT, AT, 1e-2, 'sample future_pred (textured)', min_clean=NA * NSg)
+    print('sample_batched textured: %d crop differences in %d crops, %d of %d cells tight' % (int(flips.sum()), NA * NSg * (FTg - 1), n_clean, n_all))
     assert_close(so['z_samp'][:, -1], so['prior_out'][0], 0, 0, 'include_mean puts the prior mean last')
     # uniform raster vs the oracle: tight
     with torch.no_grad():

@@ -23,11 +23,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'hip
 TW = {'recon': 1.0, 'kl': 0.004, 'coll_veh_prior': 0.05, 'coll_env_prior': 0.1}     # train_traffic.cfg:17-21
 
 
-def _oracle_step(sd, batch, map_idx, env, eps_post, eps_prior, FT=12):
+def _oracle_step(sd, batch, map_idx, env, eps_post, eps_prior, FT=12, crop_poses=None):
     from oracle import losses as ol
     sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     orc = oracle_model(sdg, FT=FT)
-    out = orc.forward(batch, map_idx, env, eps_post=eps_post, eps_prior=eps_prior)
+    out = orc.forward(batch, map_idx, env, eps_post=eps_post, eps_prior=eps_prior, crop_poses=crop_poses)
     ld = ol.traffic_model_loss(TW, batch, out, orc.get_normalizer(), orc.get_att_normalizer(), map_idx, env)
     ld['loss'].sum().backward()
     return out, ld, {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in sdg.items()}
@@ -156,11 +156,22 @@ def test_training_step_golden_and_all_gradients():
     eps_prior = synth.f32(synth.counter_normal((NA, 32), 'g5/eps_prior'))
     env_g = synth.SyntheticMapEnv(raster.clone(), dx.clone()).to(DEV)
     out, ld, grads, err = _product_step(m, batch.clone().to(DEV), map_idx.to(DEV), env_g, eps_post, eps_prior)
-    # textured raster, 11 re-sampled steps: loose on the trajectories (like the rollout goldens), terms of the loss accordingly
-    assert_close(out['future_pred'], g['train_future_pred'], 0, 1e-2, 'train future_pred')
-    assert_close(out['future_samp'], g['train_future_samp'], 0, 1e-2, 'train future_samp')
+    # textured raster, 11 re-sampled steps, against the REFERENCE's own step: the crops of both runs are compared exactly
+    # (tests/util.py); trajectories tight up to a scene's first observed crop difference, the loose bound only downstream of one;
+    # the loss terms at the tight tolerance if no crop differed anywhere, else at the loose one
+    from util import crop_flips, clean_mask, assert_close_flip_gated
+    from strive_amd.constants import state_norm_tensors
+    mean, std = state_norm_tensors()
+    env_tc = synth.SyntheticMapEnv(raster, dx)
+    nflip = 0
+    for key in ('future_pred', 'future_samp'):
+        want = torch.from_numpy(g['train_' + key])
+        flips = crop_flips(env_g, env_tc, out[key].detach().cpu(), want, map_idx[batch.batch], mean[:4], std[:4])
+        nflip += int(flips.sum())
+        n_clean, n_all = assert_close_flip_gated(out[key], want, clean_mask(flips, batch.batch), 1e-4, 2e-5, 1e-2, 'train ' + key, min_clean=NA)
+        print('training step, textured, %s vs the reference: %d crop differences, %d of %d cells tight' % (key, int(flips.sum()), n_clean, n_all))
     for k in ('loss', 'recon_loss', 'kl_loss'):
-        assert_close(ld[k], g['train_' + k], 2e-2, 1e-3, 'train ' + k)
+        assert_close(ld[k], g['train_' + k], 2e-2 if nflip else 2e-3, 1e-3 if nflip else 1e-5, 'train ' + k)
     assert int(g['train_ngrads']) == 174 and all(v is not None for v in grads.values())
     for n in ('decoder_net.mlp_out.net.6.weight', 'decoder_memory.weight_hh_l0', 'map_conv.0.weight', 'map_feature.weight',
               'prior_net.msg.0.edge_mlp.net.0.weight', 'past_encoder.net.0.weight', 'posterior_net.mlp_in.net.0.weight',
@@ -169,7 +180,19 @@ def test_training_step_golden_and_all_gradients():
         got = grads[n].detach().cpu().reshape(-1)[:w.size].numpy().reshape(w.shape) if w.size < grads[n].numel() else \
             grads[n].detach().cpu().numpy()
         rel = float(np.linalg.norm(got - w) / max(np.linalg.norm(w), 1e-30))
-        assert rel < 0.1, 'reference gradient %s: relative L2 error %.3g' % (n, rel)
+        assert rel < (0.1 if nflip else 1e-3), 'reference gradient %s: relative L2 error %.3g (%d crop differences observed)' % (n, rel, nflip)
+    # tight over the TEXTURED raster: the oracle's step cropping at the product's rollout poses (the same smooth function on both
+    # sides: the reference crops at pos.detach(), traffic_model.py:694-695) -- trajectories, loss terms and all 174 gradients at the
+    # uniform-raster tolerances, the map CNN's weight gradients over re-sampled crops included
+    out_t, ld_t, g_t = _oracle_step(sd, batch, map_idx, env_tc, eps_post, eps_prior,
+                                    crop_poses=(out['future_pred'].detach().cpu(), out['future_samp'].detach().cpu()))
+    assert_close(out['future_pred'], out_t['future_pred'], 1e-4, 2e-5, 'future_pred (textured, same crops)')
+    assert_close(out['future_samp'], out_t['future_samp'], 1e-4, 2e-5, 'future_samp (textured, same crops)')
+    for k in ('loss', 'recon_loss', 'kl_loss', 'coll_veh_prior', 'coll_env_prior'):
+        assert_close(ld[k], ld_t[k], 2e-3, 2e-3 if 'env' in k else 1e-5, k + ' (textured, same crops)')
+    worst_t = _compare_grads(grads, g_t, 2e-3, 5e-4, 'training step (textured raster, same crops)', rel_l2=1e-4)
+    print('textured raster, same crops: worst relative L2 gradient error: %s %.3g (the oracle\'s own poses would have changed %d crops)' % (
+        worst_t + (int(out_t['crop_flips_pred'].sum()) + int(out_t['crop_flips_samp'].sum()),)))
     # tight: uniform raster (smooth chain) against the oracle, all 174 gradients
     ur, udx = mg.loop_rasters('u')
     env_c = synth.SyntheticMapEnv(ur, udx)
