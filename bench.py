@@ -438,7 +438,9 @@ def train_step_factory(m, env, batch, map_idx, FT, device):
 # side measurements
 # ------------------------------------------------------------------------------------------------
 
-TRAFFIC_FILES = ('r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json')
+TRAFFIC_FILES = ('r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json')
+UTIL_FILES = ('r05_util.json',)
+PEAK_LDS_BYTES_PER_CLK_CU = 256.0   # /opt/skills/guides/MI355X_MICROARCH.md, LDS section: ds_read_b64 / b128, conflict-free (157 TB/s at 2.4 GHz)
 
 
 def _measured_traffic(kernel_name, with_source=False):
@@ -454,6 +456,30 @@ def _measured_traffic(kernel_name, with_source=False):
         except (OSError, ValueError):
             continue
     return (None, None) if with_source else None
+
+
+def _measured_util(kernel_name, launch_s):
+    """The two on-chip roofs of a kernel from the COMMITTED counter passes (profiles/r0N_util.json, written by profiles/make_util.py
+    from rocprofv3 --pmc SQ_LDS_IDX_ACTIVE ... / SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ... runs of this same command):
+    ``lds`` = {frac: share of the launch during which a CU's LDS array is busy (chip average), bank_conflict_share, GBps / bytes:
+    that share expressed against the guide's 256 B/clk/CU read peak at the launch's own clock, peak}; ``mfma_pipe`` = share of the
+    launch during which a SIMD's matrix pipe is busy.  None if not collected."""
+    for name in UTIL_FILES:
+        try:
+            with open(os.path.join(REPO, 'profiles', name)) as f:
+                ent = json.load(f).get(kernel_name)
+        except (OSError, ValueError):
+            continue
+        if ent is None:
+            continue
+        clk = ent['cycles_per_launch'] / launch_s if launch_s else 0.0          # core clock of this launch (cycles of the counter run / live duration)
+        peak = PEAK_LDS_BYTES_PER_CLK_CU * 256 * clk / 1e9
+        return {'lds': {'frac': ent['lds_array_busy_frac'], 'bank_conflict_share': ent['lds_bank_conflict_share_of_array_cycles'],
+                        'bytes': int(ent['lds_array_busy_frac'] * peak * 1e9 * launch_s), 'GBps': round(ent['lds_array_busy_frac'] * peak, 1),
+                        'peak': round(peak, 1), 'unit': 'GB/s (LDS-array cycles x 256 B/clk/CU at the launch clock of %.2f GHz)' % (clk / 1e9)},
+                'mfma_pipe': {'frac': ent['mfma_pipe_busy_frac'], 'unit': 'share of the launch a SIMD matrix pipe is busy (chip average)'},
+                'source': 'profiles/' + name}
+    return None
 
 
 def _event_time(fn, reps, warm=3):
@@ -523,6 +549,22 @@ def time_dominant_kernel(m, env, g, mi, emb, device, reps=20):
         bw[CONV_NAMES[l]] = {'algorithmic_bytes': CONV_BYTES[l] * N, 'us': round(times[l] * 1e6, 2), 'GBps': round(gbs, 1),
                              'frac_of_hbm_peak': round(gbs / PEAK_HBM_GBS, 4), 'traffic': _measured_traffic(CONV_NAMES[l])}
     rec['bandwidth_kernels'] = bw
+    # the on-chip roofs (round 5): which resource is busiest inside each kernel -- HBM (algorithmic bytes above), the LDS arrays
+    # or the matrix pipes (committed counter passes); `binding` names the largest of the three fractions
+    util = {}
+    for l in range(NK):
+        u = _measured_util(CONV_NAMES[l], times[l])
+        if u is None:
+            continue
+        fr = {'hbm': round(CONV_BYTES[l] * N / times[l] / 1e9 / PEAK_HBM_GBS, 4), 'lds': u['lds']['frac'], 'mfma_pipe': u['mfma_pipe']['frac']}
+        u['fractions'] = fr
+        u['binding'] = max(fr, key=fr.get)
+        util[CONV_NAMES[l]] = u
+    if CONV_NAMES[dom] in util:
+        rec['lds'] = util[CONV_NAMES[dom]]['lds']
+        rec['mfma_pipe'] = util[CONV_NAMES[dom]]['mfma_pipe']
+        rec['binding_resource'] = util[CONV_NAMES[dom]]['binding']
+    rec['on_chip_roofs'] = util
     return rec
 
 
@@ -698,9 +740,14 @@ def cpu_baseline(FT, scenes=4, agents=16, raster_px=4096, timed=3, warm=1):
     from oracle.model import OracleTrafficModel
     from oracle.geometry import Normalizer
     from oracle.losses import AvoidColl
+    from oracle import mapenv as _omap
     threads = _one_socket_threads()
     old_threads = torch.get_num_threads()
     torch.set_num_threads(threads)
+    old_struct = _omap.REFERENCE_CHANNEL_STRUCTURE
+    # the crop's coordinate pipeline with the reference's tensor structure (one grid per raster channel, nuscenes_utils.py:217-230,
+    # 253-262): 4 x the arithmetic of the oracle's channel-free form, same values -- the CPU number carries the reference's cost
+    _omap.REFERENCE_CHANNEL_STRUCTURE = True
     try:
         m = TrafficModel(4, 12, 256, 2)
         sd = synth.fill_state_dict(m.state_dict())
@@ -735,18 +782,20 @@ def cpu_baseline(FT, scenes=4, agents=16, raster_px=4096, timed=3, warm=1):
         dt = (time.perf_counter() - t0) / timed
     finally:
         torch.set_num_threads(old_threads)
+        _omap.REFERENCE_CHANNEL_STRUCTURE = old_struct
     n = scenes * agents * FT
     return {'value': round(n / dt, 2), 'unit': 'agent*timesteps/s', 'cores': _one_socket()[0], 'threads': threads, 'kind': 'port',
             'cpu': _cpu_model(),
             'sample': '%d scenes x %d agents, FT=%d: %d warm-up + %d timed refine closures (decode + AvoidCollLoss + backward '
-                      'incl. the CNN weight gradients the reference computes + Adam) of the CPU oracle, %.1f s per closure; '
+                      'incl. the CNN weight gradients the reference computes + Adam) of the CPU oracle with the reference\'s per-channel '
+                      'crop coordinates (nuscenes_utils.py:217-230), %.1f s per closure; '
                       'torch threads = the hardware threads of one socket, `cores` = its physical cores' % (scenes, agents, FT, warm, timed, dt)}
 
 
 def cpu_baseline_record(FT, full=False):
     """The bench line's `cpu_baseline`.  SURVEY 8(d) quotes the CPU at C2 (32 scenes x 16 agents), where one closure of the
     oracle takes minutes; the default run therefore times two bounded samples of the same workload -- 4 x 16 agents and 16 x 16 agents, each
-    with 1 warm-up + 1 timed closure -- reports the LARGER sample as `value` and states both, so the trend
+    with 1 warm-up + 2 timed closures -- reports the LARGER sample as `value` and states both, so the trend
     towards C2 is visible (it differs by host: 77 -> 31 agent*timesteps/s from 4 to 32 scenes on the 8-vCPU survey container,
     79 -> 90 from 4 to 16 scenes on the 128-thread EPYC of the GPU boxes).  ``--cpu-baseline-full`` times C2 itself (1 warm-up +
     2 timed closures, several minutes); profiles/r03_cpu_baseline_c2.json holds that run."""
@@ -754,8 +803,8 @@ def cpu_baseline_record(FT, full=False):
         rec = cpu_baseline(FT, scenes=32, agents=16, timed=2)
         rec['sample'] = 'C2 itself: ' + rec['sample']
         return rec
-    small = cpu_baseline(FT, scenes=4, agents=16, timed=1)
-    large = cpu_baseline(FT, scenes=16, agents=16, timed=1, warm=1)
+    small = cpu_baseline(FT, scenes=4, agents=16, timed=2)
+    large = cpu_baseline(FT, scenes=16, agents=16, timed=2, warm=1)
     rec = dict(large)
     rec['sample'] = ('bounded samples of C2 (32 x 16 agents): %s || %s.  `value` is the 16 x 16 sample (4 x 16: %.1f, 16 x 16: %.1f '
                      'agent*timesteps/s); C2 itself, timed with --cpu-baseline-full, is in profiles/r03_cpu_baseline_c2.json' %
@@ -986,6 +1035,10 @@ def main():
         'scaling': scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s, %s (%s)' % (closure, desc, cfg_ref[args.workload]),
                    'agents_per_gpu': NA, 'FT': args.ft, 'NC': args.nc, 'rollouts_per_closure': rollouts,
+                   'units_note': (None if rollouts != 2 or args.workload == 'full' else
+                                  'reference-equivalent units: the reference decodes twice per iteration (complementary detach, '
+                                  'adv_gen_optim.py:120-131) and both decodes are counted; executed here: 1 forward rollout + 2 '
+                                  'reverse sweeps over its tape (ops._RolloutPairFn)'),
                    'raster': '%dx%d x4 uint8 @0.25 m' % (args.raster, args.raster),
                    'parallelism': 'scene-sharded replicas x%d' % world,
                    'arithmetic': ('fp32 everywhere; the map CNN on the fp16 matrix cores with two-piece round-to-nearest operand splits '

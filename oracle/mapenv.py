@@ -43,10 +43,38 @@ def _to_pixels(xys, dx, mapixes, H, W):
     return pix
 
 
+# The reference builds the crop's sample coordinates once PER RASTER CHANNEL (gen_car_coords expands the local grid to
+# B x C x L x W before rotating it, nuscenes_utils.py:217-230, and get_map_obs divides, rounds and bounds-checks that
+# B x C x L x W x 2 tensor, :253-262): C = 4 times the arithmetic of the channel-free form above, same values.  The parity tests
+# use the light form; bench.py's cpu_baseline sets this switch so that the CPU number it reports carries the reference's cost.
+REFERENCE_CHANNEL_STRUCTURE = False
+
+
+def _map_crop_per_channel(maps, dx, frame, mapixes, bounds, L, W):
+    """get_map_obs with the reference's tensor structure (one coordinate grid per channel); bit-identical to map_crop's output"""
+    B, C = frame.shape[0], maps.shape[1]
+    dev = frame.device
+    lwise = torch.linspace(bounds[0], bounds[2], L, device=dev).view(1, 1, L, 1).expand(B, C, L, W)
+    wwise = torch.linspace(bounds[1], bounds[3], W, device=dev).view(1, 1, 1, W).expand(B, C, L, W)
+    hcos = frame[:, 2].view(B, 1, 1, 1)
+    hsin = frame[:, 3].view(B, 1, 1, 1)
+    xys = torch.stack((lwise * hcos - wwise * hsin, lwise * hsin + wwise * hcos), 4) + frame[:, :2].view(B, 1, 1, 1, 2)
+    xys[torch.isnan(xys)] = 0.0
+    xys = xys / dx[mapixes].view(B, 1, 1, 1, 2)
+    xys = torch.round(xys).long()
+    m = mapixes.view(B, 1, 1, 1).expand(B, C, L, W)
+    c = torch.arange(C, device=dev).view(1, C, 1, 1).expand(B, C, L, W)
+    outside = (xys[..., 1] < 0) | (xys[..., 1] >= maps.shape[2]) | (xys[..., 0] < 0) | (xys[..., 0] >= maps.shape[3])
+    xys[outside] = 0
+    return maps[m, c, xys[..., 1], xys[..., 0]]
+
+
 def map_crop(maps, dx, frame, mapixes, bounds, L=256, W=256):
     """uint8 crop ``(B,C,L,W)`` around ``frame (B,4)`` (UNNORMALISED x,y,hx,hy).
     Restates get_map_obs (reference src/datasets/nuscenes_utils.py:234-264); NaN frames sample
     world (0,0)."""
+    if REFERENCE_CHANNEL_STRUCTURE:
+        return _map_crop_per_channel(maps, dx, frame, mapixes, bounds, L, W)
     xys = car_grid(frame[:, :2], frame[:, 2:4], L, W, bounds=bounds)
     xys = torch.where(torch.isnan(xys), torch.zeros_like(xys), xys)
     pix = _to_pixels(xys, dx, mapixes, maps.shape[2], maps.shape[3])

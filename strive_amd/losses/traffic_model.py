@@ -67,7 +67,9 @@ class TrafficModelLoss(nn.Module):
         forward (:79-101); here that cost a dozen host synchronisations per training step (tools/sync_audit.py train)."""
         w = self.loss_weights
         key = (self._sig(scene_graph.ptr), self._sig(scene_graph.lw), self._sig(scene_graph.future_vis), self._sig(scene_graph.future_gt),
-               self._sig(map_idx), id(map_env), T, w['coll_veh_prior'] > 0.0, w['coll_env_prior'] > 0.0)
+               self._sig(map_idx), id(map_env), T, w['coll_veh_prior'] > 0.0, w['coll_env_prior'] > 0.0,
+               # (the collision modules freeze the unnormalised vehicle sizes: new attribute statistics = new modules)
+               self._sig(getattr(self.att_normalizer, 'mean_vals', None)), self._sig(getattr(self.att_normalizer, 'std_vals', None)))
         ent = scene_graph.__dict__.get('_strive_train_consts')
         if ent is not None and ent[0] == key:
             return ent[1]
@@ -88,6 +90,9 @@ class TrafficModelLoss(nn.Module):
         w = self.loss_weights
         T = pred['future_pred'].size(1)
         c = self._batch_constants(scene_graph, map_idx, map_env, T)
+        if tuple(pred['future_pred'].shape[:2]) != tuple(scene_graph.future_vis.shape[:2]):
+            # (the reference's boolean mask pred[vis == 1] raises on such a mismatch; the cached index would silently pick wrong rows)
+            raise IndexError('future_pred %s does not match future_vis %s' % (tuple(pred['future_pred'].shape), tuple(scene_graph.future_vis.shape)))
         pf = pred['future_pred'].reshape(-1, pred['future_pred'].size(-1)).index_select(0, c['vis_idx'])
         recon = -log_normal(pf, c['gt'], torch.ones_like(pf))
         pm, pv = pred['prior_out']

@@ -2,8 +2,9 @@
 
 ``MLP`` keeps the reference's parameter layout (``net.0`` Linear, ``net.{3k+1}`` LayerNorm,
 ``net.{3k+2}`` ReLU, ``net.{3k+3}`` Linear) so checkpoints load unchanged; its forward runs the fused
-HIP kernel (strive_mlp_fwd).  Gradients w.r.t. MLP weights are not provided by the HIP path (the
-latent-optimisation loops never need them); calling it on tensors that require grad raises.
+HIP kernel (strive_mlp_fwd); with autograd enabled the call is an autograd Function whose backward (strive_mlp_bwd) gives the
+gradients w.r.t. the input and -- the training step -- all weights and biases (tests/test_training.py: all 174 parameter
+gradients against the oracle's autograd).
 """
 import torch
 from torch import nn

@@ -628,6 +628,12 @@ class _RolloutPairFn(torch.autograd.Function):
     def forward(ctx, z_a, z_b, h):
         lib = h.lib
         dev = z_a.device
+        if os.environ.get('STRIVE_CHECK_PAIR') == '1' and not (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
+            # debug aid (one host synchronisation per call; the GPU tests set it): only z_a is rolled out, so a caller whose two
+            # latents differ in VALUE -- not just in which half is detached -- would silently get z_a's trajectory for both
+            if not torch.equal(z_a.detach(), z_b.detach()):
+                raise ValueError('decode_embedding_pair: the two latents must hold the same values (complementary detach of the '
+                                 'same leaves); use two decode_embedding calls for different latents')
         zz = _f32c(z_a).reshape(h.R, 32)
         traj = torch.empty((h.R, h.FT, 4), dtype=torch.float32, device=dev)
         tape = torch.empty(h.tape_bytes, dtype=torch.uint8, device=dev)

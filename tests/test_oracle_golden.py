@@ -467,3 +467,21 @@ def test_refine_function_adam_and_lbfgs_match_reference(sd):
         assert_close(z, g[name + '/z'], 1e-4, 1e-4, name + ' z')
         assert_close(res, g[name + '/result_traj'], 1e-4, 1e-4, name + ' result_traj')
     assert np.abs(g['adam/z'] - g['lbfgs/z']).max() > 0.5          # the two branches really differ
+
+
+def test_crop_with_the_reference_channel_structure_is_the_same_crop():
+    """oracle.mapenv.REFERENCE_CHANNEL_STRUCTURE (bench.py's cpu_baseline times the oracle with it): the crop with one coordinate
+    grid per raster channel, like gen_car_coords / get_map_obs build it (reference src/datasets/nuscenes_utils.py:217-230, 253-262),
+    is bit-identical to the channel-free form the parity tests use -- NaN frames and out-of-bounds samples included."""
+    raster, dx, frame, mapixes, lw = mg.g2_inputs()
+    env = synth.SyntheticMapEnv(raster, dx)
+    fr = frame.clone()
+    fr[1] = float('nan')
+    fr[2, :2] = torch.tensor([-30.0, 5.0])
+    a = mapenv.map_crop(raster, dx, fr, mapixes, env.bounds)
+    try:
+        mapenv.REFERENCE_CHANNEL_STRUCTURE = True
+        b = mapenv.map_crop(raster, dx, fr, mapixes, env.bounds)
+    finally:
+        mapenv.REFERENCE_CHANNEL_STRUCTURE = False
+    assert torch.equal(a, b)

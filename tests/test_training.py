@@ -190,7 +190,9 @@ def test_training_step_golden_and_all_gradients():
     assert_close(out['future_samp'], out_t['future_samp'], 1e-4, 2e-5, 'future_samp (textured, same crops)')
     for k in ('loss', 'recon_loss', 'kl_loss', 'coll_veh_prior', 'coll_env_prior'):
         assert_close(ld[k], ld_t[k], 2e-3, 2e-3 if 'env' in k else 1e-5, k + ' (textured, same crops)')
-    worst_t = _compare_grads(grads, g_t, 2e-3, 5e-4, 'training step (textured raster, same crops)', rel_l2=1e-4)
+    # (measured on the MI355X: worst tensor 9.6e-5 -- map_conv.0.bias, whose gradient sums conv1's output adjoint over 176 re-sampled
+    # crops -- against 1.6e-5 over the uniform raster: bound 2e-4)
+    worst_t = _compare_grads(grads, g_t, 2e-3, 5e-4, 'training step (textured raster, same crops)', rel_l2=2e-4)
     print('textured raster, same crops: worst relative L2 gradient error: %s %.3g (the oracle\'s own poses would have changed %d crops)' % (
         worst_t + (int(out_t['crop_flips_pred'].sum()) + int(out_t['crop_flips_samp'].sum()),)))
     # tight: uniform raster (smooth chain) against the oracle, all 174 gradients
