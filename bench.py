@@ -968,10 +968,12 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
+    c0 = time.thread_time()
     for _ in range(args.steps):
         loss = step()
     dt_host = time.perf_counter() - t0          # all work enqueued (diagnostic: host-bound when ~ dt_local)
-    barrier()
+    dt_host_cpu = time.thread_time() - c0       # CPU time of the enqueueing thread: the wall time above also holds the waits for a
+    barrier()                                   # free slot in the hardware queue once the GPU is the bottleneck
     dt_local = time.perf_counter() - t0
     if args.workload == 'full' and args.scenario_out and rank == 0:
         step.stats['scenarios_written'] = step.write_scenarios(args.scenario_out)
@@ -1049,6 +1051,7 @@ def main():
                    'rollout_kernels': rollout_kernels, 'hip_graph': hip_graph},
         'final_loss': float(loss.detach().cpu()),
         'host_enqueue_ms_per_step': round(dt_host / args.steps * 1e3, 3),     # diagnostic: the host has queued everything by then
+        'host_cpu_ms_per_step': round(dt_host_cpu / args.steps * 1e3, 3),    # of which the enqueueing thread was on a core
         'planner': None if planner_ms is None else planner_ms,
         'scenes_dropped': scenes_dropped if args.workload != 'full' else step.stats.get('scenes_dropped'),
         'pipeline': dict(step.stats) if args.workload == 'full' else None,

@@ -361,7 +361,8 @@ int scene_kernels_prepare() {
     if (hipFuncSetAttribute((const void*)scn::scene_fwd_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scn::FwdLds::BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)scn::scene_fwd_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scn::FwdLds::BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)scn::scene_bwd_sweep_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scn::BwdLds::BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)scn::scene_bwd_sweep_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scn::BwdLds::BYTES) != hipSuccess) {
+        hipFuncSetAttribute((const void*)scn::scene_bwd_sweep_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scn::BwdLds::BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)(scn::scene_bwd_sweep_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scn::BwdLds::BYTES) != hipSuccess) {
         strive_set_error("rollout: the scene kernels' LDS request was refused");
         return -1;
     }
@@ -993,6 +994,30 @@ extern "C" int strive_rollout_bwd(const StriveDecoder* dec, const StriveScenes* 
         // STRIVE_SCENE_PROF=1 (tools/scene_phase_probe.py): workgroup 0 adds the core-clock ticks of every phase to 16 counters at the
         // start of the workspace, which this path does not use otherwise
         const char* pe = getenv("STRIVE_SCENE_PROF");
+        // Stepwise form: one launch per reverse step, K workgroups per scene sharing the scene's edge chunks (scene_rollout.h).
+        // Default from 3 chunks per scene on (>= 12 agents: 132 edge rows); STRIVE_SWEEP_STEP = 0 (never) | K (1..4, forced).
+        const int chunks = (sc->max_n * (sc->max_n - 1) + scn::EC - 1) / scn::EC;
+        int K = chunks >= 3 ? chunks : 0;
+        if (const char* e = getenv("STRIVE_SWEEP_STEP")) K = atoi(e);
+        if (K > 4) K = 4;
+        const size_t need = (size_t)sc->B * (K > 0 ? K : 1) * (2 * scn::SWEEP_PART_FLOATS + scn::SWEEP_STATE_FLOATS) * 4 + 512;
+        if (K >= 1 && !(pe && atoi(pe) != 0) && ws_bytes >= need) {
+            a.K = K;
+            a.part = reinterpret_cast<float*>((char*)ws + 256);
+            a.state = a.part + 2 * (size_t)sc->B * K * scn::SWEEP_PART_FLOATS;
+            const GNNDev gd = gnn_dev(dec->gnn);
+            const GRUDev gr = gru_dev(dec->gru);
+            const scn::GRUFrag gf = scn::gru_frag(dec->gru);
+            const DynParams dp = dyn_params(*dec);
+            for (int t = FT - 1; t >= -1; --t) {
+                a.t = t;
+                hipLaunchKernelGGL((scn::scene_bwd_sweep_kernel<false, true>), dim3((unsigned)sc->B, (unsigned)K), dim3(scn::NTHR), scn::BwdLds::BYTES,
+                                   (hipStream_t)stream_, gd, gr, gf, dp, a, tp, (unsigned long long*)nullptr);
+            }
+            STRIVE_CHECK_LAUNCH();
+            return 0;
+        }
+        a.t = 0; a.K = 1; a.part = nullptr; a.state = nullptr;
         if (pe && atoi(pe) != 0)
             hipLaunchKernelGGL(scn::scene_bwd_sweep_kernel<true>, dim3((unsigned)sc->B), dim3(scn::NTHR), scn::BwdLds::BYTES, (hipStream_t)stream_,
                                gnn_dev(dec->gnn), gru_dev(dec->gru), scn::gru_frag(dec->gru), dyn_params(*dec), a, tp, (unsigned long long*)ws + 32);

@@ -990,7 +990,15 @@ struct SweepArgs {
     const float* par;          // StriveDecoder.scene_par
     const float* g_traj;       // (NA, FT, 4)
     float* dz;                 // (NA, 32)
+    // stepwise form only (scene_bwd_sweep_kernel<PROF, true>): the step of this launch, workgroups per scene, and the two global
+    // buffers that carry a scene's sweep from launch to launch
+    int t, K;
+    float* part;               // (2, B, K, PART_FLOATS)   dP | dQ | gpos_n of the edge chunks workgroup k walked, by step parity:
+                               // the launch of step t reads the sums of step t + 1 while its workgroups write those of step t
+    float* state;              // (B, K, STATE_FLOATS)  g_state | g_mem | dz | gin2 of workgroup k (all K hold the same values)
 };
+constexpr int SWEEP_PART_FLOATS = 2 * NR * HLD + NR * 4;
+constexpr int SWEEP_STATE_FLOATS = NR * 8 + 3 * NR * XLD + NR * 32 + NR * HLD;
 
 // one product of the sweep with a caller-supplied epilogue (identity k-step lists)
 template <int NK, typename Epi>
@@ -1002,13 +1010,25 @@ __device__ __forceinline__ void dense_rows_epi(const uint4* __restrict__ frag, f
     mma_tiles<NK>(frag, NK, wscale, nt0, NTL, nrt, ks, ks, sb, tid, epi, pre);
 }
 
-template <bool PROF>
+// STEP = false: grid = B, the whole sweep in one launch (above).
+// STEP = true (round 5): grid = (B, K), ONE reverse step per launch, FT + 1 launches.  At 16 agents per scene two thirds of the
+// one-launch sweep are the 240 edge rows of a scene walked as four 64-row chunks by ONE workgroup, on 32 of the chip's 256 CUs
+// (profiles/r04_scene_phase_32x16.txt: 1.1 of 1.7 ms).  Here workgroup k of a scene walks chunks k, k + K, ... and every one of
+// the K workgroups repeats the scene's node-level phases (GRU, dynamics, mlp_out, update; the edge partials and mlp_in) --
+// deterministic, so all K hold the same adjoint state.  What crosses workgroups are the chunk sums dP_i, dQ_j and the pose
+// adjoints: each workgroup leaves its partial sums in `part`, the launch boundary is the barrier, and the NEXT launch adds the
+// partials in workgroup order before it finishes that step's node1 / mlp_in phase and starts the following step.  Launch for step
+// t = [finish step t + 1] -> GRU(t) -> dynamics .. update(t) -> own edge chunks of t; the launch with t = -1 finishes step 0 and
+// writes dz.  With one chunk per workgroup (n (n - 1) <= 64 K) every sum is formed in the order of the one-launch sweep: the two
+// forms give the same bits (tests/test_emu_kernels.py).
+template <bool PROF, bool STEP = false>
 static __global__ __launch_bounds__(NTHR) void scene_bwd_sweep_kernel(GNNDev g, GRUDev gru, GRUFrag gf, DynParams dp, SweepArgs a,
                                                                       Tape tp, unsigned long long* prof) {
     HIP_DYNAMIC_SHARED(float, smem)
     BwdLds L(smem);
     int tid = threadIdx.x;
     const int b = blockIdx.x, NC = a.NC, H = STRIVE_HID, FT = a.FT;
+    const int kw = STEP ? (int)blockIdx.y : 0, KW = STEP ? a.K : 1;
     const int lo = a.ptr[b], n = a.ptr[b + 1] - lo;
     if (n <= 0) return;
     const int E = n * (n - 1);
@@ -1032,11 +1052,11 @@ static __global__ __launch_bounds__(NTHR) void scene_bwd_sweep_kernel(GNNDev g, 
     par_stage(L.par, a.par, tid);
     SCN_SYNC(tid);
 
-    for (int t = FT - 1; t >= 0; --t) {
+    // (tape rows and weight tiles are requested one stage ahead of their use: before the product or pass that precedes it)
+    // ================= GRU memory step backward (consumes g_mem, g_pf; produces g_mem, d_loc) =================
+    auto sec_gru = [&](const int t) {
         SCN_PHASE(tid);
         const bool more = t < FT - 1;
-        // (tape rows and weight tiles are requested one stage ahead of their use: before the product or pass that precedes it)
-        // ================= GRU memory step backward (consumes g_mem, g_pf; produces g_mem, d_loc) =================
         if (more) {
             float* s_dgi = L.U;                     // [NR][GLDS]
             float* s_dgh = L.U + NR * GLDS;         // [NR][GLDS]
@@ -1137,8 +1157,11 @@ static __global__ __launch_bounds__(NTHR) void scene_bwd_sweep_kernel(GNNDev g, 
             }
         }
         SCN_TICK(0);
+    };
 
-        // ================= dynamics + mlp_out + update backward =================
+    // ================= dynamics + mlp_out + update backward =================
+    auto sec_node2 = [&](const int t) {
+        const bool more = t < FT - 1;
         SCN_PHASE(tid);
         AF<4> f_o1, f_o0, f_u0;
         AF<2> f_u1;
@@ -1245,8 +1268,10 @@ static __global__ __launch_bounds__(NTHR) void scene_bwd_sweep_kernel(GNNDev g, 
             SCN_SYNC(tid);
             SCN_TICK(3);
         }
+    };
 
-        // ================= edge backward, chunks of EC rows =================
+    // ================= edge backward, chunks of EC rows: e_first, e_first + e_stride, ... =================
+    auto sec_edges = [&](const int t, const int e_first, const int e_stride) {
         {
             float* s_g = L.U;                         // [EC][HLD]
             float* s_grel = L.U + EC * HLD;           // [EC][4]
@@ -1257,11 +1282,11 @@ static __global__ __launch_bounds__(NTHR) void scene_bwd_sweep_kernel(GNNDev g, 
             // the wave's weight tiles of both products, kept across the chunks
             AF<2> f_e2;
             AF<4> f_e1;
-            if (E > 0) {
+            if (E > e_first) {
                 af_first<2>(f_e2, g.edge.wbf[2], 0, 8, 4, tid);
                 af_first<4>(f_e1, g.edge.wbf[1], 0, 8, 4, tid);
             }
-            for (int e0 = 0; e0 < E; e0 += EC) {
+            for (int e0 = e_first; e0 < E; e0 += e_stride) {
                 SCN_PHASE(tid);
                 const int ne = (E - e0) < EC ? (E - e0) : EC;
                 const int ne_pad = (ne + 15) & ~15, nrt = ne_pad >> 4;
@@ -1385,8 +1410,8 @@ static __global__ __launch_bounds__(NTHR) void scene_bwd_sweep_kernel(GNNDev g, 
                     // adjoint of pos_k: as a frame (its own rows, contiguous) and as a source (one row per target of the chunk)
                     const int k = tid >> 2, d = tid & 3;
                     const int i_first = e0 / (n - 1), i_last = (e0 + ne - 1) / (n - 1);
-                    float acc = L.gpos_n[tid];
-                    int eb = k * (n - 1), ee = eb + (n - 1);
+                    float acc = 0.f;                  // the chunk's own sum first (like dP / dQ): the same association whether the
+                    int eb = k * (n - 1), ee = eb + (n - 1);      // chunks are walked by one workgroup or by several
                     eb = eb < e0 ? e0 : eb;
                     ee = ee > e0 + ne ? e0 + ne : ee;
                     for (int e = eb; e < ee; ++e) acc += s_gfr[(e - e0) * 4 + d];
@@ -1395,14 +1420,16 @@ static __global__ __launch_bounds__(NTHR) void scene_bwd_sweep_kernel(GNNDev g, 
                         const int e = i * (n - 1) + k - (k > i ? 1 : 0);
                         if (e >= e0 && e < e0 + ne) acc += s_gpo[(e - e0) * 4 + d];
                     }
-                    L.gpos_n[tid] = acc;
+                    L.gpos_n[tid] += acc;
                 }
                 SCN_SYNC(tid);
                 SCN_TICK(10);
             }
         }
+    };
 
-        // ================= node features backward: edge layer-0 partials, mlp_in =================
+    // ================= node features backward: edge layer-0 partials, mlp_in =================
+    auto sec_node1 = [&](const int t) {
         SCN_PHASE(tid);
         {
             float* s_gx = L.U;                  // [NR][XLD]
@@ -1482,8 +1509,61 @@ static __global__ __launch_bounds__(NTHR) void scene_bwd_sweep_kernel(GNNDev g, 
             SCN_SYNC(tid);
             SCN_TICK(12);
         }
+    };
+
+    if (!STEP) {
+        for (int t = FT - 1; t >= 0; --t) {
+            sec_gru(t);
+            sec_node2(t);
+            sec_edges(t, 0, EC);
+            sec_node1(t);
+        }
+        for (int i = tid; i < n * STRIVE_ZDIM; i += NTHR) a.dz[(size_t)lo * STRIVE_ZDIM + i] = L.dz[i];
+    } else {
+        const int t = a.t;
+        float* st = a.state + ((size_t)b * KW + kw) * SWEEP_STATE_FLOATS;
+        if (t < FT - 1) {
+            // this workgroup's state of the previous launch ...
+            for (int i = tid; i < NR * 8; i += NTHR) L.g_state[i] = st[i];
+            for (int i = tid; i < 3 * NR * XLD; i += NTHR) L.g_mem[i] = st[NR * 8 + i];
+            for (int i = tid; i < NR * 32; i += NTHR) L.dz[i] = st[NR * 8 + 3 * NR * XLD + i];
+            for (int i = tid; i < NR * HLD; i += NTHR) L.gin2[i] = st[NR * 8 + 3 * NR * XLD + NR * 32 + i];
+            // ... and the chunk sums of step t + 1 of ALL workgroups of the scene that had chunks, added in workgroup order
+            const int nchunk = (E + EC - 1) / EC, kb = nchunk < KW ? nchunk : KW;
+            const float* part_prev = a.part + (size_t)((t + 1) & 1) * gridDim.x * KW * SWEEP_PART_FLOATS;
+            for (int i = tid; i < NR * HLD; i += NTHR) {
+                float p = 0.f, q = 0.f;
+                for (int k = 0; k < kb; ++k) {
+                    const float* pk = part_prev + ((size_t)b * KW + k) * SWEEP_PART_FLOATS;
+                    p += pk[i];
+                    q += pk[NR * HLD + i];
+                }
+                L.dP[i] = p;
+                L.dQ[i] = q;
+            }
+            if (tid < NR * 4) {
+                float v = 0.f;
+                for (int k = 0; k < kb; ++k) v += part_prev[((size_t)b * KW + k) * SWEEP_PART_FLOATS + 2 * NR * HLD + tid];
+                L.gpos_n[tid] = v;
+            }
+            SCN_SYNC(tid);
+            sec_node1(t + 1);
+        }
+        if (t >= 0) {
+            sec_gru(t);
+            sec_node2(t);
+            sec_edges(t, kw * EC, KW * EC);
+            float* pk = a.part + ((size_t)(t & 1) * gridDim.x * KW + (size_t)b * KW + kw) * SWEEP_PART_FLOATS;
+            for (int i = tid; i < NR * HLD; i += NTHR) { pk[i] = L.dP[i]; pk[NR * HLD + i] = L.dQ[i]; }
+            if (tid < NR * 4) pk[2 * NR * HLD + tid] = L.gpos_n[tid];
+            for (int i = tid; i < NR * 8; i += NTHR) st[i] = L.g_state[i];
+            for (int i = tid; i < 3 * NR * XLD; i += NTHR) st[NR * 8 + i] = L.g_mem[i];
+            for (int i = tid; i < NR * 32; i += NTHR) st[NR * 8 + 3 * NR * XLD + i] = L.dz[i];
+            for (int i = tid; i < NR * HLD; i += NTHR) st[NR * 8 + 3 * NR * XLD + NR * 32 + i] = L.gin2[i];
+        } else if (kw == 0) {
+            for (int i = tid; i < n * STRIVE_ZDIM; i += NTHR) a.dz[(size_t)lo * STRIVE_ZDIM + i] = L.dz[i];
+        }
     }
-    for (int i = tid; i < n * STRIVE_ZDIM; i += NTHR) a.dz[(size_t)lo * STRIVE_ZDIM + i] = L.dz[i];
 #undef SCN_TICK
 }
 

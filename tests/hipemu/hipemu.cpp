@@ -126,7 +126,10 @@ void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t shm
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) {
                 blockIdx.x = bx; blockIdx.y = by; blockIdx.z = bz;
-                if (shmem) memset(g.dyn_smem, 0xCD, shmem);   // poison: catches reads of unwritten LDS
+                // poison: catches reads of unwritten LDS.  HIPEMU_LDS_FILL=<byte> changes the pattern: a kernel whose results depend on
+                // it reads LDS it has not written (tests/test_emu_kernels.py)
+                static const int lds_fill = getenv("HIPEMU_LDS_FILL") ? atoi(getenv("HIPEMU_LDS_FILL")) : 0xCD;
+                if (shmem) memset(g.dyn_smem, lds_fill, shmem);
                 g.alive = nthreads;
                 g.barrier_arrived = 0;
                 for (int w = 0; w < nwaves; ++w) {

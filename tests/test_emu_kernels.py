@@ -799,7 +799,7 @@ def _rollout_both_paths(emu, sd, sizes, FT, ext=False, NC=2, monkeypatch=None, f
         dz = torch.zeros((NA, 32))
         emu.call('strive_rollout_bwd', dec.ref(), sc.ref(), L.ptr(lw), L.ptr(sem), L.ptr(z), L.ptr(extf), FT,
                  L.ptr(rw), L.ptr(dz), L.ptr(tape), tb, L.ptr(ws), wb, None)
-        out[mode] = (traj, dz, tape)
+        out[mode] = (traj, dz, tape, ws)
     # cross pairing: the tape is the same layout, so the sweep of one path runs on the tape of the other
     monkeypatch.setenv('STRIVE_SCENE_KERNELS', '1')
     dz_x = torch.zeros((NA, 32))
@@ -815,11 +815,64 @@ def test_scene_resident_rollout_equals_phase_kernels(emu, sd, sizes, FT, ext, mo
     same trajectories and latent gradients to fp32 rounding; scenes of 1, 2 and 16 agents (no edges / one edge row / four
     chunks of edge rows), teacher-forced ego rows, several steps (GRU + CNN between the steps)."""
     out, dz_x = _rollout_both_paths(emu, sd, sizes, FT, ext=ext, monkeypatch=monkeypatch)
-    (t0, d0, _), (t1, d1, _) = out['0'], out['1']
+    (t0, d0, _, _), (t1, d1, _, _) = out['0'], out['1']
     assert_close(t1, t0, 2e-5, 2e-6, 'scene-resident forward')
     scale = float(d0.abs().max())
     assert_close(d1, d0, 1e-3, 2e-5 * scale, 'scene-resident backward')
     assert_close(dz_x, d0, 1e-3, 2e-5 * scale, 'scene-resident sweep on the phase kernels\' tape')
+
+
+@pytest.mark.parametrize('sizes,FT,ext', [([16, 9], 2, True), ([13, 1, 2], 3, False)])
+def test_stepwise_sweep_equals_the_one_launch_sweep(emu, sd, sizes, FT, ext, monkeypatch):
+    """The reverse sweep of the scene-resident path as ONE launch per step with K workgroups per scene sharing the scene's edge
+    chunks (scene_bwd_sweep_kernel<.., true>; the default from 12 agents per scene on) against the one-launch sweep, on the same
+    tape: the partial sums are added in the one-launch order, so the latent gradients are the same BITS whenever every workgroup
+    walks at most one chunk (K >= the scene's chunks) and equal to fp32 rounding otherwise; the workspace arrives as NaN bytes
+    (nothing may be read before a launch has written it; the emulator runs a launch's workgroups one after the other, which is
+    how it found the partial sums of step t + 1 being overwritten by a faster workgroup's sums of step t: two buffers by parity)."""
+    batch, map_idx, raster, dx = mg.build_inputs(sizes, 'emu', NC=2)
+    env = synth.SyntheticMapEnv(raster, dx)
+    orc = oracle_model(sd)
+    NA = batch.past.shape[0]
+    emb = {'map_feat': synth.f32(synth.counter_uniform((NA, 64), 'emu/mf', -1, 1)),
+           'past_feat': synth.f32(synth.counter_uniform((NA, 64), 'emu/pf', -1, 1))}
+    z = synth.f32(synth.counter_uniform((NA, 32), 'emu/zz', -1.5, 1.5)).contiguous()
+    extf = batch.future_gt[batch.ptr[:-1]][:, :FT, :4].contiguous() if ext else None
+    dec = params.pack_decoder(sd, 2, env, 'cpu', orc.get_normalizer(), orc.get_att_normalizer(), NUSC_BIKE_PARAMS)
+    sc = params.pack_scenes(batch.ptr, 1, 'cpu')
+    tb = emu.query('strive_rollout_tape_bytes', dec.ref(), sc.ref(), FT)
+    wb = emu.query('strive_rollout_workspace_bytes', dec.ref(), sc.ref(), FT)
+    rw = synth.f32(synth.counter_uniform((NA, FT, 4), 'emu/rw', -1.0, 1.0)).contiguous()
+    mi = map_idx[batch.batch].int().contiguous()
+    lw, sem = batch.lw.contiguous(), batch.sem.contiguous()
+    monkeypatch.setenv('STRIVE_SCENE_KERNELS', '1')
+    tape, ws = torch.full((tb,), 0xFF, dtype=torch.uint8), torch.full((wb,), 0xFF, dtype=torch.uint8)
+    traj = torch.zeros((NA, FT, 4))
+    emu.call('strive_rollout_fwd', dec.ref(), sc.ref(), L.ptr(batch.past[:, -1, :].contiguous()), L.ptr(lw), L.ptr(sem),
+             L.ptr(emb['past_feat'].contiguous()), L.ptr(emb['map_feat'].contiguous()), L.ptr(z), L.ptr(mi), L.ptr(extf), FT,
+             L.ptr(traj), L.ptr(tape), tb, L.ptr(ws), wb, None)
+
+    def sweep(K):
+        if K is None:
+            monkeypatch.delenv('STRIVE_SWEEP_STEP', raising=False)
+        else:
+            monkeypatch.setenv('STRIVE_SWEEP_STEP', str(K))
+        dz = torch.full((NA, 32), float('nan'))
+        w2 = torch.full((wb,), 0xFF, dtype=torch.uint8)
+        emu.call('strive_rollout_bwd', dec.ref(), sc.ref(), L.ptr(lw), L.ptr(sem), L.ptr(z), L.ptr(extf), FT,
+                 L.ptr(rw), L.ptr(dz), L.ptr(tape), tb, L.ptr(w2), wb, None)
+        return dz
+    d_ref = sweep(0)
+    assert torch.isfinite(d_ref).all() and float(d_ref.abs().max()) > 0
+    scale = float(d_ref.abs().max())
+    chunks = (max(sizes) * (max(sizes) - 1) + 63) // 64
+    for K in (4, 3, 2, 1):
+        d = sweep(K)
+        if K >= chunks or K == 1:
+            assert torch.equal(d, d_ref), 'stepwise sweep, K = %d: %.3g apart' % (K, float((d - d_ref).abs().max()))
+        else:
+            assert_close(d, d_ref, 1e-4, 1e-6 * scale, 'stepwise sweep, K = %d' % K)
+    assert chunks >= 3 and torch.equal(sweep(None), d_ref), 'the default (stepwise from 3 chunks per scene on) gives the same bits'
 
 
 @pytest.mark.parametrize('sizes,FT,ext', [([3, 1, 5, 2], 1, False), ([16, 9], 1, True),
