@@ -69,10 +69,14 @@ class DataParallelTrainer(object):
       1. all_reduce(SUM) of the four data-dependent counts (they depend on the batch only, not on the forward);
       2. forward -> TrafficModelLoss -> backward of the rank's share of the global loss (a RuntimeError is caught like the
          reference's per-batch try/except);
-      3. ONE all_reduce(SUM) of the flat gradient bucket (1.09 M fp32 = 4.37 MB for NC = 2) whose last element is the
-         rank's "I failed" flag: if any rank failed, every rank skips the optimiser step (the skip vote), otherwise
-         ``optimizer.step()`` runs -- identical parameters on every rank.  The bucket is persistent and every ``p.grad`` is a
-         view into it, so nothing is copied in or out; a single rank never reads the flag back from the device.
+      3. ONE all_reduce(SUM) of the flat gradient bucket (1.09 M fp32 = 4.37 MB for NC = 2): if any rank failed, every rank
+         skips the optimiser step (the skip vote), otherwise ``optimizer.step()`` runs -- identical parameters on every rank.
+         The bucket is persistent and every ``p.grad`` is a view into it, so nothing is copied in or out.
+    The skip vote never touches the device (round 5): a failure IS a host event (the exception this rank's Python caught), so the
+    ranks exchange their flags through a HOST collective -- one all_reduce of a one-element CPU tensor over a gloo group next to
+    the RCCL group -- while the device queue keeps running; the bucket's last element still carries the flag for whoever inspects
+    the reduced bucket, but nobody reads it.  (Rounds 3-4 read it back after the gradient all-reduce: one device->host
+    synchronisation per step and rank as soon as N > 1.)
     """
 
     def __init__(self, model, loss_fn, optimizer, group=None):
@@ -80,6 +84,17 @@ class DataParallelTrainer(object):
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.last_error = None
+        # host-side group for the skip vote: the default group itself when it is gloo (CPU tests), else a gloo group over the same
+        # ranks (created collectively: every rank constructs its trainer)
+        self.vote_group, self.vote_transport, self._vote = None, 'single rank: no vote', False
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            self._vote = True
+            if dist.get_backend(group) == 'gloo':
+                self.vote_group, self.vote_transport = group, 'host collective (the gloo group itself)'
+            else:
+                ranks = dist.get_process_group_ranks(group) if group is not None else None
+                self.vote_group = dist.new_group(ranks=ranks, backend='gloo')
+                self.vote_transport = 'host collective (gloo group beside %s)' % dist.get_backend(group)
         # ONE persistent flat gradient buffer; every p.grad is a view into it (autograd accumulates in place), so the bucket
         # that goes through the all-reduce IS the gradients: no per-parameter copy in, no copy out.  The last element carries
         # the skip vote.
@@ -171,10 +186,13 @@ class DataParallelTrainer(object):
         self._all_reduce(self.bucket)
         if error is not None and not isinstance(error, RuntimeError):
             raise error                    # the reference's loop only swallows RuntimeError (train_traffic.py:120-131)
-        if failed:
-            return None                    # this rank knows its own outcome without looking at the device
-        if self._needs_host_vote() and bool(self.bucket[-1] > 0.0):
-            return None                    # another rank failed: nobody steps
+        any_failed = failed
+        if self._needs_host_vote():
+            vote = torch.tensor([failed], dtype=torch.float32)                  # a CPU tensor: the vote is a host collective
+            dist.all_reduce(vote, op=dist.ReduceOp.SUM, group=self.vote_group)
+            any_failed = float(vote[0])
+        if any_failed:
+            return None                    # this rank or another one failed: nobody steps
         self.optimizer.step()
         out = dict(loss_dict)
         out['global_loss'] = self._all_reduce(share.detach().clone().reshape(1))
@@ -182,6 +200,5 @@ class DataParallelTrainer(object):
 
     def _needs_host_vote(self):
         """With more than one rank another rank may have failed while this one did not: the optimiser step must then be
-        skipped here too, which needs the vote on the host (one 4-byte read after the all-reduce -- the collective has
-        synchronised the ranks anyway).  A single rank knows its own outcome already and never reads the device."""
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        skipped here too.  The flags travel host to host (``vote_group``); a single rank knows its own outcome already."""
+        return self._vote

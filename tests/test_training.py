@@ -260,7 +260,19 @@ def _dp_worker(rank, world, port, sizes, out_path):
             def boom(mean, var):
                 raise RuntimeError('injected failure')
             m.rsample = boom
-        out2 = tr.step(batch, map_idx, env)
+        # the vote travels host to host (a gloo collective of a CPU tensor), never through a read of a device tensor: from here on
+        # any bool() / .item() of the bucket would be the per-step synchronisation rounds 3-4 had at N > 1
+        assert tr.vote_transport.startswith('host collective'), tr.vote_transport
+        real_bool = torch.Tensor.__bool__
+
+        def guarded(t):
+            assert t.data_ptr() != tr.bucket[-1:].data_ptr(), 'the skip vote was read back from the gradient bucket'
+            return real_bool(t)
+        torch.Tensor.__bool__ = guarded
+        try:
+            out2 = tr.step(batch, map_idx, env)
+        finally:
+            torch.Tensor.__bool__ = real_bool
         res['skipped'] = out2 is None
         res['unchanged'] = all(torch.equal(before[n], p.detach()) for n, p in m.named_parameters())
     torch.save(res, out_path % rank)
