@@ -205,12 +205,20 @@ static __global__ __launch_bounds__(256) void node1_bwd_kernel(GNNDev g, GNNGrad
     float* s_gin = s_gb + RB_NODE * HLD;      // [RB_NODE][in_ld]
     const int tid = threadIdx.x, r0 = blockIdx.x * RB_NODE, NS = sc.NS;
     const int nrows = (a.R - r0) < RB_NODE ? (a.R - r0) : RB_NODE;
-    if (!WG && a.PRE_IN) {
-        // the forward pass kept mlp_in's pre-activations: nothing to recompute (features and x are only needed for the
-        // weight gradients)
+    if (a.PRE_IN) {
+        // the forward pass kept mlp_in's pre-activations: no dense layer is recomputed.  The weight gradients also need the
+        // network's input (the features, gathered again: loads only) and its output x (on the tape as well).  Round 5: the <WG>
+        // instantiation used to re-run the three layers of mlp_in for them (63 against 30 us per launch).
         for (int i = tid; i < RB_NODE * 2 * H; i += 256) {
             const int rr = i / (2 * H), rem = i - rr * 2 * H, l = rem / H, c = rem - l * H;
             L.pre[(size_t)l * RB_NODE * HLD + rr * HLD + c] = (r0 + rr < a.R) ? a.PRE_IN[(size_t)(r0 + rr) * 2 * H + rem] : 0.f;
+        }
+        if (WG) {
+            gather_features<RB_NODE>(f, r0, a.R, NS, L.in, in_ld, tid, 256);
+            for (int i = tid; i < RB_NODE * D; i += 256) {
+                const int rr = i / D, c = i - rr * D;
+                L.xs[rr * xs_ld + c] = (r0 + rr < a.R) ? a.X[(size_t)(r0 + rr) * D + c] : 0.f;
+            }
         }
     } else {
         // forward recompute of mlp_in (pre-activations)

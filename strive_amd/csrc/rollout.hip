@@ -568,21 +568,22 @@ static __global__ __launch_bounds__(256) void gru_bwd_kernel(GRUDev gru, GRUGrad
         s_h[i] = (r < R) ? tp.mem_t(t)[((size_t)r * 3 + l) * 64 + c] : 0.f;
     }
     __syncthreads();
-    if (!WG) {
-        // the forward sweep kept the gates (r, z, n, W_hn h + b_hn) of this step: nothing to recompute
-        for (int i = tid; i < 3 * RB_NODE * 256; i += 256) {
-            const int l = i / (RB_NODE * 256), rem = i - l * RB_NODE * 256, rr = rem >> 8, c = rem & 255;
-            s_g[i] = (r0 + rr < R) ? tp.GATES_t(t)[((size_t)(r0 + rr) * 3 + l) * 256 + c] : 0.f;
-        }
-        __syncthreads();
-    } else {
-        // forward recompute (the weight gradients also need the layer outputs)
-        for (int l = 0; l < 3; ++l) {
-            const float* x = (l == 0) ? s_x : s_hn + (size_t)(l - 1) * RB_NODE * 64;
-            gru_layer_lds(gru, l, x, l == 0 ? 4 : 64, l == 0 ? 4 : 64, s_h + (size_t)l * RB_NODE * 64, s_gi, s_gh,
-                          s_hn + (size_t)l * RB_NODE * 64, s_g + (size_t)l * RB_NODE * 256, tid);
+    // the forward sweep kept the gates (r, z, n, W_hn h + b_hn) of this step: nothing to recompute
+    for (int i = tid; i < 3 * RB_NODE * 256; i += 256) {
+        const int l = i / (RB_NODE * 256), rem = i - l * RB_NODE * 256, rr = rem >> 8, c = rem & 255;
+        s_g[i] = (r0 + rr < R) ? tp.GATES_t(t)[((size_t)(r0 + rr) * 3 + l) * 256 + c] : 0.f;
+    }
+    if (WG) {
+        // the weight gradients also need every layer's INPUT: the output of the layer below = that layer's memory of step t + 1,
+        // which the forward sweep left on the tape (this kernel only runs for t < FT - 1).  Round 5: the <WG> instantiation used to
+        // recompute the three GRU layers for them (77 against 22 us per launch).
+        for (int i = tid; i < 2 * RB_NODE * 64; i += 256) {
+            const int l = i / (RB_NODE * 64), rem = i - l * RB_NODE * 64;
+            const int r = r0 + (rem >> 6), c = rem & 63;
+            s_hn[i] = (r < R) ? tp.mem_t(t + 1)[((size_t)r * 3 + l) * 64 + c] : 0.f;
         }
     }
+    __syncthreads();
     // backward, top layer first
     for (int l = 2; l >= 0; --l) {
         float* gates = s_g + (size_t)l * RB_NODE * 256;
@@ -670,9 +671,8 @@ static __global__ __launch_bounds__(256) void node2_bwd_kernel(GNNDev g, GNNGrad
     float* s_gx = s_gb + RB_NODE * HLD;       // [RB_NODE][HLD] gradient w.r.t. x'
     float* s_gin = s_gx + RB_NODE * HLD;      // [RB_NODE][in_ld]
     const int tid = threadIdx.x, r0 = blockIdx.x * RB_NODE, t = a.t;
-    if (!WG) {
-        // pre-activations and decoder outputs of this step come from the tape (the weight gradients would also need the
-        // layer inputs: that instantiation recomputes the forward)
+    {
+        // pre-activations and decoder outputs of this step come from the tape
         for (int i = tid; i < RB_NODE * 3 * STRIVE_HID; i += 256) {
             const int rr = i / (3 * STRIVE_HID), rem = i - rr * 3 * STRIVE_HID;
             const bool live = r0 + rr < a.R;
@@ -686,9 +686,25 @@ static __global__ __launch_bounds__(256) void node2_bwd_kernel(GNNDev g, GNNGrad
             const int rr = tid >> 1, c = tid & 1;
             L.out[rr * HLD + c] = (r0 + rr < a.R) ? tp.DEC_t(t)[(size_t)(r0 + rr) * 4 + c] : 0.f;
         }
+        if (WG) {
+            // the weight gradients also need the two networks' INPUTS: (x | aggregated messages | sem) is assembled from the tape,
+            // x' = the update network's output is its last layer applied to the taped pre-activation.  Round 5: this instantiation
+            // used to recompute all five dense layers of the step (node2_forward: 44 against 18 us per launch).
+            const int D = g.D, NC = g.NC;
+            for (int i = tid; i < RB_NODE * in_ld; i += 256) {
+                const int rr = i / in_ld, k = i - rr * in_ld;
+                const int r = r0 + rr;
+                float v = 0.f;
+                if (r < a.R) {
+                    if (k < D) v = a.X[(size_t)r * D + k];
+                    else if (k < 2 * D) v = tp.A_t(t)[(size_t)r * D + (k - D)];
+                    else if (k < 2 * D + NC) v = a.sem[(size_t)(r / a.NS) * NC + (k - 2 * D)];
+                }
+                L.in[i] = v;
+            }
+        }
         __syncthreads();
-    } else {
-        node2_forward(g, a.NS, a.X, tp.A_t(t), a.sem, r0, a.R, L, in_ld, tid);
+        if (WG) mlp_forward_lds<RB_NODE>(g.update, L.in, in_ld, L.pre_u, L.act, L.xp, HLD, /*first_done=*/true, tid, 256);
     }
     const bool more = t < a.FT - 1;
     if (tid < RB_NODE) {
