@@ -20,7 +20,7 @@ KERNELS = [
     ('conv_ws_kernel<conv2>', 'conv_ws_kernel<Cin=16,Cout=32'),
     ('conv_bf6_kernel<conv3>', 'conv_bf6_kernel<Cin=32,Cout=64'),
     ('conv_bf6_kernel<conv4>', 'conv_bf6_kernel<Cin=64,Cout=64'),
-    ('cnn_tail_kernel (conv5 + conv6 + Linear)', 'cnn_tail_kernel<4'),
+    ('cnn_tail_kernel (conv5 + conv6 + Linear)', 'cnn_tail_kernel<'),
     ('scn::scene_bwd_sweep_kernel', 'scn::scene_bwd_sweep_kernel<false>'),
     ('scn::scene_fwd_step_kernel', 'scn::scene_fwd_step_kernel<false>'),
 ]

@@ -1406,7 +1406,9 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         GNStats* st[6];
         stat_slots(stats, (size_t)ch, st);
         dim3 g1(l1b::TILES_Y, n <= small_batch ? l1b::TILES_X : 1, n);
-        const int tail_s = tail_force ? tail_force : (n <= CNN_TAIL_ONE_SAMPLE ? 1 : 4);
+        // (above 256 samples: TWO samples per workgroup since round 5 -- 256 workgroups for a 512-sample chunk instead of 128 on 256
+        // CUs: refine closure 12.08 -> 12.01 ms, three alternations, profiles/r05_ab_sweep_step.json; bit-identical for every S)
+        const int tail_s = tail_force ? tail_force : (n <= CNN_TAIL_ONE_SAMPLE ? 1 : 2);
         if (map) {
             hipLaunchKernelGGL(conv1b_kernel<true>, g1, dim3(C1_NT), 0, stream, mp, pos + (size_t)n0 * 4, m, s, mapix + n0,
                                (const uint8_t*)nullptr, cnn->w1_frag, 1.0f / cnn->wscale[0], (const float*)cnn->b[0], act[0], st[0]);
@@ -1534,7 +1536,7 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
         case 3: launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], N, cnn->xscale[3], cnn->wscale[3], stream); break;
         case 4: launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], N, cnn->xscale[4], cnn->wscale[4], stream); break;
         case 5: launch_bf6s<Bfs6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w6_frag, cnn->b[5], act[5], st[5], N, cnn->xscale[5], cnn->wscale[5], stream); break;
-        case 7: launch_cnn_tail(cnn, act[3], st[3], NPARTS[3], feat, N, stream); break;      // conv5 + conv6 + Linear, fused
+        case 7: launch_cnn_tail(cnn, act[3], st[3], NPARTS[3], feat, N, stream, nullptr, N <= CNN_TAIL_ONE_SAMPLE ? 1 : 2); break;   // conv5 + conv6 + Linear, fused: the form strive_map_cnn_fwd launches for N samples
         case 27: {  // its phase profile: clock sums land in `ws` beyond the activations conv4 left (results in feat stay valid)
             unsigned long long* tp = reinterpret_cast<unsigned long long*>(act[4]);
             hipMemsetAsync(tp, 0, 64, stream);
