@@ -1028,6 +1028,14 @@ def main():
         sc = _ops.scene_info(g).pack(1)
         if pk:
             rollout_kernels = 'scene-resident' if _L.get_lib().query('strive_rollout_scene_resident', pk[0].ref(), sc.ref()) else 'per-phase'
+            if rollout_kernels == 'scene-resident':
+                # the reverse sweep's form (csrc/rollout.hip strive_rollout_bwd: stepwise from 3 edge chunks per scene on, STRIVE_SWEEP_STEP)
+                mx = int(sc.struct.max_n)
+                chunks = (mx * (mx - 1) + 63) // 64
+                k_env = os.environ.get('STRIVE_SWEEP_STEP')
+                K = int(k_env) if k_env is not None else (chunks if chunks >= 3 else 0)
+                rollout_kernels += ('; reverse sweep: one launch per step, %d workgroups per scene' % min(K, 4)) if K >= 1 else \
+                    '; reverse sweep: one launch, one workgroup per scene'
     except Exception:
         rollout_kernels = None
     out = {
