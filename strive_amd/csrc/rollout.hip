@@ -383,6 +383,7 @@ size_t fwd_ws_bytes(size_t R) {
     b += 2 * strive_align_up(R * STRIVE_HID * 4, 256);
     b += strive_align_up(R * 4, 256);
     b += strive_align_up(strive_map_cnn_workspace_bytes((int32_t)R), 256);
+    b += 2 * strive_align_up(R * 4 * scn::NR * 64 * 4, 256);      // partial maxima of the scene kernels' K-workgroup edge walk (B <= R scenes, K <= 4)
     return b;
 }
 
@@ -459,6 +460,8 @@ extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* 
     w.mapix_rows = ar.take<int32_t>(R);
     w.cnn_bytes = strive_map_cnn_workspace_bytes((int32_t)R);
     w.cnn_ws = ar.take<char>(w.cnn_bytes);
+    float* part_a = ar.take<float>(R * 4 * scn::NR * 64);
+    int32_t* part_arg = ar.take<int32_t>(R * 4 * scn::NR * 64);
     STRIVE_CHECK_ARG(ar.ok(), "workspace arena overflow");
 
     const GNNDev gd = gnn_dev(dec->gnn);
@@ -474,28 +477,44 @@ extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* 
     const scn::GRUFrag gf = scn::gru_frag(dec->gru);
     const char* pe = getenv("STRIVE_SCENE_PROF");
     const bool scene_prof = scene && pe && atoi(pe) != 0;
-    // scenes of >= STRIVE_SCENE_SPLIT agents (default 15; 0 = never): their 130-240 edge rows are 3-4 chunks on ONE CU inside the
-    // scene kernel and one workgroup per target node in gnn_edge_kernel (profiles/r04_ab_scene_split.txt)
+    // scenes of >= STRIVE_SCENE_SPLIT agents (default 12 = three 64-row edge chunks; 0 = never): their 130-240 edge rows are 3-4
+    // chunks on ONE CU inside the one-launch scene step.  Round 4 moved them to gnn_edge_kernel (one workgroup per target) from 15
+    // agents on (profiles/r04_ab_scene_split.txt); round 5 shares the chunks among K workgroups of the scene kernel itself (below):
+    // a wash against the per-target kernel at 16 agents per scene, -2 % / -4 % of the refine closure at 14 / 12 agents where the
+    // per-target kernel did not pay (profiles/r05_ab_fwd_k.json)
     const char* se = getenv("STRIVE_SCENE_SPLIT");
-    const int split_min = se ? atoi(se) : 15;
+    const int split_min = se ? atoi(se) : 12;
     const bool scene_split = scene && split_min > 0 && sc->max_n >= split_min;
+    // STRIVE_SCENE_FWD_K = workgroups per scene for the edge chunks of such scenes (default: one per chunk, <= 4; 0 = the round-4
+    // form: scene kernel | one workgroup per target in gnn_edge_kernel | scene kernel)
+    int fwd_k = (sc->max_n * (sc->max_n - 1) + scn::EC - 1) / scn::EC;
+    if (const char* fe = getenv("STRIVE_SCENE_FWD_K")) fwd_k = atoi(fe);
+    fwd_k = fwd_k > 4 ? 4 : fwd_k;
+    if (scene_prof) fwd_k = 0;
     hipLaunchKernelGGL(rollout_init_kernel, dim3((unsigned)((R * 64 + 255) / 256)), dim3(256), 0, stream, tp, past_last,
                        past_feat, map_feat, mapix, w.mapix_rows, (int)R, sc->NS);
     for (int t = 0; t < FT; ++t) {
         if (scene) {
             scn::StepArgsS a;
             a.t = t; a.FT = FT; a.NC = NC; a.max_n = sc->max_n; a.sem = sem; a.lw = lw; a.z = z; a.ext = ext_future; a.ptr = sc->ptr;
-            a.par = dec->scene_par; a.traj = traj;
-            auto launch_scene = [&](int mode) {
+            a.par = dec->scene_par; a.traj = traj; a.KW = 0; a.part_a = part_a; a.part_arg = part_arg;
+            auto launch_scene = [&](int mode, int ky = 1) {
                 a.mode = mode;
                 if (scene_prof)       // (tools/scene_phase_probe.py: phase ticks of workgroup 0 at the start of the workspace)
-                    hipLaunchKernelGGL(scn::scene_fwd_step_kernel<true>, dim3((unsigned)sc->B), dim3(scn::NTHR), scn::FwdLds::BYTES, stream, gd,
+                    hipLaunchKernelGGL(scn::scene_fwd_step_kernel<true>, dim3((unsigned)sc->B, (unsigned)ky), dim3(scn::NTHR), scn::FwdLds::BYTES, stream, gd,
                                        gr, gf, dp, a, tp, (unsigned long long*)ws);
                 else
-                    hipLaunchKernelGGL(scn::scene_fwd_step_kernel<false>, dim3((unsigned)sc->B), dim3(scn::NTHR), scn::FwdLds::BYTES, stream, gd,
+                    hipLaunchKernelGGL(scn::scene_fwd_step_kernel<false>, dim3((unsigned)sc->B, (unsigned)ky), dim3(scn::NTHR), scn::FwdLds::BYTES, stream, gd,
                                        gr, gf, dp, a, tp, (unsigned long long*)nullptr);
             };
-            if (scene_split) {
+            if (scene_split && fwd_k > 0) {
+                // large scenes, round 5: K workgroups of the scene kernel per scene share the edge chunks (node phases repeated, partial
+                // maxima folded by the second launch): two launches per step instead of three, the 64-row chunk form for the edges
+                a.KW = fwd_k;
+                launch_scene(3, fwd_k);
+                launch_scene(4);
+                a.KW = 0;
+            } else if (scene_split) {
                 // large scenes: node phases per scene, the edge rows on one workgroup per target node in between (gnn_kernels.h)
                 GnnBuffers gb = w.gb;
                 gb.A = tp.A_t(t); gb.ARG = tp.ARG_t(t); gb.X = tp.X_t(t); gb.P = tp.P_t(t); gb.Q = tp.Q_t(t);

@@ -509,10 +509,17 @@ struct StepArgsS {
     const int32_t* ptr;        // (B + 1)
     const float* par;          // StriveDecoder.scene_par
     float* traj;               // (NA, FT, 4)
+    // round 5, K workgroups per scene for the edge chunks (grid (B, K), mode 3 | mode 4 instead of 1 | gnn_edge_kernel | 4): every
+    // workgroup repeats the node-level phases of mode 1 (workgroup 0 writes the tape), walks chunks k, k + K, ... and leaves ITS
+    // running max / arg-max in `part_a / part_arg` (B, K, NR, 64); the mode-4 launch folds the K partial maxima in workgroup order
+    // with the rule of the chunk loop (a later source only wins when strictly larger): the aggregate of the one-workgroup walk
+    int KW;                    // 0 = off
+    float* part_a;
+    int* part_arg;
 };
 
 // =====================================================================================================================
-// forward: one decoder step of one scene.   grid = B, block = 512
+// forward: one decoder step of one scene.   grid = B (x K, see StepArgsS::KW), block = 512
 // =====================================================================================================================
 template <bool PROF>
 static __global__ __launch_bounds__(NTHR) void scene_fwd_step_kernel(GNNDev g, GRUDev gru, GRUFrag gf, DynParams dp, StepArgsS a,
@@ -522,6 +529,8 @@ static __global__ __launch_bounds__(NTHR) void scene_fwd_step_kernel(GNNDev g, G
     const int tid = threadIdx.x, b = blockIdx.x, t = a.t, NC = a.NC, H = STRIVE_HID;
     const int lo = a.ptr[b], n = a.ptr[b + 1] - lo;
     if (n <= 0) return;
+    const int kw = (a.KW > 0 && (a.mode & 2)) ? (int)blockIdx.y : 0, KW = (a.KW > 0 && (a.mode & 2)) ? a.KW : 1;
+    const bool tape_w = kw == 0;                 // the K workgroups of a scene hold the same node-level values: one of them stores
     long long tick = PROF ? clock64() : 0;
 #define SCN_TICK(id)                                                        \
     do {                                                                    \
@@ -588,19 +597,20 @@ static __global__ __launch_bounds__(NTHR) void scene_fwd_step_kernel(GNNDev g, G
         // keep the pre-activations of both hidden layers for the reverse sweep
         for (int i = tid; i < n * H; i += NTHR) {
             const int rr = i >> 7, c = i & 127;
-            tp.PRE_IN_t(t)[(size_t)(lo + rr) * 2 * H + c] = s_pre[rr * HLD + c];
+            if (tape_w) tp.PRE_IN_t(t)[(size_t)(lo + rr) * 2 * H + c] = s_pre[rr * HLD + c];
         }
         __syncthreads();
         ln_relu_split16([&](int r) { return s_pre + NR * HLD + r * HLD; }, n, NR, (L.par + Par::IN_G1), (L.par + Par::IN_E1), sb, tid);
         for (int i = tid; i < n * H; i += NTHR) {
             const int rr = i >> 7, c = i & 127;
-            tp.PRE_IN_t(t)[(size_t)(lo + rr) * 2 * H + H + c] = s_pre[NR * HLD + rr * HLD + c];
+            if (tape_w) tp.PRE_IN_t(t)[(size_t)(lo + rr) * 2 * H + H + c] = s_pre[NR * HLD + rr * HLD + c];
         }
         __syncthreads();
         dense_rows<4>(g.mlp_in.wf[2], g.mlp_in.wsc[2], (L.par + Par::IN_B2), 64, 1, n, sb, L.x, XLD, tid, &f2);
         __syncthreads();
     }
-    for (int i = tid; i < n * 64; i += NTHR) tp.X_t(t)[(size_t)lo * 64 + i] = L.x[(i >> 6) * XLD + (i & 63)];
+    if (tape_w)
+        for (int i = tid; i < n * 64; i += NTHR) tp.X_t(t)[(size_t)lo * 64 + i] = L.x[(i >> 6) * XLD + (i & 63)];
     SCN_TICK(0);
 
     // ---- edge layer 0, factorised: P_i = W[:, x_i | sem_i] [x_i, sem_i] + b,  Q_j = W[:, x_j | sem_j] [x_j, sem_j] ----
@@ -635,12 +645,34 @@ static __global__ __launch_bounds__(NTHR) void scene_fwd_step_kernel(GNNDev g, G
         }, &fQ);
         __syncthreads();
     }
-    for (int i = tid; i < n * H; i += NTHR) {
-        const int rr = i >> 7, c = i & 127;
-        tp.P_t(t)[(size_t)(lo + rr) * H + c] = L.P[rr * HLD + c];
-        tp.Q_t(t)[(size_t)(lo + rr) * H + c] = L.Q[rr * HLD + c];
-    }
+    if (tape_w)
+        for (int i = tid; i < n * H; i += NTHR) {
+            const int rr = i >> 7, c = i & 127;
+            tp.P_t(t)[(size_t)(lo + rr) * H + c] = L.P[rr * HLD + c];
+            tp.Q_t(t)[(size_t)(lo + rr) * H + c] = L.Q[rr * HLD + c];
+        }
     SCN_TICK(1);
+    } else if (a.KW > 0) {
+        // the node embeddings are in the tape; the aggregated messages arrive as the K workgroups' partial maxima: folded in workgroup
+        // order (= ascending source order), a later one only wins when strictly larger -- the rule of the chunk loop below
+        const int E_ = n * (n - 1), nchunk = (E_ + EC - 1) / EC, kb = nchunk < a.KW ? nchunk : a.KW;
+        for (int i = tid; i < n * 64; i += NTHR) {
+            L.x[(i >> 6) * XLD + (i & 63)] = tp.X_t(t)[(size_t)lo * 64 + i];
+            float best = 0.f;
+            int arg = -1;
+            for (int k = 0; k < kb; ++k) {
+                const size_t o = ((size_t)b * a.KW + k) * NR * 64 + i;
+                const int pa = a.part_arg[o];
+                const float pv = a.part_a[o];
+                if (pa >= 0 && (arg < 0 || pv > best)) { best = pv; arg = pa; }
+            }
+            const float v = arg < 0 ? 0.f : best;            // isolated node: aggregate 0 (interaction_net.py:188)
+            L.A[i] = v;
+            tp.A_t(t)[(size_t)lo * 64 + i] = v;
+            tp.ARG_t(t)[(size_t)lo * 64 + i] = arg;
+        }
+        par_stage(L.par, a.par, tid);
+        __syncthreads();
     } else {
         // the node embeddings and the aggregated messages of this step are in the tape (written by the launches before this one)
         for (int i = tid; i < n * 64; i += NTHR) {
@@ -661,7 +693,7 @@ static __global__ __launch_bounds__(NTHR) void scene_fwd_step_kernel(GNNDev g, G
         const int c_own = tid & 127;
         const float wr0 = Wrel[c_own], wr1 = Wrel[H + c_own], wr2 = Wrel[2 * H + c_own], wr3 = Wrel[3 * H + c_own];
         SB sb(L.sb, L.rs, 128, EC);
-        for (int e0 = 0; e0 < E; e0 += EC) {
+        for (int e0 = kw * EC; e0 < E; e0 += KW * EC) {
             const int ne = (E - e0) < EC ? (E - e0) : EC;
             const int ne_pad = (ne + 15) & ~15, nrt = ne_pad >> 4;
             if (tid < EC) {
@@ -728,12 +760,21 @@ static __global__ __launch_bounds__(NTHR) void scene_fwd_step_kernel(GNNDev g, G
             __syncthreads();
             SCN_TICK(7);
         }
+    if (a.KW > 0) {
+        // this workgroup's running maxima over ITS chunks; the mode-4 launch folds them
+        for (int i = tid; i < n * 64; i += NTHR) {
+            const size_t o = ((size_t)b * a.KW + kw) * NR * 64 + i;
+            a.part_a[o] = L.A[i];
+            a.part_arg[o] = L.ARG[i];
+        }
+    } else {
     for (int i = tid; i < n * 64; i += NTHR) {
         const int arg = L.ARG[i];
         const float v = arg < 0 ? 0.f : L.A[i];          // isolated node: aggregate 0 (interaction_net.py:188)
         L.A[i] = v;
         tp.A_t(t)[(size_t)lo * 64 + i] = v;
         tp.ARG_t(t)[(size_t)lo * 64 + i] = arg;
+    }
     }
     __syncthreads();
     }

@@ -875,6 +875,31 @@ def test_stepwise_sweep_equals_the_one_launch_sweep(emu, sd, sizes, FT, ext, mon
     assert chunks >= 3 and torch.equal(sweep(None), d_ref), 'the default (stepwise from 3 chunks per scene on) gives the same bits'
 
 
+@pytest.mark.parametrize('sizes', [[16, 9], [15, 2, 1]])
+def test_forward_edge_chunks_on_k_workgroups_equal_the_other_forms(emu, sd, sizes, monkeypatch):
+    """Scenes of >= 15 agents, forward step: K workgroups of the scene kernel per scene share the edge chunks and leave partial
+    running maxima that the second launch folds (round 5, STRIVE_SCENE_FWD_K) -- against the round-4 split (one workgroup per
+    target in gnn_edge_kernel) and the one-launch scene step: trajectories, aggregated messages and arg-max on the tape
+    bit-identical to the one-launch step for every K (the fold keeps the chunk loop's tie rule), and the reverse sweep on that tape
+    gives the same bits."""
+    res = {}
+    for name, env in (('one launch', {'STRIVE_SCENE_SPLIT': '0'}), ('K=4', {'STRIVE_SCENE_FWD_K': '4'}), ('K=2', {'STRIVE_SCENE_FWD_K': '2'}),
+                      ('K=1', {'STRIVE_SCENE_FWD_K': '1'}), ('default', {}), ('per-target edge kernel', {'STRIVE_SCENE_FWD_K': '0'})):
+        for k in ('STRIVE_SCENE_SPLIT', 'STRIVE_SCENE_FWD_K'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out, _ = _rollout_both_paths(emu, sd, sizes, 1, ext=True, monkeypatch=monkeypatch, fill=0xFF)
+        res[name] = out['1']
+    t0, d0, tape0, _ = res['one launch']
+    for name in ('K=4', 'K=2', 'K=1', 'default'):
+        t, d, tape, _ = res[name]
+        assert torch.equal(t, t0) and torch.equal(d, d0), '%s: forward / backward differ from the one-launch step' % name
+        assert torch.equal(tape, tape0), '%s: the tape differs' % name
+    t, d, _, _ = res['per-target edge kernel']
+    assert_close(t, t0, 2e-5, 2e-6, 'round-4 split forward')
+
+
 @pytest.mark.parametrize('sizes,FT,ext', [([3, 1, 5, 2], 1, False), ([16, 9], 1, True),
                                           ([4, 2], 2, False)])
 def test_rollout_reads_nothing_it_did_not_write(emu, sd, sizes, FT, ext, monkeypatch):
