@@ -776,16 +776,18 @@ def cpu_baseline(FT, scenes=4, agents=16, raster_px=4096, timed=3, warm=1):
             opt.step()
         for _ in range(warm):
             closure()
-        t0 = time.perf_counter()
+        each = []
         for _ in range(timed):
+            t0 = time.perf_counter()
             closure()
-        dt = (time.perf_counter() - t0) / timed
+            each.append(time.perf_counter() - t0)
+        dt = sum(each) / timed
     finally:
         torch.set_num_threads(old_threads)
         _omap.REFERENCE_CHANNEL_STRUCTURE = old_struct
     n = scenes * agents * FT
     return {'value': round(n / dt, 2), 'unit': 'agent*timesteps/s', 'cores': _one_socket()[0], 'threads': threads, 'kind': 'port',
-            'cpu': _cpu_model(),
+            'cpu': _cpu_model(), 'closure_s': [round(v, 2) for v in each],
             'sample': '%d scenes x %d agents, FT=%d: %d warm-up + %d timed refine closures (decode + AvoidCollLoss + backward '
                       'incl. the CNN weight gradients the reference computes + Adam) of the CPU oracle with the reference\'s per-channel '
                       'crop coordinates (nuscenes_utils.py:217-230), %.1f s per closure; '
@@ -794,8 +796,8 @@ def cpu_baseline(FT, scenes=4, agents=16, raster_px=4096, timed=3, warm=1):
 
 def cpu_baseline_record(FT, full=False):
     """The bench line's `cpu_baseline`.  SURVEY 8(d) quotes the CPU at C2 (32 scenes x 16 agents), where one closure of the
-    oracle takes minutes; the default run therefore times two bounded samples of the same workload -- 4 x 16 agents and 16 x 16 agents, each
-    with 1 warm-up + 2 timed closures -- reports the LARGER sample as `value` and states both, so the trend
+    oracle takes minutes; the default run therefore times two bounded samples of the same workload -- 4 x 16 agents (1 warm-up + 1 timed
+    closure) and 16 x 16 agents (2 timed closures) -- reports the LARGER sample as `value` and states both, so the trend
     towards C2 is visible (it differs by host: 77 -> 31 agent*timesteps/s from 4 to 32 scenes on the 8-vCPU survey container,
     79 -> 90 from 4 to 16 scenes on the 128-thread EPYC of the GPU boxes).  ``--cpu-baseline-full`` times C2 itself (1 warm-up +
     2 timed closures, several minutes); profiles/r03_cpu_baseline_c2.json holds that run."""
@@ -803,13 +805,17 @@ def cpu_baseline_record(FT, full=False):
         rec = cpu_baseline(FT, scenes=32, agents=16, timed=2)
         rec['sample'] = 'C2 itself: ' + rec['sample']
         return rec
-    small = cpu_baseline(FT, scenes=4, agents=16, timed=2)
-    large = cpu_baseline(FT, scenes=16, agents=16, timed=2, warm=1)
+    # (with the reference's per-channel crop structure a 16 x 16 closure takes ~65 s on the GPU boxes' EPYC: the small sample is also
+    # the process's warm-up -- thread pool, allocator, convolution primitives -- and the large one times its first two closures, both
+    # listed in `closure_s`, so that the default run stays at about three minutes of CPU work)
+    small = cpu_baseline(FT, scenes=4, agents=16, timed=1, warm=1)
+    large = cpu_baseline(FT, scenes=16, agents=16, timed=2, warm=0)
     rec = dict(large)
     rec['sample'] = ('bounded samples of C2 (32 x 16 agents): %s || %s.  `value` is the 16 x 16 sample (4 x 16: %.1f, 16 x 16: %.1f '
                      'agent*timesteps/s); C2 itself, timed with --cpu-baseline-full, is in profiles/r03_cpu_baseline_c2.json' %
                      (small['sample'], large['sample'], small['value'], large['value']))
-    rec['samples'] = [{'scenes': 4, 'agents': 16, 'value': small['value']}, {'scenes': 16, 'agents': 16, 'value': large['value']}]
+    rec['samples'] = [{'scenes': 4, 'agents': 16, 'value': small['value'], 'closure_s': small['closure_s']},
+                      {'scenes': 16, 'agents': 16, 'value': large['value'], 'closure_s': large['closure_s']}]
     return rec
 
 
