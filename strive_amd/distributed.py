@@ -93,8 +93,15 @@ class DataParallelTrainer(object):
                 self.vote_group, self.vote_transport = group, 'host collective (the gloo group itself)'
             else:
                 ranks = dist.get_process_group_ranks(group) if group is not None else None
-                self.vote_group = dist.new_group(ranks=ranks, backend='gloo')
-                self.vote_transport = 'host collective (gloo group beside %s)' % dist.get_backend(group)
+                import os
+                if os.environ.get('MASTER_ADDR', '') in ('127.0.0.1', 'localhost'):
+                    os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')       # single-node jobs: the container's hostname may not resolve
+                try:
+                    self.vote_group = dist.new_group(ranks=ranks, backend='gloo')
+                    self.vote_transport = 'host collective (gloo group beside %s)' % dist.get_backend(group)
+                except Exception as e:       # no usable host transport: the vote falls back to the reduced bucket (one device read per step)
+                    self.vote_group = None
+                    self.vote_transport = 'device read of the reduced bucket (gloo group unavailable: %s)' % (str(e).splitlines()[0][:120],)
         # ONE persistent flat gradient buffer; every p.grad is a view into it (autograd accumulates in place), so the bucket
         # that goes through the all-reduce IS the gradients: no per-parameter copy in, no copy out.  The last element carries
         # the skip vote.
@@ -188,9 +195,12 @@ class DataParallelTrainer(object):
             raise error                    # the reference's loop only swallows RuntimeError (train_traffic.py:120-131)
         any_failed = failed
         if self._needs_host_vote():
-            vote = torch.tensor([failed], dtype=torch.float32)                  # a CPU tensor: the vote is a host collective
-            dist.all_reduce(vote, op=dist.ReduceOp.SUM, group=self.vote_group)
-            any_failed = float(vote[0])
+            if self.vote_transport.startswith('host collective'):
+                vote = torch.tensor([failed], dtype=torch.float32)              # a CPU tensor: the vote is a host collective
+                dist.all_reduce(vote, op=dist.ReduceOp.SUM, group=self.vote_group)
+                any_failed = float(vote[0])
+            else:
+                any_failed = float(self.bucket[-1])                             # (fallback: the flag summed with the gradients)
         if any_failed:
             return None                    # this rank or another one failed: nobody steps
         self.optimizer.step()
