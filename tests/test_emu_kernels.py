@@ -822,7 +822,7 @@ def test_scene_resident_rollout_equals_phase_kernels(emu, sd, sizes, FT, ext, mo
     assert_close(dz_x, d0, 1e-3, 2e-5 * scale, 'scene-resident sweep on the phase kernels\' tape')
 
 
-@pytest.mark.parametrize('sizes,FT,ext', [([16, 9], 2, True), ([13, 1, 2], 3, False)])
+@pytest.mark.parametrize('sizes,FT,ext', [([16, 9], 2, True), ([13, 1, 2], 2, False)])
 def test_stepwise_sweep_equals_the_one_launch_sweep(emu, sd, sizes, FT, ext, monkeypatch):
     """The reverse sweep of the scene-resident path as ONE launch per step with K workgroups per scene sharing the scene's edge
     chunks (scene_bwd_sweep_kernel<.., true>; the default from 12 agents per scene on) against the one-launch sweep, on the same
