@@ -13,6 +13,8 @@ Appendix A) and, inside ``forward()`` (training), also the gradients of every pa
 Not supported (raise NotImplementedError): ``traj_encoder='gru'``, ``output_bicycle=False`` and
 non-default map-CNN shapes -- no shipped config uses them (last paragraph).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -50,6 +52,9 @@ class TrafficModel(nn.Module):
         self.dt = 0.5
         self.output_bicycle = True
         self.bicycle_params = None
+        # forward(future_sample=True): both decodes as one rollout over the batch stacked twice (STRIVE_STACK_ROLLOUTS=0: one after
+        # the other, the round-4 form)
+        self.stack_rollouts = os.environ.get('STRIVE_STACK_ROLLOUTS', '1') != '0'
         self.state_size, self.att_feat_size = 6, 2
         self.traj_encoder_type = traj_encoder
         self.mapH = self.mapW = self.map_obs_size_pix = map_obs_size_pix
@@ -239,8 +244,15 @@ class TrafficModel(nn.Module):
             pmu, pvar = emb['prior_out']
             qmu, qvar = emb['posterior_out']
             z = qmu if use_post_mean else self.rsample(qmu, qvar)
-            out = {'prior_out': (pmu, pvar), 'posterior_out': (qmu, qvar),
-                   'future_pred': self.decoder(scene_graph, emb['map_feat'], emb['past_feat'], z, map_idx, map_env)}
+            out = {'prior_out': (pmu, pvar), 'posterior_out': (qmu, qvar)}
+            if future_sample and self.stack_rollouts:
+                # the two decodes of the reference (posterior sample, then prior sample) as ONE rollout over the batch stacked
+                # twice (ops.decoder_rollout_stacked): scenes do not interact, every kernel of a step runs once instead of twice
+                zp = self.rsample(pmu, pvar)
+                out['future_pred'], out['future_samp'] = ops.decoder_rollout_stacked(self, scene_graph, emb['map_feat'], emb['past_feat'],
+                                                                                     [z, zp], map_idx, map_env, self.FT)
+                return out
+            out['future_pred'] = self.decoder(scene_graph, emb['map_feat'], emb['past_feat'], z, map_idx, map_env)
             if future_sample:
                 zp = self.rsample(pmu, pvar)
                 out['future_samp'] = self.decoder(scene_graph, emb['map_feat'], emb['past_feat'], zp, map_idx, map_env)

@@ -238,6 +238,17 @@ class SceneInfo(object):
             self._packs[NS] = p
         return p
 
+    def stacked(self, copies):
+        """the batch ``copies`` times over as ONE batch of copies * B scenes (rows of copy c at [c * NA, (c + 1) * NA)):
+        what decoder_rollout_stacked hands the library"""
+        st = self.__dict__.setdefault('_stacked', {})
+        s = st.get(copies)
+        if s is None:
+            ptr = self.ptr_cpu
+            s = SceneInfo(torch.cat([ptr[:1]] + [ptr[1:] + c * self.NA for c in range(copies)]), self.device)
+            st[copies] = s
+        return s
+
 
 def _expected_clique_keys(ptr_cpu, NA):
     keys = []
@@ -824,8 +835,31 @@ def decoder_rollout(model, g, map_feat, past_feat, z, map_idx, map_env, ext_futu
     return traj.reshape(info.NA, NS, h.FT, 4) if multi else traj.reshape(info.NA, h.FT, 4)
 
 
-def _rollout_context(model, g, map_feat, past_feat, z, map_idx, map_env, ext_future, FT, train):
-    """descriptors, per-call tensors and sizes of one rollout (shared by decoder_rollout and decoder_rollout_pair)"""
+def decoder_rollout_stacked(model, g, map_feat, past_feat, zs, map_idx, map_env, FT):
+    """``[decoder_rollout(..., z) for z in zs]`` (2-D latents, no ext_future) as ONE rollout over the batch stacked len(zs) times:
+    the scenes of copy c are scenes c * B .. (c + 1) * B - 1 of one batch of len(zs) * B scenes, so every kernel of a step runs
+    once over all copies instead of once per copy.  Scenes do not interact, so each copy's trajectories are what its own
+    rollout gives; used by the training forward (reference src/models/traffic_model.py:217-224 decodes the posterior sample and
+    the prior sample one after the other).  Not part of the reference's API."""
+    k = len(zs)
+    if k == 1:
+        return [decoder_rollout(model, g, map_feat, past_feat, zs[0], map_idx, map_env, None, FT)]
+    if any(z.dim() != 2 or z.shape != zs[0].shape for z in zs):
+        raise ValueError('decoder_rollout_stacked takes 2-D latents of one shape')
+    train = _wgrad()
+    h, info, _, _ = _rollout_context(model, g, map_feat, past_feat, zs[0], map_idx, map_env, None, FT, train, copies=k)
+    z = torch.cat(list(zs), 0)
+    if train:
+        ps = list(model.decoder_net.parameters()) + list(model.decoder_memory.parameters()) + _cnn_params(model)
+        traj = _RolloutTrainFn.apply(z, torch.cat([past_feat] * k, 0), torch.cat([map_feat] * k, 0), h, *ps)
+    else:
+        traj = _RolloutFn.apply(z, h)
+    return list(traj.reshape(k, info.NA, h.FT, 4).unbind(0))
+
+
+def _rollout_context(model, g, map_feat, past_feat, z, map_idx, map_env, ext_future, FT, train, copies=1):
+    """descriptors, per-call tensors and sizes of one rollout (shared by decoder_rollout and decoder_rollout_pair);
+    ``copies`` > 1: of the batch stacked that many times (decoder_rollout_stacked)"""
     lib = _lib_for(z, map_feat, past_feat, g.past)
     if model.normalizer is None or model.att_normalizer is None or model.bicycle_params is None:
         raise RuntimeError('set_normalizer / set_att_normalizer / set_bicycle_params must be called before decoding')
@@ -852,8 +886,8 @@ def _rollout_context(model, g, map_feat, past_feat, z, map_idx, map_env, ext_fut
     h.dec = _cached_pack(model, key, model, build, extra_sig=extra)
     if conv2_plain.on:
         h.dec = _decoder_variant(h.dec)
-    h.sc = info.pack(NS)
-    h.R = info.NA * NS
+    h.sc = info.pack(NS) if copies == 1 else info.stacked(copies).pack(NS)
+    h.R = info.NA * NS * copies
     h.FT = int(FT)
     h.past_last = _f32c(g.past[:, -1, :])
     h.lw = _f32c(g.lw)
@@ -861,6 +895,13 @@ def _rollout_context(model, g, map_feat, past_feat, z, map_idx, map_env, ext_fut
     h.past_feat = _f32c(past_feat)
     h.map_feat = _f32c(map_feat)
     h.mapix = map_idx.to(dev)[g.batch.to(dev)].to(torch.int32).contiguous()
+    if copies > 1:
+        if multi or ext_future is not None:
+            raise NotImplementedError('stacked rollouts take 2-D latents and no ext_future')
+        rep = lambda t: torch.cat([t] * copies, 0)
+        h.past_last, h.lw, h.sem, h.mapix = rep(h.past_last), rep(h.lw), rep(h.sem), rep(h.mapix)
+        if not train:       # (the training Function takes the two features as differentiable arguments, stacked by the caller)
+            h.past_feat, h.map_feat = rep(h.past_feat), rep(h.map_feat)
     h.ext = None if ext_future is None else _f32c(ext_future)
     if h.ext is not None and tuple(h.ext.shape) != (info.B, h.FT, 4):
         raise ValueError('ext_future must be (B, FT, 4), got %s' % (tuple(h.ext.shape),))

@@ -122,12 +122,17 @@ def test_training_step_all_gradients_emulated(emu_ops):
     saved = m.rsample
     m.rsample = lambda mean, var: mean + seq.pop(0).to(mean.device) * torch.sqrt(var)
     ops.GradSink.segment = counting
+    # ... and this second step decodes the two samples one after the other (the round-4 form) where the first one ran them as one
+    # rollout over the batch stacked twice (ops.decoder_rollout_stacked, the default): all 174 gradients of the two forms agree
+    assert m.stack_rollouts
+    m.stack_rollouts = False
     try:
         tr = DataParallelTrainer(m, TrafficModelLoss(TW, m.get_normalizer(), m.get_att_normalizer()), torch.optim.SGD(m.parameters(), lr=0.0))
         res = tr.step(batch.clone(), map_idx, env)
     finally:
         ops.GradSink.segment = seg0
         m.rsample = saved
+        m.stack_rollouts = True
     assert res is not None, tr.last_error
     rel = float((tr.bucket[:-1] - want).norm() / want.norm())
     assert rel < 1e-5, rel
