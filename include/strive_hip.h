@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define STRIVE_ABI_VERSION 15
+#define STRIVE_ABI_VERSION 16
 #define STRIVE_HID 128        /* hidden width of every MLP in the reference (models/common.py, interaction_net.py:32,41) */
 #define STRIVE_MAX_LAYERS 4
 #define STRIVE_ZDIM 32
@@ -467,7 +467,34 @@ int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, const float* 
  * launching stream.  It overwrites the gradient buffer of layer - 1 in `ws` (scratch of the finished call). */
 int strive_map_cnn_bwd_bench_dgrad(int32_t layer, int32_t N, void* ws, size_t ws_bytes, strive_stream_t stream);
 
+/* Kept activations (round 5): the training forward may keep the raw outputs of conv1 .. conv4 and their GroupNorm partial sums of
+ * every crop it encodes (1.74 MB per crop) so that the backward does not run those layers again -- the reference's autograd keeps
+ * ALL activations of map_conv (src/models/traffic_model.py:69-87 under loss.backward()); conv5 / conv6 and the crop are still
+ * recomputed.  strive_map_cnn_fwd_keep = strive_map_cnn_fwd that also writes rows [kept_offset, kept_offset + N) of a kept buffer
+ * sized for kept_total crops (strive_map_cnn_keep_bytes(kept_total)); strive_map_cnn_bwd_kept = strive_map_cnn_bwd over the N =
+ * kept_total crops of such a buffer, in the buffer's row order. */
+size_t strive_map_cnn_keep_bytes(int32_t N);
+int strive_map_cnn_fwd_keep(const StriveMap* map, const StriveCNN* cnn, const float* pos, const float* pos_mean4_host,
+                            const float* pos_std4_host, const int32_t* mapix, int32_t N, float* feat, void* ws, size_t ws_bytes,
+                            void* kept, size_t kept_bytes, int32_t kept_total, int32_t kept_offset, strive_stream_t stream);
+int strive_map_cnn_bwd_kept(const StriveMap* map, const StriveCNN* cnn, const float* pos, const float* pos_mean4_host,
+                            const float* pos_std4_host, const int32_t* mapix, int32_t N, const float* d_feat, float* d_params,
+                            const void* kept, size_t kept_bytes, void* ws, size_t ws_bytes, strive_stream_t stream);
+
 size_t strive_rollout_train_workspace_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT);
+
+/* strive_rollout_fwd keeping the map CNN's activations of its FT - 1 re-encoded steps in `kept` (strive_rollout_keep_bytes), and
+ * strive_rollout_bwd_train reading them instead of recomputing (same results; the tape and `kept` belong to one forward call). */
+size_t strive_rollout_keep_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT);
+int strive_rollout_fwd_keep(const StriveDecoder* dec, const StriveScenes* sc, const float* past_last, const float* lw,
+                            const float* sem, const float* past_feat, const float* map_feat, const float* z, const int32_t* mapix,
+                            const float* ext_future, int32_t FT, float* traj, void* tape, size_t tape_bytes, void* ws,
+                            size_t ws_bytes, void* kept, size_t kept_bytes, strive_stream_t stream);
+int strive_rollout_bwd_train_kept(const StriveDecoder* dec, const StriveScenes* sc, const float* lw, const float* sem,
+                                  const float* z, const float* ext_future, const int32_t* mapix, int32_t FT, const float* d_traj,
+                                  float* dz, float* d_past_feat, float* d_map_feat, float* d_gnn, float* d_gru, float* d_cnn,
+                                  const void* tape, size_t tape_bytes, const void* kept, size_t kept_bytes, void* ws,
+                                  size_t ws_bytes, strive_stream_t stream);
 
 /* autoregressive_decoder under autograd with parameter gradients (reference src/models/traffic_model.py:589-704 as used
  * by forward(), :178-225): like strive_rollout_bwd, plus d_past_feat, d_map_feat (NA,64) -- the adjoints of the encoder

@@ -174,6 +174,14 @@ PROTOTYPES = {
     'strive_rollout_train_workspace_bytes': (SZ, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), I]),
     'strive_rollout_bwd_train': (C.c_int, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), P, P, P, P, P, I, P, P, P, P, P, P, P,
                                            P, SZ, P, SZ, P]),
+    'strive_map_cnn_keep_bytes': (SZ, [I]),
+    'strive_map_cnn_fwd_keep': (C.c_int, [C.POINTER(StriveMap), C.POINTER(StriveCNN), P, F4, F4, P, I, P, P, SZ, P, SZ, I, I, P]),
+    'strive_map_cnn_bwd_kept': (C.c_int, [C.POINTER(StriveMap), C.POINTER(StriveCNN), P, F4, F4, P, I, P, P, P, SZ, P, SZ, P]),
+    'strive_rollout_keep_bytes': (SZ, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), I]),
+    'strive_rollout_fwd_keep': (C.c_int, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), P, P, P, P, P, P, P, P, I,
+                                          P, P, SZ, P, SZ, P, SZ, P]),
+    'strive_rollout_bwd_train_kept': (C.c_int, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), P, P, P, P, P, I, P, P, P, P, P, P,
+                                                P, P, SZ, P, SZ, P, SZ, P]),
     'strive_bicycle_step': (C.c_int, [C.POINTER(StriveDecoder), P, P, P, P, P, P, P, I, P]),
     'strive_rel_pose': (C.c_int, [P, P, P, P, P, P, I, I, P]),
     'strive_planner_workspace_bytes': (SZ, [C.POINTER(StrivePlanner), I, I]),
@@ -182,7 +190,7 @@ PROTOTYPES = {
 }
 
 
-ABI_VERSION = 15   # include/strive_hip.h STRIVE_ABI_VERSION
+ABI_VERSION = 16   # include/strive_hip.h STRIVE_ABI_VERSION
 
 
 class StriveLib(object):

@@ -1371,9 +1371,32 @@ extern "C" size_t strive_map_cnn_workspace_bytes(int32_t N) {
     return bytes;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Activations kept for the training backward (strive_map_cnn_fwd_keep -> strive_map_cnn_bwd_kept): the raw outputs of conv1 .. conv4
+// and their GroupNorm partial sums of EVERY sample of a training forward (1.74 MB per sample: 2.5 GB for the 1408 crops of a
+// 2 x 64-agent rollout of 12 steps -- nothing against 288 GB), so that the backward does not run these four layers again (they were
+// 2.2 of the 28 ms of a training step).  conv5 / conv6 are cheap and still recomputed; the crop (conv1's input for its weight
+// gradient) never exists in HBM in the forward and is gathered again.
+// ---------------------------------------------------------------------------------------------
+struct CnnKeep {
+    float* act[4];
+    GNStats* st[4];
+};
+static inline size_t cnn_keep_bytes(size_t N) {
+    size_t b = 256;
+    for (int l = 0; l < 4; ++l) b += strive_align_up(N * L_OUT[l] * 4, 256) + strive_align_up(N * NPARTS[l] * sizeof(GNStats), 256);
+    return b;
+}
+static inline bool cnn_keep_carve(void* p, size_t bytes, size_t N, CnnKeep& k) {
+    StriveArena ar(p, bytes);
+    for (int l = 0; l < 4; ++l) k.act[l] = ar.take<float>(N * L_OUT[l]);
+    for (int l = 0; l < 4; ++l) k.st[l] = ar.take<GNStats>(N * NPARTS[l]);
+    return ar.ok();
+}
+
 static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos, const float* pmean, const float* pstd,
                    const int32_t* mapix, const uint8_t* crop, int32_t N, float* feat, void* ws, size_t ws_bytes,
-                   hipStream_t stream, bool keep_tail_activations = false) {
+                   hipStream_t stream, bool keep_tail_activations = false, const CnnKeep* keep = nullptr, size_t keep_off = 0) {
     // keep_tail_activations: run conv5, conv6 and the Linear layer as separate kernels that leave their outputs and moments
     // in `ws` (the training backward reads them); otherwise the fused tail kernel (map_cnn_tail.h)
     if (N == 0) return 0;
@@ -1405,6 +1428,14 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         const int n = (N - n0) < ch ? (N - n0) : ch;
         GNStats* st[6];
         stat_slots(stats, (size_t)ch, st);
+        if (keep) {
+            // conv1 .. conv4 write this chunk's rows of the kept arrays instead of the (reused) workspace; the standard chain only:
+            // the kept statistics have NPARTS slots per sample
+            for (int l = 0; l < 4; ++l) {
+                act[l] = keep->act[l] + (keep_off + (size_t)n0) * L_OUT[l];
+                st[l] = keep->st[l] + (keep_off + (size_t)n0) * NPARTS[l];
+            }
+        }
         dim3 g1(l1b::TILES_Y, n <= small_batch ? l1b::TILES_X : 1, n);
         // (above 256 samples: TWO samples per workgroup since round 5 -- 256 workgroups for a 512-sample chunk instead of 128 on 256
         // CUs: refine closure 12.08 -> 12.01 ms, three alternations, profiles/r05_ab_sweep_step.json; bit-identical for every S)
@@ -1423,7 +1454,7 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
             launch_ws<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], n, cnn->xscale[1], cnn->wscale[1], stream);
         else
             launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], n, cnn->xscale[1], cnn->wscale[1], stream);
-        if (!keep_tail_activations && n <= small_batch) {
+        if (!keep_tail_activations && !keep && n <= small_batch) {
             launch_bf6<Bf3s>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
             launch_bf6<Bf4s>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, cnn->xscale[3], cnn->wscale[3], stream);
             launch_cnn_tail(cnn, act[3], st[3], Bf4s::NPART_OUT, feat + (size_t)n0 * 64, n, stream, nullptr, tail_s);
@@ -1450,6 +1481,22 @@ extern "C" int strive_map_cnn_fwd(const StriveMap* map, const StriveCNN* cnn, co
     STRIVE_CHECK_ARG(map && cnn && pos && mapix && feat && ws && pos_mean4_host && pos_std4_host, "null argument");
     STRIVE_CHECK_ARG(map->C == 4 && map->L == 256 && map->Wc == 256, "the HIP map CNN supports the default 4x256x256 crop only");
     return cnn_run(map, cnn, pos, pos_mean4_host, pos_std4_host, mapix, nullptr, N, feat, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t strive_map_cnn_keep_bytes(int32_t N) { return cnn_keep_bytes((size_t)(N > 0 ? N : 0)); }
+
+extern "C" int strive_map_cnn_fwd_keep(const StriveMap* map, const StriveCNN* cnn, const float* pos,
+                                       const float* pos_mean4_host, const float* pos_std4_host, const int32_t* mapix, int32_t N,
+                                       float* feat, void* ws, size_t ws_bytes, void* kept, size_t kept_bytes, int32_t kept_total,
+                                       int32_t kept_offset, strive_stream_t stream) {
+    STRIVE_CHECK_ARG(map && cnn && pos && mapix && feat && ws && pos_mean4_host && pos_std4_host && kept, "null argument");
+    STRIVE_CHECK_ARG(map->C == 4 && map->L == 256 && map->Wc == 256, "the HIP map CNN supports the default 4x256x256 crop only");
+    STRIVE_CHECK_ARG(N >= 0 && kept_offset >= 0 && (int64_t)kept_offset + N <= (int64_t)kept_total, "rows outside the kept arrays");
+    STRIVE_CHECK_ARG(kept_bytes >= cnn_keep_bytes((size_t)kept_total), "kept-activation buffer too small");
+    CnnKeep k;
+    STRIVE_CHECK_ARG(cnn_keep_carve(kept, kept_bytes, (size_t)kept_total, k), "kept-activation arena overflow");
+    return cnn_run(map, cnn, pos, pos_mean4_host, pos_std4_host, mapix, nullptr, N, feat, ws, ws_bytes, (hipStream_t)stream, false, &k,
+                   (size_t)kept_offset);
 }
 
 extern "C" int strive_map_cnn_fwd_from_crop(const StriveCNN* cnn, const uint8_t* crop, int32_t N, float* feat, void* ws,

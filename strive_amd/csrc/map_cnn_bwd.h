@@ -688,9 +688,10 @@ extern "C" int strive_map_cnn_bwd_bench_dgrad(int32_t layer, int32_t N, void* ws
 }
 
 // d_feat (N,64) -> CNN weight gradients at the N poses `pos`, ACCUMULATED into d_params (flat, see strive_hip.h).
-extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, const float* pos, const float* pos_mean4_host,
-                                  const float* pos_std4_host, const int32_t* mapix, int32_t N, const float* d_feat,
-                                  float* d_params, void* ws, size_t ws_bytes, strive_stream_t stream_) {
+// `keep`: the activations of these N samples as strive_map_cnn_fwd_keep left them (conv1 .. conv4 are then not run again).
+static int cnn_backward(const StriveMap* map, const StriveCNN* cnn, const float* pos, const float* pos_mean4_host,
+                        const float* pos_std4_host, const int32_t* mapix, int32_t N, const float* d_feat,
+                        float* d_params, void* ws, size_t ws_bytes, strive_stream_t stream_, const CnnKeep* keep) {
     using namespace cnnbwd;
     STRIVE_CHECK_ARG(map && cnn && pos && mapix && d_feat && d_params && ws && pos_mean4_host && pos_std4_host, "null argument");
     STRIVE_CHECK_ARG(map->C == 4 && map->L == 256 && map->Wc == 256, "the HIP map CNN supports the default 4x256x256 crop only");
@@ -722,9 +723,12 @@ extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, co
     for (int n0 = 0; n0 < N; n0 += ch) {
         const int n = (N - n0) < ch ? (N - n0) : ch;
         // forward recompute of this chunk: raw convolution outputs and GroupNorm partial sums land in fwd_ws
-        int rc = cnn_run(map, cnn, pos + (size_t)n0 * 4, pos_mean4_host, pos_std4_host, mapix + n0, nullptr, n, feat, fwd_ws,
+        int rc = 0;
+        if (!keep) {
+            rc = cnn_run(map, cnn, pos + (size_t)n0 * 4, pos_mean4_host, pos_std4_host, mapix + n0, nullptr, n, feat, fwd_ws,
                          fwd_bytes, stream, /*keep_tail_activations=*/true);
-        if (rc) return rc;
+            if (rc) return rc;
+        }
         rc = strive_map_crop_u8(map, pos + (size_t)n0 * 4, pos_mean4_host, pos_std4_host, mapix + n0, n, crop, stream_);
         if (rc) return rc;
         // the same carve-up cnn_run used for n samples
@@ -734,6 +738,20 @@ extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, co
         GNStats* stats = fa.take<GNStats>((size_t)n * STAT_SLOTS);
         GNStats* st[6];
         stat_slots(stats, (size_t)n, st);
+        if (keep) {
+            // conv1 .. conv4 of these samples are on the kept arrays (the forward ran the standard chain: NPARTS slots per sample);
+            // conv5 and conv6 run again on top of them
+            for (int l = 0; l < 4; ++l) {
+                act[l] = keep->act[l] + (size_t)n0 * L_OUT[l];
+                st[l] = keep->st[l] + (size_t)n0 * NPARTS[l];
+            }
+            rc = launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], n, cnn->xscale[4],
+                                   cnn->wscale[4], stream);
+            if (rc) return rc;
+            rc = launch_bf6s<Bfs6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w6_frag, cnn->b[5], act[5], st[5], n, cnn->xscale[5],
+                                   cnn->wscale[5], stream);
+            if (rc) return rc;
+        }
         {
             MomentsArgs ma;
             for (int l = 0; l < 6; ++l) { ma.st[l] = st[l]; ma.nparts[l] = NPARTS[l]; ma.count[l] = (double)L_OUT[l]; }
@@ -796,4 +814,21 @@ extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, co
     }
     STRIVE_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, const float* pos, const float* pos_mean4_host,
+                                  const float* pos_std4_host, const int32_t* mapix, int32_t N, const float* d_feat,
+                                  float* d_params, void* ws, size_t ws_bytes, strive_stream_t stream_) {
+    return cnn_backward(map, cnn, pos, pos_mean4_host, pos_std4_host, mapix, N, d_feat, d_params, ws, ws_bytes, stream_, nullptr);
+}
+
+extern "C" int strive_map_cnn_bwd_kept(const StriveMap* map, const StriveCNN* cnn, const float* pos, const float* pos_mean4_host,
+                                       const float* pos_std4_host, const int32_t* mapix, int32_t N, const float* d_feat,
+                                       float* d_params, const void* kept, size_t kept_bytes, void* ws, size_t ws_bytes,
+                                       strive_stream_t stream_) {
+    STRIVE_CHECK_ARG(kept, "null argument");
+    STRIVE_CHECK_ARG(N >= 0 && kept_bytes >= cnn_keep_bytes((size_t)N), "kept-activation buffer too small");
+    CnnKeep k;
+    STRIVE_CHECK_ARG(cnn_keep_carve(const_cast<void*>(kept), kept_bytes, (size_t)N, k), "kept-activation arena overflow");
+    return cnn_backward(map, cnn, pos, pos_mean4_host, pos_std4_host, mapix, N, d_feat, d_params, ws, ws_bytes, stream_, &k);
 }

@@ -438,13 +438,23 @@ extern "C" size_t strive_rollout_tape_bytes(const StriveDecoder* dec, const Stri
     return tape_bytes_for((size_t)sc->NA * sc->NS, FT, sc->max_n > 0 ? sc->max_n : 1);
 }
 
-extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* sc, const float* past_last,
-                                  const float* lw, const float* sem, const float* past_feat, const float* map_feat,
-                                  const float* z, const int32_t* mapix, const float* ext_future, int32_t FT, float* traj,
-                                  void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, strive_stream_t stream_) {
+extern "C" size_t strive_rollout_keep_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT) {
+    (void)dec;
+    if (!sc || FT < 2) return strive_map_cnn_keep_bytes(0);
+    return strive_map_cnn_keep_bytes((int32_t)((size_t)(FT - 1) * sc->NA * sc->NS));
+}
+
+// `kept` (optional): the map CNN's activations of the FT - 1 re-encoded steps are kept for strive_rollout_bwd_train_kept
+// (rows (t - 1) R .. t R of the kept arrays = the crops at pos_t, t = 1 .. FT - 1: the order strive_rollout_bwd_train walks them in)
+static int rollout_forward(const StriveDecoder* dec, const StriveScenes* sc, const float* past_last,
+                           const float* lw, const float* sem, const float* past_feat, const float* map_feat,
+                           const float* z, const int32_t* mapix, const float* ext_future, int32_t FT, float* traj,
+                           void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* kept, size_t kept_bytes,
+                           strive_stream_t stream_) {
     STRIVE_CHECK_ARG(dec && sc && past_last && lw && sem && past_feat && map_feat && z && mapix && traj && tape && ws,
                      "null argument");
     if (check_decoder(dec, sc, FT)) return -1;
+    STRIVE_CHECK_ARG(!kept || kept_bytes >= strive_rollout_keep_bytes(dec, sc, FT), "kept-activation buffer too small");
     STRIVE_CHECK_ARG(!(ext_future && sc->NS != 1), "ext_future with multiple samples is not supported");
     const size_t R = (size_t)sc->NA * sc->NS;
     if (R == 0) return 0;
@@ -493,6 +503,15 @@ extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* 
     if (scene_prof) fwd_k = 0;
     hipLaunchKernelGGL(rollout_init_kernel, dim3((unsigned)((R * 64 + 255) / 256)), dim3(256), 0, stream, tp, past_last,
                        past_feat, map_feat, mapix, w.mapix_rows, (int)R, sc->NS);
+    // map feature of step t + 1 at the pose step t produced (reference traffic_model.py:694-695)
+    auto encode_step = [&](int t) -> int {
+        if (kept)
+            return strive_map_cnn_fwd_keep(&dec->map, &dec->cnn, tp.pos_t(t + 1), dec->state_mean, dec->state_std, w.mapix_rows,
+                                           (int32_t)R, tp.mf_t(t + 1), w.cnn_ws, w.cnn_bytes, kept, kept_bytes,
+                                           (int32_t)((size_t)(FT - 1) * R), (int32_t)((size_t)t * R), stream_);
+        return strive_map_cnn_fwd(&dec->map, &dec->cnn, tp.pos_t(t + 1), dec->state_mean, dec->state_std, w.mapix_rows, (int32_t)R,
+                                  tp.mf_t(t + 1), w.cnn_ws, w.cnn_bytes, stream_);
+    };
     for (int t = 0; t < FT; ++t) {
         if (scene) {
             scn::StepArgsS a;
@@ -526,8 +545,7 @@ extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* 
                 launch_scene(7);
             }
             if (t < FT - 1) {
-                int rc = strive_map_cnn_fwd(&dec->map, &dec->cnn, tp.pos_t(t + 1), dec->state_mean, dec->state_std,
-                                            w.mapix_rows, (int32_t)R, tp.mf_t(t + 1), w.cnn_ws, w.cnn_bytes, stream_);
+                int rc = encode_step(t);
                 if (rc) return rc;
             }
             continue;
@@ -549,13 +567,30 @@ extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* 
         a.ptr = sc->ptr; a.scene_of = sc->scene_of; a.traj = traj;
         hipLaunchKernelGGL(rollout_node2_kernel, dim3(nb), dim3(256), node2r_lds_bytes(in_ld2), stream, gd, gr, dp, a, tp);
         if (t < FT - 1) {
-            int rc = strive_map_cnn_fwd(&dec->map, &dec->cnn, tp.pos_t(t + 1), dec->state_mean, dec->state_std,
-                                        w.mapix_rows, (int32_t)R, tp.mf_t(t + 1), w.cnn_ws, w.cnn_bytes, stream_);
+            int rc = encode_step(t);
             if (rc) return rc;
         }
     }
     STRIVE_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int strive_rollout_fwd(const StriveDecoder* dec, const StriveScenes* sc, const float* past_last,
+                                  const float* lw, const float* sem, const float* past_feat, const float* map_feat,
+                                  const float* z, const int32_t* mapix, const float* ext_future, int32_t FT, float* traj,
+                                  void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, strive_stream_t stream_) {
+    return rollout_forward(dec, sc, past_last, lw, sem, past_feat, map_feat, z, mapix, ext_future, FT, traj, tape, tape_bytes, ws,
+                           ws_bytes, nullptr, 0, stream_);
+}
+
+extern "C" int strive_rollout_fwd_keep(const StriveDecoder* dec, const StriveScenes* sc, const float* past_last,
+                                       const float* lw, const float* sem, const float* past_feat, const float* map_feat,
+                                       const float* z, const int32_t* mapix, const float* ext_future, int32_t FT, float* traj,
+                                       void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* kept, size_t kept_bytes,
+                                       strive_stream_t stream_) {
+    STRIVE_CHECK_ARG(kept, "null argument");
+    return rollout_forward(dec, sc, past_last, lw, sem, past_feat, map_feat, z, mapix, ext_future, FT, traj, tape, tape_bytes, ws,
+                           ws_bytes, kept, kept_bytes, stream_);
 }
 
 // =============================================================================================
@@ -808,6 +843,8 @@ struct TrainOut {
     float* d_gru;          // flat decoder_memory gradients, accumulated
     float* d_cnn;          // flat map_conv + map_feature gradients, accumulated
     const int32_t* mapix;  // (NA)
+    const void* kept;      // the forward's map-CNN activations (strive_rollout_fwd_keep) or null: recompute
+    size_t kept_bytes;
     // The adjoints of map_feat_t of ALL steps are kept ((FT, R, 64): step 0 is the encoder's map feature) and the CNN
     // backward runs ONCE over the (FT - 1) R crops after the reverse sweep: the crop is data (pos_t.detach()), so nothing in the
     // sweep waits for it, and one call over 11 x more samples fills the chip where 11 calls of R = 64 samples were latency-bound.
@@ -991,8 +1028,11 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
         // weights; positions (FT, R, 4) and adjoints (FT, R, 64) are contiguous over the steps
         const int total = (int)((FT - 1) * R);
         hipLaunchKernelGGL(tile_mapix_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, tr->mapix, tr->mapix_all, (int)R, total);
-        int rc = strive_map_cnn_bwd(&dec->map, &dec->cnn, tp.pos_t(1), dec->state_mean, dec->state_std, tr->mapix_all, (int32_t)total,
-                                    tr->g_mf_all + R * 64, tr->d_cnn, tr->cnn_ws, tr->cnn_ws_bytes, stream_);
+        int rc = tr->kept ? strive_map_cnn_bwd_kept(&dec->map, &dec->cnn, tp.pos_t(1), dec->state_mean, dec->state_std, tr->mapix_all,
+                                                    (int32_t)total, tr->g_mf_all + R * 64, tr->d_cnn, tr->kept, tr->kept_bytes, tr->cnn_ws,
+                                                    tr->cnn_ws_bytes, stream_)
+                          : strive_map_cnn_bwd(&dec->map, &dec->cnn, tp.pos_t(1), dec->state_mean, dec->state_std, tr->mapix_all,
+                                               (int32_t)total, tr->g_mf_all + R * 64, tr->d_cnn, tr->cnn_ws, tr->cnn_ws_bytes, stream_);
         if (rc) return rc;
     }
     if (tr)
@@ -1079,11 +1119,11 @@ extern "C" size_t strive_rollout_train_workspace_bytes(const StriveDecoder* dec,
 extern "C" size_t strive_gnn_param_count(const StriveGNN* gnn) { return gnn ? gnn_param_count(*gnn) : 0; }
 extern "C" size_t strive_gru_param_count(void) { return gru_param_count(); }
 
-extern "C" int strive_rollout_bwd_train(const StriveDecoder* dec, const StriveScenes* sc, const float* lw, const float* sem,
-                                        const float* z, const float* ext_future, const int32_t* mapix, int32_t FT,
-                                        const float* d_traj, float* dz, float* d_past_feat, float* d_map_feat, float* d_gnn,
-                                        float* d_gru, float* d_cnn, const void* tape, size_t tape_bytes, void* ws,
-                                        size_t ws_bytes, strive_stream_t stream_) {
+static int rollout_backward_train(const StriveDecoder* dec, const StriveScenes* sc, const float* lw, const float* sem,
+                                  const float* z, const float* ext_future, const int32_t* mapix, int32_t FT,
+                                  const float* d_traj, float* dz, float* d_past_feat, float* d_map_feat, float* d_gnn,
+                                  float* d_gru, float* d_cnn, const void* tape, size_t tape_bytes, const void* kept, size_t kept_bytes,
+                                  void* ws, size_t ws_bytes, strive_stream_t stream_) {
     STRIVE_CHECK_ARG(dec && sc && lw && sem && z && mapix && d_traj && dz && d_past_feat && d_map_feat && d_gnn && d_gru && d_cnn &&
                      tape && ws, "null argument");
     if (check_decoder(dec, sc, FT)) return -1;
@@ -1094,9 +1134,11 @@ extern "C" int strive_rollout_bwd_train(const StriveDecoder* dec, const StriveSc
     STRIVE_CHECK_ARG(ws_bytes >= strive_rollout_train_workspace_bytes(dec, sc, FT), "workspace too small");
     STRIVE_CHECK_ARG(sc->max_n >= 1, "max_n not set");
     const size_t base = strive_rollout_workspace_bytes(dec, sc, FT);
+    STRIVE_CHECK_ARG(!kept || kept_bytes >= strive_rollout_keep_bytes(dec, sc, FT), "kept-activation buffer too small");
     TrainOut tr;
     tr.d_past_feat = d_past_feat; tr.d_map_feat = d_map_feat; tr.d_gnn = d_gnn; tr.d_gru = d_gru; tr.d_cnn = d_cnn;
     tr.mapix = mapix;
+    tr.kept = kept; tr.kept_bytes = kept_bytes;
     {
         const size_t steps = FT > 1 ? (size_t)(FT - 1) : 1;
         char* p = (char*)ws + base;
@@ -1116,6 +1158,25 @@ extern "C" int strive_rollout_bwd_train(const StriveDecoder* dec, const StriveSc
     if (rc) return rc;
     STRIVE_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int strive_rollout_bwd_train(const StriveDecoder* dec, const StriveScenes* sc, const float* lw, const float* sem,
+                                        const float* z, const float* ext_future, const int32_t* mapix, int32_t FT,
+                                        const float* d_traj, float* dz, float* d_past_feat, float* d_map_feat, float* d_gnn,
+                                        float* d_gru, float* d_cnn, const void* tape, size_t tape_bytes, void* ws,
+                                        size_t ws_bytes, strive_stream_t stream_) {
+    return rollout_backward_train(dec, sc, lw, sem, z, ext_future, mapix, FT, d_traj, dz, d_past_feat, d_map_feat, d_gnn, d_gru, d_cnn,
+                                  tape, tape_bytes, nullptr, 0, ws, ws_bytes, stream_);
+}
+
+extern "C" int strive_rollout_bwd_train_kept(const StriveDecoder* dec, const StriveScenes* sc, const float* lw, const float* sem,
+                                             const float* z, const float* ext_future, const int32_t* mapix, int32_t FT,
+                                             const float* d_traj, float* dz, float* d_past_feat, float* d_map_feat, float* d_gnn,
+                                             float* d_gru, float* d_cnn, const void* tape, size_t tape_bytes, const void* kept,
+                                             size_t kept_bytes, void* ws, size_t ws_bytes, strive_stream_t stream_) {
+    STRIVE_CHECK_ARG(kept, "null argument");
+    return rollout_backward_train(dec, sc, lw, sem, z, ext_future, mapix, FT, d_traj, dz, d_past_feat, d_map_feat, d_gnn, d_gru, d_cnn,
+                                  tape, tape_bytes, kept, kept_bytes, ws, ws_bytes, stream_);
 }
 
 // =============================================================================================

@@ -468,6 +468,12 @@ def cnn_pack(model):
     return _cached_pack(model, 'cnn', (model.map_conv, model.map_feature), lambda: params.pack_cnn(model.state_dict()))
 
 
+def keep_cnn_activations():
+    """Training forward: keep the map CNN's conv1 .. conv4 outputs for the backward instead of recomputing them there
+    (strive_map_cnn_fwd_keep / strive_rollout_fwd_keep; STRIVE_KEEP_CNN_ACTIVATIONS=0: recompute, the round-4 form)."""
+    return os.environ.get('STRIVE_KEEP_CNN_ACTIVATIONS', '1') != '0'
+
+
 def _cnn_params(model):
     return list(model.map_conv.parameters()) + list(model.map_feature.parameters())
 
@@ -480,8 +486,15 @@ class _CNNFn(torch.autograd.Function):
         feat = torch.empty((h.N, 64), dtype=torch.float32, device=h.p2.device)
         wsb = h.lib.query('strive_map_cnn_workspace_bytes', h.N)
         ws = _workspace(h.p2.device, wsb, 'cnn')
-        h.lib.call('strive_map_cnn_fwd', h.mp.ref(), h.cnn.ref(), L.ptr(h.p2), h.mean4, h.std4, L.ptr(h.mapix), h.N, L.ptr(feat),
-                   L.ptr(ws), ws.numel(), _stream(h.p2))
+        ctx.kept = None
+        if keep_cnn_activations():
+            # conv1 .. conv4's outputs stay for the backward (1.74 MB per crop) instead of being recomputed there
+            ctx.kept = torch.empty(h.lib.query('strive_map_cnn_keep_bytes', h.N), dtype=torch.uint8, device=h.p2.device)
+            h.lib.call('strive_map_cnn_fwd_keep', h.mp.ref(), h.cnn.ref(), L.ptr(h.p2), h.mean4, h.std4, L.ptr(h.mapix), h.N, L.ptr(feat),
+                       L.ptr(ws), ws.numel(), L.ptr(ctx.kept), ctx.kept.numel(), h.N, 0, _stream(h.p2))
+        else:
+            h.lib.call('strive_map_cnn_fwd', h.mp.ref(), h.cnn.ref(), L.ptr(h.p2), h.mean4, h.std4, L.ptr(h.mapix), h.N, L.ptr(feat),
+                       L.ptr(ws), ws.numel(), _stream(h.p2))
         ctx.h, ctx.ps = h, ps
         return feat
 
@@ -492,8 +505,13 @@ class _CNNFn(torch.autograd.Function):
         dp, give_back = _grad_target(ctx.ps, h.lib.query('strive_map_cnn_param_count'), dev)
         wsb = h.lib.query('strive_map_cnn_bwd_workspace_bytes', h.N)
         ws = _workspace(dev, wsb, 'cnn_bwd')
-        h.lib.call('strive_map_cnn_bwd', h.mp.ref(), h.cnn.ref(), L.ptr(h.p2), h.mean4, h.std4, L.ptr(h.mapix), h.N,
-                   L.ptr(_f32c(d_feat)), L.ptr(dp), L.ptr(ws), ws.numel(), _stream(h.p2))
+        if ctx.kept is not None:
+            h.lib.call('strive_map_cnn_bwd_kept', h.mp.ref(), h.cnn.ref(), L.ptr(h.p2), h.mean4, h.std4, L.ptr(h.mapix), h.N,
+                       L.ptr(_f32c(d_feat)), L.ptr(dp), L.ptr(ctx.kept), ctx.kept.numel(), L.ptr(ws), ws.numel(), _stream(h.p2))
+            ctx.kept = None
+        else:
+            h.lib.call('strive_map_cnn_bwd', h.mp.ref(), h.cnn.ref(), L.ptr(h.p2), h.mean4, h.std4, L.ptr(h.mapix), h.N,
+                       L.ptr(_f32c(d_feat)), L.ptr(dp), L.ptr(ws), ws.numel(), _stream(h.p2))
         return (None,) + _grad_return(dp, ctx.ps, give_back)
 
 
@@ -718,9 +736,16 @@ class _RolloutTrainFn(torch.autograd.Function):
         traj = torch.empty((h.R, h.FT, 4), dtype=torch.float32, device=dev)
         tape = torch.empty(h.tape_bytes, dtype=torch.uint8, device=dev)
         ws = _workspace(dev, h.ws_bytes, 'rollout')
-        lib.call('strive_rollout_fwd', h.dec.ref(), h.sc.ref(), L.ptr(h.past_last), L.ptr(h.lw), L.ptr(h.sem), L.ptr(pf), L.ptr(mf),
-                 L.ptr(zz), L.ptr(h.mapix), L.ptr(h.ext), h.FT, L.ptr(traj), L.ptr(tape), tape.numel(), L.ptr(ws), ws.numel(),
-                 _stream(z))
+        ctx.kept = None
+        if keep_cnn_activations() and h.FT > 1:
+            ctx.kept = torch.empty(lib.query('strive_rollout_keep_bytes', h.dec.ref(), h.sc.ref(), h.FT), dtype=torch.uint8, device=dev)
+            lib.call('strive_rollout_fwd_keep', h.dec.ref(), h.sc.ref(), L.ptr(h.past_last), L.ptr(h.lw), L.ptr(h.sem), L.ptr(pf),
+                     L.ptr(mf), L.ptr(zz), L.ptr(h.mapix), L.ptr(h.ext), h.FT, L.ptr(traj), L.ptr(tape), tape.numel(), L.ptr(ws),
+                     ws.numel(), L.ptr(ctx.kept), ctx.kept.numel(), _stream(z))
+        else:
+            lib.call('strive_rollout_fwd', h.dec.ref(), h.sc.ref(), L.ptr(h.past_last), L.ptr(h.lw), L.ptr(h.sem), L.ptr(pf), L.ptr(mf),
+                     L.ptr(zz), L.ptr(h.mapix), L.ptr(h.ext), h.FT, L.ptr(traj), L.ptr(tape), tape.numel(), L.ptr(ws), ws.numel(),
+                     _stream(z))
         ctx.h, ctx.tape, ctx.zz, ctx.zshape, ctx.ps = h, tape, zz, z.shape, ps
         return traj
 
@@ -747,9 +772,16 @@ class _RolloutTrainFn(torch.autograd.Function):
         targets = [_grad_target(sub, c, dev) for sub, c in zip(blocks, counts)]
         wsb = lib.query('strive_rollout_train_workspace_bytes', h.dec.ref(), h.sc.ref(), h.FT)
         ws = _workspace(dev, wsb, 'rollout_train')
-        lib.call('strive_rollout_bwd_train', h.dec.ref(), h.sc.ref(), L.ptr(h.lw), L.ptr(h.sem), L.ptr(ctx.zz), L.ptr(h.ext),
-                 L.ptr(h.mapix), h.FT, L.ptr(_f32c(d_traj)), L.ptr(dz), L.ptr(dpf), L.ptr(dmf), L.ptr(targets[0][0]), L.ptr(targets[1][0]),
-                 L.ptr(targets[2][0]), L.ptr(ctx.tape), ctx.tape.numel(), L.ptr(ws), ws.numel(), _stream(d_traj))
+        if ctx.kept is not None:
+            lib.call('strive_rollout_bwd_train_kept', h.dec.ref(), h.sc.ref(), L.ptr(h.lw), L.ptr(h.sem), L.ptr(ctx.zz), L.ptr(h.ext),
+                     L.ptr(h.mapix), h.FT, L.ptr(_f32c(d_traj)), L.ptr(dz), L.ptr(dpf), L.ptr(dmf), L.ptr(targets[0][0]),
+                     L.ptr(targets[1][0]), L.ptr(targets[2][0]), L.ptr(ctx.tape), ctx.tape.numel(), L.ptr(ctx.kept), ctx.kept.numel(),
+                     L.ptr(ws), ws.numel(), _stream(d_traj))
+            ctx.kept = None
+        else:
+            lib.call('strive_rollout_bwd_train', h.dec.ref(), h.sc.ref(), L.ptr(h.lw), L.ptr(h.sem), L.ptr(ctx.zz), L.ptr(h.ext),
+                     L.ptr(h.mapix), h.FT, L.ptr(_f32c(d_traj)), L.ptr(dz), L.ptr(dpf), L.ptr(dmf), L.ptr(targets[0][0]),
+                     L.ptr(targets[1][0]), L.ptr(targets[2][0]), L.ptr(ctx.tape), ctx.tape.numel(), L.ptr(ws), ws.numel(), _stream(d_traj))
         grads = ()
         for (flat, give_back), sub in zip(targets, blocks):
             grads += _grad_return(flat, sub, give_back)

@@ -25,7 +25,7 @@ def test_hip_library_builds_loads_and_exports_everything():
     assert os.path.exists(path)
     lib = L.StriveLib(path)            # raises if any symbol is missing
     assert lib.missing == []
-    assert lib.query("strive_abi_version") == L.ABI_VERSION == 15
+    assert lib.query("strive_abi_version") == L.ABI_VERSION == 16
 
 
 def test_every_entry_point_cites_the_reference():

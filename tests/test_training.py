@@ -341,6 +341,7 @@ def test_map_cnn_backward_chunks_add_up():
             feat = ops.encode_map(m, pos[lo:hi].contiguous(), torch.arange(hi - lo).to(DEV), mi[lo:hi].contiguous(), env)
             feat.backward(d_feat[lo:hi].contiguous())
         return {k: p.grad.detach().clone() for k, p in m.named_parameters() if k in names}
+    assert ops.keep_cnn_activations()           # (the default: conv1 .. conv4's outputs kept by the forward, not recomputed)
     whole, a, b = grads(0, n), grads(0, 256), grads(256, n)
     worst = 0.0
     for k in names:
@@ -349,6 +350,20 @@ def test_map_cnn_backward_chunks_add_up():
         worst = max(worst, rel)
         assert rel < 2e-5, 'map CNN gradient %s: chunked call differs from the sum of its parts by %.3g' % (k, rel)
     print('worst relative difference: %.3g' % worst)
+    # the same call with the forward recomputed inside the backward (STRIVE_KEEP_CNN_ACTIVATIONS=0, the round-4 form): the kept
+    # activations are the very numbers the recompute produces, only the order of the atomic additions differs
+    os.environ['STRIVE_KEEP_CNN_ACTIVATIONS'] = '0'
+    try:
+        assert not ops.keep_cnn_activations()
+        rec = grads(0, n)
+    finally:
+        del os.environ['STRIVE_KEEP_CNN_ACTIVATIONS']
+    worst = 0.0
+    for k in names:
+        rel = float((whole[k] - rec[k]).norm() / max(float(rec[k].norm()), 1e-30))
+        worst = max(worst, rel)
+        assert rel < 1e-5, 'map CNN gradient %s: kept activations vs recomputed forward differ by %.3g' % (k, rel)
+    print('kept vs recomputed: worst relative difference %.3g' % worst)
 
 
 
