@@ -423,7 +423,12 @@ def train_step_factory(m, env, batch, map_idx, FT, device):
     g = batch.to(device)
     mi = map_idx.to(device)
     m.train()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-5)
+    # (torch's default multi-tensor Adam like the reference's optim.Adam, train_traffic.py:92-95.  Adam(fused=True) was measured no
+    #  faster here -- 21.3 vs 21.4 ms per step, profiles/r05_ab_train_small_kernels.json -- and does not bump the parameters' version
+    #  counters; DataParallelTrainer.step announces every update to the pack caches itself: params.parameters_changed().
+    #  STRIVE_BENCH_ADAM_FUSED=1 selects it.)
+    fused = torch.device(device).type == 'cuda' and os.environ.get('STRIVE_BENCH_ADAM_FUSED', '0') == '1'
+    opt = torch.optim.Adam(m.parameters(), lr=1e-5, **({'fused': True} if fused else {}))
     tr = DataParallelTrainer(m, TrafficModelLoss(TRAIN_WEIGHTS, m.get_normalizer(), m.get_att_normalizer()), opt)
 
     def step():

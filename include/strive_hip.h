@@ -110,8 +110,8 @@ typedef struct StriveMap {
 /* Map CNN: 6 x [Conv2d(stride 2, pad 0) -> GroupNorm(1 group) -> ReLU] + Linear(512, 64), default
  * architecture only (kernels 7,5,5,3,3,3; channels 4->16->32->64->64->128->128; 256x256 input);
  * reference src/models/traffic_model.py:69-87, 437-440.
- * w[l]: fp32 weights as [ci/2][ky][kx][ci&1][co] (l = 0: [ky][kx][ci][co]) -- not read by the kernels any more (all six
- * convolutions take the fp16 fragment tables w1_frag .. w6_frag below); kept so that the struct layout stays put;
+ * w[l]: not read by the kernels any more (all six convolutions take the fp16 fragment tables w1_frag .. w6_frag below; the
+ * host side points it at w_torch[l]); kept so that the struct layout stays put;
  * fc_wt: (512, 64) transposed Linear weight. */
 typedef struct StriveCNN {
     const float* w[6];
@@ -445,6 +445,12 @@ int strive_mlp_bwd(const StriveMLP* mlp, const float* x, const float* dy, int32_
  * (M+15)/16 * (K+31)/32 * 2 KiB and (K+15)/16 * (M+31)/32 * 2 KiB).  Any output may be NULL.  One launch: the training step
  * re-packs every layer after each optimiser step. */
 int strive_pack_dense(const float* w, int32_t M, int32_t K, float scale, float* wt, void* wf, void* wbf, strive_stream_t stream);
+
+/* Any two-piece fp16 fragment table of a weight tensor in one launch: out[i] (n_out x fp16) = piece idx[i] / n_w of the split of
+ * w[idx[i] % n_w] * scale, or 0 where idx[i] == 2 n_w.  The index table IS the operand layout (the convolution layouts of
+ * StriveCNN.w1_frag .. w6_frag); the training step re-packs the six convolutions after each optimiser step. */
+int strive_pack_split_gather(const float* w, int32_t n_w, const int32_t* idx, int32_t n_out, float scale, void* out,
+                             strive_stream_t stream);
 
 size_t strive_gnn_bwd_workspace_bytes(const StriveGNN* gnn, const StriveScenes* sc);
 

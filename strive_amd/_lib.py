@@ -167,6 +167,7 @@ PROTOTYPES = {
     'strive_mlp_bwd': (C.c_int, [C.POINTER(StriveMLP), P, P, I, P, P, P]),
     'strive_gnn_bwd_workspace_bytes': (SZ, [C.POINTER(StriveGNN), C.POINTER(StriveScenes)]),
     'strive_pack_dense': (C.c_int, [P, C.c_int32, C.c_int32, C.c_float, P, P, P, P]),
+    'strive_pack_split_gather': (C.c_int, [P, I, P, I, C.c_float, P, P]),
     'strive_gnn_bwd': (C.c_int, [C.POINTER(StriveGNN), C.POINTER(StriveScenes), P, P, P, P, P, P, P, SZ, P]),
     'strive_map_cnn_bwd_workspace_bytes': (SZ, [I]),
     'strive_map_cnn_bwd': (C.c_int, [C.POINTER(StriveMap), C.POINTER(StriveCNN), P, F4, F4, P, I, P, P, P, SZ, P]),

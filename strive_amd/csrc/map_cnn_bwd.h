@@ -59,18 +59,22 @@ static __global__ void moments_kernel(MomentsArgs a, float2* __restrict__ mr, in
 }
 
 // ---- Linear(512, 64) + GroupNorm6/ReLU input: G5 <- d a6 = W^T d feat;  dW += d feat^T a6;  db += sum d feat ----
-// grid = ceil(N / 8); 8 samples per workgroup so that every weight-gradient atomic carries 8 samples
+// grid = (ceil(N / FCB_S), 512 / FCB_K): a workgroup takes FCB_S samples x FCB_K of the 512 input columns -- every weight-gradient
+// atomic carries 32 samples, the weight slice sits in LDS.  (Round 5: the first form gave a workgroup 8 samples and ALL columns:
+// 32 workgroups per 256-sample chunk with 128 serial atomics per thread, 75 us per chunk.)
+constexpr int FCB_S = 32, FCB_K = 64;
 static __global__ __launch_bounds__(256) void fc_bwd_kernel(const float* __restrict__ y6, const float2* __restrict__ mr,
                                                               const float* __restrict__ gn_g, const float* __restrict__ gn_b,
                                                               const float* __restrict__ wt /* (512,64) */, const float* __restrict__ d_feat,
                                                               float* __restrict__ G5, float* __restrict__ dW /* (64,512) */,
                                                               float* __restrict__ db, int N) {
-    __shared__ float s_a[8][512];
-    __shared__ float s_d[8][64];
-    const int n0 = blockIdx.x * 8, tid = threadIdx.x;
-    const int ns = (N - n0) < 8 ? (N - n0) : 8;
-    for (int i = tid; i < 8 * 512; i += 256) {
-        const int s = i >> 9, k = i & 511;
+    __shared__ float s_a[FCB_S][FCB_K + 1];
+    __shared__ float s_d[FCB_S][64 + 1];
+    __shared__ float s_w[FCB_K][64 + 1];
+    const int n0 = blockIdx.x * FCB_S, k0 = blockIdx.y * FCB_K, tid = threadIdx.x;
+    const int ns = (N - n0) < FCB_S ? (N - n0) : FCB_S;
+    for (int i = tid; i < FCB_S * FCB_K; i += 256) {
+        const int s = i / FCB_K, kk = i - s * FCB_K, k = k0 + kk;
         float v = 0.f;
         if (s < ns) {
             const int c = k >> 2;
@@ -78,30 +82,35 @@ static __global__ __launch_bounds__(256) void fc_bwd_kernel(const float* __restr
             const float xh = (y6[(size_t)(n0 + s) * 512 + k] - m.x) * m.y;
             v = fmaxf(xh * gn_g[c] + gn_b[c], 0.f);
         }
-        s_a[s][k] = v;
+        s_a[s][kk] = v;
     }
-    for (int i = tid; i < 8 * 64; i += 256) {
+    for (int i = tid; i < FCB_S * 64; i += 256) {
         const int s = i >> 6, o = i & 63;
         s_d[s][o] = s < ns ? d_feat[(size_t)(n0 + s) * 64 + o] : 0.f;
     }
+    for (int i = tid; i < FCB_K * 64; i += 256) {
+        const int kk = i >> 6, o = i & 63;
+        s_w[kk][o] = wt[(size_t)(k0 + kk) * 64 + o];
+    }
     __syncthreads();
     // data gradient (w.r.t. the post-ReLU activation a6; the ReLU / GroupNorm part follows in the layer-5 GN backward)
-    for (int i = tid; i < 8 * 512; i += 256) {
-        const int s = i >> 9, k = i & 511;
+    for (int i = tid; i < FCB_S * FCB_K; i += 256) {
+        const int s = i / FCB_K, kk = i - s * FCB_K;
         if (s < ns) {
             float acc = 0.f;
-            for (int o = 0; o < 64; ++o) acc = fmaf(s_d[s][o], wt[(size_t)k * 64 + o], acc);
-            G5[(size_t)(n0 + s) * 512 + k] = acc;
+#pragma unroll 8
+            for (int o = 0; o < 64; ++o) acc = fmaf(s_d[s][o], s_w[kk][o], acc);
+            G5[(size_t)(n0 + s) * 512 + k0 + kk] = acc;
         }
     }
     // weight gradient: lanes over k (consecutive addresses of one output row)
-    for (int i = tid; i < 64 * 512; i += 256) {
-        const int o = i >> 9, k = i & 511;
+    for (int i = tid; i < 64 * FCB_K; i += 256) {
+        const int o = i / FCB_K, kk = i - o * FCB_K;
         float acc = 0.f;
-        for (int s = 0; s < ns; ++s) acc = fmaf(s_d[s][o], s_a[s][k], acc);
-        if (acc != 0.f) unsafeAtomicAdd(&dW[i], acc);
+        for (int s = 0; s < ns; ++s) acc = fmaf(s_d[s][o], s_a[s][kk], acc);
+        if (acc != 0.f) unsafeAtomicAdd(&dW[(size_t)o * 512 + k0 + kk], acc);
     }
-    if (tid < 64) {
+    if (blockIdx.y == 0 && tid < 64) {
         float acc = 0.f;
         for (int s = 0; s < ns; ++s) acc += s_d[s][tid];
         if (acc != 0.f) unsafeAtomicAdd(&db[tid], acc);
@@ -188,7 +197,7 @@ constexpr int GN_PPB = 2048;
 
 static __global__ __launch_bounds__(256) void gn_bwd_reduce_oct_kernel(int C, int HW, const float* __restrict__ y,
                                                                         const float2* __restrict__ mr, const float* __restrict__ gam,
-                                                                        const float* __restrict__ bet, float* __restrict__ G,
+                                                                        const float* __restrict__ bet, const float* __restrict__ G,
                                                                         double* __restrict__ S, float* __restrict__ dgam,
                                                                         float* __restrict__ dbet) {
     __shared__ float s_c[16];
@@ -206,7 +215,7 @@ static __global__ __launch_bounds__(256) void gn_bwd_reduce_oct_kernel(int C, in
     for (int c = 0; c < 8; ++c) { ga[c] = gam[oct * 8 + c]; be[c] = bet[oct * 8 + c]; dg[c] = 0.f; db[c] = 0.f; }
     double s1 = 0.0, s2 = 0.0;
     const float* yb = y + ((size_t)n * (C >> 3) + oct) * HW * 8;
-    float* gb = G + ((size_t)n * C + oct * 8) * HW;
+    const float* gb = G + ((size_t)n * C + oct * 8) * HW;
     for (int p = pb * GN_PPB + tid; p < p1; p += 256) {
         const float4 y0 = *reinterpret_cast<const float4*>(yb + (size_t)p * 8), y1 = *reinterpret_cast<const float4*>(yb + (size_t)p * 8 + 4);
         const float yy[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
@@ -215,10 +224,7 @@ static __global__ __launch_bounds__(256) void gn_bwd_reduce_oct_kernel(int C, in
         for (int c = 0; c < 8; ++c) {
             const float xh = (yy[c] - m.x) * m.y;
             const float pre = xh * ga[c] + be[c];
-            float* gp = gb + (size_t)c * HW + p;
-            const float g = *gp;
-            const float dn = pre > 0.f ? g : 0.f;
-            if (dn != g) *gp = dn;
+            const float dn = pre > 0.f ? gb[(size_t)c * HW + p] : 0.f;      // (read only: the apply pass masks again, see there)
             const float w = dn * ga[c];
             f1 += w;
             f2 = fmaf(w, xh, f2);
@@ -247,10 +253,12 @@ static __global__ __launch_bounds__(256) void gn_bwd_reduce_oct_kernel(int C, in
     else if (tid < 16) { if (s_c[tid] != 0.f) unsafeAtomicAdd(&dbet[oct * 8 + tid - 8], s_c[tid]); }
 }
 
+// (Round 5: the reduce pass used to store the ReLU-masked gradient back into G -- a scattered partial-line write of about half the
+//  elements; this pass reads y anyway and masks again with the same comparison, so the reduce pass is read-only now.)
 static __global__ __launch_bounds__(256) void gn_bwd_apply_oct_kernel(int C, int HW, const float* __restrict__ y,
                                                                        const float2* __restrict__ mr, const float* __restrict__ gam,
-                                                                       float* __restrict__ G, const double* __restrict__ S,
-                                                                       float* __restrict__ dbias) {
+                                                                       const float* __restrict__ bet, float* __restrict__ G,
+                                                                       const double* __restrict__ S, float* __restrict__ dbias) {
     __shared__ float s_c[8];
     const int n = blockIdx.y, tid = threadIdx.x;
     const int npb = (HW + GN_PPB - 1) / GN_PPB;
@@ -261,9 +269,9 @@ static __global__ __launch_bounds__(256) void gn_bwd_apply_oct_kernel(int C, int
     const float2 m = mr[n];
     const double M = (double)C * HW;
     const float a1 = (float)(S[2 * n + 0] / M), a2 = (float)(S[2 * n + 1] / M);
-    float ga[8], db[8];
+    float ga[8], be[8], db[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { ga[c] = gam[oct * 8 + c]; db[c] = 0.f; }
+    for (int c = 0; c < 8; ++c) { ga[c] = gam[oct * 8 + c]; be[c] = bet[oct * 8 + c]; db[c] = 0.f; }
     const float* yb = y + ((size_t)n * (C >> 3) + oct) * HW * 8;
     float* gb = G + ((size_t)n * C + oct * 8) * HW;
     for (int p = pb * GN_PPB + tid; p < p1; p += 256) {
@@ -273,7 +281,9 @@ static __global__ __launch_bounds__(256) void gn_bwd_apply_oct_kernel(int C, int
         for (int c = 0; c < 8; ++c) {
             const float xh = (yy[c] - m.x) * m.y;
             float* gp = gb + (size_t)c * HW + p;
-            const float dyv = m.y * (*gp * ga[c] - a1 - xh * a2);
+            const float pre = xh * ga[c] + be[c];                  // (the reduce pass's expression: the same mask)
+            const float dn = pre > 0.f ? *gp : 0.f;
+            const float dyv = m.y * (dn * ga[c] - a1 - xh * a2);
             *gp = dyv;
             db[c] += dyv;
         }
@@ -758,7 +768,7 @@ static int cnn_backward(const StriveMap* map, const StriveCNN* cnn, const float*
             hipLaunchKernelGGL(moments_kernel, dim3((n + 63) / 64, 6), dim3(64), 0, stream, ma, mr, ch, n);
         }
         hipMemsetAsync(S, 0, (size_t)6 * ch * 2 * sizeof(double), stream);      // GroupNorm-backward sums of all six layers
-        hipLaunchKernelGGL(fc_bwd_kernel, dim3((n + 7) / 8), dim3(256), 0, stream, act[5], mr + (size_t)5 * ch, cnn->gn_g[5],
+        hipLaunchKernelGGL(fc_bwd_kernel, dim3((n + FCB_S - 1) / FCB_S, 512 / FCB_K), dim3(256), 0, stream, act[5], mr + (size_t)5 * ch, cnn->gn_g[5],
                            cnn->gn_b[5], cnn->fc_wt, d_feat + (size_t)n0 * 64, G[5], gp.fcw, gp.fcb, n);
         for (int l = 5; l >= 0; --l) {
             const LayerDesc d = layer_desc(l);
@@ -772,7 +782,7 @@ static int cnn_backward(const StriveMap* map, const StriveCNN* cnn, const float*
                 hipLaunchKernelGGL(gn_bwd_reduce_oct_kernel, grid, dim3(256), 0, stream, d.cout, HW, act[l], mr + (size_t)l * ch,
                                    cnn->gn_g[l], cnn->gn_b[l], G[l], Sl, gp.g[l], gp.be[l]);
                 hipLaunchKernelGGL(gn_bwd_apply_oct_kernel, grid, dim3(256), 0, stream, d.cout, HW, act[l], mr + (size_t)l * ch,
-                                   cnn->gn_g[l], G[l], Sl, gp.b[l]);
+                                   cnn->gn_g[l], cnn->gn_b[l], G[l], Sl, gp.b[l]);
             } else {
                 hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nblk, n), dim3(256), 0, stream, d, act[l], mr + (size_t)l * ch, cnn->gn_g[l],
                                    cnn->gn_b[l], G[l], Sl, gp.g[l], gp.be[l]);

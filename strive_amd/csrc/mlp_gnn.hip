@@ -255,6 +255,34 @@ static __global__ __launch_bounds__(256) void pack_dense_kernel(const float* __r
     }
 }
 
+// Any fragment table as ONE gather: out[i] = piece p of fp16-split(w[e] * scale) with (p, e) = (idx[i] / n_w, idx[i] % n_w), or 0
+// where idx[i] == 2 n_w (the layout's zero slot).  The index table is the layout (params.py builds it once per shape).
+static __global__ __launch_bounds__(256) void pack_split_gather_kernel(const float* __restrict__ w, int n_w, const int32_t* __restrict__ idx,
+                                                                         int n_out, float scale, uint16_t* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out) return;
+    const int src = idx[i];
+    uint16_t bits = 0;
+    if (src >= 0 && src < 2 * n_w) {
+        const int piece = src >= n_w ? 1 : 0;
+        const float v = w[src - piece * n_w] * scale;
+        const _Float16 a = (_Float16)v;
+        const _Float16 c = piece ? (_Float16)(v - (float)a) : a;
+        __builtin_memcpy(&bits, &c, 2);
+    }
+    out[i] = bits;
+}
+
+extern "C" int strive_pack_split_gather(const float* w, int32_t n_w, const int32_t* idx, int32_t n_out, float scale, void* out,
+                                        strive_stream_t stream) {
+    STRIVE_CHECK_ARG(w && idx && out && n_w > 0 && n_out >= 0 && n_w < (1 << 30), "bad argument");
+    if (n_out == 0) return 0;
+    hipLaunchKernelGGL(pack_split_gather_kernel, dim3((n_out + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (int)n_w, idx, (int)n_out,
+                       scale, (uint16_t*)out);
+    STRIVE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int strive_pack_dense(const float* w, int32_t M, int32_t K, float scale, float* wt, void* wf, void* wbf,
                                  strive_stream_t stream) {
     STRIVE_CHECK_ARG(w && M > 0 && K > 0, "bad argument");

@@ -204,6 +204,8 @@ class DataParallelTrainer(object):
         if any_failed:
             return None                    # this rank or another one failed: nobody steps
         self.optimizer.step()
+        # (fused optimisers update the parameters without bumping their version counters, which the pack caches key on)
+        params.parameters_changed()
         out = dict(loss_dict)
         out['global_loss'] = self._all_reduce(share.detach().clone().reshape(1))
         return out

@@ -82,12 +82,13 @@ def _workspace(device, nbytes, tag='ws'):
 
 
 def _param_signature(*modules):
-    return tuple((p.data_ptr(), p._version) for m in modules for p in m.parameters())
+    return (params.param_epoch(),) + tuple((p.data_ptr(), p._version) for m in modules for p in m.parameters())
 
 
 def _cached_pack(owner, key, module_for_sig, builder, extra_sig=()):
-    """Re-pack only when a parameter changed (in-place updates bump ``_version``) or moved, or when ``extra_sig``
-    (plain values the pack also depends on) changed.  ``module_for_sig`` is a module or a tuple of modules."""
+    """Re-pack only when a parameter changed (in-place updates bump ``_version``; updates that do not -- fused optimisers,
+    ``p.data`` -- are announced with params.parameters_changed()) or moved, or when ``extra_sig`` (plain values the pack also
+    depends on) changed.  ``module_for_sig`` is a module or a tuple of modules."""
     cache = owner.__dict__.setdefault('_strive_packs', {})
     mods = module_for_sig if isinstance(module_for_sig, (tuple, list)) else (module_for_sig,)
     sig = (_param_signature(*mods), extra_sig)
@@ -562,11 +563,24 @@ def encode_map_crop(model, crop):
     return feat
 
 
+def _rel_pose_data(frame, poses):
+    """transform2frame(frame (N,4), poses (N,M,4)) for DATA (no gradient: the encoders' inputs are detached, reference
+    src/models/traffic_model.py:453-523) as one strive_rel_pose launch instead of ~16 elementwise ones; plain torch where
+    a gradient is asked for."""
+    if frame.requires_grad or poses.requires_grad:
+        return transform2frame(frame, poses)
+    lib = _lib_for(frame, poses)
+    fr, po = _f32c(frame), _f32c(poses)
+    out = torch.empty_like(po)
+    lib.call('strive_rel_pose', L.ptr(fr), L.ptr(po), None, L.ptr(out), None, None, po.shape[0], po.shape[1], _stream(po))
+    return out
+
+
 def encode_traj(model, encoder, g, traj, vis):
     """Past / future trajectory encoder input assembly (torch glue) + HIP MLP.
     (reference src/models/traffic_model.py:453-523)"""
     NA, T, _ = traj.shape
-    local = transform2frame(g.past[:, -1, :4], traj[:, :, :4])
+    local = _rel_pose_data(g.past[:, -1, :4], traj[:, :, :4])
     local = torch.cat([local, traj[:, :, 4:]], dim=2)
     local = torch.where((vis == 0.0).unsqueeze(-1), torch.zeros_like(local), local)
     local = torch.cat([local, vis.unsqueeze(-1)], dim=-1)

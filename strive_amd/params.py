@@ -38,8 +38,25 @@ _ABSMAX = {}          # key -> (value, tensor): the tensor reference keeps its s
                       # another tensor while its entry exists (temporaries of non-fp32 parameters would otherwise alias)
 
 
+# Parameter epoch.  The weight packs and max |w| bounds are cached per (address, in-place version) of a parameter -- but not every
+# update bumps the version counter: torch's FUSED optimisers (Adam(fused=True): torch._fused_adam_) write the parameters without
+# touching it, and so does anything that goes through ``p.data``.  ``parameters_changed()`` starts a new epoch: every cached pack
+# and bound is rebuilt at its next use.  DataParallelTrainer.step calls it after every optimiser step; a training loop of your own
+# must do the same if its optimiser is one of those.
+_PARAM_EPOCH = [0]
+
+
+def parameters_changed():
+    _PARAM_EPOCH[0] += 1
+    return _PARAM_EPOCH[0]
+
+
+def param_epoch():
+    return _PARAM_EPOCH[0]
+
+
 def _absmax_key(t):
-    return (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+    return (t.data_ptr(), t._version, tuple(t.shape), str(t.device), _PARAM_EPOCH[0])
 
 
 class lagged_absmax(object):
@@ -154,6 +171,26 @@ def absmax(t):
 # ---- operand layouts as ONE gather: the layout code below runs once per shape on an index tensor (slot -> element of the
 # flattened two-piece split, or the appended zero), and every later pack is cat + index_select ----
 _LAYOUT = {}
+
+
+def _split_gather(w, scale, key, build_index, what):
+    """_layout_gather(_f16_split2(w, scale), key, build_index) -- as one launch (strive_pack_split_gather) when the library serves
+    ``w``'s device: the cached index table is the layout, the split happens in the kernel (same bytes)."""
+    lib = _pack_lib(w)
+    if lib is None or os.environ.get('STRIVE_CHECK_PACKS') == '1':
+        return _layout_gather(_f16_split2(w, scale, what), key, build_index)
+    w = w.to(torch.float32).contiguous()
+    shape = (2,) + tuple(w.shape)
+    ck = (key, shape, str(w.device), 'i32')
+    idx = _LAYOUT.get(ck)
+    if idx is None:
+        n = 2 * w.numel()
+        pidx = torch.arange(n, dtype=torch.int64).view(shape)
+        idx = build_index(pidx, n).reshape(-1).to(torch.int32).to(w.device)
+        _LAYOUT[ck] = idx
+    out = torch.empty((idx.numel(),), dtype=torch.float16, device=w.device)
+    lib.call('strive_pack_split_gather', L.ptr(w), w.numel(), L.ptr(idx), idx.numel(), float(scale), L.ptr(out), L.stream_ptr(w))
+    return out
 
 
 def _layout_gather(pieces, key, build_index):
@@ -335,7 +372,8 @@ def _f16_split2(w, scale, what):
     comes from _pow2_scale(_checked_absmax(w)): max |w| scale <= 32768, so both pieces are finite.
     CONTRACT: max |w| is cached per (address, in-place version) of the parameter (_ABSMAX).  Parameters must therefore only be
     modified through operations that bump the version counter (optimiser steps, ``p.copy_()``, ``p.mul_()`` ...); an edit through
-    ``p.data`` or an external alias leaves a stale bound, and a weight that grew past 2 x the bound would overflow its fp16 pieces
+    ``p.data``, an external alias or a FUSED optimiser (torch._fused_adam_ does not bump it) must be followed by
+    ``parameters_changed()`` (DataParallelTrainer.step does that) -- otherwise it leaves a stale bound, and a weight that grew past 2 x the bound would overflow its fp16 pieces
     to inf without an error.  STRIVE_CHECK_PACKS=1 verifies every packed piece on the device (one synchronisation per pack)."""
     ws = w.to(torch.float32) * scale
     w0 = ws.to(torch.float16)
@@ -349,13 +387,11 @@ def _conv1_fragments(w, scale):
     """(16,4,7,7) fp32 -> int32 tensor holding [ky][piece][lane][8 x fp16]: the two-piece fp16 split of every (scaled)
     weight in the k order of conv1b_kernel (lane group g: window columns 2g, 2g+1; element = parity*4 + layer;
     column 7 is zero padding)."""
-    pieces = _f16_split2(w, scale, 'conv1')                          # (2, co, ci, ky, kx)
-
-    def index(pidx, zero):
+    def index(pidx, zero):                                           # pidx: (2, co, ci, ky, kx) slots of the two-piece split
         pad = torch.full((2, 16, 4, 7, 1), zero, dtype=torch.int64)
         pk = torch.cat([pidx, pad], dim=4).view(2, 16, 4, 7, 4, 2)   # kx -> (g, parity)
         return pk.permute(3, 0, 4, 1, 5, 2).contiguous()             # [ky][piece][g][co][parity][ci] = (7, 2, 4, 16, 2, 4)
-    frag = _layout_gather(pieces, 'conv1', index)
+    frag = _split_gather(w, scale, 'conv1', index, 'conv1')
     return frag.view(torch.int16).view(7, 2, 64, 8).contiguous().view(torch.int32)
 
 
@@ -384,7 +420,6 @@ def _conv_bf6_fragments(w, scale, pass_ch=BF6_PASS_CH):
     co, ci, k, _ = w.shape
     if pass_ch != 8:
         raise NotImplementedError('conv_bf6_kernel stages 8 channels at a time')
-    pieces = _f16_split2(w, scale, 'conv')                                           # (2, co, ci, ky, kx)
     npass, csplit = ci // pass_ch, co // 32
     order = conv_tap_order(k)
 
@@ -400,7 +435,7 @@ def _conv_bf6_fragments(w, scale, pass_ch=BF6_PASS_CH):
                     blk = pi[:, :, ky, kx, pass_ch * p_:pass_ch * p_ + 8]            # (2, co, 8)
                     out[p_, s_, :, :, h] = blk.reshape(2, csplit, 32, 8).permute(1, 0, 2, 3)
         return out
-    out = _layout_gather(pieces, 'bf6', index)
+    out = _split_gather(w, scale, 'bf6', index, 'conv')                              # slots of the (2, co, ci, ky, kx) split
     return out.view(torch.int16).view(-1, 8).contiguous().view(torch.int32)
 
 
@@ -412,11 +447,7 @@ def _fill_cnn(s, holder, sd):
         if tuple(w.shape) != (co, ci, k, k):
             raise NotImplementedError('the HIP map CNN implements the reference default architecture only '
                                       '(layer %d weight %s, expected %s)' % (l, tuple(w.shape), (co, ci, k, k)))
-        if l == 0:
-            pk = w.permute(2, 3, 1, 0).contiguous()                       # [ky][kx][ci][co]
-        else:
-            pk = w.view(co, ci // 2, 2, k, k).permute(1, 3, 4, 2, 0).contiguous()   # [ci/2][ky][kx][ci&1][co]
-        s.w[l] = holder.hold(pk)
+        s.w[l] = holder.hold(w)                                           # (not read by the kernels any more, strive_hip.h)
         s.w_torch[l] = holder.hold(w)                                     # (co, ci, ky, kx): the training backward's data gradient
         s.b[l] = holder.hold(_c(sd['map_conv.%d.bias' % (3 * l)]))
         s.gn_g[l] = holder.hold(_c(sd['map_conv.%d.weight' % (3 * l + 1)]))

@@ -768,6 +768,35 @@ def test_pack_dense_equals_torch_layout(emu, M, K):
     _pack_dense_case(emu, 'cpu', M, K, 'pack/%d/%d' % (M, K))
 
 
+def _pack_conv_case(lib, dev):
+    """the convolution fragment tables as one launch each (strive_pack_split_gather through params._split_gather) against the
+    torch layout code (two-piece split + cat + index_select), byte for byte: conv1's layout, a 5x5 and a 3x3 layer."""
+    from strive_amd import params, ops
+    saved = ops._lib_for
+
+    def packed(fn, w, sc, use_lib):
+        def lib_for(*tensors):
+            if use_lib:
+                return lib
+            raise L.StriveHipError('no library: the torch layout code')
+        ops._lib_for = lib_for
+        try:
+            return fn(w, sc)
+        finally:
+            ops._lib_for = saved
+    for fn, shape, key in ((params._conv1_fragments, (16, 4, 7, 7), 'c1'), (params._conv_bf6_fragments, (32, 16, 5, 5), 'c2'),
+                           (params._conv_bf6_fragments, (64, 64, 3, 3), 'c4')):
+        w = synth.f32(synth.counter_uniform(shape, 'packconv/' + key, -0.3, 0.3)).to(dev).contiguous()
+        w.view(-1)[3] = 0.0
+        sc = params._pow2_scale(float(w.abs().max()))
+        a, b = packed(fn, w, sc, True), packed(fn, w, sc, False)
+        assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), key
+
+
+def test_pack_conv_fragments_equal_torch_layout(emu):
+    _pack_conv_case(emu, 'cpu')
+
+
 # ---- scene-resident rollout kernels (csrc/scene_rollout.h) against the launch-per-phase kernels on the same inputs ----
 def _rollout_both_paths(emu, sd, sizes, FT, ext=False, NC=2, monkeypatch=None, fill=0):
     batch, map_idx, raster, dx = mg.build_inputs(sizes, 'emu', NC=NC)

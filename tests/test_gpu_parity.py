@@ -798,6 +798,14 @@ def test_pack_dense_equals_torch_layout(M, K):
 
 
 @pytest.mark.gpu
+def test_pack_conv_fragments_equal_torch_layout():
+    """the one-launch convolution fragment pack (strive_pack_split_gather) writes the same bytes as the torch layout code"""
+    from test_emu_kernels import _pack_conv_case
+    from strive_amd import _lib as L
+    _pack_conv_case(L.get_lib(), DEV)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('n', [3, 40, 300])
 def test_conv2_specialised_waves_bit_identical(model, n):
     """conv2 as conv_ws_kernel (producer / consumer waves, what strive_map_cnn_fwd launches) against conv_bf6_kernel on the same

@@ -126,6 +126,8 @@ def test_training_step_all_gradients_emulated(emu_ops):
     # rollout over the batch stacked twice (ops.decoder_rollout_stacked, the default): all 174 gradients of the two forms agree
     assert m.stack_rollouts
     m.stack_rollouts = False
+    from strive_amd import params
+    epoch = params.param_epoch()
     try:
         tr = DataParallelTrainer(m, TrafficModelLoss(TW, m.get_normalizer(), m.get_att_normalizer()), torch.optim.SGD(m.parameters(), lr=0.0))
         res = tr.step(batch.clone(), map_idx, env)
@@ -134,6 +136,7 @@ def test_training_step_all_gradients_emulated(emu_ops):
         m.rsample = saved
         m.stack_rollouts = True
     assert res is not None, tr.last_error
+    assert params.param_epoch() == epoch + 1        # the step announced its parameter update (see test_packs_follow_a_fused_optimiser)
     rel = float((tr.bucket[:-1] - want).norm() / want.norm())
     assert rel < 1e-5, rel
     assert len(hits) >= 6 and all(h[1] for h in hits), hits
@@ -146,6 +149,33 @@ def test_training_step_all_gradients_emulated(emu_ops):
     m.decode_embedding(z, emb, batch.clone(), map_idx, env)['future_pred'].sum().backward()
     assert z.grad is not None and all(p.grad is None for p in m.parameters())
     m.eval()
+
+
+def test_packs_follow_a_fused_optimiser():
+    """torch's fused optimisers write the parameters without bumping their version counters, which the weight-pack and max |w|
+    caches key on: params.parameters_changed() (called by DataParallelTrainer.step after every optimiser step) starts a new epoch
+    and the next use rebuilds."""
+    from strive_amd import ops, params
+    lin = torch.nn.Linear(8, 4)
+    built = []
+
+    def build():
+        built.append(lin.weight.detach().clone())
+        return len(built)
+    assert ops._cached_pack(lin, 'k', lin, build) == 1 and ops._cached_pack(lin, 'k', lin, build) == 1
+    a0 = params.absmax(lin.weight)
+    for p in lin.parameters():
+        p.grad = torch.ones_like(p)
+    try:
+        opt = torch.optim.Adam(lin.parameters(), lr=0.5, fused=True)
+    except (RuntimeError, TypeError, ValueError):
+        pytest.skip('no fused Adam for CPU tensors in this torch build')
+    opt.step()
+    assert not torch.equal(built[0], lin.weight.detach())
+    params.parameters_changed()
+    assert ops._cached_pack(lin, 'k', lin, build) == 2 and torch.equal(built[1], lin.weight.detach())
+    assert ops._cached_pack_hit(lin, 'k', lin)
+    assert params.absmax(lin.weight) == float(lin.weight.detach().abs().max()) != a0
 
 
 @pytest.mark.gpu
