@@ -473,10 +473,9 @@ int strive_map_cnn_bwd(const StriveMap* map, const StriveCNN* cnn, const float* 
  * launching stream.  It overwrites the gradient buffer of layer - 1 in `ws` (scratch of the finished call). */
 int strive_map_cnn_bwd_bench_dgrad(int32_t layer, int32_t N, void* ws, size_t ws_bytes, strive_stream_t stream);
 
-/* Kept activations (round 5): the training forward may keep the raw outputs of conv1 .. conv4 and their GroupNorm partial sums of
- * every crop it encodes (1.74 MB per crop) so that the backward does not run those layers again -- the reference's autograd keeps
- * ALL activations of map_conv (src/models/traffic_model.py:69-87 under loss.backward()); conv5 / conv6 and the crop are still
- * recomputed.  strive_map_cnn_fwd_keep = strive_map_cnn_fwd that also writes rows [kept_offset, kept_offset + N) of a kept buffer
+/* Kept activations (round 5): the training forward may keep the raw outputs of the six convolutions and their GroupNorm partial sums
+ * of every crop it encodes (1.76 MB per crop) so that the backward does not run the layers again -- the reference's autograd keeps
+ * ALL activations of map_conv (src/models/traffic_model.py:69-87 under loss.backward()); only the crop is gathered again.  strive_map_cnn_fwd_keep = strive_map_cnn_fwd that also writes rows [kept_offset, kept_offset + N) of a kept buffer
  * sized for kept_total crops (strive_map_cnn_keep_bytes(kept_total)); strive_map_cnn_bwd_kept = strive_map_cnn_bwd over the N =
  * kept_total crops of such a buffer, in the buffer's row order. */
 size_t strive_map_cnn_keep_bytes(int32_t N);

@@ -1372,25 +1372,25 @@ extern "C" size_t strive_map_cnn_workspace_bytes(int32_t N) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Activations kept for the training backward (strive_map_cnn_fwd_keep -> strive_map_cnn_bwd_kept): the raw outputs of conv1 .. conv4
-// and their GroupNorm partial sums of EVERY sample of a training forward (1.74 MB per sample: 2.5 GB for the 1408 crops of a
-// 2 x 64-agent rollout of 12 steps -- nothing against 288 GB), so that the backward does not run these four layers again (they were
-// 2.2 of the 28 ms of a training step).  conv5 / conv6 are cheap and still recomputed; the crop (conv1's input for its weight
-// gradient) never exists in HBM in the forward and is gathered again.
+// Activations kept for the training backward (strive_map_cnn_fwd_keep -> strive_map_cnn_bwd_kept): the raw outputs of all six
+// convolutions and their GroupNorm partial sums of EVERY sample of a training forward (1.76 MB per sample: 2.5 GB for the 1408 crops
+// of a 2 x 64-agent rollout of 12 steps -- nothing against 288 GB), so that the backward does not run the layers again (conv1 .. conv4
+// were 2.2 of the 28 ms of a training step, conv5 / conv6 0.6: the fused tail writes their raw outputs on its way).  The crop (conv1's
+// input for its weight gradient) never exists in HBM in the forward and is gathered again.
 // ---------------------------------------------------------------------------------------------
 struct CnnKeep {
-    float* act[4];
-    GNStats* st[4];
+    float* act[6];
+    GNStats* st[6];
 };
 static inline size_t cnn_keep_bytes(size_t N) {
     size_t b = 256;
-    for (int l = 0; l < 4; ++l) b += strive_align_up(N * L_OUT[l] * 4, 256) + strive_align_up(N * NPARTS[l] * sizeof(GNStats), 256);
+    for (int l = 0; l < 6; ++l) b += strive_align_up(N * L_OUT[l] * 4, 256) + strive_align_up(N * NPARTS[l] * sizeof(GNStats), 256);
     return b;
 }
 static inline bool cnn_keep_carve(void* p, size_t bytes, size_t N, CnnKeep& k) {
     StriveArena ar(p, bytes);
-    for (int l = 0; l < 4; ++l) k.act[l] = ar.take<float>(N * L_OUT[l]);
-    for (int l = 0; l < 4; ++l) k.st[l] = ar.take<GNStats>(N * NPARTS[l]);
+    for (int l = 0; l < 6; ++l) k.act[l] = ar.take<float>(N * L_OUT[l]);
+    for (int l = 0; l < 6; ++l) k.st[l] = ar.take<GNStats>(N * NPARTS[l]);
     return ar.ok();
 }
 
@@ -1431,11 +1431,13 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         if (keep) {
             // conv1 .. conv4 write this chunk's rows of the kept arrays instead of the (reused) workspace; the standard chain only:
             // the kept statistics have NPARTS slots per sample
-            for (int l = 0; l < 4; ++l) {
+            for (int l = 0; l < 6; ++l) {
                 act[l] = keep->act[l] + (keep_off + (size_t)n0) * L_OUT[l];
                 st[l] = keep->st[l] + (keep_off + (size_t)n0) * NPARTS[l];
             }
         }
+        TailKeep tk;
+        tk.y5 = act[4]; tk.y6 = act[5]; tk.st5 = st[4]; tk.st6 = st[5]; tk.np5 = NPARTS[4]; tk.np6 = NPARTS[5];
         dim3 g1(l1b::TILES_Y, n <= small_batch ? l1b::TILES_X : 1, n);
         // (above 256 samples: TWO samples per workgroup since round 5 -- 256 workgroups for a 512-sample chunk instead of 128 on 256
         // CUs: refine closure 12.08 -> 12.01 ms, three alternations, profiles/r05_ab_sweep_step.json; bit-identical for every S)
@@ -1463,7 +1465,7 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
         launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, cnn->xscale[3], cnn->wscale[3], stream);
         if (!keep_tail_activations) {
-            launch_cnn_tail(cnn, act[3], st[3], NPARTS[3], feat + (size_t)n0 * 64, n, stream, nullptr, tail_s);
+            launch_cnn_tail(cnn, act[3], st[3], NPARTS[3], feat + (size_t)n0 * 64, n, stream, nullptr, tail_s, keep ? &tk : nullptr);
             continue;
         }
         launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], n, cnn->xscale[4], cnn->wscale[4], stream);

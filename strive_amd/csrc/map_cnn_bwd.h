@@ -749,18 +749,12 @@ static int cnn_backward(const StriveMap* map, const StriveCNN* cnn, const float*
         GNStats* st[6];
         stat_slots(stats, (size_t)n, st);
         if (keep) {
-            // conv1 .. conv4 of these samples are on the kept arrays (the forward ran the standard chain: NPARTS slots per sample);
-            // conv5 and conv6 run again on top of them
-            for (int l = 0; l < 4; ++l) {
+            // all six layers' raw outputs of these samples are on the kept arrays (the forward ran the standard chain and the fused
+            // tail wrote conv5 / conv6's on its way: NPARTS slots per sample)
+            for (int l = 0; l < 6; ++l) {
                 act[l] = keep->act[l] + (size_t)n0 * L_OUT[l];
                 st[l] = keep->st[l] + (size_t)n0 * NPARTS[l];
             }
-            rc = launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], n, cnn->xscale[4],
-                                   cnn->wscale[4], stream);
-            if (rc) return rc;
-            rc = launch_bf6s<Bfs6>(act[4], st[4], cnn->gn_g[4], cnn->gn_b[4], cnn->w6_frag, cnn->b[5], act[5], st[5], n, cnn->xscale[5],
-                                   cnn->wscale[5], stream);
-            if (rc) return rc;
         }
         {
             MomentsArgs ma;

@@ -99,6 +99,13 @@ struct TailArgs {
     float xs5, un5, xs6, un6;   // operand pre-scales (powers of two) and the matching result scales
     float* feat;                // (N, 64)
     int N;
+    // optional (training forward, CnnKeep): the raw outputs of conv5 (octet-planar (N, 16, 36, 8)) and conv6 (NCHW (N, 128, 2, 2)) and
+    // their GroupNorm sums in slot 0 of np5 / np6 slots per sample (the other slots zero) -- what conv_bf6s_kernel leaves for the backward
+    float* y5;
+    float* y6;
+    GNStats* st5;
+    GNStats* st6;
+    int np5, np6;
 };
 
 // TIMING: clock64 stamps of the phases summed over workgroups into `tprof` (measurement hook only)
@@ -308,6 +315,11 @@ __global__ __launch_bounds__(tail::NT, 1) void cnn_tail_kernel(TailArgs A, unsig
                 fsum += v;
                 fsq = fmaf(v, v, fsq);
             }
+            if (A.y5 && valid) {
+                const int q = g - a * PPS5;
+                *reinterpret_cast<float4*>(A.y5 + ((((size_t)(n0 + a) * (COUT / 8) + (co >> 3)) * PPS5) + q) * 8 + (co & 7)) =
+                    make_float4(acc[i][4 * rg], acc[i][4 * rg + 1], acc[i][4 * rg + 2], acc[i][4 * rg + 3]);
+            }
         }
         float2* o = reinterpret_cast<float2*>(s_part) + ((size_t)g * NW + wave) * 2 + h;
         *o = make_float2(valid ? fsum : 0.f, valid ? fsq : 0.f);
@@ -326,6 +338,12 @@ __global__ __launch_bounds__(tail::NT, 1) void cnn_tail_kernel(TailArgs A, unsig
             var = var < 0.0 ? 0.0 : var;
             s_mr5[2 * wave] = (float)m;
             s_mr5[2 * wave + 1] = (float)(1.0 / sqrt(var + GN_EPS));
+            if (A.st5 && n0 + wave < N)
+                for (int p = 0; p < A.np5; ++p) {
+                    GNStats& o = A.st5[(size_t)(n0 + wave) * A.np5 + p];
+                    o.sum = p == 0 ? a : 0.0;
+                    o.sq = p == 0 ? b : 0.0;
+                }
         }
     }
     __syncthreads();
@@ -410,6 +428,7 @@ __global__ __launch_bounds__(tail::NT, 1) void cnn_tail_kernel(TailArgs A, unsig
                 c_hh[4 * rg + k] = v;
                 fsum += v;
                 fsq = fmaf(v, v, fsq);
+                if (A.y6 && valid) A.y6[((size_t)(n0 + a) * COUT + co + k) * PPS6 + q] = v;
             }
         }
         float2* o = reinterpret_cast<float2*>(s_part) + ((size_t)j * NW + wave) * 2 + h;
@@ -428,6 +447,12 @@ __global__ __launch_bounds__(tail::NT, 1) void cnn_tail_kernel(TailArgs A, unsig
                 var = var < 0.0 ? 0.0 : var;
                 s_mr6[2 * wave] = (float)m;
                 s_mr6[2 * wave + 1] = (float)(1.0 / sqrt(var + GN_EPS));
+                if (A.st6 && n0 + wave < N)
+                    for (int p = 0; p < A.np6; ++p) {
+                        GNStats& o = A.st6[(size_t)(n0 + wave) * A.np6 + p];
+                        o.sum = p == 0 ? sa : 0.0;
+                        o.sq = p == 0 ? sb : 0.0;
+                    }
             }
         }
         __syncthreads();
@@ -503,9 +528,20 @@ static void launch_cnn_tail_s(const TailArgs& a, int N, hipStream_t stream, unsi
 }
 
 // samples_per_wg: 4 = throughput form; 1 (or 2) for small batches -- see the note on S above
+struct TailKeep {          // (see TailArgs::y5 ..)
+    float* y5;
+    float* y6;
+    GNStats* st5;
+    GNStats* st6;
+    int np5, np6;
+};
 static int launch_cnn_tail(const StriveCNN* cnn, const float* act4, const GNStats* st4, int npart_in, float* feat, int N,
-                           hipStream_t stream, unsigned long long* tprof = nullptr, int samples_per_wg = 4) {
+                           hipStream_t stream, unsigned long long* tprof = nullptr, int samples_per_wg = 4,
+                           const TailKeep* keep = nullptr) {
     TailArgs a;
+    a.y5 = keep ? keep->y5 : nullptr; a.y6 = keep ? keep->y6 : nullptr;
+    a.st5 = keep ? keep->st5 : nullptr; a.st6 = keep ? keep->st6 : nullptr;
+    a.np5 = keep ? keep->np5 : 0; a.np6 = keep ? keep->np6 : 0;
     a.in = act4; a.st_in = st4; a.npart_in = npart_in;
     a.g4 = cnn->gn_g[3]; a.b4 = cnn->gn_b[3];
     a.w5 = cnn->w5_frag; a.bias5 = cnn->b[4]; a.g5 = cnn->gn_g[4]; a.b5 = cnn->gn_b[4];
