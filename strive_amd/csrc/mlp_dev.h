@@ -461,6 +461,9 @@ struct WJobTable {
     float* db[STRIVE_WJOBS_MAX];
     float* G[STRIVE_WJOBS_MAX];           // (cap, OUT)
     float* A[STRIVE_WJOBS_MAX];           // (cap, IN)
+    // wjobs_gemm_kernel's grid.z: job j owns slices z0[j] .. z0[j] + ks[j] - 1 of its rows (ks ~ rows / WJOBS_ROWS_PER_WG: the edge
+    // jobs have 15 x the rows of the node jobs; with one split count for all, 16 workgroups walked 1440 rows each while the rest idled)
+    int ks[STRIVE_WJOBS_MAX], z0[STRIVE_WJOBS_MAX], ztotal;
 };
 
 // dW[o * ldw + i] += sum_{r < nrows} g[r][o] * a[r][i]   (o < OUT, i < IN; dW in torch (out, in) layout, possibly a column
@@ -514,14 +517,28 @@ __device__ __forceinline__ void wgrad_lds(const float* g, int g_ld, int OUT, con
     }
 }
 
-// dW += G^T A, db += column sums of G for every job: 64 x 64 tile of dW per workgroup, the rows split WJOBS_KSPLIT ways.
-// grid = (ceil(maxIN / 64), ceil(maxOUT / 64), n_jobs * WJOBS_KSPLIT)
-#define WJOBS_KSPLIT 16
+// dW += G^T A, db += column sums of G for every job: 64 x 64 tile of dW per workgroup, the rows of job j split ks[j] ways.
+// grid = (ceil(maxIN / 64), ceil(maxOUT / 64), ztotal)
+#define WJOBS_ROWS_PER_WG 256
+#define WJOBS_KSPLIT_MAX 96
+static inline void wjobs_finish(WJobTable& t) {
+    int z = 0;
+    for (int j = 0; j < t.n; ++j) {
+        int k = (t.cap[j] + WJOBS_ROWS_PER_WG - 1) / WJOBS_ROWS_PER_WG;
+        k = k < 1 ? 1 : (k > WJOBS_KSPLIT_MAX ? WJOBS_KSPLIT_MAX : k);
+        t.ks[j] = k;
+        t.z0[j] = z;
+        z += k;
+    }
+    t.ztotal = z;
+}
 static __global__ __launch_bounds__(256) void wjobs_gemm_kernel(const WJobTable* __restrict__ T) {
     __shared__ float Gs[16][68];
     __shared__ float As[16][68];
-    const int job = blockIdx.z / WJOBS_KSPLIT, ks = blockIdx.z - job * WJOBS_KSPLIT;
-    if (job >= T->n) return;
+    int job = 0;
+    while (job + 1 < T->n && (int)blockIdx.z >= T->z0[job + 1]) ++job;
+    const int ks = (int)blockIdx.z - T->z0[job], WJOBS_KSPLIT = T->ks[job];
+    if (job >= T->n || ks >= WJOBS_KSPLIT) return;
     const int OUT = T->OUT[job], IN = T->IN[job], ldw = T->ldw[job];
     const int o0 = blockIdx.y * 64, i0 = blockIdx.x * 64;
     if (o0 >= OUT || i0 >= IN) return;

@@ -931,6 +931,7 @@ static WJobsPlan wjobs_plan(const StriveGNN& g, const GNNGradDev& gr, const GRUG
         wjobs_add(p, tape, gg.wih[l], gg.bih[l], GLD, xin, xin, node_cap);
         wjobs_add(p, tape, gg.whh[l], gg.bhh[l], GLD, 64, 64, node_cap);
     }
+    wjobs_finish(p.t);
     return p;
 }
 
@@ -1021,7 +1022,7 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
         hipLaunchKernelGGL(node1_bwd_kernel<WG>, dim3(nb), dim3(256), node1_bwd_lds_bytes(in_ld1, xs_ld), stream, gd, ggn, sd, f, a1);
     }
     if (tr && tr->jobs && plan.t.n > 0)
-        hipLaunchKernelGGL(wjobs_gemm_kernel, dim3((plan.max_in + 63) / 64, (plan.max_out + 63) / 64, plan.t.n * WJOBS_KSPLIT), dim3(256), 0,
+        hipLaunchKernelGGL(wjobs_gemm_kernel, dim3((plan.max_in + 63) / 64, (plan.max_out + 63) / 64, plan.t.ztotal), dim3(256), 0,
                            stream, tr->jobs);
     if (tr && FT > 1) {
         // map_feat_t = CNN(crop(pos_t.detach())), t = 1 .. FT-1 (reference traffic_model.py:694-695): the adjoints reach the CNN
