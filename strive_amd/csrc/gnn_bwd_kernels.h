@@ -341,3 +341,54 @@ static inline GnnBwdBuffers gnn_bwd_buffers_take(StriveArena& ar, size_t R, int 
     w.DPJ = ar.take<float>(R * (size_t)max_n * 4);
     return w;
 }
+
+// =============================================================================================
+// Job table of the deferred weight gradients (mlp_dev.h WJobTable): one job per weight block a backward pass touches.
+// Shared by the rollout's training sweep (rollout.hip) and the stand-alone network backward (strive_gnn_bwd).
+// =============================================================================================
+struct WJobsPlan {
+    WJobTable t;
+    size_t tape_floats;
+    int max_in, max_out;
+    bool dropped, too_large;
+};
+
+static void wjobs_add(WJobsPlan& p, float* tape, float* dW, float* db, int OUT, int IN, int ldw, int cap) {
+    if (!dW || OUT <= 0 || IN <= 0) return;
+    if (p.t.n >= STRIVE_WJOBS_MAX) { p.dropped = true; return; }      // (27 blocks today; a dropped block would silently fall back to atomics)
+    const int j = p.t.n++;
+    p.t.count[j] = 0;
+    p.t.OUT[j] = OUT; p.t.IN[j] = IN; p.t.ldw[j] = ldw; p.t.cap[j] = cap;
+    p.t.dW[j] = dW; p.t.db[j] = db;
+    p.t.G[j] = tape + p.tape_floats; p.tape_floats += (size_t)cap * OUT;
+    p.t.A[j] = tape + p.tape_floats; p.tape_floats += (size_t)cap * IN;
+    p.max_in = IN > p.max_in ? IN : p.max_in;
+    p.max_out = OUT > p.max_out ? OUT : p.max_out;
+}
+
+static void wjobs_add_mlp(WJobsPlan& p, float* tape, const StriveMLP& m, const MLPGradDev& g, int cap, bool skip_first) {
+    for (int l = skip_first ? 1 : 0; l < m.nlayers; ++l) wjobs_add(p, tape, g.w[l], g.b[l], m.dims[l + 1], m.dims[l], m.dims[l], cap);
+}
+
+
+// the blocks of one SceneInteractionNet: node jobs get node_cap rows, edge jobs edge_cap
+static void wjobs_add_gnn(WJobsPlan& p, float* tape, const StriveGNN& g, const GNNGradDev& gr, int node_cap, int edge_cap) {
+    wjobs_add_mlp(p, tape, g.mlp_in, gr.mlp_in, node_cap, false);
+    wjobs_add_mlp(p, tape, g.update, gr.update, node_cap, false);
+    wjobs_add_mlp(p, tape, g.mlp_out, gr.mlp_out, node_cap, false);
+    wjobs_add_mlp(p, tape, g.edge, gr.edge, edge_cap, true);
+    // the factorised layer 0 of the edge network: [x_i | x_j | sem_i | sem_j | rel] column blocks (gnn_bwd_kernels.h)
+    const int D = g.D, NC = g.NC, H = STRIVE_HID, EIN = g.edge.dims[0];
+    float* w0 = gr.edge.w[0];
+    if (w0) {
+        wjobs_add(p, tape, w0, gr.edge.b[0], H, D, EIN, node_cap);
+        wjobs_add(p, tape, w0 + D, nullptr, H, D, EIN, node_cap);
+        wjobs_add(p, tape, w0 + 2 * D, nullptr, H, NC, EIN, node_cap);
+        wjobs_add(p, tape, w0 + 2 * D + NC, nullptr, H, NC, EIN, node_cap);
+        wjobs_add(p, tape, w0 + 2 * D + 2 * NC, nullptr, H, 4, EIN, edge_cap);
+    }
+}
+
+static __global__ void wjobs_upload_kernel(WJobTable* dst, WJobTable src) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = src;
+}

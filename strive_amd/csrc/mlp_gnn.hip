@@ -148,11 +148,30 @@ extern "C" int strive_gnn_fwd(const StriveGNN* gnn, const StriveScenes* sc, cons
 // SceneInteractionNet backward: d_out -> dx (input features) and the weight gradients (accumulated, flat
 // named_parameters() order).  The forward is recomputed (node embeddings, partials, aggregates) into the workspace.
 // ---------------------------------------------------------------------------------------------
+// deferred weight gradients of the stand-alone backward (round 5; the rollout's sweep has had them since round 3): every kernel
+// appends its (adjoint, input) rows to per-block tapes and ONE product per block follows -- with atomics straight into dW a
+// 64-row call spent 450 us in three kernels (141 + 163 + 152), most of it in 64 atomic wave instructions per layer and workgroup
+static WJobsPlan gnn_bwd_plan(const StriveGNN& g, const StriveScenes& sc, float* d_params, float* tape) {
+    WJobsPlan p;
+    memset(&p.t, 0, sizeof(p.t));
+    p.tape_floats = 0; p.max_in = 1; p.max_out = 1;
+    p.dropped = false; p.too_large = false;
+    const size_t R = (size_t)sc.NA * sc.NS;
+    const size_t edges = sc.n_edges > 0 ? (size_t)sc.n_edges : R * (size_t)(sc.max_n > 1 ? sc.max_n : 1);
+    p.too_large = R > 0x7fffffffull || edges > 0x7fffffffull;
+    const GNNGradDev gr = gnn_grad_dev(g, d_params);
+    wjobs_add_gnn(p, tape, g, gr, p.too_large ? 1 : (int)(R > 0 ? R : 1), p.too_large ? 1 : (int)(edges > 0 ? edges : 1));
+    wjobs_finish(p.t);
+    return p;
+}
+
 extern "C" size_t strive_gnn_bwd_workspace_bytes(const StriveGNN* gnn, const StriveScenes* sc) {
     if (!gnn || !sc) return 0;
     const size_t R = (size_t)sc->NA * sc->NS;
+    float* fake = reinterpret_cast<float*>(uintptr_t(1) << 20);      // (planning only: nothing is dereferenced)
+    const size_t tape = gnn_bwd_plan(*gnn, *sc, fake, fake).tape_floats;
     return strive_gnn_workspace_bytes(gnn, sc) + gnn_bwd_buffers_bytes(R, gnn->D, sc->max_n > 0 ? sc->max_n : 1) +
-           strive_align_up(R * 4 * 4, 256) + 4096;
+           strive_align_up(R * 4 * 4, 256) + strive_align_up(sizeof(WJobTable), 256) + strive_align_up(tape * 4, 256) + 4096;
 }
 
 extern "C" int strive_gnn_bwd(const StriveGNN* gnn, const StriveScenes* sc, const float* x, const float* pos, const float* sem,
@@ -176,6 +195,9 @@ extern "C" int strive_gnn_bwd(const StriveGNN* gnn, const StriveScenes* sc, cons
     gb.PRE_E = nullptr;
     GnnBwdBuffers bw = gnn_bwd_buffers_take(ar, (size_t)R, gnn->D, sc->max_n);
     float* g_pos = ar.take<float>((size_t)R * 4);
+    WJobTable* jobs = ar.take<WJobTable>(1);
+    float* fake = reinterpret_cast<float*>(uintptr_t(1) << 20);
+    float* wtape = ar.take<float>(gnn_bwd_plan(*gnn, *sc, fake, fake).tape_floats);
     STRIVE_CHECK_ARG(ar.ok(), "workspace arena overflow");
     FeatSrc f;
     f.n = 1;
@@ -185,7 +207,14 @@ extern "C" int strive_gnn_bwd(const StriveGNN* gnn, const StriveScenes* sc, cons
     int rc = gnn_forward_launch(*gnn, *sc, f, pos, sem, gb, nullptr, stream);      // node1 + edge: X, P, Q, A, ARG
     if (rc) return rc;
     const GNNDev gd = gnn_dev(*gnn);
-    const GNNGradDev gr = gnn_grad_dev(*gnn, d_params);
+    GNNGradDev gr = gnn_grad_dev(*gnn, d_params);
+    static const bool atomics_only = getenv("STRIVE_WGRAD_ATOMICS") != nullptr;      // A/B switch: no deferred weight gradients
+    WJobsPlan plan = gnn_bwd_plan(*gnn, *sc, d_params, wtape);
+    const bool deferred = !atomics_only && !plan.too_large && !plan.dropped && plan.t.n > 0;
+    if (deferred) {
+        hipLaunchKernelGGL(wjobs_upload_kernel, dim3(1), dim3(64), 0, stream, jobs, plan.t);
+        gr.mlp_in.jobs = gr.edge.jobs = gr.update.jobs = gr.mlp_out.jobs = jobs;
+    }
     const ScenesDev sd = scenes_dev(*sc);
     const int in_ld1 = ld4(gnn->mlp_in.dims[0]), xs_ld = ld4(gnn->D + gnn->NC), in_ld2 = ld4(2 * gnn->D + gnn->NC);
     const int nb = (R + RB_NODE - 1) / RB_NODE;
@@ -198,6 +227,9 @@ extern "C" int strive_gnn_bwd(const StriveGNN* gnn, const StriveScenes* sc, cons
     a1.t = 0; a1.R = R; a1.dX = bw.dX; a1.dP = bw.dP; a1.DE1 = bw.DE1; a1.DPJ = bw.DPJ; a1.gpos_tgt = bw.gpos_tgt;
     a1.sem = sem; a1.PRE_IN = nullptr; a1.X = gb.X; a1.g_pos = g_pos; a1.g_full = dx; a1.g_pf = nullptr; a1.g_mf = nullptr; a1.dz = nullptr;
     hipLaunchKernelGGL(node1_bwd_kernel<true>, dim3(nb), dim3(256), node1_bwd_lds_bytes(in_ld1, xs_ld), stream, gd, gr, sd, f, a1);
+    if (deferred)
+        hipLaunchKernelGGL(wjobs_gemm_kernel, dim3((plan.max_in + 63) / 64, (plan.max_out + 63) / 64, plan.t.ztotal), dim3(256), 0, stream,
+                           jobs);
     STRIVE_CHECK_LAUNCH();
     return 0;
 }

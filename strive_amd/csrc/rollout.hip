@@ -874,31 +874,6 @@ static __global__ void rollout_init_bwd_kernel(const float* __restrict__ g_pf, c
     d_map_feat[i] = g_mf[i];
 }
 
-// ---- job table of the deferred weight gradients: one job per weight block the reverse sweep touches ----
-struct WJobsPlan {
-    WJobTable t;
-    size_t tape_floats;
-    int max_in, max_out;
-    bool dropped, too_large;
-};
-
-static void wjobs_add(WJobsPlan& p, float* tape, float* dW, float* db, int OUT, int IN, int ldw, int cap) {
-    if (!dW || OUT <= 0 || IN <= 0) return;
-    if (p.t.n >= STRIVE_WJOBS_MAX) { p.dropped = true; return; }      // (27 blocks today; a dropped block would silently fall back to atomics)
-    const int j = p.t.n++;
-    p.t.count[j] = 0;
-    p.t.OUT[j] = OUT; p.t.IN[j] = IN; p.t.ldw[j] = ldw; p.t.cap[j] = cap;
-    p.t.dW[j] = dW; p.t.db[j] = db;
-    p.t.G[j] = tape + p.tape_floats; p.tape_floats += (size_t)cap * OUT;
-    p.t.A[j] = tape + p.tape_floats; p.tape_floats += (size_t)cap * IN;
-    p.max_in = IN > p.max_in ? IN : p.max_in;
-    p.max_out = OUT > p.max_out ? OUT : p.max_out;
-}
-
-static void wjobs_add_mlp(WJobsPlan& p, float* tape, const StriveMLP& m, const MLPGradDev& g, int cap, bool skip_first) {
-    for (int l = skip_first ? 1 : 0; l < m.nlayers; ++l) wjobs_add(p, tape, g.w[l], g.b[l], m.dims[l + 1], m.dims[l], m.dims[l], cap);
-}
-
 // rows: every node job gets R rows per step, every edge job one row per directed edge and step: the exact count n_edges when the
 // caller's StriveScenes has it (ABI 14), else the bound R max_n (one 60-agent scene in a batch of small ones used to size the
 // five edge tapes for R x 60 rows: GBs)
@@ -912,20 +887,7 @@ static WJobsPlan wjobs_plan(const StriveGNN& g, const GNNGradDev& gr, const GRUG
     const size_t edge_rows = (n_edges > 0 ? (size_t)n_edges : R * (size_t)(max_n > 1 ? max_n : 1)) * (size_t)FT;
     p.too_large = node_rows > 0x7fffffffull || edge_rows > 0x7fffffffull;
     const int node_cap = p.too_large ? 1 : (int)node_rows, edge_cap = p.too_large ? 1 : (int)(edge_rows > 0 ? edge_rows : 1);
-    wjobs_add_mlp(p, tape, g.mlp_in, gr.mlp_in, node_cap, false);
-    wjobs_add_mlp(p, tape, g.update, gr.update, node_cap, false);
-    wjobs_add_mlp(p, tape, g.mlp_out, gr.mlp_out, node_cap, false);
-    wjobs_add_mlp(p, tape, g.edge, gr.edge, edge_cap, true);
-    // the factorised layer 0 of the edge network: [x_i | x_j | sem_i | sem_j | rel] column blocks (gnn_bwd_kernels.h)
-    const int D = g.D, NC = g.NC, H = STRIVE_HID, EIN = g.edge.dims[0];
-    float* w0 = gr.edge.w[0];
-    if (w0) {
-        wjobs_add(p, tape, w0, gr.edge.b[0], H, D, EIN, node_cap);
-        wjobs_add(p, tape, w0 + D, nullptr, H, D, EIN, node_cap);
-        wjobs_add(p, tape, w0 + 2 * D, nullptr, H, NC, EIN, node_cap);
-        wjobs_add(p, tape, w0 + 2 * D + NC, nullptr, H, NC, EIN, node_cap);
-        wjobs_add(p, tape, w0 + 2 * D + 2 * NC, nullptr, H, 4, EIN, edge_cap);
-    }
+    wjobs_add_gnn(p, tape, g, gr, node_cap, edge_cap);
     for (int l = 0; l < 3; ++l) {
         const int xin = l == 0 ? 4 : 64;
         wjobs_add(p, tape, gg.wih[l], gg.bih[l], GLD, xin, xin, node_cap);
@@ -942,9 +904,6 @@ static size_t wjobs_tape_floats(const StriveGNN& g, size_t R, int max_n, int FT,
     return wjobs_plan(g, gr, gg, fake, R, max_n, FT, n_edges).tape_floats;
 }
 
-static __global__ void wjobs_upload_kernel(WJobTable* dst, WJobTable src) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = src;
-}
 
 template <bool WG>
 int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const float* lw, const float* sem, const float* z,
