@@ -486,6 +486,13 @@ int strive_map_cnn_bwd_kept(const StriveMap* map, const StriveCNN* cnn, const fl
                             const float* pos_std4_host, const int32_t* mapix, int32_t N, const float* d_feat, float* d_params,
                             const void* kept, size_t kept_bytes, void* ws, size_t ws_bytes, strive_stream_t stream);
 
+/* ... over rows [kept_offset, kept_offset + N) of a kept buffer sized for kept_total crops; pos / mapix / d_feat point at the first
+ * of these rows (strive_rollout_bwd_train_kept hands the crops of a few steps at a time to a side stream while its sweep continues). */
+int strive_map_cnn_bwd_kept_range(const StriveMap* map, const StriveCNN* cnn, const float* pos, const float* pos_mean4_host,
+                                  const float* pos_std4_host, const int32_t* mapix, int32_t N, const float* d_feat, float* d_params,
+                                  const void* kept, size_t kept_bytes, int32_t kept_total, int32_t kept_offset, void* ws,
+                                  size_t ws_bytes, strive_stream_t stream);
+
 size_t strive_rollout_train_workspace_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT);
 
 /* strive_rollout_fwd keeping the map CNN's activations of its FT - 1 re-encoded steps in `kept` (strive_rollout_keep_bytes), and

