@@ -977,11 +977,14 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
     // leaves -- and the sweep is a chain of small kernels on <= R workgroups while the CNN backward fills the chip.  The crops of
     // `grp` consecutive steps (>= 256 samples) are handed to a library-owned side stream as soon as the sweep has passed them; the
     // caller's stream joins at the end.  STRIVE_TRAIN_OVERLAP=0: one call after the sweep (the round-4 form).
-    static const bool overlap_on = !(getenv("STRIVE_TRAIN_OVERLAP") && atoi(getenv("STRIVE_TRAIN_OVERLAP")) == 0);
+    // (both switches are read per call: the tests run the forms side by side in one process)
+    const char* oe = getenv("STRIVE_TRAIN_OVERLAP");
+    const bool overlap_on = !(oe && atoi(oe) == 0);
     const bool overlap = WG && tr && tr->kept && FT > 1 && overlap_on;
     SideStream* side = overlap ? side_stream() : nullptr;
     const int total_crops = (int)((size_t)(FT > 1 ? FT - 1 : 0) * R);
-    static const int grp_rows = getenv("STRIVE_TRAIN_OVERLAP_ROWS") ? atoi(getenv("STRIVE_TRAIN_OVERLAP_ROWS")) : 256;
+    const char* ge = getenv("STRIVE_TRAIN_OVERLAP_ROWS");
+    const int grp_rows = ge ? atoi(ge) : 256;
     int grp = (int)(((size_t)(grp_rows > 0 ? grp_rows : 256) + R - 1) / R);
     grp = grp < 1 ? 1 : grp;
     int n_handed = 0, t_hi = FT - 1;

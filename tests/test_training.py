@@ -344,6 +344,51 @@ def test_data_parallel_step_equals_single_process(tmp_path):
 
 
 @pytest.mark.gpu
+def test_training_backward_forms_agree():
+    """The training step's gradients do not depend on how its backward is scheduled: the map CNN's backward handed to the library's
+    side stream one rollout step at a time while the reverse sweep continues (STRIVE_TRAIN_OVERLAP_ROWS=1: eleven fork / join groups),
+    in the default groups, or as one call after the sweep (STRIVE_TRAIN_OVERLAP=0); and the separate-rollout form
+    (STRIVE_STACK_ROLLOUTS off).  All 174 tensors, at the noise level of the atomic additions."""
+    DEV = 'cuda:0'
+    m, sd = product_model(device=DEV)
+    batch, map_idx, raster, dx = mg.g5_inputs(None, None)
+    NA = batch.past.shape[0]
+    eps_post = synth.f32(synth.counter_normal((NA, 32), 'g5/eps_post'))
+    eps_prior = synth.f32(synth.counter_normal((NA, 32), 'g5/eps_prior'))
+    env_g = synth.SyntheticMapEnv(raster.clone(), dx.clone()).to(DEV)
+
+    def step(env_vars, stack=True):
+        saved = {k: os.environ.get(k) for k in env_vars}
+        os.environ.update(env_vars)
+        m.stack_rollouts = stack
+        try:
+            out, ld, grads, _ = _product_step(m, batch.clone().to(DEV), map_idx.to(DEV), env_g, eps_post, eps_prior)
+            torch.cuda.synchronize()
+        finally:
+            m.stack_rollouts = True
+            for k, v in saved.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        return out, ld, {k: v.detach().clone() for k, v in grads.items()}
+    ref_out, ref_ld, ref = step({'STRIVE_TRAIN_OVERLAP': '0'})
+    for what, env_vars, stack in (('one group per step', {'STRIVE_TRAIN_OVERLAP_ROWS': '1'}, True), ('default groups', {}, True),
+                                  ('separate rollouts', {}, False)):
+        out, ld, got = step(env_vars, stack)
+        assert torch.equal(out['future_pred'], ref_out['future_pred']) and torch.equal(out['future_samp'], ref_out['future_samp']), what
+        worst = ('', 0.0)
+        for k in ref:
+            den = float(ref[k].norm())
+            if den < 1e-12:
+                continue
+            rel = float((got[k] - ref[k]).norm()) / den
+            worst = (k, rel) if rel > worst[1] else worst
+            assert rel < 2e-5, '%s: gradient %s differs from the one-call form by %.3g' % (what, k, rel)
+        print('%s: worst relative difference to the one-call form %.3g (%s)' % (what, worst[1], worst[0]))
+
+
+@pytest.mark.gpu
 def test_map_cnn_backward_chunks_add_up():
     """strive_map_cnn_bwd over 300 crops (two internal chunks, 256 + 44: the rollout's batched call spans several) equals the
     sum of the gradients of the two parts computed by separate single-chunk calls (additivity of the weight gradient)."""
