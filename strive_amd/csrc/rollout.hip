@@ -846,8 +846,9 @@ struct TrainOut {
     const void* kept;      // the forward's map-CNN activations (strive_rollout_fwd_keep) or null: recompute
     size_t kept_bytes;
     // The adjoints of map_feat_t of ALL steps are kept ((FT, R, 64): step 0 is the encoder's map feature) and the CNN
-    // backward runs ONCE over the (FT - 1) R crops after the reverse sweep: the crop is data (pos_t.detach()), so nothing in the
-    // sweep waits for it, and one call over 11 x more samples fills the chip where 11 calls of R = 64 samples were latency-bound.
+    // backward runs over the (FT - 1) R crops in a few large calls, not one per step: the crop is data (pos_t.detach()), so nothing
+    // in the sweep waits for it, and a call over >= 256 samples fills the chip where 11 calls of R = 64 samples were latency-bound
+    // (one call after the sweep, or -- round 5, kept activations -- groups of steps on a side stream beside the sweep).
     float* g_mf_all;       // (FT, R, 64)
     int32_t* mapix_all;    // (FT - 1, R)
     WJobTable* jobs;       // deferred weight gradients of decoder_net / decoder_memory (mlp_dev.h), device copy ...
@@ -1024,9 +1025,9 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
         a1.t = t; a1.R = (int)R; a1.dX = bw.dX; a1.dP = bw.dP; a1.DE1 = bw.DE1; a1.DPJ = bw.DPJ; a1.gpos_tgt = bw.gpos_tgt;
         a1.sem = sem; a1.PRE_IN = tp.PRE_IN_t(t); a1.X = g2.X; a1.g_pos = g_pos; a1.g_full = nullptr; a1.g_pf = g_pf; a1.g_mf = tr ? tr->g_mf_all + (size_t)t * R * 64 : nullptr; a1.dz = dz;
         hipLaunchKernelGGL(node1_bwd_kernel<WG>, dim3(nb), dim3(256), node1_bwd_lds_bytes(in_ld1, xs_ld), stream, gd, ggn, sd, f, a1);
-        if (side && t >= 1 && (t_hi - t + 1 >= grp || t == 1)) {
-            // steps t .. t_hi are final: their crops are rows (t - 1) R .. t_hi R of the kept arrays
-            if (n_handed >= SideStream::NEV) { strive_set_error("rollout_bwd_train: more than %d CNN groups", SideStream::NEV); return -1; }
+        if (side && t >= 1 && ((t_hi - t + 1 >= grp && n_handed < SideStream::NEV - 1) || t == 1)) {
+            // steps t .. t_hi are final: their crops are rows (t - 1) R .. t_hi R of the kept arrays (with more groups than events --
+            // FT > 64 at one step per group -- the last group takes all remaining steps)
             hipEvent_t ev = side->ev[n_handed++];
             hipEventRecord(ev, stream);
             hipStreamWaitEvent(side->s, ev, 0);
@@ -1035,7 +1036,11 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
                                                    tr->mapix_all + off, (int32_t)cnt, tr->g_mf_all + R * 64 + off * 64, tr->d_cnn, tr->kept,
                                                    tr->kept_bytes, (int32_t)total_crops, (int32_t)off, tr->cnn_ws, tr->cnn_ws_bytes,
                                                    (strive_stream_t)side->s);
-            if (rc) return rc;
+            if (rc) {
+                hipEventRecord(side->done, side->s);            // (join before reporting: nothing of this call stays in flight)
+                hipStreamWaitEvent(stream, side->done, 0);
+                return rc;
+            }
             t_hi = t - 1;
         }
     }
