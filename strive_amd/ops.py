@@ -470,8 +470,8 @@ def cnn_pack(model):
 
 
 def keep_cnn_activations():
-    """Training forward: keep the map CNN's conv1 .. conv4 outputs for the backward instead of recomputing them there
-    (strive_map_cnn_fwd_keep / strive_rollout_fwd_keep; STRIVE_KEEP_CNN_ACTIVATIONS=0: recompute, the round-4 form)."""
+    """Training forward: keep the raw outputs of the map CNN's six convolutions for the backward instead of recomputing them there
+    (strive_map_cnn_fwd_keep / strive_rollout_fwd_keep, 1.76 MB per crop; STRIVE_KEEP_CNN_ACTIVATIONS=0: recompute, the round-4 form)."""
     return os.environ.get('STRIVE_KEEP_CNN_ACTIVATIONS', '1') != '0'
 
 
@@ -489,7 +489,7 @@ class _CNNFn(torch.autograd.Function):
         ws = _workspace(h.p2.device, wsb, 'cnn')
         ctx.kept = None
         if keep_cnn_activations():
-            # conv1 .. conv4's outputs stay for the backward (1.74 MB per crop) instead of being recomputed there
+            # the convolutions' raw outputs stay for the backward (1.76 MB per crop) instead of being recomputed there
             ctx.kept = torch.empty(h.lib.query('strive_map_cnn_keep_bytes', h.N), dtype=torch.uint8, device=h.p2.device)
             h.lib.call('strive_map_cnn_fwd_keep', h.mp.ref(), h.cnn.ref(), L.ptr(h.p2), h.mean4, h.std4, L.ptr(h.mapix), h.N, L.ptr(feat),
                        L.ptr(ws), ws.numel(), L.ptr(ctx.kept), ctx.kept.numel(), h.N, 0, _stream(h.p2))

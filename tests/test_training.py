@@ -149,6 +149,16 @@ def test_training_step_all_gradients_emulated(emu_ops):
     m.decode_embedding(z, emb, batch.clone(), map_idx, env)['future_pred'].sum().backward()
     assert z.grad is not None and all(p.grad is None for p in m.parameters())
     m.eval()
+    # the same forward without an autograd graph (validation: reference src/train_traffic.py:186-199 under no_grad) takes the stacked
+    # rollout too, through the optimisation path's Function: the same trajectories, bit for bit
+    seq = [eps_post, eps_prior]
+    m.rsample = lambda mean, var: mean + seq.pop(0).to(mean.device) * torch.sqrt(var)
+    try:
+        with torch.no_grad():
+            out_v = m(batch.clone(), map_idx, env, future_sample=True)
+    finally:
+        m.rsample = saved
+    assert torch.equal(out_v['future_pred'], out['future_pred']) and torch.equal(out_v['future_samp'], out['future_samp'])
 
 
 def test_packs_follow_a_fused_optimiser():
