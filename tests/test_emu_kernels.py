@@ -315,6 +315,55 @@ def test_map_cnn_eight_agents(emu, sd, monkeypatch):
         assert_close(f_fused, want[:m_], 1e-4, 1e-5, 'cnn x%d' % m_)
 
 
+def test_map_cnn_backward_over_kept_ranges(emu, sd):
+    """The forward that keeps its activations (strive_map_cnn_fwd_keep, written in two calls at row offsets like the rollout does
+    step by step) gives the features of strive_map_cnn_fwd; the backward over the kept rows as one call (strive_map_cnn_bwd_kept)
+    equals the recomputing backward (strive_map_cnn_bwd) and the sum of the per-range calls (strive_map_cnn_bwd_kept_range: what
+    the training rollout hands its side stream group by group)."""
+    raster, dx, frame, mapixes, lw = mg.g2_inputs()
+    env = synth.SyntheticMapEnv(raster, dx)
+    n = 3
+    fr = np.zeros((n, 4))
+    fr[:, 0] = synth.counter_uniform((n,), 'kr/x', 40.0, 200.0)
+    fr[:, 1] = synth.counter_uniform((n,), 'kr/y', 40.0, 200.0)
+    ang = synth.counter_uniform((n,), 'kr/h', -np.pi, np.pi)
+    fr[:, 2], fr[:, 3] = np.cos(ang), np.sin(ang)
+    fr = synth.f32(fr).contiguous()
+    mi = torch.tensor([i % 2 for i in range(n)], dtype=torch.int32)
+    d_feat = synth.f32(synth.counter_uniform((n, 64), 'kr/df', -1.0, 1.0)).contiguous()
+    cnn, mp = params.pack_cnn(sd), params.pack_map(env, 'cpu')
+    z4, o4 = L.f4([0] * 4), L.f4([1] * 4)
+    wsb = emu.query('strive_map_cnn_workspace_bytes', n)
+    ws = torch.zeros(wsb, dtype=torch.uint8)
+    feat, feat_k = torch.zeros((n, 64)), torch.zeros((n, 64))
+    emu.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(fr), z4, o4, L.ptr(mi), n, L.ptr(feat), L.ptr(ws), wsb, None)
+    kb = emu.query('strive_map_cnn_keep_bytes', n)
+    kept = torch.full((kb,), 0xFF, dtype=torch.uint8)          # (NaN bytes: every kept row must be written before it is read)
+    for lo, hi in ((0, 2), (2, 3)):
+        emu.call('strive_map_cnn_fwd_keep', mp.ref(), cnn.ref(), L.ptr(fr[lo:hi].contiguous()), z4, o4, L.ptr(mi[lo:hi].contiguous()), hi - lo,
+                 L.ptr(feat_k[lo:hi]), L.ptr(ws), wsb, L.ptr(kept), kb, n, lo, None)
+    assert_close(feat_k, feat, 2e-6, 2e-6, 'features of the keeping forward')       # (the standard chain for conv3 / conv4; same sums)
+    npar = emu.query('strive_map_cnn_param_count')
+    bwb = emu.query('strive_map_cnn_bwd_workspace_bytes', n)
+    bws = torch.zeros(bwb, dtype=torch.uint8)
+    g_rec, g_kept, g_rng = torch.zeros(npar), torch.zeros(npar), torch.zeros(npar)
+    emu.call('strive_map_cnn_bwd', mp.ref(), cnn.ref(), L.ptr(fr), z4, o4, L.ptr(mi), n, L.ptr(d_feat), L.ptr(g_rec), L.ptr(bws), bwb, None)
+    emu.call('strive_map_cnn_bwd_kept', mp.ref(), cnn.ref(), L.ptr(fr), z4, o4, L.ptr(mi), n, L.ptr(d_feat), L.ptr(g_kept), L.ptr(kept), kb,
+             L.ptr(bws), bwb, None)
+    for lo, hi in ((2, 3), (0, 2)):         # (the rollout hands its last steps over first)
+        emu.call('strive_map_cnn_bwd_kept_range', mp.ref(), cnn.ref(), L.ptr(fr[lo:hi].contiguous()), z4, o4, L.ptr(mi[lo:hi].contiguous()),
+                 hi - lo, L.ptr(d_feat[lo:hi].contiguous()), L.ptr(g_rng), L.ptr(kept), kb, n, lo, L.ptr(bws), bwb, None)
+    assert bool(torch.isfinite(g_kept).all()) and float(g_rec.norm()) > 0.0
+    for what, g in (('kept vs recomputed', g_kept), ('ranges vs one call', g_rng)):
+        ref = g_rec if what.startswith('kept') else g_kept
+        rel = float((g - ref).norm() / ref.norm())
+        assert rel < 2e-5, '%s: flat map-CNN gradient differs by %.3g' % (what, rel)
+    # rows outside the kept arrays are refused
+    with pytest.raises(L.StriveHipError):
+        emu.call('strive_map_cnn_bwd_kept_range', mp.ref(), cnn.ref(), L.ptr(fr), z4, o4, L.ptr(mi), n, L.ptr(d_feat), L.ptr(g_rng), L.ptr(kept),
+                 kb, n, 1, L.ptr(bws), bwb, None)
+
+
 # ------------------------------------------------------------------------------------------------
 # training backward: weight gradients (flat buffers in named_parameters() order) vs torch autograd of the oracle
 # ------------------------------------------------------------------------------------------------
