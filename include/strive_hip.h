@@ -14,7 +14,10 @@
  *     matching *_bytes() query; workspaces are scratch (contents undefined on return) except "tape";
  *   - work is enqueued on `stream` (a hipStream_t passed as void*), no hidden synchronisation;
  *   - return 0 on success, a negative code on failure; strive_last_error() (thread local) explains it;
- *   - re-entrant; no global mutable state besides the error string.
+ *   - re-entrant; no global mutable state besides the error string.  One exception (round 5): strive_rollout_bwd_train_kept forks
+ *     the map CNN's backward onto a library-owned side stream (one per device, created at first use) and joins it back on `stream`
+ *     with events before it returns -- no host synchronisation, the caller's stream order is what it would be without it; run one
+ *     such call at a time per device.
  */
 #ifndef STRIVE_HIP_H
 #define STRIVE_HIP_H
