@@ -1429,8 +1429,8 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         GNStats* st[6];
         stat_slots(stats, (size_t)ch, st);
         if (keep) {
-            // conv1 .. conv4 write this chunk's rows of the kept arrays instead of the (reused) workspace; the standard chain only:
-            // the kept statistics have NPARTS slots per sample
+            // every layer writes this chunk's rows of the kept arrays instead of the (reused) workspace (conv5 / conv6: the fused tail,
+            // TailKeep); the standard chain only: the kept statistics have NPARTS slots per sample
             for (int l = 0; l < 6; ++l) {
                 act[l] = keep->act[l] + (keep_off + (size_t)n0) * L_OUT[l];
                 st[l] = keep->st[l] + (keep_off + (size_t)n0) * NPARTS[l];
