@@ -14,7 +14,7 @@
  *     matching *_bytes() query; workspaces are scratch (contents undefined on return) except "tape";
  *   - work is enqueued on `stream` (a hipStream_t passed as void*), no hidden synchronisation;
  *   - return 0 on success, a negative code on failure; strive_last_error() (thread local) explains it;
- *   - re-entrant; no global mutable state besides the error string.  One exception (round 5): strive_rollout_bwd_train_kept forks
+ *   - re-entrant; no global mutable state besides the error string and the options below.  One exception (round 5): strive_rollout_bwd_train_kept forks
  *     the map CNN's backward onto a library-owned side stream (one per device, created at first use) and joins it back on `stream`
  *     with events before it returns -- no host synchronisation, the caller's stream order is what it would be without it; run one
  *     such call at a time per device.
@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define STRIVE_ABI_VERSION 16
+#define STRIVE_ABI_VERSION 17
 #define STRIVE_HID 128        /* hidden width of every MLP in the reference (models/common.py, interaction_net.py:32,41) */
 #define STRIVE_MAX_LAYERS 4
 #define STRIVE_ZDIM 32
@@ -39,6 +39,35 @@ typedef void* strive_stream_t;
 
 int strive_abi_version(void);
 const char* strive_last_error(void);
+
+/* Options (ABI 17).  Up to round 5 the library read 19 undeclared environment variables inside its entry points; it reads none
+ * any more.  Every switch is a named process-wide integer with the shipped behaviour as its default; a caller that never touches
+ * them gets exactly the documented behaviour.  Set them between calls (a call reads them when it starts); they are plain ints, not
+ * synchronised against calls running on other threads.  Reference: none (the reference has no native side to tune); the Python host
+ * (strive_amd/_lib.py) maps an environment variable STRIVE_<NAME> onto option <name> when the library is loaded and on
+ * sync_options_from_env().
+ *   algorithm choices (results agree to rounding, mostly bit for bit -- the A/B switches of DESIGN.md section 4):
+ *     cnn_small_batch (96)   map CNN: a launch of <= this many samples runs the small-batch kernel forms (0: never)
+ *     cnn_chunk (512)        samples pushed through the CNN layer stack together (8 .. 1024)
+ *     cnn_tail_s (0)         samples per workgroup of the fused CNN tail: 0 = by size, or 1 / 2 / 4
+ *     conv_ws (1)            conv2 on specialised producer / consumer waves (0: conv_bf6_kernel; bit-identical)
+ *     conv_wsx (1)           conv3 / conv4 on specialised waves with streamed weights (0: conv_bf6_kernel; bit-identical)
+ *     scene_kernels (1)      scene-resident decoder kernels where they apply (0: launch-per-phase kernels)
+ *     scene_split (12)       scenes of >= this many agents share their edge chunks among K workgroups (0: never)
+ *     scene_fwd_k (-1)       K of the forward step (-1: one workgroup per 64-row edge chunk, <= 4)
+ *     sweep_step (-1)        reverse sweep as one launch per step on K workgroups per scene (-1: from 3 chunks on; 0: never; 1..4)
+ *     train_overlap (1)      strive_rollout_bwd_train_kept: CNN backward of finished steps on the library's side stream
+ *     train_overlap_rows (256)  samples per hand-over to that stream
+ *     wgrad_atomics, dgrad_igemm, wgrad_igemm, wgrad_tile (0)   earlier forms of the training backward kept for A/B
+ *   measurement hooks (results of the affected call are INVALID or the workspace tail is written; never set in production):
+ *     conv_ws_dbg (bit mask), wgrad_dbg, scene_prof, planner_prof
+ * strive_set_option / strive_get_option return 0, or -1 for an unknown name or a value outside the option's range
+ * (strive_last_error() names it); strive_option_name(i), 0 <= i < strive_option_count(), enumerates the names. */
+int strive_set_option(const char* name_host, int64_t value);
+int strive_get_option(const char* name_host, int64_t* value_host);
+int strive_reset_options(void);
+int32_t strive_option_count(void);
+const char* strive_option_name(int32_t i);
 
 /* ------------------------------------------------------------------------------------------------
  * Shared descriptors (host structs holding device pointers)
@@ -277,8 +306,8 @@ size_t strive_rollout_workspace_bytes(const StriveDecoder* dec, const StriveScen
 /* 1 when strive_rollout_fwd / strive_rollout_bwd will run this batch on the scene-resident kernels (one workgroup per scene:
  * a decoder step is ONE launch, the reverse sweep over all FT steps is ONE launch; csrc/scene_rollout.h) -- single-sample
  * rollouts, scenes of <= 16 agents, weight packs with matrix-core fragments (StriveMLP.wf / StriveGRU.whh_f) -- else 0: the
- * launch-per-phase kernels.  Same arithmetic scheme, same tape layout; results agree to fp32 rounding.  The environment
- * variable STRIVE_SCENE_KERNELS=0 (read per call) forces 0. */
+ * launch-per-phase kernels.  Same arithmetic scheme, same tape layout; results agree to fp32 rounding.  Option
+ * scene_kernels = 0 (read per call) forces 0. */
 int strive_rollout_scene_resident(const StriveDecoder* dec, const StriveScenes* sc);
 
 /* TrafficModel.autoregressive_decoder (reference src/models/traffic_model.py:589-704).

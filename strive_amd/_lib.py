@@ -129,6 +129,11 @@ F4 = C.c_float * 4
 PROTOTYPES = {
     'strive_abi_version': (C.c_int, []),
     'strive_last_error': (C.c_char_p, []),
+    'strive_set_option': (C.c_int, [C.c_char_p, C.c_int64]),
+    'strive_get_option': (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
+    'strive_reset_options': (C.c_int, []),
+    'strive_option_count': (C.c_int32, []),
+    'strive_option_name': (C.c_char_p, [C.c_int32]),
     'strive_map_crop_u8': (C.c_int, [C.POINTER(StriveMap), P, F4, F4, P, I, P, P]),
     'strive_map_rasterize': (C.c_int, [C.POINTER(StriveRasterJob), P, P]),
     'strive_coll_point': (C.c_int, [C.POINTER(StriveMap), P, P, P, I, I, I, P, P, P, P, P]),
@@ -192,7 +197,15 @@ PROTOTYPES = {
 }
 
 
-ABI_VERSION = 16   # include/strive_hip.h STRIVE_ABI_VERSION
+ABI_VERSION = 17   # include/strive_hip.h STRIVE_ABI_VERSION
+
+
+_instances = []      # every loaded library (the product's; the tests' host-emulated build): sync_all_options_from_env() walks them
+
+
+def sync_all_options_from_env():
+    for lib in _instances:
+        lib.sync_options_from_env()
 
 
 class StriveLib(object):
@@ -221,6 +234,9 @@ class StriveLib(object):
             v = self._strive_abi_version()
             if v != ABI_VERSION:
                 raise StriveHipError('ABI version mismatch: library %d, binding %d' % (v, ABI_VERSION))
+        if 'strive_set_option' not in self.missing:
+            self.sync_options_from_env()
+            _instances.append(self)
 
     def call(self, name, *args):
         fn = getattr(self, '_' + name, None)
@@ -232,6 +248,30 @@ class StriveLib(object):
 
     def query(self, name, *args):
         return getattr(self, '_' + name)(*args)
+
+    # ---- options (include/strive_hip.h, ABI 17): the library reads no environment variable; this host maps STRIVE_<NAME> onto them ----
+    def option_names(self):
+        return [self._strive_option_name(i).decode() for i in range(self._strive_option_count())]
+
+    def set_option(self, name, value):
+        if self._strive_set_option(name.encode(), int(value)) != 0:
+            raise StriveHipError(self._strive_last_error().decode())
+
+    def get_option(self, name):
+        v = C.c_int64(0)
+        if self._strive_get_option(name.encode(), C.byref(v)) != 0:
+            raise StriveHipError(self._strive_last_error().decode())
+        return int(v.value)
+
+    def sync_options_from_env(self, environ=None):
+        """Every option back to its default, then STRIVE_<NAME>=<int> from the environment on top (A/B runs, tests).  Called when the
+        library is loaded; call it again after changing such a variable inside the process."""
+        environ = os.environ if environ is None else environ
+        self._strive_reset_options()
+        for name in self.option_names():
+            v = environ.get('STRIVE_' + name.upper())
+            if v is not None and v != '':
+                self.set_option(name, int(v))
 
 
 _default = None

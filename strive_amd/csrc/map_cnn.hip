@@ -20,7 +20,6 @@
 // epilogue of the producing convolution, per tile, and added in tile order by the consumer.
 #include "common.h"
 #include "crop_dev.h"
-#include <stdlib.h>
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -92,13 +91,13 @@ __device__ __forceinline__ uint32_t pack_f16_pair_from_bytes(uint32_t word, int 
 // The weight fragments are loaded once per workgroup.  8 waves: wave w owns output rows 2w, 2w+1 (4 pixel tiles).
 constexpr int C1_NT = 512;
 
-// VAR (round 6): 1 = no global load is consumed inside the tile loop except the raster gathers.  The bias and the crop's
-// lwise / wwise tables come from LDS: hipcc's wait-count pass cannot count the predicated gathers, so the wait it placed in front of
-// every use of a globally loaded value in the loop was s_waitcnt vmcnt(0) -- in front of each of the four output stores of a tile
-// (the bias), i.e. every store waited for the previous one to be acknowledged and for the next tile's gathers, which were meant
-// to stay in flight until deposit().  The GroupNorm sums of a lane's 16 outputs of a tile are formed in fp32 (conv_bf6_kernel's
-// rule), then float64: 2 conversions + 2 additions per 16 values instead of 16 + 32 (fp64 runs at half rate).
-template <bool FUSED_CROP, int DBG = 0, int VAR = 1>
+// Round 6: no global load is consumed inside the tile loop except the raster gathers.  The bias and the crop's lwise / wwise tables
+// come from LDS: hipcc's wait-count pass cannot count the predicated gathers, so the wait it placed in front of every use of a
+// globally loaded value in the loop was s_waitcnt vmcnt(0) -- in front of each of the four output stores of a tile (the bias), i.e.
+// every store waited for the previous one to be acknowledged and for the next tile's gathers, which were meant to stay in flight
+// until deposit().  The GroupNorm sums of a lane's 16 outputs of a tile are formed in fp32 (conv_bf6_kernel's rule), then float64:
+// 2 conversions + 2 additions per 16 values instead of 16 + 32 (fp64 runs at half rate).
+template <bool FUSED_CROP, int DBG = 0>
 __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const float* __restrict__ pos, Float4Host pmean,
                                                          Float4Host pstd, const int32_t* __restrict__ mapix,
                                                          const uint8_t* __restrict__ crop, const uint32_t* __restrict__ wfrag,
@@ -119,10 +118,8 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
 
     for (int i = tid; i < WBYTES / 16; i += C1_NT)
         reinterpret_cast<uint4*>(s_w)[i] = reinterpret_cast<const uint4*>(wfrag)[i];
-    if (VAR & 1) {
-        if (tid < COUT) s_bias[tid] = bias[tid];
-        if (FUSED_CROP && tid < 2 * IH) s_lw[tid] = tid < IH ? map.lwise[tid] : map.wwise[tid - IH];
-    }
+    if (tid < COUT) s_bias[tid] = bias[tid];
+    if (FUSED_CROP && tid < 2 * IH) s_lw[tid] = tid < IH ? map.lwise[tid] : map.wwise[tid - IH];
 
     CropFrame fr;
     const uint32_t* pk = nullptr;
@@ -147,10 +144,10 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
             float v = 0.f;
             if (i < 2 * ITH) {
                 const int r = i >> 1, l = 2 * oy0 + r;
-                if (l < IH) v = __fmul_rn((VAR & 1) ? s_lw[l] : map.lwise[l], (i & 1) ? fr.hs : fr.hc);
+                if (l < IH) v = __fmul_rn(s_lw[l], (i & 1) ? fr.hs : fr.hc);
             } else {
                 const int c = (i - 2 * ITH) >> 1, w = 2 * ox0 + c;
-                if (w < IH) v = __fmul_rn((VAR & 1) ? s_lw[IH + w] : map.wwise[w], (i & 1) ? fr.hs : fr.hc);
+                if (w < IH) v = __fmul_rn(s_lw[IH + w], (i & 1) ? fr.hs : fr.hc);
             }
             T[i] = v;
         }
@@ -209,7 +206,7 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
     // (8 samples: 17.7 -> ~8 us, profiles/r04_ab_cnn_small_batch.txt).  Same tiles, same arithmetic, same statistics slots.
     const int tpb = TILES_X / (int)gridDim.y;
     const int tx_begin = (int)blockIdx.y * tpb, tx_end = tx_begin + tpb;
-    if (VAR & 1) __syncthreads();                                    // s_lw
+    __syncthreads();                                                 // s_lw, s_bias
     if (FUSED_CROP) tables(tx_begin, tx_begin & 1);
     __syncthreads();
     gather(tx_begin, tx_begin & 1);
@@ -253,7 +250,7 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
         double lsum = 0.0, lsq = 0.0;
         float fsum = 0.f, fsq = 0.f;
         const int ox0 = tx * TOX;
-        const float4 bv = *reinterpret_cast<const float4*>(((VAR & 1) ? (const float*)s_bias : bias) + g * 4);
+        const float4 bv = *reinterpret_cast<const float4*>(s_bias + g * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int oy = oy0 + wave * 2 + (i >> 1), ox = ox0 + (i & 1) * 16 + j;
@@ -265,16 +262,12 @@ __global__ __launch_bounds__(C1_NT, 4) void conv1b_kernel(StriveMap map, const f
             if (oy < OH && ox < OH) {
                 if (DBG != 4)
                     *reinterpret_cast<float4*>(out + ((((size_t)n * (COUT / 8) + (g >> 1)) * OH + oy) * OH + ox) * 8 + (g & 1) * 4) = v;
-                if (VAR & 1) {
-                    fsum += (v.x + v.y) + (v.z + v.w);
-                    fsq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fsq))));
-                } else {
-                    lsum += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-                    lsq += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
-                }
+                fsum += (v.x + v.y) + (v.z + v.w);
+                fsq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fsq))));
             }
         }
-        if (VAR & 1) { lsum = (double)fsum; lsq = (double)fsq; }
+        lsum = (double)fsum;
+        lsq = (double)fsq;
         lsum = wave_sum_d(lsum);
         lsq = wave_sum_d(lsq);
         if (lane == 0) { s_red[buf][2 * wave] = lsum; s_red[buf][2 * wave + 1] = lsq; }
@@ -375,11 +368,7 @@ __device__ __forceinline__ void split_f16x2(const float v[8], uint4& p0, uint4& 
 
 // TIMING: phase timestamps (s_memtime) of every workgroup summed into `tprof` (measurement hook only)
 // DBG (measurement hook only, results invalid): 1 = no matrix steps, 2 = no output stores, 3 = no input loads, 4 = 1 + 2
-// VAR (A/B switches of round 6): bit 0 = the raw input loads are UNCONDITIONAL (addresses clamped into the tensor, the staging
-// zeroes what lies outside): the compiler then counts what is outstanding exactly; with predicated loads it waits for the weight
-// steps with vmcnt(11 - s) -- which, the next pass's ten input loads having been issued BEHIND the weights, forces those input
-// loads home by matrix step 3 instead of leaving them in flight for the whole matrix loop
-template <class Cfg, bool TIMING = false, int DBG = 0, int VAR = 2>
+template <class Cfg, bool TIMING = false, int DBG = 0>
 __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
                                                                 const float* __restrict__ gn_g, const float* __restrict__ gn_b,
                                                                 const uint32_t* __restrict__ wfrag, const float* __restrict__ bias,
@@ -398,7 +387,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
     float* s_gn = (float*)(s_w + 3 * Cfg::WSTEP_B);              // [CIN][2] scale, shift
     double* s_red = (double*)(s_gn + 2 * CIN);
     float* s_mr = (float*)(s_red + 2 * Cfg::NW);
-    float* s_bias = s_mr + 4;                                      // [COUT_WG] (VAR bit 1)
+    float* s_bias = s_mr + 4;                                      // [COUT_WG]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31;
@@ -430,17 +419,6 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
 #pragma unroll
         for (int k = 0; k < Cfg::UITERS; ++k) {
             const int idx = tid + k * NT;
-            if (VAR & 1) {
-                const int idc = idx < Cfg::UNITS ? idx : Cfg::UNITS - 1;
-                const int col = idc % ITW, r = idc / ITW;
-                int iy = iy0 + r, ix = ix0 + col;
-                iy = iy < IH ? iy : IH - 1;
-                ix = ix < IH ? ix : IH - 1;
-                const float4* src = reinterpret_cast<const float4*>(in_n + (((size_t)pass * IH + iy) * IH + ix) * 8);
-                raw[k][0] = src[0];
-                raw[k][1] = src[1];
-                continue;
-            }
             raw[k][0] = make_float4(0.f, 0.f, 0.f, 0.f);
             raw[k][1] = raw[k][0];
             if (idx < Cfg::UNITS && DBG != 3) {
@@ -456,10 +434,10 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
     };
     issue_loads(0);
     const float my_g = tid < CIN ? gn_g[tid] : 0.f, my_b = tid < CIN ? gn_b[tid] : 0.f;   // in flight during the reduction
-    // bit 1: the epilogue takes the bias from LDS.  A global load in the epilogue is waited for with vmcnt(0) (the wait-count pass
+    // The epilogue takes the bias from LDS (round 6).  A global load in the epilogue is waited for with vmcnt(0) (the wait-count pass
     // merges the divergent store blocks conservatively), and on gfx9 stores count in vmcnt too: every bias load waited for the
     // stores issued before it -- 16 serial store round trips per wave in conv3's epilogue.
-    if ((VAR & 2) && tid < Cfg::COUT_WG) s_bias[tid] = bias[cb * Cfg::COUT_WG + tid];
+    if (tid < Cfg::COUT_WG) s_bias[tid] = bias[cb * Cfg::COUT_WG + tid];
 
     // ---- GroupNorm moments of the input sample: the producer's per-tile partial sums, one per lane, reduced in a
     // fixed (butterfly) order ----
@@ -508,10 +486,6 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
     // fragments are stored [pass][tap pair][co / 32][piece][lane]: the CBW blocks of this workgroup are adjacent
     auto wstep_src = [&](int pass, int t) { return wsrc + ((size_t)(pass * NKS + t) * (COUT / 32) + cb * CBW) * 128; };
     const bool wmover = tid < WQ;                                 // the first 2 CBW waves move the weight fragments
-    // bit 0: every thread requests a piece (the non-movers a piece they never store: an L2 hit) so that the requests are not under
-    // control flow and the compiler can count them
-    const int wtid = (VAR & 1) ? (tid & (WQ - 1)) : tid;
-    const bool wload = (VAR & 1) ? true : wmover;
 
     for (int pass = 0; pass < Cfg::NPASS; ++pass) {
         // ALL weight fragments of the pass (13 x 16 bytes per moving thread) are requested up front and parked in
@@ -520,9 +494,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
         uint4 wq[NKS];
 #pragma unroll
         for (int t = 0; t < NKS; ++t) wq[t] = make_uint4(0u, 0u, 0u, 0u);
-        if (wload) {
+        if (wmover) {
 #pragma unroll
-            for (int t = 0; t < Cfg::W_UPFRONT; ++t) wq[t] = wstep_src(pass, t)[wtid];
+            for (int t = 0; t < Cfg::W_UPFRONT; ++t) wq[t] = wstep_src(pass, t)[tid];
         }
         __syncthreads();        // s_gn ready (pass 0) / every wave is done with the previous pass's tiles
         // ---- 8 input channels of the (2TH+KS-2) x (2TW+KS-2) window: GroupNorm + ReLU (pre-scaled), two-piece fp16 split ----
@@ -621,9 +595,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
             }
             __builtin_amdgcn_sched_barrier(0);
             if (s + 2 < NKS && wmover) reinterpret_cast<uint4*>(s_w + ((s + 2) % 3) * Cfg::WSTEP_B)[tid] = wq[s + 2];
-            if (s == Cfg::W_LATE_AT && Cfg::W_UPFRONT < NKS && wload) {
+            if (s == Cfg::W_LATE_AT && Cfg::W_UPFRONT < NKS && wmover) {
 #pragma unroll
-                for (int t = Cfg::W_UPFRONT; t < NKS; ++t) wq[t] = wstep_src(pass, t)[wtid];
+                for (int t = Cfg::W_UPFRONT; t < NKS; ++t) wq[t] = wstep_src(pass, t)[tid];
             }
             if (s + 1 < NKS) __syncthreads();
         }
@@ -646,8 +620,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int co = (cb * CBW + c) * 32 + 8 * rg + 4 * h;
-                const float4 bv = (VAR & 2) ? *reinterpret_cast<const float4*>(s_bias + c * 32 + 8 * rg + 4 * h)
-                                            : *reinterpret_cast<const float4*>(bias + co);
+                const float4 bv = *reinterpret_cast<const float4*>(s_bias + c * 32 + 8 * rg + 4 * h);
                 float4 v;
                 v.x = fmaf(acc[c][i][4 * rg + 0], unscale, bv.x);     // unscale = 2^-k exactly: one rounding, like acc + bias
                 v.y = fmaf(acc[c][i][4 * rg + 1], unscale, bv.y);
@@ -702,20 +675,13 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::WGS_PER_CU) void conv_bf6_kernel(cons
 // loop has no ring and no barrier of its own.  A workgroup walks a contiguous range of tiles (all tiles of a sample in a row:
 // halo rows come from its own XCD's L2).
 // =============================================================================================
-template <class Cfg, int NCW_ = 8, int NPW_ = 8, int NGRP_ = 1>
+template <class Cfg>
 struct WsCfg {
-    // NCW consumer waves of TH / NCW output rows each, NPW producer waves (round 3: 8 x 1 row + 8; round 6: 4 x 2 rows, one consumer
-    // per SIMD with two accumulators sharing every weight fragment, + 8)
-    static constexpr int NCONS_W = NCW_, NPW = NPW_, NT = 64 * (NCW_ + NPW_), NPROD = 64 * NPW_;
-    // NGRP consumer groups take the tiles of the workgroup in turn (group = tile & 1): while one group runs the matrix steps of its
-    // tile, the other finishes the epilogue of the previous one (bias, stores, GroupNorm sums: as long as a unit's matrix steps)
-    static constexpr int NGRP = NGRP_, GW = NCW_ / NGRP_;            // waves per group
-    static constexpr int PTW = Cfg::TH / GW;                         // output rows (pixel tiles) per consumer wave
+    static constexpr int NCONS_W = 8, NT = 1024, NPROD = 512;        // 8 consumer waves (one output row each), 8 producer waves
     static constexpr int UITERS = (Cfg::UNITS + NPROD - 1) / NPROD;
     static constexpr int W_B = Cfg::NPASS * Cfg::NKS * Cfg::WSTEP_B;
     static constexpr size_t LDS_BYTES = 2 * (size_t)Cfg::IN_B + W_B + 2 * (size_t)Cfg::CIN * 8 + 2 * 8 * 16 + 64 + Cfg::COUT * 4;
-    static_assert(Cfg::CBW == 1 && Cfg::CSPLIT == 1 && Cfg::OUT_OCT && !Cfg::ROWS2 && Cfg::TH == GW * PTW && Cfg::TH == 8 && (NGRP == 1 || NGRP == 2),
-                  "built for conv2's shape");
+    static_assert(Cfg::CBW == 1 && Cfg::CSPLIT == 1 && Cfg::OUT_OCT && !Cfg::ROWS2 && Cfg::TH == NCONS_W, "built for conv2's shape");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -737,13 +703,20 @@ struct WsUnits {
     }
 };
 
+// dbg (STRIVE_CONV_WS_DBG, measurement only, results invalid): 1 = consumers skip the matrix steps, 2 = producers skip the staging,
+// 4 = producers skip the input loads, 8 = every unit loads the same (L2-resident) tile, 16 = consumers skip the epilogue.
+// tprof (bench-layer code 81): clock sums of consumer wave 0 (matrix steps, epilogue, barrier wait) and of the first producer wave
+// (request, stage, barrier wait).  What they showed in round 6 (profiles/r06_conv_ws_decomposition.txt): matrix steps alone 115 us,
+// + epilogue 40 (in series with them), producers alone 117 us (memory), all together 190: two pipelines of about the same service
+// time coupled by a barrier per unit -- the sum of the per-unit maxima, not the maximum of the sums.
 // ---- producer waves (8-15): own function = own register allocation (raw prefetch sets; the consumers keep accumulators) ----
-template <class Cfg, class W, int VAR = 0>
+template <class Cfg>
 __device__ __forceinline__ void ws_producer(const float* __restrict__ in, const GNStats* __restrict__ st_in, const float* __restrict__ gn_g,
                                          const float* __restrict__ gn_b, float xscale, unsigned char* s_in, float* s_gn,
-                                         WsUnits<Cfg> un, int dbg, unsigned long long* __restrict__ tprof = nullptr) {
+                                         WsUnits<Cfg> un, int dbg, unsigned long long* __restrict__ tprof) {
+    using W = WsCfg<Cfg>;
     constexpr int CIN = Cfg::CIN, IH = Cfg::IH, TH = Cfg::TH, TW = Cfg::TW, ITW = Cfg::ITW;
-    long long tp_req = 0, tp_stage = 0, tp_bar = 0;                 // (tprof: measurement hook, first producer wave)
+    long long tp_req = 0, tp_stage = 0, tp_bar = 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ptid = tid - 64 * W::NCONS_W;
@@ -751,15 +724,13 @@ __device__ __forceinline__ void ws_producer(const float* __restrict__ in, const 
     // Two register sets: the loads of unit u + 1 are requested before unit u is staged, a whole unit ahead of their use.  The loads
     // are UNCONDITIONAL (addresses clamped into the tensor; stage() zeroes what lies outside): with predicated loads the compiler
     // cannot count what is outstanding and waits for ALL of it (s_waitcnt vmcnt(0)) before staging, i.e. also for the loads it
-    // has just issued -- the period was then load latency + staging, whatever the prefetch distance.
-    // VAR bit 7: a THIRD register set, loads requested two units ahead.  A unit's 40 KB are in flight for one barrier interval
-    // (~3 us) otherwise: less than this CU's share of the HBM rate x the latency under load (Little: ~16 B/clk x 4 k clk = 64 KB)
-    constexpr bool DEEP = (VAR & 128) != 0;
-    float4 raw0[W::UITERS][2], raw1[W::UITERS][2], raw2[DEEP ? W::UITERS : 1][2];
+    // has just issued -- the period was then load latency + staging, whatever the prefetch distance.  (A third set, loads two units
+    // ahead, changed nothing in round 6: 194 against 193 us.)
+    float4 raw0[W::UITERS][2], raw1[W::UITERS][2];
     auto issue_loads = [&](int u, float4 (&raw)[W::UITERS][2]) {
         int n, ty, tx, pass;
         un.tile(u, n, ty, tx, pass);
-        const float* in_n = in + (size_t)((dbg & 8) ? 0 : n) * IH * IH * CIN;            // (dbg 8: every unit re-reads sample 0's first tile: L2 hits)
+        const float* in_n = in + (size_t)((dbg & 8) ? 0 : n) * IH * IH * CIN;
         const int iy0 = (dbg & 8) ? 0 : 2 * ty * TH, ix0 = (dbg & 8) ? 0 : 2 * tx * TW;
 #pragma unroll
         for (int k = 0; k < W::UITERS; ++k) {
@@ -833,7 +804,7 @@ __device__ __forceinline__ void ws_producer(const float* __restrict__ in, const 
     int cur_sample;
     auto request = [&](int u, float4 (&raw)[W::UITERS][2]) {       // loads of unit u (+ its sample's scale / shift when it is a new one)
         if (u >= nunit) return;
-        if (!(dbg & 4)) issue_loads(u, raw);                      // (dbg 4: timing probe)
+        if (!(dbg & 4)) issue_loads(u, raw);
         int n, ty, tx, pass;
         un.tile(u, n, ty, tx, pass);
         if (n != cur_sample) {                                    // (its slot s_gn[n & 1] was last read while staging sample n - 2)
@@ -843,7 +814,7 @@ __device__ __forceinline__ void ws_producer(const float* __restrict__ in, const 
     };
     cur_sample = -1;
     request(0, raw0);
-    __syncthreads();                                              // (1) weights and the first sample's scale / shift are in LDS
+    __syncthreads();                                              // (1) weights, bias and the first sample's scale / shift are in LDS
     auto iteration = [&](int u, float4 (&raw_cur)[W::UITERS][2], float4 (&raw_next)[W::UITERS][2]) {
         const long long t0 = tprof ? clock64() : 0;
         request(u + 1, raw_next);
@@ -853,29 +824,9 @@ __device__ __forceinline__ void ws_producer(const float* __restrict__ in, const 
         __syncthreads();
         if (tprof) { tp_req += t1 - t0; tp_stage += t2 - t1; tp_bar += clock64() - t2; }
     };
-    const int nlast = nunit + (W::NGRP == 2 ? 2 : 0);             // the consumers' last barrier (two more iterations of deferred epilogues)
-    if constexpr (DEEP) {
-        float4 (&r2)[W::UITERS][2] = raw2;
-        request(1, raw1);                                         // (issued behind barrier (1): harmless, the sets are registers)
-        auto iteration2 = [&](int u, float4 (&raw_cur)[W::UITERS][2], float4 (&raw_next2)[W::UITERS][2]) {
-            const long long t0 = tprof ? clock64() : 0;
-            request(u + 2, raw_next2);
-            const long long t1 = tprof ? clock64() : 0;
-            if (u < nunit && !(dbg & 2)) stage(u, raw_cur);
-            const long long t2 = tprof ? clock64() : 0;
-            __syncthreads();
-            if (tprof) { tp_req += t1 - t0; tp_stage += t2 - t1; tp_bar += clock64() - t2; }
-        };
-        for (int u = 0; u <= nlast; u += 3) {
-            iteration2(u, raw0, r2);
-            if (u + 1 <= nlast) iteration2(u + 1, raw1, raw0);
-            if (u + 2 <= nlast) iteration2(u + 2, r2, raw1);
-        }
-    } else {
-        for (int u = 0; u <= nlast; u += 2) {
-            iteration(u, raw0, raw1);
-            if (u + 1 <= nlast) iteration(u + 1, raw1, raw0);
-        }
+    for (int u = 0; u <= nunit; u += 2) {
+        iteration(u, raw0, raw1);
+        if (u + 1 <= nunit) iteration(u + 1, raw1, raw0);
     }
     if (tprof && ptid == 0) {
         atomicAdd(tprof + 4, (unsigned long long)tp_req);
@@ -884,31 +835,28 @@ __device__ __forceinline__ void ws_producer(const float* __restrict__ in, const 
     }
 }
 
-// ---- consumer waves (0 .. NCW-1): wave w owns output rows PTW w .. PTW w + PTW - 1 of the 8-row tile ----
-template <class Cfg, class W, int VAR>
-__device__ __forceinline__ void ws_consumer(const unsigned char* s_in, const unsigned char* s_w, double* s_red, const float* __restrict__ bias,
-                                         const float* s_bias, float* __restrict__ out, GNStats* __restrict__ st_out, float unscale,
-                                         WsUnits<Cfg> un, int dbg, unsigned long long* __restrict__ tprof = nullptr) {
+// ---- consumer waves (0-7): wave w owns output row w of the 8-row tile ----
+template <class Cfg>
+__device__ __forceinline__ void ws_consumer(const unsigned char* s_in, const unsigned char* s_w, double* s_red, const float* s_bias,
+                                         float* __restrict__ out, GNStats* __restrict__ st_out, float unscale, WsUnits<Cfg> un, int dbg,
+                                         unsigned long long* __restrict__ tprof) {
+    constexpr int COUT = Cfg::COUT, OH = Cfg::OH, TH = Cfg::TH, TW = Cfg::TW, NKS = Cfg::NKS, NPASS = Cfg::NPASS;
     long long tc_mat = 0, tc_epi = 0, tc_bar = 0, tc_mark = 0;
-    constexpr int COUT = Cfg::COUT, OH = Cfg::OH, TH = Cfg::TH, TW = Cfg::TW, NKS = Cfg::NKS, NPASS = Cfg::NPASS, PTW = W::PTW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
     const int nunit = un.nunit;
-    f32x16 acc[PTW];
-    const int grp = wave / W::GW, gwave = wave - grp * W::GW;         // consumer group, wave inside the group
-    const int lane_base = (2 * PTW * gwave) * Cfg::ROW_B + j * 16;
+    f32x16 acc0;
+    const int lane_base = (2 * wave) * Cfg::ROW_B + j * 16;
     auto matrix_steps = [&](int u) {
         int n, ty, tx, pass;
         un.tile(u, n, ty, tx, pass);
         const unsigned char* buf = s_in + (u & 1) * Cfg::IN_B;
         if (pass == 0) {
 #pragma unroll
-            for (int i = 0; i < PTW; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc0[r] = 0.f;
         }
-        f16x8 fa[2][2], fb[2][PTW][2];
+        f16x8 fa[2][2], fb[2][2];
         auto load_frags = [&](int t, int set) {
             int ky, kx;
             if (Cfg::KS == 5) {
@@ -923,13 +871,8 @@ __device__ __forceinline__ void ws_consumer(const unsigned char* s_in, const uns
             const unsigned char* wb = s_w + (size_t)(pass * NKS + t) * Cfg::WSTEP_B + lane * 16;
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
-                if (!(VAR & 16) || t == 0) fa[set][pl] = *reinterpret_cast<const f16x8*>(wb + pl * 1024);      // (8, 16: timing probes, results invalid)
-                else fa[set][pl] = fa[set ^ 1][pl];
-#pragma unroll
-                for (int i = 0; i < PTW; ++i) {
-                    if (!(VAR & 8) || t == 0) fb[set][i][pl] = *reinterpret_cast<const f16x8*>(buf + pl * Cfg::PIECE_B + 2 * i * Cfg::ROW_B + lane_base + off);
-                    else fb[set][i][pl] = fb[set ^ 1][i][pl];
-                }
+                fa[set][pl] = *reinterpret_cast<const f16x8*>(wb + pl * 1024);
+                fb[set][pl] = *reinterpret_cast<const f16x8*>(buf + pl * Cfg::PIECE_B + lane_base + off);
             }
         };
         load_frags(0, 0);
@@ -940,65 +883,45 @@ __device__ __forceinline__ void ws_consumer(const unsigned char* s_in, const uns
             constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
 #pragma unroll
             for (int term = 0; term < 3; ++term)
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][TA[term]], fb[cur][TB[term]], acc0, 0, 0, 0);
+            // issue order pinned (round 6): one fragment read of step s+1 behind each matrix instruction of step s.  Left to itself the
+            // scheduler (which does not know that the dynamic LDS allocation admits one workgroup per CU, and so minimises registers)
+            // re-reads each weight fragment into ONE register set just before its use: ds_read, s_waitcnt lgkmcnt(0), two matrix
+            // instructions, ds_read ... -- an exposed LDS round trip per pair of matrix instructions.
+            if (s2 + 1 < NKS) {
 #pragma unroll
-                for (int i = 0; i < PTW; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][TA[term]], fb[cur][i][TB[term]], acc[i], 0, 0, 0);
-            if (VAR & 4) {
-                // issue order pinned: one fragment read of step s+1 behind each matrix instruction of step s.  Left to itself the
-                // scheduler (which does not know that the dynamic LDS allocation admits one workgroup per CU, and so minimises
-                // registers) re-reads each weight fragment into ONE register set just before its use: ds_read, s_waitcnt
-                // lgkmcnt(0), two matrix instructions, ds_read ... -- an exposed LDS round trip per pair of matrix instructions.
-                if (s2 + 1 < NKS) {
-                    constexpr int NRD = 2 + 2 * PTW, NMF = 3 * PTW;
-#pragma unroll
-                    for (int q = 0; q < (NRD < NMF ? NRD : NMF); ++q) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
-                    if (NMF > NRD) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
-                    if (NRD > NMF) __builtin_amdgcn_sched_group_barrier(0x100, NRD - NMF, 0);
+                for (int q = 0; q < 3; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (tprof) tc_mark = clock64();
-    };
-    // ---- epilogue of rows [i0, i1) of this wave's rows of the tile whose last unit is u ----
-    auto epilogue_rows = [&](int u, int i0, int i1) {
-        int n, ty, tx, pass;
-        un.tile(u, n, ty, tx, pass);
-        const int tl = (u / NPASS) & 1;
+        if (pass + 1 < NPASS || (dbg & 16)) return;
+        // ---- epilogue of the tile: the bias comes from LDS (see conv_bf6_kernel) ----
+        const int oy = ty * TH + wave, ox = tx * TW + j;
+        const bool valid = oy < OH && ox < OH;
+        float fsum = 0.f, fsq = 0.f;
 #pragma unroll
-        for (int i = 0; i < PTW; ++i) {
-            if (i < i0 || i >= i1) continue;
-            const int row = PTW * gwave + i;
-            const int oy = ty * TH + row, ox = tx * TW + j;
-            const bool valid = oy < OH && ox < OH;
-            float fsum = 0.f, fsq = 0.f;
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int co = 8 * rg + 4 * h;
-                const float4 bv = *reinterpret_cast<const float4*>(((VAR & 2) ? s_bias : bias) + co);   // (VAR bit 1: see conv_bf6_kernel)
-                float4 v;
-                v.x = fmaf(acc[i][4 * rg + 0], unscale, bv.x);
-                v.y = fmaf(acc[i][4 * rg + 1], unscale, bv.y);
-                v.z = fmaf(acc[i][4 * rg + 2], unscale, bv.z);
-                v.w = fmaf(acc[i][4 * rg + 3], unscale, bv.w);
-                if (valid) {
-                    if (!(VAR & 256))    // (256, 512: timing probes, results invalid)
-                        *reinterpret_cast<float4*>(out + ((((size_t)n * (COUT / 8) + (co >> 3)) * OH + oy) * OH + ox) * 8 + (co & 7)) = v;
-                    fsum += (v.x + v.y) + (v.z + v.w);
-                    fsq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fsq))));
-                }
+        for (int rg = 0; rg < 4; ++rg) {
+            const int co = 8 * rg + 4 * h;
+            const float4 bv = *reinterpret_cast<const float4*>(s_bias + co);
+            float4 v;
+            v.x = fmaf(acc0[4 * rg + 0], unscale, bv.x);
+            v.y = fmaf(acc0[4 * rg + 1], unscale, bv.y);
+            v.z = fmaf(acc0[4 * rg + 2], unscale, bv.z);
+            v.w = fmaf(acc0[4 * rg + 3], unscale, bv.w);
+            if (valid) {
+                *reinterpret_cast<float4*>(out + ((((size_t)n * (COUT / 8) + (co >> 3)) * OH + oy) * OH + ox) * 8 + (co & 7)) = v;
+                fsum += (v.x + v.y) + (v.z + v.w);
+                fsq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fsq))));
             }
-            // one float64 partial per output row, whatever the wave split: the tile's moments are the same bits in every form
-            if (VAR & 512) {
-                if (lane == 0) { s_red[(tl * 8 + row) * 2] = (double)fsum; s_red[(tl * 8 + row) * 2 + 1] = (double)fsq; }
-                continue;
-            }
-            const double lsum = wave_sum_d((double)fsum), lsq = wave_sum_d((double)fsq);
-            if (lane == 0) { s_red[(tl * 8 + row) * 2] = lsum; s_red[(tl * 8 + row) * 2 + 1] = lsq; }
         }
+        const double lsum = wave_sum_d((double)fsum), lsq = wave_sum_d((double)fsq);
+        const int tl = (u / NPASS) & 1;
+        if (lane == 0) { s_red[(tl * 8 + wave) * 2] = lsum; s_red[(tl * 8 + wave) * 2 + 1] = lsq; }
     };
     auto publish_stats = [&](int u) {                              // thread 0, one barrier after the tile's epilogue
         int n, ty, tx, pass;
@@ -1011,46 +934,16 @@ __device__ __forceinline__ void ws_consumer(const unsigned char* s_in, const uns
         o.sq = b;
     };
     __syncthreads();                                              // (1)
-    auto last_pass = [&](int L) { return L >= 0 && L < nunit && (L % NPASS) == NPASS - 1; };
-    if constexpr (W::NGRP == 1) {
-        for (int u = 0; u <= nunit; ++u) {
-            const long long t0 = tprof ? clock64() : 0;
-            tc_mark = t0;
-            if (u >= 1 && !(dbg & 1)) {
-                matrix_steps(u - 1);
-                if (last_pass(u - 1) && !(dbg & 16)) epilogue_rows(u - 1, 0, PTW);
-            }
-            if (tid == 0 && last_pass(u - 2)) publish_stats(u - 2);
-            const long long t1 = tprof ? clock64() : 0;
-            __syncthreads();
-            if (tprof) { tc_mat += tc_mark - t0; tc_epi += t1 - tc_mark; tc_bar += clock64() - t1; }
-        }
-        if (tid == 0 && last_pass(nunit - 1)) publish_stats(nunit - 1);
-    } else {
-        // Two groups: tile T (units NPASS T .. NPASS T + NPASS - 1, processed in iterations NPASS T + 1 ...) belongs to group T & 1.  The
-        // epilogue of its row i runs in iteration (last unit) + 2 + i -- while the OTHER group runs the matrix steps of tile T + 1 --
-        // and thread 0 publishes the tile's moments one barrier after its last row.
-        static_assert(W::NGRP == 1 || PTW <= NPASS, "a group's idle iterations (NPASS per tile) take one row each");
-        for (int u = 0; u <= nunit + 2; ++u) {
-            const long long t0 = tprof ? clock64() : 0;
-            tc_mark = t0;
-            if (u >= 1 && u - 1 < nunit && !(dbg & 1) && (((u - 1) / NPASS) & 1) == grp) matrix_steps(u - 1);
-            else tc_mark = t0;
-#pragma unroll
-            for (int i = 0; i < PTW; ++i) {
-                const int L = u - 2 - i;
-                if (last_pass(L) && ((L / NPASS) & 1) == grp && !(dbg & 17)) epilogue_rows(L, i, i + 1);
-            }
-            if (tid == 0 && last_pass(u - 2 - PTW)) publish_stats(u - 2 - PTW);
-            const long long t1 = tprof ? clock64() : 0;
-            __syncthreads();
-            if (tprof) { tc_mat += tc_mark - t0; tc_epi += t1 - tc_mark; tc_bar += clock64() - t1; }
-        }
-        if (tid == 0) {
-            for (int L = nunit + 1 - PTW; L < nunit; ++L)
-                if (last_pass(L)) publish_stats(L);
-        }
+    for (int u = 0; u <= nunit; ++u) {
+        const long long t0 = tprof ? clock64() : 0;
+        tc_mark = t0;
+        if (u >= 1 && !(dbg & 1)) matrix_steps(u - 1);
+        if (tid == 0 && u >= 2 && ((u - 2) % NPASS) == NPASS - 1) publish_stats(u - 2);
+        const long long t1 = tprof ? clock64() : 0;
+        __syncthreads();
+        if (tprof) { tc_mat += tc_mark - t0; tc_epi += t1 - tc_mark; tc_bar += clock64() - t1; }
     }
+    if (tid == 0 && ((nunit - 1) % NPASS) == NPASS - 1) publish_stats(nunit - 1);
     if (tprof && tid == 0) {
         atomicAdd(tprof + 0, 1ull);
         atomicAdd(tprof + 1, (unsigned long long)tc_mat);
@@ -1059,13 +952,13 @@ __device__ __forceinline__ void ws_consumer(const unsigned char* s_in, const uns
     }
 }
 
-template <class Cfg, int NCW = 8, int NPW = 8, int VAR = 6, int NGRP = 1>
-__global__ __launch_bounds__(64 * (NCW + NPW), 1) void conv_ws_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
+template <class Cfg>
+__global__ __launch_bounds__(1024, 1) void conv_ws_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
                                                            const float* __restrict__ gn_g, const float* __restrict__ gn_b,
                                                            const uint32_t* __restrict__ wfrag, const float* __restrict__ bias,
                                                            float* __restrict__ out, GNStats* __restrict__ st_out, int N, float xscale,
                                                            float unscale, int dbg, unsigned long long* __restrict__ tprof) {
-    using W = WsCfg<Cfg, NCW, NPW, NGRP>;
+    using W = WsCfg<Cfg>;
     HIP_DYNAMIC_SHARED(float, smem)
     unsigned char* s_in = reinterpret_cast<unsigned char*>(smem);          // [2][IN_B]
     unsigned char* s_w = s_in + 2 * Cfg::IN_B;                              // [pass][step][piece][lane][16 B]
@@ -1082,11 +975,370 @@ __global__ __launch_bounds__(64 * (NCW + NPW), 1) void conv_ws_kernel(const floa
     const int t_end = (un.t_begin + per) < total ? (un.t_begin + per) : total;
     un.nunit = (t_end > un.t_begin ? t_end - un.t_begin : 0) * Cfg::NPASS;
     for (int i = tid; i < W::W_B / 16; i += W::NT) reinterpret_cast<uint4*>(s_w)[i] = reinterpret_cast<const uint4*>(wfrag)[i];
-    if ((VAR & 2) && tid < Cfg::COUT) s_bias[tid] = bias[tid];
+    if (tid < Cfg::COUT) s_bias[tid] = bias[tid];
     if (un.nunit == 0) return;
     // both roles execute the same sequence of barriers: (1), then one per unit
-    if (wave >= W::NCONS_W) ws_producer<Cfg, W, VAR>(in, st_in, gn_g, gn_b, xscale, s_in, s_gn, un, dbg, tprof);
-    else ws_consumer<Cfg, W, VAR>(s_in, s_w, s_red, bias, s_bias, out, st_out, unscale, un, dbg, tprof);
+    if (wave >= W::NCONS_W) ws_producer<Cfg>(in, st_in, gn_g, gn_b, xscale, s_in, s_gn, un, dbg, tprof);
+    else ws_consumer<Cfg>(s_in, s_w, s_red, s_bias, out, st_out, unscale, un, dbg, tprof);
+}
+
+// =============================================================================================
+// Specialised waves for the layers whose weight fragments do NOT fit LDS (conv3: 208 KB, conv4: 147 KB) -- round 6.
+// conv_bf6_kernel's phases (fetch -> GroupNorm + split -> matrix steps -> epilogue) run one after the other inside a workgroup and
+// overlap only by chance across the two workgroups of a CU (tools/conv_floor_probe.py: conv3 = 84 us without matrix steps + 71 us of
+// matrix steps).  Here ONE persistent workgroup per CU of 12 waves walks a contiguous range of (tile, 8-channel pass) units:
+//   waves 0-3   CONSUME: the matrix steps of conv_bf6_kernel on the same pixel tiles in the same order (bit-identical outputs and
+//               moments), reading the unit's input from one of two LDS buffers and its weight fragments from one of two LDS
+//               weight buffers; the tile's epilogue after its last pass;
+//   waves 4-10  PRODUCE: fetch the next unit's 8-channel slice a whole unit ahead into two register sets (unconditional loads:
+//               countable), GroupNorm + ReLU + two-piece fp16 split, write the other input buffer;
+//   wave 11     STREAMS the weights: a unit's 13 matrix steps are two SUB-UNITS of 7 + 6 steps (28 + 24 KB of fragments; the 5 steps
+//               of a 3x3 layer are one), loaded into the weight buffer the consumers are not reading.
+// One barrier per sub-unit: none inside the matrix loop, no per-step weight ring.
+// =============================================================================================
+template <class Cfg, int NPW_ = 7>
+struct WxCfg {
+    static constexpr int NCW = Cfg::NW, GW = Cfg::NW, NPW = NPW_, NT = 64 * (NCW + NPW + 1), NPROD = 64 * NPW;
+    static constexpr int NSUB = Cfg::NKS > 7 ? 2 : 1;                          // weight sub-units per unit
+    static constexpr int SUB_STEPS = (Cfg::NKS + NSUB - 1) / NSUB;             // 7 (13 = 7 + 6) / 5
+    static constexpr int WSUB_B = SUB_STEPS * Cfg::WSTEP_B;
+    static constexpr int WCHUNKS = WSUB_B / 1024;                              // 1 KB (64 lanes x 16 B) pieces of a sub-unit
+    static constexpr int UITERS = (Cfg::UNITS + NPROD - 1) / NPROD;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)Cfg::IN_B + 2 * (size_t)WSUB_B + 2 * (size_t)Cfg::CIN * 8 + 2 * GW * 16 + Cfg::COUT * 4 + 64;
+    static_assert(Cfg::CSPLIT == 1 && Cfg::OUT_OCT && Cfg::NW == 4, "one workgroup computes all output channels of its tile");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(NT <= 1024, "waves");
+};
+
+template <class Cfg, class W>
+__device__ __forceinline__ void wx_producer(const float* __restrict__ in, const GNStats* __restrict__ st_in, const float* __restrict__ gn_g,
+                                         const float* __restrict__ gn_b, float xscale, unsigned char* s_in, float* s_gn, WsUnits<Cfg> un,
+                                         int dbg) {
+    // dbg (STRIVE_CONV_WS_DBG, timing probes, results invalid): 1 = no matrix steps, 2 = no staging, 4 = no input loads, 8 = no weight stream,
+    // 16 = no epilogue
+    constexpr int CIN = Cfg::CIN, IH = Cfg::IH, TH = Cfg::TH, TW = Cfg::TW, ITW = Cfg::ITW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ptid = tid - 64 * W::NCW;
+    const int nunit = un.nunit;
+    float4 raw0[W::UITERS][2], raw1[W::UITERS][2];
+    auto issue_loads = [&](int u, float4 (&raw)[W::UITERS][2]) {
+        int n, ty, tx, pass;
+        un.tile(u, n, ty, tx, pass);
+        const float* in_n = in + (size_t)n * IH * IH * CIN;
+        const int iy0 = 2 * ty * TH, ix0 = 2 * tx * TW;
+#pragma unroll
+        for (int k = 0; k < W::UITERS; ++k) {
+            int idx = ptid + k * W::NPROD;
+            idx = idx < Cfg::UNITS ? idx : Cfg::UNITS - 1;
+            const int col = idx % ITW, r = idx / ITW;
+            int iy = iy0 + r, ix = ix0 + col;
+            iy = iy < IH ? iy : IH - 1;
+            ix = ix < IH ? ix : IH - 1;
+            const float4* src = reinterpret_cast<const float4*>(in_n + (((size_t)pass * IH + iy) * IH + ix) * 8);
+            raw[k][0] = src[0];
+            raw[k][1] = src[1];
+        }
+    };
+    auto sample_moments = [&](int n) {                            // first producer wave; fixed butterfly order like conv_bf6_kernel
+        double ps = 0.0, pq = 0.0;
+        for (int i = lane; i < Cfg::NPART_IN; i += 64) {
+            ps += st_in[(size_t)n * Cfg::NPART_IN + i].sum;
+            pq += st_in[(size_t)n * Cfg::NPART_IN + i].sq;
+        }
+        ps = wave_sum_d(ps);
+        pq = wave_sum_d(pq);
+        const double cnt = (double)CIN * IH * IH;
+        const double mu = ps / cnt;
+        double var = pq / cnt - mu * mu;
+        var = var < 0.0 ? 0.0 : var;
+        const float mean = (float)mu, rstd = (float)(1.0 / sqrt(var + GN_EPS));
+        if (lane < CIN) {
+            const float sc = rstd * gn_g[lane];
+            float* g = s_gn + (n & 1) * CIN * 2;
+            g[2 * lane] = sc * xscale;
+            g[2 * lane + 1] = (gn_b[lane] - mean * sc) * xscale;
+        }
+    };
+    // iterations [k0, k1) of the staging of unit u: raw -> GroupNorm + ReLU -> two fp16 pieces -> s_in[u & 1]
+    auto stage = [&](int u, const float4 (&raw)[W::UITERS][2], int chunk) {
+        int n, ty, tx, pass;
+        un.tile(u, n, ty, tx, pass);
+        const int iy0 = 2 * ty * TH, ix0 = 2 * tx * TW;
+        unsigned char* buf = s_in + (u & 1) * Cfg::IN_B;
+        const float4* gn = reinterpret_cast<const float4*>(s_gn + (n & 1) * CIN * 2 + 2 * pass * Cfg::PASS_CH);
+        const float4 g0 = gn[0], g1 = gn[1], g2 = gn[2], g3 = gn[3];
+#pragma unroll
+        for (int k = 0; k < W::UITERS; ++k) {
+            if (chunk >= 0 && (k * W::NSUB) / W::UITERS != chunk) continue;
+            const int idx = ptid + k * W::NPROD;
+            if (idx < Cfg::UNITS) {
+                const int col = idx % ITW, r = idx / ITW;
+                const int iy = iy0 + r, ix = ix0 + col;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;             // exact zero outside the image
+                if (iy < IH && ix < IH) {
+                    const float4 a = raw[k][0], b = raw[k][1];
+                    v[0] = fmaxf(fmaf(a.x, g0.x, g0.y), 0.f);
+                    v[1] = fmaxf(fmaf(a.y, g0.z, g0.w), 0.f);
+                    v[2] = fmaxf(fmaf(a.z, g1.x, g1.y), 0.f);
+                    v[3] = fmaxf(fmaf(a.w, g1.z, g1.w), 0.f);
+                    v[4] = fmaxf(fmaf(b.x, g2.x, g2.y), 0.f);
+                    v[5] = fmaxf(fmaf(b.y, g2.z, g2.w), 0.f);
+                    v[6] = fmaxf(fmaf(b.z, g3.x, g3.y), 0.f);
+                    v[7] = fmaxf(fmaf(b.w, g3.z, g3.w), 0.f);
+                }
+                uint4 p0, p1;
+                split_f16x2(v, p0, p1);
+                unsigned char* dst = buf + r * Cfg::ROW_B + (col & 1) * Cfg::HALF_B + (col >> 1) * 16;
+                *reinterpret_cast<uint4*>(dst) = p0;
+                *reinterpret_cast<uint4*>(dst + Cfg::PIECE_B) = p1;
+            }
+        }
+    };
+    int cur_sample = -1;
+    auto request = [&](int u, float4 (&raw)[W::UITERS][2]) {       // loads of unit u (+ its sample's scale / shift when it is a new one)
+        if (u >= nunit) return;
+        if (!(dbg & 4)) issue_loads(u, raw);
+        int n, ty, tx, pass;
+        un.tile(u, n, ty, tx, pass);
+        if (n != cur_sample) {                                    // (slot s_gn[n & 1] was last read while staging sample n - 2)
+            if (wave == W::NCW) sample_moments(n);
+            cur_sample = n;
+        }
+    };
+    request(0, raw0);
+    __syncthreads();                                              // (1) the first sample's scale / shift
+    // interval 0: unit 0 whole
+    request(1, raw1);
+    if (!(dbg & 2)) stage(0, raw0, -1);
+    __syncthreads();
+    // intervals of unit us - 1 (consumers): stage unit us, chunk by chunk; the loads of unit us + 1 go out first
+    auto unit = [&](int us, float4 (&raw_cur)[W::UITERS][2], float4 (&raw_next)[W::UITERS][2]) {
+#pragma unroll
+        for (int h = 0; h < W::NSUB; ++h) {
+            if (h == 0) request(us + 1, raw_next);
+            if (us < nunit && !(dbg & 2)) stage(us, raw_cur, h);
+            __syncthreads();
+        }
+    };
+    for (int us = 1; us <= nunit; us += 2) {                      // (us == nunit: the consumers' last unit, nothing left to stage)
+        unit(us, raw1, raw0);
+        if (us + 1 <= nunit) unit(us + 1, raw0, raw1);
+    }
+}
+
+template <class Cfg, class W>
+__device__ __forceinline__ void wx_streamer(const uint32_t* __restrict__ wfrag, unsigned char* s_w, WsUnits<Cfg> un, int dbg) {
+    const int lane = threadIdx.x & 63;
+    const int nunit = un.nunit;
+    const uint4* wsrc = reinterpret_cast<const uint4*>(wfrag);
+    // sub-unit ks = (unit, half): steps [h SUB_STEPS, ...) of the unit's pass, contiguous in the fragment array
+    auto fill = [&](int ks) {
+        const int u = ks / W::NSUB, h = ks - u * W::NSUB;
+        int n, ty, tx, pass;
+        un.tile(u, n, ty, tx, pass);
+        const int s0 = h * W::SUB_STEPS;
+        const int nst = (Cfg::NKS - s0) < W::SUB_STEPS ? (Cfg::NKS - s0) : W::SUB_STEPS;
+        const uint4* src = wsrc + (size_t)(pass * Cfg::NKS + s0) * (Cfg::WSTEP_B / 16);
+        uint4* dst = reinterpret_cast<uint4*>(s_w + (ks & 1) * W::WSUB_B);
+        const int nchunk = nst * (Cfg::WSTEP_B / 1024);
+        uint4 w[W::WCHUNKS];
+#pragma unroll
+        for (int i = 0; i < W::WCHUNKS; ++i) w[i] = src[(i < nchunk ? i : nchunk - 1) * 64 + lane];   // unconditional: countable
+#pragma unroll
+        for (int i = 0; i < W::WCHUNKS; ++i)
+            if (i < nchunk) dst[i * 64 + lane] = w[i];
+    };
+    const int K = nunit * W::NSUB;
+    __syncthreads();                                              // (1)
+    fill(0);
+    __syncthreads();
+    for (int k = 1; k <= K; ++k) {
+        if (k < K && !(dbg & 8)) fill(k);
+        __syncthreads();
+    }
+}
+
+template <class Cfg, class W>
+__device__ __forceinline__ void wx_consumer(const unsigned char* s_in, const unsigned char* s_w, double* s_red, const float* s_bias,
+                                         float* __restrict__ out, GNStats* __restrict__ st_out, float unscale, WsUnits<Cfg> un, int dbg) {
+    constexpr int COUT = Cfg::COUT, OH = Cfg::OH, TH = Cfg::TH, TW = Cfg::TW, NKS = Cfg::NKS, NPASS = Cfg::NPASS, PT = Cfg::PT, CBW = Cfg::CBW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int nunit = un.nunit;
+    f32x16 acc[CBW][PT];
+    const int gwave = wave;
+    const int prow = Cfg::ROWS2 ? (j >> 4) : 0, pcol = Cfg::ROWS2 ? (j & 15) : j;
+    const int lane_base = (2 * (Cfg::TILE_ROWS * PT * gwave + prow)) * Cfg::ROW_B + pcol * 16;
+
+    // matrix steps [S0, S1) of unit u: conv_bf6_kernel's step body (same products, same order)
+    auto matrix_sub = [&](int u, auto HC) {
+        constexpr int HS = decltype(HC)::value;
+        constexpr int S0 = HS * W::SUB_STEPS, S1 = (S0 + W::SUB_STEPS) < NKS ? (S0 + W::SUB_STEPS) : NKS;
+        int n, ty, tx, pass;
+        un.tile(u, n, ty, tx, pass);
+        const unsigned char* buf = s_in + (u & 1) * Cfg::IN_B;
+        const unsigned char* wbuf = s_w + ((u * W::NSUB + HS) & 1) * W::WSUB_B;
+        if (pass == 0 && HS == 0) {
+#pragma unroll
+            for (int c = 0; c < CBW; ++c)
+#pragma unroll
+                for (int i = 0; i < PT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[c][i][r] = 0.f;
+        }
+        f16x8 fa[2][CBW][2], fb[2][PT][2];
+        auto load_frags = [&](int t, int set) {
+            int ky, kx;
+            if (Cfg::KS == 5) {
+                if (t < 10) { ky = t >> 1; kx = (t & 1) + 2 * h; }
+                else { ky = 2 * (t - 10) + h; kx = 4; ky = ky > 4 ? 4 : ky; }
+            } else {
+                if (t < 3) { ky = t; kx = 2 * h; }
+                else if (t == 3) { ky = h; kx = 1; }
+                else { ky = 2; kx = 1; }
+            }
+            const int off = ky * Cfg::ROW_B + (kx & 1) * Cfg::HALF_B + (kx >> 1) * 16;
+            const unsigned char* wb = wbuf + (t - S0) * Cfg::WSTEP_B + lane * 16;
+#pragma unroll
+            for (int c = 0; c < CBW; ++c)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) fa[set][c][pl] = *reinterpret_cast<const f16x8*>(wb + (c * 2 + pl) * 1024);
+#pragma unroll
+            for (int i = 0; i < PT; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    fb[set][i][pl] = *reinterpret_cast<const f16x8*>(buf + pl * Cfg::PIECE_B + 2 * Cfg::TILE_ROWS * i * Cfg::ROW_B + lane_base + off);
+        };
+        load_frags(S0, 0);
+#pragma unroll
+        for (int s = S0; s < S1; ++s) {
+            const int cur = (s - S0) & 1;
+            if (s + 1 < S1) load_frags(s + 1, cur ^ 1);
+            constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int c = 0; c < CBW; ++c)
+#pragma unroll
+                    for (int i = 0; i < PT; ++i)
+                        acc[c][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[cur][c][TA[term]], fb[cur][i][TB[term]], acc[c][i], 0, 0, 0);
+            if (s + 1 < S1) {
+                constexpr int NRD = 2 * CBW + 2 * PT, NMF = 3 * PT * CBW;
+#pragma unroll
+                for (int q = 0; q < (NRD < NMF ? NRD : NMF); ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                if (NMF > NRD) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
+                if (NRD > NMF) __builtin_amdgcn_sched_group_barrier(0x100, NRD - NMF, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // epilogue of the tile whose last unit is u, accumulator tiles [q0, q1) (q = c PT + i): conv_bf6_kernel's sums in the same order
+    // (per lane: fp32 over the 16 values of an accumulator tile, float64 above).  All bias values of a slice come from LDS up front,
+    // addresses are a uniform 64-bit sample base + a 32-bit lane offset.  After the last slice: wave sums -> s_red.
+    double dsum = 0.0, dsq = 0.0;
+    auto epilogue = [&](int u, int q0, int q1) {
+        int n, ty, tx, pass;
+        un.tile(u, n, ty, tx, pass);
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        float* out_n = out + (size_t)n * COUT * OH * OH;                  // [c/8][y][x][c%8]
+        constexpr int PLANE = OH * OH * 8;
+        if (q0 == 0) { dsum = 0.0; dsq = 0.0; }
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) {
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                if (c * PT + i < q0 || c * PT + i >= q1) continue;
+                float4 bv[4];
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) bv[rg] = *reinterpret_cast<const float4*>(s_bias + c * 32 + 8 * rg + 4 * h);
+                const int oy = oy0 + Cfg::TILE_ROWS * (PT * gwave + i) + prow, ox = ox0 + pcol;
+                const bool valid = oy < OH && ox < OH;
+                const int loff = (oy * OH + ox) * 8 + 4 * h;
+                float fsum = 0.f, fsq = 0.f;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    float4 v;
+                    v.x = fmaf(acc[c][i][4 * rg + 0], unscale, bv[rg].x);
+                    v.y = fmaf(acc[c][i][4 * rg + 1], unscale, bv[rg].y);
+                    v.z = fmaf(acc[c][i][4 * rg + 2], unscale, bv[rg].z);
+                    v.w = fmaf(acc[c][i][4 * rg + 3], unscale, bv[rg].w);
+                    if (valid) {
+                        if (!(dbg & 64)) *reinterpret_cast<float4*>(out_n + (loff + (c * 4 + rg) * PLANE)) = v;
+                        fsum += (v.x + v.y) + (v.z + v.w);
+                        fsq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fsq))));
+                    }
+                }
+                dsum += (double)fsum;
+                dsq += (double)fsq;
+            }
+        }
+        if (q1 == CBW * PT) {
+            const double lsum = wave_sum_d(dsum), lsq = wave_sum_d(dsq);
+            const int tl = (u / NPASS) & 1;
+            if (lane == 0) { s_red[(tl * W::GW + gwave) * 2] = lsum; s_red[(tl * W::GW + gwave) * 2 + 1] = lsq; }
+        }
+    };
+    auto publish_stats = [&](int u) {                              // thread 0, at least one barrier after the tile's last epilogue slice
+        int n, ty, tx, pass;
+        un.tile(u, n, ty, tx, pass);
+        const int tl = (u / NPASS) & 1;
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < W::GW; ++w) { a += s_red[(tl * W::GW + w) * 2]; b += s_red[(tl * W::GW + w) * 2 + 1]; }
+        GNStats& o = st_out[(size_t)n * Cfg::NPART_OUT + (ty * Cfg::TILES_X + tx)];
+        o.sum = a;
+        o.sq = b;
+    };
+    constexpr int NQ = CBW * PT;
+    __syncthreads();                                              // (1)
+    __syncthreads();                                              // interval 0: unit 0 staged, sub-unit 0's weights in LDS
+    for (int u = 0; u < nunit; ++u) {
+        if (!(dbg & 1)) matrix_sub(u, std::integral_constant<int, 0>());
+        if (tid == 0 && u >= 1 && ((u - 1) % NPASS) == NPASS - 1) publish_stats(u - 1);
+        if (W::NSUB == 1 && (u % NPASS) == NPASS - 1 && !(dbg & 16)) epilogue(u, 0, NQ);
+        __syncthreads();
+        if (W::NSUB == 2) {
+            if (!(dbg & 1)) matrix_sub(u, std::integral_constant<int, W::NSUB - 1>());
+            if ((u % NPASS) == NPASS - 1 && !(dbg & 16)) epilogue(u, 0, NQ);
+            __syncthreads();
+        }
+    }
+    if (tid == 0 && nunit >= 1 && ((nunit - 1) % NPASS) == NPASS - 1) publish_stats(nunit - 1);
+}
+
+template <class Cfg, int NPW = 7>
+__global__ __launch_bounds__(64 * (Cfg::NW + NPW + 1), 1) void conv_wsx_kernel(const float* __restrict__ in, const GNStats* __restrict__ st_in,
+                                                           const float* __restrict__ gn_g, const float* __restrict__ gn_b,
+                                                           const uint32_t* __restrict__ wfrag, const float* __restrict__ bias,
+                                                           float* __restrict__ out, GNStats* __restrict__ st_out, int N, float xscale,
+                                                           float unscale, int dbg) {
+    using W = WxCfg<Cfg, NPW>;
+    HIP_DYNAMIC_SHARED(float, smem)
+    unsigned char* s_in = reinterpret_cast<unsigned char*>(smem);          // [2][IN_B]
+    unsigned char* s_w = s_in + 2 * Cfg::IN_B;                              // [2][WSUB_B]
+    float* s_gn = (float*)(s_w + 2 * W::WSUB_B);                            // [2][CIN][2] scale, shift of the sample (parity)
+    double* s_red = (double*)(s_gn + 2 * Cfg::CIN * 2);                     // [2][GW][2]
+    float* s_bias = (float*)(s_red + 2 * W::GW * 2);                        // [COUT]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int total = N * Cfg::TILES_X * Cfg::TILES_Y;
+    const int per = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    WsUnits<Cfg> un;
+    un.t_begin = (int)blockIdx.x * per;
+    const int t_end = (un.t_begin + per) < total ? (un.t_begin + per) : total;
+    un.nunit = (t_end > un.t_begin ? t_end - un.t_begin : 0) * Cfg::NPASS;
+    if (un.nunit == 0) return;
+    if (tid < Cfg::COUT) s_bias[tid] = bias[tid];
+    // every role executes the same sequence of barriers: (1), interval 0, then one per sub-unit
+    if (wave < W::NCW) wx_consumer<Cfg, W>(s_in, s_w, s_red, s_bias, out, st_out, unscale, un, dbg);
+    else if (wave < W::NCW + W::NPW) wx_producer<Cfg, W>(in, st_in, gn_g, gn_b, xscale, s_in, s_gn, un, dbg);
+    else wx_streamer<Cfg, W>(wfrag, s_w, un, dbg);
 }
 
 // =============================================================================================
@@ -1379,16 +1631,16 @@ typedef BfsCfg<128, 128, 6, 2, 32, Bfs5::NPART_OUT, false, 1, 2> Bfs6;  // conv6
 // is faster alone and in the two-stream open loop (17.9 against 18.35 ms) but costs the closed loop 1 ms (22.8 against 21.9 ms;
 // leaving 16 or 32 CUs free changes nothing: profiles/r03_ab_conv_ws_closed_loop.json).
 
-// the specialised-wave form (conv_ws_kernel): one persistent workgroup per CU; STRIVE_CONV_WS=0 keeps conv_bf6_kernel (A/B)
-template <class Cfg, int NCW = 8, int NPW = 8, int VAR = 6, int NGRP = 1>
+// the specialised-wave form (conv_ws_kernel): one persistent workgroup per CU; option conv_ws = 0 keeps conv_bf6_kernel (A/B)
+template <class Cfg>
 static int launch_ws(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
                      const float* bias, float* out, GNStats* st_out, int N, float xscale, float wscale, hipStream_t stream,
                      unsigned long long* tprof = nullptr) {
-    using W = WsCfg<Cfg, NCW, NPW, NGRP>;
+    using W = WsCfg<Cfg>;
     static PerDeviceOnce once;
     const int dev = once.device();
     if (!once.is_done(dev)) {
-        hipFuncSetAttribute((const void*)conv_ws_kernel<Cfg, NCW, NPW, VAR, NGRP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES);
+        hipFuncSetAttribute((const void*)conv_ws_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES);
         int v = 0;
         if (!(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)) v = 256;
         once.value[dev].store(v, std::memory_order_relaxed);
@@ -1397,28 +1649,47 @@ static int launch_ws(const float* in, const GNStats* st_in, const float* g, cons
     const int ncu = once.value[dev].load(std::memory_order_relaxed);
     const int total = N * Cfg::TILES_X * Cfg::TILES_Y;
     const int grid = total < ncu ? total : ncu;
-    // STRIVE_CONV_WS_DBG (measurement only, results invalid): 1 = consumers skip the matrix steps, 2 = producers skip the staging,
-    // 8 = every unit loads the same (L2-resident) tile
-    static const int dbg = getenv("STRIVE_CONV_WS_DBG") ? atoi(getenv("STRIVE_CONV_WS_DBG")) : 0;
-    hipLaunchKernelGGL((conv_ws_kernel<Cfg, NCW, NPW, VAR, NGRP>), dim3(grid), dim3(W::NT), W::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out, st_out, N,
-                       xscale, 1.0f / (xscale * wscale), dbg, tprof);
+    hipLaunchKernelGGL(conv_ws_kernel<Cfg>, dim3(grid), dim3(W::NT), W::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out, st_out, N,
+                       xscale, 1.0f / (xscale * wscale), strive_tuning().conv_ws_dbg, tprof);
     return 0;
 }
 
-template <class Cfg, int VAR = 2>
+template <class Cfg, int NPW = 7>
+static int launch_wsx(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
+                      const float* bias, float* out, GNStats* st_out, int N, float xscale, float wscale, hipStream_t stream) {
+    using W = WxCfg<Cfg, NPW>;
+    static PerDeviceOnce once;
+    const int dev = once.device();
+    if (!once.is_done(dev)) {
+        hipFuncSetAttribute((const void*)conv_wsx_kernel<Cfg, NPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES);
+        int v = 0;
+        if (!(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)) v = 256;
+        once.value[dev].store(v, std::memory_order_relaxed);
+        once.set_done(dev);
+    }
+    const int ncu = once.value[dev].load(std::memory_order_relaxed);
+    const int total = N * Cfg::TILES_X * Cfg::TILES_Y;
+    const int grid = total < ncu ? total : ncu;
+    const int dbg = strive_tuning().conv_ws_dbg;
+    hipLaunchKernelGGL((conv_wsx_kernel<Cfg, NPW>), dim3(grid), dim3(W::NT), W::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out, st_out, N,
+                       xscale, 1.0f / (xscale * wscale), dbg);
+    return 0;
+}
+
+template <class Cfg>
 static int launch_bf6(const float* in, const GNStats* st_in, const float* g, const float* b, const uint32_t* wfrag,
                       const float* bias, float* out, GNStats* st_out, int N, float xscale, float wscale, hipStream_t stream) {
     dim3 grid(Cfg::TILES_X * Cfg::CSPLIT, Cfg::TILES_Y, (N + 7) / 8 * 8);      // z rounded up: see the id -> (sample, tile) map in the kernel
     static PerDeviceOnce once;
     const int dev = once.device();
     if (!once.is_done(dev)) {
-        hipFuncSetAttribute((const void*)conv_bf6_kernel<Cfg, false, 0, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+        hipFuncSetAttribute((const void*)conv_bf6_kernel<Cfg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
         once.set_done(dev);
     }
     // (round 5, tools/conv_dephase_probe.py at commit "dephase probe": holding back one of every two co-resident workgroups by a
     // fraction of a staging + matrix period -- by wave slot parity or by id -- changes conv2 / conv3 / conv4 by less than the
     // run-to-run noise, profiles/r05_conv_dephase_probe.txt: the workgroups of a CU do not run in lock step)
-    hipLaunchKernelGGL((conv_bf6_kernel<Cfg, false, 0, VAR>), grid, dim3(Cfg::NT), Cfg::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out,
+    hipLaunchKernelGGL((conv_bf6_kernel<Cfg>), grid, dim3(Cfg::NT), Cfg::LDS_BYTES, stream, in, st_in, g, b, wfrag, bias, out,
                        st_out, N, xscale, 1.0f / (xscale * wscale), (unsigned long long*)nullptr);
     return 0;
 }
@@ -1498,20 +1769,13 @@ constexpr int CNN_SMALL_BATCH = 96;
 // the fused tail takes ONE sample per workgroup up to here (bit-identical either way): -0.2 ms per closure at 192 samples,
 // -0.12 at 256, nothing at 512 (where the four-sample form keeps the weight streams per CU lower)
 constexpr int CNN_TAIL_ONE_SAMPLE = 256;
-// STRIVE_CNN_SMALL_BATCH=<n> moves the threshold (0: never), read per call: the tests and A/B runs exercise both chains in one process
-static int cnn_small_batch() {
-    const char* e = getenv("STRIVE_CNN_SMALL_BATCH");
-    return e ? atoi(e) : CNN_SMALL_BATCH;
-}
-// agents pushed through the layer stack together; STRIVE_CNN_CHUNK overrides (tuning knob, read once)
+// option cnn_small_batch moves the threshold (0: never): the tests and A/B runs exercise both chains in one process
+static int cnn_small_batch() { return strive_tuning().cnn_small_batch; }
+// agents pushed through the layer stack together (option cnn_chunk)
 static int cnn_chunk() {
-    static int v = 0;
-    if (!v) {
-        const char* e = getenv("STRIVE_CNN_CHUNK");
-        v = e ? atoi(e) : 512;
-        if (v < 8) v = 8;
-        if (v > CNN_CHUNK_MAX) v = CNN_CHUNK_MAX;
-    }
+    int v = strive_tuning().cnn_chunk;
+    if (v < 8) v = 8;
+    if (v > CNN_CHUNK_MAX) v = CNN_CHUNK_MAX;
     return v;
 }
 constexpr int NPARTS[6] = {l1b::NPART, Bf2::NPART_OUT, Bf3::NPART_OUT, Bf4::NPART_OUT, Bfs5::NPART_OUT, Bfs6::NPART_OUT};
@@ -1593,8 +1857,7 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
         memset(&s, 0, sizeof(s));
     }
     const int small_batch = cnn_small_batch();
-    int tail_force = 0;                                        // samples per workgroup of the fused tail (A/B switch: 1, 2 or 4)
-    if (const char* e = getenv("STRIVE_CNN_TAIL_S")) tail_force = atoi(e);
+    const int tail_force = strive_tuning().cnn_tail_s;         // samples per workgroup of the fused tail (A/B option: 1, 2 or 4; 0: by size)
     for (int n0 = 0; n0 < N; n0 += ch) {
         const int n = (N - n0) < ch ? (N - n0) : ch;
         GNStats* st[6];
@@ -1621,8 +1884,8 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
                                (const int32_t*)nullptr, crop + (size_t)n0 * 4 * 256 * 256, cnn->w1_frag, 1.0f / cnn->wscale[0],
                                (const float*)cnn->b[0], act[0], st[0]);
         }
-        // conv2: specialised producer / consumer waves (bit-identical to conv_bf6_kernel; STRIVE_CONV_WS=0 switches back)
-        static const bool conv_ws = !(getenv("STRIVE_CONV_WS") && atoi(getenv("STRIVE_CONV_WS")) == 0);
+        // conv2: specialised producer / consumer waves (bit-identical to conv_bf6_kernel; option conv_ws = 0 switches back)
+        const bool conv_ws = strive_tuning().conv_ws != 0;
         if (conv_ws && !cnn->conv2_plain)
             launch_ws<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], n, cnn->xscale[1], cnn->wscale[1], stream);
         else
@@ -1633,8 +1896,17 @@ static int cnn_run(const StriveMap* map, const StriveCNN* cnn, const float* pos,
             launch_cnn_tail(cnn, act[3], st[3], Bf4s::NPART_OUT, feat + (size_t)n0 * 64, n, stream, nullptr, tail_s);
             continue;
         }
-        launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
-        launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, cnn->xscale[3], cnn->wscale[3], stream);
+        // conv3 / conv4: specialised waves with the pass weights double-buffered through LDS (round 6; bit-identical to conv_bf6_kernel,
+        // which option conv_wsx = 0 and conv2_plain callers keep: a persistent 12-wave workgroup per CU leaves no room for another
+        // stream's small kernels)
+        const bool conv_wsx = strive_tuning().conv_wsx != 0;
+        if (conv_wsx && !cnn->conv2_plain) {
+            launch_wsx<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
+            launch_wsx<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, cnn->xscale[3], cnn->wscale[3], stream);
+        } else {
+            launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], n, cnn->xscale[2], cnn->wscale[2], stream);
+            launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], n, cnn->xscale[3], cnn->wscale[3], stream);
+        }
         if (!keep_tail_activations) {
             launch_cnn_tail(cnn, act[3], st[3], NPARTS[3], feat + (size_t)n0 * 64, n, stream, nullptr, tail_s, keep ? &tk : nullptr);
             continue;
@@ -1689,7 +1961,7 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
                                           const float* pos_mean4_host, const float* pos_std4_host, const int32_t* mapix,
                                           int32_t N, float* feat, void* ws, size_t ws_bytes, strive_stream_t stream_) {
     STRIVE_CHECK_ARG(map && cnn && pos && mapix && feat && ws, "null argument");
-    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK_MAX && layer >= 0 && layer <= 99, "bad layer / N");
+    STRIVE_CHECK_ARG(N > 0 && N <= CNN_CHUNK_MAX && layer >= 0 && layer <= 81, "bad layer / N");
     STRIVE_CHECK_ARG(ws_bytes >= strive_map_cnn_workspace_bytes(N), "workspace too small");
     hipStream_t stream = (hipStream_t)stream_;
     StriveArena ar(ws, ws_bytes);
@@ -1732,8 +2004,8 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
         case 31: case 32: case 33: case 34: case 41: case 42: case 43: case 44: {   // timing probes of conv2 (3x) / conv3 (4x): DBG 1..4, results invalid
             const int dbg = layer % 10;
 #define STRIVE_DBG_LAUNCH(CFG, D, IN, STI, G, B, W, BIAS, OUT, STO, L)                                                                   \
-    hipFuncSetAttribute((const void*)conv_bf6_kernel<CFG, false, D, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CFG::LDS_BYTES);   \
-    hipLaunchKernelGGL((conv_bf6_kernel<CFG, false, D, 0>), dim3(CFG::TILES_X * CFG::CSPLIT, CFG::TILES_Y, (N + 7) / 8 * 8), dim3(CFG::NT),  \
+    hipFuncSetAttribute((const void*)conv_bf6_kernel<CFG, false, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CFG::LDS_BYTES);   \
+    hipLaunchKernelGGL((conv_bf6_kernel<CFG, false, D>), dim3(CFG::TILES_X * CFG::CSPLIT, CFG::TILES_Y, (N + 7) / 8 * 8), dim3(CFG::NT),  \
                        CFG::LDS_BYTES, stream, IN, STI, G, B, W, BIAS, OUT, STO, N, cnn->xscale[L], 1.0f / (cnn->xscale[L] * cnn->wscale[L]), \
                        (unsigned long long*)nullptr)
             if (layer < 40) {
@@ -1752,70 +2024,14 @@ extern "C" int strive_map_cnn_bench_layer(const StriveMap* map, const StriveCNN*
         }
         case 1: launch_bf6<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
         case 51: launch_ws<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;   // conv2, specialised waves
-        case 52: launch_ws<Bf2, 4, 8>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;   // 4 consumer waves x 2 rows
-        case 53: launch_ws<Bf2, 4, 12>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
-        case 64: launch_bf6<Bf3, 2>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, cnn->xscale[2], cnn->wscale[2], stream); break;   // bias from LDS
-        case 65: launch_bf6<Bf3, 3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, cnn->xscale[2], cnn->wscale[2], stream); break;   // both
-        case 66: launch_bf6<Bf4, 3>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], N, cnn->xscale[3], cnn->wscale[3], stream); break;
-        case 67: launch_bf6<Bf2, 3>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
-        case 70:
-            hipLaunchKernelGGL((conv1b_kernel<true, 0, 1>), dim3(l1b::TILES_Y, 1, N), dim3(C1_NT), 0, stream, *map, pos, m, s,
-                               mapix, (const uint8_t*)nullptr, cnn->w1_frag, 1.0f / cnn->wscale[0], (const float*)cnn->b[0], act[0], st[0]);
-            break;
-        case 61: launch_bf6<Bf2, 1>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;   // unconditional input loads
-        case 62: launch_bf6<Bf3, 1>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, cnn->xscale[2], cnn->wscale[2], stream); break;
-        case 63: launch_bf6<Bf4, 1>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], N, cnn->xscale[3], cnn->wscale[3], stream); break;
-        case 55: launch_ws<Bf2, 8, 8, 2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;   // bias from LDS
-        case 56: launch_ws<Bf2, 4, 8, 2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
-        case 57: launch_ws<Bf2, 4, 12, 2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
-        case 58: launch_ws<Bf2, 8, 8, 6>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;   // + pinned issue order
-        case 59: launch_ws<Bf2, 4, 8, 6>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
-        case 60: launch_ws<Bf2, 4, 12, 6>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
-        case 71: launch_ws<Bf2, 4, 8, 6 + 8>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;   // probes
-        case 72: launch_ws<Bf2, 4, 8, 6 + 16>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
-        case 73: launch_ws<Bf2, 4, 8, 6 + 24>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
-        case 74: launch_ws<Bf2, 8, 8, 6 + 24>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
-        case 81: case 82: case 83: {   // phase profile of the specialised-wave conv2: clock sums of consumer wave 0 / the first producer wave land in `feat`
+        case 81: {   // phase profile of the specialised-wave conv2: clock sums of consumer wave 0 / the first producer wave land in `feat`
             unsigned long long* tp = reinterpret_cast<unsigned long long*>(feat);
             hipMemsetAsync(tp, 0, 64, stream);
-            if (layer == 81) launch_ws<Bf2, 8, 8, 6>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream, tp);
-            if (layer == 82) launch_ws<Bf2, 4, 8, 6>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream, tp);
-            if (layer == 83) launch_ws<Bf2, 4, 8, 6 + 24>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream, tp);
+            launch_ws<Bf2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream, tp);
             break;
         }
-        case 75: launch_ws<Bf2, 8, 8, 6, 2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;   // two consumer groups
-        case 84: {
-            unsigned long long* tp = reinterpret_cast<unsigned long long*>(feat);
-            hipMemsetAsync(tp, 0, 64, stream);
-            launch_ws<Bf2, 8, 8, 6, 2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream, tp);
-            break;
-        }
-        case 76: launch_ws<Bf2, 8, 8, 6 + 128>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;   // loads two units ahead
-        case 77: launch_ws<Bf2, 8, 8, 6 + 128, 2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
-        case 78: launch_ws<Bf2, 4, 8, 6 + 128>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
-        case 85: {
-            unsigned long long* tp = reinterpret_cast<unsigned long long*>(feat);
-            hipMemsetAsync(tp, 0, 64, stream);
-            launch_ws<Bf2, 8, 8, 6 + 128, 2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream, tp);
-            break;
-        }
-        case 86: case 87: case 88: {
-            unsigned long long* tp = reinterpret_cast<unsigned long long*>(feat);
-            hipMemsetAsync(tp, 0, 64, stream);
-            if (layer == 86) launch_ws<Bf2, 8, 8, 6 + 256, 2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream, tp);
-            if (layer == 87) launch_ws<Bf2, 8, 8, 6 + 512, 2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream, tp);
-            if (layer == 88) launch_ws<Bf2, 8, 8, 6 + 768, 2>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream, tp);
-            break;
-        }
-        case 90:   // round-5 forms (A/B): conv1 with the bias / tables from global memory and float64 sums per value
-            hipLaunchKernelGGL((conv1b_kernel<true, 0, 0>), dim3(l1b::TILES_Y, 1, N), dim3(C1_NT), 0, stream, *map, pos, m, s,
-                               mapix, (const uint8_t*)nullptr, cnn->w1_frag, 1.0f / cnn->wscale[0], (const float*)cnn->b[0], act[0], st[0]);
-            break;
-        case 91: launch_ws<Bf2, 8, 8, 0>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
-        case 92: launch_bf6<Bf2, 0>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
-        case 93: launch_bf6<Bf3, 0>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, cnn->xscale[2], cnn->wscale[2], stream); break;
-        case 94: launch_bf6<Bf4, 0>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], N, cnn->xscale[3], cnn->wscale[3], stream); break;
-        case 54: launch_ws<Bf2, 4, 4>(act[0], st[0], cnn->gn_g[0], cnn->gn_b[0], cnn->w2_frag, cnn->b[1], act[1], st[1], N, cnn->xscale[1], cnn->wscale[1], stream); break;
+        case 52: launch_wsx<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, cnn->xscale[2], cnn->wscale[2], stream); break;   // conv3, specialised waves + streamed weights
+        case 53: launch_wsx<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], N, cnn->xscale[3], cnn->wscale[3], stream); break;
         case 2: launch_bf6<Bf3>(act[1], st[1], cnn->gn_g[1], cnn->gn_b[1], cnn->w3_frag, cnn->b[2], act[2], st[2], N, cnn->xscale[2], cnn->wscale[2], stream); break;
         case 3: launch_bf6<Bf4>(act[2], st[2], cnn->gn_g[2], cnn->gn_b[2], cnn->w4_frag, cnn->b[3], act[3], st[3], N, cnn->xscale[3], cnn->wscale[3], stream); break;
         case 4: launch_bf6s<Bfs5>(act[3], st[3], cnn->gn_g[3], cnn->gn_b[3], cnn->w5_frag, cnn->b[4], act[4], st[4], N, cnn->xscale[4], cnn->wscale[4], stream); break;

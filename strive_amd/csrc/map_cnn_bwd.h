@@ -721,7 +721,7 @@ static int cnn_backward(const StriveMap* map, const StriveCNN* cnn, const float*
     float* feat = arena.feat;
     uint4* dfrag = arena.dfrag;
     float* wpart = arena.wpart;
-    static const bool dgrad_igemm = getenv("STRIVE_DGRAD_IGEMM") != nullptr;     // A/B switch: the fp32 implicit-GEMM form
+    const bool dgrad_igemm = strive_tuning().dgrad_igemm != 0;     // A/B switch: the fp32 implicit-GEMM form
     if (!dgrad_igemm) {
         DgradPackArgs pa;
         for (int l = 0; l < 6; ++l) pa.w[l] = cnn->w_torch[l];
@@ -792,8 +792,8 @@ static int cnn_backward(const StriveMap* map, const StriveCNN* cnn, const float*
             wp.gam_in = l > 0 ? cnn->gn_g[l - 1] : nullptr;
             wp.bet_in = l > 0 ? cnn->gn_b[l - 1] : nullptr;
             wp.dW = gp.w[l];
-            static const bool use_igemm = getenv("STRIVE_WGRAD_IGEMM") != nullptr;      // A/B switches: the round-2 implicit-GEMM form,
-            static const bool use_tile = getenv("STRIVE_WGRAD_TILE") != nullptr;        // the fp32 LDS-tile form
+            const bool use_igemm = strive_tuning().wgrad_igemm != 0;      // A/B switches: the round-2 implicit-GEMM form,
+            const bool use_tile = strive_tuning().wgrad_tile != 0;        // the fp32 LDS-tile form
             if (use_igemm) {
                 const int K = n * d.oh * d.oh, NN = d.cin * d.ks * d.ks;
                 wp.kchunk = 2048;

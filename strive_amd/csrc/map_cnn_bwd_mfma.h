@@ -611,7 +611,7 @@ static inline void launch_wgrad_mfma(const float* dy, const float* act_in, const
         hipFuncSetAttribute((const void*)wgrad_mfma_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
         once.set_done(dev_);
     }
-    static const int dbg = getenv("STRIVE_WGRAD_DBG") ? atoi(getenv("STRIVE_WGRAD_DBG")) : 0;
+    const int dbg = strive_tuning().wgrad_dbg;
     hipLaunchKernelGGL(wgrad_mfma_kernel<L>, dim3(gx, T::NSPLIT), dim3(256), T::LDS_BYTES, stream, dy, act_in, crop, mr_in, gam_in,
                        bet_in, partial, NS, dbg);
     hipLaunchKernelGGL(wgrad_reduce_kernel<L>, dim3(T::NSPLIT * T::NT * 16), dim3(1024), 0, stream, partial, dW, gx);

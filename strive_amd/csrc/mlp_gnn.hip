@@ -208,7 +208,7 @@ extern "C" int strive_gnn_bwd(const StriveGNN* gnn, const StriveScenes* sc, cons
     if (rc) return rc;
     const GNNDev gd = gnn_dev(*gnn);
     GNNGradDev gr = gnn_grad_dev(*gnn, d_params);
-    static const bool atomics_only = getenv("STRIVE_WGRAD_ATOMICS") != nullptr;      // A/B switch: no deferred weight gradients
+    const bool atomics_only = strive_tuning().wgrad_atomics != 0;      // A/B switch: no deferred weight gradients
     WJobsPlan plan = gnn_bwd_plan(*gnn, *sc, d_params, wtape);
     const bool deferred = !atomics_only && !plan.too_large && !plan.dropped && plan.t.n > 0;
     if (deferred) {

@@ -1018,7 +1018,7 @@ extern "C" int strive_planner_rollout(const StrivePlanner* pl, const double* age
     STRIVE_CHECK_ARG(L.total != 0, "workspace too small");
     Work& w = L.w;
     w.tprof = nullptr;
-    if (getenv("STRIVE_PLANNER_PROF")) {      // (measurement only: the last 64 bytes of the workspace's spare tail, accumulated over rollouts)
+    if (strive_tuning().planner_prof) {      // (measurement only: the last 64 bytes of the workspace's spare tail, accumulated over rollouts)
         w.tprof = reinterpret_cast<unsigned long long*>((char*)ws + ((L.total + 7) / 8) * 8 + 64);
     }
     hipMemsetAsync(w.traj_cnt, 0, sizeof(int32_t) * w.nzero, stream);

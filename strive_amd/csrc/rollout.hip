@@ -346,10 +346,9 @@ static __global__ void rollout_init_kernel(Tape tp, const float* __restrict__ pa
 namespace {
 
 // The scene-resident kernels (scene_rollout.h) serve single-sample rollouts of scenes with <= 16 agents whose weight packs
-// carry matrix-core fragments; STRIVE_SCENE_KERNELS=0 keeps the launch-per-phase kernels (A/B measurements).
+// carry matrix-core fragments; option scene_kernels = 0 keeps the launch-per-phase kernels (A/B measurements).
 bool scene_kernels_on(const StriveDecoder* dec, const StriveScenes* sc) {
-    const char* e = getenv("STRIVE_SCENE_KERNELS");          // read per call: tests and A/B runs switch it inside one process
-    return !(e && atoi(e) == 0) && scn::supported(*dec, *sc);
+    return strive_tuning().scene_kernels != 0 && scn::supported(*dec, *sc);   // (read per call: tests and A/B runs switch it inside one process)
 }
 
 // more than 64 KB of LDS per workgroup needs the attribute, once per device
@@ -485,20 +484,18 @@ static int rollout_forward(const StriveDecoder* dec, const StriveScenes* sc, con
     const bool scene = scene_kernels_on(dec, sc);
     if (scene && scene_kernels_prepare()) return -1;
     const scn::GRUFrag gf = scn::gru_frag(dec->gru);
-    const char* pe = getenv("STRIVE_SCENE_PROF");
-    const bool scene_prof = scene && pe && atoi(pe) != 0;
-    // scenes of >= STRIVE_SCENE_SPLIT agents (default 12 = three 64-row edge chunks; 0 = never): their 130-240 edge rows are 3-4
+    const bool scene_prof = scene && strive_tuning().scene_prof != 0;
+    // scenes of >= option scene_split agents (default 12 = three 64-row edge chunks; 0 = never): their 130-240 edge rows are 3-4
     // chunks on ONE CU inside the one-launch scene step.  Round 4 moved them to gnn_edge_kernel (one workgroup per target) from 15
     // agents on (profiles/r04_ab_scene_split.txt); round 5 shares the chunks among K workgroups of the scene kernel itself (below):
     // a wash against the per-target kernel at 16 agents per scene, -2 % / -4 % of the refine closure at 14 / 12 agents where the
     // per-target kernel did not pay (profiles/r05_ab_fwd_k.json)
-    const char* se = getenv("STRIVE_SCENE_SPLIT");
-    const int split_min = se ? atoi(se) : 12;
+    const int split_min = strive_tuning().scene_split;
     const bool scene_split = scene && split_min > 0 && sc->max_n >= split_min;
-    // STRIVE_SCENE_FWD_K = workgroups per scene for the edge chunks of such scenes (default: one per chunk, <= 4; 0 = the round-4
+    // option scene_fwd_k = workgroups per scene for the edge chunks of such scenes (default: one per chunk, <= 4; 0 = the round-4
     // form: scene kernel | one workgroup per target in gnn_edge_kernel | scene kernel)
     int fwd_k = (sc->max_n * (sc->max_n - 1) + scn::EC - 1) / scn::EC;
-    if (const char* fe = getenv("STRIVE_SCENE_FWD_K")) fwd_k = atoi(fe);
+    if (strive_tuning().scene_fwd_k >= 0) fwd_k = strive_tuning().scene_fwd_k;
     fwd_k = fwd_k > 4 ? 4 : fwd_k;
     if (scene_prof) fwd_k = 0;
     hipLaunchKernelGGL(rollout_init_kernel, dim3((unsigned)((R * 64 + 255) / 256)), dim3(256), 0, stream, tp, past_last,
@@ -977,15 +974,13 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
     // Training, kept activations: the map CNN's backward of the crops of step t needs nothing but the map-feature adjoints node1_bwd(t)
     // leaves -- and the sweep is a chain of small kernels on <= R workgroups while the CNN backward fills the chip.  The crops of
     // `grp` consecutive steps (>= 256 samples) are handed to a library-owned side stream as soon as the sweep has passed them; the
-    // caller's stream joins at the end.  STRIVE_TRAIN_OVERLAP=0: one call after the sweep (the round-4 form).
+    // caller's stream joins at the end.  option train_overlap = 0: one call after the sweep (the round-4 form).
     // (both switches are read per call: the tests run the forms side by side in one process)
-    const char* oe = getenv("STRIVE_TRAIN_OVERLAP");
-    const bool overlap_on = !(oe && atoi(oe) == 0);
+    const bool overlap_on = strive_tuning().train_overlap != 0;
     const bool overlap = WG && tr && tr->kept && FT > 1 && overlap_on;
     SideStream* side = overlap ? side_stream() : nullptr;
     const int total_crops = (int)((size_t)(FT > 1 ? FT - 1 : 0) * R);
-    const char* ge = getenv("STRIVE_TRAIN_OVERLAP_ROWS");
-    const int grp_rows = ge ? atoi(ge) : 256;
+    const int grp_rows = strive_tuning().train_overlap_rows;
     int grp = (int)(((size_t)(grp_rows > 0 ? grp_rows : 256) + R - 1) / R);
     grp = grp < 1 ? 1 : grp;
     int n_handed = 0, t_hi = FT - 1;
@@ -1093,17 +1088,17 @@ extern "C" int strive_rollout_bwd(const StriveDecoder* dec, const StriveScenes* 
         scn::SweepArgs a;
         a.FT = FT; a.NC = dec->gnn.NC; a.max_n = sc->max_n; a.sem = sem; a.lw = lw; a.ext = ext_future; a.ptr = sc->ptr;
         a.par = dec->scene_par; a.g_traj = d_traj; a.dz = dz;
-        // STRIVE_SCENE_PROF=1 (tools/scene_phase_probe.py): workgroup 0 adds the core-clock ticks of every phase to 16 counters at the
+        // option scene_prof = 1 (tools/scene_phase_probe.py): workgroup 0 adds the core-clock ticks of every phase to 16 counters at the
         // start of the workspace, which this path does not use otherwise
-        const char* pe = getenv("STRIVE_SCENE_PROF");
+        const bool prof = strive_tuning().scene_prof != 0;
         // Stepwise form: one launch per reverse step, K workgroups per scene sharing the scene's edge chunks (scene_rollout.h).
-        // Default from 3 chunks per scene on (>= 12 agents: 132 edge rows); STRIVE_SWEEP_STEP = 0 (never) | K (1..4, forced).
+        // Default from 3 chunks per scene on (>= 12 agents: 132 edge rows); option sweep_step = 0 (never) | K (1..4, forced).
         const int chunks = (sc->max_n * (sc->max_n - 1) + scn::EC - 1) / scn::EC;
         int K = chunks >= 3 ? chunks : 0;
-        if (const char* e = getenv("STRIVE_SWEEP_STEP")) K = atoi(e);
+        if (strive_tuning().sweep_step >= 0) K = strive_tuning().sweep_step;
         if (K > 4) K = 4;
         const size_t need = (size_t)sc->B * (K > 0 ? K : 1) * (2 * scn::SWEEP_PART_FLOATS + scn::SWEEP_STATE_FLOATS) * 4 + 512;
-        if (K >= 1 && !(pe && atoi(pe) != 0) && ws_bytes >= need) {
+        if (K >= 1 && !prof && ws_bytes >= need) {
             a.K = K;
             a.part = reinterpret_cast<float*>((char*)ws + 256);
             a.state = a.part + 2 * (size_t)sc->B * K * scn::SWEEP_PART_FLOATS;
@@ -1120,7 +1115,7 @@ extern "C" int strive_rollout_bwd(const StriveDecoder* dec, const StriveScenes* 
             return 0;
         }
         a.t = 0; a.K = 1; a.part = nullptr; a.state = nullptr;
-        if (pe && atoi(pe) != 0)
+        if (prof)
             hipLaunchKernelGGL(scn::scene_bwd_sweep_kernel<true>, dim3((unsigned)sc->B), dim3(scn::NTHR), scn::BwdLds::BYTES, (hipStream_t)stream_,
                                gnn_dev(dec->gnn), gru_dev(dec->gru), scn::gru_frag(dec->gru), dyn_params(*dec), a, tp, (unsigned long long*)ws + 32);
         else
@@ -1173,7 +1168,7 @@ static int rollout_backward_train(const StriveDecoder* dec, const StriveScenes* 
         p += strive_align_up((size_t)FT * R * 64 * 4, 256);
         tr.mapix_all = (int32_t*)p;
         p += strive_align_up(steps * R * 4, 256);
-        static const bool atomics_only = getenv("STRIVE_WGRAD_ATOMICS") != nullptr;      // A/B switch: no deferred weight gradients
+        const bool atomics_only = strive_tuning().wgrad_atomics != 0;      // A/B switch: no deferred weight gradients
         tr.jobs = atomics_only ? nullptr : (WJobTable*)p;
         p += strive_align_up(sizeof(WJobTable), 256);
         tr.wtape = (float*)p;

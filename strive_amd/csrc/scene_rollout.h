@@ -13,7 +13,7 @@
 // splits run with 16 lanes per row (four rows per wave instruction, DPP reductions inside a row of lanes).
 //
 // The tape layout is the one of rollout.hip, so either direction can be paired with the launch-per-phase kernels
-// (STRIVE_SCENE_KERNELS=0 keeps those; the training sweep, multi-sample rollouts and scenes of more than 16 agents use them).
+// (option scene_kernels = 0 keeps those; the training sweep, multi-sample rollouts and scenes of more than 16 agents use them).
 #pragma once
 
 namespace scn {

@@ -29,3 +29,27 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if 'slow' in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _strive_option_sync(monkeypatch):
+    """The library reads no environment variable (ABI 17): its switches are options that the Python host sets from STRIVE_<NAME>
+    variables when it loads the library.  Tests flip such variables with monkeypatch in the middle of a process, so every
+    monkeypatch.setenv / delenv of a STRIVE_ variable re-synchronises the options of every loaded library (product and emulator),
+    and every test starts from the environment as it is."""
+    from strive_amd import _lib
+    orig_set, orig_del = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, *a, **k):
+        orig_set(name, value, *a, **k)
+        if name.startswith('STRIVE_'):
+            _lib.sync_all_options_from_env()
+
+    def delenv(name, *a, **k):
+        orig_del(name, *a, **k)
+        if name.startswith('STRIVE_'):
+            _lib.sync_all_options_from_env()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    _lib.sync_all_options_from_env()
+    yield

@@ -25,7 +25,45 @@ def test_hip_library_builds_loads_and_exports_everything():
     assert os.path.exists(path)
     lib = L.StriveLib(path)            # raises if any symbol is missing
     assert lib.missing == []
-    assert lib.query("strive_abi_version") == L.ABI_VERSION == 16
+    assert lib.query("strive_abi_version") == L.ABI_VERSION == 17
+
+
+def test_library_reads_no_environment_variable():
+    """ABI 17: every switch of the library is a declared option (strive_set_option); no getenv anywhere in csrc."""
+    csrc = os.path.join(REPO, 'strive_amd', 'csrc')
+    hits = []
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith(('.hip', '.h')):
+            for i, line in enumerate(open(os.path.join(csrc, fn)), 1):
+                code = line.split('//')[0]
+                if re.search(r'\bgetenv\s*\(', code) or 'secure_getenv' in code:
+                    hits.append('%s:%d' % (fn, i))
+    assert hits == []
+
+
+def test_options_are_declared_defaulted_and_range_checked(monkeypatch):
+    import __graft_entry__ as ge
+    lib = L.StriveLib(ge.build(verbose=False))
+    names = lib.option_names()
+    hdr = open(os.path.join(REPO, 'include', 'strive_hip.h')).read()
+    assert len(names) == len(set(names)) >= 19
+    for n in names:                                    # every option is documented in the header
+        assert re.search(r'\b%s\b' % n, hdr), n
+    lib.query('strive_reset_options')
+    assert lib.get_option('conv_wsx') == 1 and lib.get_option('cnn_small_batch') == 96 and lib.get_option('sweep_step') == -1
+    lib.set_option('cnn_small_batch', 0)
+    assert lib.get_option('cnn_small_batch') == 0
+    with pytest.raises(L.StriveHipError):
+        lib.set_option('cnn_chunk', 4)                 # below the option's range
+    with pytest.raises(L.StriveHipError):
+        lib.set_option('no_such_option', 1)
+    # the host maps STRIVE_<NAME> onto the options (and back to the defaults when the variable goes away)
+    monkeypatch.setenv('STRIVE_SCENE_KERNELS', '0')
+    lib.sync_options_from_env()
+    assert lib.get_option('scene_kernels') == 0 and lib.get_option('cnn_small_batch') == 96
+    monkeypatch.delenv('STRIVE_SCENE_KERNELS')
+    lib.sync_options_from_env()
+    assert lib.get_option('scene_kernels') == 1
 
 
 def test_every_entry_point_cites_the_reference():

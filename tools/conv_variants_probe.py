@@ -1,6 +1,7 @@
 """A/B of single CNN layers through strive_map_cnn_bench_layer: interleaved rounds of launches of each code, time per launch
-(HIP events on the launching stream) and whether the layer's output block is bit-identical to the first code of its group.
-usage: python tools/conv_variants_probe.py [N] [rounds]"""
+(HIP events on the launching stream) and whether the layer's output block (and the statistics block) is bit-identical to the first
+code of its group.  STRIVE_CONV_WS_DBG=<mask> (option conv_ws_dbg) switches phases of the specialised-wave kernels off for timing.
+usage: [PROBE_GROUPS="[('conv3', 2, [52, 2])]"] python tools/conv_variants_probe.py [N] [rounds]"""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
@@ -52,10 +53,10 @@ for sz in sizes:
 stats_off = o
 # groups: (name, output block index, codes); the first code is the reference form
 GROUPS = eval(os.environ.get('PROBE_GROUPS', 'None')) or [
-    ('conv1', 0, [0, 70]),
-    ('conv2', 1, [51, 1, 55, 52, 56, 53, 57, 54, 61, 67]),
-    ('conv3', 2, [2, 62, 64, 65]),
-    ('conv4', 3, [3, 63, 66]),
+    ('conv1', 0, [0]),
+    ('conv2', 1, [51, 1]),          # specialised waves | conv_bf6_kernel
+    ('conv3', 2, [52, 2]),          # specialised waves + streamed weights | conv_bf6_kernel
+    ('conv4', 3, [53, 3]),
 ]
 for name, blk, codes in GROUPS:
     off, nb = offs[blk], sizes[blk] * 4 * n

@@ -1,4 +1,6 @@
-"""Phase profile of conv_ws_kernel (bench-layer codes 81-83): clock sums per workgroup of consumer wave 0 and the first producer wave."""
+"""Phase profile of conv_ws_kernel (bench-layer code 81): clock sums per workgroup of consumer wave 0 and the first producer wave.
+(clock64 ticks are NOT core cycles under load -- tools/tick_probe.hip: 1.49 ticks/ns with two matrix-bound waves per SIMD at an
+unchanged 2.0 GHz matrix issue rate -- read them as shares.)"""
 import sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
@@ -27,7 +29,7 @@ mean4, std4 = L.f4(nm.mean_vals[:4].tolist()), L.f4(nm.std_vals[:4].tolist())
 st = L.stream_ptr(pos)
 lib.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(pos), mean4, std4, L.ptr(mapix), n, L.ptr(feat), L.ptr(ws), wsb, st)
 names = ['consumer: matrix steps', 'consumer: epilogue', 'consumer: barrier wait', 'producer: request', 'producer: stage', 'producer: barrier wait']
-for layer in [int(a) for a in sys.argv[1:]] or [81, 82, 83]:
+for layer in [int(a) for a in sys.argv[1:]] or [81]:
     for rep in range(2):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()

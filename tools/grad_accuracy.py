@@ -37,6 +37,7 @@ def main():
     res = {}
     for mode in ('1', '0'):
         os.environ['STRIVE_SCENE_KERNELS'] = mode
+        L.sync_all_options_from_env()
         zg = z0.clone().to(dev).requires_grad_(True)
         pg = m.decode_embedding(zg, emb_g, g, mi, env_g, nfuture=FT)['future_pred']
         (pg * rw.to(dev)).sum().backward()
