@@ -202,6 +202,29 @@ def refine_closure_factory(m, env, batch, map_idx, FT, device):
         opt.step()
         return ld['loss']
     step = GraphedIteration(iteration, graphed)
+
+    def graph_vs_eager():
+        """After the timed region: from the SAME latents and Adam state, one iteration replayed from the graph and one run eagerly;
+        the largest difference of the latents they leave (the driver-timed path against the one the eager tests cover)."""
+        if step.graph is None:
+            return None
+        st = opt.state[z]
+        saved = (z.detach().clone(), {k: v.clone() for k, v in st.items() if torch.is_tensor(v)})
+
+        def restore():
+            with torch.no_grad():
+                z.copy_(saved[0])
+                for k, v in saved[1].items():
+                    st[k].copy_(v)
+        step()
+        zg = z.detach().clone()
+        restore()
+        iteration()
+        ze = z.detach().clone()
+        restore()
+        torch.cuda.synchronize()
+        return float((zg - ze).abs().max()), float((ze - saved[0]).abs().max())
+    step.graph_vs_eager = graph_vs_eager
     return step, emb, g, mi, 1
 
 
@@ -325,7 +348,7 @@ def full_pipeline_factory(m, env, batch, map_idx, FT, device, scale=1.0):
         tp, op = (pm[ego], pv[ego]), (pm[~ego], pv[~ego])
         planner = HardcodeNuscPlanner(env, PlannerConfig(**CONFIG_DICT['default']))
         cur_z, fin, dec_out, agt, tt = run_adv_gen_optim(z.clone().detach(), lr, weights, m, g, env, mi, n_adv, emb, 'hardcode', tp, op, 2,
-                                                         0.0, planner=planner)
+                                                         0.0, planner=planner, on_planner_error='drop')
         units += (2 * n_adv + 1) * NA * m.FT
         # scenes the closed loop lost to a failing planner rollout (masked out of the losses on the device from that iteration on):
         # no success test, no solution stage, no scenario file -- what the reference's run of that scene alone would have produced
@@ -986,6 +1009,7 @@ def main():
     dt_host_cpu = time.thread_time() - c0       # CPU time of the enqueueing thread: the wall time above also holds the waits for a
     barrier()                                   # free slot in the hardware queue once the GPU is the bottleneck
     dt_local = time.perf_counter() - t0
+    gve = step.graph_vs_eager() if (hip_graph and getattr(step, 'graph_vs_eager', None) is not None) else None
     if args.workload == 'full' and args.scenario_out and rank == 0:
         step.stats['scenarios_written'] = step.write_scenarios(args.scenario_out)
     planner_ms = None
@@ -1068,6 +1092,10 @@ def main():
                                   'operand splits (3 products per fp32 product, dropped terms <= 2^-24); the CNN BACKWARD (data and weight '
                                   'gradients) with two-piece bf16 operand splits: 2^-16 per product (TF32-class), fp32 accumulate'),
                    'rollout_kernels': rollout_kernels, 'hip_graph': hip_graph},
+        # the timed path (graph replay) against one eager iteration from the same latents and Adam state, after the timed region:
+        # max |z_replayed - z_eager| (and how far that iteration moved the latents); the run FAILS above 1e-5
+        'graph_vs_eager_max_abs': None if gve is None else gve[0],
+        'graph_vs_eager_step_size': None if gve is None else gve[1],
         'final_loss': float(loss.detach().cpu()),
         'host_enqueue_ms_per_step': round(dt_host / args.steps * 1e3, 3),     # diagnostic: the host has queued everything by then
         'host_cpu_ms_per_step': round(dt_host_cpu / args.steps * 1e3, 3),    # of which the enqueueing thread was on a core
@@ -1080,7 +1108,7 @@ def main():
         'distinct_devices': backend['distinct_devices'],
         'host': host_pin,
     }
-    failed = False
+    failed = gve is not None and not (gve[0] <= 1e-5)
     if rank == 0:
         if not args.no_roofline and args.workload not in ('train', 'sample', 'full'):
             try:

@@ -16,8 +16,9 @@
  *   - return 0 on success, a negative code on failure; strive_last_error() (thread local) explains it;
  *   - re-entrant; no global mutable state besides the error string and the options below.  One exception (round 5): strive_rollout_bwd_train_kept forks
  *     the map CNN's backward onto a library-owned side stream (one per device, created at first use) and joins it back on `stream`
- *     with events before it returns -- no host synchronisation, the caller's stream order is what it would be without it; run one
- *     such call at a time per device.
+ *     with events before it returns -- no host synchronisation, the caller's stream order is what it would be without it; one
+ *     such call at a time per device: a second host thread entering while the first is still enqueueing gets -3 (ABI 17; it was
+ *     a documented rule only), and a device on which the stream or its events cannot be created runs without the overlap.
  */
 #ifndef STRIVE_HIP_H
 #define STRIVE_HIP_H

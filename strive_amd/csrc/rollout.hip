@@ -909,6 +909,14 @@ struct SideStream {
     static constexpr int NEV = 64;
     hipStream_t s;
     hipEvent_t ev[NEV], done;
+    bool ok;                          // every create succeeded; otherwise the overlap is off on this device
+    std::atomic<int> in_use;          // one strive_rollout_bwd_train_kept at a time per device (host threads): the second one is refused
+};
+// the guard of one call: taken before the first hand-over, released on every way out
+struct SideStreamUse {
+    SideStream* s;
+    explicit SideStreamUse(SideStream* s_) : s(s_) {}
+    ~SideStreamUse() { if (s) s->in_use.store(0, std::memory_order_release); }
 };
 static SideStream* side_stream() {
     static SideStream table[64];
@@ -920,14 +928,17 @@ static SideStream* side_stream() {
         while (!busy.compare_exchange_weak(expect, 1)) expect = 0;      // (first use per device only)
         if (!once.is_done(dev)) {
             SideStream& t = table[dev];
-            hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking);      // (a lowest-priority stream was measured: no difference)
-            for (int i = 0; i < SideStream::NEV; ++i) hipEventCreateWithFlags(&t.ev[i], hipEventDisableTiming);
-            hipEventCreateWithFlags(&t.done, hipEventDisableTiming);
+            bool ok = hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) == hipSuccess;      // (a lowest-priority stream was measured: no difference)
+            for (int i = 0; i < SideStream::NEV; ++i) ok = (hipEventCreateWithFlags(&t.ev[i], hipEventDisableTiming) == hipSuccess) && ok;
+            ok = (hipEventCreateWithFlags(&t.done, hipEventDisableTiming) == hipSuccess) && ok;
+            (void)hipGetLastError();
+            t.ok = ok;
+            t.in_use.store(0);
             once.set_done(dev);
         }
         busy.store(0);
     }
-    return &table[dev];
+    return table[dev].ok ? &table[dev] : nullptr;      // (no side stream: the caller runs the CNN backward after the sweep, on its own stream)
 }
 
 template <bool WG>
@@ -979,6 +990,11 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
     const bool overlap_on = strive_tuning().train_overlap != 0;
     const bool overlap = WG && tr && tr->kept && FT > 1 && overlap_on;
     SideStream* side = overlap ? side_stream() : nullptr;
+    if (side && side->in_use.exchange(1, std::memory_order_acquire) != 0) {
+        strive_set_error("rollout_bwd_train_kept: another call is using this device's side stream (one such call at a time per device)");
+        return -3;
+    }
+    SideStreamUse side_guard(side);
     const int total_crops = (int)((size_t)(FT > 1 ? FT - 1 : 0) * R);
     const int grp_rows = strive_tuning().train_overlap_rows;
     int grp = (int)(((size_t)(grp_rows > 0 ? grp_rows : 256) + R - 1) / R);

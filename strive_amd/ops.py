@@ -475,6 +475,26 @@ def keep_cnn_activations():
     return os.environ.get('STRIVE_KEEP_CNN_ACTIVATIONS', '1') != '0'
 
 
+def _alloc_kept(nbytes, device):
+    """The kept-activation buffer of a training forward, or None -> the caller takes the recomputing path.  1.76 MB x crops grows
+    to tens of GB for large batches (4 scenes of 60 agents x 11 steps x 2 decodes: 10 GB): it is not requested when it would not
+    leave a quarter of the currently free device memory (or STRIVE_KEEP_MAX_BYTES) for the rest of the step, and an allocation
+    that fails all the same falls back too -- instead of surfacing as an out-of-memory error inside the trainer's step (which
+    counts it as a failed batch and skips it)."""
+    cap = os.environ.get('STRIVE_KEEP_MAX_BYTES')
+    try:
+        free = torch.cuda.mem_get_info(device)[0] + (torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
+    except Exception:
+        free = None
+    limit = int(cap) if cap else (None if free is None else int(0.75 * free))
+    if limit is not None and nbytes > limit:
+        return None
+    try:
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    except torch.cuda.OutOfMemoryError:
+        return None
+
+
 def _cnn_params(model):
     return list(model.map_conv.parameters()) + list(model.map_feature.parameters())
 
@@ -490,7 +510,8 @@ class _CNNFn(torch.autograd.Function):
         ctx.kept = None
         if keep_cnn_activations():
             # the convolutions' raw outputs stay for the backward (1.76 MB per crop) instead of being recomputed there
-            ctx.kept = torch.empty(h.lib.query('strive_map_cnn_keep_bytes', h.N), dtype=torch.uint8, device=h.p2.device)
+            ctx.kept = _alloc_kept(h.lib.query('strive_map_cnn_keep_bytes', h.N), h.p2.device)
+        if ctx.kept is not None:
             h.lib.call('strive_map_cnn_fwd_keep', h.mp.ref(), h.cnn.ref(), L.ptr(h.p2), h.mean4, h.std4, L.ptr(h.mapix), h.N, L.ptr(feat),
                        L.ptr(ws), ws.numel(), L.ptr(ctx.kept), ctx.kept.numel(), h.N, 0, _stream(h.p2))
         else:
@@ -752,7 +773,8 @@ class _RolloutTrainFn(torch.autograd.Function):
         ws = _workspace(dev, h.ws_bytes, 'rollout')
         ctx.kept = None
         if keep_cnn_activations() and h.FT > 1:
-            ctx.kept = torch.empty(lib.query('strive_rollout_keep_bytes', h.dec.ref(), h.sc.ref(), h.FT), dtype=torch.uint8, device=dev)
+            ctx.kept = _alloc_kept(lib.query('strive_rollout_keep_bytes', h.dec.ref(), h.sc.ref(), h.FT), dev)
+        if ctx.kept is not None:
             lib.call('strive_rollout_fwd_keep', h.dec.ref(), h.sc.ref(), L.ptr(h.past_last), L.ptr(h.lw), L.ptr(h.sem), L.ptr(pf),
                      L.ptr(mf), L.ptr(zz), L.ptr(h.mapix), L.ptr(h.ext), h.FT, L.ptr(traj), L.ptr(tape), tape.numel(), L.ptr(ws),
                      ws.numel(), L.ptr(ctx.kept), ctx.kept.numel(), _stream(z))

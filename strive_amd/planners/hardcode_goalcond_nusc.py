@@ -319,7 +319,8 @@ class HardcodeNuscPlanner(PlannerNusc):
         return bad
 
     # ---- rollout (reference :178-276) -------------------------------------------------------------------------------------
-    def rollout(self, agent_obs, agent_t, agent_ptr, planner_t, init_state=None, control_all=False, viz=None, coll_t=None):
+    def rollout(self, agent_obs, agent_t, agent_ptr, planner_t, init_state=None, control_all=False, viz=None, coll_t=None,
+                on_error=None):
         """agent_obs (NA-B, T, 4) UNNORMALISED futures of the non-ego agents (device tensor or numpy array), agent_t (T)
         their times, agent_ptr (B+1) scene offsets into agent_obs, planner_t (T') times at which the planner pose is returned
         -> float64 tensor (B, T', 4) of (x, y, cos h, sin h): on the device for a device ``agent_obs``, on the host for numpy."""
@@ -329,7 +330,7 @@ class HardcodeNuscPlanner(PlannerNusc):
             raise NotImplementedError('only the closed-loop attack mode of adv_gen_optim is implemented (observed other agents)')
         if viz is not None:
             raise NotImplementedError('planner visualisation (viz=...) is outside the hot path; render the returned plan instead')
-        self.check(wait=False)
+        self.check(wait=False, on_error=on_error)     # (``on_error``: this call's answer to failed scenes; None = self.on_error)
         w = self._world
         dev = w['dev']
         from_numpy = not torch.is_tensor(agent_obs)

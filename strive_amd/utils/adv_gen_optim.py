@@ -127,14 +127,17 @@ class AdvClosure(object):
 
     def __init__(self, cur_z, lr, loss_weights, model, scene_graph, map_env, map_idx, embed_info, tgt_prior_distrib,
                  other_prior_distrib, feasibility_time, feasibility_infront_min, planner_fut=None, attack_agt_idx=None,
-                 future_len=None, veh_coll_buffer=0.1, planner_name='ego', planner=None, on_planner_error='drop'):
+                 future_len=None, veh_coll_buffer=0.1, planner_name='ego', planner=None, on_planner_error='raise'):
         """``on_planner_error`` (closed loop only; not in the reference): what a planner rollout that fails in some scene -- an
         object pushed off its lane, a capacity limit: the cases in which the reference's numpy planner raises and its batch_size-1
-        run loses that scene (adv_scenario_gen.py:540-543) -- costs a BATCH here.  'drop' (default): that scene alone; from the
+        run loses that scene (adv_scenario_gen.py:540-543) -- costs a BATCH here.  'raise' (default, the reference's behaviour): the
+        whole batch (StriveHipError from the planner's deferred check), with the planner overlapped under the adversarial half.
+        'drop' (opt-in; bench.py and the full pipeline pass it): that scene alone; from the
         iteration of the failure on it is masked out of both losses on the device (the planner's ``alive`` flags go straight to the
         loss kernels, no host round trip), the other scenes continue exactly as in a batch rebuilt without it (the reference's
-        remedy for scenes it gives up after the init stage, :323-356), and the caller is told (``failed_scenes``).  'raise': the
-        whole batch (StriveHipError from the planner's deferred check), with the planner overlapped under the adversarial half."""
+        remedy for scenes it gives up after the init stage, :323-356), and the caller is told (``failed_scenes``, a RuntimeWarning
+        from run_adv_gen_optim; a batch that lost EVERY scene raises).  The planner object itself is not reconfigured: every rollout /
+        check of this closure passes its own ``on_error``."""
         from ..losses.adv_gen_nusc import TgtMatchingLoss, AdvGenLoss
         dev = cur_z.device
         NA = cur_z.size(0)
@@ -190,8 +193,8 @@ class AdvClosure(object):
             B = scene_graph.ptr.shape[0] - 1
             planner.reset(self.unn(scene_graph.past_gt[:, -1, :]), model.get_att_normalizer().unnormalize(scene_graph.lw),
                           scene_graph.batch, B, map_idx)
-            if self.report_failures:
-                planner.on_error = 'report'          # its own opportunistic look at the flags (rollout -> check(wait=False)) must not raise
+            # (with 'drop' the planner's own opportunistic look at the flags -- rollout -> check(wait=False) -- must not raise: plan()
+            # passes on_error='report' with every rollout; the caller's planner keeps its own setting)
             self.agt_ptr = (scene_graph.ptr.cpu() - torch.arange(B + 1)).numpy()
             self.plan_t = np.linspace(model.dt, model.dt * self.future_len, self.future_len)
             self.planner_fut = None
@@ -209,7 +212,8 @@ class AdvClosure(object):
         """The rule-based planner's reaction (B, FT, 4), NORMALISED, to the non-ego agents of ``future_pred`` (reference
         :133-139): the futures stay on the device, the plan comes back as a device tensor -- no host round trip."""
         agt = self.unn(future_pred.index_select(0, self.other_idx)).detach()
-        fut = self.planner.rollout(agt, self.plan_t, self.agt_ptr, self.plan_t, control_all=False).to(self.scene_graph.future_gt)
+        kw = {'on_error': 'report'} if self.report_failures else {}
+        fut = self.planner.rollout(agt, self.plan_t, self.agt_ptr, self.plan_t, control_all=False, **kw).to(self.scene_graph.future_gt)
         return self.model.get_normalizer().normalize(fut)
 
     def _two_rollouts(self, z_a, z_b, after_a=None):
@@ -290,10 +294,11 @@ class AdvClosure(object):
 def run_adv_gen_optim(cur_z, lr, loss_weights, model, scene_graph, map_env, map_idx, num_iters, embed_info,
                       planner_name, tgt_prior_distrib, other_prior_distrib, feasibility_time, feasibility_infront_min,
                       planner=None, planner_viz_out=None, attack_agt_idx=None, future_len=None, veh_coll_buffer=0.1,
-                      log=None, on_planner_error='drop'):
+                      log=None, on_planner_error='raise'):
     """Same arguments and return value as the reference (src/utils/adv_gen_optim.py:39-211).  ``on_planner_error`` (closed loop,
-    see AdvClosure): with 'drop' a scene whose planner rollout fails leaves the losses from that iteration on instead of ending
-    the whole batch; the scenes lost this way are listed in ``final_decoder_out['scenes_dropped']`` (with the limits they hit in
+    see AdvClosure; default 'raise' = the reference, whose planner raises at :133-139): with 'drop' a scene whose planner rollout fails
+    leaves the losses from that iteration on instead of ending the whole batch; a RuntimeWarning names the scenes lost this way,
+    a batch that lost all of its scenes raises, and they are listed in ``final_decoder_out['scenes_dropped']`` (with the limits they hit in
     ``final_decoder_out['planner_failures']``) -- their rows of the returned tensors are meaningless (the planner's trajectory
     is NaN) and the caller drops them like the reference drops scenes after its init stage (adv_scenario_gen.py:323-356)."""
     if planner_viz_out is not None:
@@ -326,6 +331,16 @@ def run_adv_gen_optim(cur_z, lr, loss_weights, model, scene_graph, map_env, map_
             failures = planner.check(on_error='report') if c.report_failures else planner.check()
             final_decoder_out['planner_failures'] = dict(failures or {})
             final_decoder_out['scenes_dropped'] = sorted((failures or {}).keys())
+            if failures:
+                B = int(scene_graph.ptr.shape[0]) - 1
+                if len(failures) >= B:
+                    from .._lib import StriveHipError
+                    raise StriveHipError('run_adv_gen_optim: the planner rollout failed in every scene of the batch (%s): nothing to '
+                                         'return' % '; '.join('scene %d: %s' % (b, v[0]) for b, v in sorted(failures.items())))
+                import warnings
+                warnings.warn('run_adv_gen_optim(on_planner_error=\'drop\'): planner rollout failed in scene(s) %s -- their rows of the '
+                              'returned tensors are meaningless (final_decoder_out[\'scenes_dropped\'])' % sorted(failures.keys()),
+                              RuntimeWarning)
     tgt_traj = final_result_traj[ego_inds, torch.zeros_like(ego_inds)]
     fin_kw = {'scene_alive': planner.alive} if c.report_failures else {}
     with torch.no_grad():

@@ -550,7 +550,7 @@ def test_closed_loop_quarantines_a_failing_scene(model, kill_at):
     def closure_for(g, g_mi, e, zs, tp, op):
         planner = HardcodeNuscPlanner(env, PlannerConfig(**CONFIG_DICT['default']))
         return AdvClosure(zs, 0.05, bench.ADV_WEIGHTS, m, g, env, g_mi, e, tp, op, 2, 0.0, future_len=12, veh_coll_buffer=0.1,
-                          planner_name='hardcode', planner=planner), planner
+                          planner_name='hardcode', planner=planner, on_planner_error='drop'), planner
 
     # ---- run F: the full batch; scene j's planner rollout "fails" at iteration kill_at ----
     cf, pf = closure_for(bg, mi, emb, z0, (pm[ego], pv[ego]), (pm[~ego], pv[~ego]))
@@ -617,8 +617,13 @@ def test_closed_loop_quarantines_a_failing_scene(model, kill_at):
             reset(*a, **k)
             planner._status[j, 5] = 1
         planner.reset = reset_and_fail
-        z_adv, fin, dec, agt, tt = run_adv_gen_optim(z0.clone(), 0.05, bench.ADV_WEIGHTS, m, bg, env, mi, 3, emb, 'hardcode',
-                                                     (pm[ego], pv[ego]), (pm[~ego], pv[~ego]), 2, 0.0, planner=planner, future_len=12)
+        with pytest.warns(RuntimeWarning, match='planner rollout failed in scene'):
+            z_adv, fin, dec, agt, tt = run_adv_gen_optim(z0.clone(), 0.05, bench.ADV_WEIGHTS, m, bg, env, mi, 3, emb, 'hardcode',
+                                                         (pm[ego], pv[ego]), (pm[~ego], pv[~ego]), 2, 0.0, planner=planner, future_len=12,
+                                                         on_planner_error='drop')
+        assert planner.on_error == 'raise', 'the closure must not reconfigure the caller\'s planner'
+        with pytest.raises(Exception, match=r'scene\(s\) 2'):           # ... which therefore still raises when asked directly
+            planner.check()
         assert dec['scenes_dropped'] == [j] and 'outside a route' in dec['planner_failures'][j][0]
         assert torch.isfinite(z_adv).all() and len(agt) == B
         ok_rows = keep_scene[bg.batch.to(DEV)]
@@ -628,7 +633,7 @@ def test_closed_loop_quarantines_a_failing_scene(model, kill_at):
             r2 = p2.reset
             p2.reset = lambda *a, **k: (r2(*a, **k), p2._status.__setitem__((j, 5), 1))[0]
             run_adv_gen_optim(z0.clone(), 0.05, bench.ADV_WEIGHTS, m, bg, env, mi, 3, emb, 'hardcode', (pm[ego], pv[ego]),
-                              (pm[~ego], pv[~ego]), 2, 0.0, planner=p2, future_len=12, on_planner_error='raise')
+                              (pm[~ego], pv[~ego]), 2, 0.0, planner=p2, future_len=12)      # the default is the reference's: raise
 
 
 # ------------------------------------------------------------------------------------------------
@@ -858,3 +863,88 @@ def test_sample_batched_at_the_reference_operating_point(model):
         wo = orc.sample_batched(sub, map_idx[3:4], synth.SyntheticMapEnv(uraster, udx), eps[:3, 48:64].cpu(), include_mean=False,
                                 nfuture=FT)
     assert_close(fp[48:64, :3], wo['future_pred'], RT, AT, 'joint rollout rows vs the oracle')
+
+
+# ------------------------------------------------------------------------------------------------
+# configs[1] as bench.py times it: the 32 x 16-agent refine iteration REPLAYED as a HIP graph
+# ------------------------------------------------------------------------------------------------
+
+def _headline_refine(m, env, batch, map_idx, z0, iters, monkeypatch, graph):
+    from strive_amd.refine_traffic_optim import refine_traffic_optim
+    from strive_amd.utils import graphed as gmod
+    replays = {'n': 0}
+    orig_call = gmod.GraphedIteration.__call__
+
+    def counting(self):
+        r = orig_call(self)
+        if self.graph is not None:
+            replays['n'] += 1
+        return r
+    monkeypatch.setattr(gmod.GraphedIteration, '__call__', counting)
+    monkeypatch.setenv('STRIVE_HIP_GRAPH', '1' if graph else '0')
+    _, z, _, emb = refine_traffic_optim(batch.clone().to(DEV), map_idx.to(DEV), env, m, mg.REFINE_WEIGHTS, iters, 16, 16, True, 0.05,
+                                        z_init=z0.clone().to(DEV))
+    monkeypatch.setattr(gmod.GraphedIteration, '__call__', orig_call)
+    return z.detach().cpu().clone(), z.grad.detach().cpu().clone(), emb, replays['n']
+
+
+def test_graph_replay_equals_eager_at_the_headline_size(model, monkeypatch):
+    """The driver-timed number is the 512-agent refine iteration (decode_embedding(nfuture=16) + AvoidCollLoss + backward + Adam,
+    reference src/refine_traffic_optim.py:184-220) replayed as a HIP graph (strive_amd/utils/graphed.py; bench.py config.hip_graph).
+    At this size the capture takes other branches than the one-scene case of test_loops.py (stepwise reverse sweep on 4 workgroups
+    per scene, the throughput CNN chain with specialised waves, per-graph workspaces).  Same function, same latents, graph on / off,
+    both with Adam's device-side step count (capturable) so that the arithmetic is the same: 3 eager + 5 replayed iterations on a
+    uniform raster agree to 1e-6 relative (measured: bit for bit), and the replay count is what it should be.  Then over the TEXTURED
+    raster: the 4th iteration (the first replayed one) against the eager one from bit-identical state -- latents after it and the
+    gradient it left -- and that gradient against the ORACLE's closure at the same latents, cropping at the product's poses
+    (oracle/loops.py refine_loop, num_iters 1)."""
+    from strive_amd.utils import graphed as gmod
+    from oracle import loops
+    from strive_amd.utils.scenario_gen import detach_embed_info
+    m, sd = model
+    monkeypatch.setattr(gmod, 'adam_kwargs', lambda graphed: {'capturable': True})
+    import strive_amd.refine_traffic_optim as rmod
+    monkeypatch.setattr(rmod, 'adam_kwargs', lambda graphed: {'capturable': True})
+    batch, map_idx = synth.make_batch([16] * 32, key='gc/graph', map_extent=(512.0, 512.0))
+    # ---- uniform raster: 8 iterations ----
+    raster, dx = uniform(4096)
+    env = dev_env(raster, dx)
+    with torch.no_grad():
+        emb = m.embed(batch.clone().to(DEV), map_idx.to(DEV), env)
+    z0 = synth.make_latents(emb['prior_out'][0].cpu(), emb['prior_out'][1].cpu(), key='gc/graph/z')
+    zg, gg, _, ng = _headline_refine(m, env, batch, map_idx, z0, 8, monkeypatch, True)
+    ze, ge, _, ne = _headline_refine(m, env, batch, map_idx, z0, 8, monkeypatch, False)
+    assert ng == 5 and ne == 0, 'iterations replayed from the graph: %d (graph on), %d (off)' % (ng, ne)
+    scale = float(ze.abs().max())
+    d_u = float((zg - ze).abs().max())
+    assert d_u <= 1e-6 * scale, 'uniform raster, 8 iterations: latents %.3g apart (scale %.3g)' % (d_u, scale)
+    assert float((zg - z0).abs().max()) > 1e-3, 'the iterations moved the latents'
+    # ---- textured raster: the first replayed iteration against the eager one ----
+    rt, dxt = synth.make_raster(2048, 2048)
+    env_t = dev_env(rt, dxt)
+    with torch.no_grad():
+        emb_t = m.embed(batch.clone().to(DEV), map_idx.to(DEV), env_t)
+    z0t = synth.make_latents(emb_t['prior_out'][0].cpu(), emb_t['prior_out'][1].cpu(), key='gc/graph/zt')
+    z3, _, _, n3 = _headline_refine(m, env_t, batch, map_idx, z0t, 3, monkeypatch, True)
+    z4g, g4g, emb_g, n4 = _headline_refine(m, env_t, batch, map_idx, z0t, 4, monkeypatch, True)
+    z4e, g4e, _, _ = _headline_refine(m, env_t, batch, map_idx, z0t, 4, monkeypatch, False)
+    assert n3 == 0 and n4 == 1
+    gs = float(g4e.abs().max())
+    d_z, d_g = float((z4g - z4e).abs().max()), float((g4g - g4e).abs().max())
+    assert d_z <= 1e-6 * float(z4e.abs().max()) and d_g <= 1e-5 * gs, \
+        'textured raster, iteration 4 replayed vs eager: latents %.3g, gradient %.3g apart (gradient scale %.3g)' % (d_z, d_g, gs)
+    # ---- ... and against the oracle's closure at z3, cropping where the product cropped ----
+    orc = oracle_model(sd, FT=12)
+    bg, mi = batch.clone().to(DEV), map_idx.to(DEV)
+    with torch.no_grad():
+        poses = m.decode_embedding(z3.to(DEV), emb_g, bg, mi, env_t, nfuture=16)['future_pred'].cpu()
+    emb_c = {k: (tuple(t.cpu() for t in v) if isinstance(v, tuple) else v.cpu()) for k, v in detach_embed_info(emb_g).items()}
+    t = []
+    loops.refine_loop(orc, batch, map_idx, synth.SyntheticMapEnv(rt, dxt), emb_c, z3, mg.REFINE_WEIGHTS, 1, 0.05, 16, trace=t,
+                      init_z=z0t, crop_poses=poses)
+    want = t[0]['grad'].double().reshape(-1)
+    rel = float((g4g.double().reshape(-1) - want).norm() / want.norm())
+    print('graph replay at 32 x 16: uniform 8 iterations %.3g apart; textured iteration 4 replay vs eager latents %.3g gradient %.3g; '
+          'replayed gradient vs the oracle at the same latents %.3g (relative L2), %d crop flips' % (
+              d_u, d_z, d_g, rel, int(want.numel() and t[0]['crop_flips'].sum())))
+    assert rel <= 5e-3, 'replayed closure gradient vs the oracle at the product latents: %.3g (relative L2)' % rel
