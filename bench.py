@@ -864,6 +864,7 @@ def pin_host_threads(local, nlocal):
         mine = cpus[local * per:(local + 1) * per] or cpus
         os.sched_setaffinity(0, mine)
         info['affinity'] = '%d cores (%d-%d)' % (len(mine), mine[0], mine[-1])
+        info['cores'] = list(mine)
         torch.set_num_threads(max(1, min(8, len(mine))))
     except (AttributeError, OSError):
         torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // nlocal)))
@@ -1034,7 +1035,7 @@ def main():
     props = torch.cuda.get_device_properties(device)
     dev_id = str(getattr(props, 'uuid', '')) or '%s/pci%s' % (props.name, getattr(props, 'pci_bus_id', local))
     dt, units, per_rank, backend = gather_ranks(use_dist, world, device, dt_local, units_local,
-                                                [rank, NA, round(dt_local / args.steps * 1e3, 3), dev_id, local])
+                                                [rank, NA, round(dt_local / args.steps * 1e3, 3), dev_id, local, host_pin.get('cores')])
     if args.planner == 'hardcode':
         closure_adv = ('closed-loop adversarial closure: 2 x decode_embedding(nfuture=%d) with complementary detach + '
                        'HardcodeNuscPlanner.rollout (31 planner steps per scene, device) + TgtMatchingLoss + AdvGenLoss + backward + Adam')
@@ -1102,7 +1103,8 @@ def main():
         'planner': None if planner_ms is None else planner_ms,
         'scenes_dropped': scenes_dropped if args.workload != 'full' else step.stats.get('scenes_dropped'),
         'pipeline': dict(step.stats) if args.workload == 'full' else None,
-        'per_rank': [{'rank': r, 'agents': a, 'ms_per_step': t, 'device': d, 'local_rank': lr} for r, a, t, d, lr in per_rank],
+        'per_rank': [{'rank': r[0], 'agents': r[1], 'ms_per_step': r[2], 'device': r[3], 'local_rank': r[4], 'cores': r[5] if len(r) > 5 else None}
+                     for r in per_rank],
         # what the collective backend saw (N > 1: RCCL = torch.distributed 'nccl'): world size it reports and the distinct devices
         'rccl_world_size': backend['rccl_world_size'], 'rccl_backend': backend['rccl_backend'],
         'distinct_devices': backend['distinct_devices'],
@@ -1187,14 +1189,15 @@ def dry_run(args, rank, world):
     rollouts = 2 if args.workload in ('adv', 'sharded4096', 'train') else 1
     units_local = rollouts * mine['agents'] * args.ft * args.steps
     dt, units, per_rank, backend = gather_ranks(use_dist, world, torch.device('cpu'), dt_local, units_local,
-                                                [rank, mine['agents'], round(dt_local / args.steps * 1e3, 3), 'cpu:rank%d/pid%d' % (rank, os.getpid()), local])
+                                                [rank, mine['agents'], round(dt_local / args.steps * 1e3, 3), 'cpu:rank%d/pid%d' % (rank, os.getpid()), local,
+                                                 host_pin.get('cores')])
     if rank == 0:
         keys = [k for e in everyone for k in e['scenes']]
         rec = {'dry_run': True, 'n_gpus': world, 'ranks_joined': sorted(e['rank'] for e in everyone), 'scaling': scaling,
                'workload': desc, 'agents_per_rank': [e['agents'] for e in everyone], 'total_agents': sum(e['agents'] for e in everyone),
                'scenes_per_rank': [len(e['scenes']) for e in everyone], 'disjoint': len(keys) == len(set(keys)),
                'units': units, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-               'per_rank': [{'rank': r, 'agents': a, 'ms_per_step': t, 'device': d, 'local_rank': lr} for r, a, t, d, lr in per_rank],
+               'per_rank': [{'rank': r[0], 'agents': r[1], 'ms_per_step': r[2], 'device': r[3], 'local_rank': r[4], 'cores': r[5]} for r in per_rank],
                'rccl_world_size': backend['rccl_world_size'], 'rccl_backend': backend['rccl_backend'],
                'distinct_devices': backend['distinct_devices'], 'host': host_pin}
         if args.workload == 'sharded4096':
