@@ -342,6 +342,43 @@ def g4_rollout(R):
     save('g4_rollout.npz', **out)
 
 
+def g4u_inputs():
+    """g4's scenes over a UNIFORM raster (layer 0 = 1 everywhere): every crop is the same image, so the reference's free-running
+    rollout and the product's cannot part at a crop flip -- a tight reference-direct comparison of bare rollouts."""
+    batch, map_idx, _, dx = build_inputs(G4_SIZES, 'g4')
+    raster = torch.zeros((1, 4, RASTER_HW, RASTER_HW), dtype=torch.uint8)
+    raster[:, 0] = 1
+    return batch, map_idx, raster, dx
+
+
+def g4u_rollout(R):
+    """The reference's decode_embedding (src/models/traffic_model.py:405-414, 626-698) over the uniform raster: nfuture 12 / 16,
+    ext_future, NS = 2, each with d(sum(pred * r))/dz."""
+    out = {}
+    tm, _ = ref_model(R, FT=12)
+    batch, map_idx, raster, dx = g4u_inputs()
+    env = ref_map_env(R, raster, dx)
+    with torch.no_grad():
+        emb = R.scenario_gen.detach_embed_info(tm.embed(batch, map_idx, env))
+    out['map_feat'] = npy(emb['map_feat'])
+    out['past_feat'] = npy(emb['past_feat'])
+    out['prior_mu'] = npy(emb['prior_out'][0])
+    out['prior_var'] = npy(emb['prior_out'][1])
+    ego = batch.ptr[:-1]
+    ext = batch.future_gt[ego][:, :, :4]
+    z1 = synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='g4/z')
+    z2 = torch.stack([z1, synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='g4/z_b')], dim=1)
+    for name, zz, kw, rk in (('ft12', z1, {'nfuture': 12}, 'g4u/r12'), ('ft16', z1, {'nfuture': 16}, 'g4u/r16'),
+                             ('ext', z1, {'ext_future': ext}, 'g4u/rext'), ('ns', z2, {}, 'g4u/rns')):
+        z = zz.clone().requires_grad_(True)
+        pred = tm.decode_embedding(z, emb, batch, map_idx, env, **kw)['future_pred']
+        rw = synth.f32(synth.counter_uniform(tuple(pred.shape), rk, -1.0, 1.0))
+        gz, = torch.autograd.grad((pred * rw).sum(), [z])
+        out['pred_' + name] = npy(pred)
+        out['gz_' + name] = npy(gz)
+    save('g4u_rollout.npz', **out)
+
+
 G4B_SIZES = [4, 2, 1]
 
 
@@ -1018,8 +1055,8 @@ G8_CASES = [(15.0, 0, 0.0, None, False), (15.0, 2, 0.5, None, True), (25.0, 1, 0
 if __name__ == '__main__':
     torch.set_num_threads(8)
     R = import_reference()
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g4b', 'g5', 'g6', 'g6l', 'g6h', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g4u', 'g4b', 'g5', 'g6', 'g6l', 'g6h', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12']
     fns = {'g1': g1_ops, 'g2': g2_crop, 'g3': g3_gnn, 'g4': g4_rollout, 'g5': g5_losses, 'g6': g6_loop, 'g7': g7_sample,
-           'g8': g8_checks, 'g9': g9_wire, 'g6l': g6_loops, 'g4b': g4b_nc5, 'g10': g10_planner, 'g6h': g6h_hardcode, 'g11': g11_eval, 'g12': g12_refine_fn}
+           'g8': g8_checks, 'g9': g9_wire, 'g6l': g6_loops, 'g4b': g4b_nc5, 'g4u': g4u_rollout, 'g10': g10_planner, 'g6h': g6h_hardcode, 'g11': g11_eval, 'g12': g12_refine_fn}
     for w in which:
         fns[w](R)

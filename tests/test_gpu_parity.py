@@ -367,6 +367,41 @@ def test_rollout_textured_tight_at_the_same_crops(model, sizes, FT, NS, ext):
 
 
 @pytest.mark.parametrize('case', ['ft12', 'ft16', 'ext', 'ns'])
+def test_rollout_golden_uniform(model, case):
+    """Bare rollouts against the REFERENCE, no oracle in between and no crop flips to gate: fixture g4u = the reference's
+    decode_embedding (src/models/traffic_model.py:405-414, 626-698) on g4's scenes over a uniform raster -- nfuture 12 / 16,
+    ext_future, NS = 2 -- with d/dz.  Forward 1e-4 relative / 2e-5 absolute on every cell, gradient 2e-3 relative."""
+    m, sd = model
+    g = golden('g4u_rollout.npz')
+    batch, map_idx, raster, dx = mg.g4u_inputs()
+    env = dev_env(raster, dx)
+    bg = batch.clone().to(DEV)
+    with torch.no_grad():
+        emb_own = m.embed(bg, map_idx.to(DEV), env)
+    assert_close(emb_own['map_feat'], g['map_feat'], RT, AT, 'g4u map_feat')
+    emb = {'map_feat': torch.from_numpy(g['map_feat']).to(DEV), 'past_feat': torch.from_numpy(g['past_feat']).to(DEV)}
+    pmu, pvar = torch.from_numpy(g['prior_mu']), torch.from_numpy(g['prior_var'])
+    z = synth.make_latents(pmu, pvar, key='g4/z')
+    kw = {}
+    if case == 'ft12':
+        rk, kw = 'g4u/r12', {'nfuture': 12}
+    elif case == 'ft16':
+        rk, kw = 'g4u/r16', {'nfuture': 16}
+    elif case == 'ext':
+        rk, kw = 'g4u/rext', {'ext_future': bg.future_gt[bg.ptr[:-1].to(DEV)][:, :, :4].contiguous()}
+    else:
+        rk = 'g4u/rns'
+        z = torch.stack([z, synth.make_latents(pmu, pvar, key='g4/z_b')], dim=1)
+    zg = z.to(DEV).requires_grad_(True)
+    pred = m.decode_embedding(zg, emb, bg, map_idx.to(DEV), env, **kw)['future_pred']
+    rw = synth.f32(synth.counter_uniform(tuple(pred.shape), rk, -1.0, 1.0)).to(DEV)
+    (pred * rw).sum().backward()
+    assert_close(pred, g['pred_' + case], RT, AT, 'g4u pred_' + case)
+    gw = g['gz_' + case]
+    assert_close(zg.grad, gw, 2e-3, 1e-6 + 2e-4 * float(np.abs(gw).max()), 'g4u gz_' + case)
+
+
+@pytest.mark.parametrize('case', ['ft12', 'ft16', 'ext', 'ns'])
 def test_rollout_golden_textured(model, case):
     m, sd = model
     g = golden('g4_rollout.npz')
@@ -405,7 +440,12 @@ def test_rollout_golden_textured(model, case):
                        mean[:4], std[:4], ext_rows=ext_rows)
     group = (batch.batch.view(-1, 1) * NS + torch.arange(NS).view(1, NS)).reshape(-1)
     clean = clean_mask(flips, group)
-    n_clean, n_all = assert_close_flip_gated(pred.reshape(R, FT, 4), want.reshape(R, FT, 4), clean, RT, AT, 1e-2, pk, min_clean=R)
+    # at least this fraction of the (row, step) cells must be tight (measured in round 5: 35 / 108, 38 / 144, 32 / 108, 83 / 216 -- the
+    # same deterministic inputs every run; three quarters of that as the floor.  The tight reference-direct statement over ALL cells
+    # is test_rollout_golden_uniform)
+    min_frac = {'ft12': 0.24, 'ft16': 0.19, 'ext': 0.22, 'ns': 0.28}[case]
+    n_clean, n_all = assert_close_flip_gated(pred.reshape(R, FT, 4), want.reshape(R, FT, 4), clean, RT, AT, 1e-2, pk,
+                                             min_clean=max(R, int(np.ceil(min_frac * R * FT))))
     print('golden %s: %d crop differences in %d (row, step) crops, %d of %d cells tight' % (case, int(flips.sum()), R * (FT - 1), n_clean, n_all))
     gw = g[gk]
     if not bool(flips.any()):

@@ -159,6 +159,32 @@ def test_g4_rollout(g4_setup, case):
     assert_close(gz, g[gk], 1e-3, 1e-6, gk)
 
 
+@pytest.mark.parametrize('case', ['ft12', 'ft16', 'ext', 'ns'])
+def test_g4u_rollout_uniform_raster(sd, case):
+    """The oracle against fixture g4u (the reference's rollouts of g4's scenes over a uniform raster): the same bound as g4."""
+    g = golden('g4u_rollout.npz')
+    batch, map_idx, raster, dx = mg.g4u_inputs()
+    env = synth.SyntheticMapEnv(raster, dx)
+    orc = oracle_model(sd)
+    with torch.no_grad():
+        emb = orc.embed(batch, map_idx, env)
+    assert_close(emb['map_feat'], g['map_feat'], RT, AT, 'g4u map_feat')
+    z = synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='g4/z')
+    kw, rk = {}, 'g4u/r' + {'ft12': '12', 'ft16': '16', 'ext': 'ext', 'ns': 'ns'}[case]
+    if case in ('ft12', 'ft16'):
+        kw = {'nfuture': int(case[2:])}
+    elif case == 'ext':
+        kw = {'ext_future': batch.future_gt[batch.ptr[:-1]][:, :, :4]}
+    else:
+        z = torch.stack([z, synth.make_latents(emb['prior_out'][0], emb['prior_out'][1], key='g4/z_b')], dim=1)
+    z = z.requires_grad_(True)
+    pred = orc.decode_embedding(z, emb, batch, map_idx, env, **kw)['future_pred']
+    rw = synth.f32(synth.counter_uniform(tuple(pred.shape), rk, -1.0, 1.0))
+    gz, = torch.autograd.grad((pred * rw).sum(), [z])
+    assert_close(pred, g['pred_' + case], RT, AT, 'g4u pred_' + case)
+    assert_close(gz, g['gz_' + case], 1e-3, 1e-6, 'g4u gz_' + case)
+
+
 def test_g4b_nc5():
     """NC = 5 (reduce_cats): embed + rollout forward / d/dz of the oracle vs the reference, textured and uniform raster."""
     g = golden('g4b_nc5.npz')
