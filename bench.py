@@ -138,13 +138,16 @@ def workload_scenes(args, rank, world):
     return own, 'one batch of %d agents in %d scenes of 2..30, scene-sharded over %d ranks' % (sum(sizes), len(sizes), world), 'strong'
 
 
-def build_model(device, NC):
+def build_model(device, NC, lane_keeping=False):
+    """Random-init weights of the reference architecture (synth.fill_state_dict); the closed-loop workloads (rule-based planner) take the
+    lane-keeping variant (synth.lane_keeping_weights: the decoder's output layer scaled down so that agents follow their lanes)."""
     from strive_amd import synth
     from strive_amd.constants import NUSC_BIKE_PARAMS, state_norm_tensors, att_norm_tensors
     from strive_amd.models.traffic_model import TrafficModel
     from strive_amd.datasets.utils import MeanStdNormalizer
     m = TrafficModel(4, 12, 256, NC)
-    m.load_state_dict(synth.fill_state_dict(m.state_dict()))
+    sd = synth.fill_state_dict(m.state_dict())
+    m.load_state_dict(synth.lane_keeping_weights(sd) if lane_keeping else sd)
     m.set_normalizer(MeanStdNormalizer(*state_norm_tensors()))
     m.set_att_normalizer(MeanStdNormalizer(*att_norm_tensors()))
     m.set_bicycle_params(NUSC_BIKE_PARAMS)
@@ -165,7 +168,10 @@ def build_batch(own, NC, raster_px, FT_data=12, lane_graph=None):
         per_row = max(1, int((extent - 240.0) // 120.0))
         for b, (n, key) in enumerate(own):
             centre = (129.0 + 120.0 * (b % per_row), 129.0 + 120.0 * ((b // per_row) % per_row))
-            poses = synth.lane_scene_poses(lane_graph, n, key + '/lane', radius=30.0 + 1.5 * n, centre=centre)
+            # (10 m between agents and speeds of 4..6 m/s: with 6 m and 2..8 m/s a quarter of the scenes had the rule-based planner
+            # run into a slower agent on its own lane before the adversary did anything -- scenes the reference drops after its
+            # init stage, src/adv_scenario_gen.py:323-356)
+            poses = synth.lane_scene_poses(lane_graph, n, key + '/lane', radius=34.0 + 2.2 * n, centre=centre, min_gap=10.0, speed=(4.0, 6.0))
             scenes.append(synth.make_scene(n, key, FT=FT_data, NC=NC, poses=poses))
     batch = Batch.from_data_list(scenes)
     return batch, torch.zeros((len(own),), dtype=torch.long)
@@ -969,10 +975,10 @@ def main():
         dist.barrier()
 
     own, desc, scaling = workload_scenes(args, rank, world)
-    m = build_model(device, args.nc)
     lane_graph = None
     if args.workload == 'full':
         args.planner = 'hardcode'
+    m = build_model(device, args.nc, lane_keeping=args.planner == 'hardcode')
     if args.planner == 'hardcode':
         if args.workload not in ('adv', 'full'):
             raise SystemExit("bench.py: --planner hardcode belongs to --workload adv / full")
@@ -1092,7 +1098,10 @@ def main():
                                   'fp32 everywhere; forward map CNN and dense layers on the fp16 matrix cores with two-piece round-to-nearest '
                                   'operand splits (3 products per fp32 product, dropped terms <= 2^-24); the CNN BACKWARD (data and weight '
                                   'gradients) with two-piece bf16 operand splits: 2^-16 per product (TF32-class), fp32 accumulate'),
-                   'rollout_kernels': rollout_kernels, 'hip_graph': hip_graph},
+                   'rollout_kernels': rollout_kernels, 'hip_graph': hip_graph,
+                   'weights': ('random init (synth.fill_state_dict)' if args.planner != 'hardcode' else
+                               'random init, decoder output layer scaled (acceleration x0.3, yaw acceleration x0.05: synth.lane_keeping_weights) '
+                               'so that the predicted agents follow their lanes -- what the rule-based planner assumes')},
         # the timed path (graph replay) against one eager iteration from the same latents and Adam state, after the timed region:
         # max |z_replayed - z_eager| (and how far that iteration moved the latents); the run FAILS above 1e-5
         'graph_vs_eager_max_abs': None if gve is None else gve[0],

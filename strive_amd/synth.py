@@ -187,6 +187,22 @@ def make_batch(sizes, key='scene', PT=4, FT=12, NC=2, map_extent=(256.0, 256.0),
 # weights
 # --------------------------------------------------------------------------------------------
 
+def lane_keeping_weights(sd, yaw=0.05, acc=0.3):
+    """A copy of a synthetic state dict whose decoder steers and accelerates gently: the last layer of ``decoder_net.mlp_out``
+    (2 outputs per agent and step: acceleration, yaw acceleration -- reference src/models/traffic_model.py:655-662) scaled by
+    ``acc`` / ``yaw``.  With the plain random weights the predicted agents swing 40-60 degrees off their lanes within the 6 s
+    horizon and end up 10 m from any lane: the rule-based planner (reference src/planners/hardcode_goalcond_nusc.py), whose routes
+    follow lanes, then gives up on a third of the scenes ('arc length outside a route'), which says something about random
+    weights, not about adv_gen_rule_based.cfg.  Same shapes, same kernels, same cost: only the closed-loop workloads use it."""
+    out = {k: v.clone() for k, v in sd.items()}
+    w, b = out['decoder_net.mlp_out.net.6.weight'], out['decoder_net.mlp_out.net.6.bias']
+    w[0] *= acc
+    b[0] *= acc
+    w[1] *= yaw
+    b[1] *= yaw
+    return out
+
+
 def fill_state_dict(sd, key='weights', scale=1.0):
     """Overwrite every tensor of a TrafficModel ``state_dict`` with counter-based values:
     Linear/Conv/GRU weights and biases U(+-scale/sqrt(fan_in)); LayerNorm/GroupNorm weight 1+small, bias small.
@@ -322,9 +338,9 @@ def make_lane_graph(extent=256.0, period=40.0, centre=9.0, lane_off=3.0, step=2.
     return assemble_lane_graph(lanes, outgoing)
 
 
-def lane_scene_poses(lane_graph, n, key, radius=35.0, centre=(128.0, 128.0)):
+def lane_scene_poses(lane_graph, n, key, radius=35.0, centre=(128.0, 128.0), min_gap=6.0, speed=(2.0, 8.0)):
     """(px, py, h, s) of ``n`` agents sitting on lane nodes within ``radius`` of ``centre`` (ego = the node closest to the
-    centre), headed along their lane, speeds 2..8 m/s, no two closer than 6 m."""
+    centre), headed along their lane, speeds ``speed`` (default 2..8 m/s), no two closer than ``min_gap`` (default 6 m)."""
     xy = lane_graph['xy']
     d = np.linalg.norm(xy - np.asarray(centre)[None], axis=1)
     cand = [int(i) for i in np.argsort(d) if d[i] <= radius and len(lane_graph['out_edges'][int(i)]) > 0]
@@ -334,12 +350,12 @@ def lane_scene_poses(lane_graph, n, key, radius=35.0, centre=(128.0, 128.0)):
         c = cand[int(k)]
         if len(pick) >= n:
             break
-        if all(np.linalg.norm(xy[c] - xy[q]) >= 6.0 for q in pick):
+        if all(np.linalg.norm(xy[c] - xy[q]) >= min_gap for q in pick):
             pick.append(c)
     assert len(pick) == n, 'not enough lane nodes for %d agents' % n
     px, py = xy[pick, 0].copy(), xy[pick, 1].copy()
     nxt = [lane_graph['out_edges'][c][0] for c in pick]
     hd = xy[nxt] - xy[pick]
     h = np.arctan2(hd[:, 1], hd[:, 0])
-    s = counter_uniform((n,), key + '/ls', 2.0, 8.0)
+    s = counter_uniform((n,), key + '/ls', speed[0], speed[1])
     return px, py, h, s

@@ -468,3 +468,49 @@ def test_device_planner_gpu_512_agents():
     o1, _ = both_planners(bad, 'default', device=dev)
     with pytest.raises(ValueError):
         o1.rollout(bad[4].copy(), t, bad[6], t, control_all=False)
+
+
+def test_bench_world_is_one_the_oracle_planner_completes():
+    """bench.py's closed-loop workloads (--planner hardcode, --workload full) are only a statement about adv_gen_rule_based.cfg if the
+    rule-based planner can drive their synthetic world.  Every third scene of the 512-agent bench batch (lane graph, poses 10 m apart
+    at 4..6 m/s, the lane-keeping synthetic weights): the ORACLE model's decode of the posterior mean (what iteration 0 of the
+    adversarial loop hands the planner, reference src/utils/adv_gen_optim.py:133-139) goes through the ORACLE's restatement of
+    HardcodeNuscPlanner.rollout scene by scene -- which raises, like the reference, when an object leaves its route.  At most one in ten
+    scenes may be rejected (with the plain random weights the agents swing off their lanes and a third is)."""
+    import bench
+    from oracle.planner import HardcodeNuscPlanner as OPlanner, PlannerConfig as OConfig, CONFIG_DICT as OCFG
+    from util import oracle_model, product_model
+    from strive_amd.graph import Batch
+    sizes = bench.variable_scene_sizes(512, 'bench/adv/r0')
+    own = [(n, 'bench/adv/r0/%d' % b) for b, n in enumerate(sizes)]
+    lg = synth.make_lane_graph(extent=1024.0)
+    batch, _ = bench.build_batch(own, 2, 4096, lane_graph=lg)
+    scenes = batch.to_data_list()[0::3]
+    sub = Batch.from_data_list(scenes)
+    B = len(scenes)
+    map_idx = torch.zeros((B,), dtype=torch.long)
+    raster, dx = synth.make_raster(4096, 4096)
+    env = synth.SyntheticMapEnv(raster, dx, lane_graph=lg)
+    _, sd = product_model()
+    orc = oracle_model(synth.lane_keeping_weights(sd))
+    with torch.no_grad():
+        emb = orc.embed(sub, map_idx, env)
+        pred = orc.decode_embedding(emb['posterior_out'][0], emb, sub, map_idx, env, nfuture=12)['future_pred']
+    unn = orc.get_normalizer().unnormalize
+    fut = unn(pred).numpy()                                            # (NA, 12, 4)
+    st = unn(sub.past_gt[:, -1, :])
+    att = orc.get_att_normalizer().unnormalize(sub.lw)
+    ptr = sub.ptr.numpy()
+    t = np.linspace(0.5, 6.0, 12)
+    rejected = []
+    for b in range(B):
+        lo, hi = int(ptr[b]), int(ptr[b + 1])
+        pl = OPlanner(mg._LaneEnv(lg), OConfig(**OCFG['default']))
+        pl.reset(st[lo:hi], att[lo:hi], torch.zeros((hi - lo,), dtype=torch.long), 1, torch.zeros((1,), dtype=torch.long))
+        try:
+            plan = pl.rollout(fut[lo + 1:hi].astype(np.float32), t, np.array([0, hi - lo - 1]), t, control_all=False)
+            assert np.isfinite(np.asarray(plan)).all()
+        except (AssertionError, ValueError) as e:
+            rejected.append((b, str(e)[:80]))
+    print('bench world, %d of %d scenes: the oracle planner rejects %d %s' % (B, len(sizes), len(rejected), rejected))
+    assert len(rejected) <= B // 10, rejected
