@@ -63,12 +63,16 @@ PEAK_HBM_GBS = 8000.0              # same guide: HBM3E ~8 TB/s
 # (the fifth kernel is the fused tail: conv5 + conv6 + Linear(512, 64) in one launch)
 CONV_FLOPS = [2 * 16 * 125 * 125 * 4 * 49, 2 * 32 * 61 * 61 * 16 * 25, 2 * 64 * 29 * 29 * 32 * 25,
               2 * 64 * 14 * 14 * 64 * 9, 2 * 128 * 6 * 6 * 64 * 9 + 2 * 128 * 2 * 2 * 128 * 9 + 2 * 512 * 64]
-# conv2 runs on specialised producer / consumer waves (conv_ws_kernel) unless STRIVE_CONV_WS=0 keeps conv_bf6_kernel: time the one
-# the closure launches
+# conv2 runs on specialised producer / consumer waves (conv_ws_kernel), conv3 / conv4 on specialised waves with streamed weights
+# (conv_wsx_kernel) unless the options conv_ws / conv_wsx (STRIVE_CONV_WS=0, STRIVE_CONV_WSX=0) keep conv_bf6_kernel: time the ones the
+# closure launches
 CONV_WS = os.environ.get('STRIVE_CONV_WS', '1') != '0'
+CONV_WSX = os.environ.get('STRIVE_CONV_WSX', '1') != '0'
 CONV_NAMES = ['conv1b_kernel<true> (fused crop -> conv1)', 'conv_ws_kernel<conv2>' if CONV_WS else 'conv_bf6_kernel<conv2>',
-              'conv_bf6_kernel<conv3>', 'conv_bf6_kernel<conv4>', 'cnn_tail_kernel (conv5 + conv6 + Linear)']
-CONV_LAYER_IDS = [0, 51 if CONV_WS else 1, 2, 3, 7]      # strive_map_cnn_bench_layer ids of the kernels strive_map_cnn_fwd launches
+              'conv_wsx_kernel<conv3>' if CONV_WSX else 'conv_bf6_kernel<conv3>',
+              'conv_wsx_kernel<conv4>' if CONV_WSX else 'conv_bf6_kernel<conv4>', 'cnn_tail_kernel (conv5 + conv6 + Linear)']
+# strive_map_cnn_bench_layer ids of the kernels strive_map_cnn_fwd launches
+CONV_LAYER_IDS = [0, 51 if CONV_WS else 1, 52 if CONV_WSX else 2, 53 if CONV_WSX else 3, 7]
 # algorithmic HBM bytes per agent of the CNN kernels: input read once + output written once (fp32 activations, uint8 raster)
 CONV_BYTES = [4 * 256 * 256 + 16 * 125 * 125 * 4, (16 * 125 * 125 + 32 * 61 * 61) * 4, (32 * 61 * 61 + 64 * 29 * 29) * 4,
               (64 * 29 * 29 + 64 * 14 * 14) * 4, (64 * 14 * 14 + 64) * 4]
@@ -472,8 +476,8 @@ def train_step_factory(m, env, batch, map_idx, FT, device):
 # side measurements
 # ------------------------------------------------------------------------------------------------
 
-TRAFFIC_FILES = ('r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json')
-UTIL_FILES = ('r05_util.json',)
+TRAFFIC_FILES = ('r06_traffic.json', 'r05_traffic.json', 'r04_traffic.json', 'r03_traffic.json', 'r02_traffic.json', 'r01_traffic.json')
+UTIL_FILES = ('r06_util.json', 'r05_util.json')
 PEAK_LDS_BYTES_PER_CLK_CU = 256.0   # /opt/skills/guides/MI355X_MICROARCH.md, LDS section: ds_read_b64 / b128, conflict-free (157 TB/s at 2.4 GHz)
 
 
@@ -547,6 +551,10 @@ def time_dominant_kernel(m, env, g, mi, emb, device, reps=20):
     st = L.stream_ptr(pos)
     lib.call('strive_map_cnn_fwd', mp.ref(), cnn.ref(), L.ptr(pos), mean4, std4, L.ptr(mapix), N, L.ptr(feat), L.ptr(ws), wsb, st)
     torch.cuda.synchronize()
+    # Each kernel alone, twenty launches back to back between two events.  (Tried in round 6: the five kernels in the closure's order
+    # with an event between every two -- an event record drains and releases the caches at system scope, which adds 15-30 us to every
+    # kernel (conv2 240 us against 202 in the rocprofv3 trace of the same run); the isolated loop is 4-7 % above the in-closure average
+    # because a kernel that follows itself starts while its own 0.25-0.5 GB of output is still being written back.)
     times = []
     for layer in CONV_LAYER_IDS:
         times.append(_event_time(lambda: lib.call('strive_map_cnn_bench_layer', mp.ref(), cnn.ref(), layer, L.ptr(pos), mean4,
@@ -834,7 +842,7 @@ def cpu_baseline_record(FT, full=False):
     closure) and 16 x 16 agents (2 timed closures) -- reports the LARGER sample as `value` and states both, so the trend
     towards C2 is visible (it differs by host: 77 -> 31 agent*timesteps/s from 4 to 32 scenes on the 8-vCPU survey container,
     79 -> 90 from 4 to 16 scenes on the 128-thread EPYC of the GPU boxes).  ``--cpu-baseline-full`` times C2 itself (1 warm-up +
-    2 timed closures, several minutes); profiles/r03_cpu_baseline_c2.json holds that run."""
+    2 timed closures, several minutes); profiles/r06_cpu_baseline_c2.json holds that run (75.6 agent*timesteps/s)."""
     if full:
         rec = cpu_baseline(FT, scenes=32, agents=16, timed=2)
         rec['sample'] = 'C2 itself: ' + rec['sample']
@@ -846,7 +854,7 @@ def cpu_baseline_record(FT, full=False):
     large = cpu_baseline(FT, scenes=16, agents=16, timed=2, warm=0)
     rec = dict(large)
     rec['sample'] = ('bounded samples of C2 (32 x 16 agents): %s || %s.  `value` is the 16 x 16 sample (4 x 16: %.1f, 16 x 16: %.1f '
-                     'agent*timesteps/s); C2 itself, timed with --cpu-baseline-full, is in profiles/r03_cpu_baseline_c2.json' %
+                     'agent*timesteps/s); C2 itself, timed with --cpu-baseline-full, is in profiles/r06_cpu_baseline_c2.json' %
                      (small['sample'], large['sample'], small['value'], large['value']))
     rec['samples'] = [{'scenes': 4, 'agents': 16, 'value': small['value'], 'closure_s': small['closure_s']},
                       {'scenes': 16, 'agents': 16, 'value': large['value'], 'closure_s': large['closure_s']}]

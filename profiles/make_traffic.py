@@ -15,6 +15,8 @@ KERNELS = [
     ('conv1b_kernel<true> (fused crop -> conv1)', 'conv1b_kernel<true, 0>', 4 * 256 * 256 + 16 * 125 * 125 * 4),
     ('conv_bf6_kernel<conv2>', 'conv_bf6_kernel<Cin=16,Cout=32', (16 * 125 * 125 + 32 * 61 * 61) * 4),
     ('conv_ws_kernel<conv2>', 'conv_ws_kernel<Cin=16,Cout=32', (16 * 125 * 125 + 32 * 61 * 61) * 4),
+    ('conv_wsx_kernel<conv3>', 'conv_wsx_kernel<Cin=32,Cout=64', (32 * 61 * 61 + 64 * 29 * 29) * 4),
+    ('conv_wsx_kernel<conv4>', 'conv_wsx_kernel<Cin=64,Cout=64', (64 * 29 * 29 + 64 * 14 * 14) * 4),
     ('conv_bf6_kernel<conv3>', 'conv_bf6_kernel<Cin=32,Cout=64', (32 * 61 * 61 + 64 * 29 * 29) * 4),
     ('conv_bf6_kernel<conv4>', 'conv_bf6_kernel<Cin=64,Cout=64', (64 * 29 * 29 + 64 * 14 * 14) * 4),
     ('cnn_tail_kernel (conv5 + conv6 + Linear)', 'cnn_tail_kernel<', (64 * 14 * 14 + 64) * 4),

@@ -18,6 +18,8 @@ NCU, NSIMD, NXCD = 256, 1024, 8
 KERNELS = [
     ('conv1b_kernel<true> (fused crop -> conv1)', 'conv1b_kernel<true, 0>'),
     ('conv_ws_kernel<conv2>', 'conv_ws_kernel<Cin=16,Cout=32'),
+    ('conv_wsx_kernel<conv3>', 'conv_wsx_kernel<Cin=32,Cout=64'),
+    ('conv_wsx_kernel<conv4>', 'conv_wsx_kernel<Cin=64,Cout=64'),
     ('conv_bf6_kernel<conv3>', 'conv_bf6_kernel<Cin=32,Cout=64'),
     ('conv_bf6_kernel<conv4>', 'conv_bf6_kernel<Cin=64,Cout=64'),
     ('cnn_tail_kernel (conv5 + conv6 + Linear)', 'cnn_tail_kernel<'),

@@ -12,6 +12,9 @@ def short(name):
     m = re.match(r'conv_bf6_kernel<BfCfg<(\d+), (\d+), (\d+), (\d+), (\d+)', name)
     if m:
         return 'conv_bf6_kernel<Cin=%s,Cout=%s,k=%s,in=%s,out=%s>' % m.groups()
+    m = re.match(r'conv_wsx_kernel<BfCfg<(\d+), (\d+), (\d+), (\d+), (\d+)', name)
+    if m:
+        return 'conv_wsx_kernel<Cin=%s,Cout=%s,k=%s,in=%s,out=%s>' % m.groups()
     m = re.match(r'conv_ws_kernel<BfCfg<(\d+), (\d+), (\d+), (\d+), (\d+)', name)
     if m:
         return 'conv_ws_kernel<Cin=%s,Cout=%s,k=%s,in=%s,out=%s>' % m.groups()

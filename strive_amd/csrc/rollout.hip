@@ -376,13 +376,21 @@ struct FwdWs {
     size_t cnn_bytes;
 };
 
-size_t fwd_ws_bytes(size_t R) {
+// elements of each of the two partial-maxima arrays the scene kernels' K-workgroup edge walk writes: (B, K <= 4, NR, 64), and none
+// when the batch can never run on the scene kernels (multi-sample, > 16 agents per scene, weights without fragments).  Sized from
+// what the batch supports, not from the options of the moment, so that an option set between the size query and the call cannot
+// outgrow the workspace.
+size_t fwd_part_elems(const StriveDecoder* dec, const StriveScenes* sc) {
+    return dec && sc && scn::supported(*dec, *sc) ? (size_t)sc->B * 4 * scn::NR * 64 : 0;
+}
+
+size_t fwd_ws_bytes(size_t R, size_t part_elems) {
     size_t b = 0;
     b += strive_align_up(R * 64 * 4, 256);
     b += 2 * strive_align_up(R * STRIVE_HID * 4, 256);
     b += strive_align_up(R * 4, 256);
     b += strive_align_up(strive_map_cnn_workspace_bytes((int32_t)R), 256);
-    b += 2 * strive_align_up(R * 4 * scn::NR * 64 * 4, 256);      // partial maxima of the scene kernels' K-workgroup edge walk (B <= R scenes, K <= 4)
+    b += 2 * strive_align_up(part_elems * 4, 256);
     return b;
 }
 
@@ -469,8 +477,9 @@ static int rollout_forward(const StriveDecoder* dec, const StriveScenes* sc, con
     w.mapix_rows = ar.take<int32_t>(R);
     w.cnn_bytes = strive_map_cnn_workspace_bytes((int32_t)R);
     w.cnn_ws = ar.take<char>(w.cnn_bytes);
-    float* part_a = ar.take<float>(R * 4 * scn::NR * 64);
-    int32_t* part_arg = ar.take<int32_t>(R * 4 * scn::NR * 64);
+    const size_t part_n = fwd_part_elems(dec, sc);
+    float* part_a = ar.take<float>(part_n);
+    int32_t* part_arg = ar.take<int32_t>(part_n);
     STRIVE_CHECK_ARG(ar.ok(), "workspace arena overflow");
 
     const GNNDev gd = gnn_dev(dec->gnn);
@@ -1083,7 +1092,7 @@ int rollout_backward(const StriveDecoder* dec, const StriveScenes* sc, const flo
 extern "C" size_t strive_rollout_workspace_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT) {
     if (!sc) return 0;
     const size_t R = (size_t)sc->NA * sc->NS;
-    const size_t f = fwd_ws_bytes(R), b = bwd_ws_bytes(R, sc->max_n > 0 ? sc->max_n : 1);
+    const size_t f = fwd_ws_bytes(R, fwd_part_elems(dec, sc)), b = bwd_ws_bytes(R, sc->max_n > 0 ? sc->max_n : 1);
     return (f > b ? f : b) + 4096;
 }
 

@@ -353,7 +353,7 @@ def test_device_planner_status_of_earlier_rollouts_is_kept(emu_ops):
     # it surfaces at a later rollout's non-blocking look at the flags (here, on the host device, the very next one; on the GPU
     # when the asynchronous snapshot has arrived) or at the loop's final check() -- never lost behind later, clean rollouts
     real_check = dev.check
-    dev.check = lambda wait=True: real_check(wait) if wait else None          # loop without the opportunistic look
+    dev.check = lambda wait=True, on_error=None: real_check(wait, on_error=on_error) if wait else None   # loop without the opportunistic look
     for _ in range(2):
         plan = dev.rollout(obs, world[5], world[6], world[5], control_all=False)       # later rollouts are clean
         assert not bool(torch.isnan(plan).any())
