@@ -20,6 +20,8 @@ struct StriveTuning {
     int train_overlap, train_overlap_rows;
     int wgrad_atomics, dgrad_igemm, wgrad_igemm, wgrad_tile, wgrad_dbg;
     int planner_prof;
+    int planner_dbg;
+    int planner_groups;
 };
 StriveTuning& strive_tuning();
 

@@ -38,11 +38,13 @@ constexpr int POOLF = 640;
 constexpr int POOLB = 160;
 constexpr int MAXP = 320;       // nodes of one backward + forward chain (+ 2 extensions)
 constexpr int MAXK = 384;       // resampled knots of a route
+static_assert(3 * MAXK <= 4 * MAXP, "RouteLds: the knots' arc lengths and headings reuse the node arrays");
 constexpr int MAXNT = 32;       // nsteps + 1
 constexpr int MAXPRED = 8;      // predicted speed profiles per route
 constexpr int MAXPROF = 64;     // ego speed profiles
 constexpr int PBLK = 25;        // profiles whose running minima a gap thread keeps in registers
-constexpr int NCHUNK = 16;      // trajectory chunks per scene in the gap kernel
+constexpr int NCHUNK = 32;      // most trajectory chunks per scene in the gap kernel (the launch chooses Work::nchunk <= this)
+
 constexpr double LANE_DS = 0.4, LANE_SIG2 = 3.5 * 3.5, SBUFFER = 4.0;   // constants of rollout() (:211-213)
 
 enum { ST_MATCH = 0, ST_KEEP = 1, ST_CHAIN = 2, ST_NODES = 3, ST_KNOTS = 4, ST_RANGE = 5, ST_TRAJ = 6, ST_ACT = 7 };
@@ -57,15 +59,6 @@ struct ChainTab {
     int n, npool;
 };
 
-// A window of 64 consecutive node records (count, first connection, its length) in LDS: the nodes of a lane are consecutive in
-// the reference's lane graph, so a chain walk that would otherwise be one dependent L2 round trip per node reads one coalesced
-// window per 64 nodes.
-struct NodeWin {
-    double len0[64];
-    int n[64], node0[64];
-    int base;
-};
-
 struct RouteLds {
     double m_px[MAXM], m_py[MAXM], m_d[MAXM];
     int m_v0[MAXM], m_v1[MAXM];
@@ -75,11 +68,24 @@ struct RouteLds {
     short queue[MAXM];
     ChainTab<MAXCHF, POOLF> cf;
     ChainTab<MAXCHB, POOLB> cb;
-    double px[MAXP], py[MAXP], cd[MAXP], sn[MAXP];
-    double ks[MAXK], kx[MAXK], ky[MAXK], khx[MAXK], khy[MAXK];
+    // One route's working set.  The node arrays (positions, distances to the pose, arc lengths) are dead once the knots are
+    // resampled from them, and the knots' headings and arc lengths are only written after that (assemble_route: a barrier lies
+    // between): both live in `a`, which takes RouteLds from 35 to 25 KB -- six waves per CU instead of four for a kernel whose
+    // every phase is a latency chain.
+    alignas(16) double a[4 * MAXP];
+    alignas(16) double kx[MAXK], ky[MAXK];
+    __device__ __forceinline__ double* px() { return a; }
+    __device__ __forceinline__ double* py() { return a + MAXP; }
+    __device__ __forceinline__ double* sn() { return a + 2 * MAXP; }
+    __device__ __forceinline__ double* cd() { return a + 3 * MAXP; }
+    __device__ __forceinline__ double* ks() { return a; }
+    __device__ __forceinline__ double* khx() { return a + MAXK; }
+    __device__ __forceinline__ double* khy() { return a + 2 * MAXK; }
+    __device__ __forceinline__ const double* ks() const { return a; }
+    __device__ __forceinline__ const double* khx() const { return a + MAXK; }
+    __device__ __forceinline__ const double* khy() const { return a + 2 * MAXK; }
     double bc[8];                 // broadcast slots
-    int nm, nkept, np, nk, bad;
-    NodeWin win;
+    int nm, nkept, np, nk, bad, flag;
 };
 
 struct Pose { double x, y, h, s; };
@@ -116,33 +122,105 @@ __device__ __forceinline__ double lerp_at(const double* t, const double* y, int 
     return slope * (q - t[lo]) + y[lo];
 }
 
+// a[0] = 0, a[i] = a[i-1] + a[i] for i = 1 .. n-1: numpy's sequential cumulative sum, same additions in the same order, by the calling
+// thread.  What is serial is the chain of float64 additions and nothing else: the terms come from LDS sixteen at a time (as pairs:
+// `a` is 16-byte aligned and the batches start at even indices), the next batch while the current one is added up, and every sum is
+// written into the register its term came in (no copies).  214 knots: 26 k cycles as a load-add-store loop, 11 k with batched loads
+// and a running register, ~3 k like this (routes kernel: 225 of 1081 us were this function, option planner_dbg 8192).
+__device__ __forceinline__ void seq_cumsum(double* a, int n) {
+    constexpr int CB = 16;
+    a[0] = 0.0;
+    if (n < 2) return;
+    double acc = a[1];                       // 0.0 + a[1] is a[1] (the sum starts from +0.0; -0.0 + 0.0 = +0.0 either way)
+    acc = 0.0 + acc;
+    a[1] = acc;
+    int i = 2;
+    if (i + CB <= n) {
+        double2 v[CB / 2], nx[CB / 2];
+        const double2* src = reinterpret_cast<const double2*>(a);
+        double2* dst = reinterpret_cast<double2*>(a);
+#pragma unroll
+        for (int j = 0; j < CB / 2; ++j) v[j] = src[i / 2 + j];
+        for (;;) {
+            const bool more = i + 2 * CB <= n;
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < CB / 2; ++j) nx[j] = src[(i + CB) / 2 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < CB / 2; ++j) {
+                v[j].x = acc + v[j].x;
+                v[j].y = v[j].x + v[j].y;
+                acc = v[j].y;
+            }
+#pragma unroll
+            for (int j = 0; j < CB / 2; ++j) dst[i / 2 + j] = v[j];
+            i += CB;
+            if (!more) break;
+#pragma unroll
+            for (int j = 0; j < CB / 2; ++j) v[j] = nx[j];
+        }
+    }
+    for (; i < n; ++i) { acc = acc + a[i]; a[i] = acc; }
+}
+
+// wave-uniform helpers of the chain walk: lane `idx`'s copy of a value, and a condition every lane agrees on as a scalar
+__device__ __forceinline__ int lane_val(int v, int idx) { return __builtin_amdgcn_readlane(v, idx); }
+__device__ __forceinline__ double lane_val(double v, int idx) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), idx), __builtin_amdgcn_readlane(__double2loint(v), idx));
+}
+__device__ __forceinline__ bool uniform(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
+
 // all chains from v: breadth first, connection lists in order (expand_verts, :379-414).  WHOLE WAVE, uniform control flow: every
-// lane walks the same chain on the same values (the window is refilled cooperatively), lane 0 writes the tables.
+// lane walks the same chain on the same values, the workgroup's first thread writes the tables.  The nodes of a lane are consecutive
+// in the reference's lane graph, so a walk that would be one dependent L2 round trip per node keeps a WINDOW of 64 consecutive node
+// records (count, first connection, its length) in registers, one record per lane, refilled by one coalesced load per 64 nodes;
+// a step of the walk is three v_readlane and one float64 addition (round 6: the window used to live in LDS -- three dependent LDS
+// reads per node, 77 k of the routes kernel's 335 k ticks per pose).
 // dir = +1 walks successors (the window reaches forward), -1 predecessors (backward).
 template <int NCH, int NPOOL>
-__device__ void build_chains(ChainTab<NCH, NPOOL>& c, NodeWin& win, const StriveLaneNode* rec, int N, const int32_t* cptr,
+__device__ void build_chains(ChainTab<NCH, NPOOL>& c, const StriveLaneNode* rec, int N, const int32_t* cptr,
                              const int32_t* cidx, const double* clen, int v, double mindist, bool first_only, int dir, int32_t* status) {
     const int lane = lane_id();
     int n = 1, npool = 0;
     __syncthreads();
-    if (leader()) { c.parent[0] = -1; c.fork[0] = 0; c.first[0] = v; c.len[0] = 0.0; win.base = -1000; }
+    if (leader()) { c.parent[0] = -1; c.fork[0] = 0; c.first[0] = v; c.len[0] = 0.0; }
     __syncthreads();
+    int wb = -1000;                      // lane l holds the record of node wb + l
+    int w_n = 0, w_node0 = 0;
+    double w_len0 = 0.0;
+    unsigned long long plain = 0ull;
     for (int ci = 0; ci < n; ++ci) {
         double length = c.len[ci];
-        int cur = c.first[ci];
-        int total = c.fork[ci] + 1, cnt = 0;
+        int cur = __builtin_amdgcn_readfirstlane(c.first[ci]);
+        int total = __builtin_amdgcn_readfirstlane((int)c.fork[ci]) + 1, cnt = 0;
         const int ownoff = npool;
-        while (length <= mindist) {
-            int wb = win.base;
+        while (uniform(length <= mindist)) {
             if (cur < wb || cur >= wb + 64) {
-                __syncthreads();
                 wb = dir > 0 ? cur : cur - 63;
                 const int i = wb + lane;
-                if (i >= 0 && i < N) { win.n[lane] = rec[i].n; win.node0[lane] = rec[i].node[0]; win.len0[lane] = rec[i].len[0]; }
-                if (leader()) win.base = wb;
-                __syncthreads();
+                w_n = 0;
+                if (i >= 0 && i < N) { w_n = rec[i].n; w_node0 = rec[i].node[0]; w_len0 = rec[i].len[0]; }
+                // nodes whose only step (first_only: whose first step) leads to the next node of the window
+                plain = __ballot((first_only ? w_n >= 1 : w_n == 1) && w_node0 == i + dir);
             }
-            const int rn = win.n[cur - wb];
+            const int idx = cur - wb;
+            {
+                // a run of plain nodes from cur on: nothing to look at but the lengths -- two v_readlane and one addition per node
+                const unsigned long long m = dir > 0 ? (plain >> idx) : (plain << (63 - idx));
+                const int run = ~m == 0ull ? 64 : (dir > 0 ? __builtin_ctzll(~m) : __builtin_clzll(~m));
+                int steps = 0;
+                while (steps < run && npool + steps < NPOOL && total + steps < MAXP - 4 && uniform(length <= mindist)) {
+                    length = length + lane_val(w_len0, idx + dir * steps);
+                    ++steps;
+                }
+                if (steps > 0) {
+                    if (threadIdx.x < 64 && lane < steps) c.pool[npool + lane] = cur + dir * (lane + 1);
+                    cur += dir * steps; npool += steps; cnt += steps; total += steps;
+                    continue;
+                }
+            }
+            const int rn = lane_val(w_n, idx);
             if (rn == 0) break;
             if (!first_only && rn > 1) {
                 const StriveLaneNode r = rec[cur];
@@ -156,14 +234,14 @@ __device__ void build_chains(ChainTab<NCH, NPOOL>& c, NodeWin& win, const Strive
                 }
             }
             if (npool >= NPOOL || total >= MAXP - 4) { if (leader()) flag(status, ST_NODES); break; }
-            length = length + win.len0[cur - wb];
-            cur = win.node0[cur - wb];
+            length = length + lane_val(w_len0, idx);
+            cur = lane_val(w_node0, idx);
             if (leader()) c.pool[npool] = cur;
             ++npool; ++cnt; ++total;
         }
         if (leader()) { c.ownoff[ci] = (short)ownoff; c.nown[ci] = (short)cnt; c.len[ci] = length; }
         if (first_only) break;
-        __syncthreads();                 // the next chain's start (written by lane 0 above) is read by every lane
+        __syncthreads();                 // the next chain's start (written by the first thread above) is read by every lane
     }
     if (leader()) { c.n = n; c.npool = npool; }
     __syncthreads();
@@ -172,19 +250,39 @@ __device__ void build_chains(ChainTab<NCH, NPOOL>& c, NodeWin& win, const Strive
 template <int NCH, int NPOOL>
 __device__ __forceinline__ int chain_nodes(const ChainTab<NCH, NPOOL>& c, int ci) { return c.fork[ci] + 1 + c.nown[ci]; }
 
-// node positions of chain ci into px/py at index base + sign * position (whole wave)
+// node ids of chain ci into nid at index base + sign * position (whole wave; LDS to LDS)
 template <int NCH, int NPOOL>
-__device__ void fill_chain(const ChainTab<NCH, NPOOL>& c, int ci, const double* xy, double* px, double* py, int base, int sign) {
+__device__ void chain_ids(const ChainTab<NCH, NPOOL>& c, int ci, int* nid, int base, int sign) {
     int cur = ci, hi = chain_nodes(c, ci);
     while (cur >= 0) {
         const int lo = c.fork[cur];
-        for (int pos = lo + lane_id(); pos < hi; pos += 64) {
-            const int v = pos == lo ? c.first[cur] : c.pool[c.ownoff[cur] + pos - lo - 1];
-            px[base + sign * pos] = xy[2 * v];
-            py[base + sign * pos] = xy[2 * v + 1];
-        }
+        for (int pos = lo + lane_id(); pos < hi; pos += 64)
+            nid[base + sign * pos] = pos == lo ? c.first[cur] : c.pool[c.ownoff[cur] + pos - lo - 1];
         hi = lo;
         cur = c.parent[cur];
+    }
+}
+
+// positions of the nodes nid[first .. first + n) into px / py (whole wave): the ids are collected first so that every position load
+// of a route is in flight together -- gathered level by level of the chain tree (LDS read -> global load -> LDS store per level,
+// for both chains in turn) the positions were half of assemble_route
+__device__ void gather_nodes(const int* nid, const double* xy, double* px, double* py, int first, int n) {
+    constexpr int U = (MAXP + 63) / 64;
+    const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;       // (the workgroup shares the positions: one wave takes five each, eleven one)
+    int v[U];
+    double x[U], y[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int p = tid + nthr * u;
+        v[u] = p < n ? nid[first + p] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (v[u] >= 0) { x[u] = xy[2 * v[u]]; y[u] = xy[2 * v[u] + 1]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int p = tid + nthr * u;
+        if (v[u] >= 0) { px[first + p] = x[u]; py[first + p] = y[u]; }
     }
 }
 
@@ -298,8 +396,8 @@ __device__ void match_and_cluster(RouteLds& R, const StrivePlannerMap& mp, const
 __device__ void straight_route(RouteLds& R, const Pose& o, const RouteGeom& g) {
     if (leader()) {
         const double c = cos(o.h), s = sin(o.h);
-        R.ks[0] = -g.back; R.kx[0] = o.x - g.back * c; R.ky[0] = o.y - g.back * s; R.khx[0] = c; R.khy[0] = s;
-        R.ks[1] = g.fwd;   R.kx[1] = o.x + g.fwd * c;  R.ky[1] = o.y + g.fwd * s;  R.khx[1] = c; R.khy[1] = s;
+        R.ks()[0] = -g.back; R.kx[0] = o.x - g.back * c; R.ky[0] = o.y - g.back * s; R.khx()[0] = c; R.khy()[0] = s;
+        R.ks()[1] = g.fwd;   R.kx[1] = o.x + g.fwd * c;  R.ky[1] = o.y + g.fwd * s;  R.khx()[1] = c; R.khy()[1] = s;
         R.nk = 2;
         R.bad = 0;
     }
@@ -307,9 +405,14 @@ __device__ void straight_route(RouteLds& R, const Pose& o, const RouteGeom& g) {
 }
 
 // one route through (backward chain bi, forward chain fi) of the current match (local_lane_closest / xy2spline, :433-556).
-// Whole wave; leaves the knots in R.ks / kx / ky / khx / khy (R.nk) and R.bad != 0 if the route could not be built.
-__device__ void assemble_route(RouteLds& R, const StrivePlannerMap& mp, const Pose& o, const RouteGeom& g, int fi, int bi, int32_t* status) {
+// Whole wave; leaves the knots in R.ks() / kx / ky / khx / khy (R.nk) and R.bad != 0 if the route could not be built.
+__device__ void assemble_route(RouteLds& R, const StrivePlannerMap& mp, const Pose& o, const RouteGeom& g, int fi, int bi, int32_t* status,
+                               unsigned long long* tp = nullptr, int dbg = 0) {
+    // (option planner_dbg, measurement only: 256 / 512 / 1024 / 2048 run the node gather / the closest-point loop / the resampling /
+    //  the heading loop twice, 4096 / 8192 add a second cumulative sum of the node / of 128 knot terms: the differences are the phases)
     const int lane = lane_id();
+    long long ta = tp ? (long long)clock64() : 0;
+    auto tka = [&](int id) { if (tp) { const long long n = (long long)clock64(); tp[id] += (unsigned long long)(n - ta); ta = n; } };
     const int nbv = chain_nodes(R.cb, bi), nfv = chain_nodes(R.cf, fi);
     const double flen = R.cf.len[fi], blen = R.cb.len[bi];
     const bool ext_f = flen <= g.need_f, ext_b = blen <= g.need_b;
@@ -321,121 +424,135 @@ __device__ void assemble_route(RouteLds& R, const StrivePlannerMap& mp, const Po
         __syncthreads();
         return;
     }
-    fill_chain(R.cb, bi, mp.xy, R.px, R.py, shift + nbv - 1, -1);
-    fill_chain(R.cf, fi, mp.xy, R.px, R.py, shift + nbv, +1);
+    for (int rep = 0; rep < ((dbg & 256) ? 2 : 1); ++rep) {
+        int* nid = reinterpret_cast<int*>(R.cd());        // (the distances that live there are written further down)
+        __syncthreads();
+        chain_ids(R.cb, bi, nid, shift + nbv - 1, -1);
+        chain_ids(R.cf, fi, nid, shift + nbv, +1);
+        __syncthreads();
+        gather_nodes(nid, mp.xy, R.px(), R.py(), shift, nbv + nfv);
+    }
     __syncthreads();
+    tka(0);                 // node positions
     if (leader()) {
         R.bad = 0;
         if (ext_f) {                    // dead end ahead: extend straight
             const int last = shift + nbv + nfv - 1;
-            double dx = R.px[last] - R.px[last - 1], dy = R.py[last] - R.py[last - 1];
+            double dx = R.px()[last] - R.px()[last - 1], dy = R.py()[last] - R.py()[last - 1];
             const double n = norm2(dx, dy);
             dx = dx / n; dy = dy / n;
             const double ext = 1.0 + g.need_f - flen;
-            R.px[last + 1] = R.px[last] + dx * ext;
-            R.py[last + 1] = R.py[last] + dy * ext;
+            R.px()[last + 1] = R.px()[last] + dx * ext;
+            R.py()[last + 1] = R.py()[last] + dy * ext;
         }
         if (ext_b) {
-            double dx = R.px[1] - R.px[2], dy = R.py[1] - R.py[2];
+            double dx = R.px()[1] - R.px()[2], dy = R.py()[1] - R.py()[2];
             const double n = norm2(dx, dy);
             dx = dx / n; dy = dy / n;
             const double ext = 1.0 + g.need_b - blen;
-            R.px[0] = R.px[1] + dx * ext;
-            R.py[0] = R.py[1] + dy * ext;
+            R.px()[0] = R.px()[1] + dx * ext;
+            R.py()[0] = R.py()[1] + dy * ext;
         }
         R.np = np;
     }
     __syncthreads();
     const int ns = np - 1;
-    for (int i = lane; i < ns; i += 64) {
-        const double sx = R.px[i + 1] - R.px[i], sy = R.py[i + 1] - R.py[i];
+    const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;       // (loops over nodes and knots are shared by the workgroup's waves)
+    for (int rep = 0; rep < ((dbg & 512) ? 2 : 1); ++rep)
+    for (int i = tid; i < ns; i += nthr) {
+        const double sx = R.px()[i + 1] - R.px()[i], sy = R.py()[i + 1] - R.py()[i];
         const double sl = norm2(sx, sy);
         const double dx = sx / sl, dy = sy / sl;
-        double along = (o.x - R.px[i]) * dx + (o.y - R.py[i]) * dy;
+        double along = (o.x - R.px()[i]) * dx + (o.y - R.py()[i]) * dy;
         along = fmin(fmax(along, 0.0), sl);
-        const double cx = R.px[i] + along * dx, cy = R.py[i] + along * dy;
-        R.cd[i] = norm2(o.x - cx, o.y - cy);
-        R.sn[i + 1] = sl;
+        const double cx = R.px()[i] + along * dx, cy = R.py()[i] + along * dy;
+        R.cd()[i] = norm2(o.x - cx, o.y - cy);
+        R.sn()[i + 1] = sl;
     }
     __syncthreads();
     if (leader()) {
         // the locally closest point, walking downhill from the matched edge
         int k = nbv - 1 + shift;
-        while (k - 1 >= 0 && R.cd[k - 1] < R.cd[k]) --k;
-        while (k + 1 < ns && R.cd[k + 1] < R.cd[k]) ++k;
-        const double sx = R.px[k + 1] - R.px[k], sy = R.py[k + 1] - R.py[k];
-        const double sl = R.sn[k + 1];
+        while (k - 1 >= 0 && R.cd()[k - 1] < R.cd()[k]) --k;
+        while (k + 1 < ns && R.cd()[k + 1] < R.cd()[k]) ++k;
+        const double sx = R.px()[k + 1] - R.px()[k], sy = R.py()[k + 1] - R.py()[k];
+        const double sl = R.sn()[k + 1];
         const double dx = sx / sl, dy = sy / sl;
-        double along = (o.x - R.px[k]) * dx + (o.y - R.py[k]) * dy;
+        double along = (o.x - R.px()[k]) * dx + (o.y - R.py()[k]) * dy;
         along = fmin(fmax(along, 0.0), sl);
-        const double ax = R.px[k] + along * dx, ay = R.py[k] + along * dy;
-        R.sn[0] = 0.0;
-        double acc = 0.0;                               // (running sum in a register: same additions in the same order, without
-        for (int i = 1; i < np; ++i) { acc = acc + R.sn[i]; R.sn[i] = acc; }      //  a store -> load round trip through LDS per term)
+        const double ax = R.px()[k] + along * dx, ay = R.py()[k] + along * dy;
+        if (dbg & 4096) seq_cumsum(R.cd(), np);
+        seq_cumsum(R.sn(), np);
         R.bc[0] = ax; R.bc[1] = ay;
-        R.bc[2] = R.sn[k];
-        R.bc[3] = norm2(ax - R.px[k], ay - R.py[k]);
+        R.flag = 0;
+        R.bc[2] = R.sn()[k];
+        R.bc[3] = norm2(ax - R.px()[k], ay - R.py()[k]);
     }
     __syncthreads();
     {
         const double off1 = R.bc[2], off2 = R.bc[3];
         __syncthreads();
-        for (int i = threadIdx.x; i < np; i += blockDim.x) R.sn[i] = R.sn[i] - off1 - off2;      // (in place: once per element)
+        for (int i = threadIdx.x; i < np; i += blockDim.x) R.sn()[i] = R.sn()[i] - off1 - off2;      // (in place: once per element)
     }
     __syncthreads();
     const double ax = R.bc[0], ay = R.bc[1];
+    tka(1);                 // closest point, arc lengths
     bool range_bad = false;
-    for (int i = lane; i < nk; i += 64) {
+    for (int rep = 0; rep < ((dbg & 1024) ? 2 : 1); ++rep)
+    for (int i = tid; i < nk; i += nthr) {
         const double q = s_eval_at(g, i);
-        if (q < R.sn[0] || q > R.sn[np - 1]) { range_bad = true; R.kx[i] = 0; R.ky[i] = 0; continue; }
-        const int hi = knot_hi(R.sn, np, q), lo = hi - 1;
+        if (q < R.sn()[0] || q > R.sn()[np - 1]) { range_bad = true; R.kx[i] = 0; R.ky[i] = 0; continue; }
+        const int hi = knot_hi(R.sn(), np, q), lo = hi - 1;
         const double e = exp(-(q * q) / LANE_SIG2);
-        R.kx[i] = lerp_at(R.sn, R.px, lo, hi, q) + (o.x - ax) * e;
-        R.ky[i] = lerp_at(R.sn, R.py, lo, hi, q) + (o.y - ay) * e;
+        R.kx[i] = lerp_at(R.sn(), R.px(), lo, hi, q) + (o.x - ax) * e;
+        R.ky[i] = lerp_at(R.sn(), R.py(), lo, hi, q) + (o.y - ay) * e;
     }
-    if (__ballot(range_bad) != 0ull) {
+    if (range_bad) R.flag = 1;              // (cleared by the first thread two barriers ago)
+    __syncthreads();
+    if (R.flag) {
         if (leader()) { flag(status, ST_RANGE); R.bad = 1; }
         __syncthreads();
         return;
     }
-    __syncthreads();
-    for (int i = lane; i < nk - 1; i += 64) {
+    tka(2);                 // resampling + blend
+    for (int rep = 0; rep < ((dbg & 2048) ? 2 : 1); ++rep)
+    for (int i = tid; i < nk - 1; i += nthr) {
         const double dx = R.kx[i + 1] - R.kx[i], dy = R.ky[i + 1] - R.ky[i];
         const double dl = norm2(dx, dy);
-        R.khx[i] = dx / dl;
-        R.khy[i] = dy / dl;
-        R.ks[i + 1] = dl;
+        R.khx()[i] = dx / dl;
+        R.khy()[i] = dy / dl;
+        R.ks()[i + 1] = dl;
     }
     __syncthreads();
     if (leader()) {
-        R.khx[nk - 1] = R.khx[nk - 2];
-        R.khy[nk - 1] = R.khy[nk - 2];
-        R.khx[g.nb] = cos(o.h);             // the route passes through the object's heading exactly
-        R.khy[g.nb] = sin(o.h);
-        R.ks[0] = 0.0;
-        double acc = 0.0;
-        for (int i = 1; i < nk; ++i) { acc = acc + R.ks[i]; R.ks[i] = acc; }
-        R.bc[4] = R.ks[g.nb];
+        R.khx()[nk - 1] = R.khx()[nk - 2];
+        R.khy()[nk - 1] = R.khy()[nk - 2];
+        R.khx()[g.nb] = cos(o.h);             // the route passes through the object's heading exactly
+        R.khy()[g.nb] = sin(o.h);
+        if (dbg & 8192) seq_cumsum(R.a + 3 * MAXK, 4 * MAXP - 3 * MAXK);
+        seq_cumsum(R.ks(), nk);
+        R.bc[4] = R.ks()[g.nb];
         R.nk = nk;
     }
     __syncthreads();
     {
         const double s0 = R.bc[4];
         __syncthreads();
-        for (int i = threadIdx.x; i < nk; i += blockDim.x) R.ks[i] = R.ks[i] - s0;               // (in place: once per element)
+        for (int i = threadIdx.x; i < nk; i += blockDim.x) R.ks()[i] = R.ks()[i] - s0;               // (in place: once per element)
     }
     __syncthreads();
-    if (leader() && !(R.ks[0] < -g.back && R.ks[nk - 1] > g.fwd)) { flag(status, ST_RANGE); R.bad = 1; }
+    if (leader() && !(R.ks()[0] < -g.back && R.ks()[nk - 1] > g.fwd)) { flag(status, ST_RANGE); R.bad = 1; }
     __syncthreads();
+    tka(3);                 // headings, knot arc lengths
 }
 
 // (x, y, heading angle) of the route in R at arc length q; false outside the route
 __device__ __forceinline__ bool route_pose(const RouteLds& R, double q, double& x, double& y, double& h) {
-    if (q < R.ks[0] || q > R.ks[R.nk - 1]) return false;
-    const int hi = knot_hi(R.ks, R.nk, q), lo = hi - 1;
-    x = lerp_at(R.ks, R.kx, lo, hi, q);
-    y = lerp_at(R.ks, R.ky, lo, hi, q);
-    h = atan2(lerp_at(R.ks, R.khy, lo, hi, q), lerp_at(R.ks, R.khx, lo, hi, q));
+    if (q < R.ks()[0] || q > R.ks()[R.nk - 1]) return false;
+    const int hi = knot_hi(R.ks(), R.nk, q), lo = hi - 1;
+    x = lerp_at(R.ks(), R.kx, lo, hi, q);
+    y = lerp_at(R.ks(), R.ky, lo, hi, q);
+    h = atan2(lerp_at(R.ks(), R.khy(), lo, hi, q), lerp_at(R.ks(), R.khx(), lo, hi, q));
     return true;
 }
 
@@ -476,6 +593,9 @@ struct Work {
     double* poses;          // (B, K, 4)
     int32_t* scene_bad;     // (B)
     int K, cap, ENT, P, NT;
+    int nchunk;             // trajectory chunks per scene of this launch (<= NCHUNK)
+    int dbg;                // option planner_dbg (measurement only): 1 gap: no circle pairs, 4 no staging arithmetic,
+                            // 8 gap: prologue only; 16 ego: no route / profiles / circles; 32 routes: no emission, 64 routes: no assembly, 128 routes: matches only
     size_t nzero;
     unsigned long long* tprof;   // measurement only (STRIVE_PLANNER_PROF): clock sums of the ego kernel's phases, in the workspace's spare tail
 };
@@ -531,10 +651,10 @@ __global__ void planner_world_kernel(StrivePlanner pl, Work w, const double* __r
 // `on_route(i)` is called by the whole wave for i = 0..n-1 with the knots in R (R.bad != 0: the route could not be built)
 template <bool FIRST_ONLY, class G, class F>
 __device__ int for_each_route(RouteLds& R, const StrivePlannerMap& mp, const StrivePlannerCfg& cfg, const Pose& o, int32_t* status,
-                              G&& begin_group, F&& on_route, unsigned long long* tp = nullptr) {
+                              G&& begin_group, F&& on_route, unsigned long long* tp = nullptr, int dbg = 0) {
     const RouteGeom g = route_geom(cfg, o.s);
     long long t0 = tp ? (long long)clock64() : 0;
-    auto tk = [&](int id) { if (tp) { const long long n = (long long)clock64(); atomicAdd(tp + id, (unsigned long long)(n - t0)); t0 = n; } };
+    auto tk = [&](int id) { if (tp) { const long long n = (long long)clock64(); tp[id] += (unsigned long long)(n - t0); t0 = n; } };
     match_and_cluster(R, mp, cfg, o, status);
     tk(0);
     const int nkept = R.nkept;
@@ -545,17 +665,17 @@ __device__ int for_each_route(RouteLds& R, const StrivePlannerMap& mp, const Str
         __syncthreads();
         return 0;
     }
-    const int nmatch = FIRST_ONLY ? 1 : nkept;
+    const int nmatch = (dbg & 128) ? 0 : (FIRST_ONLY ? 1 : nkept);          // (128: matches only)
     for (int mi = 0; mi < nmatch; ++mi) {
         const int m = R.kept[mi];
-        build_chains(R.cf, R.win, mp.succ, mp.N, mp.succ_ptr, mp.succ_idx, mp.succ_len, R.m_v1[m], g.need_f, FIRST_ONLY, +1, status);
-        build_chains(R.cb, R.win, mp.pred, mp.N, mp.pred_ptr, mp.pred_idx, mp.pred_len, R.m_v0[m], g.need_b, FIRST_ONLY, -1, status);
+        build_chains(R.cf, mp.succ, mp.N, mp.succ_ptr, mp.succ_idx, mp.succ_len, R.m_v1[m], g.need_f, FIRST_ONLY, +1, status);
+        build_chains(R.cb, mp.pred, mp.N, mp.pred_ptr, mp.pred_idx, mp.pred_len, R.m_v0[m], g.need_b, FIRST_ONLY, -1, status);
         tk(1);
         const int nf = FIRST_ONLY ? 1 : R.cf.n, nb = FIRST_ONLY ? 1 : R.cb.n;
         begin_group(nf * nb);
         for (int fi = 0; fi < nf; ++fi)
             for (int bi = 0; bi < nb; ++bi) {
-                assemble_route(R, mp, o, g, fi, bi, status);
+                if (!(dbg & 64)) assemble_route(R, mp, o, g, fi, bi, status, (tp && !FIRST_ONLY) ? tp + 12 : nullptr, dbg);
                 on_route(fi * nb + bi);
                 __syncthreads();
             }
@@ -597,12 +717,24 @@ __global__ void __launch_bounds__(64) planner_routes_kernel(StrivePlanner pl, Wo
     __syncthreads();
     const int slot = b * w.K + k;
     double* tbase = w.traj + (size_t)slot * w.cap * w.ENT;
+    // (measurement only, option planner_prof: clock sums over ALL waves -- slots 8.. of the profile tail: match, chains, assemble +
+    //  emit, emit alone, poses, routes)
+    unsigned long long prof[16] = {0};           // (summed per wave, added to the global slots once at the end: sixteen hot addresses
+    unsigned long long* tp = (w.tprof && lane == 0) ? prof : nullptr;      //  under atomics from 1500 waves distorted the first profile)
+    if (tp) tp[4] += 1ull;
     auto begin_group = [&](int n) {
         __syncthreads();
         if (lane == 0) slot_base = atomicAdd(w.traj_cnt + slot, n * npred);
+        if (tp) tp[5] += (unsigned long long)n;
         __syncthreads();
     };
     auto on_route = [&](int ri) {
+        if (w.dbg & 32) return;
+        const long long t_emit = tp ? (long long)clock64() : 0;
+        struct EmitTimer {
+            unsigned long long* tp; long long t0;
+            __device__ ~EmitTimer() { if (tp) tp[3] += (unsigned long long)((long long)clock64() - t0); }
+        } emit_timer{tp, t_emit};
         const int base = slot_base + ri * npred;
         const bool bad = R.bad != 0;
         if (base + npred > w.cap) { if (lane == 0) { flag(status, ST_TRAJ); w.scene_bad[b] = 1; } return; }
@@ -634,7 +766,9 @@ __global__ void __launch_bounds__(64) planner_routes_kernel(StrivePlanner pl, Wo
         __syncthreads();
         if (lane < npred) tbase[(size_t)(base + lane) * w.ENT + 4] = (double)(unsigned)dmask[lane];
     };
-    for_each_route<false>(R, mp, cfg, o, status, begin_group, on_route);
+    for_each_route<false>(R, mp, cfg, o, status, begin_group, on_route, tp, w.dbg);
+    if (tp)
+        for (int i = 0; i < 16; ++i) atomicAdd(w.tprof + 8 + i, prof[i]);
 }
 
 // circle centres of a box (boxes2circles, :860-882): c[0..3] towards the corners, c[4] the centre
@@ -651,12 +785,12 @@ __device__ __forceinline__ void box_circles(double x, double y, double h, double
     cx[4] = x; cy[4] = y;
 }
 
-__global__ void __launch_bounds__(256) planner_ego_kernel(StrivePlanner pl, Work w, int k, int32_t* status_all) {
+__global__ void __launch_bounds__(1024) planner_ego_kernel(StrivePlanner pl, Work w, int k, int b0, int32_t* status_all) {
     __shared__ RouteLds R;
     __shared__ double pdist[MAXPROF][MAXNT];        // distances of the profiles; before that, (1 - pr) of step k-1's profiles
-    __shared__ double risk[MAXPROF];
+    __shared__ double risk[MAXPROF], pfd[MAXPROF];
     const int lane = lane_id(), tid = threadIdx.x, nthr = blockDim.x;
-    const int b = blockIdx.x;
+    const int b = blockIdx.x + b0;
     int32_t* status = status_all + NSTATUS * (size_t)b;
     const StrivePlannerCfg& cfg = pl.cfg;
     const StrivePlannerMap& mp = pl.maps[pl.scene_map[b]];
@@ -670,37 +804,53 @@ __global__ void __launch_bounds__(256) planner_ego_kernel(StrivePlanner pl, Work
             tlast = now;
         }
     };
+    auto sub = [&](int id) {        // (cumulative since the kernel's start, slots 14..19: where inside the first phase)
+        if (w.tprof && tid == 0 && b == 0) atomicAdd(w.tprof + id, (unsigned long long)((long long)clock64() - tlast));
+    };
     if (k == 0 && tid == 0) {
         const double* in = pl.init + 6 * (size_t)(pl.ptr[b] + pl.ego_idx);
         for (int c = 0; c < 6; ++c) eg[c] = in[c];
     }
     __syncthreads();
     if (k > 0) {
+        // the route of step k-1 (what the action below is read from) back into LDS with one coalesced load: its binary search used
+        // to be eight dependent round trips to global memory by thread 0, ~5 of the kernel's 48 us
+        {
+            const double* rt = w.route + (size_t)b * 5 * MAXK;
+            const int nk = w.route_nk[b];
+            for (int i = tid; i < nk; i += nthr) {
+                R.ks()[i] = rt[i]; R.kx[i] = rt[MAXK + i]; R.ky[i] = rt[2 * MAXK + i]; R.khx()[i] = rt[3 * MAXK + i]; R.khy()[i] = rt[4 * MAXK + i];
+            }
+            if (tid < P) pfd[tid] = w.prof[((size_t)b * MAXPROF + tid) * 3 + 2];      // (final distances of the profiles, for the choice)
+        }
         // risk of the profiles of step k-1 (score_dists, :724-728; plot_plan_info, :768-801): all threads take the minimum over
         // the trajectory chunks and the tanh score of one (profile, time) each, then one lane per profile multiplies in time order
         int nother = 0;
-        for (int c = 0; c < NCHUNK; ++c) nother += w.part_cnt[b * NCHUNK + c];
+        for (int c = 0; c < w.nchunk; ++c) nother += w.part_cnt[b * NCHUNK + c];
+        sub(14);
         for (int it = tid; it < P * NT; it += nthr) {
             const int p = it / NT, t = it % NT;
             double gap = INFINITY;
-            for (int c = 0; c < NCHUNK; ++c) gap = fmin(gap, w.part[(((size_t)b * NCHUNK + c) * P + p) * NT + t]);
+            for (int c = 0; c < w.nchunk; ++c) gap = fmin(gap, w.part[(((size_t)b * NCHUNK + c) * P + p) * NT + t]);
             const double wt = cfg.score_wmin + (double)t * cfg.score_wfac;
             double pr = 1.0 + tanh(-gap * wt);
             if (gap < 0) pr = 1.0;
             pdist[p][t] = 1.0 - pr;
         }
         __syncthreads();
+        sub(15);
         if (tid < P) {
             double prod = 1.0;
             for (int t = 0; t < NT; ++t) prod = prod * pdist[tid][t];
             risk[tid] = 1.0 - prod;
         }
         __syncthreads();
+        sub(16);
         if (tid == 0) {
             const double* pf = w.prof + (size_t)b * MAXPROF * 3;
             int best = 0;
             if (nother == 0) {
-                for (int p = 1; p < P; ++p) if (pf[3 * p + 2] > pf[3 * best + 2]) best = p;
+                for (int p = 1; p < P; ++p) if (pfd[p] > pfd[best]) best = p;
             } else {
                 int first_ok = -1;
                 for (int p = 0; p < P; ++p) if (risk[p] < cfg.col_plim) { first_ok = p; break; }
@@ -711,22 +861,23 @@ __global__ void __launch_bounds__(256) planner_ego_kernel(StrivePlanner pl, Work
                     const bool stop = w.prefer_stop[b] != 0;
                     for (int p = first_ok + 1; p < P; ++p) {
                         if (!(risk[p] < cfg.col_plim)) continue;
-                        if (stop ? pf[3 * p + 2] < pf[3 * best + 2] : pf[3 * p + 2] > pf[3 * best + 2]) best = p;
+                        if (stop ? pfd[p] < pfd[best] : pfd[p] > pfd[best]) best = p;
                     }
                 }
             }
+            sub(17);
             // compute_action (:829-857) / postprocess_act_for_speed (:642-666)
             const double x = eg[0], y = eg[1], h = eg[2], s = eg[3];
             const double s_next = ramp_at(s, pf[3 * best], pf[3 * best + 1], 1, cfg.dt);
-            const double* rt = w.route + (size_t)b * 5 * MAXK;
+            const double* rt = R.ks();                 // (the route of step k-1, loaded above)
             const int nk = w.route_nk[b];
             const double q = cfg.dt * s_next;
             double px, py, ph;
             bool ok = nk >= 2 && !(q < rt[0] || q > rt[nk - 1]);
             if (ok) {
                 const int hi = knot_hi(rt, nk, q), lo = hi - 1;
-                const double nx = lerp_at(rt, rt + MAXK, lo, hi, q), ny = lerp_at(rt, rt + 2 * MAXK, lo, hi, q);
-                const double nh = atan2(lerp_at(rt, rt + 4 * MAXK, lo, hi, q), lerp_at(rt, rt + 3 * MAXK, lo, hi, q));
+                const double nx = lerp_at(rt, R.kx, lo, hi, q), ny = lerp_at(rt, R.ky, lo, hi, q);
+                const double nh = atan2(lerp_at(rt, R.khy(), lo, hi, q), lerp_at(rt, R.khx(), lo, hi, q));
                 const double sp = signed_speed(x, y, nx, ny, nh, cfg.dt);
                 const int sg0 = sp > 0 ? 1 : (sp < 0 ? -1 : 0), sg1 = s_next > 0 ? 1 : (s_next < 0 ? -1 : 0);
                 const double dx = nx - x, dy = ny - y;
@@ -751,17 +902,18 @@ __global__ void __launch_bounds__(256) planner_ego_kernel(StrivePlanner pl, Work
     }
     tick(0);                                          // risk scores, choice, action
     if (k >= w.K) return;
+    if (w.dbg & 16) return;
     if (w.scene_bad[b]) return;                       // (NaN state: nothing more to plan for this scene)
     const Pose o = {eg[0], eg[1], eg[2], eg[3]};
     const double el = eg[4], ew = eg[5];
     double* rt = w.route + (size_t)b * 5 * MAXK;
     auto on_route = [&](int) {
         for (int i = tid; i < R.nk; i += nthr) {
-            rt[i] = R.ks[i]; rt[MAXK + i] = R.kx[i]; rt[2 * MAXK + i] = R.ky[i]; rt[3 * MAXK + i] = R.khx[i]; rt[4 * MAXK + i] = R.khy[i];
+            rt[i] = R.ks()[i]; rt[MAXK + i] = R.kx[i]; rt[2 * MAXK + i] = R.ky[i]; rt[3 * MAXK + i] = R.khx()[i]; rt[4 * MAXK + i] = R.khy()[i];
         }
         if (tid == 0) { w.route_nk[b] = R.bad ? 0 : R.nk; if (R.bad) w.scene_bad[b] = 1; }
     };
-    const int nkept = for_each_route<true>(R, mp, cfg, o, status, [](int) {}, on_route, w.tprof && tid == 0 && b == 0 ? w.tprof + 4 : nullptr);
+    const int nkept = for_each_route<true>(R, mp, cfg, o, status, [](int) {}, on_route, w.tprof && tid == 0 && b == 0 ? w.tprof + 4 : nullptr, w.dbg & ~(64 | 128));
     __syncthreads();
     tick(1);                                          // match + chains + route
     if (tid == 0) w.prefer_stop[b] = nkept == 0;
@@ -810,13 +962,19 @@ __global__ void __launch_bounds__(256) planner_ego_kernel(StrivePlanner pl, Work
 // centre, so no gap to a box whose centre is D away can be below D - m_e - m_o (an exact cull, the minimum is unchanged).
 // Trajectory points marked as bit-for-bit duplicates by the routes kernel are not staged at all.
 constexpr int GAP_TJ = 16;          // trajectories staged per round
-__global__ void __launch_bounds__(1024) planner_gap_kernel(StrivePlanner pl, Work w, int k) {
-    __shared__ double ocx[GAP_TJ][MAXNT][5], ocy[GAP_TJ][MAXNT][5];
-    __shared__ double om[GAP_TJ], or4[GAP_TJ];
-    __shared__ unsigned char ook[GAP_TJ][MAXNT];
+static size_t gap_lds_bytes(int NT) { return ((size_t)(2 * GAP_TJ * NT * 5 + 2 * GAP_TJ) * 8 + (size_t)GAP_TJ * NT + 15) / 16 * 16; }
+__global__ void __launch_bounds__(1024) planner_gap_kernel(StrivePlanner pl, Work w, int k, int b0) {
+    // staged boxes, sized by the launch's NT (gap_lds_bytes): 14.5 KB at 11 times instead of 41 KB at the cap of 32, so that all
+    // (scene, chunk) workgroups of a step are resident together
+    HIP_DYNAMIC_SHARED(double, gap_lds)
     __shared__ int cnt;
-    const int b = blockIdx.x, chunk = blockIdx.y;
+    const int b = blockIdx.x + b0, chunk = blockIdx.y;
     const int P = w.P, NT = w.NT;
+    double* const ocx = gap_lds;                        // (GAP_TJ, NT, 5)
+    double* const ocy = ocx + GAP_TJ * NT * 5;
+    double* const om = ocy + GAP_TJ * NT * 5;           // (GAP_TJ)
+    double* const or4 = om + GAP_TJ;
+    unsigned char* const ook = reinterpret_cast<unsigned char*>(or4 + GAP_TJ);      // (GAP_TJ, NT)
     const int tid = threadIdx.x, nthr = blockDim.x;
     const bool active = tid < P * NT;
     const int p = active ? tid / NT : 0, t = active ? tid % NT : 0;
@@ -835,11 +993,12 @@ __global__ void __launch_bounds__(1024) planner_gap_kernel(StrivePlanner pl, Wor
     const int slot = b * w.K + k;
     int J = w.traj_cnt[slot];
     if (J > w.cap) J = w.cap;
-    const int per = (J + NCHUNK - 1) / NCHUNK;
+    const int per = (J + w.nchunk - 1) / w.nchunk;
     const int j0 = chunk * per, j1 = (j0 + per < J) ? j0 + per : J;
     const double* tb = w.traj + (size_t)slot * w.cap * w.ENT;
     if (tid == 0) cnt = 0;
     double gm = INFINITY;
+    if (w.dbg & 8) { if (active) w.part[(((size_t)b * NCHUNK + chunk) * P + p) * NT + t] = e[0]; return; }
     for (int jb = j0; jb < j1; jb += GAP_TJ) {
         const int nj = (j1 - jb) < GAP_TJ ? (j1 - jb) : GAP_TJ;
         __syncthreads();
@@ -857,15 +1016,15 @@ __global__ void __launch_bounds__(1024) planner_gap_kernel(StrivePlanner pl, Wor
                 or4[jj] = Wo / 4;
                 if (near) atomicAdd(&cnt, 1);
             }
-            ook[jj][tt] = (near && !dup) ? 1 : 0;
-            if (near && !dup) box_circles(ent[5 + 3 * tt], ent[6 + 3 * tt], ent[7 + 3 * tt], ol, ow, ocx[jj][tt], ocy[jj][tt]);
+            ook[jj * NT + tt] = (near && !dup) ? 1 : 0;
+            if (near && !dup && !(w.dbg & 4)) box_circles(ent[5 + 3 * tt], ent[6 + 3 * tt], ent[7 + 3 * tt], ol, ow, ocx + (jj * NT + tt) * 5, ocy + (jj * NT + tt) * 5);
         }
         __syncthreads();
         if (active) {
-            for (int jj = 0; jj < nj; ++jj) {
-                if (!ook[jj][t]) continue;
-                const double* cx = ocx[jj][t];
-                const double* cy = ocy[jj][t];
+            for (int jj = 0; jj < ((w.dbg & 1) ? 0 : nj); ++jj) {
+                if (!ook[jj * NT + t]) continue;
+                const double* cx = ocx + (jj * NT + t) * 5;
+                const double* cy = ocy + (jj * NT + t) * 5;
                 const double cdx = cx[4] - e[8], cdy = cy[4] - e[9];
                 const double m22 = cdx * cdx + cdy * cdy;
                 if (sqrt(m22) - m_e - om[jj] - 1e-6 > gm) continue;
@@ -940,7 +1099,7 @@ __global__ void __launch_bounds__(64) planner_routes_debug_kernel(StrivePlanner 
         if (R.bad) return;
         for (int i = lane; i < R.nk && i < maxk; i += 64) {
             double* kn = knots + ((size_t)ri * maxk + i) * 5;
-            kn[0] = R.ks[i]; kn[1] = R.kx[i]; kn[2] = R.ky[i]; kn[3] = R.khx[i]; kn[4] = R.khy[i];
+            kn[0] = R.ks()[i]; kn[1] = R.kx[i]; kn[2] = R.ky[i]; kn[3] = R.khx()[i]; kn[4] = R.khy()[i];
         }
     };
     for_each_route<false>(R, pl.maps[mapix], pl.cfg, o, status, begin_group, on_route);
@@ -998,6 +1157,49 @@ int check_cfg(const StrivePlanner* pl, int nstep, int traj_cap) {
     return 0;
 }
 
+// Library-owned streams per device for the scene groups of one rollout (forked from and joined to the caller's stream with events
+// inside the call: the caller never sees them).  One rollout at a time per device uses them; a second one that arrives meanwhile
+// (another host thread) runs on its own stream alone.
+constexpr int MAXGROUPS = 4;
+struct GroupStreams {
+    hipStream_t s[MAXGROUPS - 1];
+    hipEvent_t start, done[MAXGROUPS - 1];
+    bool ok;
+    std::atomic<int> in_use;
+};
+struct GroupStreamsUse {
+    GroupStreams* g;
+    explicit GroupStreamsUse(GroupStreams* g_) : g(g_) {}
+    ~GroupStreamsUse() { if (g) g->in_use.store(0, std::memory_order_release); }
+};
+GroupStreams* group_streams() {
+    static GroupStreams table[64];
+    static PerDeviceOnce once;
+    static std::atomic<int> busy{0};
+    const int dev = once.device();
+    if (!once.is_done(dev)) {
+        int expect = 0;
+        while (!busy.compare_exchange_weak(expect, 1)) expect = 0;      // (first use per device only)
+        if (!once.is_done(dev)) {
+            GroupStreams& t = table[dev];
+            bool ok = hipEventCreateWithFlags(&t.start, hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; i < MAXGROUPS - 1; ++i) {
+                ok = (hipStreamCreateWithFlags(&t.s[i], hipStreamNonBlocking) == hipSuccess) && ok;
+                ok = (hipEventCreateWithFlags(&t.done[i], hipEventDisableTiming) == hipSuccess) && ok;
+            }
+            (void)hipGetLastError();
+            t.ok = ok;
+            t.in_use.store(0);
+            once.set_done(dev);
+        }
+        busy.store(0);
+    }
+    GroupStreams* g = &table[dev];
+    if (!g->ok) return nullptr;
+    int expect = 0;
+    return g->in_use.compare_exchange_strong(expect, 1, std::memory_order_acquire) ? g : nullptr;
+}
+
 }  // namespace strive_planner
 using namespace strive_planner;
 
@@ -1018,6 +1220,7 @@ extern "C" int strive_planner_rollout(const StrivePlanner* pl, const double* age
     STRIVE_CHECK_ARG(L.total != 0, "workspace too small");
     Work& w = L.w;
     w.tprof = nullptr;
+    w.dbg = strive_tuning().planner_dbg;
     if (strive_tuning().planner_prof) {      // (measurement only: the last 64 bytes of the workspace's spare tail, accumulated over rollouts)
         w.tprof = reinterpret_cast<unsigned long long*>((char*)ws + ((L.total + 7) / 8) * 8 + 64);
     }
@@ -1027,10 +1230,49 @@ extern "C" int strive_planner_rollout(const StrivePlanner* pl, const double* age
         hipLaunchKernelGGL(planner_routes_kernel, dim3(pl->NR * w.K), dim3(64), 0, stream, *pl, w, status);
     }
     const int gap_threads = ((w.P * w.NT + 63) / 64) * 64;
-    for (int k = 0; k <= w.K; ++k) {
-        hipLaunchKernelGGL(planner_ego_kernel, dim3(pl->B), dim3(256), 0, stream, *pl, w, k, status);
-        if (k < w.K)
-            hipLaunchKernelGGL(planner_gap_kernel, dim3(pl->B, NCHUNK), dim3(gap_threads), 0, stream, *pl, w, k);
+    // one thread per (profile, time) of the risk scores and the circles where that fits (25 x 26 -> 704: one pass)
+    const int ego_threads = gap_threads < 256 ? 256 : gap_threads;
+    // Scene groups.  A planner step is ego kernel -> gap kernel -> next step's ego kernel: the ego kernel is one workgroup per scene
+    // walking latency chains (36 CUs of 256 busy for 48 us), the gap kernel fills the chip for 26 us.  Scenes are independent, so
+    // the batch is cut into G groups whose step loops run on G streams: one group's gap kernel runs under the others' ego kernels
+    // (option planner_groups, default 3; 1 = everything on the caller's stream).
+    int G = strive_tuning().planner_groups;
+    if (G > MAXGROUPS) G = MAXGROUPS;
+    if (G > (int)pl->B / 2) G = (int)pl->B / 2;
+    if (G < 1) G = 1;
+    GroupStreams* gs = G > 1 ? group_streams() : nullptr;
+    GroupStreamsUse gs_guard(gs);
+    if (!gs) G = 1;
+    hipStream_t gstream[MAXGROUPS];
+    int gb0[MAXGROUPS + 1];
+    Work gw[MAXGROUPS];
+    gstream[0] = stream;
+    for (int g = 0; g <= G; ++g) gb0[g] = (int)(((long long)pl->B * g) / G);
+    for (int g = 0; g < G; ++g) {
+        if (g > 0) gstream[g] = gs->s[g - 1];
+        gw[g] = w;
+        // chunks per scene: as many as keep the (scene, chunk) workgroups of the groups' gap kernels resident at once -- a workgroup
+        // of P x NT threads is 11 waves at the default 25 x 26, two of them fit a CU, 512 the chip
+        const int waves = gap_threads / 64, per_cu = 32 / waves < 1 ? 1 : 32 / waves;
+        const int nb = gb0[g + 1] - gb0[g];
+        const int nc = (256 * per_cu) / (nb * (G > 1 ? 2 : 1));          // (two groups' gap kernels may coincide)
+        gw[g].nchunk = nc < 4 ? 4 : (nc > NCHUNK ? NCHUNK : nc);
+    }
+    if (G > 1) {
+        hipEventRecord(gs->start, stream);
+        for (int g = 1; g < G; ++g) hipStreamWaitEvent(gstream[g], gs->start, 0);
+    }
+    for (int k = 0; k <= w.K; ++k)
+        for (int g = 0; g < G; ++g) {
+            const int nb = gb0[g + 1] - gb0[g];
+            hipLaunchKernelGGL(planner_ego_kernel, dim3(nb), dim3(ego_threads), 0, gstream[g], *pl, gw[g], k, gb0[g], status);
+            if (k < w.K)
+                hipLaunchKernelGGL(planner_gap_kernel, dim3(nb, gw[g].nchunk), dim3(gap_threads), gap_lds_bytes(w.NT), gstream[g], *pl, gw[g], k,
+                                   gb0[g]);
+        }
+    for (int g = 1; g < G; ++g) {
+        hipEventRecord(gs->done[g - 1], gstream[g]);
+        hipStreamWaitEvent(stream, gs->done[g - 1], 0);
     }
     hipLaunchKernelGGL(planner_interp_kernel, dim3((pl->B * TP + 63) / 64), dim3(64), 0, stream, w, (int)pl->B, t_out, planner_t, (int)TP,
                        plan, status);

@@ -350,6 +350,7 @@ class HardcodeNuscPlanner(PlannerNusc):
         if nbytes == 0:
             raise L.StriveHipError('strive_planner_workspace_bytes: ' + lib.query('strive_last_error').decode())
         ws = ops._workspace(dev, nbytes, tag='planner')
+        self._ws, self._ws_prof_offset = ws, nbytes - 192        # (tools/planner_bench.py: the option planner_prof's counters)
         if os.environ.get('STRIVE_POISON_WS') == '1':
             ws.fill_(0x25)                # debug aid (the tests set it): a kernel that reads workspace it did not write sees garbage
         TP = planner_t.shape[0]

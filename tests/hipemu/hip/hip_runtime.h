@@ -35,6 +35,7 @@ struct dim3 {
 };
 struct uint3_emu { unsigned x, y, z; };
 struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(16) double2 { double x, y; };
 struct alignas(8) float2 { float x, y; };
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
@@ -184,6 +185,12 @@ inline int __builtin_amdgcn_update_dpp(int /*old*/, int src, int ctrl, int, int,
     return hipemu_exchange(src, from);
 }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return hipemu_exchange(v, lane); }
+inline int __double2hiint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b >> 32); }
+inline int __double2loint(double d) { long long b; memcpy(&b, &d, 8); return (int)(b & 0xffffffffll); }
+inline double __hiloint2double(int hi, int lo) {
+    const long long b = ((long long)hi << 32) | (long long)(unsigned)lo;
+    double d; memcpy(&d, &b, 8); return d;
+}
 template <typename T> inline T __shfl(T v, int src, int width = 64) {
     int lane = hipemu_lane();
     return hipemu_exchange(v, (lane / width) * width + (src % width));
