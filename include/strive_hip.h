@@ -59,8 +59,6 @@ const char* strive_last_error(void);
  *     sweep_step (-1)        reverse sweep as one launch per step on K workgroups per scene (-1: from 3 chunks on; 0: never; 1..4)
  *     train_overlap (1)      strive_rollout_bwd_train_kept: CNN backward of finished steps on the library's side stream
  *     train_overlap_rows (256)  samples per hand-over to that stream
- *     planner_groups (1)     strive_planner_rollout: scene groups whose step loops run side by side on library-owned streams (1: off;
- *                            measured: the planner alone 3.45 -> 3.26 ms with 3 groups, the closed-loop iteration around it 14.40 -> 14.71 ms)
  *     wgrad_atomics, dgrad_igemm, wgrad_igemm, wgrad_tile (0)   earlier forms of the training backward kept for A/B
  *   measurement hooks (results of the affected call are INVALID or the workspace tail is written; never set in production):
  *     conv_ws_dbg (bit mask), wgrad_dbg, scene_prof, planner_prof, planner_dbg (bit mask)

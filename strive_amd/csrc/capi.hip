@@ -41,7 +41,6 @@ const OptionDesc g_options[] = {
     STRIVE_OPT(wgrad_tile, 0, 0, 1),               // A/B: fp32 LDS-tile weight gradient
     STRIVE_OPT(wgrad_dbg, 0, 0, 255),              // measurement only
     STRIVE_OPT(planner_prof, 0, 0, 1),             // measurement only: planner phase clocks into the workspace tail
-    STRIVE_OPT(planner_groups, 1, 1, 4),           // planner rollout: scene groups whose step loops run on library-owned streams (1: caller's stream only)
     STRIVE_OPT(planner_dbg, 0, 0, 65535),            // measurement only (results invalid): phase switches of the planner kernels
 };
 #undef STRIVE_OPT

@@ -21,7 +21,6 @@ struct StriveTuning {
     int wgrad_atomics, dgrad_igemm, wgrad_igemm, wgrad_tile, wgrad_dbg;
     int planner_prof;
     int planner_dbg;
-    int planner_groups;
 };
 StriveTuning& strive_tuning();
 

@@ -785,12 +785,12 @@ __device__ __forceinline__ void box_circles(double x, double y, double h, double
     cx[4] = x; cy[4] = y;
 }
 
-__global__ void __launch_bounds__(1024) planner_ego_kernel(StrivePlanner pl, Work w, int k, int b0, int32_t* status_all) {
+__global__ void __launch_bounds__(1024) planner_ego_kernel(StrivePlanner pl, Work w, int k, int32_t* status_all) {
     __shared__ RouteLds R;
     __shared__ double pdist[MAXPROF][MAXNT];        // distances of the profiles; before that, (1 - pr) of step k-1's profiles
     __shared__ double risk[MAXPROF], pfd[MAXPROF];
     const int lane = lane_id(), tid = threadIdx.x, nthr = blockDim.x;
-    const int b = blockIdx.x + b0;
+    const int b = blockIdx.x;
     int32_t* status = status_all + NSTATUS * (size_t)b;
     const StrivePlannerCfg& cfg = pl.cfg;
     const StrivePlannerMap& mp = pl.maps[pl.scene_map[b]];
@@ -963,12 +963,12 @@ __global__ void __launch_bounds__(1024) planner_ego_kernel(StrivePlanner pl, Wor
 // Trajectory points marked as bit-for-bit duplicates by the routes kernel are not staged at all.
 constexpr int GAP_TJ = 16;          // trajectories staged per round
 static size_t gap_lds_bytes(int NT) { return ((size_t)(2 * GAP_TJ * NT * 5 + 2 * GAP_TJ) * 8 + (size_t)GAP_TJ * NT + 15) / 16 * 16; }
-__global__ void __launch_bounds__(1024) planner_gap_kernel(StrivePlanner pl, Work w, int k, int b0) {
+__global__ void __launch_bounds__(1024) planner_gap_kernel(StrivePlanner pl, Work w, int k) {
     // staged boxes, sized by the launch's NT (gap_lds_bytes): 14.5 KB at 11 times instead of 41 KB at the cap of 32, so that all
     // (scene, chunk) workgroups of a step are resident together
     HIP_DYNAMIC_SHARED(double, gap_lds)
     __shared__ int cnt;
-    const int b = blockIdx.x + b0, chunk = blockIdx.y;
+    const int b = blockIdx.x, chunk = blockIdx.y;
     const int P = w.P, NT = w.NT;
     double* const ocx = gap_lds;                        // (GAP_TJ, NT, 5)
     double* const ocy = ocx + GAP_TJ * NT * 5;
@@ -1157,49 +1157,6 @@ int check_cfg(const StrivePlanner* pl, int nstep, int traj_cap) {
     return 0;
 }
 
-// Library-owned streams per device for the scene groups of one rollout (forked from and joined to the caller's stream with events
-// inside the call: the caller never sees them).  One rollout at a time per device uses them; a second one that arrives meanwhile
-// (another host thread) runs on its own stream alone.
-constexpr int MAXGROUPS = 4;
-struct GroupStreams {
-    hipStream_t s[MAXGROUPS - 1];
-    hipEvent_t start, done[MAXGROUPS - 1];
-    bool ok;
-    std::atomic<int> in_use;
-};
-struct GroupStreamsUse {
-    GroupStreams* g;
-    explicit GroupStreamsUse(GroupStreams* g_) : g(g_) {}
-    ~GroupStreamsUse() { if (g) g->in_use.store(0, std::memory_order_release); }
-};
-GroupStreams* group_streams() {
-    static GroupStreams table[64];
-    static PerDeviceOnce once;
-    static std::atomic<int> busy{0};
-    const int dev = once.device();
-    if (!once.is_done(dev)) {
-        int expect = 0;
-        while (!busy.compare_exchange_weak(expect, 1)) expect = 0;      // (first use per device only)
-        if (!once.is_done(dev)) {
-            GroupStreams& t = table[dev];
-            bool ok = hipEventCreateWithFlags(&t.start, hipEventDisableTiming) == hipSuccess;
-            for (int i = 0; i < MAXGROUPS - 1; ++i) {
-                ok = (hipStreamCreateWithFlags(&t.s[i], hipStreamNonBlocking) == hipSuccess) && ok;
-                ok = (hipEventCreateWithFlags(&t.done[i], hipEventDisableTiming) == hipSuccess) && ok;
-            }
-            (void)hipGetLastError();
-            t.ok = ok;
-            t.in_use.store(0);
-            once.set_done(dev);
-        }
-        busy.store(0);
-    }
-    GroupStreams* g = &table[dev];
-    if (!g->ok) return nullptr;
-    int expect = 0;
-    return g->in_use.compare_exchange_strong(expect, 1, std::memory_order_acquire) ? g : nullptr;
-}
-
 }  // namespace strive_planner
 using namespace strive_planner;
 
@@ -1232,47 +1189,18 @@ extern "C" int strive_planner_rollout(const StrivePlanner* pl, const double* age
     const int gap_threads = ((w.P * w.NT + 63) / 64) * 64;
     // one thread per (profile, time) of the risk scores and the circles where that fits (25 x 26 -> 704: one pass)
     const int ego_threads = gap_threads < 256 ? 256 : gap_threads;
-    // Scene groups.  A planner step is ego kernel -> gap kernel -> next step's ego kernel: the ego kernel is one workgroup per scene
-    // walking latency chains (36 CUs of 256 busy for 48 us), the gap kernel fills the chip for 26 us.  Scenes are independent, so
-    // the batch is cut into G groups whose step loops run on G streams: one group's gap kernel runs under the others' ego kernels
-    // (option planner_groups, default 3; 1 = everything on the caller's stream).
-    int G = strive_tuning().planner_groups;
-    if (G > MAXGROUPS) G = MAXGROUPS;
-    if (G > (int)pl->B / 2) G = (int)pl->B / 2;
-    if (G < 1) G = 1;
-    GroupStreams* gs = G > 1 ? group_streams() : nullptr;
-    GroupStreamsUse gs_guard(gs);
-    if (!gs) G = 1;
-    hipStream_t gstream[MAXGROUPS];
-    int gb0[MAXGROUPS + 1];
-    Work gw[MAXGROUPS];
-    gstream[0] = stream;
-    for (int g = 0; g <= G; ++g) gb0[g] = (int)(((long long)pl->B * g) / G);
-    for (int g = 0; g < G; ++g) {
-        if (g > 0) gstream[g] = gs->s[g - 1];
-        gw[g] = w;
-        // chunks per scene: as many as keep the (scene, chunk) workgroups of the groups' gap kernels resident at once -- a workgroup
-        // of P x NT threads is 11 waves at the default 25 x 26, two of them fit a CU, 512 the chip
+    // chunks per scene: as many as keep ALL (scene, chunk) workgroups of a step resident at once -- a workgroup of P x NT threads
+    // is 11 waves at the default 25 x 26, two of them fit a CU, 512 the chip; 36 scenes x 16 chunks = 576 workgroups ran as one full
+    // round and a second one of 64
+    {
         const int waves = gap_threads / 64, per_cu = 32 / waves < 1 ? 1 : 32 / waves;
-        const int nb = gb0[g + 1] - gb0[g];
-        const int nc = (256 * per_cu) / (nb * (G > 1 ? 2 : 1));          // (two groups' gap kernels may coincide)
-        gw[g].nchunk = nc < 4 ? 4 : (nc > NCHUNK ? NCHUNK : nc);
+        const int nc = (256 * per_cu) / (int)pl->B;
+        w.nchunk = nc < 4 ? 4 : (nc > NCHUNK ? NCHUNK : nc);
     }
-    if (G > 1) {
-        hipEventRecord(gs->start, stream);
-        for (int g = 1; g < G; ++g) hipStreamWaitEvent(gstream[g], gs->start, 0);
-    }
-    for (int k = 0; k <= w.K; ++k)
-        for (int g = 0; g < G; ++g) {
-            const int nb = gb0[g + 1] - gb0[g];
-            hipLaunchKernelGGL(planner_ego_kernel, dim3(nb), dim3(ego_threads), 0, gstream[g], *pl, gw[g], k, gb0[g], status);
-            if (k < w.K)
-                hipLaunchKernelGGL(planner_gap_kernel, dim3(nb, gw[g].nchunk), dim3(gap_threads), gap_lds_bytes(w.NT), gstream[g], *pl, gw[g], k,
-                                   gb0[g]);
-        }
-    for (int g = 1; g < G; ++g) {
-        hipEventRecord(gs->done[g - 1], gstream[g]);
-        hipStreamWaitEvent(stream, gs->done[g - 1], 0);
+    for (int k = 0; k <= w.K; ++k) {
+        hipLaunchKernelGGL(planner_ego_kernel, dim3(pl->B), dim3(ego_threads), 0, stream, *pl, w, k, status);
+        if (k < w.K)
+            hipLaunchKernelGGL(planner_gap_kernel, dim3(pl->B, w.nchunk), dim3(gap_threads), gap_lds_bytes(w.NT), stream, *pl, w, k);
     }
     hipLaunchKernelGGL(planner_interp_kernel, dim3((pl->B * TP + 63) / 64), dim3(64), 0, stream, w, (int)pl->B, t_out, planner_t, (int)TP,
                        plan, status);
