@@ -1077,7 +1077,8 @@ def main():
         pk = [v[1] for k, v in m.__dict__.get('_strive_packs', {}).items() if isinstance(k, tuple) and k and k[0] == 'dec']
         sc = _ops.scene_info(g).pack(1)
         if pk:
-            rollout_kernels = 'scene-resident' if _L.get_lib().query('strive_rollout_scene_resident', pk[0].ref(), sc.ref()) else 'per-phase'
+            kind = _L.get_lib().query('strive_rollout_scene_resident', pk[0].ref(), sc.ref())
+            rollout_kernels = {1: 'scene-resident', 2: 'per-phase; forward node phases on the scene kernel in 16-row tiles'}.get(kind, 'per-phase')
             if rollout_kernels == 'scene-resident':
                 # the reverse sweep's form (csrc/rollout.hip strive_rollout_bwd: stepwise from 3 edge chunks per scene on, STRIVE_SWEEP_STEP)
                 mx = int(sc.struct.max_n)

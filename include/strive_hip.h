@@ -54,6 +54,8 @@ const char* strive_last_error(void);
  *     conv_ws (1)            conv2 on specialised producer / consumer waves (0: conv_bf6_kernel; bit-identical)
  *     conv_wsx (1)           conv3 / conv4 on specialised waves with streamed weights (0: conv_bf6_kernel; bit-identical)
  *     scene_kernels (1)      scene-resident decoder kernels where they apply (0: launch-per-phase kernels)
+ *     scene_tiles (1)        batches with scenes of > 16 agents: the forward step's node-level phases on the scene kernel in 16-row
+ *                            tiles (0: launch-per-phase kernels; results agree to fp32 rounding)
  *     scene_split (12)       scenes of >= this many agents share their edge chunks among K workgroups (0: never)
  *     scene_fwd_k (-1)       K of the forward step (-1: one workgroup per 64-row edge chunk, <= 4)
  *     sweep_step (-1)        reverse sweep as one launch per step on K workgroups per scene (-1: from 3 chunks on; 0: never; 1..4)
@@ -308,7 +310,9 @@ size_t strive_rollout_workspace_bytes(const StriveDecoder* dec, const StriveScen
  * a decoder step is ONE launch, the reverse sweep over all FT steps is ONE launch; csrc/scene_rollout.h) -- single-sample
  * rollouts, scenes of <= 16 agents, weight packs with matrix-core fragments (StriveMLP.wf / StriveGRU.whh_f) -- else 0: the
  * launch-per-phase kernels.  Same arithmetic scheme, same tape layout; results agree to fp32 rounding.  Option
- * scene_kernels = 0 (read per call) forces 0. */
+ * scene_kernels = 0 (read per call) forces 0.  2 (round 6): a single-sample batch with scenes of more than 16 agents -- the node-level
+ * phases of the forward step (mlp_in .. edge partials; update MLP .. GRU .. dynamics) run on the scene kernel in 16-row tiles of
+ * every scene, the edge rows and the reverse sweep on the launch-per-phase kernels (option scene_tiles = 0: all per-phase). */
 int strive_rollout_scene_resident(const StriveDecoder* dec, const StriveScenes* sc);
 
 /* TrafficModel.autoregressive_decoder (reference src/models/traffic_model.py:589-704).

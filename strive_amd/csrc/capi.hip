@@ -29,6 +29,7 @@ const OptionDesc g_options[] = {
     STRIVE_OPT(conv_wsx, 1, 0, 1),                 // conv3 / conv4 on specialised waves with streamed weights (0: conv_bf6_kernel)
     STRIVE_OPT(conv_ws_dbg, 0, 0, 255),            // measurement only (results invalid): phase switches of the specialised-wave kernels
     STRIVE_OPT(scene_kernels, 1, 0, 1),            // scene-resident decoder kernels where they apply (0: launch-per-phase kernels)
+    STRIVE_OPT(scene_tiles, 1, 0, 1),              // scenes of > 16 agents: forward node phases on the scene kernel in 16-row tiles (0: per-phase kernels)
     STRIVE_OPT(scene_prof, 0, 0, 1),               // measurement only: phase clocks of workgroup 0 into the workspace
     STRIVE_OPT(scene_split, 12, 0, 64),            // scenes of >= this many agents share their edge chunks among K workgroups (0: never)
     STRIVE_OPT(scene_fwd_k, -1, -1, 4),            // workgroups per scene for those edge chunks (-1: one per chunk, <= 4)

@@ -16,7 +16,7 @@ void strive_set_error(const char* fmt, ...);
 // the Python host maps STRIVE_<NAME> environment variables onto these options (strive_amd/_lib.py).
 struct StriveTuning {
     int cnn_small_batch, cnn_chunk, cnn_tail_s, conv_ws, conv_wsx, conv_ws_dbg;
-    int scene_kernels, scene_prof, scene_split, scene_fwd_k, sweep_step;
+    int scene_kernels, scene_tiles, scene_prof, scene_split, scene_fwd_k, sweep_step;
     int train_overlap, train_overlap_rows;
     int wgrad_atomics, dgrad_igemm, wgrad_igemm, wgrad_tile, wgrad_dbg;
     int planner_prof;

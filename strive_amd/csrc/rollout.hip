@@ -351,6 +351,12 @@ bool scene_kernels_on(const StriveDecoder* dec, const StriveScenes* sc) {
     return strive_tuning().scene_kernels != 0 && scn::supported(*dec, *sc);   // (read per call: tests and A/B runs switch it inside one process)
 }
 
+// Batches with scenes of more than 16 agents (single-sample): the node-level phases of the FORWARD step on the scene kernel in
+// 16-row tiles (option scene_tiles, default 1), the edge rows and the reverse sweep on the launch-per-phase kernels.
+bool scene_tiles_on(const StriveDecoder* dec, const StriveScenes* sc) {
+    return strive_tuning().scene_kernels != 0 && strive_tuning().scene_tiles != 0 && sc->max_n > scn::NR && scn::supported(*dec, *sc, true);
+}
+
 // more than 64 KB of LDS per workgroup needs the attribute, once per device
 int scene_kernels_prepare() {
     static std::atomic<unsigned long long> done{0};
@@ -437,7 +443,8 @@ int check_decoder(const StriveDecoder* dec, const StriveScenes* sc, int FT) {
 }  // namespace
 
 extern "C" int strive_rollout_scene_resident(const StriveDecoder* dec, const StriveScenes* sc) {
-    return dec && sc && scene_kernels_on(dec, sc) ? 1 : 0;
+    if (!dec || !sc) return 0;
+    return scene_kernels_on(dec, sc) ? 1 : (scene_tiles_on(dec, sc) ? 2 : 0);
 }
 
 extern "C" size_t strive_rollout_tape_bytes(const StriveDecoder* dec, const StriveScenes* sc, int32_t FT) {
@@ -491,7 +498,8 @@ static int rollout_forward(const StriveDecoder* dec, const StriveScenes* sc, con
     const int nb = (int)((R + RB_NODE - 1) / RB_NODE);
 
     const bool scene = scene_kernels_on(dec, sc);
-    if (scene && scene_kernels_prepare()) return -1;
+    const bool scene_tiles = !scene && scene_tiles_on(dec, sc);
+    if ((scene || scene_tiles) && scene_kernels_prepare()) return -1;
     const scn::GRUFrag gf = scn::gru_frag(dec->gru);
     const bool scene_prof = scene && strive_tuning().scene_prof != 0;
     // scenes of >= option scene_split agents (default 12 = three 64-row edge chunks; 0 = never): their 130-240 edge rows are 3-4
@@ -564,6 +572,27 @@ static int rollout_forward(const StriveDecoder* dec, const StriveScenes* sc, con
         gb.Q = tp.Q_t(t);
         gb.PRE_IN = tp.PRE_IN_t(t);
         gb.PRE_E = tp.PRE_E_t(t);
+        if (scene_tiles) {
+            // scenes of more than 16 agents: mlp_in .. P / Q and update MLP .. GRU .. dynamics per 16-row tile of a scene on the scene
+            // kernel (grid (B, 1, tiles): matrix tiles of 16 rows instead of 4-row blocks, one launch each), the edge rows in between
+            // on one workgroup per target node
+            scn::StepArgsS a;
+            a.t = t; a.FT = FT; a.NC = NC; a.max_n = sc->max_n; a.sem = sem; a.lw = lw; a.z = z; a.ext = ext_future; a.ptr = sc->ptr;
+            a.par = dec->scene_par; a.traj = traj; a.KW = 0; a.part_a = nullptr; a.part_arg = nullptr;
+            const dim3 grid((unsigned)sc->B, 1, (unsigned)((sc->max_n + scn::NR - 1) / scn::NR));
+            a.mode = 1;
+            hipLaunchKernelGGL(scn::scene_fwd_step_kernel<false>, grid, dim3(scn::NTHR), scn::FwdLds::BYTES, stream, gd, gr, gf, dp, a, tp,
+                               (unsigned long long*)nullptr);
+            hipLaunchKernelGGL(gnn_edge_kernel, dim3((unsigned)R), dim3(256), EdgeLds::bytes(), stream, gd, sd, tp.pos_t(t), gb);
+            a.mode = 4;
+            hipLaunchKernelGGL(scn::scene_fwd_step_kernel<false>, grid, dim3(scn::NTHR), scn::FwdLds::BYTES, stream, gd, gr, gf, dp, a, tp,
+                               (unsigned long long*)nullptr);
+            if (t < FT - 1) {
+                int rc = encode_step(t);
+                if (rc) return rc;
+            }
+            continue;
+        }
         FeatSrc f = decoder_features(tp, t, sem, z, lw, NC);
         hipLaunchKernelGGL(gnn_node1_kernel, dim3(nb), dim3(256), Node1Lds::bytes(in_ld1, xs_ld), stream, gd, sc->NS, f, sem,
                            gb, (int)R);

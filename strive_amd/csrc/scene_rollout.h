@@ -64,8 +64,10 @@ static inline GRUFrag gru_frag(const StriveGRU& g) {
 }
 
 // Are the matrix-core operands this path needs all there (weights packed with fragments, GRU included)?
-static inline bool supported(const StriveDecoder& d, const StriveScenes& sc) {
-    if (sc.NS != 1 || sc.max_n > NR || sc.max_n < 1 || !d.scene_par) return false;
+// (`any_size`: the node-level phases of the forward step run in 16-row tiles of a scene of any size -- scene_fwd_step_kernel modes
+//  1 and 4 on a (B, 1, tiles) grid; everything else needs the whole scene in one tile)
+static inline bool supported(const StriveDecoder& d, const StriveScenes& sc, bool any_size = false) {
+    if (sc.NS != 1 || (sc.max_n > NR && !any_size) || sc.max_n < 1 || !d.scene_par) return false;
     if (d.gnn.D != 64 || d.gnn.NC > 8) return false;
     // k-step counts the kernels are written for: mlp_in 162 + NC -> 6, edge layer 0 (132 + 2 NC: sem_i, sem_j and the relative
     // pose share the 5th step), update 128 + NC -> 5
@@ -527,8 +529,15 @@ static __global__ __launch_bounds__(NTHR) void scene_fwd_step_kernel(GNNDev g, G
     HIP_DYNAMIC_SHARED(float, smem)
     FwdLds L(smem);
     const int tid = threadIdx.x, b = blockIdx.x, t = a.t, NC = a.NC, H = STRIVE_HID;
-    const int lo = a.ptr[b], n = a.ptr[b + 1] - lo;
+    // Rows of this workgroup: the whole scene (<= NR agents, grid (B, K)), or -- round 6, scenes of any size -- the 16-row node tile
+    // blockIdx.z of it (grid (B, 1, tiles), modes 1 and 4 only: the node-level phases are row-wise, the edge rows between them run
+    // on gnn_edge_kernel, one workgroup per target node).  lo / n below are the tile's.
+    const int lo_s = a.ptr[b], n_s = a.ptr[b + 1] - lo_s;
+    const int tile = (int)blockIdx.z;
+    const int lo = lo_s + tile * NR;
+    const int n = n_s - tile * NR < NR ? n_s - tile * NR : NR;
     if (n <= 0) return;
+    if (n_s > NR && (a.mode & 2)) return;        // (the edge chunks need the whole scene in one tile: never launched like this)
     const int kw = (a.KW > 0 && (a.mode & 2)) ? (int)blockIdx.y : 0, KW = (a.KW > 0 && (a.mode & 2)) ? a.KW : 1;
     const bool tape_w = kw == 0;                 // the K workgroups of a scene hold the same node-level values: one of them stores
     long long tick = PROF ? clock64() : 0;
@@ -888,7 +897,7 @@ static __global__ __launch_bounds__(NTHR) void scene_fwd_step_kernel(GNNDev g, G
             float* tr = a.traj + ((size_t)r * a.FT + t) * 4;
             for (int i = 0; i < 4; ++i) tr[i] = bk.out[i];
             float gin[4] = {bk.out[0], bk.out[1], bk.out[2], bk.out[3]};
-            if (a.ext && tid == 0) {                                  // the ego is the first agent of its scene
+            if (a.ext && tid == 0 && tile == 0) {                     // the ego is the first agent of its scene
                 const float* e = a.ext + ((size_t)b * a.FT + t) * 4;
                 for (int i = 0; i < 4; ++i) gin[i] = e[i];
             }

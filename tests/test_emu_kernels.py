@@ -887,6 +887,48 @@ def _rollout_both_paths(emu, sd, sizes, FT, ext=False, NC=2, monkeypatch=None, f
     return out, dz_x
 
 
+def test_forward_node_phases_on_scene_tiles_equal_the_phase_kernels(emu, sd, monkeypatch):
+    """Scenes of more than 16 agents (round 6): the forward step's node-level phases on scene_fwd_step_kernel in 16-row tiles
+    (grid (B, 1, tiles), modes 1 and 4; the edge rows on gnn_edge_kernel in between) against the launch-per-phase kernels (option
+    scene_tiles = 0): trajectories to fp32 rounding, the per-phase reverse sweep on either tape; a scene of 19 agents (two tiles, the
+    second with 3 rows), one of 16 (one full tile) and one of 2, teacher-forced ego rows, two steps."""
+    sizes, FT = [19, 16, 2], 2
+    batch, map_idx, raster, dx = mg.build_inputs(sizes, 'emu', NC=2)
+    env = synth.SyntheticMapEnv(raster, dx)
+    orc = oracle_model(sd)
+    NA = batch.past.shape[0]
+    emb = {'map_feat': synth.f32(synth.counter_uniform((NA, 64), 'emu/mf', -1, 1)),
+           'past_feat': synth.f32(synth.counter_uniform((NA, 64), 'emu/pf', -1, 1))}
+    z = synth.f32(synth.counter_uniform((NA, 32), 'emu/zz', -1.5, 1.5)).contiguous()
+    extf = batch.future_gt[batch.ptr[:-1]][:, :FT, :4].contiguous()
+    dec = params.pack_decoder(sd, 2, env, 'cpu', orc.get_normalizer(), orc.get_att_normalizer(), NUSC_BIKE_PARAMS)
+    sc = params.pack_scenes(batch.ptr, 1, 'cpu')
+    tb = emu.query('strive_rollout_tape_bytes', dec.ref(), sc.ref(), FT)
+    wb = emu.query('strive_rollout_workspace_bytes', dec.ref(), sc.ref(), FT)
+    rw = synth.f32(synth.counter_uniform((NA, FT, 4), 'emu/rw', -1.0, 1.0)).contiguous()
+    mi = map_idx[batch.batch].int().contiguous()
+    lw, sem = batch.lw.contiguous(), batch.sem.contiguous()
+    out = {}
+    for tiles in ('0', '1'):
+        monkeypatch.setenv('STRIVE_SCENE_TILES', tiles)
+        assert emu.query('strive_rollout_scene_resident', dec.ref(), sc.ref()) == (2 if tiles == '1' else 0)
+        tape, ws = torch.full((tb,), 0xFF, dtype=torch.uint8), torch.full((wb,), 0xFF, dtype=torch.uint8)
+        traj = torch.zeros((NA, FT, 4))
+        emu.call('strive_rollout_fwd', dec.ref(), sc.ref(), L.ptr(batch.past[:, -1, :].contiguous()), L.ptr(lw), L.ptr(sem),
+                 L.ptr(emb['past_feat'].contiguous()), L.ptr(emb['map_feat'].contiguous()), L.ptr(z), L.ptr(mi), L.ptr(extf), FT,
+                 L.ptr(traj), L.ptr(tape), tb, L.ptr(ws), wb, None)
+        dz = torch.full((NA, 32), float('nan'))
+        w2 = torch.full((wb,), 0xFF, dtype=torch.uint8)
+        emu.call('strive_rollout_bwd', dec.ref(), sc.ref(), L.ptr(lw), L.ptr(sem), L.ptr(z), L.ptr(extf), FT,
+                 L.ptr(rw), L.ptr(dz), L.ptr(tape), tb, L.ptr(w2), wb, None)
+        out[tiles] = (traj, dz)
+    (t0, d0), (t1, d1) = out['0'], out['1']
+    assert torch.isfinite(t1).all() and torch.isfinite(d1).all()
+    assert_close(t1, t0, 2e-5, 2e-6, 'forward node phases on scene tiles')
+    scale = float(d0.abs().max())
+    assert_close(d1, d0, 1e-3, 2e-5 * scale, 'per-phase sweep on the tape the scene tiles wrote')
+
+
 @pytest.mark.parametrize('sizes,FT,ext', [([3, 1, 5, 2], 1, False), ([16, 9], 1, True), ([4, 2], 3, True)])
 def test_scene_resident_rollout_equals_phase_kernels(emu, sd, sizes, FT, ext, monkeypatch):
     """One workgroup per scene (a step = one launch, the reverse sweep = one launch) against the launch-per-phase kernels:
