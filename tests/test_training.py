@@ -368,8 +368,13 @@ def test_training_backward_forms_agree():
     env_g = synth.SyntheticMapEnv(raster.clone(), dx.clone()).to(DEV)
 
     def step(env_vars, stack=True):
+        from strive_amd import _lib as L
         saved = {k: os.environ.get(k) for k in env_vars}
         os.environ.update(env_vars)
+        L.sync_all_options_from_env()           # (the library's switches are options since ABI 17: the host maps STRIVE_<NAME> onto them)
+        for k, v in env_vars.items():
+            if k[len('STRIVE_'):].lower() in L.get_lib().option_names():
+                assert L.get_lib().get_option(k[len('STRIVE_'):].lower()) == int(v), k
         m.stack_rollouts = stack
         try:
             out, ld, grads, _ = _product_step(m, batch.clone().to(DEV), map_idx.to(DEV), env_g, eps_post, eps_prior)
@@ -381,10 +386,13 @@ def test_training_backward_forms_agree():
                     del os.environ[k]
                 else:
                     os.environ[k] = v
+            L.sync_all_options_from_env()
         return out, ld, {k: v.detach().clone() for k, v in grads.items()}
     ref_out, ref_ld, ref = step({'STRIVE_TRAIN_OVERLAP': '0'})
+    # ('kept activations refused': ops._alloc_kept declines the buffer -- STRIVE_KEEP_MAX_BYTES, or 75 % of the free memory in
+    #  production -- and the step takes the recomputing backward instead of failing: ADVICE r05)
     for what, env_vars, stack in (('one group per step', {'STRIVE_TRAIN_OVERLAP_ROWS': '1'}, True), ('default groups', {}, True),
-                                  ('separate rollouts', {}, False)):
+                                  ('separate rollouts', {}, False), ('kept activations refused', {'STRIVE_KEEP_MAX_BYTES': '1'}, True)):
         out, ld, got = step(env_vars, stack)
         assert torch.equal(out['future_pred'], ref_out['future_pred']) and torch.equal(out['future_samp'], ref_out['future_samp']), what
         worst = ('', 0.0)
